@@ -1,0 +1,173 @@
+/*
+ * virconv_hip.h -- C ABI of libvirconv_hip.so: the MI355X (gfx950) Virtual-Sparse-Convolution hot path.
+ *
+ * Drop-in boundary.  In the reference (hailanyi/VirConv) this arithmetic is NOT in the
+ * repository: it is reached through the un-vendored `spconv` pip package (setup.py:41, README.md:52,60,70)
+ * from pcdet/utils/spconv_utils.py:33-36 and pcdet/datasets/processor/data_processor.py:14-41.  The
+ * reference's own native-op convention (the lower half we keep) is pcdet/ops/pointnet2/pointnet2_stack:
+ *   Python caller pre-allocates torch tensors, asserts contiguity      voxel_query_utils.py:31-37
+ *   C++ wrapper extracts raw pointers and calls a plain launcher        src/voxel_query.cpp:25-41
+ *   launcher(int..., const float*, const int*, ...) on a stream         src/voxel_query_gpu.cu:92-113
+ * Each entry point below cites the spconv interface (via its reference call site) that it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless named host_*; the caller owns all memory (no allocation here;
+ *     scratch is passed in, sized by the matching *_workspace_bytes query)
+ *   - `stream` is a hipStream_t passed as void* (the caller's current stream; never the legacy default)
+ *   - features are float32 row-major (N, C); indices are int32 row-major (N, ndim+1) = [b, z, y, x] (3-D) or
+ *     [b, u, v] (2-D); spatial shapes are host int32[ndim] in the same axis order
+ *   - conv weights are the spconv-2.x canonical layout (Cout, kz, ky, kx, Cin) == (Cout, KV, Cin), float32
+ *     (detector3d_template.py:358-370), so released checkpoints load unchanged
+ *   - kernel offsets kappa are enumerated row-major over (kz, ky, kx); pair tables are dense int32
+ *     (KV, N) with -1 = no neighbour
+ *   - return value: VC_OK (0) or a negative vc_status; never exit()/abort (the reference ops fprintf+exit(-1):
+ *     voxel_query.cpp:10-22); vc_last_error() gives a thread-local message
+ *   - re-entrant; all launches are asynchronous on `stream`; no host synchronisation inside except where
+ *     a function is documented as returning a host count
+ */
+#ifndef VIRCONV_HIP_H_
+#define VIRCONV_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum vc_status {
+  VC_OK = 0,
+  VC_EINVAL = -1,    /* bad argument (null pointer, unsupported channel count, ndim, ...) */
+  VC_ECAPACITY = -2, /* workspace / output capacity too small */
+  VC_EHIP = -3       /* HIP runtime error (see vc_last_error) */
+} vc_status;
+
+const char* vc_version(void);
+const char* vc_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------ K3 hash
+ * Coordinate -> row hash (open addressing, 64-bit linearised key, duplicate rule rep(c) = max row; SURVEY
+ * App-A.5).  Replaces cumm's LinearHashTable insert inside spconv's indice generation, reached from every
+ * spconv.SubMConv3d/SubMConv2d forward (spconv_backbone.py:89,113).                                         */
+size_t vc_hash_workspace_bytes(int64_t n);
+int vc_hash_build(const int32_t* indices, int64_t n, int ndim, const int32_t* host_spatial_shape,
+                  void* hash_ws, size_t hash_ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ K4 subm rulebook
+ * pair_fwd[k, i] = rep(coord_i + (kappa_k - ksize/2) * dilation) or -1; the centre tap of row i is i.
+ * rep_out (nullable, int32[n]) receives rep(coord_i) (== i when coordinates are unique).
+ * Replaces spconv generate_subm_conv_inds (call sites spconv_backbone.py:89,113).                            */
+int vc_subm_rulebook(const int32_t* indices, int64_t n, int ndim, const int32_t* host_spatial_shape,
+                     const int32_t* host_ksize, const int32_t* host_dilation, const void* hash_ws,
+                     size_t hash_ws_bytes, int32_t* pair_fwd, int32_t* rep_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ K5 strided rulebook
+ * Regular sparse conv index generation: p = q*stride - pad + kappa*dil.  Output rows are all in-bounds q with
+ * an active (p, kappa), in ASCENDING linear-index order (spconv-CUDA order).  Implemented
+ * with an occupancy bitmap over the output grid + popcount prefix scan (no sort, no hash).
+ *   step 1  vc_spconv_mark_count : marks candidates, scans, writes the output-row count to *n_out_dev (device int32)
+ *   step 2  (caller reads n_out, allocates out_indices / pair_fwd / pair_bwd)
+ *   step 3  vc_spconv_emit_pairs : writes out_indices (n_out, ndim+1), pair_fwd (KV, n_out), pair_bwd (KV, n)
+ * Replaces spconv generate_conv_inds_stage1 / unique / stage2 (call sites spconv_backbone.py:92,116,561-563). */
+size_t vc_spconv_workspace_bytes(int batch_size, int ndim, const int32_t* host_out_shape);
+int vc_spconv_mark_count(const int32_t* indices, int64_t n, int ndim, int batch_size,
+                         const int32_t* host_out_shape, const int32_t* host_ksize, const int32_t* host_stride,
+                         const int32_t* host_padding, const int32_t* host_dilation, void* ws, size_t ws_bytes,
+                         int32_t* n_out_dev, void* stream);
+int vc_spconv_emit_pairs(const int32_t* indices, int64_t n, int ndim, int batch_size,
+                         const int32_t* host_out_shape, const int32_t* host_ksize, const int32_t* host_stride,
+                         const int32_t* host_padding, const int32_t* host_dilation, const void* ws,
+                         size_t ws_bytes, int64_t n_out, int32_t* out_indices, int32_t* pair_fwd,
+                         int32_t* pair_bwd, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ K6/K7 gather-GEMM
+ * Output-stationary implicit GEMM on fp32 MFMA (v_mfma_f32_16x16x4_f32), no atomics, run-to-run bitwise stable:
+ *     out[o, :] = sum_k  src_k[ tbl[k, o], : ] @ Wsel(k)
+ * forward      : src = x (n_src, cin),  tbl = pair_fwd (KV, n_out), Wsel(k) = W[:, k, :]^T      -> out (n_out, cout)
+ * backward-in  : src = dy (n_src, cout), tbl = pair_bwd (KV, n_out=n_in rows), Wsel(k) = W[:, k', :]
+ *                with k' = mirror ? KV-1-k : k                                                   -> out (n_in, cin)
+ *   SubM backward passes tbl = pair_fwd and mirror = 1 (pair_bwd[k] == pair_fwd[KV-1-k]).
+ *   Duplicate-coordinate SubM backward (2-D image-space branch): src_centre = dy is used for the
+ *   centre tap, src = group-summed dy (vc_group_sum) for the others, and rows with rep[o] != o take the centre
+ *   tap only.  Pass centre = -1, rep = NULL, src_centre = NULL when not needed.
+ * Replaces spconv ops.implicit_gemm / indice_conv fwd and bwd-input (autograd of spconv_backbone.py:89-125).   */
+int vc_conv_forward(const float* x, int64_t n_in, const int32_t* pair_fwd, int64_t n_out, int kv,
+                    const float* weight, int cin, int cout, float* y, void* stream);
+int vc_conv_backward_input(const float* dy, const float* dy_centre, int64_t n_src, const int32_t* tbl,
+                           int64_t n_in, int kv, const float* weight, int cin, int cout, int mirror, int centre,
+                           const int32_t* rep, float* dx, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ K8 weight gradient
+ * dW[:, k, :] = sum_o dy[o, :]^T (outer) x[pair_fwd[k, o], :]; wave-ballot compaction of the active pairs, MFMA
+ * outer products, deterministic two-stage split-N reduction through `ws`.
+ * Replaces spconv implicit_gemm bwd-weight (autograd of spconv_backbone.py:89-125).                            */
+size_t vc_conv_backward_weight_workspace_bytes(int64_t n_out, int kv, int cin, int cout);
+int vc_conv_backward_weight(const float* x, const float* dy, const int32_t* pair_fwd, int64_t n_out, int kv,
+                            int cin, int cout, float* dweight, void* ws, size_t ws_bytes, void* stream);
+
+/* dy_grp[rep[i], :] += dy[i, :]  (dy_grp zeroed here first; fp32 atomics -- only used by the duplicate-coordinate
+ * SubM backward; order of summation inside a pixel group is not fixed).                                         */
+int vc_group_sum(const float* dy, const int32_t* rep, int64_t n, int c, float* dy_grp, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ K9 projection
+ * Voxel index -> image pixel index.  Replaces index2points + index2uv +
+ * X_TRANS.backward_with_param + Calibration.lidar_to_rect_cuda/rect_to_img_cuda
+ * (spconv_backbone.py:8-24,54-83; X_transform.py:139-154; calibration_kitti.py:120-153).
+ *   calib : (B, 33) float32 = V2C (3x4 row-major) | R0 (3x3) | P2 (3x4)
+ *   trans : (B, 3)  float32 = [rot, flip, scale] or NULL
+ *   params: (B, 32) float32 scratch written by vc_project_prepare, read by vc_project_uv
+ *   uv    : (n, 3) int32 [b, u, v];  depth (nullable): (n,) float32                                             */
+int vc_project_prepare(const float* calib, const float* trans, int batch_size, float* params, void* stream);
+int vc_project_uv(const int32_t* indices, int64_t n, const float* params, int batch_size, int stride,
+                  int32_t* uv, float* depth, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ K2 discard
+ * Row gather of (features, indices) by keep indices: the device half of layer_voxel_discard
+ * (spconv_backbone.py:134-147: features[randoms], indices[randoms]).                                            */
+int vc_gather_rows(const float* features, const int32_t* indices, int c, int icols, const int64_t* keep,
+                   int64_t n_keep, float* features_out, int32_t* indices_out, void* stream);
+/* grad_in[keep[j], :] = grad_out[j, :], other rows zero (keep indices are unique).                              */
+int vc_scatter_rows(const float* grad_out, int c, const int64_t* keep, int64_t n_keep, int64_t n_in,
+                    float* grad_in, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ K10 dense
+ * SparseConvTensor.dense(): (B, C, *spatial) <- rows; `dense` must be zero-filled by the caller
+ * (height_compression.py:29).  The backward is a gather (vc_from_dense).                                        */
+int vc_to_dense(const float* features, const int32_t* indices, int64_t n, int c, int ndim, int batch_size,
+                const int32_t* host_spatial_shape, float* dense, void* stream);
+int vc_from_dense(const float* dense, const int32_t* indices, int64_t n, int c, int ndim, int batch_size,
+                  const int32_t* host_spatial_shape, float* features, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ K1 voxelize + a3 MeanVFE
+ * First-touch voxelisation of one frame's points with the mean (+ 'max' on the last channel) fused
+ * (SURVEY App-A.9, A.13).  Replaces spconv.utils.Point2VoxelCPU3d.point_to_voxel (data_processor.py:35-41,53)
+ * + MeanVFE.forward (mean_vfe.py:39-49).
+ *   points (p, f) float32, host_range = [xmin,ymin,zmin,xmax,ymax,zmax], host_vsize = [vx,vy,vz]
+ *   outputs sized max_voxels: features (max_voxels, f), coords (max_voxels, 3) int32 [z,y,x],
+ *   num_points (max_voxels,) int32, *n_voxels_dev device int32 = number of voxels produced.                      */
+size_t vc_voxelize_workspace_bytes(int64_t p, int max_points);
+int vc_voxelize_mean(const float* points, int64_t p, int f, const float* host_range, const float* host_vsize,
+                     int max_points, int max_voxels, int vfe_max_last, void* ws, size_t ws_bytes,
+                     float* features, int32_t* coords, int32_t* num_points, int32_t* n_voxels_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ K11 BN(+ReLU)
+ * Per-channel batch statistics over the N active rows and the fused normalise(+ReLU) pass -- the
+ * nn.BatchNorm1d(eps=1e-3, momentum=0.01) + nn.ReLU that follow every conv (spconv_backbone.py:101-105,160).
+ *   vc_bn_stats      : sums (2, c) float64-accumulated -> mean (c), biased var (c)  (two-stage, deterministic);
+ *                      optionally updates running_mean / running_var (unbiased var) in place with `momentum`
+ *   vc_bn_apply_relu : y = relu?( (x - mean) * rsqrt(var + eps) * gamma + beta ), optionally written at a column
+ *                      offset of a wider row (fuses the channel concat of NRConvBlock, spconv_backbone.py:227)
+ *   vc_bn_relu_backward : dx, dgamma, dbeta for the training-mode BN(+ReLU)                                       */
+size_t vc_bn_workspace_bytes(int64_t n, int c);
+int vc_bn_stats(const float* x, int64_t n, int c, float* mean, float* var, float* running_mean /*nullable*/,
+                float* running_var /*nullable*/, float momentum, void* ws, size_t ws_bytes, void* stream);
+int vc_bn_apply_relu(const float* x, int64_t n, int c, const float* mean, const float* var, const float* gamma,
+                     const float* beta, float eps, int relu, float* y, int y_stride, int y_col0, void* stream);
+int vc_bn_relu_backward(const float* x, const float* dy, int dy_stride, int dy_col0, int64_t n, int c,
+                        const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                        int relu, float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIRCONV_HIP_H_ */

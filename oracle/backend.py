@@ -1,0 +1,137 @@
+"""OracleBackend: exposes the CPU oracle through the product's backend interface (virconv_amd/backend_hip.py).
+
+TEST INFRASTRUCTURE ONLY.  Injected by tests with ``virconv_amd.ops.use_backend(OracleBackend())`` to (a) run the
+reference's own composition layer on CPU and produce golden fixtures, and (b) exercise host-side logic (facade,
+rulebook caching, autograd wiring, DDP) without a GPU.  The product never instantiates this class.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import geometry, sparse_ref
+
+
+def _np(t: torch.Tensor) -> np.ndarray:
+    return t.detach().cpu().numpy()
+
+
+class OracleBackend:
+    name = "oracle"
+
+    # ------------------------------------------------------------------ rulebooks
+    def subm_rulebook(self, indices, spatial_shape, ksize, dilation, want_rep: bool):
+        idx = _np(indices)
+        pair = sparse_ref.subm_rulebook(idx, spatial_shape, ksize, dilation)
+        rep = None
+        if want_rep:
+            lut = sparse_ref.CoordLookup(idx, spatial_shape)
+            rep = torch.from_numpy(lut.find(idx[:, 0].astype(np.int64), idx[:, 1:].astype(np.int64)).astype(np.int32))
+        return torch.from_numpy(pair), rep
+
+    def sparse_rulebook(self, indices, spatial_shape, batch_size, ksize, stride, padding, dilation):
+        oi, oshape, pf, pb = sparse_ref.sparse_rulebook(_np(indices), spatial_shape, batch_size, ksize, stride, padding,
+                                                        dilation)
+        return torch.from_numpy(oi), oshape, torch.from_numpy(pf), torch.from_numpy(pb)
+
+    # ------------------------------------------------------------------ convolution
+    def conv_forward(self, x, weight, pair_fwd):
+        return sparse_ref.conv_forward(x.detach(), weight.detach(), _np(pair_fwd))
+
+    def conv_backward_input(self, dy, weight, tbl, n_in, mirror, centre=-1, rep=None):
+        """dX of the three conv flavours, in the product's calling convention (include/virconv_hip.h).
+
+        SubM (mirror=True, tbl = pair_fwd): the EXACT transpose of the forward gather,
+            dx[j] = sum_{k,o : pair_fwd[k,o] = j} dy[o] @ W_k^T,
+        computed by scatter-add straight from pair_fwd -- independent of the product's mirrored-table / group-sum
+        formulation, so it checks that formulation (duplicate coordinates included; `centre`/`rep` are ignored).
+        Strided conv (tbl = pair_bwd) and inverse conv (tbl = pair_fwd of the forward conv): gather form
+            dx[i] = sum_k dy[tbl[k,i]] @ W_k^T.
+        """
+        t = _np(tbl)
+        dy = dy.detach()
+        w = weight.detach()
+        if mirror:
+            dx, _ = sparse_ref.conv_backward(dy.new_zeros((n_in, w.shape[-1])), w, t, dy)
+            return dx
+        wk = sparse_ref.weight_per_offset(w)  # (KV, Cin, Cout)
+        dx = dy.new_zeros((n_in, w.shape[-1]))
+        for k in range(t.shape[0]):
+            rows = np.nonzero(t[k] >= 0)[0]
+            if rows.size == 0:
+                continue
+            g = dy.index_select(0, torch.from_numpy(t[k, rows].astype(np.int64)))
+            dx.index_add_(0, torch.from_numpy(rows.astype(np.int64)), g @ wk[k].t())
+        return dx
+
+    def conv_backward_weight(self, x, dy, pair_fwd, weight_shape):
+        w0 = x.new_zeros(tuple(weight_shape))
+        _, dw = sparse_ref.conv_backward(x.detach(), w0, _np(pair_fwd), dy.detach())
+        return dw
+
+    # ------------------------------------------------------------------ projection / discard / dense
+    def project_uv(self, indices, calib, trans, batch_size, stride, want_depth=False):
+        cal = _np(calib)
+        calibs = [{"Tr_velo2cam": c[0:12].reshape(3, 4), "R0": c[12:21].reshape(3, 3), "P2": c[21:33].reshape(3, 4)}
+                  for c in cal]
+        tp = None if trans is None else _np(trans)
+        uv, depth = geometry.index2uv(_np(indices), batch_size, calibs, stride, tp)
+        return torch.from_numpy(uv), (torch.from_numpy(depth) if want_depth else None)
+
+    def gather_rows(self, features, indices, keep):
+        k = keep.long()
+        return features.detach()[k], (None if indices is None else indices[k])
+
+    def scatter_rows(self, grad_out, keep, n_in):
+        g = grad_out.new_zeros((n_in, grad_out.shape[1]))
+        g[keep.long()] = grad_out
+        return g
+
+    def to_dense(self, features, indices, spatial_shape, batch_size):
+        return sparse_ref.to_dense(features.detach(), _np(indices), spatial_shape, batch_size)
+
+    def from_dense(self, dense, indices, spatial_shape, batch_size):
+        idx = indices.long()
+        sl = (idx[:, 0], slice(None)) + tuple(idx[:, a + 1] for a in range(idx.shape[1] - 1))
+        return dense[sl].contiguous()
+
+    # ------------------------------------------------------------------ voxelise + MeanVFE
+    def voxelize_mean(self, points, pc_range, voxel_size, max_points, max_voxels, vfe_max_last):
+        vox, coords, num = geometry.voxelize(_np(points), voxel_size, pc_range, max_points, max_voxels)
+        feats = geometry.mean_vfe(vox, num, "max" if vfe_max_last else None)
+        return torch.from_numpy(feats), torch.from_numpy(coords), torch.from_numpy(num)
+
+    # ------------------------------------------------------------------ BatchNorm(+ReLU)
+    def bn_forward(self, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, out=None, out_col0=0):
+        x = x.detach()
+        n = x.shape[0]
+        if training:
+            xd = x.double()
+            mean = xd.mean(0)
+            var = (xd * xd).mean(0) - mean * mean
+            var = var.clamp_min(0)
+            if running_mean is not None:
+                running_mean.mul_(1 - momentum).add_(momentum * mean.float())
+                unb = var * n / max(n - 1, 1)
+                running_var.mul_(1 - momentum).add_(momentum * unb.float())
+            mean, var = mean.float(), var.float()
+        else:
+            mean, var = running_mean, running_var
+        y = (x - mean) / torch.sqrt(var + eps) * gamma.detach() + beta.detach()
+        if relu:
+            y = torch.relu(y)
+        return y, mean, var
+
+    def bn_backward(self, x, dy, dy_col0, mean, var, gamma, beta, eps, relu):
+        n, c = x.shape
+        dy = dy[:, dy_col0:dy_col0 + c]
+        istd = 1.0 / torch.sqrt(var + eps)
+        xh = (x - mean) * istd
+        if relu:
+            dy = torch.where(xh * gamma + beta > 0, dy, torch.zeros_like(dy))
+        dbeta = dy.double().sum(0).float()
+        dgamma = (dy * xh).double().sum(0).float()
+        dx = gamma * istd * (dy - dbeta / n - xh * dgamma / n)
+        return dx, dgamma, dbeta

@@ -1,0 +1,88 @@
+"""ctypes binding of libvirconv_hip.so (the C ABI declared in include/virconv_hip.h).
+
+This is the binder a maintainer of the reference would place under ``pcdet/ops/virconv/``:
+raw device pointers + sizes + the current HIP stream, mirroring the reference's own native-op convention
+(pcdet/ops/pointnet2/pointnet2_stack/voxel_query_utils.py:31-37 -> src/voxel_query.cpp:25-41).
+
+There is NO CPU fallback: if the shared object cannot be loaded the import of any op raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvirconv_hip.so")
+
+VC_OK, VC_EINVAL, VC_ECAPACITY, VC_EHIP = 0, -1, -2, -3
+
+_P, _I64, _I, _SZ, _F = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_float
+
+# name -> (restype, argtypes); must list every symbol of include/virconv_hip.h (checked by tests/test_abi.py)
+SIGNATURES = {
+    "vc_version": (C.c_char_p, []),
+    "vc_last_error": (C.c_char_p, []),
+    "vc_hash_workspace_bytes": (_SZ, [_I64]),
+    "vc_hash_build": (_I, [_P, _I64, _I, _P, _P, _SZ, _P]),
+    "vc_subm_rulebook": (_I, [_P, _I64, _I, _P, _P, _P, _P, _SZ, _P, _P, _P]),
+    "vc_spconv_workspace_bytes": (_SZ, [_I, _I, _P]),
+    "vc_spconv_mark_count": (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P, _P]),
+    "vc_spconv_emit_pairs": (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _I64, _P, _P, _P, _P]),
+    "vc_conv_forward": (_I, [_P, _I64, _P, _I64, _I, _P, _I, _I, _P, _P]),
+    "vc_conv_backward_input": (_I, [_P, _P, _I64, _P, _I64, _I, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "vc_conv_backward_weight_workspace_bytes": (_SZ, [_I64, _I, _I, _I]),
+    "vc_conv_backward_weight": (_I, [_P, _P, _P, _I64, _I, _I, _I, _P, _P, _SZ, _P]),
+    "vc_group_sum": (_I, [_P, _P, _I64, _I, _P, _P]),
+    "vc_project_prepare": (_I, [_P, _P, _I, _P, _P]),
+    "vc_project_uv": (_I, [_P, _I64, _P, _I, _I, _P, _P, _P]),
+    "vc_gather_rows": (_I, [_P, _P, _I, _I, _P, _I64, _P, _P, _P]),
+    "vc_scatter_rows": (_I, [_P, _I, _P, _I64, _I64, _P, _P]),
+    "vc_to_dense": (_I, [_P, _P, _I64, _I, _I, _I, _P, _P, _P]),
+    "vc_from_dense": (_I, [_P, _P, _I64, _I, _I, _I, _P, _P, _P]),
+    "vc_voxelize_workspace_bytes": (_SZ, [_I64, _I]),
+    "vc_voxelize_mean": (_I, [_P, _I64, _I, _P, _P, _I, _I, _I, _P, _SZ, _P, _P, _P, _P, _P]),
+    "vc_bn_workspace_bytes": (_SZ, [_I64, _I]),
+    "vc_bn_stats": (_I, [_P, _I64, _I, _P, _P, _P, _P, _F, _P, _SZ, _P]),
+    "vc_bn_apply_relu": (_I, [_P, _I64, _I, _P, _P, _P, _P, _F, _I, _P, _I, _I, _P]),
+    "vc_bn_relu_backward": (_I, [_P, _P, _I, _I, _I64, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _SZ, _P]),
+}
+
+_lib = None
+
+
+class VirConvError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load (once) and type the shared object; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VirConvError(
+            f"{LIB_PATH} is missing: build it with `python -m virconv_amd.build` (hipcc, gfx950). "
+            "virconv_amd has no CPU or PyTorch fallback for its operators.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != VC_OK:
+        msg = load().vc_last_error().decode("utf-8", "replace")
+        raise VirConvError(f"{what} failed with vc_status {status}: {msg}")
+
+
+def i32arr(vals):
+    vals = [int(v) for v in vals]
+    return (C.c_int32 * len(vals))(*vals)
+
+
+def f32arr(vals):
+    vals = [float(v) for v in vals]
+    return (C.c_float * len(vals))(*vals)

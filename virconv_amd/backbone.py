@@ -1,0 +1,232 @@
+"""MI355X-native VirConv backbones: drop-in for ``pcdet.models.backbones_3d`` ``VirConvL8x`` / ``VirConv8x``.
+
+Same constructor ``(model_cfg, input_channels, grid_size, **kwargs)``, same ``forward(batch_dict) -> batch_dict`` keys,
+same submodule names (hence the same state_dict keys, so released VirConv-*.pth load unchanged) as
+pcdet/models/backbones_3d/spconv_backbone.py:150-229 (NRConvBlock), :232-535 (VirConv8x), :538-699 (VirConvL8x).
+
+What is different from running the reference file on the facade (which also works):
+  * the voxel->pixel projection ``index2uv`` (python loop over the batch, ~15 small kernels + 3 host syncs per sample,
+    spconv_backbone.py:54-83) is ONE HIP kernel over all rows (vc_project_uv), no host sync
+  * the two 3-D SubM convs of a block share one rulebook (same coordinates; the reference gives them different
+    indice_keys :186,199 and rebuilds), likewise the two 2-D convs
+  * BatchNorm1d+ReLU run as a fused two-pass HIP op
+  * layer discard (StVD) is a real device gather with injectable keep indices; ``LAYER_DISCARD_MODE`` selects the
+    spconv-1.x in-place behaviour (paper) or the spconv-2.x silent no-op
+"""
+from __future__ import annotations
+
+from functools import partial
+from typing import Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+from . import spconv
+
+
+def _cfg_get(cfg, key, default=None):
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    if hasattr(cfg, "get"):
+        try:
+            return cfg.get(key, default)
+        except TypeError:
+            pass
+    return getattr(cfg, key, default)
+
+
+def post_act_block(in_channels, out_channels, kernel_size, indice_key=None, stride=1, padding=0, conv_type="subm",
+                   norm_fn=None):
+    """spconv_backbone.py:86-107."""
+    if conv_type == "subm":
+        conv = spconv.SubMConv3d(in_channels, out_channels, kernel_size, bias=False, indice_key=indice_key)
+        relu = nn.ReLU()
+    elif conv_type == "spconv":
+        conv = spconv.SparseConv3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=False,
+                                   indice_key=indice_key)
+        relu = nn.ReLU(inplace=True)
+    elif conv_type == "inverseconv":
+        conv = spconv.SparseInverseConv3d(in_channels, out_channels, kernel_size, indice_key=indice_key, bias=False)
+        relu = nn.ReLU()
+    else:
+        raise NotImplementedError
+    return spconv.SparseSequential(conv, norm_fn(out_channels), relu)
+
+
+def post_act_block2d(in_channels, out_channels, kernel_size, indice_key=None, stride=1, padding=0, conv_type="subm",
+                     norm_fn=None):
+    """spconv_backbone.py:110-131."""
+    if conv_type == "subm":
+        conv = spconv.SubMConv2d(in_channels, out_channels, kernel_size, bias=False, indice_key=indice_key)
+        relu = nn.ReLU()
+    elif conv_type == "spconv":
+        conv = spconv.SparseConv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=False,
+                                   indice_key=indice_key)
+        relu = nn.ReLU(inplace=True)
+    elif conv_type == "inverseconv":
+        conv = spconv.SparseInverseConv2d(in_channels, out_channels, kernel_size, indice_key=indice_key, bias=False)
+        relu = nn.ReLU()
+    else:
+        raise NotImplementedError
+    return spconv.SparseSequential(conv, norm_fn(out_channels), relu)
+
+
+def layer_voxel_discard(sp: spconv.SparseConvTensor, rate: float, keep: Optional[torch.Tensor] = None):
+    """StVD layer discard (spconv_backbone.py:134-147), spconv-1.x semantics: keep rows ``perm[:int(N*(1-rate))]`` in
+    permuted order.  ``keep`` injects the permutation prefix (tests / benchmarks); otherwise a device randperm is drawn
+    (no host round trip -- the reference does np.random.permutation + H2D)."""
+    if rate == 0:
+        return sp
+    n = sp.features.shape[0]
+    n_keep = int(n * (1 - rate))
+    if keep is None:
+        keep = torch.randperm(n, device=sp.features.device)[:n_keep]
+    else:
+        keep = keep.to(sp.features.device)
+        assert keep.shape[0] == n_keep, f"injected keep has {keep.shape[0]} rows, expected int({n}*(1-{rate}))={n_keep}"
+    f, idx = ops.discard_rows(sp.features, sp.indices, keep)
+    return spconv.SparseConvTensor(f, idx, sp.spatial_shape, sp.batch_size)
+
+
+class NRConvBlock(nn.Module):
+    """Noise-resistant conv block (the paper's NRConv / "VirConvBlock"): 3-D convs + image-space 2-D convs, concatenated.
+    spconv_backbone.py:150-229."""
+
+    IMAGE_SHAPE = [1600, 600]  # spconv_backbone.py:220
+
+    def __init__(self, input_c=16, output_c=16, stride=1, padding=1, indice_key="vir1", conv_depth=False):
+        super().__init__()
+        self.stride = stride
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        self.conv_depth = conv_depth
+        if self.stride > 1:
+            self.down_layer = post_act_block(input_c, output_c, 3, norm_fn=norm_fn, stride=stride, padding=padding,
+                                             indice_key=("sp" + indice_key), conv_type="spconv")
+        c1 = output_c if self.stride > 1 else input_c
+        if self.conv_depth:
+            c1 += 4
+        c2 = output_c
+        # the two 3-D (2-D) SubM convs see identical coordinates: one shared rulebook each
+        self.d3_conv1 = post_act_block(c1, c2 // 2, 3, norm_fn=norm_fn, padding=1, indice_key=("subm3d" + indice_key))
+        self.d2_conv1 = post_act_block2d(c2 // 2, c2 // 2, 3, norm_fn=norm_fn, padding=1, indice_key=("subm2d" + indice_key))
+        self.d3_conv2 = post_act_block(c2 // 2, c2 // 2, 3, norm_fn=norm_fn, padding=1, indice_key=("subm3d" + indice_key))
+        self.d2_conv2 = post_act_block2d(c2 // 2, c2 // 2, 3, norm_fn=norm_fn, padding=1, indice_key=("subm2d" + indice_key))
+
+    def forward(self, sp_tensor, batch_size, calib, stride, x_trans_train=None, trans_param=None):
+        if self.stride > 1:
+            sp_tensor = self.down_layer(sp_tensor)
+        d3_feat1 = self.d3_conv1(sp_tensor)
+        d3_feat2 = self.d3_conv2(d3_feat1)
+
+        if not torch.is_tensor(calib):
+            calib = ops.calib_tensor(calib, d3_feat2.indices.device)
+        if trans_param is not None:
+            trans_param = torch.as_tensor(trans_param, dtype=torch.float32, device=d3_feat2.indices.device).reshape(batch_size, 3)
+        uv_coords = ops.project_uv(d3_feat2.indices, calib, trans_param, batch_size, stride)
+        d2_sp_tensor1 = spconv.SparseConvTensor(d3_feat2.features, uv_coords, self.IMAGE_SHAPE, batch_size)
+        d2_feat1 = self.d2_conv1(d2_sp_tensor1)
+        d2_feat2 = self.d2_conv2(d2_feat1)
+        return d3_feat2.replace_feature(torch.cat([d3_feat2.features, d2_feat2.features], -1))
+
+
+class VirConvL8x(nn.Module):
+    """VirConv-L backbone: one stream over fused LiDAR+virtual voxels (spconv_backbone.py:538-699)."""
+
+    def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.return_num_features_as_dict = _cfg_get(model_cfg, "RETURN_NUM_FEATURES_AS_DICT", False)
+        self.out_features = _cfg_get(model_cfg, "OUT_FEATURES", 64)
+        self.layer_discard_rate = _cfg_get(model_cfg, "LAYER_DISCARD_RATE", 0.0)
+        self.layer_discard_mode = _cfg_get(model_cfg, "LAYER_DISCARD_MODE", "spconv1_inplace")
+        assert self.layer_discard_mode in ("spconv1_inplace", "spconv2_noop")
+        num_filters = _cfg_get(model_cfg, "NUM_FILTERS")
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        self.sparse_shape = [int(v) for v in (np.asarray(grid_size)[::-1] + [1, 0, 0])]
+
+        self.vir_conv1 = NRConvBlock(input_channels, num_filters[0], stride=1, indice_key="vir1")
+        self.vir_conv2 = NRConvBlock(num_filters[0], num_filters[1], stride=2, indice_key="vir2")
+        self.vir_conv3 = NRConvBlock(num_filters[1], num_filters[2], stride=2, indice_key="vir3")
+        self.vir_conv4 = NRConvBlock(num_filters[2], num_filters[3], stride=2, padding=(0, 1, 1), indice_key="vir4")
+
+        last_pad = _cfg_get(model_cfg, "last_pad", 0)
+        self.conv_out = spconv.SparseSequential(
+            spconv.SparseConv3d(num_filters[3], self.out_features, (3, 1, 1), stride=(2, 1, 1), padding=last_pad,
+                                bias=False, indice_key="spconv_down2"),
+            norm_fn(self.out_features),
+            nn.ReLU(),
+        )
+        self.num_point_features = self.out_features
+        if self.return_num_features_as_dict:
+            self.num_point_features = {"x_conv1": num_filters[0], "x_conv2": num_filters[1], "x_conv3": num_filters[2],
+                                       "x_conv4": num_filters[3]}
+
+    def _discard(self, sp, batch_dict, tag):
+        if not self.training or self.layer_discard_mode == "spconv2_noop" or self.layer_discard_rate == 0:
+            return sp
+        keep = None
+        inj = batch_dict.get("layer_discard_keep")
+        if inj is not None:
+            keep = inj[tag]
+        return layer_voxel_discard(sp, self.layer_discard_rate, keep)
+
+    def forward(self, batch_dict):
+        if "transform_param" in batch_dict:
+            rot_num = batch_dict["transform_param"].shape[1]
+        else:
+            rot_num = 1
+        batch_size = batch_dict["batch_size"]
+        calib = batch_dict["calib"]
+        if not torch.is_tensor(calib):
+            calib = ops.calib_tensor(calib, batch_dict["voxel_features"].device)
+
+        for i in range(rot_num):
+            rid = "" if i == 0 else str(i)
+            feats, coords = batch_dict["voxel_features" + rid], batch_dict["voxel_coords" + rid]
+            feats[:, 4:7] = 0  # remove the RGB features, in place on the batch tensor (spconv_backbone.py:636)
+            x0 = spconv.SparseConvTensor(feats, coords.int(), self.sparse_shape, batch_size)
+
+            if "aug_param" in batch_dict:
+                trans_param = batch_dict["aug_param"]
+            else:
+                trans_param = None
+            if "transform_param" in batch_dict:
+                trans_param = batch_dict["transform_param"][:, i, :]
+
+            x1 = self.vir_conv1(x0, batch_size, calib, 1, None, trans_param)
+            x1 = self._discard(x1, batch_dict, f"x_conv1{rid}")
+            x2 = self.vir_conv2(x1, batch_size, calib, 2, None, trans_param)
+            x2 = self._discard(x2, batch_dict, f"x_conv2{rid}")
+            x3 = self.vir_conv3(x2, batch_size, calib, 4, None, trans_param)
+            x3 = self._discard(x3, batch_dict, f"x_conv3{rid}")
+            x4 = self.vir_conv4(x3, batch_size, calib, 8, None, trans_param)
+            out = self.conv_out(x4)
+
+            batch_dict.update({
+                "encoded_spconv_tensor" + rid: out,
+                "encoded_spconv_tensor_stride" + rid: 8,
+                "multi_scale_3d_features" + rid: {"x_conv1": x1, "x_conv2": x2, "x_conv3": x3, "x_conv4": x4},
+                "multi_scale_3d_strides" + rid: {"x_conv1": 1, "x_conv2": 2, "x_conv3": 4, "x_conv4": 8},
+            })
+        return batch_dict
+
+
+class HeightCompression(nn.Module):
+    """First consumer of the path's output (pcdet/models/backbones_2d/map_to_bev/height_compression.py:27-31)."""
+
+    def __init__(self, model_cfg=None, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.num_bev_features = _cfg_get(model_cfg, "NUM_BEV_FEATURES", 256) if model_cfg is not None else 256
+
+    def forward(self, batch_dict):
+        batch_dict["spatial_features_stride"] = batch_dict["encoded_spconv_tensor_stride"]
+        sp = batch_dict["encoded_spconv_tensor"].dense()
+        n, c, d, h, w = sp.shape
+        batch_dict["spatial_features"] = sp.view(n, c * d, h, w)
+        return batch_dict
+
+
+__all__ = {"VirConvL8x": VirConvL8x}

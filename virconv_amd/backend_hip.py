@@ -1,0 +1,253 @@
+"""HipBackend: torch-tensor wrappers over the C ABI (device memory, streams: plumbing only).
+
+Every method takes/returns contiguous CUDA tensors, launches on torch's CURRENT stream and allocates outputs and
+scratch through torch's caching allocator (the library itself never allocates, include/virconv_hip.h).
+Calling any of them with CPU tensors raises: there is no CPU path in the product.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, i32arr, f32arr
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _need(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.VirConvError(f"{name}: expected a CUDA/HIP tensor; virconv_amd has no CPU path")
+    if t.dtype != dtype:
+        raise _lib.VirConvError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def conv_out_shape(in_shape, ksize, stride, padding, dilation):
+    return tuple((int(i) + 2 * p - d * (k - 1) - 1) // s + 1 for i, k, s, p, d in zip(in_shape, ksize, stride, padding, dilation))
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+
+    # ------------------------------------------------------------------ rulebooks
+    def subm_rulebook(self, indices: torch.Tensor, spatial_shape: Sequence[int], ksize, dilation, want_rep: bool):
+        """-> pair_fwd (KV, N) int32, rep (N,) int32 or None."""
+        indices = _need(indices, torch.int32, "indices")
+        n, ndim = indices.shape[0], indices.shape[1] - 1
+        kv = int(np.prod(ksize))
+        dev = indices.device
+        pair = torch.empty((kv, n), dtype=torch.int32, device=dev)
+        rep = torch.empty((n,), dtype=torch.int32, device=dev) if want_rep else None
+        if n == 0:
+            return pair, rep
+        ws_bytes = self.lib.vc_hash_workspace_bytes(n)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        shp = i32arr(spatial_shape)
+        st = _stream()
+        check(self.lib.vc_hash_build(_ptr(indices), n, ndim, shp, _ptr(ws), ws_bytes, st), "vc_hash_build")
+        check(self.lib.vc_subm_rulebook(_ptr(indices), n, ndim, shp, i32arr(ksize), i32arr(dilation), _ptr(ws), ws_bytes,
+                                        _ptr(pair), _ptr(rep), st), "vc_subm_rulebook")
+        return pair, rep
+
+    def sparse_rulebook(self, indices: torch.Tensor, spatial_shape, batch_size: int, ksize, stride, padding, dilation):
+        """-> out_indices (M, ndim+1) int32 ascending, out_shape, pair_fwd (KV, M), pair_bwd (KV, N)."""
+        indices = _need(indices, torch.int32, "indices")
+        n, ndim = indices.shape[0], indices.shape[1] - 1
+        out_shape = conv_out_shape(spatial_shape, ksize, stride, padding, dilation)
+        kv = int(np.prod(ksize))
+        dev = indices.device
+        oshp = i32arr(out_shape)
+        ws_bytes = self.lib.vc_spconv_workspace_bytes(batch_size, ndim, oshp)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        n_out_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
+        st = _stream()
+        ks, sd, pd, dl = i32arr(ksize), i32arr(stride), i32arr(padding), i32arr(dilation)
+        check(self.lib.vc_spconv_mark_count(_ptr(indices), n, ndim, batch_size, oshp, ks, sd, pd, dl, _ptr(ws), ws_bytes,
+                                            _ptr(n_out_dev), st), "vc_spconv_mark_count")
+        n_out = int(n_out_dev.item())  # the one host sync of a strided conv (data-dependent output size)
+        out_indices = torch.empty((n_out, ndim + 1), dtype=torch.int32, device=dev)
+        pair_fwd = torch.empty((kv, n_out), dtype=torch.int32, device=dev)
+        pair_bwd = torch.empty((kv, n), dtype=torch.int32, device=dev)
+        check(self.lib.vc_spconv_emit_pairs(_ptr(indices), n, ndim, batch_size, oshp, ks, sd, pd, dl, _ptr(ws), ws_bytes,
+                                            n_out, _ptr(out_indices), _ptr(pair_fwd), _ptr(pair_bwd), st),
+              "vc_spconv_emit_pairs")
+        return out_indices, out_shape, pair_fwd, pair_bwd
+
+    # ------------------------------------------------------------------ convolution
+    def conv_forward(self, x: torch.Tensor, weight: torch.Tensor, pair_fwd: torch.Tensor) -> torch.Tensor:
+        x = _need(x, torch.float32, "features")
+        weight = _need(weight, torch.float32, "weight")
+        pair_fwd = _need(pair_fwd, torch.int32, "pair_fwd")
+        kv, n_out = pair_fwd.shape
+        cout, cin = weight.shape[0], weight.shape[-1]
+        assert weight.numel() == cout * kv * cin and x.shape[1] == cin
+        y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+        check(self.lib.vc_conv_forward(_ptr(x), x.shape[0], _ptr(pair_fwd), n_out, kv, _ptr(weight), cin, cout, _ptr(y),
+                                       _stream()), "vc_conv_forward")
+        return y
+
+    def conv_backward_input(self, dy: torch.Tensor, weight: torch.Tensor, tbl: torch.Tensor, n_in: int, mirror: bool,
+                            centre: int = -1, rep: Optional[torch.Tensor] = None) -> torch.Tensor:
+        dy = _need(dy, torch.float32, "grad_out")
+        weight = _need(weight, torch.float32, "weight")
+        tbl = _need(tbl, torch.int32, "pair table")
+        kv = tbl.shape[0]
+        assert tbl.shape[1] == n_in
+        cout, cin = weight.shape[0], weight.shape[-1]
+        dx = torch.empty((n_in, cin), dtype=torch.float32, device=dy.device)
+        src, src_centre = dy, None
+        if rep is not None:
+            rep = _need(rep, torch.int32, "rep")
+            grp = torch.empty_like(dy)
+            check(self.lib.vc_group_sum(_ptr(dy), _ptr(rep), dy.shape[0], cout, _ptr(grp), _stream()), "vc_group_sum")
+            src, src_centre = grp, dy
+        check(self.lib.vc_conv_backward_input(_ptr(src), _ptr(src_centre), dy.shape[0], _ptr(tbl), n_in, kv, _ptr(weight),
+                                              cin, cout, 1 if mirror else 0, centre if rep is not None else -1,
+                                              _ptr(rep), _ptr(dx), _stream()), "vc_conv_backward_input")
+        return dx
+
+    def conv_backward_weight(self, x: torch.Tensor, dy: torch.Tensor, pair_fwd: torch.Tensor, weight_shape) -> torch.Tensor:
+        x = _need(x, torch.float32, "features")
+        dy = _need(dy, torch.float32, "grad_out")
+        pair_fwd = _need(pair_fwd, torch.int32, "pair_fwd")
+        kv, n_out = pair_fwd.shape
+        cout, cin = int(weight_shape[0]), int(weight_shape[-1])
+        dw = torch.empty(tuple(weight_shape), dtype=torch.float32, device=x.device)
+        ws_bytes = self.lib.vc_conv_backward_weight_workspace_bytes(n_out, kv, cin, cout)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+        check(self.lib.vc_conv_backward_weight(_ptr(x), _ptr(dy), _ptr(pair_fwd), n_out, kv, cin, cout, _ptr(dw), _ptr(ws),
+                                               ws_bytes, _stream()), "vc_conv_backward_weight")
+        return dw
+
+    # ------------------------------------------------------------------ projection / discard / dense
+    def project_uv(self, indices: torch.Tensor, calib: torch.Tensor, trans: Optional[torch.Tensor], batch_size: int,
+                   stride: int, want_depth: bool = False):
+        indices = _need(indices, torch.int32, "indices")
+        calib = _need(calib, torch.float32, "calib")
+        assert indices.shape[1] == 4 and calib.shape == (batch_size, 33)
+        if trans is not None:
+            trans = _need(trans, torch.float32, "trans_param")
+            assert trans.shape == (batch_size, 3)
+        n = indices.shape[0]
+        dev = indices.device
+        params = torch.empty((batch_size, 32), dtype=torch.float32, device=dev)
+        uv = torch.empty((n, 3), dtype=torch.int32, device=dev)
+        depth = torch.empty((n,), dtype=torch.float32, device=dev) if want_depth else None
+        st = _stream()
+        check(self.lib.vc_project_prepare(_ptr(calib), _ptr(trans), batch_size, _ptr(params), st), "vc_project_prepare")
+        check(self.lib.vc_project_uv(_ptr(indices), n, _ptr(params), batch_size, int(stride), _ptr(uv), _ptr(depth), st),
+              "vc_project_uv")
+        return uv, depth
+
+    def gather_rows(self, features: torch.Tensor, indices: Optional[torch.Tensor], keep: torch.Tensor):
+        features = _need(features, torch.float32, "features")
+        keep = _need(keep, torch.int64, "keep")
+        nk, c = keep.shape[0], features.shape[1]
+        fo = torch.empty((nk, c), dtype=torch.float32, device=features.device)
+        io, icols = None, 0
+        if indices is not None:
+            indices = _need(indices, torch.int32, "indices")
+            icols = indices.shape[1]
+            io = torch.empty((nk, icols), dtype=torch.int32, device=features.device)
+        check(self.lib.vc_gather_rows(_ptr(features), _ptr(indices), c, icols, _ptr(keep), nk, _ptr(fo), _ptr(io),
+                                      _stream()), "vc_gather_rows")
+        return fo, io
+
+    def scatter_rows(self, grad_out: torch.Tensor, keep: torch.Tensor, n_in: int) -> torch.Tensor:
+        grad_out = _need(grad_out, torch.float32, "grad_out")
+        keep = _need(keep, torch.int64, "keep")
+        c = grad_out.shape[1]
+        gi = torch.empty((n_in, c), dtype=torch.float32, device=grad_out.device)
+        check(self.lib.vc_scatter_rows(_ptr(grad_out), c, _ptr(keep), keep.shape[0], n_in, _ptr(gi), _stream()),
+              "vc_scatter_rows")
+        return gi
+
+    def to_dense(self, features: torch.Tensor, indices: torch.Tensor, spatial_shape, batch_size: int) -> torch.Tensor:
+        features = _need(features, torch.float32, "features")
+        indices = _need(indices, torch.int32, "indices")
+        n, c = features.shape
+        ndim = indices.shape[1] - 1
+        dense = torch.zeros((batch_size, c) + tuple(int(s) for s in spatial_shape), dtype=torch.float32,
+                            device=features.device)
+        check(self.lib.vc_to_dense(_ptr(features), _ptr(indices), n, c, ndim, batch_size, i32arr(spatial_shape),
+                                   _ptr(dense), _stream()), "vc_to_dense")
+        return dense
+
+    def from_dense(self, dense: torch.Tensor, indices: torch.Tensor, spatial_shape, batch_size: int) -> torch.Tensor:
+        dense = _need(dense, torch.float32, "dense")
+        indices = _need(indices, torch.int32, "indices")
+        n, c = indices.shape[0], dense.shape[1]
+        ndim = indices.shape[1] - 1
+        f = torch.empty((n, c), dtype=torch.float32, device=dense.device)
+        check(self.lib.vc_from_dense(_ptr(dense), _ptr(indices), n, c, ndim, batch_size, i32arr(spatial_shape), _ptr(f),
+                                     _stream()), "vc_from_dense")
+        return f
+
+    # ------------------------------------------------------------------ voxelise + MeanVFE
+    def voxelize_mean(self, points: torch.Tensor, pc_range, voxel_size, max_points: int, max_voxels: int,
+                      vfe_max_last: bool):
+        points = _need(points, torch.float32, "points")
+        p, f = points.shape
+        dev = points.device
+        ws_bytes = self.lib.vc_voxelize_workspace_bytes(p, max_points)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        feats = torch.zeros((max_voxels, f), dtype=torch.float32, device=dev)
+        coords = torch.zeros((max_voxels, 3), dtype=torch.int32, device=dev)
+        num = torch.zeros((max_voxels,), dtype=torch.int32, device=dev)
+        nv = torch.zeros((1,), dtype=torch.int32, device=dev)
+        check(self.lib.vc_voxelize_mean(_ptr(points), p, f, f32arr(pc_range), f32arr(voxel_size), max_points, max_voxels,
+                                        1 if vfe_max_last else 0, _ptr(ws), ws_bytes, _ptr(feats), _ptr(coords),
+                                        _ptr(num), _ptr(nv), _stream()), "vc_voxelize_mean")
+        m = int(nv.item())
+        return feats[:m], coords[:m], num[:m]
+
+    # ------------------------------------------------------------------ BatchNorm(+ReLU)
+    def bn_forward(self, x: torch.Tensor, gamma, beta, running_mean, running_var, training: bool, momentum: float,
+                   eps: float, relu: bool, out: Optional[torch.Tensor] = None, out_col0: int = 0):
+        """-> (y, mean, var).  `out` (N, Ctot) lets the result land at a column offset of a wider row (fused concat)."""
+        x = _need(x, torch.float32, "features")
+        n, c = x.shape
+        dev = x.device
+        st = _stream()
+        if training:
+            mean = torch.empty((c,), dtype=torch.float32, device=dev)
+            var = torch.empty((c,), dtype=torch.float32, device=dev)
+            ws_bytes = self.lib.vc_bn_workspace_bytes(n, c)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+            check(self.lib.vc_bn_stats(_ptr(x), n, c, _ptr(mean), _ptr(var), _ptr(running_mean), _ptr(running_var),
+                                       float(momentum), _ptr(ws), ws_bytes, st), "vc_bn_stats")
+        else:
+            mean, var = running_mean, running_var
+        if out is None:
+            out = torch.empty((n, c), dtype=torch.float32, device=dev)
+            out_col0 = 0
+        check(self.lib.vc_bn_apply_relu(_ptr(x), n, c, _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), float(eps),
+                                        1 if relu else 0, _ptr(out), out.shape[1], out_col0, st), "vc_bn_apply_relu")
+        return out, mean, var
+
+    def bn_backward(self, x, dy, dy_col0, mean, var, gamma, beta, eps: float, relu: bool):
+        x = _need(x, torch.float32, "features")
+        dy = _need(dy, torch.float32, "grad_out")
+        n, c = x.shape
+        dev = x.device
+        dx = torch.empty_like(x)
+        dgamma = torch.empty((c,), dtype=torch.float32, device=dev)
+        dbeta = torch.empty((c,), dtype=torch.float32, device=dev)
+        ws_bytes = self.lib.vc_bn_workspace_bytes(n, c)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        check(self.lib.vc_bn_relu_backward(_ptr(x), _ptr(dy), dy.shape[1], dy_col0, n, c, _ptr(mean), _ptr(var), _ptr(gamma),
+                                           _ptr(beta), float(eps), 1 if relu else 0, _ptr(dx), _ptr(dgamma), _ptr(dbeta),
+                                           _ptr(ws), ws_bytes, _stream()), "vc_bn_relu_backward")
+        return dx, dgamma, dbeta

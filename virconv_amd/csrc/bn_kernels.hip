@@ -1,0 +1,254 @@
+// K11: training/eval BatchNorm1d(+ReLU) over the N active rows of a sparse tensor, HBM-bound elementwise/reduction
+// work (replaces nn.BatchNorm1d(eps=1e-3, momentum=0.01) + nn.ReLU after every conv, spconv_backbone.py:101-105,160).
+// Reductions are two-stage with a fixed summation order (bit-stable run to run); accumulation across threads in fp64.
+#include "common.h"
+
+namespace vc {
+
+static constexpr int kMaxBnBlocks = 512;
+
+// Per-block partial sums of (a, b) per channel, where for STATS: a = x, b = x*x;
+// for BWD: a = dyr (relu-masked dy), b = dyr * xhat.
+template <bool BWD>
+__global__ void __launch_bounds__(256) bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        int dy_stride, int dy_col0, int64_t n, int c,
+                                                        const float* __restrict__ mean, const float* __restrict__ var,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, int relu, int64_t rows_per_block,
+                                                        double* __restrict__ partial) {
+  __shared__ double lds[256 * 8];
+  const int c4 = c >> 2;
+  const int R = 256 / c4;           // row-threads per block (power of two)
+  const int cq = threadIdx.x % c4;  // which float4 of the row
+  const int rt = threadIdx.x / c4;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(r0 + rows_per_block, n);
+  float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+  float mu[4], istd[4], g[4], bt[4];
+  if (BWD) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ch = cq * 4 + j;
+      mu[j] = mean[ch];
+      istd[j] = 1.0f / sqrtf(var[ch] + eps);
+      g[j] = gamma ? gamma[ch] : 1.f;
+      bt[j] = beta ? beta[ch] : 0.f;
+    }
+  }
+  if (rt < R) {
+    for (int64_t r = r0 + rt; r < r1; r += R) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + r * c + cq * 4);
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+      if (!BWD) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sa[j] += xs[j]; sb[j] += xs[j] * xs[j]; }
+      } else {
+        const float4 dv = *reinterpret_cast<const float4*>(dy + r * dy_stride + dy_col0 + cq * 4);
+        const float ds[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (xs[j] - mu[j]) * istd[j];
+          float d = ds[j];
+          if (relu && !(xh * g[j] + bt[j] > 0.f)) d = 0.f;
+          sa[j] += d;
+          sb[j] += d * xh;
+        }
+      }
+    }
+  }
+  double* my = lds + threadIdx.x * 8;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { my[j] = (double)sa[j]; my[4 + j] = (double)sb[j]; }
+  __syncthreads();
+  for (int s = R >> 1; s >= 1; s >>= 1) {
+    if (rt < s) {
+      const double* o = lds + (threadIdx.x + s * c4) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) my[j] += o[j];
+    }
+    __syncthreads();
+  }
+  if (rt == 0) {
+    double* dst = partial + (int64_t)blockIdx.x * 2 * c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      dst[cq * 4 + j] = my[j];
+      dst[c + cq * 4 + j] = my[4 + j];
+    }
+  }
+}
+
+__global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, int nb, int64_t n, int c,
+                                         float* __restrict__ mean, float* __restrict__ var,
+                                         float* __restrict__ running_mean, float* __restrict__ running_var,
+                                         float momentum) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < nb; ++b) {
+    s += partial[(int64_t)b * 2 * c + ch];
+    ss += partial[(int64_t)b * 2 * c + c + ch];
+  }
+  const double m = s / (double)n;
+  double v = ss / (double)n - m * m;
+  if (v < 0.0) v = 0.0;
+  mean[ch] = (float)m;
+  var[ch] = (float)v;
+  if (running_mean) running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)m;
+  if (running_var) {
+    const double unb = (n > 1) ? v * (double)n / (double)(n - 1) : v;
+    running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unb;
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nb, int c, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ sums /* [2][c]: dbeta, dgamma */) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < nb; ++b) {
+    s += partial[(int64_t)b * 2 * c + ch];
+    ss += partial[(int64_t)b * 2 * c + c + ch];
+  }
+  if (dbeta) dbeta[ch] = (float)s;
+  if (dgamma) dgamma[ch] = (float)ss;
+  sums[ch] = (float)s;
+  sums[c + ch] = (float)ss;
+}
+
+__global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__ x, int64_t n, int c,
+                                                       const float* __restrict__ mean, const float* __restrict__ var,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps, int relu, float* __restrict__ y, int y_stride,
+                                                       int y_col0) {
+  const int c4 = c >> 2;
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * c4) return;
+  const int64_t r = t / c4;
+  const int cq = (int)(t - r * c4);
+  const float4 xv = *reinterpret_cast<const float4*>(x + r * c + cq * 4);
+  const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+  float o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ch = cq * 4 + j;
+    const float istd = 1.0f / sqrtf(var[ch] + eps);
+    float v = (xs[j] - mean[ch]) * istd * (gamma ? gamma[ch] : 1.f) + (beta ? beta[ch] : 0.f);
+    if (relu) v = fmaxf(v, 0.f);
+    o[j] = v;
+  }
+  *reinterpret_cast<float4*>(y + r * y_stride + y_col0 + cq * 4) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// dx = gamma * istd * (dyr - dbeta/N - xhat * dgamma/N)         (training-mode BN)
+__global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        int dy_stride, int dy_col0, int64_t n, int c,
+                                                        const float* __restrict__ mean, const float* __restrict__ var,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, int relu, const float* __restrict__ sums,
+                                                        float* __restrict__ dx) {
+  const int c4 = c >> 2;
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * c4) return;
+  const int64_t r = t / c4;
+  const int cq = (int)(t - r * c4);
+  const float4 xv = *reinterpret_cast<const float4*>(x + r * c + cq * 4);
+  const float4 dv = *reinterpret_cast<const float4*>(dy + r * dy_stride + dy_col0 + cq * 4);
+  const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+  const float ds[4] = {dv.x, dv.y, dv.z, dv.w};
+  const float inv_n = 1.0f / (float)n;
+  float o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ch = cq * 4 + j;
+    const float istd = 1.0f / sqrtf(var[ch] + eps);
+    const float g = gamma ? gamma[ch] : 1.f, bt = beta ? beta[ch] : 0.f;
+    const float xh = (xs[j] - mean[ch]) * istd;
+    float d = ds[j];
+    if (relu && !(xh * g + bt > 0.f)) d = 0.f;
+    o[j] = g * istd * (d - sums[ch] * inv_n - xh * sums[c + ch] * inv_n);
+  }
+  *reinterpret_cast<float4*>(dx + r * c + cq * 4) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+static inline void bn_split(int64_t n, int c, int& nb, int64_t& rpb) {
+  const int R = 256 / (c >> 2);
+  int64_t want = cdiv(n, (int64_t)R * 8);
+  if (want < 1) want = 1;
+  if (want > kMaxBnBlocks) want = kMaxBnBlocks;
+  rpb = cdiv(n, want);
+  nb = (int)cdiv(n, rpb);
+}
+
+static inline bool bn_c_ok(int c) { return c == 4 || c == 8 || c == 16 || c == 32 || c == 64 || c == 128; }
+
+}  // namespace vc
+
+using namespace vc;
+
+extern "C" {
+
+size_t vc_bn_workspace_bytes(int64_t n, int c) {
+  (void)n;
+  if (c < 1) return 0;
+  return (size_t)kMaxBnBlocks * 2 * c * sizeof(double) + 2 * c * sizeof(float) + 64;
+}
+
+int vc_bn_stats(const float* x, int64_t n, int c, float* mean, float* var, float* running_mean, float* running_var,
+                float momentum, void* ws, size_t ws_bytes, void* stream) {
+  VC_REQUIRE(bn_c_ok(c), "vc_bn_stats: unsupported channel count %d", c);
+  VC_REQUIRE(n >= 1 && x && mean && var && ws, "vc_bn_stats: null/invalid argument (n=%lld)", (long long)n);
+  if (ws_bytes < vc_bn_workspace_bytes(n, c)) { set_error("vc_bn_stats: workspace too small"); return VC_ECAPACITY; }
+  hipStream_t st = (hipStream_t)stream;
+  int nb;
+  int64_t rpb;
+  bn_split(n, c, nb, rpb);
+  double* partial = (double*)ws;
+  hipLaunchKernelGGL((bn_reduce_kernel<false>), dim3(nb), dim3(256), 0, st, x, (const float*)nullptr, 0, 0, n, c,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f, 0,
+                     rpb, partial);
+  VC_CHECK_LAUNCH("bn_reduce_kernel<stats>");
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(1), dim3(128), 0, st, partial, nb, n, c, mean, var, running_mean,
+                     running_var, momentum);
+  VC_CHECK_LAUNCH("bn_stats_finalize_kernel");
+  return VC_OK;
+}
+
+int vc_bn_apply_relu(const float* x, int64_t n, int c, const float* mean, const float* var, const float* gamma,
+                     const float* beta, float eps, int relu, float* y, int y_stride, int y_col0, void* stream) {
+  VC_REQUIRE(c > 0 && c % 4 == 0 && y_stride >= c && y_stride % 4 == 0 && y_col0 % 4 == 0 && y_col0 + c <= y_stride,
+             "vc_bn_apply_relu: bad channel/stride arguments (c=%d stride=%d col0=%d)", c, y_stride, y_col0);
+  if (n == 0) return VC_OK;
+  VC_REQUIRE(n > 0 && x && mean && var && y, "vc_bn_apply_relu: null argument");
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)cdiv(n * (c / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, n, c,
+                     mean, var, gamma, beta, eps, relu, y, y_stride, y_col0);
+  VC_CHECK_LAUNCH("bn_apply_kernel");
+  return VC_OK;
+}
+
+int vc_bn_relu_backward(const float* x, const float* dy, int dy_stride, int dy_col0, int64_t n, int c, const float* mean,
+                        const float* var, const float* gamma, const float* beta, float eps, int relu, float* dx,
+                        float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream) {
+  VC_REQUIRE(bn_c_ok(c), "vc_bn_relu_backward: unsupported channel count %d", c);
+  VC_REQUIRE(dy_stride >= c && dy_stride % 4 == 0 && dy_col0 % 4 == 0 && dy_col0 + c <= dy_stride,
+             "vc_bn_relu_backward: bad stride arguments");
+  VC_REQUIRE(n >= 1 && x && dy && mean && var && dx && ws, "vc_bn_relu_backward: null/invalid argument");
+  if (ws_bytes < vc_bn_workspace_bytes(n, c)) { set_error("vc_bn_relu_backward: workspace too small"); return VC_ECAPACITY; }
+  hipStream_t st = (hipStream_t)stream;
+  int nb;
+  int64_t rpb;
+  bn_split(n, c, nb, rpb);
+  double* partial = (double*)ws;
+  float* sums = (float*)(partial + (size_t)kMaxBnBlocks * 2 * c);
+  hipLaunchKernelGGL((bn_reduce_kernel<true>), dim3(nb), dim3(256), 0, st, x, dy, dy_stride, dy_col0, n, c, mean, var,
+                     gamma, beta, eps, relu, rpb, partial);
+  VC_CHECK_LAUNCH("bn_reduce_kernel<bwd>");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(128), 0, st, partial, nb, c, dgamma, dbeta, sums);
+  VC_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+  hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3((unsigned)cdiv(n * (c / 4), 256)), dim3(256), 0, st, x, dy, dy_stride,
+                     dy_col0, n, c, mean, var, gamma, beta, eps, relu, sums, dx);
+  VC_CHECK_LAUNCH("bn_bwd_dx_kernel");
+  return VC_OK;
+}
+
+}  // extern "C"

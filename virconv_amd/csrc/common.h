@@ -1,0 +1,113 @@
+// Shared host/device helpers for libvirconv_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/virconv_hip.h"
+
+namespace vc {
+
+void set_error(const char* fmt, ...);
+
+#define VC_REQUIRE(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      ::vc::set_error(__VA_ARGS__);      \
+      return VC_EINVAL;                  \
+    }                                    \
+  } while (0)
+
+#define VC_CHECK_LAUNCH(name)                                                      \
+  do {                                                                             \
+    hipError_t e__ = hipGetLastError();                                            \
+    if (e__ != hipSuccess) {                                                       \
+      ::vc::set_error("%s: HIP launch error: %s", name, hipGetErrorString(e__));   \
+      return VC_EHIP;                                                              \
+    }                                                                              \
+  } while (0)
+
+#define VC_CHECK_HIP(expr)                                                         \
+  do {                                                                             \
+    hipError_t e__ = (expr);                                                       \
+    if (e__ != hipSuccess) {                                                       \
+      ::vc::set_error("%s: %s", #expr, hipGetErrorString(e__));                    \
+      return VC_EHIP;                                                              \
+    }                                                                              \
+  } while (0)
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Internal 3-D view of a 2-D or 3-D index row: 2-D tensors are (D=1, H=S0, W=S1) with z = 0.
+struct Dims {
+  int ndim;  // 2 or 3
+  int D, H, W;
+};
+
+static inline Dims make_dims(int ndim, const int32_t* shape) {
+  Dims d;
+  d.ndim = ndim;
+  if (ndim == 3) {
+    d.D = shape[0]; d.H = shape[1]; d.W = shape[2];
+  } else {
+    d.D = 1; d.H = shape[0]; d.W = shape[1];
+  }
+  return d;
+}
+
+struct Kern3 {  // kernel geometry in the internal 3-D view
+  int k[3], s[3], p[3], d[3];
+  int kv;
+};
+
+static inline Kern3 make_kern(int ndim, const int32_t* ks, const int32_t* st, const int32_t* pd, const int32_t* dl) {
+  Kern3 g;
+  for (int a = 0; a < 3; ++a) { g.k[a] = 1; g.s[a] = 1; g.p[a] = 0; g.d[a] = 1; }
+  int o = 3 - ndim;
+  for (int a = 0; a < ndim; ++a) {
+    g.k[o + a] = ks[a];
+    if (st) g.s[o + a] = st[a];
+    if (pd) g.p[o + a] = pd[a];
+    if (dl) g.d[o + a] = dl[a];
+  }
+  g.kv = g.k[0] * g.k[1] * g.k[2];
+  return g;
+}
+
+#ifdef __HIPCC__
+__device__ __forceinline__ void load_coord(const int32_t* __restrict__ indices, int64_t i, int ndim, int& b, int& z,
+                                           int& y, int& x) {
+  const int32_t* r = indices + i * (ndim + 1);
+  b = r[0];
+  if (ndim == 3) { z = r[1]; y = r[2]; x = r[3]; }
+  else { z = 0; y = r[1]; x = r[2]; }
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+  return k;
+}
+
+static constexpr uint64_t kEmptyKey = ~0ULL;
+
+// hash workspace = [keys: cap x u64][vals: cap x i32]
+__device__ __forceinline__ int hash_lookup(const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals,
+                                           uint64_t mask, uint64_t key) {
+  uint64_t slot = mix64(key) & mask;
+  for (;;) {
+    uint64_t k = keys[slot];
+    if (k == key) return vals[slot];
+    if (k == kEmptyKey) return -1;
+    slot = (slot + 1) & mask;
+  }
+}
+#endif
+
+static inline uint64_t hash_capacity(int64_t n) {
+  uint64_t cap = 1024;
+  while (cap < (uint64_t)(2 * n)) cap <<= 1;
+  return cap;
+}
+
+}  // namespace vc

@@ -1,0 +1,417 @@
+// Feature-side kernels of the VirConv hot path for gfx950:
+//   K6/K7  output-stationary gather-GEMM (forward and backward-input) on v_mfma_f32_16x16x4_f32
+//   K8     weight gradient: wave-ballot compaction of active pairs + MFMA outer products + 2-stage reduction
+//   group-sum for the duplicate-coordinate (2-D image-space) SubM backward
+//
+// MFMA mapping (wave64, v_mfma_f32_16x16x4_f32; A[i=l&15][k=l>>4], B[k=l>>4][n=l&15], D[row=(l>>4)*4+reg][col=l&15]):
+//   M = 16 output rows of the tile, N = 16 output channels, K = 4 source channels per instruction.
+//   Lane (i, q) gathers V contiguous source channels [ch*4V + q*V, +V) of row tbl[k][row0+i] with ONE vector load
+//   (64 contiguous bytes per gathered row across the 4 q-lanes) and feeds element j to MFMA step j; the weight
+//   fragment is permuted identically, so the K order inside a chunk is (j, q) -- a fixed order, results are
+//   run-to-run bit-stable.  fp32 MFMA is exact fp32 (bitwise an fmaf chain), so the 1e-4 parity bound holds.
+#include "common.h"
+
+namespace vc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int V>
+struct VecLoad;
+template <>
+struct VecLoad<4> {
+  static __device__ __forceinline__ void ld(const float* p, float* o) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  }
+};
+template <>
+struct VecLoad<2> {
+  static __device__ __forceinline__ void ld(const float* p, float* o) {
+    float2 v = *reinterpret_cast<const float2*>(p);
+    o[0] = v.x; o[1] = v.y;
+  }
+};
+template <>
+struct VecLoad<1> {
+  static __device__ __forceinline__ void ld(const float* p, float* o) { o[0] = *p; }
+};
+
+// out[o, :] = sum_k src_k[tbl[k, o], :] @ Wsel(k)       CK = source channels (GEMM K), CN = output channels (GEMM N)
+// BWD = false: Wsel(k)[kk][n] = w[(n*kv + kw)*CK + kk]   (w = (Cout=CN, KV, Cin=CK))
+// BWD = true : Wsel(k)[kk][n] = w[(kk*kv + kw)*CN + n]   (w = (Cout=CK, KV, Cin=CN))
+template <int CK, int CN, bool BWD, int RT>
+__global__ void __launch_bounds__(256) gather_gemm_kernel(const float* __restrict__ src,
+                                                          const float* __restrict__ src_centre,
+                                                          const int32_t* __restrict__ tbl, const float* __restrict__ w,
+                                                          float* __restrict__ out, const int32_t* __restrict__ rep,
+                                                          int64_t n_out, int kv, int centre, int mirror) {
+  constexpr int V = (CK >= 16) ? 4 : CK / 4;
+  constexpr int NCH = CK / (4 * V);
+  constexpr int NT = (CN + 15) / 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * (RT * 16);
+  if (row0 >= n_out) return;  // wave-uniform
+
+  f32x4 acc[RT][NT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  bool centre_only[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    const int64_t r = row0 + t * 16 + i;
+    centre_only[t] = (rep != nullptr) && (r < n_out) && (rep[r] != (int32_t)r);
+  }
+
+  for (int k = 0; k < kv; ++k) {
+    int id[RT];
+    bool anyv = false;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const int64_t r = row0 + t * 16 + i;
+      int v = (r < n_out) ? tbl[(int64_t)k * n_out + r] : -1;
+      if (centre_only[t] && k != centre) v = -1;
+      id[t] = v;
+      anyv |= (v >= 0);
+    }
+    if (__ballot(anyv) == 0ULL) continue;  // no active pair in this wave's rows for offset k
+    const float* __restrict__ S = (k == centre && src_centre != nullptr) ? src_centre : src;
+    const int kw = mirror ? (kv - 1 - k) : k;
+    unsigned long long tmask[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) tmask[t] = __ballot(id[t] >= 0);
+
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      float b[NT][V];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 16 + i;
+        if (n < CN) {
+          if (!BWD) {
+            VecLoad<V>::ld(w + ((int64_t)n * kv + kw) * CK + ch * 4 * V + q * V, b[nt]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+              const int kk = ch * 4 * V + q * V + j;
+              b[nt][j] = w[((int64_t)kk * kv + kw) * CN + n];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < V; ++j) b[nt][j] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        if (tmask[t] == 0ULL) continue;  // wave-uniform
+        float a[V];
+        if (id[t] >= 0) {
+          VecLoad<V>::ld(S + (int64_t)id[t] * CK + ch * 4 * V + q * V, a);
+        } else {
+#pragma unroll
+          for (int j = 0; j < V; ++j) a[j] = 0.f;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int j = 0; j < V; ++j)
+            acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[nt][j], acc[t][nt], 0, 0, 0);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 16 + i;
+      if (n >= CN) continue;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int64_t r = row0 + t * 16 + q * 4 + reg;
+        if (r < n_out) out[r * CN + n] = acc[t][nt][reg];
+      }
+    }
+}
+
+// --------------------------------------------------------------------------------------------- K8 weight gradient
+// grid (nsplit, kv); each block owns offset k = blockIdx.y and a contiguous range of output rows.  Each wave scans its
+// rows 64 at a time, ballot/prefix-compacts the active (in, out) pairs into an LDS queue, and consumes the queue four
+// pairs per MFMA step:  dW_k[ci][co] += x[in_p][ci] * dy[out_p][co]   (M = ci, N = co, K = pair).
+template <int CI, int CO>
+__global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         const int32_t* __restrict__ tbl, int64_t n_out, int kv,
+                                                         int64_t rows_per_block, float* __restrict__ partial) {
+  constexpr int MT = (CI + 15) / 16, NT = (CO + 15) / 16;
+  __shared__ int q_in[4][136];
+  __shared__ int q_out[4][136];
+  __shared__ float red[MT * 16 * NT * 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int k = blockIdx.y;
+  const int64_t brow0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t bend = min(brow0 + rows_per_block, n_out);
+  const int64_t rpw = rows_per_block / 4;  // rows_per_block is a multiple of 256
+  const int64_t wstart = brow0 + wave * rpw;
+  const int64_t wend = min(wstart + rpw, bend);
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int* qi = q_in[wave];
+  int* qo = q_out[wave];
+  int qlen = 0;
+  for (int64_t base = wstart; base < wend; base += 64) {
+    const int64_t r = base + lane;
+    const int v = (r < wend) ? tbl[(int64_t)k * n_out + r] : -1;
+    const bool valid = v >= 0;
+    const unsigned long long m = __ballot(valid);
+    if (m == 0ULL) continue;
+    const int pos = __popcll(m & ((1ULL << lane) - 1ULL));
+    if (valid) { qi[qlen + pos] = v; qo[qlen + pos] = (int)r; }
+    qlen += __popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    const int ng = qlen >> 2;
+    for (int g = 0; g < ng; ++g) {
+      const int pin = qi[g * 4 + q], pout = qo[g * 4 + q];
+      float a[MT], b[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = (mt * 16 + i < CI) ? x[(int64_t)pin * CI + mt * 16 + i] : 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[nt] = (nt * 16 + i < CO) ? dy[(int64_t)pout * CO + nt * 16 + i] : 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+    }
+    const int rem = qlen - ng * 4;
+    int t1 = 0, t2 = 0;
+    if (lane < rem) { t1 = qi[ng * 4 + lane]; t2 = qo[ng * 4 + lane]; }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < rem) { qi[lane] = t1; qo[lane] = t2; }
+    qlen = rem;
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (qlen > 0) {  // tail group, padded with zero operands
+    const bool ok = q < qlen;
+    const int pin = ok ? qi[q] : 0, pout = ok ? qo[q] : 0;
+    float a[MT], b[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[mt] = (ok && mt * 16 + i < CI) ? x[(int64_t)pin * CI + mt * 16 + i] : 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = (ok && nt * 16 + i < CO) ? dy[(int64_t)pout * CO + nt * 16 + i] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+  }
+
+  // fixed-order cross-wave reduction through LDS (wave 0 stores, waves 1..3 add in order)
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int ci = mt * 16 + q * 4 + reg, co = nt * 16 + i;
+            float* p = &red[ci * (NT * 16) + co];
+            *p = (wv == 0) ? acc[mt][nt][reg] : (*p + acc[mt][nt][reg]);
+          }
+    }
+    __syncthreads();
+  }
+  float* dst = partial + ((int64_t)blockIdx.x * kv + k) * (CI * CO);
+  for (int e = threadIdx.x; e < CI * CO; e += 256) {
+    const int ci = e / CO, co = e - ci * CO;
+    dst[e] = red[ci * (NT * 16) + co];
+  }
+}
+
+// dweight[(co*kv + k)*CI + ci] = sum_s partial[s][k][ci][co]   (fixed order over s)
+__global__ void __launch_bounds__(256) bwd_weight_reduce_kernel(const float* __restrict__ partial, int nsplit, int kv,
+                                                                int ci_n, int co_n, float* __restrict__ dweight) {
+  const int total = kv * ci_n * co_n;
+  int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int ci = e % ci_n;
+  const int k = (e / ci_n) % kv;
+  const int co = e / (ci_n * kv);
+  const int64_t off = ((int64_t)k * ci_n + ci) * co_n + co;
+  float s = 0.f;
+  for (int sp = 0; sp < nsplit; ++sp) s += partial[(int64_t)sp * total + off];
+  dweight[e] = s;
+}
+
+// --------------------------------------------------------------------------------------------- group sum (dup path)
+__global__ void __launch_bounds__(256) group_sum_kernel(const float* __restrict__ dy, const int32_t* __restrict__ rep,
+                                                        int64_t n, int c, float* __restrict__ grp) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * c) return;
+  int64_t r = t / c;
+  int ch = (int)(t - r * c);
+  int g = rep[r];
+  if (g < 0) g = (int)r;
+  unsafeAtomicAdd(&grp[(int64_t)g * c + ch], dy[t]);
+}
+
+// --------------------------------------------------------------------------------------------- dispatch
+static constexpr int kRT = 2;  // 32 rows per wave, 128 rows per 256-thread block
+
+template <int CK, int CN, bool BWD>
+static int launch_gg(const float* src, const float* src_centre, const int32_t* tbl, const float* w, float* out,
+                     const int32_t* rep, int64_t n_out, int kv, int centre, int mirror, hipStream_t st) {
+  const int64_t rows_per_block = 4 * kRT * 16;
+  hipLaunchKernelGGL((gather_gemm_kernel<CK, CN, BWD, kRT>), dim3((unsigned)cdiv(n_out, rows_per_block)), dim3(256), 0,
+                     st, src, src_centre, tbl, w, out, rep, n_out, kv, centre, mirror);
+  VC_CHECK_LAUNCH("gather_gemm_kernel");
+  return VC_OK;
+}
+
+template <int CK, bool BWD>
+static int dispatch_cn(int cn, const float* src, const float* src_centre, const int32_t* tbl, const float* w, float* out,
+                       const int32_t* rep, int64_t n_out, int kv, int centre, int mirror, hipStream_t st) {
+  switch (cn) {
+    case 4: return launch_gg<CK, 4, BWD>(src, src_centre, tbl, w, out, rep, n_out, kv, centre, mirror, st);
+    case 8: return launch_gg<CK, 8, BWD>(src, src_centre, tbl, w, out, rep, n_out, kv, centre, mirror, st);
+    case 16: return launch_gg<CK, 16, BWD>(src, src_centre, tbl, w, out, rep, n_out, kv, centre, mirror, st);
+    case 32: return launch_gg<CK, 32, BWD>(src, src_centre, tbl, w, out, rep, n_out, kv, centre, mirror, st);
+    case 64: return launch_gg<CK, 64, BWD>(src, src_centre, tbl, w, out, rep, n_out, kv, centre, mirror, st);
+  }
+  set_error("gather-GEMM: unsupported output channel count %d (supported: 4,8,16,32,64)", cn);
+  return VC_EINVAL;
+}
+
+template <bool BWD>
+static int dispatch_ck(int ck, int cn, const float* src, const float* src_centre, const int32_t* tbl, const float* w,
+                       float* out, const int32_t* rep, int64_t n_out, int kv, int centre, int mirror, hipStream_t st) {
+  switch (ck) {
+    case 4: return dispatch_cn<4, BWD>(cn, src, src_centre, tbl, w, out, rep, n_out, kv, centre, mirror, st);
+    case 8: return dispatch_cn<8, BWD>(cn, src, src_centre, tbl, w, out, rep, n_out, kv, centre, mirror, st);
+    case 16: return dispatch_cn<16, BWD>(cn, src, src_centre, tbl, w, out, rep, n_out, kv, centre, mirror, st);
+    case 32: return dispatch_cn<32, BWD>(cn, src, src_centre, tbl, w, out, rep, n_out, kv, centre, mirror, st);
+    case 64: return dispatch_cn<64, BWD>(cn, src, src_centre, tbl, w, out, rep, n_out, kv, centre, mirror, st);
+  }
+  set_error("gather-GEMM: unsupported source channel count %d (supported: 4,8,16,32,64)", ck);
+  return VC_EINVAL;
+}
+
+static constexpr int kMaxSplit = 64;
+
+static inline void bw_split(int64_t n_out, int& nsplit, int64_t& rows_per_block) {
+  int64_t want = cdiv(n_out, 4096);
+  if (want < 1) want = 1;
+  if (want > kMaxSplit) want = kMaxSplit;
+  rows_per_block = cdiv(cdiv(n_out, want), 256) * 256;
+  if (rows_per_block < 256) rows_per_block = 256;
+  nsplit = (int)cdiv(n_out, rows_per_block);
+  if (nsplit < 1) nsplit = 1;
+}
+
+template <int CI, int CO>
+static int launch_bw(const float* x, const float* dy, const int32_t* tbl, int64_t n_out, int kv, float* dweight,
+                     float* partial, hipStream_t st) {
+  int nsplit;
+  int64_t rpb;
+  bw_split(n_out, nsplit, rpb);
+  hipLaunchKernelGGL((bwd_weight_kernel<CI, CO>), dim3(nsplit, kv), dim3(256), 0, st, x, dy, tbl, n_out, kv, rpb, partial);
+  VC_CHECK_LAUNCH("bwd_weight_kernel");
+  const int total = kv * CI * CO;
+  hipLaunchKernelGGL(bwd_weight_reduce_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, partial, nsplit, kv,
+                     CI, CO, dweight);
+  VC_CHECK_LAUNCH("bwd_weight_reduce_kernel");
+  return VC_OK;
+}
+
+template <int CI>
+static int dispatch_bw_co(int co, const float* x, const float* dy, const int32_t* tbl, int64_t n_out, int kv,
+                          float* dweight, float* partial, hipStream_t st) {
+  switch (co) {
+    case 4: return launch_bw<CI, 4>(x, dy, tbl, n_out, kv, dweight, partial, st);
+    case 8: return launch_bw<CI, 8>(x, dy, tbl, n_out, kv, dweight, partial, st);
+    case 16: return launch_bw<CI, 16>(x, dy, tbl, n_out, kv, dweight, partial, st);
+    case 32: return launch_bw<CI, 32>(x, dy, tbl, n_out, kv, dweight, partial, st);
+    case 64: return launch_bw<CI, 64>(x, dy, tbl, n_out, kv, dweight, partial, st);
+  }
+  set_error("bwd-weight: unsupported output channel count %d", co);
+  return VC_EINVAL;
+}
+
+}  // namespace vc
+
+using namespace vc;
+
+extern "C" {
+
+int vc_conv_forward(const float* x, int64_t n_in, const int32_t* pair_fwd, int64_t n_out, int kv, const float* weight,
+                    int cin, int cout, float* y, void* stream) {
+  VC_REQUIRE(n_in >= 0 && n_out >= 0 && kv >= 1 && weight, "vc_conv_forward: null/invalid argument");
+  if (n_out == 0) return VC_OK;
+  VC_REQUIRE(pair_fwd && y && (x || n_in == 0), "vc_conv_forward: null argument");
+  return dispatch_ck<false>(cin, cout, x, nullptr, pair_fwd, weight, y, nullptr, n_out, kv, -1, 0, (hipStream_t)stream);
+}
+
+int vc_conv_backward_input(const float* dy, const float* dy_centre, int64_t n_src, const int32_t* tbl, int64_t n_in,
+                           int kv, const float* weight, int cin, int cout, int mirror, int centre, const int32_t* rep,
+                           float* dx, void* stream) {
+  VC_REQUIRE(n_src >= 0 && n_in >= 0 && kv >= 1 && weight, "vc_conv_backward_input: null/invalid argument");
+  if (n_in == 0) return VC_OK;
+  VC_REQUIRE(tbl && dx && (dy || n_src == 0), "vc_conv_backward_input: null argument");
+  VC_REQUIRE(centre >= -1 && centre < kv, "vc_conv_backward_input: centre out of range");
+  return dispatch_ck<true>(cout, cin, dy, dy_centre, tbl, weight, dx, rep, n_in, kv, centre, mirror ? 1 : 0,
+                           (hipStream_t)stream);
+}
+
+size_t vc_conv_backward_weight_workspace_bytes(int64_t n_out, int kv, int cin, int cout) {
+  (void)n_out;
+  if (kv < 1 || cin < 1 || cout < 1) return 0;
+  return (size_t)kMaxSplit * kv * cin * cout * sizeof(float);
+}
+
+int vc_conv_backward_weight(const float* x, const float* dy, const int32_t* pair_fwd, int64_t n_out, int kv, int cin,
+                            int cout, float* dweight, void* ws, size_t ws_bytes, void* stream) {
+  VC_REQUIRE(n_out >= 0 && kv >= 1 && dweight && ws, "vc_conv_backward_weight: null/invalid argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (ws_bytes < vc_conv_backward_weight_workspace_bytes(n_out, kv, cin, cout)) {
+    set_error("vc_conv_backward_weight: workspace too small");
+    return VC_ECAPACITY;
+  }
+  if (n_out == 0) {
+    VC_CHECK_HIP(hipMemsetAsync(dweight, 0, (size_t)kv * cin * cout * 4, st));
+    return VC_OK;
+  }
+  VC_REQUIRE(x && dy && pair_fwd, "vc_conv_backward_weight: null argument");
+  float* partial = (float*)ws;
+  switch (cin) {
+    case 4: return dispatch_bw_co<4>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, st);
+    case 8: return dispatch_bw_co<8>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, st);
+    case 16: return dispatch_bw_co<16>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, st);
+    case 32: return dispatch_bw_co<32>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, st);
+    case 64: return dispatch_bw_co<64>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, st);
+  }
+  set_error("bwd-weight: unsupported input channel count %d", cin);
+  return VC_EINVAL;
+}
+
+int vc_group_sum(const float* dy, const int32_t* rep, int64_t n, int c, float* dy_grp, void* stream) {
+  VC_REQUIRE(n >= 0 && c > 0, "vc_group_sum: invalid argument");
+  if (n == 0) return VC_OK;
+  VC_REQUIRE(dy && rep && dy_grp, "vc_group_sum: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  VC_CHECK_HIP(hipMemsetAsync(dy_grp, 0, (size_t)n * c * 4, st));
+  hipLaunchKernelGGL(group_sum_kernel, dim3((unsigned)cdiv(n * c, 256)), dim3(256), 0, st, dy, rep, n, c, dy_grp);
+  VC_CHECK_LAUNCH("group_sum_kernel");
+  return VC_OK;
+}
+
+}  // extern "C"

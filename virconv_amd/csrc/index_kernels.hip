@@ -1,0 +1,748 @@
+// Index-side kernels of the VirConv hot path for gfx950 (HBM/L2-bound integer work; no MFMA here):
+//   K3 coordinate hash, K4 submanifold rulebook, K5 strided rulebook (bitmap + popcount scan),
+//   K9 voxel->pixel projection, K2 row gather/scatter (layer discard), K10 dense scatter/gather,
+//   K1 first-touch voxelisation with fused MeanVFE.
+// Compiled with -ffp-contract=off: the projection and voxeliser float math must round once per operation so that
+// integer outputs are bit-identical to oracle/geometry.py.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace vc {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------------ block scan helper
+// exclusive scan of one int per thread over a 256-thread block (4 waves of 64); returns block total in *total.
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int* total, int* lds /* >= 4 ints */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    int t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    int s = lds[w];
+    if (w < wave) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+// ------------------------------------------------------------------------------------------ K3 hash build
+__global__ void __launch_bounds__(256) hash_insert_kernel(const int32_t* __restrict__ indices, int64_t n, int ndim,
+                                                          int D, int H, int W, uint64_t* __restrict__ keys,
+                                                          int32_t* __restrict__ vals, uint64_t mask) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int b, z, y, x;
+  load_coord(indices, i, ndim, b, z, y, x);
+  uint64_t key = (((uint64_t)b * D + z) * H + y) * W + x;
+  uint64_t slot = mix64(key) & mask;
+  for (;;) {
+    unsigned long long prev = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)kEmptyKey,
+                                        (unsigned long long)key);
+    if (prev == kEmptyKey || prev == key) {
+      atomicMax(&vals[slot], (int)i);  // duplicate rule: highest row wins
+      return;
+    }
+    slot = (slot + 1) & mask;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ K4 subm rulebook
+__global__ void __launch_bounds__(256) subm_rulebook_kernel(const int32_t* __restrict__ indices, int64_t n, int ndim,
+                                                            int D, int H, int W, int kz, int ky, int kx, int dz,
+                                                            int dy, int dx, const uint64_t* __restrict__ keys,
+                                                            const int32_t* __restrict__ vals, uint64_t mask,
+                                                            int32_t* __restrict__ pair, int32_t* __restrict__ rep) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int k = blockIdx.y;
+  const int kv = kz * ky * kx;
+  const int centre = ((kz / 2) * ky + ky / 2) * kx + kx / 2;
+  int b, z, y, x;
+  load_coord(indices, i, ndim, b, z, y, x);
+  if (k == centre) {
+    pair[(int64_t)k * n + i] = (int32_t)i;
+    if (rep) {
+      uint64_t key = (((uint64_t)b * D + z) * H + y) * W + x;
+      rep[i] = hash_lookup(keys, vals, mask, key);
+    }
+    return;
+  }
+  (void)kv;
+  const int oz = k / (ky * kx), oy = (k / kx) % ky, ox = k % kx;
+  const int nz = z + (oz - kz / 2) * dz, ny = y + (oy - ky / 2) * dy, nx = x + (ox - kx / 2) * dx;
+  int r = -1;
+  if (nz >= 0 && nz < D && ny >= 0 && ny < H && nx >= 0 && nx < W) {
+    uint64_t key = (((uint64_t)b * D + nz) * H + ny) * W + nx;
+    r = hash_lookup(keys, vals, mask, key);
+  }
+  pair[(int64_t)k * n + i] = r;
+}
+
+// ------------------------------------------------------------------------------------------ K5 strided rulebook
+static constexpr int kWordsPerThread = 8;
+static constexpr int kWordsPerBlock = 256 * kWordsPerThread;
+
+struct SpGeom {
+  int Do, Ho, Wo;
+  int k[3], s[3], p[3], d[3];
+};
+
+// candidate output cell (linear, 64-bit) of input row coordinate (b,z,y,x) through kernel offset k, or -1
+__device__ __forceinline__ int64_t sp_candidate(const SpGeom& g, int b, int z, int y, int x, int k) {
+  const int oz = k / (g.k[1] * g.k[2]), oy = (k / g.k[2]) % g.k[1], ox = k % g.k[2];
+  const int tz = z + g.p[0] - oz * g.d[0], ty = y + g.p[1] - oy * g.d[1], tx = x + g.p[2] - ox * g.d[2];
+  if (tz < 0 || ty < 0 || tx < 0) return -1;
+  if (tz % g.s[0] || ty % g.s[1] || tx % g.s[2]) return -1;
+  const int qz = tz / g.s[0], qy = ty / g.s[1], qx = tx / g.s[2];
+  if (qz >= g.Do || qy >= g.Ho || qx >= g.Wo) return -1;
+  return (((int64_t)b * g.Do + qz) * g.Ho + qy) * g.Wo + qx;
+}
+
+__global__ void __launch_bounds__(256) sp_mark_kernel(const int32_t* __restrict__ indices, int64_t n, int ndim,
+                                                      SpGeom g, unsigned long long* __restrict__ bitmap) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int b, z, y, x;
+  load_coord(indices, i, ndim, b, z, y, x);
+  int64_t L = sp_candidate(g, b, z, y, x, blockIdx.y);
+  if (L >= 0) atomicOr(&bitmap[L >> 6], 1ULL << (L & 63));
+}
+
+__global__ void __launch_bounds__(256) sp_blocksum_kernel(const unsigned long long* __restrict__ bitmap,
+                                                          int64_t nwords, int32_t* __restrict__ blocksum) {
+  __shared__ int lds[4];
+  int64_t w0 = (int64_t)blockIdx.x * kWordsPerBlock + (int64_t)threadIdx.x * kWordsPerThread;
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < kWordsPerThread; ++j)
+    if (w0 + j < nwords) c += __popcll(bitmap[w0 + j]);
+  int tot;
+  block_exclusive_scan_256(c, &tot, lds);
+  if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
+}
+
+// single block: in-place exclusive scan of blocksum[0..nb); total -> *total_out (and total_out2 if non-null)
+__global__ void __launch_bounds__(256) scan_blocksums_kernel(int32_t* __restrict__ blocksum, int64_t nb,
+                                                             int32_t* __restrict__ total_out,
+                                                             int32_t* __restrict__ total_out2) {
+  __shared__ int lds[4];
+  int carry = 0;
+  for (int64_t base = 0; base < nb; base += 256) {
+    int64_t j = base + threadIdx.x;
+    int v = (j < nb) ? blocksum[j] : 0;
+    int tot;
+    int ex = block_exclusive_scan_256(v, &tot, lds);
+    if (j < nb) blocksum[j] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) {
+    *total_out = carry;
+    if (total_out2) *total_out2 = carry;
+  }
+}
+
+__global__ void __launch_bounds__(256) sp_emit_kernel(const unsigned long long* __restrict__ bitmap, int64_t nwords,
+                                                      const int32_t* __restrict__ blocksum,
+                                                      uint32_t* __restrict__ prefix, int ndim, int Do, int Ho, int Wo,
+                                                      int64_t n_out, int32_t* __restrict__ out_indices) {
+  __shared__ int lds[4];
+  int64_t w0 = (int64_t)blockIdx.x * kWordsPerBlock + (int64_t)threadIdx.x * kWordsPerThread;
+  unsigned long long wv[kWordsPerThread];
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < kWordsPerThread; ++j) {
+    wv[j] = (w0 + j < nwords) ? bitmap[w0 + j] : 0ULL;
+    c += __popcll(wv[j]);
+  }
+  int tot;
+  int ex = block_exclusive_scan_256(c, &tot, lds) + blocksum[blockIdx.x];
+  const int64_t cells = (int64_t)Do * Ho * Wo;
+  const int hw = Ho * Wo;
+#pragma unroll
+  for (int j = 0; j < kWordsPerThread; ++j) {
+    if (w0 + j >= nwords) break;
+    prefix[w0 + j] = (uint32_t)ex;
+    unsigned long long m = wv[j];
+    while (m) {
+      int bit = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      int64_t L = (w0 + j) * 64 + bit;
+      int64_t row = ex++;
+      if (row < n_out) {
+        int b = (int)(L / cells);
+        int rem = (int)(L - (int64_t)b * cells);
+        int z = rem / hw;
+        rem -= z * hw;
+        int y = rem / Wo, x = rem - y * Wo;
+        int32_t* o = out_indices + row * (ndim + 1);
+        o[0] = b;
+        if (ndim == 3) { o[1] = z; o[2] = y; o[3] = x; }
+        else { o[1] = y; o[2] = x; }
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) sp_pairs_kernel(const int32_t* __restrict__ indices, int64_t n, int ndim,
+                                                       SpGeom g, const unsigned long long* __restrict__ bitmap,
+                                                       const uint32_t* __restrict__ prefix, int64_t n_out,
+                                                       int32_t* __restrict__ pair_fwd,
+                                                       int32_t* __restrict__ pair_bwd) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int k = blockIdx.y;
+  int b, z, y, x;
+  load_coord(indices, i, ndim, b, z, y, x);
+  int64_t L = sp_candidate(g, b, z, y, x, k);
+  int o = -1;
+  if (L >= 0) {
+    unsigned long long w = bitmap[L >> 6];
+    o = (int)prefix[L >> 6] + __popcll(w & ((1ULL << (L & 63)) - 1ULL));
+    atomicMax(&pair_fwd[(int64_t)k * n_out + o], (int)i);  // duplicate inputs: highest row wins
+  }
+  pair_bwd[(int64_t)k * n + i] = o;
+}
+
+// ------------------------------------------------------------------------------------------ K9 projection
+// params per sample (32 floats): [0..11] M1 = V2C^T @ R0^T (4x3 row-major), [12..23] P2T (4x3), [24] cos(-rot),
+// [25] sin(-rot), [26] flip (0/1), [27] scale, [28] has_trans (0/1)
+__global__ void project_prepare_kernel(const float* __restrict__ calib, const float* __restrict__ trans, int B,
+                                       float* __restrict__ params) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* v2c = calib + b * 33;  // 3x4
+  const float* r0 = v2c + 12;         // 3x3
+  const float* p2 = v2c + 21;         // 3x4
+  float* P = params + b * 32;
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 3; ++c) {
+      float acc = __fmul_rn(v2c[0 * 4 + r], r0[c * 3 + 0]);
+      acc = __fadd_rn(acc, __fmul_rn(v2c[1 * 4 + r], r0[c * 3 + 1]));
+      acc = __fadd_rn(acc, __fmul_rn(v2c[2 * 4 + r], r0[c * 3 + 2]));
+      P[r * 3 + c] = acc;
+    }
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 3; ++c) P[12 + r * 3 + c] = p2[c * 4 + r];
+  if (trans) {
+    const float* t = trans + b * 3;
+    double a = -(double)t[0];
+    P[24] = (float)cos(a);
+    P[25] = (float)sin(a);
+    P[26] = (t[1] != 0.0f) ? 1.0f : 0.0f;
+    P[27] = t[2];
+    P[28] = 1.0f;
+  } else {
+    P[24] = 1.0f; P[25] = 0.0f; P[26] = 0.0f; P[27] = 1.0f; P[28] = 0.0f;
+  }
+  P[29] = P[30] = P[31] = 0.0f;
+}
+
+__device__ __forceinline__ int sat_int(float f) {
+  if (f != f) return 0;
+  if (f >= 2147483648.0f) return 2147483647;
+  if (f <= -2147483648.0f) return (int)0x80000000;
+  return (int)f;  // truncation toward zero
+}
+
+__global__ void __launch_bounds__(256) project_uv_kernel(const int32_t* __restrict__ indices, int64_t n,
+                                                         const float* __restrict__ params, int B, int stride,
+                                                         float vsx, float vsy, float vsz, float minx, float miny,
+                                                         float minz, int32_t* __restrict__ uv,
+                                                         float* __restrict__ depth) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int4 r = *reinterpret_cast<const int4*>(indices + i * 4);  // [b, z, y, x]
+  const int b = r.x;
+  int u = 0, v = 0;
+  float dep = 0.0f;
+  if (b >= 0 && b < B) {
+    const float* P = params + b * 32;
+    float X = __fadd_rn(__fmul_rn((float)r.w, vsx), minx);
+    float Y = __fadd_rn(__fmul_rn((float)r.z, vsy), miny);
+    float Z = __fadd_rn(__fmul_rn((float)r.y, vsz), minz);
+    if (P[28] != 0.0f) {
+      const float sc = P[27];
+      X = __fdiv_rn(X, sc); Y = __fdiv_rn(Y, sc); Z = __fdiv_rn(Z, sc);
+      if (P[26] != 0.0f) Y = -Y;
+      const float ca = P[24], sa = P[25], nsa = -P[25];
+      const float X2 = __fadd_rn(__fmul_rn(X, ca), __fmul_rn(Y, nsa));
+      const float Y2 = __fadd_rn(__fmul_rn(X, sa), __fmul_rn(Y, ca));
+      X = X2; Y = Y2;
+    }
+    float rect[3], hom[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      rect[c] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(X, P[0 + c]), __fmul_rn(Y, P[3 + c])), __fmul_rn(Z, P[6 + c])),
+                          P[9 + c]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      hom[c] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(rect[0], P[12 + c]), __fmul_rn(rect[1], P[15 + c])),
+                                   __fmul_rn(rect[2], P[18 + c])),
+                         P[21 + c]);
+    u = sat_int(__fdiv_rn(hom[0], rect[2]));
+    v = sat_int(__fdiv_rn(hom[1], rect[2]));
+    dep = __fsub_rn(hom[2], P[21 + 2]);
+  }
+  u = min(max(u, 0), 1400 - 1) / stride;
+  v = min(max(v, 0), 600 - 1) / stride;
+  int32_t* o = uv + i * 3;
+  o[0] = b; o[1] = u; o[2] = v;
+  if (depth) depth[i] = dep;
+}
+
+// ------------------------------------------------------------------------------------------ K2 gather / scatter rows
+// one thread per float4 (or scalar tail) of an output row; C is a multiple of 4 on the hot path
+__global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restrict__ feat,
+                                                          const int32_t* __restrict__ idx, int c, int icols,
+                                                          const int64_t* __restrict__ keep, int64_t n_keep,
+                                                          float* __restrict__ feat_out,
+                                                          int32_t* __restrict__ idx_out) {
+  const int c4 = c >> 2;
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_keep * c4) return;
+  int64_t j = t / c4;
+  int q = (int)(t - j * c4);
+  int64_t src = keep[j];
+  reinterpret_cast<float4*>(feat_out)[j * c4 + q] = reinterpret_cast<const float4*>(feat)[src * c4 + q];
+  if (q == 0 && idx_out)
+    for (int a = 0; a < icols; ++a) idx_out[j * icols + a] = idx[src * icols + a];
+}
+
+__global__ void __launch_bounds__(256) scatter_rows_kernel(const float* __restrict__ gout, int c,
+                                                           const int64_t* __restrict__ keep, int64_t n_keep,
+                                                           float* __restrict__ gin) {
+  const int c4 = c >> 2;
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_keep * c4) return;
+  int64_t j = t / c4;
+  int q = (int)(t - j * c4);
+  reinterpret_cast<float4*>(gin)[keep[j] * c4 + q] = reinterpret_cast<const float4*>(gout)[j * c4 + q];
+}
+
+// ------------------------------------------------------------------------------------------ K10 dense
+template <bool TO_DENSE>
+__global__ void __launch_bounds__(256) dense_kernel(float* __restrict__ feat, const int32_t* __restrict__ indices,
+                                                    int64_t n, int c, int ndim, int D, int H, int W,
+                                                    float* __restrict__ dense) {
+  // thread per (channel, row) with rows fastest: consecutive threads hit consecutive rows of one channel plane
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * c) return;
+  int ch = (int)(t / n);
+  int64_t i = t - (int64_t)ch * n;
+  int b, z, y, x;
+  load_coord(indices, i, ndim, b, z, y, x);
+  int64_t off = ((((int64_t)b * c + ch) * D + z) * H + y) * W + x;
+  if (TO_DENSE) dense[off] = feat[i * c + ch];
+  else feat[i * c + ch] = dense[off];
+}
+
+// ------------------------------------------------------------------------------------------ generic int scan (flags)
+__global__ void __launch_bounds__(256) flag_blocksum_kernel(const int32_t* __restrict__ flags, int64_t n,
+                                                            int32_t* __restrict__ blocksum) {
+  __shared__ int lds[4];
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int v = (i < n) ? flags[i] : 0;
+  int tot;
+  block_exclusive_scan_256(v, &tot, lds);
+  if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
+}
+
+// ------------------------------------------------------------------------------------------ K1 voxelise + MeanVFE
+struct VoxGeom {
+  float minx, miny, minz, vx, vy, vz;
+  int gx, gy, gz;
+};
+
+__global__ void __launch_bounds__(256) vox_init_kernel(uint64_t* keys, int32_t* first, int32_t* cellvid, int32_t* slots,
+                                                       int64_t cap, int maxp) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= cap) return;
+  keys[i] = kEmptyKey;
+  first[i] = 0x7fffffff;
+  cellvid[i] = -1;
+  for (int j = 0; j < maxp; ++j) slots[i * maxp + j] = 0x7fffffff;
+}
+
+__global__ void __launch_bounds__(256) vox_insert_kernel(const float* __restrict__ points, int64_t p, int f, VoxGeom g,
+                                                         uint64_t* keys, int32_t* first, int32_t* slots, uint64_t mask,
+                                                         int maxp, int32_t* __restrict__ pslot) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p) return;
+  const float* pt = points + i * f;
+  // float32: subtract, divide, floor -- one rounding each
+  const float fx = floorf(__fdiv_rn(__fsub_rn(pt[0], g.minx), g.vx));
+  const float fy = floorf(__fdiv_rn(__fsub_rn(pt[1], g.miny), g.vy));
+  const float fz = floorf(__fdiv_rn(__fsub_rn(pt[2], g.minz), g.vz));
+  if (!(fx >= 0.0f && fx < (float)g.gx && fy >= 0.0f && fy < (float)g.gy && fz >= 0.0f && fz < (float)g.gz)) {
+    pslot[i] = -1;
+    return;
+  }
+  const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
+  const uint64_t key = ((uint64_t)cz * g.gy + cy) * g.gx + cx;
+  uint64_t slot = mix64(key) & mask;
+  for (;;) {
+    unsigned long long prev = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)kEmptyKey,
+                                        (unsigned long long)key);
+    if (prev == kEmptyKey || prev == key) break;
+    slot = (slot + 1) & mask;
+  }
+  pslot[i] = (int)slot;
+  atomicMin(&first[slot], (int)i);
+  // keep the maxp smallest point indices of the cell, sorted: atomic bubble-insert
+  int v = (int)i;
+  int32_t* s = slots + slot * maxp;
+  for (int j = 0; j < maxp; ++j) {
+    int old = atomicMin(&s[j], v);
+    if (old == 0x7fffffff) break;
+    if (old > v) v = old;  // displaced the larger value, carry it on
+  }
+}
+
+__global__ void __launch_bounds__(256) vox_creator_kernel(const int32_t* __restrict__ pslot,
+                                                          const int32_t* __restrict__ first, int64_t p,
+                                                          int32_t* __restrict__ flag) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p) return;
+  int s = pslot[i];
+  flag[i] = (s >= 0 && first[s] == (int)i) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256) vox_assign_kernel(const float* __restrict__ points, int f, VoxGeom g,
+                                                         const int32_t* __restrict__ pslot,
+                                                         const int32_t* __restrict__ flag,
+                                                         const int32_t* __restrict__ blocksum, int64_t p,
+                                                         int max_voxels, int32_t* __restrict__ cellvid,
+                                                         int32_t* __restrict__ coords) {
+  __shared__ int lds[4];
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int v = (i < p) ? flag[i] : 0;
+  int tot;
+  int rank = block_exclusive_scan_256(v, &tot, lds) + blocksum[blockIdx.x];
+  if (i < p && v && rank < max_voxels) {
+    cellvid[pslot[i]] = rank;
+    const float* pt = points + i * f;
+    coords[rank * 3 + 0] = (int)floorf(__fdiv_rn(__fsub_rn(pt[2], g.minz), g.vz));
+    coords[rank * 3 + 1] = (int)floorf(__fdiv_rn(__fsub_rn(pt[1], g.miny), g.vy));
+    coords[rank * 3 + 2] = (int)floorf(__fdiv_rn(__fsub_rn(pt[0], g.minx), g.vx));
+  }
+}
+
+__global__ void __launch_bounds__(256) vox_reduce_kernel(const float* __restrict__ points, int f, int maxp,
+                                                         const int32_t* __restrict__ cellvid,
+                                                         const int32_t* __restrict__ slots, int64_t cap,
+                                                         int vfe_max_last, float* __restrict__ features,
+                                                         int32_t* __restrict__ num_points) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= cap * f) return;
+  int64_t s = t / f;
+  int ch = (int)(t - s * f);
+  int vid = cellvid[s];
+  if (vid < 0) return;
+  const int32_t* sl = slots + s * maxp;
+  float sum = 0.0f;
+  int cnt = 0;
+  for (int j = 0; j < maxp; ++j) {
+    int pi = sl[j];
+    if (pi == 0x7fffffff) break;
+    float val = points[(int64_t)pi * f + ch];
+    sum = (j == 0) ? val : __fadd_rn(sum, val);
+    ++cnt;
+  }
+  float out = __fdiv_rn(sum, (float)max(cnt, 1));
+  if (vfe_max_last && ch == f - 1) {
+    // max over ALL maxp slots incl. zero padding, exactly as voxels.max(dim=1)
+    float m2 = (cnt < maxp) ? 0.0f : -3.402823466e+38f;
+    for (int j = 0; j < cnt; ++j) m2 = fmaxf(m2, points[(int64_t)sl[j] * f + ch]);
+    out = m2;
+  }
+  features[(int64_t)vid * f + ch] = out;
+  if (ch == 0) num_points[vid] = cnt;
+}
+
+__global__ void vox_count_kernel(const int32_t* total, int max_voxels, int32_t* n_voxels) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *n_voxels = min(*total, max_voxels);
+}
+
+}  // namespace vc
+
+using namespace vc;
+
+// ============================================================================================== C ABI
+extern "C" {
+
+const char* vc_version(void) { return "virconv_hip 0.1 (gfx950)"; }
+const char* vc_last_error(void) { return g_err; }
+
+size_t vc_hash_workspace_bytes(int64_t n) { return (size_t)hash_capacity(n < 0 ? 0 : n) * 12; }
+
+int vc_hash_build(const int32_t* indices, int64_t n, int ndim, const int32_t* shape, void* ws, size_t ws_bytes,
+                  void* stream) {
+  VC_REQUIRE(ndim == 2 || ndim == 3, "vc_hash_build: ndim must be 2 or 3 (got %d)", ndim);
+  VC_REQUIRE(n >= 0 && ws && shape && (indices || n == 0), "vc_hash_build: null argument");
+  const uint64_t cap = hash_capacity(n);
+  if (ws_bytes < cap * 12) { set_error("vc_hash_build: workspace %zu < %llu", ws_bytes, (unsigned long long)cap * 12); return VC_ECAPACITY; }
+  hipStream_t st = (hipStream_t)stream;
+  VC_CHECK_HIP(hipMemsetAsync(ws, 0xFF, cap * 12, st));
+  if (n == 0) return VC_OK;
+  Dims d = make_dims(ndim, shape);
+  uint64_t* keys = (uint64_t*)ws;
+  int32_t* vals = (int32_t*)(keys + cap);
+  hipLaunchKernelGGL(hash_insert_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, indices, n, ndim, d.D, d.H,
+                     d.W, keys, vals, cap - 1);
+  VC_CHECK_LAUNCH("hash_insert_kernel");
+  return VC_OK;
+}
+
+int vc_subm_rulebook(const int32_t* indices, int64_t n, int ndim, const int32_t* shape, const int32_t* ksize,
+                     const int32_t* dilation, const void* ws, size_t ws_bytes, int32_t* pair_fwd, int32_t* rep_out,
+                     void* stream) {
+  VC_REQUIRE(ndim == 2 || ndim == 3, "vc_subm_rulebook: ndim must be 2 or 3");
+  VC_REQUIRE(n >= 0 && ws && shape && ksize && (n == 0 || (indices && pair_fwd)), "vc_subm_rulebook: null argument");
+  if (n == 0) return VC_OK;
+  const uint64_t cap = hash_capacity(n);
+  if (ws_bytes < cap * 12) { set_error("vc_subm_rulebook: workspace too small"); return VC_ECAPACITY; }
+  Dims d = make_dims(ndim, shape);
+  Kern3 g = make_kern(ndim, ksize, nullptr, nullptr, dilation);
+  for (int a = 0; a < 3; ++a) VC_REQUIRE(g.k[a] % 2 == 1, "vc_subm_rulebook: kernel sizes must be odd");
+  const uint64_t* keys = (const uint64_t*)ws;
+  const int32_t* vals = (const int32_t*)(keys + cap);
+  hipLaunchKernelGGL(subm_rulebook_kernel, dim3((unsigned)cdiv(n, 256), g.kv), dim3(256), 0, (hipStream_t)stream,
+                     indices, n, ndim, d.D, d.H, d.W, g.k[0], g.k[1], g.k[2], g.d[0], g.d[1], g.d[2], keys, vals,
+                     cap - 1, pair_fwd, rep_out);
+  VC_CHECK_LAUNCH("subm_rulebook_kernel");
+  return VC_OK;
+}
+
+// spconv workspace: [bitmap u64 x nwords][prefix u32 x nwords][blocksum i32 x nb][total i32]
+static inline void sp_layout(int batch, int ndim, const int32_t* out_shape, int64_t& nwords, int64_t& nb) {
+  Dims d = make_dims(ndim, out_shape);
+  int64_t cells = (int64_t)batch * d.D * d.H * d.W;
+  nwords = cdiv(cells, 64);
+  if (nwords < 1) nwords = 1;
+  nb = cdiv(nwords, kWordsPerBlock);
+}
+
+size_t vc_spconv_workspace_bytes(int batch_size, int ndim, const int32_t* out_shape) {
+  if (!out_shape || (ndim != 2 && ndim != 3) || batch_size < 1) return 0;
+  int64_t nwords, nb;
+  sp_layout(batch_size, ndim, out_shape, nwords, nb);
+  return (size_t)(nwords * 12 + (nb + 1) * 4 + 64);
+}
+
+static inline SpGeom make_spgeom(const Dims& o, const Kern3& k) {
+  SpGeom g;
+  g.Do = o.D; g.Ho = o.H; g.Wo = o.W;
+  for (int a = 0; a < 3; ++a) { g.k[a] = k.k[a]; g.s[a] = k.s[a]; g.p[a] = k.p[a]; g.d[a] = k.d[a]; }
+  return g;
+}
+
+int vc_spconv_mark_count(const int32_t* indices, int64_t n, int ndim, int batch_size, const int32_t* out_shape,
+                         const int32_t* ksize, const int32_t* stride_, const int32_t* padding, const int32_t* dilation,
+                         void* ws, size_t ws_bytes, int32_t* n_out_dev, void* stream) {
+  VC_REQUIRE(ndim == 2 || ndim == 3, "vc_spconv_mark_count: ndim must be 2 or 3");
+  VC_REQUIRE(n >= 0 && batch_size >= 1 && out_shape && ksize && stride_ && padding && ws && n_out_dev &&
+                 (indices || n == 0), "vc_spconv_mark_count: null/invalid argument");
+  Dims o = make_dims(ndim, out_shape);
+  VC_REQUIRE((int64_t)o.D * o.H * o.W < (1LL << 31), "vc_spconv_mark_count: output grid per sample must be < 2^31 cells");
+  int64_t nwords, nb;
+  sp_layout(batch_size, ndim, out_shape, nwords, nb);
+  if (ws_bytes < vc_spconv_workspace_bytes(batch_size, ndim, out_shape)) { set_error("vc_spconv_mark_count: workspace too small"); return VC_ECAPACITY; }
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* bitmap = (unsigned long long*)ws;
+  uint32_t* prefix = (uint32_t*)(bitmap + nwords);
+  int32_t* blocksum = (int32_t*)(prefix + nwords);
+  VC_CHECK_HIP(hipMemsetAsync(bitmap, 0, nwords * 8, st));
+  Kern3 k = make_kern(ndim, ksize, stride_, padding, dilation);
+  SpGeom g = make_spgeom(o, k);
+  if (n > 0) {
+    hipLaunchKernelGGL(sp_mark_kernel, dim3((unsigned)cdiv(n, 256), k.kv), dim3(256), 0, st, indices, n, ndim, g, bitmap);
+    VC_CHECK_LAUNCH("sp_mark_kernel");
+  }
+  hipLaunchKernelGGL(sp_blocksum_kernel, dim3((unsigned)nb), dim3(256), 0, st, bitmap, nwords, blocksum);
+  VC_CHECK_LAUNCH("sp_blocksum_kernel");
+  hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(256), 0, st, blocksum, nb, n_out_dev, blocksum + nb);
+  VC_CHECK_LAUNCH("scan_blocksums_kernel");
+  return VC_OK;
+}
+
+int vc_spconv_emit_pairs(const int32_t* indices, int64_t n, int ndim, int batch_size, const int32_t* out_shape,
+                         const int32_t* ksize, const int32_t* stride_, const int32_t* padding, const int32_t* dilation,
+                         const void* ws, size_t ws_bytes, int64_t n_out, int32_t* out_indices, int32_t* pair_fwd,
+                         int32_t* pair_bwd, void* stream) {
+  VC_REQUIRE(ndim == 2 || ndim == 3, "vc_spconv_emit_pairs: ndim must be 2 or 3");
+  VC_REQUIRE(n >= 0 && n_out >= 0 && out_shape && ksize && stride_ && padding && ws, "vc_spconv_emit_pairs: null argument");
+  VC_REQUIRE(n_out == 0 || (out_indices && pair_fwd), "vc_spconv_emit_pairs: null outputs");
+  VC_REQUIRE(n == 0 || (indices && pair_bwd), "vc_spconv_emit_pairs: null inputs");
+  Dims o = make_dims(ndim, out_shape);
+  int64_t nwords, nb;
+  sp_layout(batch_size, ndim, out_shape, nwords, nb);
+  if (ws_bytes < vc_spconv_workspace_bytes(batch_size, ndim, out_shape)) { set_error("vc_spconv_emit_pairs: workspace too small"); return VC_ECAPACITY; }
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned long long* bitmap = (const unsigned long long*)ws;
+  uint32_t* prefix = (uint32_t*)(bitmap + nwords);
+  const int32_t* blocksum = (const int32_t*)(prefix + nwords);
+  Kern3 k = make_kern(ndim, ksize, stride_, padding, dilation);
+  SpGeom g = make_spgeom(o, k);
+  hipLaunchKernelGGL(sp_emit_kernel, dim3((unsigned)nb), dim3(256), 0, st, bitmap, nwords, blocksum, prefix, ndim, o.D,
+                     o.H, o.W, n_out, out_indices);
+  VC_CHECK_LAUNCH("sp_emit_kernel");
+  if (n_out > 0) VC_CHECK_HIP(hipMemsetAsync(pair_fwd, 0xFF, (size_t)k.kv * n_out * 4, st));
+  if (n > 0) {
+    hipLaunchKernelGGL(sp_pairs_kernel, dim3((unsigned)cdiv(n, 256), k.kv), dim3(256), 0, st, indices, n, ndim, g,
+                       bitmap, prefix, n_out, pair_fwd, pair_bwd);
+    VC_CHECK_LAUNCH("sp_pairs_kernel");
+  }
+  return VC_OK;
+}
+
+int vc_project_prepare(const float* calib, const float* trans, int batch_size, float* params, void* stream) {
+  VC_REQUIRE(calib && params && batch_size >= 1, "vc_project_prepare: null/invalid argument");
+  hipLaunchKernelGGL(project_prepare_kernel, dim3((unsigned)cdiv(batch_size, 64)), dim3(64), 0, (hipStream_t)stream,
+                     calib, trans, batch_size, params);
+  VC_CHECK_LAUNCH("project_prepare_kernel");
+  return VC_OK;
+}
+
+int vc_project_uv(const int32_t* indices, int64_t n, const float* params, int batch_size, int stride, int32_t* uv,
+                  float* depth, void* stream) {
+  VC_REQUIRE(n >= 0 && params && stride >= 1 && (n == 0 || (indices && uv)), "vc_project_uv: null/invalid argument");
+  if (n == 0) return VC_OK;
+  // hard-coded range / voxel size of the reference (spconv_backbone.py:8): python floats (fp64) rounded to fp32 on use
+  const double vs = 0.05 * stride;
+  const float vsf = (float)vs;
+  const float minx = (float)(0.0 + vs / 2), miny = (float)(-40.0 + vs / 2), minz = (float)(-3.0 + vs / 2);
+  hipLaunchKernelGGL(project_uv_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, indices, n,
+                     params, batch_size, stride, vsf, vsf, vsf, minx, miny, minz, uv, depth);
+  VC_CHECK_LAUNCH("project_uv_kernel");
+  return VC_OK;
+}
+
+int vc_gather_rows(const float* features, const int32_t* indices, int c, int icols, const int64_t* keep, int64_t n_keep,
+                   float* features_out, int32_t* indices_out, void* stream) {
+  VC_REQUIRE(c > 0 && c % 4 == 0, "vc_gather_rows: channel count must be a positive multiple of 4 (got %d)", c);
+  VC_REQUIRE(n_keep >= 0 && (n_keep == 0 || (features && keep && features_out)), "vc_gather_rows: null argument");
+  VC_REQUIRE(!indices_out || (indices && icols > 0), "vc_gather_rows: indices_out without indices");
+  if (n_keep == 0) return VC_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)cdiv(n_keep * (c / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                     features, indices, c, icols, keep, n_keep, features_out, indices_out);
+  VC_CHECK_LAUNCH("gather_rows_kernel");
+  return VC_OK;
+}
+
+int vc_scatter_rows(const float* grad_out, int c, const int64_t* keep, int64_t n_keep, int64_t n_in, float* grad_in,
+                    void* stream) {
+  VC_REQUIRE(c > 0 && c % 4 == 0, "vc_scatter_rows: channel count must be a positive multiple of 4");
+  VC_REQUIRE(n_keep >= 0 && n_in >= 0 && (n_in == 0 || grad_in), "vc_scatter_rows: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (n_in > 0) VC_CHECK_HIP(hipMemsetAsync(grad_in, 0, (size_t)n_in * c * 4, st));
+  if (n_keep == 0) return VC_OK;
+  VC_REQUIRE(grad_out && keep, "vc_scatter_rows: null argument");
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)cdiv(n_keep * (c / 4), 256)), dim3(256), 0, st, grad_out, c,
+                     keep, n_keep, grad_in);
+  VC_CHECK_LAUNCH("scatter_rows_kernel");
+  return VC_OK;
+}
+
+int vc_to_dense(const float* features, const int32_t* indices, int64_t n, int c, int ndim, int batch_size,
+                const int32_t* shape, float* dense, void* stream) {
+  VC_REQUIRE((ndim == 2 || ndim == 3) && shape && c > 0 && batch_size >= 1, "vc_to_dense: invalid argument");
+  if (n == 0) return VC_OK;
+  VC_REQUIRE(features && indices && dense, "vc_to_dense: null argument");
+  Dims d = make_dims(ndim, shape);
+  hipLaunchKernelGGL(dense_kernel<true>, dim3((unsigned)cdiv(n * c, 256)), dim3(256), 0, (hipStream_t)stream,
+                     const_cast<float*>(features), indices, n, c, ndim, d.D, d.H, d.W, dense);
+  VC_CHECK_LAUNCH("dense_kernel<to>");
+  return VC_OK;
+}
+
+int vc_from_dense(const float* dense, const int32_t* indices, int64_t n, int c, int ndim, int batch_size,
+                  const int32_t* shape, float* features, void* stream) {
+  VC_REQUIRE((ndim == 2 || ndim == 3) && shape && c > 0 && batch_size >= 1, "vc_from_dense: invalid argument");
+  if (n == 0) return VC_OK;
+  VC_REQUIRE(features && indices && dense, "vc_from_dense: null argument");
+  Dims d = make_dims(ndim, shape);
+  hipLaunchKernelGGL(dense_kernel<false>, dim3((unsigned)cdiv(n * c, 256)), dim3(256), 0, (hipStream_t)stream, features,
+                     indices, n, c, ndim, d.D, d.H, d.W, const_cast<float*>(dense));
+  VC_CHECK_LAUNCH("dense_kernel<from>");
+  return VC_OK;
+}
+
+// voxeliser workspace: keys u64[cap] | first i32[cap] | cellvid i32[cap] | slots i32[cap*maxp] | pslot i32[p] |
+//                      flag i32[p] | blocksum i32[nb+1]
+size_t vc_voxelize_workspace_bytes(int64_t p, int max_points) {
+  if (p < 0 || max_points < 1) return 0;
+  uint64_t cap = hash_capacity(p);
+  int64_t nb = cdiv(p > 0 ? p : 1, 256);
+  return (size_t)(cap * (8 + 4 + 4 + 4 * (uint64_t)max_points) + (uint64_t)p * 8 + (nb + 1) * 4 + 64);
+}
+
+int vc_voxelize_mean(const float* points, int64_t p, int f, const float* range, const float* vsize, int max_points,
+                     int max_voxels, int vfe_max_last, void* ws, size_t ws_bytes, float* features, int32_t* coords,
+                     int32_t* num_points, int32_t* n_voxels_dev, void* stream) {
+  VC_REQUIRE(p >= 0 && f >= 3 && range && vsize && max_points >= 1 && max_voxels >= 1 && ws && features && coords &&
+                 num_points && n_voxels_dev && (points || p == 0), "vc_voxelize_mean: null/invalid argument");
+  if (ws_bytes < vc_voxelize_workspace_bytes(p, max_points)) { set_error("vc_voxelize_mean: workspace too small"); return VC_ECAPACITY; }
+  hipStream_t st = (hipStream_t)stream;
+  const uint64_t cap = hash_capacity(p);
+  const int64_t nb = cdiv(p > 0 ? p : 1, 256);
+  uint64_t* keys = (uint64_t*)ws;
+  int32_t* first = (int32_t*)(keys + cap);
+  int32_t* cellvid = first + cap;
+  int32_t* slots = cellvid + cap;
+  int32_t* pslot = slots + cap * max_points;
+  int32_t* flag = pslot + p;
+  int32_t* blocksum = flag + p;
+  VoxGeom g;
+  g.minx = range[0]; g.miny = range[1]; g.minz = range[2];
+  g.vx = vsize[0]; g.vy = vsize[1]; g.vz = vsize[2];
+  g.gx = (int)llround(((double)range[3] - (double)range[0]) / (double)vsize[0]);
+  g.gy = (int)llround(((double)range[4] - (double)range[1]) / (double)vsize[1]);
+  g.gz = (int)llround(((double)range[5] - (double)range[2]) / (double)vsize[2]);
+  hipLaunchKernelGGL(vox_init_kernel, dim3((unsigned)cdiv((int64_t)cap, 256)), dim3(256), 0, st, keys, first, cellvid,
+                     slots, (int64_t)cap, max_points);
+  VC_CHECK_LAUNCH("vox_init_kernel");
+  if (p > 0) {
+    hipLaunchKernelGGL(vox_insert_kernel, dim3((unsigned)cdiv(p, 256)), dim3(256), 0, st, points, p, f, g, keys, first,
+                       slots, cap - 1, max_points, pslot);
+    VC_CHECK_LAUNCH("vox_insert_kernel");
+    hipLaunchKernelGGL(vox_creator_kernel, dim3((unsigned)cdiv(p, 256)), dim3(256), 0, st, pslot, first, p, flag);
+    VC_CHECK_LAUNCH("vox_creator_kernel");
+    hipLaunchKernelGGL(flag_blocksum_kernel, dim3((unsigned)nb), dim3(256), 0, st, flag, p, blocksum);
+    VC_CHECK_LAUNCH("flag_blocksum_kernel");
+  } else {
+    VC_CHECK_HIP(hipMemsetAsync(blocksum, 0, (nb + 1) * 4, st));
+  }
+  hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(256), 0, st, blocksum, p > 0 ? nb : 0, blocksum + nb,
+                     (int32_t*)nullptr);
+  VC_CHECK_LAUNCH("scan_blocksums_kernel");
+  hipLaunchKernelGGL(vox_count_kernel, dim3(1), dim3(64), 0, st, blocksum + nb, max_voxels, n_voxels_dev);
+  VC_CHECK_LAUNCH("vox_count_kernel");
+  if (p > 0) {
+    hipLaunchKernelGGL(vox_assign_kernel, dim3((unsigned)nb), dim3(256), 0, st, points, f, g, pslot, flag, blocksum, p,
+                       max_voxels, cellvid, coords);
+    VC_CHECK_LAUNCH("vox_assign_kernel");
+    hipLaunchKernelGGL(vox_reduce_kernel, dim3((unsigned)cdiv((int64_t)cap * f, 256)), dim3(256), 0, st, points, f,
+                       max_points, cellvid, slots, (int64_t)cap, vfe_max_last, features, num_points);
+    VC_CHECK_LAUNCH("vox_reduce_kernel");
+  }
+  return VC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,225 @@
+"""Functional operator layer: rulebooks + autograd Functions over the active backend.
+
+The only backend shipped is :class:`virconv_amd.backend_hip.HipBackend` (the C ABI of libvirconv_hip.so).  The backend
+is an object so that tests can inject the CPU oracle (``oracle/backend.py``) to exercise host-side logic without a GPU;
+nothing in this package ever selects a CPU implementation by itself.
+"""
+from __future__ import annotations
+
+import contextlib
+from dataclasses import dataclass, field
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+_BACKEND = None
+
+
+def get_backend():
+    global _BACKEND
+    if _BACKEND is None:
+        from .backend_hip import HipBackend  # raises loudly if libvirconv_hip.so is missing
+        _BACKEND = HipBackend()
+    return _BACKEND
+
+
+def set_backend(backend) -> None:
+    """Test hook (tests/ only): replace the operator backend."""
+    global _BACKEND
+    _BACKEND = backend
+
+
+@contextlib.contextmanager
+def use_backend(backend):
+    global _BACKEND
+    prev = _BACKEND
+    _BACKEND = backend
+    try:
+        yield backend
+    finally:
+        _BACKEND = prev
+
+
+def ntuple(v, n: int) -> Tuple[int, ...]:
+    if isinstance(v, (list, tuple, np.ndarray)):
+        assert len(v) == n, f"expected {n} values, got {v}"
+        return tuple(int(x) for x in v)
+    return (int(v),) * n
+
+
+@dataclass
+class Rulebook:
+    """Cached index structure of one sparse conv (what spconv keeps in ``indice_dict[indice_key]``)."""
+    kind: str                       # 'subm' | 'sparse'
+    pair_fwd: torch.Tensor          # (KV, n_out) int32: input row feeding output row through offset k, or -1
+    pair_bwd: Optional[torch.Tensor]  # (KV, n_in) int32 (sparse only; subm uses the mirrored pair_fwd)
+    rep: Optional[torch.Tensor]     # (n,) int32 representative row per row (duplicate-coordinate subm), else None
+    n_in: int
+    n_out: int
+    in_indices: torch.Tensor
+    out_indices: torch.Tensor
+    in_shape: Tuple[int, ...]
+    out_shape: Tuple[int, ...]
+    ksize: Tuple[int, ...]
+    stride: Tuple[int, ...]
+    padding: Tuple[int, ...]
+    dilation: Tuple[int, ...]
+
+    @property
+    def kv(self) -> int:
+        return int(np.prod(self.ksize))
+
+    @property
+    def centre(self) -> int:
+        return int(np.ravel_multi_index(tuple(k // 2 for k in self.ksize), self.ksize))
+
+
+def build_subm_rulebook(indices: torch.Tensor, spatial_shape, ksize, dilation=1, allow_duplicates: bool = False) -> Rulebook:
+    ndim = indices.shape[1] - 1
+    ks, dl = ntuple(ksize, ndim), ntuple(dilation, ndim)
+    shape = tuple(int(s) for s in spatial_shape)
+    pair, rep = get_backend().subm_rulebook(indices, shape, ks, dl, want_rep=allow_duplicates)
+    n = indices.shape[0]
+    return Rulebook("subm", pair, None, rep if allow_duplicates else None, n, n, indices, indices, shape, shape, ks,
+                    (1,) * ndim, tuple(k // 2 for k in ks), dl)
+
+
+def build_sparse_rulebook(indices: torch.Tensor, spatial_shape, batch_size: int, ksize, stride, padding, dilation=1) -> Rulebook:
+    ndim = indices.shape[1] - 1
+    ks, st = ntuple(ksize, ndim), ntuple(stride, ndim)
+    pd, dl = ntuple(padding, ndim), ntuple(dilation, ndim)
+    shape = tuple(int(s) for s in spatial_shape)
+    out_idx, out_shape, pf, pb = get_backend().sparse_rulebook(indices, shape, int(batch_size), ks, st, pd, dl)
+    return Rulebook("sparse", pf, pb, None, indices.shape[0], out_idx.shape[0], indices, out_idx, shape,
+                    tuple(int(s) for s in out_shape), ks, st, pd, dl)
+
+
+class SparseConvFunction(torch.autograd.Function):
+    """y = conv(features, weight | rulebook); replaces spconv's SparseConvFunction / SubMConvFunction /
+    SparseImplicitGemmFunction."""
+
+    @staticmethod
+    def forward(ctx, features, weight, rb: Rulebook, inverse: bool):
+        be = get_backend()
+        ctx.rb, ctx.inverse = rb, inverse
+        ctx.save_for_backward(features, weight)
+        tbl = rb.pair_bwd if inverse else rb.pair_fwd
+        return be.conv_forward(features, weight, tbl)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        be = get_backend()
+        features, weight = ctx.saved_tensors
+        rb: Rulebook = ctx.rb
+        grad_out = grad_out.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            if ctx.inverse:
+                dx = be.conv_backward_input(grad_out, weight, rb.pair_fwd, rb.n_out, mirror=False)
+            elif rb.kind == "subm":
+                dx = be.conv_backward_input(grad_out, weight, rb.pair_fwd, rb.n_in, mirror=True, centre=rb.centre,
+                                            rep=rb.rep)
+            else:
+                dx = be.conv_backward_input(grad_out, weight, rb.pair_bwd, rb.n_in, mirror=False)
+        if ctx.needs_input_grad[1]:
+            tbl = rb.pair_bwd if ctx.inverse else rb.pair_fwd
+            dw = be.conv_backward_weight(features, grad_out, tbl, tuple(weight.shape))
+        return dx, dw, None, None
+
+
+def sparse_conv(features: torch.Tensor, weight: torch.Tensor, rb: Rulebook, inverse: bool = False) -> torch.Tensor:
+    return SparseConvFunction.apply(features, weight, rb, inverse)
+
+
+class GatherRowsFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, keep):
+        ctx.n_in = features.shape[0]
+        ctx.save_for_backward(keep)
+        fo, _ = get_backend().gather_rows(features, None, keep)
+        return fo
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (keep,) = ctx.saved_tensors
+        return get_backend().scatter_rows(grad_out.contiguous(), keep, ctx.n_in), None
+
+
+def discard_rows(features: torch.Tensor, indices: torch.Tensor, keep: torch.Tensor):
+    """Device half of layer_voxel_discard (spconv_backbone.py:134-147): (features[keep], indices[keep])."""
+    keep = keep.to(device=features.device, dtype=torch.int64)
+    f = GatherRowsFunction.apply(features, keep)
+    # indices carry no gradient; gather them with the same kernel through a 4-channel float view is not possible
+    # (int payload), so use the index half of vc_gather_rows on a detached call
+    _, idx = get_backend().gather_rows(features.detach(), indices, keep)
+    return f, idx
+
+
+class ToDenseFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, indices, spatial_shape, batch_size):
+        ctx.meta = (tuple(spatial_shape), int(batch_size))
+        ctx.save_for_backward(indices)
+        return get_backend().to_dense(features, indices, spatial_shape, batch_size)
+
+    @staticmethod
+    def backward(ctx, grad_dense):
+        (indices,) = ctx.saved_tensors
+        shape, bs = ctx.meta
+        return get_backend().from_dense(grad_dense.contiguous(), indices, shape, bs), None, None, None
+
+
+def to_dense(features, indices, spatial_shape, batch_size):
+    return ToDenseFunction.apply(features, indices, tuple(int(s) for s in spatial_shape), batch_size)
+
+
+class BNReLUFunction(torch.autograd.Function):
+    """Training-mode BatchNorm1d(+ReLU) over the active rows."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+        be = get_backend()
+        y, mean, var = be.bn_forward(x, gamma, beta, running_mean, running_var, training, momentum, eps, relu)
+        ctx.cfg = (training, float(eps), bool(relu))
+        ctx.save_for_backward(x, mean, var, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        be = get_backend()
+        x, mean, var, gamma, beta = ctx.saved_tensors
+        training, eps, relu = ctx.cfg
+        if not training:
+            raise NotImplementedError("virconv_amd: backward through eval-mode BatchNorm is not supported")
+        dx, dgamma, dbeta = be.bn_backward(x, grad_out.contiguous(), 0, mean, var, gamma, beta, eps, relu)
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def bn_relu(x: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool) -> torch.Tensor:
+    """Fused BatchNorm1d(+ReLU) using the parameters/buffers of a stock nn.BatchNorm1d module."""
+    training = bn.training or not bn.track_running_stats
+    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    momentum = 0.0 if bn.momentum is None else bn.momentum
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return BNReLUFunction.apply(x, bn.weight, bn.bias, rm, rv, training, momentum, bn.eps, relu)
+
+
+def project_uv(indices, calib, trans, batch_size, stride):
+    uv, _ = get_backend().project_uv(indices, calib, trans, batch_size, stride)
+    return uv
+
+
+def calib_tensor(calibs, device) -> torch.Tensor:
+    """Pack per-sample calibration (objects with .V2C/.R0/.P2 or dicts) into the (B, 33) float32 block of the ABI."""
+    rows = []
+    for c in calibs:
+        if isinstance(c, dict):
+            v2c, r0, p2 = c["Tr_velo2cam"], c["R0"], c["P2"]
+        else:
+            v2c, r0, p2 = c.V2C, c.R0, c.P2
+        rows.append(np.concatenate([np.asarray(v2c, np.float32).reshape(12), np.asarray(r0, np.float32).reshape(9),
+                                    np.asarray(p2, np.float32).reshape(12)]))
+    return torch.from_numpy(np.stack(rows)).to(device)

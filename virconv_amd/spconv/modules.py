@@ -1,0 +1,86 @@
+"""SparseModule / SparseSequential (used at spconv_backbone.py:101-105,125-129,248-291,561-567)."""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from .. import ops
+from .core import SparseConvTensor
+
+
+class SparseModule(nn.Module):
+    """Marker base: modules that take and return a SparseConvTensor."""
+
+
+def is_spconv_module(m: nn.Module) -> bool:
+    return isinstance(m, SparseModule)
+
+
+class SparseSequential(SparseModule):
+    """Runs modules in order.  SparseModules see the SparseConvTensor; plain nn.Modules (BatchNorm1d, ReLU) are applied
+    to ``.features`` (N, C) and re-wrapped.  ``BatchNorm1d`` [+ ``ReLU``] pairs run as ONE fused HIP pass
+    (vc_bn_stats + vc_bn_apply_relu) unless ``fuse_bn_relu`` is False; parameters stay in the stock nn.BatchNorm1d so
+    state_dict keys are unchanged."""
+
+    fuse_bn_relu = True
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], OrderedDict):
+            for key, module in args[0].items():
+                self.add_module(key, module)
+        else:
+            for idx, module in enumerate(args):
+                self.add_module(str(idx), module)
+        for name, module in kwargs.items():
+            if name in self._modules:
+                raise ValueError("name exists.")
+            self.add_module(name, module)
+
+    def __getitem__(self, idx):
+        if not (-len(self) <= idx < len(self)):
+            raise IndexError("index {} is out of range".format(idx))
+        if idx < 0:
+            idx += len(self)
+        it = iter(self._modules.values())
+        for _ in range(idx):
+            next(it)
+        return next(it)
+
+    def __len__(self):
+        return len(self._modules)
+
+    def add(self, module, name=None):
+        if name is None:
+            name = str(len(self._modules))
+            if name in self._modules:
+                raise KeyError("name exists")
+        self.add_module(name, module)
+
+    def forward(self, input):
+        mods = list(self._modules.values())
+        k = 0
+        while k < len(mods):
+            module = mods[k]
+            if is_spconv_module(module):
+                assert isinstance(input, SparseConvTensor)
+                input = module(input)
+                k += 1
+                continue
+            if isinstance(input, SparseConvTensor):
+                if input.indices.shape[0] != 0:
+                    feats = input.features
+                    fused = (self.fuse_bn_relu and type(module) is nn.BatchNorm1d and feats.is_cuda
+                             and module.affine and module.momentum is not None and feats.shape[1] % 4 == 0)
+                    if fused:
+                        relu = k + 1 < len(mods) and type(mods[k + 1]) is nn.ReLU
+                        input = input.replace_feature(ops.bn_relu(feats, module, relu))
+                        k += 2 if relu else 1
+                        continue
+                    input = input.replace_feature(module(feats))
+            else:
+                input = module(input)
+            k += 1
+        return input
