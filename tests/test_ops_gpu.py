@@ -1,0 +1,279 @@
+"""GPU parity tests proper: every HIP operator (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Integer / index outputs are compared bit-exactly; float outputs within the north-star tolerance (1e-4 fp32).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dense_ref, geometry, sparse_ref
+from oracle.backend import OracleBackend
+from virconv_amd import ops, synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+SHAPE3 = (21, 64, 48)
+
+
+def _rel_err(a: np.ndarray, b: np.ndarray) -> float:
+    return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+
+
+def _indices3(seed, n, bs=2, shape=SHAPE3):
+    return synth.small_scene_indices(seed, n, shape, bs)
+
+
+def _indices2(seed, n, bs=2, shape=(160, 60), dup=True):
+    rng = np.random.default_rng(seed)
+    b = rng.integers(0, bs, n)
+    u = rng.integers(0, shape[0] if not dup else shape[0] // 4, n)
+    v = rng.integers(0, shape[1] if not dup else shape[1] // 4, n)
+    idx = np.stack([b, u, v], 1).astype(np.int32)
+    if not dup:
+        idx = np.unique(idx, axis=0)
+        idx = idx[rng.permutation(idx.shape[0])]
+    return idx
+
+
+# ------------------------------------------------------------------------------------------------ rulebooks
+@pytest.mark.parametrize("n", [0, 1, 63, 2000])
+def test_subm_rulebook_3d_bit_exact(hip_backend, n):
+    idx = _indices3(1, n) if n else np.zeros((0, 4), np.int32)
+    pair, rep = hip_backend.subm_rulebook(torch.from_numpy(idx).cuda(), SHAPE3, (3, 3, 3), (1, 1, 1), want_rep=True)
+    ref = sparse_ref.subm_rulebook(idx, SHAPE3, (3, 3, 3))
+    np.testing.assert_array_equal(pair.cpu().numpy(), ref)
+    np.testing.assert_array_equal(rep.cpu().numpy(), np.arange(idx.shape[0]))
+
+
+def test_subm_rulebook_2d_duplicates_bit_exact(hip_backend):
+    shape = (160, 60)
+    idx = _indices2(2, 3000, dup=True)
+    assert np.unique(idx, axis=0).shape[0] < idx.shape[0]  # duplicates present
+    pair, rep = hip_backend.subm_rulebook(torch.from_numpy(idx).cuda(), shape, (3, 3), (1, 1), want_rep=True)
+    np.testing.assert_array_equal(pair.cpu().numpy(), sparse_ref.subm_rulebook(idx, shape, (3, 3)))
+    lut = sparse_ref.CoordLookup(idx, shape)
+    np.testing.assert_array_equal(rep.cpu().numpy(), lut.find(idx[:, 0].astype(np.int64), idx[:, 1:].astype(np.int64)))
+
+
+@pytest.mark.parametrize("ks,st,pd", [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1)),
+                                      ((3, 1, 1), (2, 1, 1), (0, 0, 0)), ((3, 3, 3), (1, 1, 1), (1, 1, 1))])
+def test_sparse_rulebook_bit_exact(hip_backend, ks, st, pd):
+    idx = _indices3(3, 2500)
+    oi, osh, pf, pb = hip_backend.sparse_rulebook(torch.from_numpy(idx).cuda(), SHAPE3, 2, ks, st, pd, (1, 1, 1))
+    roi, rosh, rpf, rpb = sparse_ref.sparse_rulebook(idx, SHAPE3, 2, ks, st, pd)
+    assert tuple(osh) == tuple(rosh)
+    np.testing.assert_array_equal(oi.cpu().numpy(), roi)
+    np.testing.assert_array_equal(pf.cpu().numpy(), rpf)
+    np.testing.assert_array_equal(pb.cpu().numpy(), rpb)
+
+
+def test_sparse_rulebook_empty_and_single(hip_backend):
+    for idx in (np.zeros((0, 4), np.int32), np.array([[1, 0, 0, 0]], np.int32), np.array([[0, 20, 63, 47]], np.int32)):
+        oi, osh, pf, pb = hip_backend.sparse_rulebook(torch.from_numpy(idx).cuda(), SHAPE3, 2, (3, 3, 3), (2, 2, 2),
+                                                      (1, 1, 1), (1, 1, 1))
+        roi, rosh, rpf, rpb = sparse_ref.sparse_rulebook(idx, SHAPE3, 2, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+        np.testing.assert_array_equal(oi.cpu().numpy(), roi)
+        np.testing.assert_array_equal(pf.cpu().numpy(), rpf)
+        np.testing.assert_array_equal(pb.cpu().numpy(), rpb)
+
+
+# ------------------------------------------------------------------------------------------------ convolution
+CHANNELS = [(8, 8), (32, 16), (16, 16), (64, 32), (32, 32), (16, 32), (32, 64), (64, 64), (4, 16), (8, 16)]
+
+
+@pytest.mark.parametrize("cin,cout", CHANNELS)
+def test_subm_conv_forward_backward_vs_oracle(hip_backend, cin, cout):
+    rng = np.random.default_rng(cin * 100 + cout)
+    idx = _indices3(4, 3000)
+    n = idx.shape[0]
+    x = rng.standard_normal((n, cin)).astype(np.float32)
+    w = (rng.standard_normal((cout, 3, 3, 3, cin)) / np.sqrt(27 * cin)).astype(np.float32)
+    g = rng.standard_normal((n, cout)).astype(np.float32)
+    pair = sparse_ref.subm_rulebook(idx, SHAPE3, (3, 3, 3))
+    xt, wt, gt, pt = (torch.from_numpy(a).cuda() for a in (x, w, g, pair))
+    y = hip_backend.conv_forward(xt, wt, pt)
+    y_ref = sparse_ref.conv_forward(torch.from_numpy(x).double(), torch.from_numpy(w).double(), pair).numpy()
+    assert _rel_err(y.cpu().numpy(), y_ref) < TOL
+    dx = hip_backend.conv_backward_input(gt, wt, pt, n, mirror=True)
+    dw = hip_backend.conv_backward_weight(xt, gt, pt, w.shape)
+    dx_ref, dw_ref = sparse_ref.conv_backward(torch.from_numpy(x).double(), torch.from_numpy(w).double(), pair,
+                                              torch.from_numpy(g).double())
+    assert _rel_err(dx.cpu().numpy(), dx_ref.numpy()) < TOL
+    assert _rel_err(dw.cpu().numpy(), dw_ref.numpy()) < TOL
+
+
+def test_subm_conv_matches_dense_oracle(hip_backend):
+    """HIP rulebook + HIP conv against the INDEPENDENT dense conv3d oracle."""
+    rng = np.random.default_rng(11)
+    idx = _indices3(5, 1500)
+    n = idx.shape[0]
+    x = rng.standard_normal((n, 16)).astype(np.float32)
+    w = (rng.standard_normal((32, 3, 3, 3, 16)) / 20).astype(np.float32)
+    pair, _ = hip_backend.subm_rulebook(torch.from_numpy(idx).cuda(), SHAPE3, (3, 3, 3), (1, 1, 1), want_rep=False)
+    y = hip_backend.conv_forward(torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda(), pair)
+    yd = dense_ref.subm_conv(torch.from_numpy(x).double(), idx, SHAPE3, 2, torch.from_numpy(w).double()).numpy()
+    assert _rel_err(y.cpu().numpy(), yd) < TOL
+
+
+@pytest.mark.parametrize("ks,st,pd,cin,cout", [((3, 3, 3), (2, 2, 2), (1, 1, 1), 16, 32),
+                                               ((3, 3, 3), (2, 2, 2), (0, 1, 1), 64, 64),
+                                               ((3, 1, 1), (2, 1, 1), (0, 0, 0), 64, 64)])
+def test_strided_conv_forward_backward_vs_dense_oracle(hip_backend, ks, st, pd, cin, cout):
+    rng = np.random.default_rng(5)
+    idx = _indices3(6, 2500)
+    n = idx.shape[0]
+    x = rng.standard_normal((n, cin)).astype(np.float32)
+    w = (rng.standard_normal((cout,) + ks + (cin,)) / np.sqrt(np.prod(ks) * cin)).astype(np.float32)
+    oi, osh, pf, pb = hip_backend.sparse_rulebook(torch.from_numpy(idx).cuda(), SHAPE3, 2, ks, st, pd, (1, 1, 1))
+    xt, wt = torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda()
+    y = hip_backend.conv_forward(xt, wt, pf)
+    xd = torch.from_numpy(x).double().requires_grad_(True)
+    wd = torch.from_numpy(w).double().requires_grad_(True)
+    yd, oid, _ = dense_ref.sparse_conv(xd, idx, SHAPE3, 2, wd, st, pd)
+    np.testing.assert_array_equal(oi.cpu().numpy(), oid)
+    assert _rel_err(y.cpu().numpy(), yd.detach().numpy()) < TOL
+    g = rng.standard_normal(tuple(yd.shape)).astype(np.float32)
+    gx, gw = torch.autograd.grad(yd, (xd, wd), torch.from_numpy(g).double())
+    gt = torch.from_numpy(g).cuda()
+    dx = hip_backend.conv_backward_input(gt, wt, pb, n, mirror=False)
+    dw = hip_backend.conv_backward_weight(xt, gt, pf, w.shape)
+    assert _rel_err(dx.cpu().numpy(), gx.numpy()) < TOL
+    assert _rel_err(dw.cpu().numpy(), gw.numpy()) < TOL
+
+
+def test_subm2d_duplicates_forward_backward_vs_oracle(hip_backend):
+    """Image-space branch: duplicate pixels (SURVEY App-A.5 rule), backward through the group-sum path."""
+    rng = np.random.default_rng(9)
+    shape = (160, 60)
+    idx = _indices2(7, 4000, dup=True)
+    n, cin, cout = idx.shape[0], 16, 16
+    x = rng.standard_normal((n, cin)).astype(np.float32)
+    w = (rng.standard_normal((cout, 3, 3, cin)) / 12).astype(np.float32)
+    g = rng.standard_normal((n, cout)).astype(np.float32)
+    it = torch.from_numpy(idx).cuda()
+    pair, rep = hip_backend.subm_rulebook(it, shape, (3, 3), (1, 1), want_rep=True)
+    xt, wt, gt = (torch.from_numpy(a).cuda() for a in (x, w, g))
+    y = hip_backend.conv_forward(xt, wt, pair)
+    pref = sparse_ref.subm_rulebook(idx, shape, (3, 3))
+    xd, wd, gd = (torch.from_numpy(a).double() for a in (x, w, g))
+    assert _rel_err(y.cpu().numpy(), sparse_ref.conv_forward(xd, wd, pref).numpy()) < TOL
+    dx = hip_backend.conv_backward_input(gt, wt, pair, n, mirror=True, centre=4, rep=rep)
+    dw = hip_backend.conv_backward_weight(xt, gt, pair, w.shape)
+    dx_ref, dw_ref = sparse_ref.conv_backward(xd, wd, pref, gd)  # exact transpose of the forward gather
+    assert _rel_err(dx.cpu().numpy(), dx_ref.numpy()) < TOL
+    assert _rel_err(dw.cpu().numpy(), dw_ref.numpy()) < TOL
+
+
+def test_conv_forward_is_bitwise_deterministic(hip_backend):
+    rng = np.random.default_rng(3)
+    idx = _indices3(8, 3000)
+    x = torch.from_numpy(rng.standard_normal((idx.shape[0], 32)).astype(np.float32)).cuda()
+    w = torch.from_numpy(rng.standard_normal((32, 3, 3, 3, 32)).astype(np.float32)).cuda()
+    g = torch.from_numpy(rng.standard_normal((idx.shape[0], 32)).astype(np.float32)).cuda()
+    pair, _ = hip_backend.subm_rulebook(torch.from_numpy(idx).cuda(), SHAPE3, (3, 3, 3), (1, 1, 1), want_rep=False)
+    a = hip_backend.conv_forward(x, w, pair)
+    b = hip_backend.conv_forward(x, w, pair)
+    assert torch.equal(a, b)
+    assert torch.equal(hip_backend.conv_backward_weight(x, g, pair, w.shape), hip_backend.conv_backward_weight(x, g, pair, w.shape))
+
+
+def test_unsupported_channels_raise(hip_backend):
+    from virconv_amd._lib import VirConvError
+    pair = torch.zeros((27, 10), dtype=torch.int32, device="cuda")
+    with pytest.raises(VirConvError):
+        hip_backend.conv_forward(torch.zeros((10, 7), device="cuda"), torch.zeros((8, 3, 3, 3, 7), device="cuda"), pair)
+    with pytest.raises(VirConvError):
+        hip_backend.conv_forward(torch.zeros((10, 8)), torch.zeros((8, 3, 3, 3, 8)), pair.cpu())  # CPU tensors: no CPU path
+
+
+# ------------------------------------------------------------------------------------------------ BN(+ReLU)
+@pytest.mark.parametrize("c,relu", [(8, True), (16, True), (32, False), (64, True)])
+def test_bn_relu_forward_backward_vs_torch(hip_backend, c, relu):
+    torch.manual_seed(c)
+    n = 5000
+    x = (torch.randn(n, c) * 2 + 0.5).cuda()
+    bn = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.3, 0.3)
+    bn2 = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).cuda()
+    bn2.load_state_dict(bn.state_dict())
+    xa = x.clone().requires_grad_(True)
+    xb = x.clone().requires_grad_(True)
+    ya = ops.bn_relu(xa, bn, relu)
+    yb = bn2(xb)
+    if relu:
+        yb = torch.relu(yb)
+    g = torch.randn_like(ya)
+    ya.backward(g)
+    yb.backward(g)
+    assert _rel_err(ya.detach().cpu().numpy(), yb.detach().cpu().numpy()) < TOL
+    assert _rel_err(xa.grad.cpu().numpy(), xb.grad.cpu().numpy()) < TOL
+    assert _rel_err(bn.weight.grad.cpu().numpy(), bn2.weight.grad.cpu().numpy()) < TOL
+    assert _rel_err(bn.bias.grad.cpu().numpy(), bn2.bias.grad.cpu().numpy()) < TOL
+    assert _rel_err(bn.running_mean.cpu().numpy(), bn2.running_mean.cpu().numpy()) < 1e-5
+    assert _rel_err(bn.running_var.cpu().numpy(), bn2.running_var.cpu().numpy()) < 1e-5
+    bn.eval(); bn2.eval()
+    with torch.no_grad():
+        ye = ops.bn_relu(x, bn, relu)
+        yr = torch.relu(bn2(x)) if relu else bn2(x)
+    assert _rel_err(ye.cpu().numpy(), yr.cpu().numpy()) < TOL
+
+
+# ------------------------------------------------------------------------------------------------ projection etc.
+@pytest.mark.parametrize("stride", [1, 2, 4, 8])
+@pytest.mark.parametrize("with_trans", [True, False])
+def test_project_uv_bit_exact(hip_backend, stride, with_trans):
+    rng = np.random.default_rng(stride)
+    bs, n = 3, 20000
+    shape = np.array([81, 1600, 1408]) // np.array([stride if stride < 8 else 8] * 3)
+    idx = np.stack([rng.integers(0, bs, n), rng.integers(0, max(shape[0], 1), n), rng.integers(0, shape[1], n),
+                    rng.integers(0, shape[2], n)], 1).astype(np.int32)
+    calibs = []
+    for b in range(bs):
+        c = synth.default_calib()
+        c["P2"] = c["P2"] + rng.uniform(-1, 1, (3, 4)).astype(np.float32) * np.float32(0.01)
+        calibs.append(c)
+    trans = np.stack([[rng.uniform(-0.78, 0.78), float(b % 2), rng.uniform(0.95, 1.05)] for b in range(bs)]).astype(np.float32)
+    tp = trans if with_trans else None
+    uv_ref, depth_ref = geometry.index2uv(idx, bs, calibs, stride, tp)
+    uv, depth = hip_backend.project_uv(torch.from_numpy(idx).cuda(), ops.calib_tensor(calibs, "cuda"),
+                                       None if tp is None else torch.from_numpy(tp).cuda(), bs, stride, want_depth=True)
+    np.testing.assert_array_equal(uv.cpu().numpy(), uv_ref)
+    np.testing.assert_allclose(depth.cpu().numpy(), depth_ref, rtol=0, atol=0)
+
+
+def test_gather_scatter_rows_and_dense(hip_backend):
+    rng = np.random.default_rng(0)
+    idx = _indices3(9, 1000)
+    n = idx.shape[0]
+    f = rng.standard_normal((n, 32)).astype(np.float32)
+    keep = rng.permutation(n)[: int(n * 0.9)]
+    fo, io = hip_backend.gather_rows(torch.from_numpy(f).cuda(), torch.from_numpy(idx).cuda(), torch.from_numpy(keep).cuda())
+    np.testing.assert_array_equal(fo.cpu().numpy(), f[keep])
+    np.testing.assert_array_equal(io.cpu().numpy(), idx[keep])
+    gi = hip_backend.scatter_rows(fo, torch.from_numpy(keep).cuda(), n).cpu().numpy()
+    exp = np.zeros_like(f)
+    exp[keep] = f[keep]
+    np.testing.assert_array_equal(gi, exp)
+    d = hip_backend.to_dense(torch.from_numpy(f).cuda(), torch.from_numpy(idx).cuda(), SHAPE3, 2)
+    dref = sparse_ref.to_dense(torch.from_numpy(f), idx, SHAPE3, 2).numpy()
+    np.testing.assert_array_equal(d.cpu().numpy(), dref)
+    back = hip_backend.from_dense(d, torch.from_numpy(idx).cuda(), SHAPE3, 2)
+    np.testing.assert_array_equal(back.cpu().numpy(), f)
+
+
+@pytest.mark.parametrize("max_voxels", [40000, 3000])
+def test_voxelize_mean_vs_oracle(hip_backend, max_voxels):
+    fr = synth.make_frame(21, n_lidar=6000, n_virtual=9000)
+    pts = np.concatenate([fr["points_lidar"], fr["points_virtual"]])
+    out_of_range = np.array([[-1.0, 0, 0, 0, 0, 0, 0, 2], [10, 45.0, 0, 0, 0, 0, 0, 2], [10, 0, 1.5, 0, 0, 0, 0, 1]], np.float32)
+    pts = np.concatenate([pts[:100], out_of_range, pts[100:]])
+    f, c, num = hip_backend.voxelize_mean(torch.from_numpy(pts).cuda(), synth.POINT_CLOUD_RANGE, synth.VOXEL_SIZE, 5,
+                                          max_voxels, True)
+    vox, cref, nref = geometry.voxelize(pts, synth.VOXEL_SIZE, synth.POINT_CLOUD_RANGE, 5, max_voxels)
+    fref = geometry.mean_vfe(vox, nref, "max")
+    np.testing.assert_array_equal(c.cpu().numpy(), cref)
+    np.testing.assert_array_equal(num.cpu().numpy(), nref)
+    np.testing.assert_allclose(f.cpu().numpy(), fref, rtol=0, atol=1e-6)
