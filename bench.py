@@ -1,0 +1,191 @@
+"""bench.py -- VirConv-L backbone train step (fwd + bwd + Adam) on synthetic KITTI-shaped frames.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  A "step" = one pass of the hot path over one batch: BASELINE.json configs[2]
+(VirConv-L forward + backward + Adam, bs=4 frames per GPU, train mode, layer discard 0.1, NRConv 2-D branch on); frames
+shard across ranks with no data-path collective, the only exchange is the DDP gradient all-reduce (RCCL).  Inputs
+(voxel features/coords, calib, aug params) are resident in HBM before the timed region; weak scaling (4 frames per GPU).
+
+Rank 0 prints ONE JSON line: metric/value/unit/..., plus
+  "roofline":     the dominant kernel (gather-GEMM forward/backward-input family, fp32 MFMA) -- achieved algorithmic
+                  TFLOP/s from HIP events bracketing every launch of the traced instantiation inside the timed steps
+  "cpu_baseline": the CPU oracle (torch-CPU index_select/mm/index_add port of the reference algorithm class) on a
+                  bounded sample (rank 0, N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from virconv_amd import data, ops, parallel, synth  # noqa: E402
+from virconv_amd.backbone import VirConvL8x  # noqa: E402
+
+MODEL_CFG = dict(NAME="VirConvL8x", NUM_FILTERS=[16, 32, 64, 64], RETURN_NUM_FEATURES_AS_DICT=True, OUT_FEATURES=64,
+                 LAYER_DISCARD_RATE=0.1, LAYER_DISCARD_MODE="spconv1_inplace")
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+HBM_PEAK_GBS = 8000.0
+
+
+def make_batch(frame_seeds, device, training=True):
+    """Synthetic frames -> reference data path (input discard, LiDAR-first fusion) -> GPU voxeliser+MeanVFE -> batch."""
+    frames, calibs, augs = [], [], []
+    for s in frame_seeds:
+        fr = synth.make_frame(s)
+        rng = np.random.default_rng(10_000 + s)
+        frames.append(data.prepare_frame(fr["points_lidar"], fr["points_virtual"], training=training, rng=rng))
+        calibs.append(fr["calib"])
+        augs.append(fr["aug_param"])
+    feats, coords, _ = data.voxelize_batch(frames, synth.POINT_CLOUD_RANGE, synth.VOXEL_SIZE, 5, 40000, True, device)
+    return {
+        "batch_size": len(frame_seeds),
+        "voxel_features": feats,
+        "voxel_coords": coords.float(),  # load_data_to_gpu casts everything to float (models/__init__.py:24)
+        "calib": ops.calib_tensor(calibs, device),
+        "aug_param": torch.from_numpy(np.stack(augs)).to(device),
+    }
+
+
+def make_loss_weights(device):
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    w = {"dense": torch.randn((1, 64, 4, 200, 176), generator=g).to(device) * 0.01}
+    for name, c in (("x_conv1", 16), ("x_conv2", 32), ("x_conv3", 64), ("x_conv4", 64)):
+        w[name] = torch.randn((c,), generator=g).to(device) * 0.01
+    return w
+
+
+def train_step(model, optimizer, batch, lw):
+    """fwd + bwd + Adam.  loss = (out.dense()*G).sum() + sum_i (x_conv_i.features * g_i).sum()  (heads out of scope)."""
+    optimizer.zero_grad(set_to_none=True)
+    bd = dict(batch)
+    bd["voxel_features"] = batch["voxel_features"].clone()  # the backbone zeroes RGB in place
+    out = model(bd)
+    loss = (out["encoded_spconv_tensor"].dense() * lw["dense"]).sum()
+    for name, t in out["multi_scale_3d_features"].items():
+        loss = loss + (t.features * lw[name]).sum()
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)  # train_utils.py:50
+    optimizer.step()
+    return loss
+
+
+def cpu_baseline(sample_frames=1, repeats=1):
+    """Time the CPU oracle (kind 'port') on a bounded sample of the same workload: `sample_frames` frame(s), fwd+bwd+Adam."""
+    from oracle.backend import OracleBackend
+    cores = os.cpu_count() or 1
+    threads = min(cores, 16)  # more threads than this slow the small gather/mm/scatter ops down
+    torch.set_num_threads(threads)
+    be = OracleBackend()
+    with ops.use_backend(be):
+        # inputs through the oracle voxeliser (CPU), same synthetic frames
+        batch = make_batch(list(range(sample_frames)), "cpu", training=True)
+        model = VirConvL8x(MODEL_CFG, input_channels=8, grid_size=synth.GRID_SIZE)
+        model.train()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01)
+        lw = make_loss_weights("cpu")
+        t0 = time.perf_counter()
+        train_step(model, opt, batch, lw)  # warm-up (allocator, thread pools)
+        warm = time.perf_counter() - t0
+        repeats = int(min(10, max(repeats, np.ceil(12.0 / max(warm, 1e-3)))))  # ~10-30 s of CPU work in total
+        t0 = time.perf_counter()
+        for _ in range(repeats):
+            train_step(model, opt, batch, lw)
+        dt = (time.perf_counter() - t0) / repeats
+    return {"value": round(sample_frames / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{sample_frames} synthetic KITTI frame(s), VirConv-L fwd+bwd+Adam, oracle (torch-CPU gather-mm-scatter), "
+                      f"{repeats} timed step(s) of {dt:.2f} s after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-size", type=int, default=4, help="frames per GPU (BASELINE config 3: bs=4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--trace", default="fwd,64,32", help="gather-GEMM instantiation timed for the roofline: dir,CK,CN")
+    args = ap.parse_args()
+
+    rank, local_rank, world = parallel.init_distributed()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    device = torch.device("cuda", local_rank % torch.cuda.device_count())
+    torch.cuda.set_device(device)
+    be = ops.get_backend()
+
+    bs = args.batch_size
+    seeds = parallel.shard_frames(list(range(bs * world)), rank, world)
+    batch = make_batch(seeds, device, training=True)
+    torch.manual_seed(0)
+    model = VirConvL8x(MODEL_CFG, input_channels=8, grid_size=synth.GRID_SIZE).to(device)
+    model.train()
+    ddp = parallel.wrap_ddp(model, device)
+    optimizer = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01)
+    lw = make_loss_weights(device)
+    torch.manual_seed(100 + rank)  # layer-discard permutations
+
+    for _ in range(args.warmup):
+        train_step(ddp, optimizer, batch, lw)
+
+    tdir, tck, tcn = args.trace.split(",")
+    be.trace_begin(tdir, int(tck), int(tcn))
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        train_step(ddp, optimizer, batch, lw)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    dt = time.perf_counter() - t0
+    trace = be.trace_end()
+    dt = parallel.max_over_ranks(dt, device)
+
+    if rank != 0:
+        return
+    frames = bs * world * args.steps
+    n_launch = len(trace)
+    roof = None
+    if n_launch:
+        t_ms = sum(e["ms"] for e in trace)
+        flops = sum(e["flops"] for e in trace)
+        byts = sum(e["bytes"] for e in trace)
+        ach = flops / (t_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                "kernel": f"gather_gemm_kernel<CK={tck},CN={tcn},BWD={'true' if tdir == 'bwd' else 'false'}>",
+                "launches": n_launch, "avg_us": round(t_ms / n_launch * 1e3, 2),
+                "algorithmic_gflop_per_launch": round(flops / n_launch / 1e9, 4),
+                "algorithmic_mb_per_launch": round(byts / n_launch / 1e6, 3),
+                "hbm_frac_of_algorithmic_bytes": round(byts / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    res = {
+        "metric": "KITTI frames/sec (fwd+bwd) VirConv-L backbone", "value": round(frames / dt, 3), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: VirConv-L train step (fwd+bwd+Adam), train mode, layer discard 0.1, "
+                               "NRConv 2-D branch on, synthetic KITTI frames (20k LiDAR + 60k virtual points, input "
+                               "discard 0.8, <=40000 voxels/frame)",
+                   "frames_per_gpu": bs, "global_batch": bs * world, "voxels_rank0": int(batch["voxel_features"].shape[0]),
+                   "parallelism": f"dp{world}"},
+        "roofline": roof,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline()
+    else:
+        res["cpu_baseline"] = None
+    print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -63,6 +63,10 @@ def load() -> C.CDLL:
         raise VirConvError(
             f"{LIB_PATH} is missing: build it with `python -m virconv_amd.build` (hipcc, gfx950). "
             "virconv_amd has no CPU or PyTorch fallback for its operators.")
+    # torch ships its own HIP runtime (torch/lib/libamdhip64.so).  It must be loaded FIRST so that this library binds to
+    # the same runtime instance (same device context, same streams) instead of /opt/rocm's copy: loading ours first
+    # gives two runtimes in one process and "no ROCm-capable device is detected" from the second one.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol

@@ -40,6 +40,44 @@ class HipBackend:
 
     def __init__(self):
         self.lib = _lib.load()
+        self._trace = None      # (direction, CK, CN) of the gather-GEMM instantiation being timed, or None
+        self._trace_log = []
+
+    # ------------------------------------------------------------------ kernel timing for bench.py's roofline
+    def trace_begin(self, direction: str, ck: int, cn: int) -> None:
+        """Bracket every launch of gather_gemm_kernel<CK, CN, BWD=(direction=='bwd')> with HIP events on the current
+        stream and log its algorithmic flops / bytes (SURVEY §8d formulas)."""
+        assert direction in ("fwd", "bwd")
+        self._trace = (direction, int(ck), int(cn))
+        self._trace_log = []
+
+    def trace_end(self):
+        log, self._trace, self._trace_log = self._trace_log, None, []
+        if not log:
+            return []
+        torch.cuda.synchronize()
+        out = []
+        for e in log:
+            pairs = int(e["pairs"].item())
+            kv, ck, cn = e["kv"], e["ck"], e["cn"]
+            out.append({"ms": e["start"].elapsed_time(e["end"]), "flops": 2.0 * pairs * ck * cn,
+                        "bytes": 4.0 * (e["n_src"] * ck + e["n_out"] * cn + kv * ck * cn) + 4.0 * kv * e["n_out"],
+                        "pairs": pairs, "n_out": e["n_out"]})
+        return out
+
+    def _traced(self, direction, ck, cn):
+        return self._trace is not None and self._trace == (direction, ck, cn)
+
+    def _trace_open(self, tbl, n_src, ck, cn):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        rec = {"pairs": (tbl >= 0).sum(), "kv": tbl.shape[0], "n_out": tbl.shape[1], "n_src": n_src, "ck": ck, "cn": cn,
+               "start": ev0, "end": ev1}
+        ev0.record()
+        return rec
+
+    def _trace_close(self, rec):
+        rec["end"].record()
+        self._trace_log.append(rec)
 
     # ------------------------------------------------------------------ rulebooks
     def subm_rulebook(self, indices: torch.Tensor, spatial_shape: Sequence[int], ksize, dilation, want_rep: bool):
@@ -94,8 +132,11 @@ class HipBackend:
         cout, cin = weight.shape[0], weight.shape[-1]
         assert weight.numel() == cout * kv * cin and x.shape[1] == cin
         y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+        rec = self._trace_open(pair_fwd, x.shape[0], cin, cout) if self._traced("fwd", cin, cout) else None
         check(self.lib.vc_conv_forward(_ptr(x), x.shape[0], _ptr(pair_fwd), n_out, kv, _ptr(weight), cin, cout, _ptr(y),
                                        _stream()), "vc_conv_forward")
+        if rec is not None:
+            self._trace_close(rec)
         return y
 
     def conv_backward_input(self, dy: torch.Tensor, weight: torch.Tensor, tbl: torch.Tensor, n_in: int, mirror: bool,
@@ -113,9 +154,12 @@ class HipBackend:
             grp = torch.empty_like(dy)
             check(self.lib.vc_group_sum(_ptr(dy), _ptr(rep), dy.shape[0], cout, _ptr(grp), _stream()), "vc_group_sum")
             src, src_centre = grp, dy
+        rec = self._trace_open(tbl, dy.shape[0], cout, cin) if self._traced("bwd", cout, cin) else None
         check(self.lib.vc_conv_backward_input(_ptr(src), _ptr(src_centre), dy.shape[0], _ptr(tbl), n_in, kv, _ptr(weight),
                                               cin, cout, 1 if mirror else 0, centre if rep is not None else -1,
                                               _ptr(rep), _ptr(dx), _stream()), "vc_conv_backward_input")
+        if rec is not None:
+            self._trace_close(rec)
         return dx
 
     def conv_backward_weight(self, x: torch.Tensor, dy: torch.Tensor, pair_fwd: torch.Tensor, weight_shape) -> torch.Tensor:

@@ -78,17 +78,30 @@ __global__ void __launch_bounds__(256) bn_reduce_kernel(const float* __restrict_
   }
 }
 
-__global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, int nb, int64_t n, int c,
-                                         float* __restrict__ mean, float* __restrict__ var,
-                                         float* __restrict__ running_mean, float* __restrict__ running_var,
-                                         float momentum) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per channel: lane l sums partials l, l+64, ... (fixed order), then a fixed-order butterfly; 4 channels/block.
+__device__ __forceinline__ void wave_sum2(double& a, double& b) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    a += __shfl_xor(a, off, 64);
+    b += __shfl_xor(b, off, 64);
+  }
+}
+
+__global__ void __launch_bounds__(256) bn_stats_finalize_kernel(const double* __restrict__ partial, int nb, int64_t n,
+                                                                int c, float* __restrict__ mean,
+                                                                float* __restrict__ var,
+                                                                float* __restrict__ running_mean,
+                                                                float* __restrict__ running_var, float momentum) {
+  const int lane = threadIdx.x & 63;
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ch >= c) return;
   double s = 0.0, ss = 0.0;
-  for (int b = 0; b < nb; ++b) {
+  for (int b = lane; b < nb; b += 64) {
     s += partial[(int64_t)b * 2 * c + ch];
     ss += partial[(int64_t)b * 2 * c + c + ch];
   }
+  wave_sum2(s, ss);
+  if (lane != 0) return;
   const double m = s / (double)n;
   double v = ss / (double)n - m * m;
   if (v < 0.0) v = 0.0;
@@ -101,15 +114,19 @@ __global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, int
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nb, int c, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ sums /* [2][c]: dbeta, dgamma */) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const double* __restrict__ partial, int nb, int c,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ sums /* [2][c]: dbeta, dgamma */) {
+  const int lane = threadIdx.x & 63;
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ch >= c) return;
   double s = 0.0, ss = 0.0;
-  for (int b = 0; b < nb; ++b) {
+  for (int b = lane; b < nb; b += 64) {
     s += partial[(int64_t)b * 2 * c + ch];
     ss += partial[(int64_t)b * 2 * c + c + ch];
   }
+  wave_sum2(s, ss);
+  if (lane != 0) return;
   if (dbeta) dbeta[ch] = (float)s;
   if (dgamma) dgamma[ch] = (float)ss;
   sums[ch] = (float)s;
@@ -208,8 +225,8 @@ int vc_bn_stats(const float* x, int64_t n, int c, float* mean, float* var, float
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f, 0,
                      rpb, partial);
   VC_CHECK_LAUNCH("bn_reduce_kernel<stats>");
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(1), dim3(128), 0, st, partial, nb, n, c, mean, var, running_mean,
-                     running_var, momentum);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, partial, nb, n, c, mean, var,
+                     running_mean, running_var, momentum);
   VC_CHECK_LAUNCH("bn_stats_finalize_kernel");
   return VC_OK;
 }
@@ -243,7 +260,7 @@ int vc_bn_relu_backward(const float* x, const float* dy, int dy_stride, int dy_c
   hipLaunchKernelGGL((bn_reduce_kernel<true>), dim3(nb), dim3(256), 0, st, x, dy, dy_stride, dy_col0, n, c, mean, var,
                      gamma, beta, eps, relu, rpb, partial);
   VC_CHECK_LAUNCH("bn_reduce_kernel<bwd>");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(128), 0, st, partial, nb, c, dgamma, dbeta, sums);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, partial, nb, c, dgamma, dbeta, sums);
   VC_CHECK_LAUNCH("bn_bwd_finalize_kernel");
   hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3((unsigned)cdiv(n * (c / 4), 256)), dim3(256), 0, st, x, dy, dy_stride,
                      dy_col0, n, c, mean, var, gamma, beta, eps, relu, sums, dx);

@@ -158,45 +158,66 @@ __global__ void __launch_bounds__(256) scan_blocksums_kernel(int32_t* __restrict
   }
 }
 
-__global__ void __launch_bounds__(256) sp_emit_kernel(const unsigned long long* __restrict__ bitmap, int64_t nwords,
-                                                      const int32_t* __restrict__ blocksum,
-                                                      uint32_t* __restrict__ prefix, int ndim, int Do, int Ho, int Wo,
-                                                      int64_t n_out, int32_t* __restrict__ out_indices) {
+// prefix[w] = number of set bits before word w (block-local scan + scanned block sums)
+__global__ void __launch_bounds__(256) sp_prefix_kernel(const unsigned long long* __restrict__ bitmap, int64_t nwords,
+                                                        const int32_t* __restrict__ blocksum,
+                                                        uint32_t* __restrict__ prefix) {
   __shared__ int lds[4];
   int64_t w0 = (int64_t)blockIdx.x * kWordsPerBlock + (int64_t)threadIdx.x * kWordsPerThread;
-  unsigned long long wv[kWordsPerThread];
+  int pc[kWordsPerThread];
   int c = 0;
 #pragma unroll
   for (int j = 0; j < kWordsPerThread; ++j) {
-    wv[j] = (w0 + j < nwords) ? bitmap[w0 + j] : 0ULL;
-    c += __popcll(wv[j]);
+    pc[j] = (w0 + j < nwords) ? __popcll(bitmap[w0 + j]) : 0;
+    c += pc[j];
   }
   int tot;
   int ex = block_exclusive_scan_256(c, &tot, lds) + blocksum[blockIdx.x];
-  const int64_t cells = (int64_t)Do * Ho * Wo;
-  const int hw = Ho * Wo;
 #pragma unroll
   for (int j = 0; j < kWordsPerThread; ++j) {
-    if (w0 + j >= nwords) break;
-    prefix[w0 + j] = (uint32_t)ex;
-    unsigned long long m = wv[j];
-    while (m) {
-      int bit = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      int64_t L = (w0 + j) * 64 + bit;
-      int64_t row = ex++;
-      if (row < n_out) {
-        int b = (int)(L / cells);
-        int rem = (int)(L - (int64_t)b * cells);
-        int z = rem / hw;
-        rem -= z * hw;
-        int y = rem / Wo, x = rem - y * Wo;
-        int32_t* o = out_indices + row * (ndim + 1);
-        o[0] = b;
-        if (ndim == 3) { o[1] = z; o[2] = y; o[3] = x; }
-        else { o[1] = y; o[2] = x; }
+    if (w0 + j < nwords) prefix[w0 + j] = (uint32_t)ex;
+    ex += pc[j];
+  }
+}
+
+// one thread per bitmap word: occupied cells are clustered, so the emission is spread as thinly as possible; the
+// coordinate of bit 0 is decoded once (one 64-bit division) and then walked with carries.
+__global__ void __launch_bounds__(256) sp_emit_kernel(const unsigned long long* __restrict__ bitmap, int64_t nwords,
+                                                      const uint32_t* __restrict__ prefix, int ndim, int Do, int Ho,
+                                                      int Wo, int64_t n_out, int32_t* __restrict__ out_indices) {
+  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (w >= nwords) return;
+  unsigned long long m = bitmap[w];
+  if (m == 0ULL) return;
+  int64_t row = prefix[w];
+  const int64_t cells = (int64_t)Do * Ho * Wo;
+  const int hw = Ho * Wo;
+  const int64_t L0 = w * 64;
+  int b = (int)(L0 / cells);
+  int rem = (int)(L0 - (int64_t)b * cells);
+  int z = rem / hw;
+  rem -= z * hw;
+  int y = rem / Wo, x = rem - y * Wo;
+  int prev = 0;
+  while (m) {
+    const int bit = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    x += bit - prev;
+    prev = bit;
+    while (x >= Wo) {
+      x -= Wo;
+      if (++y >= Ho) {
+        y = 0;
+        if (++z >= Do) { z = 0; ++b; }
       }
     }
+    if (row < n_out) {
+      int32_t* o = out_indices + row * (ndim + 1);
+      o[0] = b;
+      if (ndim == 3) { o[1] = z; o[2] = y; o[3] = x; }
+      else { o[1] = y; o[2] = x; }
+    }
+    ++row;
   }
 }
 
@@ -600,8 +621,10 @@ int vc_spconv_emit_pairs(const int32_t* indices, int64_t n, int ndim, int batch_
   const int32_t* blocksum = (const int32_t*)(prefix + nwords);
   Kern3 k = make_kern(ndim, ksize, stride_, padding, dilation);
   SpGeom g = make_spgeom(o, k);
-  hipLaunchKernelGGL(sp_emit_kernel, dim3((unsigned)nb), dim3(256), 0, st, bitmap, nwords, blocksum, prefix, ndim, o.D,
-                     o.H, o.W, n_out, out_indices);
+  hipLaunchKernelGGL(sp_prefix_kernel, dim3((unsigned)nb), dim3(256), 0, st, bitmap, nwords, blocksum, prefix);
+  VC_CHECK_LAUNCH("sp_prefix_kernel");
+  hipLaunchKernelGGL(sp_emit_kernel, dim3((unsigned)cdiv(nwords, 256)), dim3(256), 0, st, bitmap, nwords, prefix, ndim,
+                     o.D, o.H, o.W, n_out, out_indices);
   VC_CHECK_LAUNCH("sp_emit_kernel");
   if (n_out > 0) VC_CHECK_HIP(hipMemsetAsync(pair_fwd, 0xFF, (size_t)k.kv * n_out * 4, st));
   if (n > 0) {
