@@ -1,0 +1,76 @@
+"""The C-ABI library loads and exports every symbol include/virconv_hip.h declares (no compute calls: no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from virconv_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "virconv_hip.h")
+
+
+def header_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vc_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_expected_entry_points():
+    syms = header_symbols()
+    assert len(syms) >= 24
+    for must in ("vc_hash_build", "vc_subm_rulebook", "vc_spconv_mark_count", "vc_spconv_emit_pairs", "vc_conv_forward",
+                 "vc_conv_backward_input", "vc_conv_backward_weight", "vc_project_uv", "vc_gather_rows", "vc_to_dense",
+                 "vc_voxelize_mean", "vc_bn_stats"):
+        assert must in syms
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    path = build.build(force=False, verbose=False)
+    assert os.path.exists(path)
+    lib = ctypes.CDLL(path)
+    for s in header_symbols():
+        assert hasattr(lib, s), f"{s} declared in include/virconv_hip.h but not exported by {path}"
+
+
+def test_binding_table_covers_header_exactly():
+    assert sorted(_lib.SIGNATURES.keys()) == header_symbols()
+    lib = _lib.load()
+    assert lib.vc_version().decode().startswith("virconv_hip")
+
+
+def test_host_side_queries_and_argument_validation_without_gpu():
+    lib = _lib.load()
+    assert lib.vc_hash_workspace_bytes(1000) == 2048 * 12
+    assert lib.vc_spconv_workspace_bytes(1, 3, _lib.i32arr([41, 800, 704])) > 41 * 800 * 704 // 8
+    assert lib.vc_conv_backward_weight_workspace_bytes(1000, 27, 64, 64) >= 16 * 27 * 64 * 64 * 4
+    assert lib.vc_voxelize_workspace_bytes(1000, 5) > 0 and lib.vc_bn_workspace_bytes(1000, 64) > 0
+    # invalid arguments are rejected with a status code + message, never exit()/abort (include/virconv_hip.h)
+    st = lib.vc_hash_build(None, 10, 5, _lib.i32arr([1, 2, 3]), None, 0, None)
+    assert st == _lib.VC_EINVAL and b"ndim" in lib.vc_last_error()
+    st = lib.vc_conv_forward(None, 0, None, 10, 27, None, 8, 8, None, None)
+    assert st == _lib.VC_EINVAL
+    st = lib.vc_gather_rows(None, None, 7, 4, None, 0, None, None, None)
+    assert st == _lib.VC_EINVAL and b"multiple of 4" in lib.vc_last_error()
+    with pytest.raises(_lib.VirConvError):
+        _lib.check(st, "vc_gather_rows")
+
+
+def test_product_has_no_cpu_path():
+    import torch
+    from virconv_amd.backend_hip import HipBackend
+    be = HipBackend()
+    with pytest.raises(_lib.VirConvError, match="no CPU path"):
+        be.conv_forward(torch.zeros(4, 8), torch.zeros(8, 3, 3, 3, 8), torch.zeros((27, 4), dtype=torch.int32))
+    with pytest.raises(_lib.VirConvError, match="no CPU path"):
+        be.subm_rulebook(torch.zeros((4, 4), dtype=torch.int32), (4, 4, 4), (3, 3, 3), (1, 1, 1), False)
+
+
+def test_no_product_module_imports_the_oracle():
+    pkg = os.path.join(ROOT, "virconv_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"

@@ -1,0 +1,153 @@
+"""Host logic of the spconv facade, autograd wiring and the backbone, exercised on the CPU oracle operators."""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from helpers import GRID, MODEL_CFG, fill_parameters, golden_batch, load_golden
+from oracle import dense_ref
+from virconv_amd import ops, spconv, synth
+from virconv_amd.backbone import HeightCompression, VirConvL8x, layer_voxel_discard
+
+SHAPE = (9, 24, 20)
+
+
+def _tensor(seed=0, n=400, c=8, bs=2, dtype=torch.float32):
+    idx = synth.small_scene_indices(seed, n, SHAPE, bs)
+    g = torch.Generator().manual_seed(seed)
+    return spconv.SparseConvTensor(torch.randn((idx.shape[0], c), generator=g, dtype=dtype), torch.from_numpy(idx), SHAPE, bs)
+
+
+def test_spconv_names_and_weight_layout(oracle_backend):
+    m = spconv.SubMConv3d(8, 16, 3, bias=False, indice_key="k")
+    assert isinstance(m, spconv.conv.SparseConvolution) and isinstance(m, spconv.SparseModule)
+    assert tuple(m.weight.shape) == (16, 3, 3, 3, 8)  # (Cout, kz, ky, kx, Cin)
+    assert tuple(spconv.SparseConv3d(8, 8, (3, 1, 1), stride=(2, 1, 1)).weight.shape) == (8, 3, 1, 1, 8)
+    assert tuple(spconv.SubMConv2d(4, 4, 3).weight.shape) == (4, 3, 3, 4)
+    import virconv_amd.spconv.pytorch as sp2
+    assert sp2.SparseConvTensor is spconv.SparseConvTensor
+
+
+def test_indice_key_reuse_and_replace_feature(oracle_backend):
+    x = _tensor()
+    a = spconv.SubMConv3d(8, 8, 3, bias=False, indice_key="subm1")
+    b = spconv.SubMConv3d(8, 8, 3, bias=False, indice_key="subm1")
+    ya = a(x)
+    rb = x.indice_dict["subm1"]
+    yb = b(ya)
+    assert yb.indice_dict["subm1"] is rb and ya.indices is x.indices
+    z = ya.replace_feature(ya.features * 2)
+    assert z is not ya and z.indices is ya.indices and z.indice_dict is ya.indice_dict
+    # same key on a tensor with a different row count must not silently reuse
+    other = _tensor(seed=5, n=300)
+    other.indice_dict = x.indice_dict
+    with pytest.raises(AssertionError):
+        a(other)
+
+
+def test_strided_conv_then_inverse_conv_roundtrip_shapes(oracle_backend):
+    x = _tensor()
+    down = spconv.SparseConv3d(8, 16, 3, stride=2, padding=1, bias=False, indice_key="sp")
+    up = spconv.SparseInverseConv3d(16, 8, 3, indice_key="sp", bias=False)
+    y = down(x)
+    assert y.spatial_shape == [5, 12, 10] and y.features.shape[1] == 16
+    z = up(y)
+    assert z.spatial_shape == list(SHAPE) and torch.equal(z.indices, x.indices) and z.features.shape == (x.features.shape[0], 8)
+
+
+def test_sequential_applies_plain_modules_to_features(oracle_backend):
+    x = _tensor()
+    seq = spconv.SparseSequential(spconv.SubMConv3d(8, 8, 3, bias=False, indice_key="a"), nn.BatchNorm1d(8), nn.ReLU())
+    y = seq(x)
+    assert isinstance(y, spconv.SparseConvTensor) and (y.features >= 0).all() and len(seq) == 3 and seq[1].num_features == 8
+
+
+def test_autograd_matches_dense_autograd(oracle_backend):
+    """d/dx, d/dW of SubM -> strided conv through SparseConvFunction == autograd through the dense oracle (O3)."""
+    x = _tensor(dtype=torch.float64)
+    f = x.features.clone().requires_grad_(True)
+    c1 = spconv.SubMConv3d(8, 8, 3, bias=False, indice_key="a").double()
+    c2 = spconv.SparseConv3d(8, 4, 3, stride=2, padding=1, bias=False, indice_key="b").double()
+    y = c2(c1(x.replace_feature(f)))
+    g = torch.randn_like(y.features)
+    y.features.backward(g)
+    fd = x.features.clone().requires_grad_(True)
+    w1 = c1.weight.detach().clone().requires_grad_(True)
+    w2 = c2.weight.detach().clone().requires_grad_(True)
+    idx = x.indices.numpy()
+    h = dense_ref.subm_conv(fd, idx, SHAPE, 2, w1)
+    yd, oid, _ = dense_ref.sparse_conv(h, idx, SHAPE, 2, w2, 2, 1)
+    np.testing.assert_array_equal(y.indices.numpy(), oid)
+    yd.backward(g)
+    assert torch.allclose(y.features, yd, atol=1e-10)
+    assert torch.allclose(f.grad, fd.grad, atol=1e-10)
+    assert torch.allclose(c1.weight.grad, w1.grad, atol=1e-9) and torch.allclose(c2.weight.grad, w2.grad, atol=1e-9)
+
+
+def test_subm2d_duplicates_gradient_is_exact_transpose(oracle_backend):
+    rng = np.random.default_rng(0)
+    idx = np.stack([rng.integers(0, 2, 300), rng.integers(0, 10, 300), rng.integers(0, 8, 300)], 1).astype(np.int32)
+    f = torch.randn(300, 4, dtype=torch.float64, requires_grad=True)
+    conv = spconv.SubMConv2d(4, 4, 3, bias=False, indice_key="d").double()
+    y = conv(spconv.SparseConvTensor(f, torch.from_numpy(idx), (40, 30), 2))
+    assert y.indice_dict["d"].rep is not None
+    assert torch.autograd.gradcheck(lambda t: conv(spconv.SparseConvTensor(t, torch.from_numpy(idx), (40, 30), 2)).features, (f,),
+                                    eps=1e-6, atol=1e-6)
+
+
+def test_dense_and_height_compression(oracle_backend):
+    x = _tensor(c=4)
+    d = x.dense()
+    assert d.shape == (2, 4) + SHAPE
+    assert x.dense(channels_first=False).shape == (2,) + SHAPE + (4,)
+    idx = x.indices.long()
+    assert torch.equal(d[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]], x.features)
+    out = HeightCompression({"NUM_BEV_FEATURES": 36})({"encoded_spconv_tensor": x, "encoded_spconv_tensor_stride": 8})
+    assert out["spatial_features"].shape == (2, 4 * 9, 24, 20) and out["spatial_features_stride"] == 8
+
+
+def test_layer_discard_modes_and_injection(oracle_backend):
+    x = _tensor(c=8)
+    n = x.features.shape[0]
+    perm = torch.from_numpy(np.random.default_rng(0).permutation(n))
+    keep = perm[: int(n * 0.9)]
+    y = layer_voxel_discard(x, 0.1, keep)
+    assert torch.equal(y.features, x.features[keep]) and torch.equal(y.indices, x.indices[keep])
+    assert layer_voxel_discard(x, 0, None) is x
+    g = load_golden()
+    for mode, expect_fewer in (("spconv1_inplace", True), ("spconv2_noop", False)):
+        model = VirConvL8x(dict(MODEL_CFG, LAYER_DISCARD_MODE=mode), 8, GRID).train()
+        fill_parameters(model, 7)
+        with torch.no_grad():
+            out = model(golden_batch(g))
+        n1 = out["multi_scale_3d_features"]["x_conv1"].features.shape[0]
+        assert (n1 == int(g["voxel_features"].shape[0] * 0.9)) == expect_fewer
+
+
+def test_backbone_backward_runs_and_fills_all_grads(oracle_backend):
+    g = load_golden()
+    model = VirConvL8x(dict(MODEL_CFG), 8, GRID).train()
+    fill_parameters(model, 7)
+    out = model(golden_batch(g))
+    loss = out["encoded_spconv_tensor"].dense().square().mean() + sum(t.features.mean() for t in out["multi_scale_3d_features"].values())
+    loss.backward()
+    missing = [k for k, p in model.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+    assert not missing, missing
+    assert out["encoded_spconv_tensor_stride"] == 8 and out["multi_scale_3d_strides"]["x_conv3"] == 4
+    assert model.num_point_features == {"x_conv1": 16, "x_conv2": 32, "x_conv3": 64, "x_conv4": 64}
+
+
+def test_permutation_invariance_of_input_rows(oracle_backend):
+    """SubM3d -> strided conv: strided outputs come out in canonical (ascending) order whatever the input row order.
+    (The 2-D image-space branch is deliberately NOT invariant: rep(c) = highest row index)"""
+    x = _tensor(seed=3, n=500)
+    c1 = spconv.SubMConv3d(8, 8, 3, bias=False, indice_key="a")
+    c2 = spconv.SparseConv3d(8, 16, 3, stride=2, padding=1, bias=False, indice_key="b")
+    perm = torch.from_numpy(np.random.default_rng(1).permutation(x.features.shape[0]))
+    xp = spconv.SparseConvTensor(x.features[perm], x.indices[perm], SHAPE, 2)
+    with torch.no_grad():
+        y0, y1 = c2(c1(x)), c2(c1(xp))
+        s0, s1 = c1(x), c1(xp)
+    assert torch.equal(y0.indices, y1.indices)
+    assert torch.allclose(y0.features, y1.features, atol=1e-5)
+    assert torch.allclose(s0.features[perm], s1.features, atol=1e-5)  # SubM keeps the caller's row order

@@ -1,0 +1,229 @@
+"""Pins the CPU oracle: sparse restatement vs the independent dense conv oracle, hand-computable known answers,
+vectorised voxeliser vs the literal sequential loop, and (build container only) the reference's own python functions."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import refharness
+from oracle import dense_ref, geometry, sparse_ref
+from virconv_amd import data, synth
+
+SHAPE = (9, 24, 20)
+
+
+def _rand_case(seed, n=500, bs=2, cin=8, cout=16, ks=(3, 3, 3)):
+    rng = np.random.default_rng(seed)
+    idx = synth.small_scene_indices(seed, n, SHAPE, bs)
+    x = torch.from_numpy(rng.standard_normal((idx.shape[0], cin)))
+    w = torch.from_numpy(rng.standard_normal((cout,) + ks + (cin,)))
+    return idx, x, w
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_subm_sparse_equals_dense_fwd_bwd(seed):
+    idx, x, w = _rand_case(seed)
+    x.requires_grad_(True); w.requires_grad_(True)
+    pair = sparse_ref.subm_rulebook(idx, SHAPE, (3, 3, 3))
+    y = sparse_ref.conv_forward(x, w, pair)
+    yd = dense_ref.subm_conv(x, idx, SHAPE, 2, w)
+    assert torch.allclose(y, yd, atol=1e-10)
+    g = torch.randn_like(y)
+    dx, dw = sparse_ref.conv_backward(x.detach(), w.detach(), pair, g)
+    gx, gw = torch.autograd.grad(yd, (x, w), g)
+    assert torch.allclose(dx, gx, atol=1e-10) and torch.allclose(dw, gw, atol=1e-9)
+    ax, aw = torch.autograd.grad(y, (x, w), g)  # autograd through the sparse oracle itself
+    assert torch.allclose(ax, gx, atol=1e-10) and torch.allclose(aw, gw, atol=1e-9)
+
+
+@pytest.mark.parametrize("ks,st,pd", [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1)),
+                                      ((3, 1, 1), (2, 1, 1), (0, 0, 0)), ((3, 3, 3), (1, 1, 1), (0, 0, 0))])
+def test_strided_sparse_equals_dense(ks, st, pd):
+    idx, x, w = _rand_case(3, ks=ks)
+    x.requires_grad_(True); w.requires_grad_(True)
+    oi, osh, pf, pb = sparse_ref.sparse_rulebook(idx, SHAPE, 2, ks, st, pd)
+    y = sparse_ref.conv_forward(x, w, pf)
+    yd, oid, oshd = dense_ref.sparse_conv(x, idx, SHAPE, 2, w, st, pd)
+    assert tuple(osh) == tuple(oshd)
+    np.testing.assert_array_equal(oi, oid)  # ascending linear order (App-A.3)
+    assert np.all(np.diff(sparse_ref.linear_index(oi, osh)) > 0)
+    assert torch.allclose(y, yd, atol=1e-10)
+    g = torch.randn_like(y)
+    dx, dw = sparse_ref.conv_backward(x.detach(), w.detach(), pf, g)
+    gx, gw = torch.autograd.grad(yd, (x, w), g)
+    assert torch.allclose(dx, gx, atol=1e-10) and torch.allclose(dw, gw, atol=1e-9)
+    for k in range(pf.shape[0]):  # pair_bwd is the inverse map of pair_fwd
+        o = np.nonzero(pf[k] >= 0)[0]
+        np.testing.assert_array_equal(pb[k][pf[k][o]], o)
+
+
+def test_subm2d_sparse_equals_dense():
+    rng = np.random.default_rng(5)
+    shape = (40, 30)
+    idx = np.unique(np.stack([rng.integers(0, 2, 500), rng.integers(0, 40, 500), rng.integers(0, 30, 500)], 1), axis=0).astype(np.int32)
+    x = torch.from_numpy(rng.standard_normal((idx.shape[0], 8)))
+    w = torch.from_numpy(rng.standard_normal((8, 3, 3, 8)))
+    y = sparse_ref.conv_forward(x, w, sparse_ref.subm_rulebook(idx, shape, (3, 3)))
+    assert torch.allclose(y, dense_ref.subm_conv(x, idx, shape, 2, w), atol=1e-10)
+
+
+# ---------------------------------------------------------------------------------------------- known answers (by hand)
+def _w(cout, ks, cin, seed=0):
+    return torch.from_numpy(np.random.default_rng(seed).standard_normal((cout,) + ks + (cin,)))
+
+
+def test_kat_single_voxel_and_two_neighbours():
+    w = _w(2, (3, 3, 3), 3)
+    x = torch.tensor([[1.0, 2.0, 3.0]], dtype=torch.float64)
+    idx = np.array([[0, 4, 5, 6]], np.int32)
+    y = sparse_ref.conv_forward(x, w, sparse_ref.subm_rulebook(idx, SHAPE, (3, 3, 3)))
+    assert torch.allclose(y[0], w[:, 1, 1, 1, :] @ x[0])  # only the centre tap
+    # two x-neighbours: row0 at x=6, row1 at x=7.  out[0] sees row1 through kappa=(1,1,2); out[1] sees row0 through (1,1,0)
+    x2 = torch.tensor([[1.0, 2.0, 3.0], [-1.0, 0.5, 2.0]], dtype=torch.float64)
+    idx2 = np.array([[0, 4, 5, 6], [0, 4, 5, 7]], np.int32)
+    y2 = sparse_ref.conv_forward(x2, w, sparse_ref.subm_rulebook(idx2, SHAPE, (3, 3, 3)))
+    assert torch.allclose(y2[0], w[:, 1, 1, 1, :] @ x2[0] + w[:, 1, 1, 2, :] @ x2[1])
+    assert torch.allclose(y2[1], w[:, 1, 1, 1, :] @ x2[1] + w[:, 1, 1, 0, :] @ x2[0])
+
+
+def test_kat_boundary_and_batch_isolation():
+    pair = sparse_ref.subm_rulebook(np.array([[0, 0, 0, 0], [0, 8, 23, 19], [1, 0, 0, 1]], np.int32), SHAPE, (3, 3, 3))
+    assert (pair >= 0).sum() == 3  # corner voxels and a different-batch neighbour: centre taps only
+
+
+def test_kat_stride2_parity():
+    """k3 s2 p1 (App-A.3): an even coordinate feeds 1 output per axis, an odd one 2 -> 1 / 8 candidate outputs."""
+    for coord, n_out in (((0, 4, 6, 8)), 1), (((0, 3, 5, 7)), 8):
+        oi, osh, pf, pb = sparse_ref.sparse_rulebook(np.array([coord], np.int32), SHAPE, 1, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+        assert oi.shape[0] == n_out and tuple(osh) == (5, 12, 10)
+    # p even: q = p/2 through kappa = 1 (p = 2q - 1 + kappa)
+    oi, _, pf, _ = sparse_ref.sparse_rulebook(np.array([[0, 4, 6, 8]], np.int32), SHAPE, 1, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+    np.testing.assert_array_equal(oi, [[0, 2, 3, 4]])
+    assert pf[13, 0] == 0 and (pf >= 0).sum() == 1
+    # padding (0,1,1) of vir_conv4: z = 0..2 -> q_z = 0 only for p_z in {0,1,2}
+    oi, osh, _, _ = sparse_ref.sparse_rulebook(np.array([[0, 2, 6, 8]], np.int32), SHAPE, 1, (3, 3, 3), (2, 2, 2), (0, 1, 1))
+    assert tuple(osh) == (4, 12, 10) and oi[:, 1].tolist() == [0, 1]
+
+
+def test_kat_conv_out_z_only_kernel():
+    """conv_out: k(3,1,1) s(2,1,1) p0 -- mixes z only."""
+    w = _w(1, (3, 1, 1), 1)
+    idx = np.array([[0, 0, 3, 3], [0, 1, 3, 3], [0, 2, 3, 3], [0, 4, 3, 3]], np.int32)
+    x = torch.tensor([[1.0], [10.0], [100.0], [1000.0]], dtype=torch.float64)
+    oi, osh, pf, _ = sparse_ref.sparse_rulebook(idx, SHAPE, 1, (3, 1, 1), (2, 1, 1), (0, 0, 0))
+    assert tuple(osh) == (4, 24, 20)
+    np.testing.assert_array_equal(oi, [[0, 0, 3, 3], [0, 1, 3, 3], [0, 2, 3, 3]])
+    y = sparse_ref.conv_forward(x, w, pf)[:, 0]
+    wz = w[0, :, 0, 0, 0]
+    assert torch.allclose(y, torch.stack([wz[0] * 1 + wz[1] * 10 + wz[2] * 100, wz[0] * 100 + wz[2] * 1000, wz[0] * 1000]))
+
+
+def test_kat_duplicate_pixel_rule():
+    """App-A.5: neighbours see rep(c) = the highest row at that pixel; every row keeps its own centre tap."""
+    w = _w(1, (3, 3), 1)
+    idx = np.array([[0, 5, 5], [0, 5, 5], [0, 5, 6]], np.int32)  # rows 0,1 share a pixel; row 2 is its +v neighbour
+    x = torch.tensor([[1.0], [10.0], [100.0]], dtype=torch.float64)
+    pair = sparse_ref.subm_rulebook(idx, (40, 30), (3, 3))
+    y = sparse_ref.conv_forward(x, w, pair)[:, 0]
+    wc, wp, wm = w[0, 1, 1, 0], w[0, 1, 2, 0], w[0, 1, 0, 0]
+    assert torch.allclose(y, torch.stack([wc * 1 + wp * 100, wc * 10 + wp * 100, wc * 100 + wm * 10]))
+
+
+def test_to_dense_last_write_wins_and_layout():
+    f = torch.tensor([[1.0, 2.0], [3.0, 4.0], [5.0, 6.0]])
+    idx = np.array([[0, 1, 2, 3], [1, 0, 0, 0], [0, 1, 2, 3]], np.int32)
+    d = sparse_ref.to_dense(f, idx, (2, 3, 4), 2)
+    assert d.shape == (2, 2, 2, 3, 4)
+    assert d[0, :, 1, 2, 3].tolist() == [5.0, 6.0] and d[1, :, 0, 0, 0].tolist() == [3.0, 4.0] and d.sum() == 18.0
+
+
+# ---------------------------------------------------------------------------------------------- voxeliser / VFE / discards
+@pytest.mark.parametrize("max_voxels", [100000, 300])
+def test_voxelize_vectorised_equals_sequential(max_voxels):
+    fr = synth.make_frame(3, n_lidar=600, n_virtual=1200)
+    pts = np.concatenate([fr["points_lidar"], fr["points_virtual"]])
+    pts = np.concatenate([pts, pts[:300] + np.float32(0.001), np.array([[-5, 0, 0, 0, 0, 0, 0, 2]], np.float32)])
+    a = geometry.voxelize(pts, synth.VOXEL_SIZE, synth.POINT_CLOUD_RANGE, 5, max_voxels)
+    b = geometry.voxelize_sequential(pts, synth.VOXEL_SIZE, synth.POINT_CLOUD_RANGE, 5, max_voxels)
+    for u, v in zip(a, b):
+        np.testing.assert_array_equal(u, v)
+    assert a[2].max() > 1 and a[2].max() <= 5
+
+
+def test_voxelize_empty_and_mean_vfe():
+    v, c, n = geometry.voxelize(np.zeros((0, 8), np.float32), synth.VOXEL_SIZE, synth.POINT_CLOUD_RANGE, 5, 10)
+    assert v.shape == (0, 5, 8) and c.shape == (0, 3) and n.shape == (0,)
+    vox = np.zeros((1, 5, 8), np.float32)
+    vox[0, 0] = [1, 2, 3, 0.5, 0, 0, 0, 1]
+    vox[0, 1] = [3, 2, 1, 0.1, 0, 0, 0, 2]
+    f = geometry.mean_vfe(vox, np.array([2], np.int32), "max")
+    np.testing.assert_allclose(f[0], [2, 2, 2, 0.3, 0, 0, 0, 2])  # mean, flag channel <- max (mixed voxel -> LiDAR)
+
+
+def test_product_input_discard_equals_oracle_restatement():
+    fr = synth.make_frame(5, n_lidar=100, n_virtual=5000)
+    for bins in (2, 10):
+        a = data.input_point_discard(fr["points_virtual"], bins, 0.8, np.random.default_rng(1).permutation)
+        b = geometry.input_point_discard(fr["points_virtual"], bins, 0.8, np.random.default_rng(1).permutation)
+        np.testing.assert_array_equal(a, b)
+        assert a.shape[0] < fr["points_virtual"].shape[0]
+
+
+def test_layer_voxel_discard_oracle():
+    f = np.arange(40, dtype=np.float32).reshape(10, 4)
+    idx = np.arange(40, dtype=np.int32).reshape(10, 4)
+    perm = np.random.default_rng(0).permutation(10)
+    fo, io = geometry.layer_voxel_discard(f, idx, 0.15, perm)
+    assert fo.shape[0] == 8
+    np.testing.assert_array_equal(fo, f[perm[:8]])
+    np.testing.assert_array_equal(io, idx[perm[:8]])
+
+
+# ---------------------------------------------------------------------------------------------- against the reference's python
+needs_ref = pytest.mark.skipif(not refharness.available(), reason="/root/reference not present (GPU box)")
+
+
+@needs_ref
+def test_input_point_discard_equals_reference_function():
+    refharness.import_reference_backbone()
+    from pcdet.datasets.dataset import DatasetTemplate
+    obj = DatasetTemplate.__new__(DatasetTemplate)
+    fr = synth.make_frame(6, n_lidar=100, n_virtual=8000)
+    for bins in (2, 10):
+        np.random.seed(123)
+        ref = DatasetTemplate.input_point_discard(obj, fr["points_virtual"].copy(), bin_num=bins, rate=0.8)
+        np.random.seed(123)
+        ours = geometry.input_point_discard(fr["points_virtual"].copy(), bins, 0.8, np.random.permutation)
+        np.testing.assert_array_equal(ref, ours)
+
+
+@needs_ref
+@pytest.mark.parametrize("stride", [1, 2, 4, 8])
+def test_index2uv_equals_reference_torch_code(stride):
+    ref = refharness.import_reference_backbone()
+    from pcdet.datasets.augmentor.X_transform import X_TRANS
+    rng = np.random.default_rng(stride)
+    bs, n = 2, 3000
+    idx = np.stack([rng.integers(0, bs, n), rng.integers(0, 81 // stride, n), rng.integers(0, 1600 // stride, n),
+                    rng.integers(0, 1408 // stride, n)], 1).astype(np.int32)
+    calibs = [synth.default_calib() for _ in range(bs)]
+    aug = np.array([[0.3, 1.0, 1.02], [-0.5, 0.0, 0.97]], np.float32)
+    rc = [refharness.make_reference_calib(c) for c in calibs]
+    for tp in (aug, None):
+        uv_ref, _ = ref.index2uv(torch.from_numpy(idx), bs, rc, stride, X_TRANS(), None if tp is None else torch.from_numpy(tp.copy()))
+        uv, _ = geometry.index2uv(idx, bs, calibs, stride, tp)
+        mism = (uv_ref.numpy() != uv).any(axis=1).mean()
+        assert mism <= 1e-3, f"projection differs from the reference torch code on {mism:.4%} of rows"
+
+
+@needs_ref
+def test_mean_vfe_equals_reference_module():
+    refharness.import_reference_backbone()
+    from pcdet.models.backbones_3d.vfe.mean_vfe import MeanVFE
+    fr = synth.make_frame(8, n_lidar=500, n_virtual=800)
+    pts = np.concatenate([fr["points_lidar"], fr["points_virtual"]])
+    vox, c, num = geometry.voxelize(pts, synth.VOXEL_SIZE, synth.POINT_CLOUD_RANGE, 5, 40000)
+    m = MeanVFE({"MODEL": "max"}, 8)
+    out = m({"voxels": torch.from_numpy(vox), "voxel_num_points": torch.from_numpy(num)})["voxel_features"].numpy()
+    np.testing.assert_allclose(geometry.mean_vfe(vox, num, "max"), out, rtol=0, atol=1e-6)

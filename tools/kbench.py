@@ -1,0 +1,118 @@
+"""Kernel micro-benchmark: every conv layer shape of VirConv-L on a synthetic KITTI batch, one kernel at a time.
+
+    python tools/kbench.py [--bs 4] [--iters 20] [--only fwd|bwd|dw|all]
+
+For each layer: N_in, N_out, active pairs P, and per kernel (forward gather-GEMM, backward-input gather-GEMM,
+weight-gradient) the average HIP-event time, achieved algorithmic TFLOP/s (2*P*Cin*Cout / t) and the fraction of the
+157.3 TFLOP/s fp32-MFMA peak, plus algorithmic GB/s (SURVEY §8d byte formulas).  Used to iterate on kernel variants;
+bench.py remains the whole-step measurement.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+from virconv_amd import ops, synth  # noqa: E402
+
+PEAK = 157.3
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--bs", type=int, default=4)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="all")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    be = ops.get_backend()
+    batch = bench.make_batch(list(range(args.bs)), dev, training=True)
+    idx = batch["voxel_coords"].int()
+    shape = [int(v) for v in (np.asarray(synth.GRID_SIZE)[::-1] + [1, 0, 0])]
+    bs = args.bs
+    calib, trans = batch["calib"], batch["aug_param"]
+    g = torch.Generator(device="cpu").manual_seed(0)
+
+    layers = []  # (name, rulebook, cin, cout)
+    cur_idx, cur_shape = idx, shape
+    chans = [(8, 16), (16, 32), (32, 64), (64, 64)]
+    for stage, (cin, cout) in enumerate(chans):
+        stride = 2 ** stage
+        if stage > 0:
+            pad = (0, 1, 1) if stage == 3 else (1, 1, 1)
+            rb = ops.build_sparse_rulebook(cur_idx, cur_shape, bs, (3, 3, 3), (2, 2, 2), pad, 1)
+            layers.append((f"s{stage + 1}.down {cin}->{cout}", rb, cin, cout))
+            cur_idx, cur_shape = rb.out_indices, list(rb.out_shape)
+            c1 = cout
+        else:
+            c1 = cin
+        rb3 = ops.build_subm_rulebook(cur_idx, cur_shape, (3, 3, 3), 1, False)
+        layers.append((f"s{stage + 1}.d3_conv1 {c1}->{cout // 2}", rb3, c1, cout // 2))
+        layers.append((f"s{stage + 1}.d3_conv2 {cout // 2}->{cout // 2}", rb3, cout // 2, cout // 2))
+        uv = ops.project_uv(cur_idx, calib, trans, bs, stride)
+        rb2 = ops.build_subm_rulebook(uv, [1600, 600], (3, 3), 1, True)
+        layers.append((f"s{stage + 1}.d2_conv {cout // 2}->{cout // 2} (2D)", rb2, cout // 2, cout // 2))
+    rbo = ops.build_sparse_rulebook(cur_idx, cur_shape, bs, (3, 1, 1), (2, 1, 1), (0, 0, 0), 1)
+    layers.append(("conv_out 64->64", rbo, 64, 64))
+
+    print(f"{'layer':34s} {'N_in':>7s} {'N_out':>7s} {'P/N':>5s} | {'fwd us':>8s} {'TF':>6s} {'%pk':>5s} {'GB/s':>6s} | "
+          f"{'bwd us':>8s} {'TF':>6s} {'%pk':>5s} | {'dW us':>8s} {'TF':>6s} {'%pk':>5s}")
+    tot = {"fwd": 0.0, "bwd": 0.0, "dw": 0.0, "flops": 0.0}
+    for name, rb, cin, cout in layers:
+        kv = rb.kv
+        x = torch.randn((rb.n_in, cin), generator=g).to(dev)
+        w = (torch.randn((cout, kv, cin), generator=g) / np.sqrt(kv * cin)).to(dev).reshape((cout,) + tuple(rb.ksize) + (cin,))
+        dy = torch.randn((rb.n_out, cout), generator=g).to(dev)
+        pairs = int((rb.pair_fwd >= 0).sum().item())
+        flops = 2.0 * pairs * cin * cout
+        byts = 4.0 * (rb.n_in * cin + rb.n_out * cout + kv * cin * cout) + 4.0 * kv * rb.n_out
+        res = {}
+        if args.only in ("all", "fwd"):
+            res["fwd"] = timeit(lambda: be.conv_forward(x, w, rb.pair_fwd), args.iters)
+        if args.only in ("all", "bwd"):
+            if rb.kind == "subm":
+                res["bwd"] = timeit(lambda: be.conv_backward_input(dy, w, rb.pair_fwd, rb.n_in, True, rb.centre, rb.rep), args.iters)
+            else:
+                res["bwd"] = timeit(lambda: be.conv_backward_input(dy, w, rb.pair_bwd, rb.n_in, False), args.iters)
+        if args.only in ("all", "dw"):
+            res["dw"] = timeit(lambda: be.conv_backward_weight(x, dy, rb.pair_fwd, w.shape), args.iters)
+
+        def tf(us):
+            return flops / (us * 1e-6) / 1e12
+
+        f, b, d = res.get("fwd"), res.get("bwd"), res.get("dw")
+        line = f"{name:34s} {rb.n_in:7d} {rb.n_out:7d} {pairs / max(rb.n_out, 1):5.2f} | "
+        line += (f"{f:8.1f} {tf(f):6.2f} {100 * tf(f) / PEAK:5.1f} {byts / (f * 1e-6) / 1e9:6.0f} | " if f else " " * 34 + "| ")
+        line += (f"{b:8.1f} {tf(b):6.2f} {100 * tf(b) / PEAK:5.1f} | " if b else " " * 23 + "| ")
+        line += (f"{d:8.1f} {tf(d):6.2f} {100 * tf(d) / PEAK:5.1f}" if d else "")
+        print(line)
+        for k in ("fwd", "bwd", "dw"):
+            if res.get(k):
+                tot[k] += res[k]
+        tot["flops"] += flops
+    print(f"TOTAL  fwd {tot['fwd']:.0f} us  bwd-in {tot['bwd']:.0f} us  dW {tot['dw']:.0f} us   algorithmic GFLOP/pass {tot['flops'] / 1e9:.2f}"
+          f"  -> fwd {tot['flops'] / max(tot['fwd'], 1e-9) / 1e6:.1f} TF, all three {3 * tot['flops'] / max(tot['fwd'] + tot['bwd'] + tot['dw'], 1e-9) / 1e6:.1f} TF")
+
+
+if __name__ == "__main__":
+    main()

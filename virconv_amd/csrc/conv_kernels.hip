@@ -147,6 +147,7 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
                                                          const int32_t* __restrict__ tbl, int64_t n_out, int kv,
                                                          int64_t rows_per_block, float* __restrict__ partial) {
   constexpr int MT = (CI + 15) / 16, NT = (CO + 15) / 16;
+  constexpr int U = (MT + NT <= 4) ? 4 : 2;  // groups of 4 pairs gathered per iteration
   __shared__ int q_in[4][136];
   __shared__ int q_out[4][136];
   __shared__ float red[MT * 16 * NT * 16];
@@ -179,7 +180,27 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
     qlen += __popcll(m);
     __builtin_amdgcn_wave_barrier();
     const int ng = qlen >> 2;
-    for (int g = 0; g < ng; ++g) {
+    int g = 0;
+    // U groups (16 pairs) per iteration: all gathers of the chunk are issued before the first MFMA consumes them
+    for (; g + U <= ng; g += U) {
+      float a[U][MT], b[U][NT];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int pin = qi[(g + u) * 4 + q], pout = qo[(g + u) * 4 + q];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[u][mt] = (mt * 16 + i < CI) ? x[(int64_t)pin * CI + mt * 16 + i] : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[u][nt] = (nt * 16 + i < CO) ? dy[(int64_t)pout * CO + nt * 16 + i] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][mt], b[u][nt], acc[mt][nt], 0, 0, 0);
+    }
+    for (; g < ng; ++g) {
       const int pin = qi[g * 4 + q], pout = qo[g * 4 + q];
       float a[MT], b[NT];
 #pragma unroll
@@ -306,12 +327,22 @@ static int dispatch_ck(int ck, int cn, const float* src, const float* src_centre
   return VC_EINVAL;
 }
 
-static constexpr int kMaxSplit = 64;
+static constexpr int kMaxSplit = 256;
+static constexpr size_t kMaxPartialBytes = 24u << 20;
 
-static inline void bw_split(int64_t n_out, int& nsplit, int64_t& rows_per_block) {
-  int64_t want = cdiv(n_out, 4096);
+static inline int bw_max_split(int kv, int cin, int cout) {
+  size_t per = (size_t)kv * cin * cout * sizeof(float);
+  int m = (int)(kMaxPartialBytes / per);
+  if (m < 16) m = 16;
+  if (m > kMaxSplit) m = kMaxSplit;
+  return m;
+}
+
+static inline void bw_split(int64_t n_out, int kv, int cin, int cout, int& nsplit, int64_t& rows_per_block) {
+  int64_t want = cdiv(n_out, 1024);
+  const int cap = bw_max_split(kv, cin, cout);
   if (want < 1) want = 1;
-  if (want > kMaxSplit) want = kMaxSplit;
+  if (want > cap) want = cap;
   rows_per_block = cdiv(cdiv(n_out, want), 256) * 256;
   if (rows_per_block < 256) rows_per_block = 256;
   nsplit = (int)cdiv(n_out, rows_per_block);
@@ -323,7 +354,7 @@ static int launch_bw(const float* x, const float* dy, const int32_t* tbl, int64_
                      float* partial, hipStream_t st) {
   int nsplit;
   int64_t rpb;
-  bw_split(n_out, nsplit, rpb);
+  bw_split(n_out, kv, CI, CO, nsplit, rpb);
   hipLaunchKernelGGL((bwd_weight_kernel<CI, CO>), dim3(nsplit, kv), dim3(256), 0, st, x, dy, tbl, n_out, kv, rpb, partial);
   VC_CHECK_LAUNCH("bwd_weight_kernel");
   const int total = kv * CI * CO;
@@ -375,7 +406,7 @@ int vc_conv_backward_input(const float* dy, const float* dy_centre, int64_t n_sr
 size_t vc_conv_backward_weight_workspace_bytes(int64_t n_out, int kv, int cin, int cout) {
   (void)n_out;
   if (kv < 1 || cin < 1 || cout < 1) return 0;
-  return (size_t)kMaxSplit * kv * cin * cout * sizeof(float);
+  return (size_t)bw_max_split(kv, cin, cout) * kv * cin * cout * sizeof(float);
 }
 
 int vc_conv_backward_weight(const float* x, const float* dy, const int32_t* pair_fwd, int64_t n_out, int kv, int cin,
