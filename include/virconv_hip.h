@@ -44,6 +44,8 @@ typedef enum vc_status {
 
 const char* vc_version(void);
 const char* vc_last_error(void);
+/* developer switch for A/B measurements (tools/kbench.py): "conv_variant" = 1 | 2 */
+int vc_debug_set(const char* key, int value);
 
 /* ------------------------------------------------------------------------------------------------ K3 hash
  * Coordinate -> row hash (open addressing, 64-bit linearised key, duplicate rule rep(c) = max row; SURVEY

@@ -22,6 +22,7 @@ _P, _I64, _I, _SZ, _F = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_float
 SIGNATURES = {
     "vc_version": (C.c_char_p, []),
     "vc_last_error": (C.c_char_p, []),
+    "vc_debug_set": (_I, [C.c_char_p, _I]),
     "vc_hash_workspace_bytes": (_SZ, [_I64]),
     "vc_hash_build": (_I, [_P, _I64, _I, _P, _P, _SZ, _P]),
     "vc_subm_rulebook": (_I, [_P, _I64, _I, _P, _P, _P, _P, _SZ, _P, _P, _P]),

@@ -138,6 +138,216 @@ __global__ void __launch_bounds__(256) gather_gemm_kernel(const float* __restric
     }
 }
 
+// --------------------------------------------------------------------------------------------- K6/K7 v2 (pipelined)
+// Same math and the same fixed accumulation order as gather_gemm_kernel, restructured so that the matrix pipe is not
+// parked behind dependent loads:
+//   * the block's (KV x 128) slice of the pair table is staged into LDS once (one coalesced burst, one latency) and the
+//     per-wave / per-block activity of every kernel offset is reduced to two 32-bit masks (ballot + LDS atomicOr)
+//   * the block walks ONLY the offsets active somewhere in its 128 rows; for each, the weight slice W_k is staged once
+//     per block into LDS in MFMA-fragment order (4x fewer VMEM instructions than per-wave loads; conflict-free
+//     ds_read_b128), double buffered
+//   * gathers go through a buffer descriptor: row index -1 wraps to an out-of-range offset and the hardware returns
+//     zeros, so every load is UNCONDITIONAL (no exec-masked branches => hipcc keeps counted vmcnt waits) and the
+//     gathers + W_k loads of the NEXT active offset are in flight under the MFMAs of the current one
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+template <int V>
+struct BufLoad;
+template <>
+struct BufLoad<4> {
+  static __device__ __forceinline__ void ld(__amdgpu_buffer_rsrc_t r, unsigned off, float* o) {
+    i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    o[0] = __int_as_float(v.x); o[1] = __int_as_float(v.y); o[2] = __int_as_float(v.z); o[3] = __int_as_float(v.w);
+  }
+};
+template <>
+struct BufLoad<2> {
+  static __device__ __forceinline__ void ld(__amdgpu_buffer_rsrc_t r, unsigned off, float* o) {
+    i32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+    o[0] = __int_as_float(v.x); o[1] = __int_as_float(v.y);
+  }
+};
+template <>
+struct BufLoad<1> {
+  static __device__ __forceinline__ void ld(__amdgpu_buffer_rsrc_t r, unsigned off, float* o) {
+    o[0] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+  }
+};
+
+template <int CK, int CN, bool BWD>
+__global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __restrict__ src,
+                                                             const float* __restrict__ src_centre, int64_t n_src,
+                                                             const int32_t* __restrict__ tbl,
+                                                             const float* __restrict__ w, float* __restrict__ out,
+                                                             const int32_t* __restrict__ rep, int64_t n_out, int kv,
+                                                             int centre, int mirror) {
+  constexpr int V = (CK >= 16) ? 4 : CK / 4;
+  constexpr int NCH = CK / (4 * V);
+  constexpr int NT = (CN + 15) / 16;
+  constexpr int RT = 2, TM = 128;
+  constexpr int NFRAG = NCH * NT * 64;                   // fragment vectors (V floats each) of one W_k image
+  constexpr int BF = NFRAG * V;
+  constexpr int BLD = (NFRAG + 255) / 256;               // fragment vectors staged per thread
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* s_b = reinterpret_cast<float*>(smem);           // [2][BF]
+  int* s_idx = reinterpret_cast<int*>(smem + 2 * BF * sizeof(float));  // [kv][TM]
+  unsigned* s_mask = reinterpret_cast<unsigned*>(s_idx + kv * TM);     // [4] per-wave offset masks
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int64_t brow0 = (int64_t)blockIdx.x * TM;
+
+  const __amdgpu_buffer_rsrc_t rs_src =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)(n_src * CK * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_ctr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(src_centre ? src_centre : src), 0, (int)(n_src * CK * 4), 0x00020000);
+
+  if (tid < 4) s_mask[tid] = 0u;
+  __syncthreads();
+  {  // ---- phase 0: stage the pair-table slice; thread handles row r of offsets k0, k0+2, ...
+    const int r = tid & (TM - 1);
+    const int64_t row = brow0 + r;
+    const bool inb = row < n_out;
+    const bool centre_only = (rep != nullptr) && inb && (rep[row] != (int32_t)row);
+    for (int k = tid >> 7; k < kv; k += 2) {
+      int v = inb ? tbl[(int64_t)k * n_out + row] : -1;
+      if (centre_only && k != centre) v = -1;
+      s_idx[k * TM + r] = v;
+      const unsigned long long m = __ballot(v >= 0);   // 64 consecutive rows = two compute waves
+      if (lane == 0) {
+        const int cw = (wave & 1) * 2;
+        if ((unsigned)m) atomicOr(&s_mask[cw], 1u << k);
+        if ((unsigned)(m >> 32)) atomicOr(&s_mask[cw + 1], 1u << k);
+      }
+    }
+  }
+  __syncthreads();
+  unsigned bmask = s_mask[0] | s_mask[1] | s_mask[2] | s_mask[3];
+  bmask = (unsigned)__builtin_amdgcn_readfirstlane((int)bmask);
+
+  f32x4 acc[RT][NT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float breg[BLD][V];
+  float a_cur[RT][NCH][V], a_nxt[RT][NCH][V];
+  int act_cur[RT], act_nxt[RT];
+
+#define VC_LOAD_B(K)                                                                               \
+  do {                                                                                             \
+    const int kw_ = mirror ? (kv - 1 - (K)) : (K);                                                 \
+    _Pragma("unroll") for (int u = 0; u < BLD; ++u) {                                              \
+      const int f = tid + u * 256;                                                                 \
+      if (NFRAG % 256 == 0 || f < NFRAG) {                                                         \
+        const int fl = f & 63, nt_ = (f >> 6) % NT, ch_ = (f >> 6) / NT;                           \
+        const int n_ = nt_ * 16 + (fl & 15), kk0 = ch_ * 4 * V + (fl >> 4) * V;                    \
+        if (CN % 16 == 0 || n_ < CN) {                                                             \
+          if (!BWD) {                                                                              \
+            VecLoad<V>::ld(w + ((int64_t)n_ * kv + kw_) * CK + kk0, breg[u]);                      \
+          } else {                                                                                 \
+            _Pragma("unroll") for (int j = 0; j < V; ++j)                                          \
+                breg[u][j] = w[((int64_t)(kk0 + j) * kv + kw_) * CN + n_];                         \
+          }                                                                                        \
+        } else {                                                                                   \
+          _Pragma("unroll") for (int j = 0; j < V; ++j) breg[u][j] = 0.f;                          \
+        }                                                                                          \
+      }                                                                                            \
+    }                                                                                              \
+  } while (0)
+
+#define VC_STORE_B(BUF)                                                                            \
+  do {                                                                                             \
+    _Pragma("unroll") for (int u = 0; u < BLD; ++u) {                                              \
+      const int f = tid + u * 256;                                                                 \
+      if (NFRAG % 256 == 0 || f < NFRAG) {                                                         \
+        _Pragma("unroll") for (int j = 0; j < V; ++j) s_b[(BUF) * BF + f * V + j] = breg[u][j];    \
+      }                                                                                            \
+    }                                                                                              \
+  } while (0)
+
+#define VC_GATHER_A(K, A, ACT)                                                                     \
+  do {                                                                                             \
+    const __amdgpu_buffer_rsrc_t rs_ = ((K) == centre) ? rs_ctr : rs_src;                          \
+    _Pragma("unroll") for (int t = 0; t < RT; ++t) {                                               \
+      const int id = s_idx[(K) * TM + wave * (RT * 16) + t * 16 + i];                              \
+      ACT[t] = __builtin_amdgcn_readfirstlane((int)(__ballot(id >= 0) != 0ULL));                   \
+      const unsigned base = (unsigned)id * (unsigned)(CK * 4) + (unsigned)(q * V * 4);             \
+      _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
+          BufLoad<V>::ld(rs_, base + (unsigned)(ch * 4 * V * 4), A[t][ch]);                        \
+    }                                                                                              \
+  } while (0)
+
+  // Software pipeline.  Loads of offset n+1 (W slice -> breg, gathers -> a_nxt) are issued before the MFMAs of offset n;
+  // they are consumed (LDS store / register rotate) at the TOP of the next iteration, so the MFMAs only ever read
+  // registers with no load pending and hipcc emits no vmcnt wait in front of them.
+  if (bmask != 0u) {
+    int knext = __ffs((int)bmask) - 1;
+    bmask &= bmask - 1;
+    VC_LOAD_B(knext);
+    VC_GATHER_A(knext, a_nxt, act_nxt);
+    int buf = 0;
+    for (;;) {
+      VC_STORE_B(buf);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        act_cur[t] = act_nxt[t];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+          for (int j = 0; j < V; ++j) a_cur[t][ch][j] = a_nxt[t][ch][j];
+      }
+      __syncthreads();
+      knext = bmask ? (__ffs((int)bmask) - 1) : -1;
+      bmask &= bmask - 1;
+      if (knext >= 0) {   // block-uniform (scalar) branch
+        VC_LOAD_B(knext);
+        VC_GATHER_A(knext, a_nxt, act_nxt);
+      }
+      {
+        const float* __restrict__ B = s_b + buf * BF;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+          float b[NT][V];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) VecLoad<V>::ld(B + ((ch * NT + nt) * 64 + lane) * V, b[nt]);
+#pragma unroll
+          for (int t = 0; t < RT; ++t) {
+            if (act_cur[t]) {  // scalar
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < V; ++j)
+                  acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t][ch][j], b[nt][j], acc[t][nt], 0, 0, 0);
+            }
+          }
+        }
+      }
+      if (knext < 0) break;
+      buf ^= 1;
+    }
+  }
+#undef VC_LOAD_B
+#undef VC_STORE_B
+#undef VC_GATHER_A
+
+  const int64_t row0 = brow0 + wave * (RT * 16);
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 16 + i;
+      if (n >= CN) continue;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int64_t r = row0 + t * 16 + q * 4 + reg;
+        if (r < n_out) out[r * CN + n] = acc[t][nt][reg];
+      }
+    }
+}
+
 // --------------------------------------------------------------------------------------------- K8 weight gradient
 // grid (nsplit, kv); each block owns offset k = blockIdx.y and a contiguous range of output rows.  Each wave scans its
 // rows 64 at a time, ballot/prefix-compacts the active (in, out) pairs into an LDS queue, and consumes the queue four
@@ -288,11 +498,22 @@ __global__ void __launch_bounds__(256) group_sum_kernel(const float* __restrict_
 
 // --------------------------------------------------------------------------------------------- dispatch
 static constexpr int kRT = 2;  // 32 rows per wave, 128 rows per 256-thread block
+int g_conv_variant = 2;        // 1 = gather_gemm_kernel (per-wave loads), 2 = gather_gemm_v2_kernel (LDS-staged, pipelined)
 
 template <int CK, int CN, bool BWD>
-static int launch_gg(const float* src, const float* src_centre, const int32_t* tbl, const float* w, float* out,
-                     const int32_t* rep, int64_t n_out, int kv, int centre, int mirror, hipStream_t st) {
+static int launch_gg(const float* src, const float* src_centre, int64_t n_src, const int32_t* tbl, const float* w,
+                     float* out, const int32_t* rep, int64_t n_out, int kv, int centre, int mirror, hipStream_t st) {
   const int64_t rows_per_block = 4 * kRT * 16;
+  if (g_conv_variant == 2 && kv <= 32 && n_src * CK * 4 < (1LL << 31)) {
+    constexpr int V = (CK >= 16) ? 4 : CK / 4;
+    constexpr int NCH = CK / (4 * V);
+    constexpr int NT = (CN + 15) / 16;
+    const size_t lds = (size_t)2 * NCH * NT * 64 * V * sizeof(float) + (size_t)kv * 128 * sizeof(int) + 16;
+    hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD>), dim3((unsigned)cdiv(n_out, 128)), dim3(256), lds, st, src,
+                       src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror);
+    VC_CHECK_LAUNCH("gather_gemm_v2_kernel");
+    return VC_OK;
+  }
   hipLaunchKernelGGL((gather_gemm_kernel<CK, CN, BWD, kRT>), dim3((unsigned)cdiv(n_out, rows_per_block)), dim3(256), 0,
                      st, src, src_centre, tbl, w, out, rep, n_out, kv, centre, mirror);
   VC_CHECK_LAUNCH("gather_gemm_kernel");
@@ -300,28 +521,28 @@ static int launch_gg(const float* src, const float* src_centre, const int32_t* t
 }
 
 template <int CK, bool BWD>
-static int dispatch_cn(int cn, const float* src, const float* src_centre, const int32_t* tbl, const float* w, float* out,
+static int dispatch_cn(int cn, const float* src, const float* src_centre, int64_t n_src, const int32_t* tbl, const float* w, float* out,
                        const int32_t* rep, int64_t n_out, int kv, int centre, int mirror, hipStream_t st) {
   switch (cn) {
-    case 4: return launch_gg<CK, 4, BWD>(src, src_centre, tbl, w, out, rep, n_out, kv, centre, mirror, st);
-    case 8: return launch_gg<CK, 8, BWD>(src, src_centre, tbl, w, out, rep, n_out, kv, centre, mirror, st);
-    case 16: return launch_gg<CK, 16, BWD>(src, src_centre, tbl, w, out, rep, n_out, kv, centre, mirror, st);
-    case 32: return launch_gg<CK, 32, BWD>(src, src_centre, tbl, w, out, rep, n_out, kv, centre, mirror, st);
-    case 64: return launch_gg<CK, 64, BWD>(src, src_centre, tbl, w, out, rep, n_out, kv, centre, mirror, st);
+    case 4: return launch_gg<CK, 4, BWD>(src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror, st);
+    case 8: return launch_gg<CK, 8, BWD>(src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror, st);
+    case 16: return launch_gg<CK, 16, BWD>(src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror, st);
+    case 32: return launch_gg<CK, 32, BWD>(src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror, st);
+    case 64: return launch_gg<CK, 64, BWD>(src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror, st);
   }
   set_error("gather-GEMM: unsupported output channel count %d (supported: 4,8,16,32,64)", cn);
   return VC_EINVAL;
 }
 
 template <bool BWD>
-static int dispatch_ck(int ck, int cn, const float* src, const float* src_centre, const int32_t* tbl, const float* w,
+static int dispatch_ck(int ck, int cn, const float* src, const float* src_centre, int64_t n_src, const int32_t* tbl, const float* w,
                        float* out, const int32_t* rep, int64_t n_out, int kv, int centre, int mirror, hipStream_t st) {
   switch (ck) {
-    case 4: return dispatch_cn<4, BWD>(cn, src, src_centre, tbl, w, out, rep, n_out, kv, centre, mirror, st);
-    case 8: return dispatch_cn<8, BWD>(cn, src, src_centre, tbl, w, out, rep, n_out, kv, centre, mirror, st);
-    case 16: return dispatch_cn<16, BWD>(cn, src, src_centre, tbl, w, out, rep, n_out, kv, centre, mirror, st);
-    case 32: return dispatch_cn<32, BWD>(cn, src, src_centre, tbl, w, out, rep, n_out, kv, centre, mirror, st);
-    case 64: return dispatch_cn<64, BWD>(cn, src, src_centre, tbl, w, out, rep, n_out, kv, centre, mirror, st);
+    case 4: return dispatch_cn<4, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror, st);
+    case 8: return dispatch_cn<8, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror, st);
+    case 16: return dispatch_cn<16, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror, st);
+    case 32: return dispatch_cn<32, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror, st);
+    case 64: return dispatch_cn<64, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror, st);
   }
   set_error("gather-GEMM: unsupported source channel count %d (supported: 4,8,16,32,64)", ck);
   return VC_EINVAL;
@@ -384,12 +605,18 @@ using namespace vc;
 
 extern "C" {
 
+int vc_debug_set(const char* key, int value) {
+  if (key && !strcmp(key, "conv_variant")) { g_conv_variant = value; return VC_OK; }
+  set_error("vc_debug_set: unknown key");
+  return VC_EINVAL;
+}
+
 int vc_conv_forward(const float* x, int64_t n_in, const int32_t* pair_fwd, int64_t n_out, int kv, const float* weight,
                     int cin, int cout, float* y, void* stream) {
   VC_REQUIRE(n_in >= 0 && n_out >= 0 && kv >= 1 && weight, "vc_conv_forward: null/invalid argument");
   if (n_out == 0) return VC_OK;
   VC_REQUIRE(pair_fwd && y && (x || n_in == 0), "vc_conv_forward: null argument");
-  return dispatch_ck<false>(cin, cout, x, nullptr, pair_fwd, weight, y, nullptr, n_out, kv, -1, 0, (hipStream_t)stream);
+  return dispatch_ck<false>(cin, cout, x, nullptr, n_in, pair_fwd, weight, y, nullptr, n_out, kv, -1, 0, (hipStream_t)stream);
 }
 
 int vc_conv_backward_input(const float* dy, const float* dy_centre, int64_t n_src, const int32_t* tbl, int64_t n_in,
@@ -399,7 +626,7 @@ int vc_conv_backward_input(const float* dy, const float* dy_centre, int64_t n_sr
   if (n_in == 0) return VC_OK;
   VC_REQUIRE(tbl && dx && (dy || n_src == 0), "vc_conv_backward_input: null argument");
   VC_REQUIRE(centre >= -1 && centre < kv, "vc_conv_backward_input: centre out of range");
-  return dispatch_ck<true>(cout, cin, dy, dy_centre, tbl, weight, dx, rep, n_in, kv, centre, mirror ? 1 : 0,
+  return dispatch_ck<true>(cout, cin, dy, dy_centre, n_src, tbl, weight, dx, rep, n_in, kv, centre, mirror ? 1 : 0,
                            (hipStream_t)stream);
 }
 
