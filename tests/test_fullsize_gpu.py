@@ -1,0 +1,125 @@
+"""KITTI-scale (BASELINE.json full sizes) GPU tests: size-independent properties + oracle parity where the oracle finishes
+in seconds (one full synthetic frame: 20k LiDAR + 60k virtual points -> ~35k voxels)."""
+import numpy as np
+import pytest
+import torch
+
+import bench
+from oracle import geometry, sparse_ref
+from oracle.backend import OracleBackend
+from virconv_amd import data, ops, synth
+from virconv_amd.backbone import VirConvL8x
+
+pytestmark = pytest.mark.gpu
+SHAPE0 = [81, 1600, 1408]
+
+
+@pytest.fixture(scope="module")
+def frame_batch():
+    return bench.make_batch([0, 1], torch.device("cuda", 0), training=True)
+
+
+def test_fullsize_voxelizer_bit_exact(hip_backend):
+    fr = synth.make_frame(0)
+    pts = data.prepare_frame(fr["points_lidar"], fr["points_virtual"], True, rng=np.random.default_rng(10_000))
+    f, c, n = hip_backend.voxelize_mean(torch.from_numpy(pts).cuda(), synth.POINT_CLOUD_RANGE, synth.VOXEL_SIZE, 5, 40000, True)
+    vox, cref, nref = geometry.voxelize(pts, synth.VOXEL_SIZE, synth.POINT_CLOUD_RANGE, 5, 40000)
+    assert 20000 < cref.shape[0] <= 40000
+    np.testing.assert_array_equal(c.cpu().numpy(), cref)
+    np.testing.assert_array_equal(n.cpu().numpy(), nref)
+    np.testing.assert_allclose(f.cpu().numpy(), geometry.mean_vfe(vox, nref, "max"), rtol=0, atol=1e-6)
+
+
+def test_fullsize_rulebook_properties(hip_backend, frame_batch):
+    idx = frame_batch["voxel_coords"].int()
+    n = idx.shape[0]
+    pair, _ = hip_backend.subm_rulebook(idx, SHAPE0, (3, 3, 3), (1, 1, 1), want_rep=False)
+    kv = pair.shape[0]
+    ar = torch.arange(n, device="cuda", dtype=torch.int32)
+    assert torch.equal(pair[13], ar)  # centre tap is the identity
+    for k in (0, 5, 12):  # mirror symmetry on unique coordinates: pair[KV-1-k][pair[k][i]] == i
+        v = pair[k]
+        sel = v >= 0
+        assert torch.equal(pair[kv - 1 - k][v[sel].long()], ar[sel])
+    oi, osh, pf, pb = hip_backend.sparse_rulebook(idx, SHAPE0, 2, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1))
+    assert tuple(osh) == (41, 800, 704)
+    lin = ((oi[:, 0].long() * 41 + oi[:, 1]) * 800 + oi[:, 2]) * 704 + oi[:, 3]
+    assert bool((lin[1:] > lin[:-1]).all())  # strictly ascending => sorted and unique
+    m = oi.shape[0]
+    am = torch.arange(m, device="cuda", dtype=torch.int32)
+    for k in range(0, 27, 4):  # pair_bwd is the inverse map of pair_fwd
+        v = pf[k]
+        sel = v >= 0
+        assert torch.equal(pb[k][v[sel].long()], am[sel])
+    assert int((pf >= 0).sum()) == int((pb >= 0).sum())
+    # every input row reaches at least one output (k3 s2 p1 covers every coordinate)
+    assert bool(((pb >= 0).sum(0) >= 1).all())
+    # against the oracle (bit-exact, full size)
+    roi, rosh, rpf, rpb = sparse_ref.sparse_rulebook(idx.cpu().numpy(), SHAPE0, 2, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+    np.testing.assert_array_equal(oi.cpu().numpy(), roi)
+    np.testing.assert_array_equal(pf.cpu().numpy(), rpf)
+
+
+def test_fullsize_conv_linearity_determinism_and_oracle(hip_backend, frame_batch):
+    idx = frame_batch["voxel_coords"].int()
+    oi, osh, pf, pb = hip_backend.sparse_rulebook(idx, SHAPE0, 2, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1))
+    pair, _ = hip_backend.subm_rulebook(oi, list(osh), (3, 3, 3), (1, 1, 1), want_rep=False)
+    n = oi.shape[0]
+    g = torch.Generator().manual_seed(0)
+    x1 = torch.randn((n, 32), generator=g).cuda()
+    x2 = torch.randn((n, 32), generator=g).cuda()
+    w = (torch.randn((16, 3, 3, 3, 32), generator=g) / 30).cuda()
+    y1, y2 = hip_backend.conv_forward(x1, w, pair), hip_backend.conv_forward(x2, w, pair)
+    y12 = hip_backend.conv_forward(2.5 * x1 + x2, w, pair)
+    assert float((y12 - (2.5 * y1 + y2)).abs().max()) < 1e-4 * float(y12.abs().max())
+    assert torch.equal(y1, hip_backend.conv_forward(x1, w, pair))  # run-to-run bitwise stable
+    yref = sparse_ref.conv_forward(x1.cpu().double(), w.cpu().double(), pair.cpu().numpy())
+    assert float((y1.cpu().double() - yref).abs().max()) < 1e-4 * max(1.0, float(yref.abs().max()))
+    # adjoint identity <conv(x), g> == <x, conv^T(g)>  (backward-input is the exact transpose)
+    gy = torch.randn((n, 16), generator=g).cuda()
+    dx = hip_backend.conv_backward_input(gy, w, pair, n, mirror=True)
+    lhs, rhs = float((y1.double() * gy.double()).sum()), float((x1.double() * dx.double()).sum())
+    assert abs(lhs - rhs) < 1e-5 * max(abs(lhs), 1.0)
+    # and <conv_W(x), g> is linear in W: dW is its gradient
+    dw = hip_backend.conv_backward_weight(x1, gy, pair, w.shape)
+    assert abs(float((dw.double() * w.double()).sum()) - lhs) < 1e-5 * max(abs(lhs), 1.0)
+
+
+def test_fullsize_dense_roundtrip(hip_backend, frame_batch):
+    idx = frame_batch["voxel_coords"].int()
+    oi, osh, _, _ = hip_backend.sparse_rulebook(idx, SHAPE0, 2, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1))
+    oi2, osh2, _, _ = hip_backend.sparse_rulebook(oi, list(osh), 2, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1))
+    f = torch.randn((oi2.shape[0], 16)).cuda()
+    d = hip_backend.to_dense(f, oi2, osh2, 2)
+    assert d.shape == (2, 16) + tuple(osh2) and int((d != 0).sum()) == int((f != 0).sum())
+    assert torch.equal(hip_backend.from_dense(d, oi2, osh2, 2), f)
+
+
+def test_fullsize_backbone_eval_vs_oracle_and_deterministic(hip_backend, frame_batch):
+    """Whole VirConv-L forward on one full frame: HIP vs the CPU oracle (indices bit-exact, features 1e-4)."""
+    b1 = bench.make_batch([0], torch.device("cuda", 0), training=False)
+    torch.manual_seed(1)
+    model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).cuda().eval()
+
+    def run(m, batch):
+        bd = dict(batch)
+        bd["voxel_features"] = batch["voxel_features"].clone()
+        with torch.no_grad():
+            return m(bd)
+
+    o1, o2 = run(model, b1), run(model, b1)
+    for name in ("x_conv1", "x_conv2", "x_conv3", "x_conv4"):
+        assert torch.equal(o1["multi_scale_3d_features"][name].features, o2["multi_scale_3d_features"][name].features)
+    cpu_model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).eval()
+    cpu_model.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+    bc = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in b1.items()}
+    with ops.use_backend(OracleBackend()):
+        oc = run(cpu_model, bc)
+    for name in ("x_conv1", "x_conv2", "x_conv3", "x_conv4"):
+        a, b = o1["multi_scale_3d_features"][name], oc["multi_scale_3d_features"][name]
+        assert torch.equal(a.indices.cpu(), b.indices), name
+        err = float((a.features.cpu() - b.features).abs().max())
+        assert err < 1e-4 * max(1.0, float(b.features.abs().max())), (name, err)
+    a, b = o1["encoded_spconv_tensor"], oc["encoded_spconv_tensor"]
+    assert torch.equal(a.indices.cpu(), b.indices)
+    assert float((a.features.cpu() - b.features).abs().max()) < 1e-4 * max(1.0, float(b.features.abs().max()))

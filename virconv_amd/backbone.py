@@ -213,6 +213,144 @@ class VirConvL8x(nn.Module):
         return batch_dict
 
 
+class VirConv8x(nn.Module):
+    """VirConv-T / VirConv-S backbone (spconv_backbone.py:232-535): a LiDAR stream (conv_input, conv1..4, conv_out with
+    shared rulebooks per stage) and, with ``MM: True``, the virtual-point stream of four NRConvBlocks.
+
+    Training: the LiDAR stream runs once per transformed frame (:362-407).  Eval: the ``rot_num`` frames are
+    concatenated along x into ONE sparse tensor of width 4*W (:409-442) so a single set of launches serves all frames,
+    then split back with ``decompose_tensor`` (:314-337, strict ``begin < x < end`` -- the x == begin voxels of each slab
+    are dropped, reference quirk kept; 64-bit coordinate keys make the 7.3e8-cell tensor safe at any batch size).
+    """
+
+    def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.return_num_features_as_dict = _cfg_get(model_cfg, "RETURN_NUM_FEATURES_AS_DICT", False)
+        self.out_features = _cfg_get(model_cfg, "OUT_FEATURES", 64)
+        self.layer_discard_rate = _cfg_get(model_cfg, "LAYER_DISCARD_RATE", 0.0)
+        self.layer_discard_mode = _cfg_get(model_cfg, "LAYER_DISCARD_MODE", "spconv1_inplace")
+        assert self.layer_discard_mode in ("spconv1_inplace", "spconv2_noop")
+        self.mm = bool(_cfg_get(model_cfg, "MM", False))
+        nf = _cfg_get(model_cfg, "NUM_FILTERS")
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        self.sparse_shape = [int(v) for v in (np.asarray(grid_size)[::-1] + [1, 0, 0])]
+        block = post_act_block
+
+        self.conv_input = spconv.SparseSequential(
+            spconv.SubMConv3d(input_channels, nf[0], 3, padding=1, bias=False, indice_key="subm1"),
+            norm_fn(nf[0]), nn.ReLU())
+        self.conv1 = spconv.SparseSequential(block(nf[0], nf[0], 3, norm_fn=norm_fn, padding=1, indice_key="subm1"))
+        self.conv2 = spconv.SparseSequential(
+            block(nf[0], nf[1], 3, norm_fn=norm_fn, stride=2, padding=1, indice_key="spconv2", conv_type="spconv"),
+            block(nf[1], nf[1], 3, norm_fn=norm_fn, padding=1, indice_key="subm2"),
+            block(nf[1], nf[1], 3, norm_fn=norm_fn, padding=1, indice_key="subm2"))
+        self.conv3 = spconv.SparseSequential(
+            block(nf[1], nf[2], 3, norm_fn=norm_fn, stride=2, padding=1, indice_key="spconv3", conv_type="spconv"),
+            block(nf[2], nf[2], 3, norm_fn=norm_fn, padding=1, indice_key="subm3"),
+            block(nf[2], nf[2], 3, norm_fn=norm_fn, padding=1, indice_key="subm3"))
+        self.conv4 = spconv.SparseSequential(
+            block(nf[2], nf[3], 3, norm_fn=norm_fn, stride=2, padding=(0, 1, 1), indice_key="spconv4", conv_type="spconv"),
+            block(nf[3], nf[3], 3, norm_fn=norm_fn, padding=1, indice_key="subm4"),
+            block(nf[3], nf[3], 3, norm_fn=norm_fn, padding=1, indice_key="subm4"))
+        last_pad = _cfg_get(model_cfg, "last_pad", 0)
+        self.conv_out = spconv.SparseSequential(
+            spconv.SparseConv3d(nf[3], self.out_features, (3, 1, 1), stride=(2, 1, 1), padding=last_pad, bias=False,
+                                indice_key="spconv_down2"),
+            norm_fn(self.out_features), nn.ReLU())
+        if self.mm:
+            self.vir_conv1 = NRConvBlock(input_channels, nf[0], stride=1, indice_key="vir1")
+            self.vir_conv2 = NRConvBlock(nf[0], nf[1], stride=2, indice_key="vir2")
+            self.vir_conv3 = NRConvBlock(nf[1], nf[2], stride=2, indice_key="vir3")
+            self.vir_conv4 = NRConvBlock(nf[2], nf[3], stride=2, padding=(0, 1, 1), indice_key="vir4")
+        self.num_point_features = self.out_features
+        if self.return_num_features_as_dict:
+            self.num_point_features = {"x_conv1": nf[0], "x_conv2": nf[1], "x_conv3": nf[2], "x_conv4": nf[3]}
+
+    @staticmethod
+    def decompose_tensor(tensor, i, batch_size):
+        """Slab i of an x-concatenated tensor (spconv_backbone.py:314-337)."""
+        w = tensor.spatial_shape[2]
+        begin, end = i * (w // 4), (i + 1) * (w // 4)
+        x = tensor.indices[:, 3]
+        keep = torch.nonzero((begin < x) & (x < end)).squeeze(1)
+        if tensor.features.is_cuda:
+            feats, idx = ops.discard_rows(tensor.features, tensor.indices, keep)
+        else:
+            feats, idx = tensor.features[keep], tensor.indices[keep]
+        idx = idx.clone()
+        idx[:, 3] -= begin
+        shape = [tensor.spatial_shape[0], tensor.spatial_shape[1], tensor.spatial_shape[2] // 4]
+        return spconv.SparseConvTensor(feats, idx.int(), shape, batch_size)
+
+    def _lidar_stream(self, sp):
+        x = self.conv_input(sp)
+        x1 = self.conv1(x)
+        x2 = self.conv2(x1)
+        x3 = self.conv3(x2)
+        x4 = self.conv4(x3)
+        return x1, x2, x3, x4, self.conv_out(x4)
+
+    def _discard(self, sp, batch_dict, tag):
+        if not self.training or self.layer_discard_mode == "spconv2_noop" or self.layer_discard_rate == 0:
+            return sp
+        inj = batch_dict.get("layer_discard_keep")
+        return layer_voxel_discard(sp, self.layer_discard_rate, None if inj is None else inj[tag])
+
+    def forward(self, batch_dict):
+        rot_num = batch_dict["transform_param"].shape[1] if "transform_param" in batch_dict else 1
+        batch_size = batch_dict["batch_size"]
+        strides = {"x_conv1": 1, "x_conv2": 2, "x_conv3": 4, "x_conv4": 8}
+        rids = ["" if i == 0 else str(i) for i in range(rot_num)]
+
+        if self.training:
+            for rid in rids:
+                sp = spconv.SparseConvTensor(batch_dict["voxel_features" + rid], batch_dict["voxel_coords" + rid].int(),
+                                             self.sparse_shape, batch_size)
+                x1, x2, x3, x4, out = self._lidar_stream(sp)
+                batch_dict.update({"encoded_spconv_tensor" + rid: out, "encoded_spconv_tensor_stride" + rid: 8,
+                                   "multi_scale_3d_features" + rid: {"x_conv1": x1, "x_conv2": x2, "x_conv3": x3, "x_conv4": x4},
+                                   "multi_scale_3d_strides" + rid: dict(strides)})
+        else:
+            feats, coords = [], []
+            for i, rid in enumerate(rids):
+                c = batch_dict["voxel_coords" + rid].clone()
+                c[:, 3] += i * self.sparse_shape[2]
+                feats.append(batch_dict["voxel_features" + rid])
+                coords.append(c)
+            new_shape = [self.sparse_shape[0], self.sparse_shape[1], self.sparse_shape[2] * 4]
+            sp = spconv.SparseConvTensor(torch.cat(feats, 0), torch.cat(coords).int(), new_shape, batch_size)
+            x1, x2, x3, x4, out = self._lidar_stream(sp)
+            for i, rid in enumerate(rids):
+                batch_dict.update({
+                    "encoded_spconv_tensor" + rid: self.decompose_tensor(out, i, batch_size),
+                    "encoded_spconv_tensor_stride" + rid: 8,
+                    "multi_scale_3d_features" + rid: {"x_conv1": None, "x_conv2": None,
+                                                      "x_conv3": self.decompose_tensor(x3, i, batch_size),
+                                                      "x_conv4": self.decompose_tensor(x4, i, batch_size)},
+                    "multi_scale_3d_strides" + rid: dict(strides)})
+
+        if self.mm:
+            calib = batch_dict["calib"]
+            if not torch.is_tensor(calib):
+                calib = ops.calib_tensor(calib, batch_dict["voxel_features_mm"].device)
+            for i, rid in enumerate(rids):
+                sp = spconv.SparseConvTensor(batch_dict["voxel_features_mm" + rid], batch_dict["voxel_coords_mm" + rid].int(),
+                                             self.sparse_shape, batch_size)
+                sp = self._discard(sp, batch_dict, f"mm_input{rid}")  # the MM stream also discards its input (:488-489)
+                trans_param = batch_dict.get("aug_param")
+                if "transform_param" in batch_dict:
+                    trans_param = batch_dict["transform_param"][:, i, :]
+                m1 = self._discard(self.vir_conv1(sp, batch_size, calib, 1, None, trans_param), batch_dict, f"mm_x_conv1{rid}")
+                m2 = self._discard(self.vir_conv2(m1, batch_size, calib, 2, None, trans_param), batch_dict, f"mm_x_conv2{rid}")
+                m3 = self._discard(self.vir_conv3(m2, batch_size, calib, 4, None, trans_param), batch_dict, f"mm_x_conv3{rid}")
+                m4 = self.vir_conv4(m3, batch_size, calib, 8, None, trans_param)
+                batch_dict.update({"encoded_spconv_tensor_stride_mm" + rid: 8,
+                                   "multi_scale_3d_features_mm" + rid: {"x_conv1": m1, "x_conv2": m2, "x_conv3": m3, "x_conv4": m4},
+                                   "multi_scale_3d_strides" + rid: dict(strides)})
+        return batch_dict
+
+
 class HeightCompression(nn.Module):
     """First consumer of the path's output (pcdet/models/backbones_2d/map_to_bev/height_compression.py:27-31)."""
 
@@ -229,4 +367,4 @@ class HeightCompression(nn.Module):
         return batch_dict
 
 
-__all__ = {"VirConvL8x": VirConvL8x}
+__all__ = {"VirConvL8x": VirConvL8x, "VirConv8x": VirConv8x}
