@@ -1,0 +1,40 @@
+"""Host-side profile of the bench step (cProfile): where the Python/torch time of one train step goes."""
+import cProfile
+import os
+import pstats
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from virconv_amd import synth  # noqa: E402
+from virconv_amd.backbone import VirConvL8x  # noqa: E402
+
+dev = torch.device("cuda", 0)
+batch = bench.make_batch([0, 1, 2, 3], dev, True)
+model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).to(dev).train()
+opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01)
+lw = bench.make_loss_weights(dev)
+for _ in range(3):
+    bench.train_step(model, opt, batch, lw)
+torch.cuda.synchronize()
+# pure host cost: time to ENQUEUE a step when the GPU is not the bottleneck is approximated by timing without final sync
+t0 = time.perf_counter()
+for _ in range(5):
+    bench.train_step(model, opt, batch, lw)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f"enqueue {1e3 * (t1 - t0) / 5:.2f} ms/step, drained after +{1e3 * (t2 - t1):.2f} ms")
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(5):
+    bench.train_step(model, opt, batch, lw)
+torch.cuda.synchronize()
+pr.disable()
+st = pstats.Stats(pr)
+st.sort_stats("tottime").print_stats(28)
+st.sort_stats("cumulative").print_stats(30)

@@ -352,15 +352,19 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
 // grid (nsplit, kv); each block owns offset k = blockIdx.y and a contiguous range of output rows.  Each wave scans its
 // rows 64 at a time, ballot/prefix-compacts the active (in, out) pairs into an LDS queue, and consumes the queue four
 // pairs per MFMA step:  dW_k[ci][co] += x[in_p][ci] * dy[out_p][co]   (M = ci, N = co, K = pair).
+// Operand vectorisation: lane (i, q) loads VA = CI/16 contiguous input channels [VA*i, VA*i+VA) of pair q's input row and
+// VB = CO/16 contiguous output channels of its dy row with ONE vector load each and issues VA x VB MFMAs per 4 pairs;
+// tile (ja, jb) therefore holds dW[ci = VA*m + ja][co = VB*n + jb] (a fixed permutation of the M / N dimensions).
 template <int CI, int CO>
 __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                          const int32_t* __restrict__ tbl, int64_t n_out, int kv,
                                                          int64_t rows_per_block, float* __restrict__ partial) {
-  constexpr int MT = (CI + 15) / 16, NT = (CO + 15) / 16;
-  constexpr int U = (MT + NT <= 4) ? 4 : 2;  // groups of 4 pairs gathered per iteration
+  constexpr int VA = (CI >= 16) ? CI / 16 : 1, VB = (CO >= 16) ? CO / 16 : 1;
+  constexpr int MA = (CI >= 16) ? 16 : CI, NB = (CO >= 16) ? 16 : CO;  // lanes of the tile that carry data
+  constexpr int U = (VA * VB >= 8) ? 2 : 4;                            // groups of 4 pairs gathered per iteration
   __shared__ int q_in[4][136];
   __shared__ int q_out[4][136];
-  __shared__ float red[MT * 16 * NT * 16];
+  __shared__ float red[CI * CO];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int k = blockIdx.y;
@@ -369,12 +373,13 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
   const int64_t rpw = rows_per_block / 4;  // rows_per_block is a multiple of 256
   const int64_t wstart = brow0 + wave * rpw;
   const int64_t wend = min(wstart + rpw, bend);
+  const bool a_ok = i < MA, b_ok = i < NB;
 
-  f32x4 acc[MT][NT];
+  f32x4 acc[VA][VB];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+  for (int ja = 0; ja < VA; ++ja)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int jb = 0; jb < VB; ++jb) acc[ja][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   int* qi = q_in[wave];
   int* qo = q_out[wave];
@@ -391,37 +396,48 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
     __builtin_amdgcn_wave_barrier();
     const int ng = qlen >> 2;
     int g = 0;
-    // U groups (16 pairs) per iteration: all gathers of the chunk are issued before the first MFMA consumes them
     for (; g + U <= ng; g += U) {
-      float a[U][MT], b[U][NT];
+      float a[U][VA], b[U][VB];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int pin = qi[(g + u) * 4 + q], pout = qo[(g + u) * 4 + q];
+        if (a_ok) VecLoad<VA>::ld(x + (int64_t)pin * CI + VA * i, a[u]);
+        else {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[u][mt] = (mt * 16 + i < CI) ? x[(int64_t)pin * CI + mt * 16 + i] : 0.f;
+          for (int j = 0; j < VA; ++j) a[u][j] = 0.f;
+        }
+        if (b_ok) VecLoad<VB>::ld(dy + (int64_t)pout * CO + VB * i, b[u]);
+        else {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[u][nt] = (nt * 16 + i < CO) ? dy[(int64_t)pout * CO + nt * 16 + i] : 0.f;
+          for (int j = 0; j < VB; ++j) b[u][j] = 0.f;
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int ja = 0; ja < VA; ++ja)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][mt], b[u][nt], acc[mt][nt], 0, 0, 0);
+          for (int jb = 0; jb < VB; ++jb)
+            acc[ja][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][ja], b[u][jb], acc[ja][jb], 0, 0, 0);
     }
     for (; g < ng; ++g) {
       const int pin = qi[g * 4 + q], pout = qo[g * 4 + q];
-      float a[MT], b[NT];
+      float a[VA], b[VB];
+      if (a_ok) VecLoad<VA>::ld(x + (int64_t)pin * CI + VA * i, a);
+      else {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a[mt] = (mt * 16 + i < CI) ? x[(int64_t)pin * CI + mt * 16 + i] : 0.f;
+        for (int j = 0; j < VA; ++j) a[j] = 0.f;
+      }
+      if (b_ok) VecLoad<VB>::ld(dy + (int64_t)pout * CO + VB * i, b);
+      else {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) b[nt] = (nt * 16 + i < CO) ? dy[(int64_t)pout * CO + nt * 16 + i] : 0.f;
+        for (int j = 0; j < VB; ++j) b[j] = 0.f;
+      }
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int ja = 0; ja < VA; ++ja)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        for (int jb = 0; jb < VB; ++jb)
+          acc[ja][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ja], b[jb], acc[ja][jb], 0, 0, 0);
     }
     const int rem = qlen - ng * 4;
     int t1 = 0, t2 = 0;
@@ -434,66 +450,97 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
   if (qlen > 0) {  // tail group, padded with zero operands
     const bool ok = q < qlen;
     const int pin = ok ? qi[q] : 0, pout = ok ? qo[q] : 0;
-    float a[MT], b[NT];
+    float a[VA], b[VB];
+    if (ok && a_ok) VecLoad<VA>::ld(x + (int64_t)pin * CI + VA * i, a);
+    else {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = (ok && mt * 16 + i < CI) ? x[(int64_t)pin * CI + mt * 16 + i] : 0.f;
+      for (int j = 0; j < VA; ++j) a[j] = 0.f;
+    }
+    if (ok && b_ok) VecLoad<VB>::ld(dy + (int64_t)pout * CO + VB * i, b);
+    else {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = (ok && nt * 16 + i < CO) ? dy[(int64_t)pout * CO + nt * 16 + i] : 0.f;
+      for (int j = 0; j < VB; ++j) b[j] = 0.f;
+    }
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int ja = 0; ja < VA; ++ja)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+      for (int jb = 0; jb < VB; ++jb)
+        acc[ja][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ja], b[jb], acc[ja][jb], 0, 0, 0);
   }
 
   // fixed-order cross-wave reduction through LDS (wave 0 stores, waves 1..3 add in order)
   for (int wv = 0; wv < 4; ++wv) {
     if (wave == wv) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int ja = 0; ja < VA; ++ja)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int jb = 0; jb < VB; ++jb)
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
-            const int ci = mt * 16 + q * 4 + reg, co = nt * 16 + i;
-            float* p = &red[ci * (NT * 16) + co];
-            *p = (wv == 0) ? acc[mt][nt][reg] : (*p + acc[mt][nt][reg]);
+            const int m = q * 4 + reg, ci = VA * m + ja, co = VB * i + jb;
+            if (m < MA && i < NB) {
+              float* p = &red[ci * CO + co];
+              *p = (wv == 0) ? acc[ja][jb][reg] : (*p + acc[ja][jb][reg]);
+            }
           }
     }
     __syncthreads();
   }
   float* dst = partial + ((int64_t)blockIdx.x * kv + k) * (CI * CO);
-  for (int e = threadIdx.x; e < CI * CO; e += 256) {
-    const int ci = e / CO, co = e - ci * CO;
-    dst[e] = red[ci * (NT * 16) + co];
+  for (int e = threadIdx.x; e < CI * CO; e += 256) dst[e] = red[e];
+}
+
+// dweight[(co*kv + k)*CI + ci] = sum_s partial[s][k][ci][co]   (fixed order: 4 interleaved partial sums, then 0+1+2+3)
+// 64 consecutive (k, ci, co) elements per block in the partial's native order (coalesced reads), 4 split-groups.
+__global__ void __launch_bounds__(256) bwd_weight_reduce_kernel(const float* __restrict__ partial, int nsplit, int kv,
+                                                                int ci_n, int co_n, float* __restrict__ dweight) {
+  __shared__ float red[4][64];
+  const int total = kv * ci_n * co_n;
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int sg = threadIdx.x >> 6;
+  float s = 0.f;
+  if (e < total)
+    for (int sp = sg; sp < nsplit; sp += 4) s += partial[(int64_t)sp * total + e];
+  red[sg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sg == 0 && e < total) {
+    const float v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    const int co = e % co_n;
+    const int ci = (e / co_n) % ci_n;
+    const int k = e / (co_n * ci_n);
+    dweight[((int64_t)co * kv + k) * ci_n + ci] = v;
   }
 }
 
-// dweight[(co*kv + k)*CI + ci] = sum_s partial[s][k][ci][co]   (fixed order over s)
-__global__ void __launch_bounds__(256) bwd_weight_reduce_kernel(const float* __restrict__ partial, int nsplit, int kv,
-                                                                int ci_n, int co_n, float* __restrict__ dweight) {
-  const int total = kv * ci_n * co_n;
-  int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= total) return;
-  const int ci = e % ci_n;
-  const int k = (e / ci_n) % kv;
-  const int co = e / (ci_n * kv);
-  const int64_t off = ((int64_t)k * ci_n + ci) * co_n + co;
-  float s = 0.f;
-  for (int sp = 0; sp < nsplit; ++sp) s += partial[(int64_t)sp * total + off];
-  dweight[e] = s;
-}
-
 // --------------------------------------------------------------------------------------------- group sum (dup path)
+// thread = (chunk of kGsRows consecutive rows, channel): consecutive rows that share a representative (very common: the
+// voxels outside the camera frustum all clamp onto border pixels) are summed in registers and flushed with ONE atomic
+// per run, which removes almost all same-address contention.
+static constexpr int kGsRows = 32;
 __global__ void __launch_bounds__(256) group_sum_kernel(const float* __restrict__ dy, const int32_t* __restrict__ rep,
                                                         int64_t n, int c, float* __restrict__ grp) {
-  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= n * c) return;
-  int64_t r = t / c;
-  int ch = (int)(t - r * c);
-  int g = rep[r];
-  if (g < 0) g = (int)r;
-  unsafeAtomicAdd(&grp[(int64_t)g * c + ch], dy[t]);
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t chunk = t / c;
+  const int ch = (int)(t - chunk * c);
+  const int64_t r0 = chunk * kGsRows;
+  if (r0 >= n) return;
+  const int64_t r1 = min(r0 + (int64_t)kGsRows, n);
+  int cur = rep[r0];
+  if (cur < 0) cur = (int)r0;
+  float acc = dy[r0 * c + ch];
+  for (int64_t r = r0 + 1; r < r1; ++r) {
+    int g = rep[r];
+    if (g < 0) g = (int)r;
+    const float v = dy[r * c + ch];
+    if (g != cur) {
+      unsafeAtomicAdd(&grp[(int64_t)cur * c + ch], acc);
+      cur = g;
+      acc = v;
+    } else {
+      acc += v;
+    }
+  }
+  unsafeAtomicAdd(&grp[(int64_t)cur * c + ch], acc);
 }
 
 // --------------------------------------------------------------------------------------------- dispatch
@@ -579,7 +626,7 @@ static int launch_bw(const float* x, const float* dy, const int32_t* tbl, int64_
   hipLaunchKernelGGL((bwd_weight_kernel<CI, CO>), dim3(nsplit, kv), dim3(256), 0, st, x, dy, tbl, n_out, kv, rpb, partial);
   VC_CHECK_LAUNCH("bwd_weight_kernel");
   const int total = kv * CI * CO;
-  hipLaunchKernelGGL(bwd_weight_reduce_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, partial, nsplit, kv,
+  hipLaunchKernelGGL(bwd_weight_reduce_kernel, dim3((unsigned)cdiv(total, 64)), dim3(256), 0, st, partial, nsplit, kv,
                      CI, CO, dweight);
   VC_CHECK_LAUNCH("bwd_weight_reduce_kernel");
   return VC_OK;
@@ -667,7 +714,8 @@ int vc_group_sum(const float* dy, const int32_t* rep, int64_t n, int c, float* d
   VC_REQUIRE(dy && rep && dy_grp, "vc_group_sum: null argument");
   hipStream_t st = (hipStream_t)stream;
   VC_CHECK_HIP(hipMemsetAsync(dy_grp, 0, (size_t)n * c * 4, st));
-  hipLaunchKernelGGL(group_sum_kernel, dim3((unsigned)cdiv(n * c, 256)), dim3(256), 0, st, dy, rep, n, c, dy_grp);
+  hipLaunchKernelGGL(group_sum_kernel, dim3((unsigned)cdiv(cdiv(n, kGsRows) * c, 256)), dim3(256), 0, st, dy, rep, n, c,
+                     dy_grp);
   VC_CHECK_LAUNCH("group_sum_kernel");
   return VC_OK;
 }
