@@ -135,6 +135,10 @@ def main():
     optimizer = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01)
     lw = make_loss_weights(device)
     torch.manual_seed(100 + rank)  # layer-discard permutations
+    # the inputs are resident in HBM from here on: lets the backbone's geometry plan run ahead on its side stream
+    torch.cuda.synchronize()
+    batch["inputs_ready_event"] = torch.cuda.Event()
+    batch["inputs_ready_event"].record()
 
     # Setup (untimed, not a step): park a few GB of blocks in torch's caching allocator.  Layer discard is random, so
     # tensor sizes differ from step to step and the first steps would otherwise pay hipMalloc for every new size.

@@ -162,7 +162,8 @@ int vc_voxelize_mean(const float* points, int64_t p, int f, const float* host_ra
  *   vc_bn_relu_backward : dx, dgamma, dbeta for the training-mode BN(+ReLU)                                       */
 size_t vc_bn_workspace_bytes(int64_t n, int c);
 int vc_bn_stats(const float* x, int64_t n, int c, float* mean, float* var, float* running_mean /*nullable*/,
-                float* running_var /*nullable*/, float momentum, void* ws, size_t ws_bytes, void* stream);
+                float* running_var /*nullable*/, int64_t* num_batches_tracked /*nullable, += 1*/, float momentum,
+                void* ws, size_t ws_bytes, void* stream);
 int vc_bn_apply_relu(const float* x, int64_t n, int c, const float* mean, const float* var, const float* gamma,
                      const float* beta, float eps, int relu, float* y, int y_stride, int y_col0, void* stream);
 int vc_bn_relu_backward(const float* x, const float* dy, int dy_stride, int dy_col0, int64_t n, int c,

@@ -82,7 +82,7 @@ class OracleBackend:
 
     def gather_rows(self, features, indices, keep):
         k = keep.long()
-        return features.detach()[k], (None if indices is None else indices[k])
+        return (None if features is None else features.detach()[k]), (None if indices is None else indices[k])
 
     def scatter_rows(self, grad_out, keep, n_in):
         g = grad_out.new_zeros((n_in, grad_out.shape[1]))
@@ -104,8 +104,11 @@ class OracleBackend:
         return torch.from_numpy(feats), torch.from_numpy(coords), torch.from_numpy(num)
 
     # ------------------------------------------------------------------ BatchNorm(+ReLU)
-    def bn_forward(self, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, out=None, out_col0=0):
+    def bn_forward(self, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, out=None, out_col0=0,
+                   num_batches_tracked=None):
         x = x.detach()
+        if training and num_batches_tracked is not None:
+            num_batches_tracked.add_(1)
         n = x.shape[0]
         if training:
             xd = x.double()

@@ -114,21 +114,79 @@ class NRConvBlock(nn.Module):
         self.d3_conv2 = post_act_block(c2 // 2, c2 // 2, 3, norm_fn=norm_fn, padding=1, indice_key=("subm3d" + indice_key))
         self.d2_conv2 = post_act_block2d(c2 // 2, c2 // 2, 3, norm_fn=norm_fn, padding=1, indice_key=("subm2d" + indice_key))
 
-    def forward(self, sp_tensor, batch_size, calib, stride, x_trans_train=None, trans_param=None):
+    # ---- geometry: everything below depends on coordinates only (never on features)
+    def _keys(self):
+        k3 = self.d3_conv1[0].indice_key
+        k2 = self.d2_conv1[0].indice_key
+        kd = self.down_layer[0].indice_key if self.stride > 1 else None
+        return kd, k3, k2
+
+    def plan(self, indices, spatial_shape, batch_size, calib, stride, trans_param):
+        """Build every index structure of the block from the input coordinates: the strided-conv rulebook (+ its output
+        coordinates), the shared 3-D SubM rulebook, the pixel coordinates and the shared 2-D SubM rulebook."""
+        kd, k3, k2 = self._keys()
+        rbs3, shape = {}, list(spatial_shape)
+        if self.stride > 1:
+            conv = self.down_layer[0]
+            rb = ops.build_sparse_rulebook(indices, shape, batch_size, conv.kernel_size, conv.stride, conv.padding,
+                                           conv.dilation)
+            rbs3[kd] = rb
+            indices, shape = rb.out_indices, list(rb.out_shape)
+        rbs3[k3] = ops.build_subm_rulebook(indices, shape, self.d3_conv1[0].kernel_size, self.d3_conv1[0].dilation, False)
+        if trans_param is not None:
+            trans_param = torch.as_tensor(trans_param, dtype=torch.float32, device=indices.device).reshape(batch_size, 3)
+        uv = ops.project_uv(indices, calib, trans_param, batch_size, stride)
+        rb2 = ops.build_subm_rulebook(uv, self.IMAGE_SHAPE, self.d2_conv1[0].kernel_size, self.d2_conv1[0].dilation, True)
+        return {"rb3d": rbs3, "uv": uv, "rb2d": {k2: rb2}, "out_indices": indices, "out_shape": shape}
+
+    def forward(self, sp_tensor, batch_size, calib, stride, x_trans_train=None, trans_param=None, plan=None):
+        if plan is not None:
+            sp_tensor.indice_dict.update(plan["rb3d"])
         if self.stride > 1:
             sp_tensor = self.down_layer(sp_tensor)
         d3_feat1 = self.d3_conv1(sp_tensor)
         d3_feat2 = self.d3_conv2(d3_feat1)
 
-        if not torch.is_tensor(calib):
-            calib = ops.calib_tensor(calib, d3_feat2.indices.device)
-        if trans_param is not None:
-            trans_param = torch.as_tensor(trans_param, dtype=torch.float32, device=d3_feat2.indices.device).reshape(batch_size, 3)
-        uv_coords = ops.project_uv(d3_feat2.indices, calib, trans_param, batch_size, stride)
-        d2_sp_tensor1 = spconv.SparseConvTensor(d3_feat2.features, uv_coords, self.IMAGE_SHAPE, batch_size)
+        if plan is not None:
+            uv_coords, d2_dict = plan["uv"], dict(plan["rb2d"])
+        else:
+            if not torch.is_tensor(calib):
+                calib = ops.calib_tensor(calib, d3_feat2.indices.device)
+            if trans_param is not None:
+                trans_param = torch.as_tensor(trans_param, dtype=torch.float32,
+                                              device=d3_feat2.indices.device).reshape(batch_size, 3)
+            uv_coords, d2_dict = ops.project_uv(d3_feat2.indices, calib, trans_param, batch_size, stride), None
+        d2_sp_tensor1 = spconv.SparseConvTensor(d3_feat2.features, uv_coords, self.IMAGE_SHAPE, batch_size,
+                                                indice_dict=d2_dict)
         d2_feat1 = self.d2_conv1(d2_sp_tensor1)
         d2_feat2 = self.d2_conv2(d2_feat1)
         return d3_feat2.replace_feature(torch.cat([d3_feat2.features, d2_feat2.features], -1))
+
+
+def _record_stream(obj, stream):
+    """Mark every tensor reachable from a plan as used on `stream` (it was allocated on the plan stream)."""
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, ops.Rulebook):
+        for t in (obj.pair_fwd, obj.pair_bwd, obj.rep, obj.in_indices, obj.out_indices):
+            _record_stream(t, stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _record_stream(v, stream)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _record_stream(v, stream)
+
+
+_PLAN_STREAMS = {}
+
+
+def _plan_stream(device):
+    key = torch.device(device).index
+    if key not in _PLAN_STREAMS:
+        _PLAN_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _PLAN_STREAMS[key]
 
 
 class VirConvL8x(nn.Module):
@@ -142,6 +200,7 @@ class VirConvL8x(nn.Module):
         self.layer_discard_rate = _cfg_get(model_cfg, "LAYER_DISCARD_RATE", 0.0)
         self.layer_discard_mode = _cfg_get(model_cfg, "LAYER_DISCARD_MODE", "spconv1_inplace")
         assert self.layer_discard_mode in ("spconv1_inplace", "spconv2_noop")
+        self.plan_ahead = bool(_cfg_get(model_cfg, "PLAN_AHEAD", True))
         num_filters = _cfg_get(model_cfg, "NUM_FILTERS")
         norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
         self.sparse_shape = [int(v) for v in (np.asarray(grid_size)[::-1] + [1, 0, 0])]
@@ -163,14 +222,66 @@ class VirConvL8x(nn.Module):
             self.num_point_features = {"x_conv1": num_filters[0], "x_conv2": num_filters[1], "x_conv3": num_filters[2],
                                        "x_conv4": num_filters[3]}
 
+    def _discard_active(self):
+        return self.training and self.layer_discard_mode != "spconv2_noop" and self.layer_discard_rate != 0
+
+    def _draw_keep(self, n, batch_dict, tag, device):
+        n_keep = int(n * (1 - self.layer_discard_rate))
+        inj = batch_dict.get("layer_discard_keep")
+        if inj is not None:
+            keep = inj[tag].to(device=device, dtype=torch.int64)
+            assert keep.shape[0] == n_keep, f"injected keep has {keep.shape[0]} rows, expected {n_keep}"
+            return keep
+        return torch.randperm(n, device=device)[:n_keep]
+
     def _discard(self, sp, batch_dict, tag):
-        if not self.training or self.layer_discard_mode == "spconv2_noop" or self.layer_discard_rate == 0:
+        if not self._discard_active():
             return sp
         keep = None
         inj = batch_dict.get("layer_discard_keep")
         if inj is not None:
             keep = inj[tag]
         return layer_voxel_discard(sp, self.layer_discard_rate, keep)
+
+    def build_plan(self, coords, batch_size, calib, trans_param, batch_dict, rid=""):
+        """GEOMETRY PLAN.  All rulebooks, pixel coordinates, strided-conv output sets and discard permutations of the
+        whole backbone depend on coordinates only, so they are built first -- on a side stream, where the four
+        data-dependent size reads (one per strided conv) only wait for a few short index kernels instead of draining
+        the feature work queued on the main stream.  The feature pass that follows is free of host syncs."""
+        on_gpu = coords.is_cuda
+        if on_gpu:
+            main = torch.cuda.current_stream()
+            side = _plan_stream(coords.device)
+            ready = batch_dict.get("inputs_ready_event")
+            if ready is not None:
+                side.wait_event(ready)  # inputs were produced before this event: no need to wait for the stream tail
+            else:
+                side.wait_stream(main)
+            ctx = torch.cuda.stream(side)
+        else:
+            import contextlib
+            ctx = contextlib.nullcontext()
+        blocks = [(self.vir_conv1, 1), (self.vir_conv2, 2), (self.vir_conv3, 4), (self.vir_conv4, 8)]
+        with ctx:
+            idx, shape, stages = coords.int(), list(self.sparse_shape), []
+            in_idx = idx
+            for bi, (blk, stride) in enumerate(blocks):
+                p = blk.plan(in_idx, shape, batch_size, calib, stride, trans_param)
+                in_idx, shape = p["out_indices"], p["out_shape"]
+                p["keep"] = None
+                if bi < 3 and self._discard_active():
+                    keep = self._draw_keep(in_idx.shape[0], batch_dict, f"x_conv{bi + 1}{rid}", in_idx.device)
+                    _, in_idx = ops.get_backend().gather_rows(None, in_idx, keep)
+                    p["keep"], p["kept_indices"] = keep, in_idx
+                stages.append(p)
+            co = self.conv_out[0]
+            rb_out = ops.build_sparse_rulebook(in_idx, shape, batch_size, co.kernel_size, co.stride, co.padding, co.dilation)
+            plan = {"in_indices": idx, "stages": stages, "conv_out": {co.indice_key: rb_out}}
+        if not on_gpu:
+            return plan
+        main.wait_stream(side)
+        _record_stream(plan, main)
+        return plan
 
     def forward(self, batch_dict):
         if "transform_param" in batch_dict:
@@ -186,7 +297,6 @@ class VirConvL8x(nn.Module):
             rid = "" if i == 0 else str(i)
             feats, coords = batch_dict["voxel_features" + rid], batch_dict["voxel_coords" + rid]
             feats[:, 4:7] = 0  # remove the RGB features, in place on the batch tensor (spconv_backbone.py:636)
-            x0 = spconv.SparseConvTensor(feats, coords.int(), self.sparse_shape, batch_size)
 
             if "aug_param" in batch_dict:
                 trans_param = batch_dict["aug_param"]
@@ -195,14 +305,30 @@ class VirConvL8x(nn.Module):
             if "transform_param" in batch_dict:
                 trans_param = batch_dict["transform_param"][:, i, :]
 
-            x1 = self.vir_conv1(x0, batch_size, calib, 1, None, trans_param)
-            x1 = self._discard(x1, batch_dict, f"x_conv1{rid}")
-            x2 = self.vir_conv2(x1, batch_size, calib, 2, None, trans_param)
-            x2 = self._discard(x2, batch_dict, f"x_conv2{rid}")
-            x3 = self.vir_conv3(x2, batch_size, calib, 4, None, trans_param)
-            x3 = self._discard(x3, batch_dict, f"x_conv3{rid}")
-            x4 = self.vir_conv4(x3, batch_size, calib, 8, None, trans_param)
-            out = self.conv_out(x4)
+            if self.plan_ahead:
+                plan = self.build_plan(coords, batch_size, calib, trans_param, batch_dict, rid)
+                x = spconv.SparseConvTensor(feats, plan["in_indices"], self.sparse_shape, batch_size)
+                outs = []
+                blocks = [(self.vir_conv1, 1), (self.vir_conv2, 2), (self.vir_conv3, 4), (self.vir_conv4, 8)]
+                for (blk, stride), p in zip(blocks, plan["stages"]):
+                    x = blk(x, batch_size, calib, stride, None, trans_param, plan=p)
+                    if p["keep"] is not None:
+                        f = ops.GatherRowsFunction.apply(x.features, p["keep"])
+                        x = spconv.SparseConvTensor(f, p["kept_indices"], x.spatial_shape, batch_size)
+                    outs.append(x)
+                x1, x2, x3, x4 = outs
+                x4.indice_dict.update(plan["conv_out"])
+                out = self.conv_out(x4)
+            else:
+                x0 = spconv.SparseConvTensor(feats, coords.int(), self.sparse_shape, batch_size)
+                x1 = self.vir_conv1(x0, batch_size, calib, 1, None, trans_param)
+                x1 = self._discard(x1, batch_dict, f"x_conv1{rid}")
+                x2 = self.vir_conv2(x1, batch_size, calib, 2, None, trans_param)
+                x2 = self._discard(x2, batch_dict, f"x_conv2{rid}")
+                x3 = self.vir_conv3(x2, batch_size, calib, 4, None, trans_param)
+                x3 = self._discard(x3, batch_dict, f"x_conv3{rid}")
+                x4 = self.vir_conv4(x3, batch_size, calib, 8, None, trans_param)
+                out = self.conv_out(x4)
 
             batch_dict.update({
                 "encoded_spconv_tensor" + rid: out,

@@ -28,7 +28,8 @@ def _need(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    # raw hipStream_t of torch's CURRENT stream on the current device (fast path of torch.cuda.current_stream().cuda_stream)
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def conv_out_shape(in_shape, ksize, stride, padding, dilation):
@@ -195,9 +196,15 @@ class HipBackend:
               "vc_project_uv")
         return uv, depth
 
-    def gather_rows(self, features: torch.Tensor, indices: Optional[torch.Tensor], keep: torch.Tensor):
-        features = _need(features, torch.float32, "features")
+    def gather_rows(self, features: Optional[torch.Tensor], indices: Optional[torch.Tensor], keep: torch.Tensor):
         keep = _need(keep, torch.int64, "keep")
+        if features is None:  # index-only gather (geometry plan)
+            indices = _need(indices, torch.int32, "indices")
+            io = torch.empty((keep.shape[0], indices.shape[1]), dtype=torch.int32, device=indices.device)
+            check(self.lib.vc_gather_rows(None, _ptr(indices), 0, indices.shape[1], _ptr(keep), keep.shape[0], None,
+                                          _ptr(io), _stream()), "vc_gather_rows")
+            return None, io
+        features = _need(features, torch.float32, "features")
         nk, c = keep.shape[0], features.shape[1]
         fo = torch.empty((nk, c), dtype=torch.float32, device=features.device)
         io, icols = None, 0
@@ -259,7 +266,8 @@ class HipBackend:
 
     # ------------------------------------------------------------------ BatchNorm(+ReLU)
     def bn_forward(self, x: torch.Tensor, gamma, beta, running_mean, running_var, training: bool, momentum: float,
-                   eps: float, relu: bool, out: Optional[torch.Tensor] = None, out_col0: int = 0):
+                   eps: float, relu: bool, out: Optional[torch.Tensor] = None, out_col0: int = 0,
+                   num_batches_tracked: Optional[torch.Tensor] = None):
         """-> (y, mean, var).  `out` (N, Ctot) lets the result land at a column offset of a wider row (fused concat)."""
         x = _need(x, torch.float32, "features")
         n, c = x.shape
@@ -271,7 +279,7 @@ class HipBackend:
             ws_bytes = self.lib.vc_bn_workspace_bytes(n, c)
             ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
             check(self.lib.vc_bn_stats(_ptr(x), n, c, _ptr(mean), _ptr(var), _ptr(running_mean), _ptr(running_var),
-                                       float(momentum), _ptr(ws), ws_bytes, st), "vc_bn_stats")
+                                       _ptr(num_batches_tracked), float(momentum), _ptr(ws), ws_bytes, st), "vc_bn_stats")
         else:
             mean, var = running_mean, running_var
         if out is None:

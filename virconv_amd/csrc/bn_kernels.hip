@@ -91,10 +91,13 @@ __global__ void __launch_bounds__(256) bn_stats_finalize_kernel(const double* __
                                                                 int c, float* __restrict__ mean,
                                                                 float* __restrict__ var,
                                                                 float* __restrict__ running_mean,
-                                                                float* __restrict__ running_var, float momentum) {
+                                                                float* __restrict__ running_var,
+                                                                long long* __restrict__ num_batches_tracked,
+                                                                float momentum) {
   const int lane = threadIdx.x & 63;
   const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ch >= c) return;
+  if (num_batches_tracked && ch == 0 && lane == 0) *num_batches_tracked += 1;
   double s = 0.0, ss = 0.0;
   for (int b = lane; b < nb; b += 64) {
     s += partial[(int64_t)b * 2 * c + ch];
@@ -212,7 +215,7 @@ size_t vc_bn_workspace_bytes(int64_t n, int c) {
 }
 
 int vc_bn_stats(const float* x, int64_t n, int c, float* mean, float* var, float* running_mean, float* running_var,
-                float momentum, void* ws, size_t ws_bytes, void* stream) {
+                int64_t* num_batches_tracked, float momentum, void* ws, size_t ws_bytes, void* stream) {
   VC_REQUIRE(bn_c_ok(c), "vc_bn_stats: unsupported channel count %d", c);
   VC_REQUIRE(n >= 1 && x && mean && var && ws, "vc_bn_stats: null/invalid argument (n=%lld)", (long long)n);
   if (ws_bytes < vc_bn_workspace_bytes(n, c)) { set_error("vc_bn_stats: workspace too small"); return VC_ECAPACITY; }
@@ -226,7 +229,7 @@ int vc_bn_stats(const float* x, int64_t n, int c, float* mean, float* var, float
                      rpb, partial);
   VC_CHECK_LAUNCH("bn_reduce_kernel<stats>");
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, partial, nb, n, c, mean, var,
-                     running_mean, running_var, momentum);
+                     running_mean, running_var, (long long*)num_batches_tracked, momentum);
   VC_CHECK_LAUNCH("bn_stats_finalize_kernel");
   return VC_OK;
 }

@@ -346,6 +346,17 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restric
     for (int a = 0; a < icols; ++a) idx_out[j * icols + a] = idx[src * icols + a];
 }
 
+// index-only variant (geometry plan: the coordinates of the kept rows are needed before any feature exists)
+__global__ void __launch_bounds__(256) gather_index_rows_kernel(const int32_t* __restrict__ idx, int icols,
+                                                                const int64_t* __restrict__ keep, int64_t n_keep,
+                                                                int32_t* __restrict__ idx_out) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_keep * icols) return;
+  int64_t j = t / icols;
+  int a = (int)(t - j * icols);
+  idx_out[t] = idx[keep[j] * icols + a];
+}
+
 __global__ void __launch_bounds__(256) scatter_rows_kernel(const float* __restrict__ gout, int c,
                                                            const int64_t* __restrict__ keep, int64_t n_keep,
                                                            float* __restrict__ gin) {
@@ -659,9 +670,17 @@ int vc_project_uv(const int32_t* indices, int64_t n, const float* params, int ba
 
 int vc_gather_rows(const float* features, const int32_t* indices, int c, int icols, const int64_t* keep, int64_t n_keep,
                    float* features_out, int32_t* indices_out, void* stream) {
+  VC_REQUIRE(!indices_out || (indices && icols > 0), "vc_gather_rows: indices_out without indices");
+  if (!features && !features_out && indices_out) {  // index-only gather
+    VC_REQUIRE(n_keep >= 0 && (n_keep == 0 || keep), "vc_gather_rows: null argument");
+    if (n_keep == 0) return VC_OK;
+    hipLaunchKernelGGL(gather_index_rows_kernel, dim3((unsigned)cdiv(n_keep * icols, 256)), dim3(256), 0,
+                       (hipStream_t)stream, indices, icols, keep, n_keep, indices_out);
+    VC_CHECK_LAUNCH("gather_index_rows_kernel");
+    return VC_OK;
+  }
   VC_REQUIRE(c > 0 && c % 4 == 0, "vc_gather_rows: channel count must be a positive multiple of 4 (got %d)", c);
   VC_REQUIRE(n_keep >= 0 && (n_keep == 0 || (features && keep && features_out)), "vc_gather_rows: null argument");
-  VC_REQUIRE(!indices_out || (indices && icols > 0), "vc_gather_rows: indices_out without indices");
   if (n_keep == 0) return VC_OK;
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)cdiv(n_keep * (c / 4), 256)), dim3(256), 0, (hipStream_t)stream,
                      features, indices, c, icols, keep, n_keep, features_out, indices_out);

@@ -178,9 +178,10 @@ class BNReLUFunction(torch.autograd.Function):
     """Training-mode BatchNorm1d(+ReLU) over the active rows."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, nbt=None):
         be = get_backend()
-        y, mean, var = be.bn_forward(x, gamma, beta, running_mean, running_var, training, momentum, eps, relu)
+        y, mean, var = be.bn_forward(x, gamma, beta, running_mean, running_var, training, momentum, eps, relu,
+                                     num_batches_tracked=nbt)
         ctx.cfg = (training, float(eps), bool(relu))
         ctx.save_for_backward(x, mean, var, gamma, beta)
         return y
@@ -193,18 +194,18 @@ class BNReLUFunction(torch.autograd.Function):
         if not training:
             raise NotImplementedError("virconv_amd: backward through eval-mode BatchNorm is not supported")
         dx, dgamma, dbeta = be.bn_backward(x, grad_out.contiguous(), 0, mean, var, gamma, beta, eps, relu)
-        return dx, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 def bn_relu(x: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool) -> torch.Tensor:
     """Fused BatchNorm1d(+ReLU) using the parameters/buffers of a stock nn.BatchNorm1d module."""
     training = bn.training or not bn.track_running_stats
-    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
     momentum = 0.0 if bn.momentum is None else bn.momentum
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
-    return BNReLUFunction.apply(x, bn.weight, bn.bias, rm, rv, training, momentum, bn.eps, relu)
+    # num_batches_tracked is incremented inside the stats-finalize kernel (no extra launch)
+    nbt = bn.num_batches_tracked if (training and bn.track_running_stats) else None
+    return BNReLUFunction.apply(x, bn.weight, bn.bias, rm, rv, training, momentum, bn.eps, relu, nbt)
 
 
 def project_uv(indices, calib, trans, batch_size, stride):
