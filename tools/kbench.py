@@ -44,11 +44,13 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="all")
     ap.add_argument("--variant", type=int, default=0, help="gather-GEMM variant (vc_debug_set conv_variant); 0 = default")
+    ap.add_argument("--rt", type=int, default=0, help="v2 row tiles per wave (vc_debug_set conv_rt); 0 = heuristic")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     be = ops.get_backend()
     if args.variant:
         assert be.lib.vc_debug_set(b"conv_variant", args.variant) == 0
+    assert be.lib.vc_debug_set(b"conv_rt", args.rt) == 0
     batch = bench.make_batch(list(range(args.bs)), dev, training=True)
     idx = batch["voxel_coords"].int()
     shape = [int(v) for v in (np.asarray(synth.GRID_SIZE)[::-1] + [1, 0, 0])]

@@ -175,7 +175,7 @@ struct BufLoad<1> {
   }
 };
 
-template <int CK, int CN, bool BWD>
+template <int CK, int CN, bool BWD, int RT>
 __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __restrict__ src,
                                                              const float* __restrict__ src_centre, int64_t n_src,
                                                              const int32_t* __restrict__ tbl,
@@ -185,14 +185,14 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
   constexpr int V = (CK >= 16) ? 4 : CK / 4;
   constexpr int NCH = CK / (4 * V);
   constexpr int NT = (CN + 15) / 16;
-  constexpr int RT = 2, TM = 128;
+  constexpr int TM = 64 * RT;                            // output rows per block: 4 waves x RT tiles of 16
   constexpr int NFRAG = NCH * NT * 64;                   // fragment vectors (V floats each) of one W_k image
   constexpr int BF = NFRAG * V;
   constexpr int BLD = (NFRAG + 255) / 256;               // fragment vectors staged per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* s_b = reinterpret_cast<float*>(smem);           // [2][BF]
   int* s_idx = reinterpret_cast<int*>(smem + 2 * BF * sizeof(float));  // [kv][TM]
-  unsigned* s_mask = reinterpret_cast<unsigned*>(s_idx + kv * TM);     // [4] per-wave offset masks
+  unsigned* s_mask = reinterpret_cast<unsigned*>(s_idx + kv * TM);     // [1] offsets active in this block
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
@@ -203,28 +203,22 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
   const __amdgpu_buffer_rsrc_t rs_ctr = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(src_centre ? src_centre : src), 0, (int)(n_src * CK * 4), 0x00020000);
 
-  if (tid < 4) s_mask[tid] = 0u;
+  if (tid == 0) s_mask[0] = 0u;
   __syncthreads();
-  {  // ---- phase 0: stage the pair-table slice; thread handles row r of offsets k0, k0+2, ...
-    const int r = tid & (TM - 1);
+  {  // ---- phase 0: stage the pair-table slice; thread handles row r of offsets k0, k0 + 256/TM, ...
+    const int r = tid % TM;
     const int64_t row = brow0 + r;
     const bool inb = row < n_out;
     const bool centre_only = (rep != nullptr) && inb && (rep[row] != (int32_t)row);
-    for (int k = tid >> 7; k < kv; k += 2) {
+    for (int k = tid / TM; k < kv; k += 256 / TM) {
       int v = inb ? tbl[(int64_t)k * n_out + row] : -1;
       if (centre_only && k != centre) v = -1;
       s_idx[k * TM + r] = v;
-      const unsigned long long m = __ballot(v >= 0);   // 64 consecutive rows = two compute waves
-      if (lane == 0) {
-        const int cw = (wave & 1) * 2;
-        if ((unsigned)m) atomicOr(&s_mask[cw], 1u << k);
-        if ((unsigned)(m >> 32)) atomicOr(&s_mask[cw + 1], 1u << k);
-      }
+      if (__ballot(v >= 0) != 0ULL && lane == 0) atomicOr(&s_mask[0], 1u << k);
     }
   }
   __syncthreads();
-  unsigned bmask = s_mask[0] | s_mask[1] | s_mask[2] | s_mask[3];
-  bmask = (unsigned)__builtin_amdgcn_readfirstlane((int)bmask);
+  unsigned bmask = (unsigned)__builtin_amdgcn_readfirstlane((int)s_mask[0]);
 
   f32x4 acc[RT][NT];
 #pragma unroll
@@ -280,55 +274,56 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
     }                                                                                              \
   } while (0)
 
-  // Software pipeline.  Loads of offset n+1 (W slice -> breg, gathers -> a_nxt) are issued before the MFMAs of offset n;
-  // they are consumed (LDS store / register rotate) at the TOP of the next iteration, so the MFMAs only ever read
-  // registers with no load pending and hipcc emits no vmcnt wait in front of them.
+  // Software pipeline, two offsets per trip with ping-pong register sets (A0/A1): the loads of offset n+1 (W slice ->
+  // breg, gathers -> the other A set) are issued before the MFMAs of offset n and are all UNCONDITIONAL (past the last
+  // active offset they re-load the current one), so the loop body is straight-line code and hipcc keeps counted vmcnt
+  // waits: the MFMAs never wait for the loads issued in their own half-trip.
+#define VC_MFMA(A, ACT, BUF)                                                                       \
+  do {                                                                                             \
+    const float* __restrict__ B_ = s_b + (BUF) * BF;                                               \
+    _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch) {                                           \
+      float b[NT][V];                                                                              \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                            \
+          VecLoad<V>::ld(B_ + ((ch * NT + nt) * 64 + lane) * V, b[nt]);                            \
+      _Pragma("unroll") for (int t = 0; t < RT; ++t) {                                             \
+        if (ACT[t]) {                                                                              \
+          _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                        \
+              _Pragma("unroll") for (int j = 0; j < V; ++j)                                        \
+                  acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[t][ch][j], b[nt][j], acc[t][nt], 0, 0, 0); \
+        }                                                                                          \
+      }                                                                                            \
+    }                                                                                              \
+  } while (0)
+
   if (bmask != 0u) {
-    int knext = __ffs((int)bmask) - 1;
+    int kcur = __ffs((int)bmask) - 1;
     bmask &= bmask - 1;
-    VC_LOAD_B(knext);
-    VC_GATHER_A(knext, a_nxt, act_nxt);
-    int buf = 0;
+    VC_LOAD_B(kcur);
+    VC_GATHER_A(kcur, a_cur, act_cur);
     for (;;) {
-      VC_STORE_B(buf);
-#pragma unroll
-      for (int t = 0; t < RT; ++t) {
-        act_cur[t] = act_nxt[t];
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-          for (int j = 0; j < V; ++j) a_cur[t][ch][j] = a_nxt[t][ch][j];
-      }
+      // ---- half-trip 0: consume (breg, A0 = a_cur) as offset kcur, prefetch the next into (breg, A1 = a_nxt)
+      VC_STORE_B(0);
       __syncthreads();
-      knext = bmask ? (__ffs((int)bmask) - 1) : -1;
+      const bool more0 = bmask != 0u;
+      const int k1 = more0 ? (__ffs((int)bmask) - 1) : kcur;
       bmask &= bmask - 1;
-      if (knext >= 0) {   // block-uniform (scalar) branch
-        VC_LOAD_B(knext);
-        VC_GATHER_A(knext, a_nxt, act_nxt);
-      }
-      {
-        const float* __restrict__ B = s_b + buf * BF;
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-          float b[NT][V];
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) VecLoad<V>::ld(B + ((ch * NT + nt) * 64 + lane) * V, b[nt]);
-#pragma unroll
-          for (int t = 0; t < RT; ++t) {
-            if (act_cur[t]) {  // scalar
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int j = 0; j < V; ++j)
-                  acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t][ch][j], b[nt][j], acc[t][nt], 0, 0, 0);
-            }
-          }
-        }
-      }
-      if (knext < 0) break;
-      buf ^= 1;
+      VC_LOAD_B(k1);
+      VC_GATHER_A(k1, a_nxt, act_nxt);
+      VC_MFMA(a_cur, act_cur, 0);
+      if (!more0) break;
+      // ---- half-trip 1: consume (breg, A1) as offset k1, prefetch the next into (breg, A0)
+      VC_STORE_B(1);
+      __syncthreads();
+      const bool more1 = bmask != 0u;
+      kcur = more1 ? (__ffs((int)bmask) - 1) : k1;
+      bmask &= bmask - 1;
+      VC_LOAD_B(kcur);
+      VC_GATHER_A(kcur, a_cur, act_cur);
+      VC_MFMA(a_nxt, act_nxt, 1);
+      if (!more1) break;
     }
   }
+#undef VC_MFMA
 #undef VC_LOAD_B
 #undef VC_STORE_B
 #undef VC_GATHER_A
@@ -546,6 +541,7 @@ __global__ void __launch_bounds__(256) group_sum_kernel(const float* __restrict_
 // --------------------------------------------------------------------------------------------- dispatch
 static constexpr int kRT = 2;  // 32 rows per wave, 128 rows per 256-thread block
 int g_conv_variant = 2;        // 1 = gather_gemm_kernel (per-wave loads), 2 = gather_gemm_v2_kernel (LDS-staged, pipelined)
+int g_conv_rt = 0;             // v2 row tiles per wave: 1 (64 rows/block) | 2 (128 rows/block) | 0 = heuristic
 
 template <int CK, int CN, bool BWD>
 static int launch_gg(const float* src, const float* src_centre, int64_t n_src, const int32_t* tbl, const float* w,
@@ -555,9 +551,16 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
     constexpr int V = (CK >= 16) ? 4 : CK / 4;
     constexpr int NCH = CK / (4 * V);
     constexpr int NT = (CN + 15) / 16;
-    const size_t lds = (size_t)2 * NCH * NT * 64 * V * sizeof(float) + (size_t)kv * 128 * sizeof(int) + 16;
-    hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD>), dim3((unsigned)cdiv(n_out, 128)), dim3(256), lds, st, src,
-                       src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror);
+    // finer blocks fill the last round of the grid better and raise occupancy; coarser blocks reuse W_k more
+    int rt = g_conv_rt;
+    if (rt == 0) rt = (n_out >= 400000 && CK * CN >= 2048) ? 2 : 1;
+    const size_t lds = (size_t)2 * NCH * NT * 64 * V * sizeof(float) + (size_t)kv * 64 * rt * sizeof(int) + 16;
+    if (rt == 2)
+      hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 2>), dim3((unsigned)cdiv(n_out, 128)), dim3(256), lds, st,
+                         src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror);
+    else
+      hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 1>), dim3((unsigned)cdiv(n_out, 64)), dim3(256), lds, st,
+                         src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror);
     VC_CHECK_LAUNCH("gather_gemm_v2_kernel");
     return VC_OK;
   }
@@ -654,6 +657,7 @@ extern "C" {
 
 int vc_debug_set(const char* key, int value) {
   if (key && !strcmp(key, "conv_variant")) { g_conv_variant = value; return VC_OK; }
+  if (key && !strcmp(key, "conv_rt")) { g_conv_rt = value; return VC_OK; }
   set_error("vc_debug_set: unknown key");
   return VC_EINVAL;
 }
