@@ -12,7 +12,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvirconv_hip.so")
+LIB_PATH = os.environ.get("VIRCONV_LIB", os.path.join(_HERE, "libvirconv_hip.so"))  # override: A/B builds only
 
 VC_OK, VC_EINVAL, VC_ECAPACITY, VC_EHIP = 0, -1, -2, -3
 

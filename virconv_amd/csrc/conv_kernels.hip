@@ -552,15 +552,16 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
     constexpr int NCH = CK / (4 * V);
     constexpr int NT = (CN + 15) / 16;
     // finer blocks fill the last round of the grid better and raise occupancy; coarser blocks reuse W_k more
-    int rt = g_conv_rt;
-    if (rt == 0) rt = (n_out >= 400000 && CK * CN >= 2048) ? 2 : 1;
+    // rows per block = 64 * rt.  Measured (tools/kbench.py): rt = 1 wins or ties everywhere -- the kernel is bound by
+    // L2 latency / occupancy, not by the W_k re-staging traffic: a variant looping 2/4/8 row tiles per staged W_k (W
+    // traffic and barriers / RT) was 5-60 % SLOWER because of its lower occupancy, and was removed.
+    const int rt = (g_conv_rt == 2) ? 2 : 1;
     const size_t lds = (size_t)2 * NCH * NT * 64 * V * sizeof(float) + (size_t)kv * 64 * rt * sizeof(int) + 16;
-    if (rt == 2)
-      hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 2>), dim3((unsigned)cdiv(n_out, 128)), dim3(256), lds, st,
-                         src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror);
-    else
-      hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 1>), dim3((unsigned)cdiv(n_out, 64)), dim3(256), lds, st,
-                         src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror);
+    const dim3 grid((unsigned)cdiv(n_out, (int64_t)64 * rt));
+#define VC_ARGS src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror
+    if (rt == 2) hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 2>), grid, dim3(256), lds, st, VC_ARGS);
+    else hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 1>), grid, dim3(256), lds, st, VC_ARGS);
+#undef VC_ARGS
     VC_CHECK_LAUNCH("gather_gemm_v2_kernel");
     return VC_OK;
   }
