@@ -185,7 +185,9 @@ _PLAN_STREAMS = {}
 def _plan_stream(device):
     key = torch.device(device).index
     if key not in _PLAN_STREAMS:
-        _PLAN_STREAMS[key] = torch.cuda.Stream(device=device)
+        # high priority: the plan's short index kernels (and the host waiting on their counts) must not queue behind
+        # the main stream's long conv kernels
+        _PLAN_STREAMS[key] = torch.cuda.Stream(device=device, priority=-1)
     return _PLAN_STREAMS[key]
 
 

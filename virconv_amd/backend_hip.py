@@ -163,7 +163,9 @@ class HipBackend:
             self._trace_close(rec)
         return dx
 
-    def conv_backward_weight(self, x: torch.Tensor, dy: torch.Tensor, pair_fwd: torch.Tensor, weight_shape) -> torch.Tensor:
+    def conv_backward_weight(self, x: torch.Tensor, dy: torch.Tensor, pair_fwd: torch.Tensor, weight_shape,
+                             stream: Optional[int] = None) -> torch.Tensor:
+        """`stream` (raw hipStream_t) overrides torch's current stream for the launches (the caller joins the streams)."""
         x = _need(x, torch.float32, "features")
         dy = _need(dy, torch.float32, "grad_out")
         pair_fwd = _need(pair_fwd, torch.int32, "pair_fwd")
@@ -173,7 +175,8 @@ class HipBackend:
         ws_bytes = self.lib.vc_conv_backward_weight_workspace_bytes(n_out, kv, cin, cout)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
         check(self.lib.vc_conv_backward_weight(_ptr(x), _ptr(dy), _ptr(pair_fwd), n_out, kv, cin, cout, _ptr(dw), _ptr(ws),
-                                               ws_bytes, _stream()), "vc_conv_backward_weight")
+                                               ws_bytes, _stream() if stream is None else stream),
+              "vc_conv_backward_weight")
         return dw
 
     # ------------------------------------------------------------------ projection / discard / dense

@@ -75,12 +75,19 @@ class SparseConvolution(SparseModule):
             x.indice_dict[self.indice_key] = rb
         return rb
 
-    def forward(self, x: SparseConvTensor) -> SparseConvTensor:
+    @property
+    def fusable_with_bn(self) -> bool:
+        return self.bias is None
+
+    def forward(self, x: SparseConvTensor, fuse_bn=None, fuse_relu: bool = False) -> SparseConvTensor:
         assert isinstance(x, SparseConvTensor)
         assert x.features.shape[1] == self.in_channels, "channel size mismatch"
         assert len(x.spatial_shape) == self.ndim
         rb = self._rulebook(x)
-        feats = ops.sparse_conv(x.features, self.weight, rb, self.inverse)
+        if fuse_bn is not None:
+            feats = ops.conv_bn_relu(x.features, self.weight, rb, self.inverse, fuse_bn, fuse_relu)
+        else:
+            feats = ops.sparse_conv(x.features, self.weight, rb, self.inverse)
         if self.bias is not None:
             feats = feats + self.bias
         if self.inverse:
