@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="all")
     ap.add_argument("--variant", type=int, default=0, help="gather-GEMM variant (vc_debug_set conv_variant); 0 = default")
+    ap.add_argument("--no-xcd", action="store_true", help="disable the XCD-aware block swizzle of the gather-GEMM")
     ap.add_argument("--rt", type=int, default=0, help="v2 row tiles per wave (vc_debug_set conv_rt); 0 = heuristic")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -51,6 +52,8 @@ def main():
     if args.variant:
         assert be.lib.vc_debug_set(b"conv_variant", args.variant) == 0
     assert be.lib.vc_debug_set(b"conv_rt", args.rt) == 0
+    torch.zeros(1, device=dev)
+    assert be.lib.vc_debug_set(b"xcd_swizzle_off", 1 if args.no_xcd else 0) == 0
     batch = bench.make_batch(list(range(args.bs)), dev, training=True)
     idx = batch["voxel_coords"].int()
     shape = [int(v) for v in (np.asarray(synth.GRID_SIZE)[::-1] + [1, 0, 0])]

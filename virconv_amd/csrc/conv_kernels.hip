@@ -14,6 +14,7 @@
 namespace vc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ int g_xcd_swizzle_off = 0;  // developer switch (tools/kbench.py --no-xcd)
 
 template <int V>
 struct VecLoad;
@@ -196,7 +197,16 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
-  const int64_t brow0 = (int64_t)blockIdx.x * TM;
+  // XCD-aware block -> row-range mapping: the dispatcher places block b on XCD b % 8 (each XCD has its own 4 MiB L2).
+  // Give every XCD one CONTIGUOUS eighth of the rows so that the rows gathered by neighbouring blocks (same (y,z)
+  // neighbourhood) are served by the same L2 instead of being fetched eight times.  Bijective for any grid size.
+  int64_t lbid;
+  {
+    const unsigned nb = gridDim.x, bid = blockIdx.x, xcd = bid & 7u, qd = nb >> 3, rm = nb & 7u;
+    lbid = (int64_t)(xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    if (g_xcd_swizzle_off) lbid = bid;
+  }
+  const int64_t brow0 = lbid * TM;
 
   const __amdgpu_buffer_rsrc_t rs_src =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)(n_src * CK * 4), 0x00020000);
@@ -379,9 +389,12 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
   int* qi = q_in[wave];
   int* qo = q_out[wave];
   int qlen = 0;
+  int v_next = (wstart + lane < wend) ? tbl[(int64_t)k * n_out + wstart + lane] : -1;
   for (int64_t base = wstart; base < wend; base += 64) {
     const int64_t r = base + lane;
-    const int v = (r < wend) ? tbl[(int64_t)k * n_out + r] : -1;
+    const int v = v_next;
+    // prefetch the next 64 table entries: their latency hides under the gathers / MFMAs of this batch
+    v_next = (r + 64 < wend) ? tbl[(int64_t)k * n_out + r + 64] : -1;
     const bool valid = v >= 0;
     const unsigned long long m = __ballot(valid);
     if (m == 0ULL) continue;
@@ -659,6 +672,9 @@ extern "C" {
 int vc_debug_set(const char* key, int value) {
   if (key && !strcmp(key, "conv_variant")) { g_conv_variant = value; return VC_OK; }
   if (key && !strcmp(key, "conv_rt")) { g_conv_rt = value; return VC_OK; }
+  if (key && !strcmp(key, "xcd_swizzle_off")) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_swizzle_off), &value, sizeof(int)) == hipSuccess ? VC_OK : VC_EHIP;
+  }
   set_error("vc_debug_set: unknown key");
   return VC_EINVAL;
 }
