@@ -108,10 +108,22 @@ def cpu_baseline(sample_frames=1, repeats=1):
                       f"{repeats} timed step(s) of {dt:.2f} s after 1 warm-up"}
 
 
+def _pmc_traffic(tdir, tck, tcn):
+    """HBM bytes per launch of the traced kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected in separate
+    runs of this same command and corrected as MI355X_MICROARCH.md prescribes; summary committed under profiles/).
+    PMC counters cannot be read from inside the process, so the number comes from that file; None if absent."""
+    path = os.path.join(ROOT, "profiles", f"r01_traffic_gather_gemm_{tck}_{tcn}_{tdir}.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["hbm_bytes_per_launch_corrected"])
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch-size", type=int, default=4, help="frames per GPU (BASELINE config 3: bs=4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -172,8 +184,8 @@ def main():
         byts = sum(e["bytes"] for e in trace)
         ach = flops / (t_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-                "kernel": f"gather_gemm_kernel<CK={tck},CN={tcn},BWD={'true' if tdir == 'bwd' else 'false'}>",
+                "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": _pmc_traffic(tdir, tck, tcn),
+                "kernel": f"gather_gemm_v2_kernel<CK={tck},CN={tcn},BWD={'true' if tdir == 'bwd' else 'false'},RT=1>",
                 "launches": n_launch, "avg_us": round(t_ms / n_launch * 1e3, 2),
                 "algorithmic_gflop_per_launch": round(flops / n_launch / 1e9, 4),
                 "algorithmic_mb_per_launch": round(byts / n_launch / 1e6, 3),

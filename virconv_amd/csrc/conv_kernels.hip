@@ -291,16 +291,16 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
 #define VC_MFMA(A, ACT, BUF)                                                                       \
   do {                                                                                             \
     const float* __restrict__ B_ = s_b + (BUF) * BF;                                               \
-    _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch) {                                           \
-      float b[NT][V];                                                                              \
-      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                            \
-          VecLoad<V>::ld(B_ + ((ch * NT + nt) * 64 + lane) * V, b[nt]);                            \
-      _Pragma("unroll") for (int t = 0; t < RT; ++t) {                                             \
-        if (ACT[t]) {                                                                              \
-          _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                        \
-              _Pragma("unroll") for (int j = 0; j < V; ++j)                                        \
-                  acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[t][ch][j], b[nt][j], acc[t][nt], 0, 0, 0); \
-        }                                                                                          \
+    float b[NCH][NT][V];                                                                           \
+    _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                             \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                          \
+            VecLoad<V>::ld(B_ + ((ch * NT + nt) * 64 + lane) * V, b[ch][nt]);                      \
+    _Pragma("unroll") for (int t = 0; t < RT; ++t) {                                               \
+      if (ACT[t]) {                                                                                \
+        _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                         \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                      \
+                _Pragma("unroll") for (int j = 0; j < V; ++j)                                      \
+                    acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[t][ch][j], b[ch][nt][j], acc[t][nt], 0, 0, 0); \
       }                                                                                            \
     }                                                                                              \
   } while (0)
