@@ -123,8 +123,8 @@ def _pmc_traffic(tdir, tck, tcn):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=15)
     ap.add_argument("--batch-size", type=int, default=4, help="frames per GPU (BASELINE config 3: bs=4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--trace", default="fwd,64,32", help="gather-GEMM instantiation timed for the roofline: dir,CK,CN")
