@@ -23,6 +23,11 @@ import os
 import sys
 import time
 
+# Must be set before the HIP runtime initialises.  The step uses 3 streams (main, geometry plan, dW side stream); with an
+# RCCL communicator alive and the default 4 hardware queues the plan stream's count reads stall behind other queues
+# (10.8 vs 7.9 ms/step measured, 16.4 ms with 8 queues); 3 queues is best with and without RCCL.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
+
 import numpy as np
 import torch
 
@@ -66,7 +71,7 @@ def make_loss_weights(device):
     return w
 
 
-def train_step(model, optimizer, batch, lw):
+def train_step(model, optimizer, batch, lw, grad_sync=None):
     """fwd + bwd + Adam.  loss = (out.dense()*G).sum() + sum_i (x_conv_i.features * g_i).sum()  (heads out of scope)."""
     optimizer.zero_grad(set_to_none=True)
     bd = dict(batch)
@@ -76,6 +81,8 @@ def train_step(model, optimizer, batch, lw):
     for name, t in out["multi_scale_3d_features"].items():
         loss = loss + (t.features * lw[name]).sum()
     loss.backward()
+    if grad_sync is not None:
+        grad_sync()  # data-parallel exchange: one flat RCCL all-reduce of the gradients
     torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)  # train_utils.py:50
     optimizer.step()
     return loss
@@ -143,7 +150,9 @@ def main():
     torch.manual_seed(0)
     model = VirConvL8x(MODEL_CFG, input_channels=8, grid_size=synth.GRID_SIZE).to(device)
     model.train()
-    ddp = parallel.wrap_ddp(model, device)
+    use_torch_ddp = os.environ.get("VIRCONV_TORCH_DDP") == "1"   # stock DistributedDataParallel instead (slower here)
+    ddp = parallel.wrap_ddp(model, device) if use_torch_ddp else model
+    grad_sync = None if use_torch_ddp else parallel.FlatGradAllReduce(model)
     optimizer = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01)
     lw = make_loss_weights(device)
     torch.manual_seed(100 + rank)  # layer-discard permutations
@@ -158,7 +167,7 @@ def main():
     del prime
 
     for _ in range(args.warmup):
-        train_step(ddp, optimizer, batch, lw)
+        train_step(ddp, optimizer, batch, lw, grad_sync)
 
     tdir, tck, tcn = args.trace.split(",")
     be.trace_begin(tdir, int(tck), int(tcn))
@@ -166,7 +175,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        train_step(ddp, optimizer, batch, lw)
+        train_step(ddp, optimizer, batch, lw, grad_sync)
     torch.cuda.synchronize()
     parallel.barrier()
     dt = time.perf_counter() - t0

@@ -10,13 +10,24 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
-from virconv_amd import synth  # noqa: E402
+from virconv_amd import parallel, synth  # noqa: E402
 from virconv_amd.backbone import VirConvL8x  # noqa: E402
 
+parallel.init_distributed()
 dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
 batch = bench.make_batch([0, 1, 2, 3], dev, True)
 model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).to(dev).train()
-opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01)
+raw = model
+import os as _os
+gs = None
+if _os.environ.get('VIRCONV_TORCH_DDP') == '1':
+    model = parallel.wrap_ddp(model, dev)
+else:
+    gs = parallel.FlatGradAllReduce(model)
+_ts = bench.train_step
+bench.train_step = lambda m, o, b, l: _ts(m, o, b, l, gs)
+opt = torch.optim.AdamW(raw.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01)
 lw = bench.make_loss_weights(dev)
 torch.cuda.synchronize()
 batch["inputs_ready_event"] = torch.cuda.Event()

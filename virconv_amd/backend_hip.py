@@ -41,6 +41,8 @@ class HipBackend:
 
     def __init__(self):
         self.lib = _lib.load()
+        self._pinned = None
+        self._pin_ev = None
         self._trace = None      # (direction, CK, CN) of the gather-GEMM instantiation being timed, or None
         self._trace_log = []
 
@@ -80,6 +82,19 @@ class HipBackend:
         rec["end"].record()
         self._trace_log.append(rec)
 
+    def _read_count(self, dev_scalar: torch.Tensor) -> int:
+        """Device int32 -> host: async copy into a pinned slot, then POLL the event.  (A blocking .item() goes through
+        pageable-memory staging + a blocking stream sync; with an RCCL communicator alive in the process that costs
+        ~0.8 ms instead of ~0.25 ms -- measured, 4 reads per step.)"""
+        if self._pinned is None:
+            self._pinned = torch.empty((16,), dtype=torch.int32).pin_memory()
+            self._pin_ev = torch.cuda.Event()
+        self._pinned[:1].copy_(dev_scalar, non_blocking=True)
+        self._pin_ev.record()
+        while not self._pin_ev.query():
+            pass
+        return int(self._pinned[0])
+
     # ------------------------------------------------------------------ rulebooks
     def subm_rulebook(self, indices: torch.Tensor, spatial_shape: Sequence[int], ksize, dilation, want_rep: bool):
         """-> pair_fwd (KV, N) int32, rep (N,) int32 or None."""
@@ -115,7 +130,7 @@ class HipBackend:
         ks, sd, pd, dl = i32arr(ksize), i32arr(stride), i32arr(padding), i32arr(dilation)
         check(self.lib.vc_spconv_mark_count(_ptr(indices), n, ndim, batch_size, oshp, ks, sd, pd, dl, _ptr(ws), ws_bytes,
                                             _ptr(n_out_dev), st), "vc_spconv_mark_count")
-        n_out = int(n_out_dev.item())  # the one host sync of a strided conv (data-dependent output size)
+        n_out = self._read_count(n_out_dev)  # the one host sync of a strided conv (data-dependent output size)
         out_indices = torch.empty((n_out, ndim + 1), dtype=torch.int32, device=dev)
         pair_fwd = torch.empty((kv, n_out), dtype=torch.int32, device=dev)
         pair_bwd = torch.empty((kv, n), dtype=torch.int32, device=dev)
@@ -264,7 +279,7 @@ class HipBackend:
         check(self.lib.vc_voxelize_mean(_ptr(points), p, f, f32arr(pc_range), f32arr(voxel_size), max_points, max_voxels,
                                         1 if vfe_max_last else 0, _ptr(ws), ws_bytes, _ptr(feats), _ptr(coords),
                                         _ptr(num), _ptr(nv), _stream()), "vc_voxelize_mean")
-        m = int(nv.item())
+        m = self._read_count(nv)
         return feats[:m], coords[:m], num[:m]
 
     # ------------------------------------------------------------------ BatchNorm(+ReLU)
