@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, mode="ddp"):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -48,10 +48,15 @@ def _worker(rank, world, port, out_dir):
              "calib": [full["calib"][mine[0]]], "aug_param": full["aug_param"][mine[0]:mine[0] + 1]}
     model = VirConvL8x(dict(MODEL_CFG, LAYER_DISCARD_MODE="spconv2_noop"), 8, GRID).train()
     fill_parameters(model, 7 + rank)          # deliberately different: DDP must broadcast rank 0's parameters
-    ddp = parallel.wrap_ddp(model, "cpu")
+    if mode == "ddp":
+        ddp, sync = parallel.wrap_ddp(model, "cpu"), None
+    else:  # the exchange bench.py uses: one flat all-reduce of the packed gradients
+        ddp, sync = model, parallel.FlatGradAllReduce(model)
     out = ddp(batch)
     loss = out["encoded_spconv_tensor"].features.square().mean() + out["multi_scale_3d_features"]["x_conv2"].features.mean()
     loss.backward()
+    if sync is not None:
+        sync()
     grads = {k: p.grad.clone() for k, p in model.named_parameters()}
     w0 = model.vir_conv1.d3_conv1[0].weight.detach().clone()
     torch.save({"grads": grads, "w0": w0, "loss": float(loss)}, os.path.join(out_dir, f"rank{rank}.pt"))
@@ -83,9 +88,10 @@ def _single(frame):
 
 
 @pytest.mark.timeout(600)
-def test_ddp_world2_gloo_grad_allreduce(tmp_path):
+@pytest.mark.parametrize("mode", ["ddp", "flat"])
+def test_ddp_world2_gloo_grad_allreduce(tmp_path, mode):
     world, port = 2, _free_port()
-    mp.start_processes(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    mp.start_processes(_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True, start_method="spawn")
     r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
     r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
     assert torch.equal(r0["w0"], r1["w0"])  # parameters were broadcast from rank 0
