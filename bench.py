@@ -115,6 +115,37 @@ def cpu_baseline(sample_frames=1, repeats=1):
                       f"{repeats} timed step(s) of {dt:.2f} s after 1 warm-up"}
 
 
+def run_infer(args, model, batch, device, rank, world):
+    """BASELINE configs[1]: VirConv-L forward only, eval mode (no discard), `--batch-size` frames per GPU (1 in the config)."""
+    model.eval()
+
+    def step():
+        bd = dict(batch)
+        bd["voxel_features"] = batch["voxel_features"].clone()
+        with torch.no_grad():
+            out = model(bd)
+            return out["encoded_spconv_tensor"].dense()
+
+    for _ in range(args.warmup):
+        step()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, device)
+    if rank == 0:
+        bs = args.batch_size
+        print(json.dumps({"metric": "KITTI frames/sec (forward only) VirConv-L backbone", "value": round(bs * world * args.steps / dt, 3),
+                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "BASELINE configs[1]: VirConv-L forward only, eval mode, + dense()",
+                                     "frames_per_gpu": bs, "voxels_rank0": int(batch["voxel_features"].shape[0])}}), flush=True)
+
+
 def _pmc_traffic(tdir, tck, tcn):
     """HBM bytes per launch of the traced kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected in separate
     runs of this same command and corrected as MI355X_MICROARCH.md prescribes; summary committed under profiles/).
@@ -134,6 +165,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=15)
     ap.add_argument("--batch-size", type=int, default=4, help="frames per GPU (BASELINE config 3: bs=4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="train", choices=["train", "infer"],
+                    help="train = BASELINE configs[2] (default, the headline metric); infer = configs[1]: forward only, eval mode")
     ap.add_argument("--trace", default="fwd,64,32", help="gather-GEMM instantiation timed for the roofline: dir,CK,CN")
     args = ap.parse_args()
 
@@ -165,6 +198,9 @@ def main():
     # tensor sizes differ from step to step and the first steps would otherwise pay hipMalloc for every new size.
     prime = [torch.empty((1 << 30,), dtype=torch.uint8, device=device) for _ in range(8)]
     del prime
+
+    if args.mode == "infer":
+        return run_infer(args, model, batch, device, rank, world)
 
     for _ in range(args.warmup):
         train_step(ddp, optimizer, batch, lw, grad_sync)
