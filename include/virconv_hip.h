@@ -107,9 +107,12 @@ size_t vc_conv_backward_weight_workspace_bytes(int64_t n_out, int kv, int cin, i
 int vc_conv_backward_weight(const float* x, const float* dy, const int32_t* pair_fwd, int64_t n_out, int kv,
                             int cin, int cout, float* dweight, void* ws, size_t ws_bytes, void* stream);
 
-/* dy_grp[rep[i], :] += dy[i, :]  (dy_grp zeroed here first; fp32 atomics -- only used by the duplicate-coordinate
- * SubM backward; order of summation inside a pixel group is not fixed).                                         */
-int vc_group_sum(const float* dy, const int32_t* rep, int64_t n, int c, float* dy_grp, void* stream);
+/* dy_grp[rep[i], :] = sum over the rows i sharing representative rep[i] of dy[i, :]  (rows that are nobody's
+ * representative get 0).  Only used by the duplicate-coordinate SubM backward.  Bit-stable: the sum is carried in
+ * 64-bit fixed point scaled by the tensor's max |dy| (integer adds are associative), then rounded once to fp32.       */
+size_t vc_group_sum_workspace_bytes(int64_t n, int c);
+int vc_group_sum(const float* dy, const int32_t* rep, int64_t n, int c, float* dy_grp, void* ws, size_t ws_bytes,
+                 void* stream);
 
 /* ------------------------------------------------------------------------------------------------ K9 projection
  * Voxel index -> image pixel index.  Replaces index2points + index2uv +

@@ -66,7 +66,7 @@ class OracleBackend:
             dx.index_add_(0, torch.from_numpy(rows.astype(np.int64)), g @ wk[k].t())
         return dx
 
-    def conv_backward_weight(self, x, dy, pair_fwd, weight_shape, stream=None):
+    def conv_backward_weight(self, x, dy, pair_fwd, weight_shape, stream=None, keep_alive=None):
         w0 = x.new_zeros(tuple(weight_shape))
         _, dw = sparse_ref.conv_backward(x.detach(), w0, _np(pair_fwd), dy.detach())
         return dw

@@ -123,3 +123,33 @@ def test_fullsize_backbone_eval_vs_oracle_and_deterministic(hip_backend, frame_b
     a, b = o1["encoded_spconv_tensor"], oc["encoded_spconv_tensor"]
     assert torch.equal(a.indices.cpu(), b.indices)
     assert float((a.features.cpu() - b.features).abs().max()) < 1e-4 * max(1.0, float(b.features.abs().max()))
+
+
+def test_fullsize_train_step_gradients_are_bitwise_deterministic(hip_backend):
+    """Whole VirConv-L forward + backward (2-D branch, injected layer-discard permutations) twice: every gradient bit-equal."""
+    b1 = bench.make_batch([0], torch.device("cuda", 0), training=True)
+    torch.manual_seed(3)
+    model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).cuda().train()
+    lw = bench.make_loss_weights("cuda")
+
+    def run(keeps):
+        model.zero_grad(set_to_none=True)
+        bd = dict(b1)
+        bd["voxel_features"] = b1["voxel_features"].clone()
+        if keeps is not None:
+            bd["layer_discard_keep"] = keeps
+        torch.manual_seed(5)
+        out = model(bd)
+        loss = (out["encoded_spconv_tensor"].dense() * lw["dense"]).sum()
+        for name, t in out["multi_scale_3d_features"].items():
+            loss = loss + (t.features * lw[name]).sum()
+        loss.backward()
+        return float(loss.detach()), {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    bn_state = {k: v.clone() for k, v in model.state_dict().items()}
+    l1, g1 = run(None)
+    model.load_state_dict(bn_state)  # BN running stats back to the same start
+    l2, g2 = run(None)               # same torch seed => same device randperm
+    assert l1 == l2
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k

@@ -277,3 +277,25 @@ def test_voxelize_mean_vs_oracle(hip_backend, max_voxels):
     np.testing.assert_array_equal(c.cpu().numpy(), cref)
     np.testing.assert_array_equal(num.cpu().numpy(), nref)
     np.testing.assert_allclose(f.cpu().numpy(), fref, rtol=0, atol=1e-6)
+
+
+def test_duplicate_pixel_backward_is_bitwise_deterministic(hip_backend):
+    """The group sum of the duplicate-coordinate SubM backward is carried in 64-bit fixed point: re-runs are bit-equal
+    even with thousands of rows clamped onto one border pixel."""
+    rng = np.random.default_rng(21)
+    shape = (160, 60)
+    idx = _indices2(11, 20000, dup=True)
+    idx[:6000, 1:] = 0  # a huge group on one pixel (what out-of-frustum voxels do)
+    n = idx.shape[0]
+    it = torch.from_numpy(idx).cuda()
+    pair, rep = hip_backend.subm_rulebook(it, shape, (3, 3), (1, 1), want_rep=True)
+    w = torch.from_numpy((rng.standard_normal((32, 3, 3, 32)) / 17).astype(np.float32)).cuda()
+    g = torch.from_numpy((rng.standard_normal((n, 32)) * 1e-3).astype(np.float32)).cuda()
+    a = hip_backend.conv_backward_input(g, w, pair, n, mirror=True, centre=4, rep=rep)
+    for _ in range(3):
+        assert torch.equal(a, hip_backend.conv_backward_input(g, w, pair, n, mirror=True, centre=4, rep=rep))
+    pref = sparse_ref.subm_rulebook(idx, shape, (3, 3))
+    dx_ref, _ = sparse_ref.conv_backward(torch.zeros((n, 32), dtype=torch.float64), w.cpu().double(), pref, g.cpu().double())
+    assert _rel_err(a.cpu().numpy(), dx_ref.numpy()) < TOL
+    z = hip_backend.conv_backward_input(torch.zeros_like(g), w, pair, n, mirror=True, centre=4, rep=rep)
+    assert float(z.abs().max()) == 0.0  # all-zero gradient: scale 0 path

@@ -33,7 +33,8 @@ SIGNATURES = {
     "vc_conv_backward_input": (_I, [_P, _P, _I64, _P, _I64, _I, _P, _I, _I, _I, _I, _P, _P, _P]),
     "vc_conv_backward_weight_workspace_bytes": (_SZ, [_I64, _I, _I, _I]),
     "vc_conv_backward_weight": (_I, [_P, _P, _P, _I64, _I, _I, _I, _P, _P, _SZ, _P]),
-    "vc_group_sum": (_I, [_P, _P, _I64, _I, _P, _P]),
+    "vc_group_sum_workspace_bytes": (_SZ, [_I64, _I]),
+    "vc_group_sum": (_I, [_P, _P, _I64, _I, _P, _P, _SZ, _P]),
     "vc_project_prepare": (_I, [_P, _P, _I, _P, _P]),
     "vc_project_uv": (_I, [_P, _I64, _P, _I, _I, _P, _P, _P]),
     "vc_gather_rows": (_I, [_P, _P, _I, _I, _P, _I64, _P, _P, _P]),

@@ -168,7 +168,10 @@ class HipBackend:
         if rep is not None:
             rep = _need(rep, torch.int32, "rep")
             grp = torch.empty_like(dy)
-            check(self.lib.vc_group_sum(_ptr(dy), _ptr(rep), dy.shape[0], cout, _ptr(grp), _stream()), "vc_group_sum")
+            gws_bytes = self.lib.vc_group_sum_workspace_bytes(dy.shape[0], cout)
+            gws = torch.empty((gws_bytes,), dtype=torch.uint8, device=dy.device)
+            check(self.lib.vc_group_sum(_ptr(dy), _ptr(rep), dy.shape[0], cout, _ptr(grp), _ptr(gws), gws_bytes, _stream()),
+                  "vc_group_sum")
             src, src_centre = grp, dy
         rec = self._trace_open(tbl, dy.shape[0], cout, cin) if self._traced("bwd", cout, cin) else None
         check(self.lib.vc_conv_backward_input(_ptr(src), _ptr(src_centre), dy.shape[0], _ptr(tbl), n_in, kv, _ptr(weight),
@@ -179,8 +182,11 @@ class HipBackend:
         return dx
 
     def conv_backward_weight(self, x: torch.Tensor, dy: torch.Tensor, pair_fwd: torch.Tensor, weight_shape,
-                             stream: Optional[int] = None) -> torch.Tensor:
-        """`stream` (raw hipStream_t) overrides torch's current stream for the launches (the caller joins the streams)."""
+                             stream: Optional[int] = None, keep_alive: Optional[list] = None) -> torch.Tensor:
+        """`stream` (raw hipStream_t) overrides torch's current stream for the launches; the caller joins the streams and
+        MUST pass `keep_alive`: the scratch buffer is appended to it so that torch's allocator (which only knows about the
+        current stream) cannot hand its memory to another tensor before the join."""
+        assert stream is None or keep_alive is not None
         x = _need(x, torch.float32, "features")
         dy = _need(dy, torch.float32, "grad_out")
         pair_fwd = _need(pair_fwd, torch.int32, "pair_fwd")
@@ -192,6 +198,8 @@ class HipBackend:
         check(self.lib.vc_conv_backward_weight(_ptr(x), _ptr(dy), _ptr(pair_fwd), n_out, kv, cin, cout, _ptr(dw), _ptr(ws),
                                                ws_bytes, _stream() if stream is None else stream),
               "vc_conv_backward_weight")
+        if keep_alive is not None:
+            keep_alive.extend((ws, x, dy, pair_fwd))
         return dw
 
     # ------------------------------------------------------------------ projection / discard / dense

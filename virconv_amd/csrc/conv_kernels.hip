@@ -521,34 +521,66 @@ __global__ void __launch_bounds__(256) bwd_weight_reduce_kernel(const float* __r
 }
 
 // --------------------------------------------------------------------------------------------- group sum (dup path)
+// Bit-stable group sum.  fp32 atomics would make the result depend on the arrival order of a pixel's rows, so the sum is
+// carried in 64-bit FIXED POINT: integer addition is associative, hence any arrival order gives the same bits.
+//   scale = 2^(40 - exponent(max|dy|))  =>  |q| <= 2^40 per addend, up to 2^22 addends fit in int64, and the quantisation
+//   step is max|dy| * 2^-40 (2^-16 of an fp32 ulp of the largest element): more accurate than fp32 accumulation.
 // thread = (chunk of kGsRows consecutive rows, channel): consecutive rows that share a representative (very common: the
 // voxels outside the camera frustum all clamp onto border pixels) are summed in registers and flushed with ONE atomic
 // per run, which removes almost all same-address contention.
 static constexpr int kGsRows = 32;
-__global__ void __launch_bounds__(256) group_sum_kernel(const float* __restrict__ dy, const int32_t* __restrict__ rep,
-                                                        int64_t n, int c, float* __restrict__ grp) {
+
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));  // non-negative floats order like their bit patterns
+}
+
+__device__ __forceinline__ double gs_scale(unsigned absmax_bits) {
+  const float am = __uint_as_float(absmax_bits);
+  if (!(am > 0.f) || !isfinite(am)) return 0.0;
+  int e;
+  frexpf(am, &e);                 // am = f * 2^e, f in [0.5, 1)
+  return ldexp(1.0, 40 - e);      // |x| * scale < 2^40
+}
+
+__global__ void __launch_bounds__(256) group_sum_fixed_kernel(const float* __restrict__ dy, const int32_t* __restrict__ rep,
+                                                              int64_t n, int c, const unsigned* __restrict__ absmax,
+                                                              long long* __restrict__ acc_out) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t chunk = t / c;
   const int ch = (int)(t - chunk * c);
   const int64_t r0 = chunk * kGsRows;
   if (r0 >= n) return;
+  const double scale = gs_scale(*absmax);
   const int64_t r1 = min(r0 + (int64_t)kGsRows, n);
   int cur = rep[r0];
   if (cur < 0) cur = (int)r0;
-  float acc = dy[r0 * c + ch];
+  long long acc = __double2ll_rn((double)dy[r0 * c + ch] * scale);
   for (int64_t r = r0 + 1; r < r1; ++r) {
     int g = rep[r];
     if (g < 0) g = (int)r;
-    const float v = dy[r * c + ch];
+    const long long v = __double2ll_rn((double)dy[r * c + ch] * scale);
     if (g != cur) {
-      unsafeAtomicAdd(&grp[(int64_t)cur * c + ch], acc);
+      atomicAdd((unsigned long long*)&acc_out[(int64_t)cur * c + ch], (unsigned long long)acc);
       cur = g;
       acc = v;
     } else {
       acc += v;
     }
   }
-  unsafeAtomicAdd(&grp[(int64_t)cur * c + ch], acc);
+  atomicAdd((unsigned long long*)&acc_out[(int64_t)cur * c + ch], (unsigned long long)acc);
+}
+
+__global__ void __launch_bounds__(256) group_sum_convert_kernel(const long long* __restrict__ acc, int64_t total,
+                                                                const unsigned* __restrict__ absmax,
+                                                                float* __restrict__ grp) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const double scale = gs_scale(*absmax);
+  grp[e] = (scale > 0.0) ? (float)((double)acc[e] / scale) : 0.f;
 }
 
 // --------------------------------------------------------------------------------------------- dispatch
@@ -729,15 +761,31 @@ int vc_conv_backward_weight(const float* x, const float* dy, const int32_t* pair
   return VC_EINVAL;
 }
 
-int vc_group_sum(const float* dy, const int32_t* rep, int64_t n, int c, float* dy_grp, void* stream) {
+size_t vc_group_sum_workspace_bytes(int64_t n, int c) {
+  if (n < 0 || c < 1) return 0;
+  return (size_t)n * c * sizeof(long long) + 64;
+}
+
+int vc_group_sum(const float* dy, const int32_t* rep, int64_t n, int c, float* dy_grp, void* ws, size_t ws_bytes,
+                 void* stream) {
   VC_REQUIRE(n >= 0 && c > 0, "vc_group_sum: invalid argument");
   if (n == 0) return VC_OK;
-  VC_REQUIRE(dy && rep && dy_grp, "vc_group_sum: null argument");
+  VC_REQUIRE(dy && rep && dy_grp && ws, "vc_group_sum: null argument");
+  if (ws_bytes < vc_group_sum_workspace_bytes(n, c)) { set_error("vc_group_sum: workspace too small"); return VC_ECAPACITY; }
   hipStream_t st = (hipStream_t)stream;
-  VC_CHECK_HIP(hipMemsetAsync(dy_grp, 0, (size_t)n * c * 4, st));
-  hipLaunchKernelGGL(group_sum_kernel, dim3((unsigned)cdiv(cdiv(n, kGsRows) * c, 256)), dim3(256), 0, st, dy, rep, n, c,
-                     dy_grp);
-  VC_CHECK_LAUNCH("group_sum_kernel");
+  unsigned* absmax = (unsigned*)ws;                 // [0..63] header, then the int64 accumulators
+  long long* acc = (long long*)((char*)ws + 64);
+  const int64_t total = n * c;
+  VC_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)total * sizeof(long long) + 64, st));
+  int64_t nb = cdiv(total, 256 * 8);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)nb), dim3(256), 0, st, dy, total, absmax);
+  VC_CHECK_LAUNCH("absmax_kernel");
+  hipLaunchKernelGGL(group_sum_fixed_kernel, dim3((unsigned)cdiv(cdiv(n, kGsRows) * c, 256)), dim3(256), 0, st, dy, rep, n, c,
+                     absmax, acc);
+  VC_CHECK_LAUNCH("group_sum_fixed_kernel");
+  hipLaunchKernelGGL(group_sum_convert_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, acc, total, absmax, dy_grp);
+  VC_CHECK_LAUNCH("group_sum_convert_kernel");
   return VC_OK;
 }
 

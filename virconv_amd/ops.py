@@ -123,11 +123,13 @@ def _conv_backward(rb: "Rulebook", inverse: bool, features, weight, grad_out, ne
     tbl_w = rb.pair_bwd if inverse else rb.pair_fwd
     side = _side_stream(grad_out.device) if (OVERLAP_WEIGHT_GRAD and need_dx and need_dw and grad_out.is_cuda) else None
     if side is not None:
-        # buffers are allocated on the main stream; the join below orders every later reuse after the side stream's
-        # work, so no record_stream bookkeeping is needed
+        # buffers are allocated on the main stream and kept referenced until the join below, which orders every later
+        # reuse after the side stream's work (no record_stream bookkeeping needed)
         main = torch.cuda.current_stream()
         side.wait_stream(main)
-        dw = be.conv_backward_weight(features, grad_out, tbl_w, tuple(weight.shape), stream=side.cuda_stream)
+        alive = []  # scratch + operands of the side-stream launch stay referenced until the join
+        dw = be.conv_backward_weight(features, grad_out, tbl_w, tuple(weight.shape), stream=side.cuda_stream,
+                                     keep_alive=alive)
     if need_dx:
         if inverse:
             dx = be.conv_backward_input(grad_out, weight, rb.pair_fwd, rb.n_out, mirror=False)
@@ -137,6 +139,7 @@ def _conv_backward(rb: "Rulebook", inverse: bool, features, weight, grad_out, ne
             dx = be.conv_backward_input(grad_out, weight, rb.pair_bwd, rb.n_in, mirror=False)
     if side is not None:
         main.wait_stream(side)
+        del alive
     elif need_dw:
         dw = be.conv_backward_weight(features, grad_out, tbl_w, tuple(weight.shape))
     return dx, dw
