@@ -92,12 +92,22 @@ int vc_spconv_emit_pairs(const int32_t* indices, int64_t n, int ndim, int batch_
  *   Duplicate-coordinate SubM backward (2-D image-space branch): src_centre = dy is used for the
  *   centre tap, src = group-summed dy (vc_group_sum) for the others, and rows with rep[o] != o take the centre
  *   tap only.  Pass centre = -1, rep = NULL, src_centre = NULL when not needed.
+ *   row_order (optional, NULL = natural order): a permutation of [0, n_out) from vc_row_order; tile slot s computes output
+ *   row row_order[s].  A pure scheduling hint -- results are bit-identical with and without it.
  * Replaces spconv ops.implicit_gemm / indice_conv fwd and bwd-input (autograd of spconv_backbone.py:89-125).   */
 int vc_conv_forward(const float* x, int64_t n_in, const int32_t* pair_fwd, int64_t n_out, int kv,
-                    const float* weight, int cin, int cout, float* y, void* stream);
+                    const float* weight, int cin, int cout, const int32_t* row_order, float* y, void* stream);
 int vc_conv_backward_input(const float* dy, const float* dy_centre, int64_t n_src, const int32_t* tbl,
                            int64_t n_in, int kv, const float* weight, int cin, int cout, int mirror, int centre,
-                           const int32_t* rep, float* dx, void* stream);
+                           const int32_t* rep, const int32_t* row_order, float* dx, void* stream);
+
+/* Row permutation that makes the gather-GEMM's 16-row tiles homogeneous: within each window of `window` (1024 | 2048 |
+ * 4096) consecutive rows of `tbl` (KV, n) the rows are stably sorted by their active-offset bit mask (bit k set <=> tbl[k, r] >= 0; rows with
+ * rep[r] != r count as {centre} only, matching the duplicate-pixel backward).  kv <= 32.  order (n) int32.
+ * spconv's implicit-GEMM path does the equivalent with its `mask_argsort` (SURVEY §8 a7 "mask argsort"); here it is
+ * one LDS bitonic sort per window and never changes results.                                                      */
+int vc_row_order(const int32_t* tbl, int64_t n, int kv, const int32_t* rep, int centre, int window, int32_t* order,
+                 void* stream);
 
 /* ------------------------------------------------------------------------------------------------ K8 weight gradient
  * dW[:, k, :] = sum_o dy[o, :]^T (outer) x[pair_fwd[k, o], :]; wave-ballot compaction of the active pairs, MFMA

@@ -37,10 +37,13 @@ class OracleBackend:
         return torch.from_numpy(oi), oshape, torch.from_numpy(pf), torch.from_numpy(pb)
 
     # ------------------------------------------------------------------ convolution
-    def conv_forward(self, x, weight, pair_fwd):
+    def row_order(self, tbl, rep=None, centre=-1, window=1024):
+        return None  # scheduling hint of the HIP path only; results never depend on it
+
+    def conv_forward(self, x, weight, pair_fwd, order=None):
         return sparse_ref.conv_forward(x.detach(), weight.detach(), _np(pair_fwd))
 
-    def conv_backward_input(self, dy, weight, tbl, n_in, mirror, centre=-1, rep=None):
+    def conv_backward_input(self, dy, weight, tbl, n_in, mirror, centre=-1, rep=None, order=None):
         """dX of the three conv flavours, in the product's calling convention (include/virconv_hip.h).
 
         SubM (mirror=True, tbl = pair_fwd): the EXACT transpose of the forward gather,

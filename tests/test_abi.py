@@ -49,7 +49,7 @@ def test_host_side_queries_and_argument_validation_without_gpu():
     # invalid arguments are rejected with a status code + message, never exit()/abort (include/virconv_hip.h)
     st = lib.vc_hash_build(None, 10, 5, _lib.i32arr([1, 2, 3]), None, 0, None)
     assert st == _lib.VC_EINVAL and b"ndim" in lib.vc_last_error()
-    st = lib.vc_conv_forward(None, 0, None, 10, 27, None, 8, 8, None, None)
+    st = lib.vc_conv_forward(None, 0, None, 10, 27, None, 8, 8, None, None, None)
     assert st == _lib.VC_EINVAL
     st = lib.vc_gather_rows(None, None, 7, 4, None, 0, None, None, None)
     assert st == _lib.VC_EINVAL and b"multiple of 4" in lib.vc_last_error()

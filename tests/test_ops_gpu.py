@@ -299,3 +299,70 @@ def test_duplicate_pixel_backward_is_bitwise_deterministic(hip_backend):
     assert _rel_err(a.cpu().numpy(), dx_ref.numpy()) < TOL
     z = hip_backend.conv_backward_input(torch.zeros_like(g), w, pair, n, mirror=True, centre=4, rep=rep)
     assert float(z.abs().max()) == 0.0  # all-zero gradient: scale 0 path
+
+
+# ------------------------------------------------------------------------------------------------ row order (scheduling hint)
+def _masks(pair: np.ndarray, rep=None, centre=-1) -> np.ndarray:
+    m = np.zeros(pair.shape[1], np.int64)
+    for k in range(pair.shape[0]):
+        m |= (pair[k] >= 0).astype(np.int64) << k
+    if rep is not None:
+        m = np.where(rep != np.arange(rep.shape[0]), np.int64(1) << centre, m)
+    return m
+
+
+@pytest.mark.parametrize("win", [1024, 2048, 4096])
+@pytest.mark.parametrize("n", [1, 100, 4096, 4097, 9000])
+def test_row_order_is_windowed_stable_mask_sort(hip_backend, n, win):
+    idx = synth.small_scene_indices(21, n, (21, 128, 96), 2)
+    pair = sparse_ref.subm_rulebook(idx, (21, 128, 96), (3, 3, 3))
+    order = hip_backend.row_order(torch.from_numpy(pair).cuda(), window=win).cpu().numpy()
+    m = _masks(pair)
+    want = np.concatenate([s + np.argsort(m[s:s + win], kind="stable") for s in range(0, pair.shape[1], win)])
+    np.testing.assert_array_equal(order, want.astype(np.int32))
+
+
+def test_row_order_with_duplicate_pixels_uses_centre_only_rows(hip_backend):
+    idx = _indices2(3, 6000)
+    pair, rep = sparse_ref.subm_rulebook(idx, (160, 60), (3, 3)), None
+    pt = torch.from_numpy(pair).cuda()
+    _, rep_t = hip_backend.subm_rulebook(torch.from_numpy(idx).cuda(), (160, 60), (3, 3), (1, 1), want_rep=True)
+    rep = rep_t.cpu().numpy()
+    order = hip_backend.row_order(pt, rep_t, 4, window=4096).cpu().numpy()
+    m = _masks(pair, rep, 4)
+    want = np.concatenate([s + np.argsort(m[s:s + 4096], kind="stable") for s in range(0, pair.shape[1], 4096)])
+    np.testing.assert_array_equal(order, want.astype(np.int32))
+
+
+@pytest.mark.parametrize("cin,cout", [(8, 8), (32, 16), (64, 32), (64, 64)])
+def test_row_order_never_changes_conv_results(hip_backend, cin, cout):
+    """The permutation is a scheduling hint: forward / backward-input are BIT-identical with and without it, for the
+    sorted order and for an arbitrary permutation (subm, strided, duplicate-pixel 2-D)."""
+    rng = np.random.default_rng(cin + cout)
+    idx = _indices3(8, 5000)
+    n = idx.shape[0]
+    it = torch.from_numpy(idx).cuda()
+    x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.standard_normal((cout, 3, 3, 3, cin)) / 10).astype(np.float32)).cuda()
+    g = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32)).cuda()
+    pair, _ = hip_backend.subm_rulebook(it, SHAPE3, (3, 3, 3), (1, 1, 1), want_rep=False)
+    rand = torch.from_numpy(rng.permutation(n).astype(np.int32)).cuda()
+    for order in (hip_backend.row_order(pair), rand):
+        assert torch.equal(hip_backend.conv_forward(x, w, pair), hip_backend.conv_forward(x, w, pair, order=order))
+        assert torch.equal(hip_backend.conv_backward_input(g, w, pair, n, mirror=True),
+                           hip_backend.conv_backward_input(g, w, pair, n, mirror=True, order=order))
+    oi, _, pf, pb = hip_backend.sparse_rulebook(it, SHAPE3, 2, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1))
+    go = torch.from_numpy(rng.standard_normal((oi.shape[0], cout)).astype(np.float32)).cuda()
+    assert torch.equal(hip_backend.conv_forward(x, w, pf), hip_backend.conv_forward(x, w, pf, order=hip_backend.row_order(pf)))
+    assert torch.equal(hip_backend.conv_backward_input(go, w, pb, n, mirror=False),
+                       hip_backend.conv_backward_input(go, w, pb, n, mirror=False, order=hip_backend.row_order(pb)))
+    if cin == cout:
+        idx2 = torch.from_numpy(_indices2(5, 4000)).cuda()
+        n2 = idx2.shape[0]
+        p2, rep = hip_backend.subm_rulebook(idx2, (160, 60), (3, 3), (1, 1), want_rep=True)
+        w2 = torch.from_numpy((rng.standard_normal((cout, 3, 3, cin)) / 5).astype(np.float32)).cuda()
+        g2 = torch.from_numpy(rng.standard_normal((n2, cout)).astype(np.float32)).cuda()
+        a = hip_backend.conv_backward_input(g2, w2, p2, n2, mirror=True, centre=4, rep=rep)
+        b = hip_backend.conv_backward_input(g2, w2, p2, n2, mirror=True, centre=4, rep=rep,
+                                            order=hip_backend.row_order(p2, rep, 4))
+        assert torch.equal(a, b)

@@ -46,12 +46,14 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="gather-GEMM variant (vc_debug_set conv_variant); 0 = default")
     ap.add_argument("--no-xcd", action="store_true", help="disable the XCD-aware block swizzle of the gather-GEMM")
     ap.add_argument("--rt", type=int, default=0, help="v2 row tiles per wave (vc_debug_set conv_rt); 0 = heuristic")
+    ap.add_argument("--bw-legacy", action="store_true", help="offset-major block order in the weight-gradient kernel")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     be = ops.get_backend()
     if args.variant:
         assert be.lib.vc_debug_set(b"conv_variant", args.variant) == 0
     assert be.lib.vc_debug_set(b"conv_rt", args.rt) == 0
+    assert be.lib.vc_debug_set(b"bw_legacy_order", 1 if args.bw_legacy else 0) == 0
     torch.zeros(1, device=dev)
     assert be.lib.vc_debug_set(b"xcd_swizzle_off", 1 if args.no_xcd else 0) == 0
     batch = bench.make_batch(list(range(args.bs)), dev, training=True)
@@ -96,12 +98,12 @@ def main():
         byts = 4.0 * (rb.n_in * cin + rb.n_out * cout + kv * cin * cout) + 4.0 * kv * rb.n_out
         res = {}
         if args.only in ("all", "fwd"):
-            res["fwd"] = timeit(lambda: be.conv_forward(x, w, rb.pair_fwd), args.iters)
+            res["fwd"] = timeit(lambda: be.conv_forward(x, w, rb.pair_fwd, order=rb.order_fwd), args.iters)
         if args.only in ("all", "bwd"):
             if rb.kind == "subm":
-                res["bwd"] = timeit(lambda: be.conv_backward_input(dy, w, rb.pair_fwd, rb.n_in, True, rb.centre, rb.rep), args.iters)
+                res["bwd"] = timeit(lambda: be.conv_backward_input(dy, w, rb.pair_fwd, rb.n_in, True, rb.centre, rb.rep, order=rb.order_bwd), args.iters)
             else:
-                res["bwd"] = timeit(lambda: be.conv_backward_input(dy, w, rb.pair_bwd, rb.n_in, False), args.iters)
+                res["bwd"] = timeit(lambda: be.conv_backward_input(dy, w, rb.pair_bwd, rb.n_in, False, order=rb.order_bwd), args.iters)
         if args.only in ("all", "dw"):
             res["dw"] = timeit(lambda: be.conv_backward_weight(x, dy, rb.pair_fwd, w.shape), args.iters)
 
@@ -113,6 +115,8 @@ def main():
         line += (f"{f:8.1f} {tf(f):6.2f} {100 * tf(f) / PEAK:5.1f} {byts / (f * 1e-6) / 1e9:6.0f} | " if f else " " * 34 + "| ")
         line += (f"{b:8.1f} {tf(b):6.2f} {100 * tf(b) / PEAK:5.1f} | " if b else " " * 23 + "| ")
         line += (f"{d:8.1f} {tf(d):6.2f} {100 * tf(d) / PEAK:5.1f}" if d else "")
+        if ops.ROW_ORDER != "none":
+            line += f" | ord {timeit(lambda: be.row_order(rb.pair_fwd, window=ops.ROW_ORDER_WINDOW), args.iters):6.1f}"
         print(line)
         for k in ("fwd", "bwd", "dw"):
             if res.get(k):

@@ -140,7 +140,17 @@ class HipBackend:
         return out_indices, out_shape, pair_fwd, pair_bwd
 
     # ------------------------------------------------------------------ convolution
-    def conv_forward(self, x: torch.Tensor, weight: torch.Tensor, pair_fwd: torch.Tensor) -> torch.Tensor:
+    def row_order(self, tbl: torch.Tensor, rep: Optional[torch.Tensor] = None, centre: int = -1,
+                  window: int = 1024) -> torch.Tensor:
+        """(KV, n) pair table -> (n,) int32 permutation grouping rows with equal active-offset sets (vc_row_order)."""
+        kv, n = tbl.shape
+        order = torch.empty((n,), dtype=torch.int32, device=tbl.device)
+        check(self.lib.vc_row_order(_ptr(tbl), n, kv, _ptr(rep), centre if rep is not None else -1, window, _ptr(order),
+                                    _stream()), "vc_row_order")
+        return order
+
+    def conv_forward(self, x: torch.Tensor, weight: torch.Tensor, pair_fwd: torch.Tensor,
+                     order: Optional[torch.Tensor] = None) -> torch.Tensor:
         x = _need(x, torch.float32, "features")
         weight = _need(weight, torch.float32, "weight")
         pair_fwd = _need(pair_fwd, torch.int32, "pair_fwd")
@@ -149,14 +159,15 @@ class HipBackend:
         assert weight.numel() == cout * kv * cin and x.shape[1] == cin
         y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
         rec = self._trace_open(pair_fwd, x.shape[0], cin, cout) if self._traced("fwd", cin, cout) else None
-        check(self.lib.vc_conv_forward(_ptr(x), x.shape[0], _ptr(pair_fwd), n_out, kv, _ptr(weight), cin, cout, _ptr(y),
-                                       _stream()), "vc_conv_forward")
+        check(self.lib.vc_conv_forward(_ptr(x), x.shape[0], _ptr(pair_fwd), n_out, kv, _ptr(weight), cin, cout,
+                                       _ptr(order), _ptr(y), _stream()), "vc_conv_forward")
         if rec is not None:
             self._trace_close(rec)
         return y
 
     def conv_backward_input(self, dy: torch.Tensor, weight: torch.Tensor, tbl: torch.Tensor, n_in: int, mirror: bool,
-                            centre: int = -1, rep: Optional[torch.Tensor] = None) -> torch.Tensor:
+                            centre: int = -1, rep: Optional[torch.Tensor] = None,
+                            order: Optional[torch.Tensor] = None) -> torch.Tensor:
         dy = _need(dy, torch.float32, "grad_out")
         weight = _need(weight, torch.float32, "weight")
         tbl = _need(tbl, torch.int32, "pair table")
@@ -176,7 +187,7 @@ class HipBackend:
         rec = self._trace_open(tbl, dy.shape[0], cout, cin) if self._traced("bwd", cout, cin) else None
         check(self.lib.vc_conv_backward_input(_ptr(src), _ptr(src_centre), dy.shape[0], _ptr(tbl), n_in, kv, _ptr(weight),
                                               cin, cout, 1 if mirror else 0, centre if rep is not None else -1,
-                                              _ptr(rep), _ptr(dx), _stream()), "vc_conv_backward_input")
+                                              _ptr(rep), _ptr(order), _ptr(dx), _stream()), "vc_conv_backward_input")
         if rec is not None:
             self._trace_close(rec)
         return dx

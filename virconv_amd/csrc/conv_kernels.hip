@@ -181,7 +181,8 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
                                                              const float* __restrict__ src_centre, int64_t n_src,
                                                              const int32_t* __restrict__ tbl,
                                                              const float* __restrict__ w, float* __restrict__ out,
-                                                             const int32_t* __restrict__ rep, int64_t n_out, int kv,
+                                                             const int32_t* __restrict__ rep,
+                                                             const int32_t* __restrict__ order, int64_t n_out, int kv,
                                                              int centre, int mirror) {
   constexpr int V = (CK >= 16) ? 4 : CK / 4;
   constexpr int NCH = CK / (4 * V);
@@ -193,7 +194,8 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* s_b = reinterpret_cast<float*>(smem);           // [2][BF]
   int* s_idx = reinterpret_cast<int*>(smem + 2 * BF * sizeof(float));  // [kv][TM]
-  unsigned* s_mask = reinterpret_cast<unsigned*>(s_idx + kv * TM);     // [1] offsets active in this block
+  int* s_row = s_idx + kv * TM;                                        // [TM] output row of each tile slot (-1: none)
+  unsigned* s_mask = reinterpret_cast<unsigned*>(s_row + TM);          // [1] offsets active in this block
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
@@ -216,9 +218,13 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
   if (tid == 0) s_mask[0] = 0u;
   __syncthreads();
   {  // ---- phase 0: stage the pair-table slice; thread handles row r of offsets k0, k0 + 256/TM, ...
+    // `order` (optional) is a permutation of the rows that puts rows with equal active-offset sets next to each other:
+    // tile slot s computes output row order[s].  Results do not depend on it (every row is computed independently with
+    // the same offset order); it only makes the per-tile union of active offsets -- the work actually issued -- smaller.
     const int r = tid % TM;
-    const int64_t row = brow0 + r;
-    const bool inb = row < n_out;
+    const bool inb = brow0 + r < n_out;
+    const int64_t row = inb ? (order ? (int64_t)order[brow0 + r] : brow0 + r) : -1;
+    if (tid < TM) s_row[r] = (int)row;
     const bool centre_only = (rep != nullptr) && inb && (rep[row] != (int32_t)row);
     for (int k = tid / TM; k < kv; k += 256 / TM) {
       int v = inb ? tbl[(int64_t)k * n_out + row] : -1;
@@ -338,19 +344,20 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
 #undef VC_STORE_B
 #undef VC_GATHER_A
 
-  const int64_t row0 = brow0 + wave * (RT * 16);
 #pragma unroll
-  for (int t = 0; t < RT; ++t)
+  for (int t = 0; t < RT; ++t) {
+    int64_t orow[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) orow[reg] = s_row[wave * (RT * 16) + t * 16 + q * 4 + reg];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int n = nt * 16 + i;
       if (n >= CN) continue;
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int64_t r = row0 + t * 16 + q * 4 + reg;
-        if (r < n_out) out[r * CN + n] = acc[t][nt][reg];
-      }
+      for (int reg = 0; reg < 4; ++reg)
+        if (orow[reg] >= 0) out[orow[reg] * CN + n] = acc[t][nt][reg];
     }
+  }
 }
 
 // --------------------------------------------------------------------------------------------- K8 weight gradient
@@ -363,7 +370,8 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
 template <int CI, int CO>
 __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                          const int32_t* __restrict__ tbl, int64_t n_out, int kv,
-                                                         int64_t rows_per_block, float* __restrict__ partial) {
+                                                         int64_t rows_per_block, int nsplit, int legacy_order,
+                                                         float* __restrict__ partial) {
   constexpr int VA = (CI >= 16) ? CI / 16 : 1, VB = (CO >= 16) ? CO / 16 : 1;
   constexpr int MA = (CI >= 16) ? 16 : CI, NB = (CO >= 16) ? 16 : CO;  // lanes of the tile that carry data
   constexpr int U = (VA * VB >= 8) ? 2 : 4;                            // groups of 4 pairs gathered per iteration
@@ -372,8 +380,21 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
   __shared__ float red[CI * CO];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, q = lane >> 4;
-  const int k = blockIdx.y;
-  const int64_t brow0 = (int64_t)blockIdx.x * rows_per_block;
+  // Block order: the kv offset-blocks of one row range are adjacent in launch order AND on the same XCD (hardware
+  // places block b on XCD b % 8), so the range's x / dy rows are pulled from HBM once and the other kv-1 passes hit that
+  // XCD's L2.  The legacy order (all ranges of offset 0, then offset 1, ...) streamed x and dy from HBM kv times.
+  int k, split;
+  if (legacy_order) {
+    k = blockIdx.x / nsplit;
+    split = blockIdx.x - k * nsplit;
+  } else {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int rl = j / kv;
+    k = j - rl * kv;
+    split = rl * 8 + xcd;
+  }
+  if (split >= nsplit) return;
+  const int64_t brow0 = (int64_t)split * rows_per_block;
   const int64_t bend = min(brow0 + rows_per_block, n_out);
   const int64_t rpw = rows_per_block / 4;  // rows_per_block is a multiple of 256
   const int64_t wstart = brow0 + wave * rpw;
@@ -494,7 +515,7 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
     }
     __syncthreads();
   }
-  float* dst = partial + ((int64_t)blockIdx.x * kv + k) * (CI * CO);
+  float* dst = partial + ((int64_t)split * kv + k) * (CI * CO);
   for (int e = threadIdx.x; e < CI * CO; e += 256) dst[e] = red[e];
 }
 
@@ -531,11 +552,24 @@ __global__ void __launch_bounds__(256) bwd_weight_reduce_kernel(const float* __r
 static constexpr int kGsRows = 32;
 
 __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
+  // <= 512 blocks and ONE atomic per block: thousands of same-address atomics serialise in L2 (70 us measured)
+  __shared__ float red[4];
   float m = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+  const int64_t n4 = n >> 2;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = x4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));  // non-negative floats order like their bit patterns
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (m > 0.f) atomicMax(out, __float_as_uint(m));  // non-negative floats order like their bit patterns
+  }
 }
 
 __device__ __forceinline__ double gs_scale(unsigned absmax_bits) {
@@ -590,7 +624,7 @@ int g_conv_rt = 0;             // v2 row tiles per wave: 1 (64 rows/block) | 2 (
 
 template <int CK, int CN, bool BWD>
 static int launch_gg(const float* src, const float* src_centre, int64_t n_src, const int32_t* tbl, const float* w,
-                     float* out, const int32_t* rep, int64_t n_out, int kv, int centre, int mirror, hipStream_t st) {
+                     float* out, const int32_t* rep, const int32_t* order, int64_t n_out, int kv, int centre, int mirror, hipStream_t st) {
   const int64_t rows_per_block = 4 * kRT * 16;
   if (g_conv_variant == 2 && kv <= 32 && n_src * CK * 4 < (1LL << 31)) {
     constexpr int V = (CK >= 16) ? 4 : CK / 4;
@@ -601,9 +635,9 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
     // L2 latency / occupancy, not by the W_k re-staging traffic: a variant looping 2/4/8 row tiles per staged W_k (W
     // traffic and barriers / RT) was 5-60 % SLOWER because of its lower occupancy, and was removed.
     const int rt = (g_conv_rt == 2) ? 2 : 1;
-    const size_t lds = (size_t)2 * NCH * NT * 64 * V * sizeof(float) + (size_t)kv * 64 * rt * sizeof(int) + 16;
+    const size_t lds = (size_t)2 * NCH * NT * 64 * V * sizeof(float) + (size_t)(kv + 1) * 64 * rt * sizeof(int) + 16;
     const dim3 grid((unsigned)cdiv(n_out, (int64_t)64 * rt));
-#define VC_ARGS src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror
+#define VC_ARGS src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror
     if (rt == 2) hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 2>), grid, dim3(256), lds, st, VC_ARGS);
     else hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 1>), grid, dim3(256), lds, st, VC_ARGS);
 #undef VC_ARGS
@@ -618,13 +652,13 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
 
 template <int CK, bool BWD>
 static int dispatch_cn(int cn, const float* src, const float* src_centre, int64_t n_src, const int32_t* tbl, const float* w, float* out,
-                       const int32_t* rep, int64_t n_out, int kv, int centre, int mirror, hipStream_t st) {
+                       const int32_t* rep, const int32_t* order, int64_t n_out, int kv, int centre, int mirror, hipStream_t st) {
   switch (cn) {
-    case 4: return launch_gg<CK, 4, BWD>(src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror, st);
-    case 8: return launch_gg<CK, 8, BWD>(src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror, st);
-    case 16: return launch_gg<CK, 16, BWD>(src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror, st);
-    case 32: return launch_gg<CK, 32, BWD>(src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror, st);
-    case 64: return launch_gg<CK, 64, BWD>(src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror, st);
+    case 4: return launch_gg<CK, 4, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, st);
+    case 8: return launch_gg<CK, 8, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, st);
+    case 16: return launch_gg<CK, 16, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, st);
+    case 32: return launch_gg<CK, 32, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, st);
+    case 64: return launch_gg<CK, 64, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, st);
   }
   set_error("gather-GEMM: unsupported output channel count %d (supported: 4,8,16,32,64)", cn);
   return VC_EINVAL;
@@ -632,18 +666,19 @@ static int dispatch_cn(int cn, const float* src, const float* src_centre, int64_
 
 template <bool BWD>
 static int dispatch_ck(int ck, int cn, const float* src, const float* src_centre, int64_t n_src, const int32_t* tbl, const float* w,
-                       float* out, const int32_t* rep, int64_t n_out, int kv, int centre, int mirror, hipStream_t st) {
+                       float* out, const int32_t* rep, const int32_t* order, int64_t n_out, int kv, int centre, int mirror, hipStream_t st) {
   switch (ck) {
-    case 4: return dispatch_cn<4, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror, st);
-    case 8: return dispatch_cn<8, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror, st);
-    case 16: return dispatch_cn<16, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror, st);
-    case 32: return dispatch_cn<32, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror, st);
-    case 64: return dispatch_cn<64, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, n_out, kv, centre, mirror, st);
+    case 4: return dispatch_cn<4, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, st);
+    case 8: return dispatch_cn<8, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, st);
+    case 16: return dispatch_cn<16, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, st);
+    case 32: return dispatch_cn<32, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, st);
+    case 64: return dispatch_cn<64, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, st);
   }
   set_error("gather-GEMM: unsupported source channel count %d (supported: 4,8,16,32,64)", ck);
   return VC_EINVAL;
 }
 
+int g_bw_legacy_order = 0;      // debug: 1 = offset-major block order of the weight-gradient kernel
 static constexpr int kMaxSplit = 256;
 static constexpr size_t kMaxPartialBytes = 24u << 20;
 
@@ -672,7 +707,9 @@ static int launch_bw(const float* x, const float* dy, const int32_t* tbl, int64_
   int nsplit;
   int64_t rpb;
   bw_split(n_out, kv, CI, CO, nsplit, rpb);
-  hipLaunchKernelGGL((bwd_weight_kernel<CI, CO>), dim3(nsplit, kv), dim3(256), 0, st, x, dy, tbl, n_out, kv, rpb, partial);
+  const unsigned nblocks = g_bw_legacy_order ? (unsigned)(nsplit * kv) : (unsigned)(cdiv(nsplit, 8) * 8 * kv);
+  hipLaunchKernelGGL((bwd_weight_kernel<CI, CO>), dim3(nblocks), dim3(256), 0, st, x, dy, tbl, n_out, kv, rpb, nsplit,
+                     g_bw_legacy_order, partial);
   VC_CHECK_LAUNCH("bwd_weight_kernel");
   const int total = kv * CI * CO;
   hipLaunchKernelGGL(bwd_weight_reduce_kernel, dim3((unsigned)cdiv(total, 64)), dim3(256), 0, st, partial, nsplit, kv,
@@ -704,6 +741,7 @@ extern "C" {
 int vc_debug_set(const char* key, int value) {
   if (key && !strcmp(key, "conv_variant")) { g_conv_variant = value; return VC_OK; }
   if (key && !strcmp(key, "conv_rt")) { g_conv_rt = value; return VC_OK; }
+  if (key && !strcmp(key, "bw_legacy_order")) { g_bw_legacy_order = value; return VC_OK; }
   if (key && !strcmp(key, "xcd_swizzle_off")) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_swizzle_off), &value, sizeof(int)) == hipSuccess ? VC_OK : VC_EHIP;
   }
@@ -712,22 +750,23 @@ int vc_debug_set(const char* key, int value) {
 }
 
 int vc_conv_forward(const float* x, int64_t n_in, const int32_t* pair_fwd, int64_t n_out, int kv, const float* weight,
-                    int cin, int cout, float* y, void* stream) {
+                    int cin, int cout, const int32_t* row_order, float* y, void* stream) {
   VC_REQUIRE(n_in >= 0 && n_out >= 0 && kv >= 1 && weight, "vc_conv_forward: null/invalid argument");
   if (n_out == 0) return VC_OK;
   VC_REQUIRE(pair_fwd && y && (x || n_in == 0), "vc_conv_forward: null argument");
-  return dispatch_ck<false>(cin, cout, x, nullptr, n_in, pair_fwd, weight, y, nullptr, n_out, kv, -1, 0, (hipStream_t)stream);
+  return dispatch_ck<false>(cin, cout, x, nullptr, n_in, pair_fwd, weight, y, nullptr, row_order, n_out, kv, -1, 0,
+                            (hipStream_t)stream);
 }
 
 int vc_conv_backward_input(const float* dy, const float* dy_centre, int64_t n_src, const int32_t* tbl, int64_t n_in,
                            int kv, const float* weight, int cin, int cout, int mirror, int centre, const int32_t* rep,
-                           float* dx, void* stream) {
+                           const int32_t* row_order, float* dx, void* stream) {
   VC_REQUIRE(n_src >= 0 && n_in >= 0 && kv >= 1 && weight, "vc_conv_backward_input: null/invalid argument");
   if (n_in == 0) return VC_OK;
   VC_REQUIRE(tbl && dx && (dy || n_src == 0), "vc_conv_backward_input: null argument");
   VC_REQUIRE(centre >= -1 && centre < kv, "vc_conv_backward_input: centre out of range");
-  return dispatch_ck<true>(cout, cin, dy, dy_centre, n_src, tbl, weight, dx, rep, n_in, kv, centre, mirror ? 1 : 0,
-                           (hipStream_t)stream);
+  return dispatch_ck<true>(cout, cin, dy, dy_centre, n_src, tbl, weight, dx, rep, row_order, n_in, kv, centre,
+                           mirror ? 1 : 0, (hipStream_t)stream);
 }
 
 size_t vc_conv_backward_weight_workspace_bytes(int64_t n_out, int kv, int cin, int cout) {
@@ -777,8 +816,8 @@ int vc_group_sum(const float* dy, const int32_t* rep, int64_t n, int c, float* d
   long long* acc = (long long*)((char*)ws + 64);
   const int64_t total = n * c;
   VC_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)total * sizeof(long long) + 64, st));
-  int64_t nb = cdiv(total, 256 * 8);
-  if (nb > 2048) nb = 2048;
+  int64_t nb = cdiv(total, 256 * 16);
+  if (nb > 512) nb = 512;
   hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)nb), dim3(256), 0, st, dy, total, absmax);
   VC_CHECK_LAUNCH("absmax_kernel");
   hipLaunchKernelGGL(group_sum_fixed_kernel, dim3((unsigned)cdiv(cdiv(n, kGsRows) * c, 256)), dim3(256), 0, st, dy, rep, n, c,
