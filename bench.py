@@ -41,6 +41,7 @@ from virconv_amd.backbone import VirConvL8x  # noqa: E402
 MODEL_CFG = dict(NAME="VirConvL8x", NUM_FILTERS=[16, 32, 64, 64], RETURN_NUM_FEATURES_AS_DICT=True, OUT_FEATURES=64,
                  LAYER_DISCARD_RATE=0.1, LAYER_DISCARD_MODE="spconv1_inplace")
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+MFMA_16BIT_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16/f16 dense MFMA peak (16x16x32 / 32x32x16; the 16x16x16 forms run at half of it)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -167,6 +168,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="train = BASELINE configs[2] (default, the headline metric); infer = configs[1]: forward only, eval mode")
+    ap.add_argument("--operand", default="f32", choices=["f32", "f16", "bf16"],
+                    help="MFMA operand type of the conv kernels.  f32 (default) is the headline / parity configuration; f16 | "
+                         "bf16 = BASELINE configs[4] 'fp16 MFMA contraction' experiment (fp32 tensors, fp32 accumulate), "
+                         "reported with its own dtype and a 16-bit MFMA peak, never as the headline number")
     ap.add_argument("--trace", default="fwd,64,32", help="gather-GEMM instantiation timed for the roofline: dir,CK,CN")
     args = ap.parse_args()
 
@@ -176,6 +181,7 @@ def main():
     device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     be = ops.get_backend()
+    ops.MFMA_OPERAND = args.operand
 
     bs = args.batch_size
     seeds = parallel.shard_frames(list(range(bs * world)), rank, world)
@@ -186,7 +192,8 @@ def main():
     use_torch_ddp = os.environ.get("VIRCONV_TORCH_DDP") == "1"   # stock DistributedDataParallel instead (slower here)
     ddp = parallel.wrap_ddp(model, device) if use_torch_ddp else model
     grad_sync = None if use_torch_ddp else parallel.FlatGradAllReduce(model)
-    optimizer = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01)
+    optimizer = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01,
+                                  fused=True)  # stock torch multi-tensor AdamW kernel (a16: optimizer stays stock torch)
     lw = make_loss_weights(device)
     torch.manual_seed(100 + rank)  # layer-discard permutations
     # the inputs are resident in HBM from here on: lets the backbone's geometry plan run ahead on its side stream
@@ -228,8 +235,9 @@ def main():
         flops = sum(e["flops"] for e in trace)
         byts = sum(e["bytes"] for e in trace)
         ach = flops / (t_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": _pmc_traffic(tdir, tck, tcn),
+        peak = MFMA_F32_PEAK_TFLOPS if args.operand == "f32" else MFMA_16BIT_PEAK_TFLOPS
+        roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": _pmc_traffic(tdir, tck, tcn) if args.operand == "f32" else None,
                 "kernel": f"gather_gemm_v2_kernel<CK={tck},CN={tcn},BWD={'true' if tdir == 'bwd' else 'false'},RT=1>",
                 "launches": n_launch, "avg_us": round(t_ms / n_launch * 1e3, 2),
                 "algorithmic_gflop_per_launch": round(flops / n_launch / 1e9, 4),
@@ -238,7 +246,9 @@ def main():
     res = {
         "metric": "KITTI frames/sec (fwd+bwd) VirConv-L backbone", "value": round(frames / dt, 3), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.operand == "f32" else f"{args.operand} MFMA operands, f32 accumulate, f32 tensors",
+        "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: VirConv-L train step (fwd+bwd+Adam), train mode, layer discard 0.1, "
                                "NRConv 2-D branch on, synthetic KITTI frames (20k LiDAR + 60k virtual points, input "
                                "discard 0.8, <=40000 voxels/frame)",

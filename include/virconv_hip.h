@@ -42,6 +42,13 @@ typedef enum vc_status {
   VC_EHIP = -3       /* HIP runtime error (see vc_last_error) */
 } vc_status;
 
+/* arithmetic type of the MFMA operands of the conv kernels (accumulation is always fp32; tensors are always fp32) */
+typedef enum vc_operand {
+  VC_OPERAND_F32 = 0, /* v_mfma_f32_16x16x4_f32  : exact fp32, the default, the 1e-4 parity path */
+  VC_OPERAND_F16 = 1, /* v_mfma_f32_16x16x16_f16 : operands rounded to fp16 in registers */
+  VC_OPERAND_BF16 = 2 /* v_mfma_f32_16x16x16_bf16: operands rounded to bf16 in registers */
+} vc_operand;
+
 const char* vc_version(void);
 const char* vc_last_error(void);
 /* developer switch for A/B measurements (tools/kbench.py): "conv_variant" = 1 | 2 */
@@ -49,7 +56,8 @@ int vc_debug_set(const char* key, int value);
 
 /* ------------------------------------------------------------------------------------------------ K3 hash
  * Coordinate -> row hash (open addressing, 64-bit linearised key, duplicate rule rep(c) = max row; SURVEY
- * App-A.5).  Replaces cumm's LinearHashTable insert inside spconv's indice generation, reached from every
+ * App-A.5).  Locality-preserving: the 8 keys of an aligned x-octet occupy 8 consecutive slots, so the x-1/x/x+1 probes
+ * of x-consecutive rows share cache lines; workspace = 96 bytes per 2n-rounded-up-to-a-power-of-two rows.  Replaces cumm's LinearHashTable insert inside spconv's indice generation, reached from every
  * spconv.SubMConv3d/SubMConv2d forward (spconv_backbone.py:89,113).                                         */
 size_t vc_hash_workspace_bytes(int64_t n);
 int vc_hash_build(const int32_t* indices, int64_t n, int ndim, const int32_t* host_spatial_shape,
@@ -92,14 +100,19 @@ int vc_spconv_emit_pairs(const int32_t* indices, int64_t n, int ndim, int batch_
  *   Duplicate-coordinate SubM backward (2-D image-space branch): src_centre = dy is used for the
  *   centre tap, src = group-summed dy (vc_group_sum) for the others, and rows with rep[o] != o take the centre
  *   tap only.  Pass centre = -1, rep = NULL, src_centre = NULL when not needed.
+ *   operand_type: VC_OPERAND_F32 (exact fp32 MFMA; the parity path) | VC_OPERAND_F16 | VC_OPERAND_BF16 -- tensors stay fp32
+ *   in memory, the MFMA operands are rounded (RNE) to 16 bit in registers and accumulate in fp32 (BASELINE configs[4],
+ *   "fp16 MFMA contraction"; the reference has no reduced-precision path, tolerance 2e-2 relative).  Layers with fewer than
+ *   16 channels on either side always contract in fp32.
  *   row_order (optional, NULL = natural order): a permutation of [0, n_out) from vc_row_order; tile slot s computes output
  *   row row_order[s].  A pure scheduling hint -- results are bit-identical with and without it.
  * Replaces spconv ops.implicit_gemm / indice_conv fwd and bwd-input (autograd of spconv_backbone.py:89-125).   */
 int vc_conv_forward(const float* x, int64_t n_in, const int32_t* pair_fwd, int64_t n_out, int kv,
-                    const float* weight, int cin, int cout, const int32_t* row_order, float* y, void* stream);
+                    const float* weight, int cin, int cout, const int32_t* row_order, int operand_type, float* y,
+                    void* stream);
 int vc_conv_backward_input(const float* dy, const float* dy_centre, int64_t n_src, const int32_t* tbl,
                            int64_t n_in, int kv, const float* weight, int cin, int cout, int mirror, int centre,
-                           const int32_t* rep, const int32_t* row_order, float* dx, void* stream);
+                           const int32_t* rep, const int32_t* row_order, int operand_type, float* dx, void* stream);
 
 /* Row permutation that makes the gather-GEMM's 16-row tiles homogeneous: within each window of `window` (1024 | 2048 |
  * 4096) consecutive rows of `tbl` (KV, n) the rows are stably sorted by their active-offset bit mask (bit k set <=> tbl[k, r] >= 0; rows with
@@ -115,7 +128,8 @@ int vc_row_order(const int32_t* tbl, int64_t n, int kv, const int32_t* rep, int 
  * Replaces spconv implicit_gemm bwd-weight (autograd of spconv_backbone.py:89-125).                            */
 size_t vc_conv_backward_weight_workspace_bytes(int64_t n_out, int kv, int cin, int cout);
 int vc_conv_backward_weight(const float* x, const float* dy, const int32_t* pair_fwd, int64_t n_out, int kv,
-                            int cin, int cout, float* dweight, void* ws, size_t ws_bytes, void* stream);
+                            int cin, int cout, int operand_type, float* dweight, void* ws, size_t ws_bytes,
+                            void* stream);
 
 /* dy_grp[rep[i], :] = sum over the rows i sharing representative rep[i] of dy[i, :]  (rows that are nobody's
  * representative get 0).  Only used by the duplicate-coordinate SubM backward.  Bit-stable: the sum is carried in

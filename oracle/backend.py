@@ -40,10 +40,21 @@ class OracleBackend:
     def row_order(self, tbl, rep=None, centre=-1, window=1024):
         return None  # scheduling hint of the HIP path only; results never depend on it
 
-    def conv_forward(self, x, weight, pair_fwd, order=None):
-        return sparse_ref.conv_forward(x.detach(), weight.detach(), _np(pair_fwd))
+    @staticmethod
+    def _operands(operand, cin, cout, *tensors):
+        """Emulation of the product's reduced-precision mode: MFMA operands rounded (RNE) to fp16 / bf16, exact products,
+        wide accumulation -- only where both channel counts are >= 16 (include/virconv_hip.h, vc_operand)."""
+        ts = [t.detach() for t in tensors]
+        if operand == "f32" or cin < 16 or cout < 16:
+            return ts
+        dt = {"f16": torch.float16, "bf16": torch.bfloat16}[operand]
+        return [t.to(dt).to(t.dtype) for t in ts]
 
-    def conv_backward_input(self, dy, weight, tbl, n_in, mirror, centre=-1, rep=None, order=None):
+    def conv_forward(self, x, weight, pair_fwd, order=None, operand="f32"):
+        x, weight = self._operands(operand, weight.shape[-1], weight.shape[0], x, weight)
+        return sparse_ref.conv_forward(x, weight, _np(pair_fwd))
+
+    def conv_backward_input(self, dy, weight, tbl, n_in, mirror, centre=-1, rep=None, order=None, operand="f32"):
         """dX of the three conv flavours, in the product's calling convention (include/virconv_hip.h).
 
         SubM (mirror=True, tbl = pair_fwd): the EXACT transpose of the forward gather,
@@ -54,8 +65,7 @@ class OracleBackend:
             dx[i] = sum_k dy[tbl[k,i]] @ W_k^T.
         """
         t = _np(tbl)
-        dy = dy.detach()
-        w = weight.detach()
+        dy, w = self._operands(operand, weight.shape[-1], weight.shape[0], dy, weight)
         if mirror:
             dx, _ = sparse_ref.conv_backward(dy.new_zeros((n_in, w.shape[-1])), w, t, dy)
             return dx
@@ -69,9 +79,10 @@ class OracleBackend:
             dx.index_add_(0, torch.from_numpy(rows.astype(np.int64)), g @ wk[k].t())
         return dx
 
-    def conv_backward_weight(self, x, dy, pair_fwd, weight_shape, stream=None, keep_alive=None):
+    def conv_backward_weight(self, x, dy, pair_fwd, weight_shape, stream=None, keep_alive=None, operand="f32"):
         w0 = x.new_zeros(tuple(weight_shape))
-        _, dw = sparse_ref.conv_backward(x.detach(), w0, _np(pair_fwd), dy.detach())
+        x, dy = self._operands(operand, int(weight_shape[-1]), int(weight_shape[0]), x, dy)
+        _, dw = sparse_ref.conv_backward(x, w0, _np(pair_fwd), dy)
         return dw
 
     # ------------------------------------------------------------------ projection / discard / dense

@@ -42,14 +42,14 @@ def test_binding_table_covers_header_exactly():
 
 def test_host_side_queries_and_argument_validation_without_gpu():
     lib = _lib.load()
-    assert lib.vc_hash_workspace_bytes(1000) == 2048 * 12
+    assert lib.vc_hash_workspace_bytes(1000) == 8 * 2048 * 12  # 8 slots per x-octet, octet load factor <= 1/2
     assert lib.vc_spconv_workspace_bytes(1, 3, _lib.i32arr([41, 800, 704])) > 41 * 800 * 704 // 8
     assert lib.vc_conv_backward_weight_workspace_bytes(1000, 27, 64, 64) >= 16 * 27 * 64 * 64 * 4
     assert lib.vc_voxelize_workspace_bytes(1000, 5) > 0 and lib.vc_bn_workspace_bytes(1000, 64) > 0
     # invalid arguments are rejected with a status code + message, never exit()/abort (include/virconv_hip.h)
     st = lib.vc_hash_build(None, 10, 5, _lib.i32arr([1, 2, 3]), None, 0, None)
     assert st == _lib.VC_EINVAL and b"ndim" in lib.vc_last_error()
-    st = lib.vc_conv_forward(None, 0, None, 10, 27, None, 8, 8, None, None, None)
+    st = lib.vc_conv_forward(None, 0, None, 10, 27, None, 8, 8, None, 0, None, None)
     assert st == _lib.VC_EINVAL
     st = lib.vc_gather_rows(None, None, 7, 4, None, 0, None, None, None)
     assert st == _lib.VC_EINVAL and b"multiple of 4" in lib.vc_last_error()

@@ -366,3 +366,79 @@ def test_row_order_never_changes_conv_results(hip_backend, cin, cout):
         b = hip_backend.conv_backward_input(g2, w2, p2, n2, mirror=True, centre=4, rep=rep,
                                             order=hip_backend.row_order(p2, rep, 4))
         assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------ 16-bit MFMA operands
+# BASELINE configs[4] ("fp16 MFMA contraction"): the reference has no reduced-precision path, so the bound is re-declared:
+#   * against the oracle with the SAME operand rounding (exact products, wide accumulation): the fp32 tolerance 1e-4
+#   * against the full-precision oracle: 2e-2 relative
+TOL_REDUCED = 2e-2
+
+
+@pytest.mark.parametrize("operand", ["f16", "bf16"])
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 16), (64, 32), (32, 64), (64, 64)])
+def test_reduced_operand_subm_conv_vs_oracle(hip_backend, operand, cin, cout):
+    rng = np.random.default_rng(cin * 7 + cout)
+    idx = _indices3(14, 3000)
+    n = idx.shape[0]
+    x = rng.standard_normal((n, cin)).astype(np.float32)
+    w = (rng.standard_normal((cout, 3, 3, 3, cin)) / np.sqrt(27 * cin)).astype(np.float32)
+    g = rng.standard_normal((n, cout)).astype(np.float32)
+    pair = sparse_ref.subm_rulebook(idx, SHAPE3, (3, 3, 3))
+    xt, wt, gt, pt = (torch.from_numpy(a).cuda() for a in (x, w, g, pair))
+    ob = OracleBackend()
+    xd, wd, gd = (torch.from_numpy(a).double() for a in (x, w, g))
+    pc = torch.from_numpy(pair)
+    y = hip_backend.conv_forward(xt, wt, pt, operand=operand).cpu().numpy()
+    dx = hip_backend.conv_backward_input(gt, wt, pt, n, mirror=True, operand=operand).cpu().numpy()
+    dw = hip_backend.conv_backward_weight(xt, gt, pt, w.shape, operand=operand).cpu().numpy()
+    # same rounding, wide accumulation
+    assert _rel_err(y, ob.conv_forward(xd, wd, pc, operand=operand).numpy()) < TOL
+    assert _rel_err(dx, ob.conv_backward_input(gd, wd, pc, n, True, operand=operand).numpy()) < TOL
+    assert _rel_err(dw, ob.conv_backward_weight(xd, gd, pc, w.shape, operand=operand).numpy()) < TOL
+    # full precision oracle
+    assert _rel_err(y, ob.conv_forward(xd, wd, pc).numpy()) < TOL_REDUCED
+    assert _rel_err(dx, ob.conv_backward_input(gd, wd, pc, n, True).numpy()) < TOL_REDUCED
+    assert _rel_err(dw, ob.conv_backward_weight(xd, gd, pc, w.shape).numpy()) < TOL_REDUCED
+    # and the mode really is reduced precision (not silently fp32)
+    y32 = hip_backend.conv_forward(xt, wt, pt).cpu().numpy()
+    assert np.abs(y - y32).max() > 0
+
+
+@pytest.mark.parametrize("operand", ["f16", "bf16"])
+def test_reduced_operand_strided_conv_and_row_order(hip_backend, operand):
+    rng = np.random.default_rng(3)
+    idx = _indices3(15, 2500)
+    n, cin, cout = idx.shape[0], 32, 64
+    it = torch.from_numpy(idx).cuda()
+    x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.standard_normal((cout, 3, 3, 3, cin)) / 20).astype(np.float32)).cuda()
+    oi, _, pf, pb = hip_backend.sparse_rulebook(it, SHAPE3, 2, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1))
+    g = torch.from_numpy(rng.standard_normal((oi.shape[0], cout)).astype(np.float32)).cuda()
+    ob = OracleBackend()
+    y = hip_backend.conv_forward(x, w, pf, operand=operand)
+    dx = hip_backend.conv_backward_input(g, w, pb, n, mirror=False, operand=operand)
+    dw = hip_backend.conv_backward_weight(x, g, pf, tuple(w.shape), operand=operand)
+    xd, wd, gd = x.cpu().double(), w.cpu().double(), g.cpu().double()
+    assert _rel_err(y.cpu().numpy(), ob.conv_forward(xd, wd, pf.cpu(), operand=operand).numpy()) < TOL
+    assert _rel_err(dx.cpu().numpy(), ob.conv_backward_input(gd, wd, pb.cpu(), n, False, operand=operand).numpy()) < TOL
+    assert _rel_err(dw.cpu().numpy(), ob.conv_backward_weight(xd, gd, pf.cpu(), tuple(w.shape), operand=operand).numpy()) < TOL
+    # the scheduling hint stays a pure hint in this mode too
+    assert torch.equal(dx, hip_backend.conv_backward_input(g, w, pb, n, mirror=False, operand=operand,
+                                                           order=hip_backend.row_order(pb)))
+
+
+def test_reduced_operand_is_ignored_below_16_channels(hip_backend):
+    rng = np.random.default_rng(9)
+    idx = _indices3(16, 2000)
+    n = idx.shape[0]
+    pair = torch.from_numpy(sparse_ref.subm_rulebook(idx, SHAPE3, (3, 3, 3))).cuda()
+    for cin, cout in ((8, 8), (8, 16), (16, 8)):
+        x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).cuda()
+        w = torch.from_numpy(rng.standard_normal((cout, 3, 3, 3, cin)).astype(np.float32)).cuda()
+        g = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32)).cuda()
+        assert torch.equal(hip_backend.conv_forward(x, w, pair), hip_backend.conv_forward(x, w, pair, operand="f16"))
+        assert torch.equal(hip_backend.conv_backward_input(g, w, pair, n, mirror=True),
+                           hip_backend.conv_backward_input(g, w, pair, n, mirror=True, operand="f16"))
+        assert torch.equal(hip_backend.conv_backward_weight(x, g, pair, tuple(w.shape)),
+                           hip_backend.conv_backward_weight(x, g, pair, tuple(w.shape), operand="bf16"))

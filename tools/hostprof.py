@@ -27,7 +27,7 @@ else:
     gs = parallel.FlatGradAllReduce(model)
 _ts = bench.train_step
 bench.train_step = lambda m, o, b, l: _ts(m, o, b, l, gs)
-opt = torch.optim.AdamW(raw.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01)
+opt = torch.optim.AdamW(raw.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, fused=True)
 lw = bench.make_loss_weights(dev)
 torch.cuda.synchronize()
 batch["inputs_ready_event"] = torch.cuda.Event()

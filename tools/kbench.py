@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="gather-GEMM variant (vc_debug_set conv_variant); 0 = default")
     ap.add_argument("--no-xcd", action="store_true", help="disable the XCD-aware block swizzle of the gather-GEMM")
     ap.add_argument("--rt", type=int, default=0, help="v2 row tiles per wave (vc_debug_set conv_rt); 0 = heuristic")
+    ap.add_argument("--operand", default="f32", choices=["f32", "f16", "bf16"], help="MFMA operand type")
     ap.add_argument("--bw-legacy", action="store_true", help="offset-major block order in the weight-gradient kernel")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -85,6 +86,21 @@ def main():
     rbo = ops.build_sparse_rulebook(cur_idx, cur_shape, bs, (3, 1, 1), (2, 1, 1), (0, 0, 0), 1)
     layers.append(("conv_out 64->64", rbo, 64, 64))
 
+    if args.only in ("all", "rulebook"):
+        # geometry kernels (plan stream): hash build + SubM rulebook, and the whole strided rulebook (incl. its count read)
+        print("rulebook timings (us per build, includes the hash build / the host count read):")
+        seen = set()
+        for name, rb, _, _ in layers:
+            if id(rb) in seen:
+                continue
+            seen.add(id(rb))
+            if rb.kind == "subm":
+                t = timeit(lambda: be.subm_rulebook(rb.in_indices, rb.in_shape, rb.ksize, rb.dilation, want_rep=rb.rep is not None), args.iters)
+            else:
+                t = timeit(lambda: be.sparse_rulebook(rb.in_indices, rb.in_shape, bs, rb.ksize, rb.stride, rb.padding, rb.dilation), args.iters)
+            print(f"  {name:34s} {rb.kind:6s} N_in {rb.n_in:7d} N_out {rb.n_out:7d}  {t:8.1f}")
+        if args.only == "rulebook":
+            return
     print(f"{'layer':34s} {'N_in':>7s} {'N_out':>7s} {'P/N':>5s} | {'fwd us':>8s} {'TF':>6s} {'%pk':>5s} {'GB/s':>6s} | "
           f"{'bwd us':>8s} {'TF':>6s} {'%pk':>5s} | {'dW us':>8s} {'TF':>6s} {'%pk':>5s}")
     tot = {"fwd": 0.0, "bwd": 0.0, "dw": 0.0, "flops": 0.0}
@@ -98,14 +114,14 @@ def main():
         byts = 4.0 * (rb.n_in * cin + rb.n_out * cout + kv * cin * cout) + 4.0 * kv * rb.n_out
         res = {}
         if args.only in ("all", "fwd"):
-            res["fwd"] = timeit(lambda: be.conv_forward(x, w, rb.pair_fwd, order=rb.order_fwd), args.iters)
+            res["fwd"] = timeit(lambda: be.conv_forward(x, w, rb.pair_fwd, order=rb.order_fwd, operand=args.operand), args.iters)
         if args.only in ("all", "bwd"):
             if rb.kind == "subm":
-                res["bwd"] = timeit(lambda: be.conv_backward_input(dy, w, rb.pair_fwd, rb.n_in, True, rb.centre, rb.rep, order=rb.order_bwd), args.iters)
+                res["bwd"] = timeit(lambda: be.conv_backward_input(dy, w, rb.pair_fwd, rb.n_in, True, rb.centre, rb.rep, order=rb.order_bwd, operand=args.operand), args.iters)
             else:
-                res["bwd"] = timeit(lambda: be.conv_backward_input(dy, w, rb.pair_bwd, rb.n_in, False, order=rb.order_bwd), args.iters)
+                res["bwd"] = timeit(lambda: be.conv_backward_input(dy, w, rb.pair_bwd, rb.n_in, False, order=rb.order_bwd, operand=args.operand), args.iters)
         if args.only in ("all", "dw"):
-            res["dw"] = timeit(lambda: be.conv_backward_weight(x, dy, rb.pair_fwd, w.shape), args.iters)
+            res["dw"] = timeit(lambda: be.conv_backward_weight(x, dy, rb.pair_fwd, w.shape, operand=args.operand), args.iters)
 
         def tf(us):
             return flops / (us * 1e-6) / 1e12

@@ -14,6 +14,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VIRCONV_LIB", os.path.join(_HERE, "libvirconv_hip.so"))  # override: A/B builds only
 
+OPERAND_TYPES = {"f32": 0, "f16": 1, "bf16": 2}  # vc_operand (include/virconv_hip.h)
 VC_OK, VC_EINVAL, VC_ECAPACITY, VC_EHIP = 0, -1, -2, -3
 
 _P, _I64, _I, _SZ, _F = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_float
@@ -29,11 +30,11 @@ SIGNATURES = {
     "vc_spconv_workspace_bytes": (_SZ, [_I, _I, _P]),
     "vc_spconv_mark_count": (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P, _P]),
     "vc_spconv_emit_pairs": (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _I64, _P, _P, _P, _P]),
-    "vc_conv_forward": (_I, [_P, _I64, _P, _I64, _I, _P, _I, _I, _P, _P, _P]),
-    "vc_conv_backward_input": (_I, [_P, _P, _I64, _P, _I64, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "vc_conv_forward": (_I, [_P, _I64, _P, _I64, _I, _P, _I, _I, _P, _I, _P, _P]),
+    "vc_conv_backward_input": (_I, [_P, _P, _I64, _P, _I64, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
     "vc_row_order": (_I, [_P, _I64, _I, _P, _I, _I, _P, _P]),
     "vc_conv_backward_weight_workspace_bytes": (_SZ, [_I64, _I, _I, _I]),
-    "vc_conv_backward_weight": (_I, [_P, _P, _P, _I64, _I, _I, _I, _P, _P, _SZ, _P]),
+    "vc_conv_backward_weight": (_I, [_P, _P, _P, _I64, _I, _I, _I, _I, _P, _P, _SZ, _P]),
     "vc_group_sum_workspace_bytes": (_SZ, [_I64, _I]),
     "vc_group_sum": (_I, [_P, _P, _I64, _I, _P, _P, _SZ, _P]),
     "vc_project_prepare": (_I, [_P, _P, _I, _P, _P]),

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import check, i32arr, f32arr
+from ._lib import OPERAND_TYPES, check, i32arr, f32arr
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -150,7 +150,7 @@ class HipBackend:
         return order
 
     def conv_forward(self, x: torch.Tensor, weight: torch.Tensor, pair_fwd: torch.Tensor,
-                     order: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     order: Optional[torch.Tensor] = None, operand: str = "f32") -> torch.Tensor:
         x = _need(x, torch.float32, "features")
         weight = _need(weight, torch.float32, "weight")
         pair_fwd = _need(pair_fwd, torch.int32, "pair_fwd")
@@ -160,14 +160,14 @@ class HipBackend:
         y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
         rec = self._trace_open(pair_fwd, x.shape[0], cin, cout) if self._traced("fwd", cin, cout) else None
         check(self.lib.vc_conv_forward(_ptr(x), x.shape[0], _ptr(pair_fwd), n_out, kv, _ptr(weight), cin, cout,
-                                       _ptr(order), _ptr(y), _stream()), "vc_conv_forward")
+                                       _ptr(order), OPERAND_TYPES[operand], _ptr(y), _stream()), "vc_conv_forward")
         if rec is not None:
             self._trace_close(rec)
         return y
 
     def conv_backward_input(self, dy: torch.Tensor, weight: torch.Tensor, tbl: torch.Tensor, n_in: int, mirror: bool,
                             centre: int = -1, rep: Optional[torch.Tensor] = None,
-                            order: Optional[torch.Tensor] = None) -> torch.Tensor:
+                            order: Optional[torch.Tensor] = None, operand: str = "f32") -> torch.Tensor:
         dy = _need(dy, torch.float32, "grad_out")
         weight = _need(weight, torch.float32, "weight")
         tbl = _need(tbl, torch.int32, "pair table")
@@ -187,13 +187,15 @@ class HipBackend:
         rec = self._trace_open(tbl, dy.shape[0], cout, cin) if self._traced("bwd", cout, cin) else None
         check(self.lib.vc_conv_backward_input(_ptr(src), _ptr(src_centre), dy.shape[0], _ptr(tbl), n_in, kv, _ptr(weight),
                                               cin, cout, 1 if mirror else 0, centre if rep is not None else -1,
-                                              _ptr(rep), _ptr(order), _ptr(dx), _stream()), "vc_conv_backward_input")
+                                              _ptr(rep), _ptr(order), OPERAND_TYPES[operand], _ptr(dx), _stream()),
+              "vc_conv_backward_input")
         if rec is not None:
             self._trace_close(rec)
         return dx
 
     def conv_backward_weight(self, x: torch.Tensor, dy: torch.Tensor, pair_fwd: torch.Tensor, weight_shape,
-                             stream: Optional[int] = None, keep_alive: Optional[list] = None) -> torch.Tensor:
+                             stream: Optional[int] = None, keep_alive: Optional[list] = None,
+                             operand: str = "f32") -> torch.Tensor:
         """`stream` (raw hipStream_t) overrides torch's current stream for the launches; the caller joins the streams and
         MUST pass `keep_alive`: the scratch buffer is appended to it so that torch's allocator (which only knows about the
         current stream) cannot hand its memory to another tensor before the join."""
@@ -206,8 +208,9 @@ class HipBackend:
         dw = torch.empty(tuple(weight_shape), dtype=torch.float32, device=x.device)
         ws_bytes = self.lib.vc_conv_backward_weight_workspace_bytes(n_out, kv, cin, cout)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
-        check(self.lib.vc_conv_backward_weight(_ptr(x), _ptr(dy), _ptr(pair_fwd), n_out, kv, cin, cout, _ptr(dw), _ptr(ws),
-                                               ws_bytes, _stream() if stream is None else stream),
+        check(self.lib.vc_conv_backward_weight(_ptr(x), _ptr(dy), _ptr(pair_fwd), n_out, kv, cin, cout,
+                                               OPERAND_TYPES[operand], _ptr(dw), _ptr(ws), ws_bytes,
+                                               _stream() if stream is None else stream),
               "vc_conv_backward_weight")
         if keep_alive is not None:
             keep_alive.extend((ws, x, dy, pair_fwd))

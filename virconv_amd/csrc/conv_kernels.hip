@@ -14,7 +14,47 @@
 namespace vc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ int g_xcd_swizzle_off = 0;  // developer switch (tools/kbench.py --no-xcd)
+
+// Reduced-precision MFMA operands (BASELINE configs[4]: "fp16 MFMA contraction"): features / gradients / weights stay fp32
+// in HBM, are rounded (RNE) to fp16 or bf16 in registers right before the MFMA, products are exact and accumulate in fp32.
+//   OT = VC_OPERAND_F32 : v_mfma_f32_16x16x4_f32     (exact fp32, the default and the 1e-4 parity path)
+//   OT = VC_OPERAND_F16 : v_mfma_f32_16x16x16_f16    (4 K-steps per instruction, 8x the fp32 MFMA rate)
+//   OT = VC_OPERAND_BF16: v_mfma_f32_16x16x16_bf16   (same shape; fp32 exponent range, for gradients that underflow fp16)
+// A lane's 4 consecutive channels [ch*16 + 4q, +4) are exactly the 4 K-slots k = 4q..4q+3 the 16x16x16 layouts want, so
+// the gather pattern, the W fragment order and the accumulator layout are the same as in the fp32 kernels.
+template <int OT>
+struct Pack4;
+template <>
+struct Pack4<VC_OPERAND_F16> {
+  static __device__ __forceinline__ u32x2 cvt(const float* f) {
+    const f32x4 v = {f[0], f[1], f[2], f[3]};
+    return __builtin_bit_cast(u32x2, __builtin_convertvector(v, f16x4));
+  }
+};
+template <>
+struct Pack4<VC_OPERAND_BF16> {
+  static __device__ __forceinline__ u32x2 cvt(const float* f) {
+    const f32x2 lo = {f[0], f[1]}, hi = {f[2], f[3]};
+    u32x2 r;
+    r.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
+    r.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
+    return r;
+  }
+};
+template <int OT>
+__device__ __forceinline__ f32x4 mfma16(u32x2 a, u32x2 b, f32x4 c) {
+  if constexpr (OT == VC_OPERAND_F16) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+  }
+}
 
 template <int V>
 struct VecLoad;
@@ -176,7 +216,7 @@ struct BufLoad<1> {
   }
 };
 
-template <int CK, int CN, bool BWD, int RT>
+template <int CK, int CN, bool BWD, int RT, int OT>
 __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __restrict__ src,
                                                              const float* __restrict__ src_centre, int64_t n_src,
                                                              const int32_t* __restrict__ tbl,
@@ -190,10 +230,12 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
   constexpr int TM = 64 * RT;                            // output rows per block: 4 waves x RT tiles of 16
   constexpr int NFRAG = NCH * NT * 64;                   // fragment vectors (V floats each) of one W_k image
   constexpr int BF = NFRAG * V;
+  constexpr int BBYTES = BF * (OT == VC_OPERAND_F32 ? 4 : 2);  // one W_k image in LDS (fp32, or 16-bit operands)
   constexpr int BLD = (NFRAG + 255) / 256;               // fragment vectors staged per thread
+  static_assert(OT == VC_OPERAND_F32 || V == 4, "16-bit MFMA operands need >= 16 source channels");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* s_b = reinterpret_cast<float*>(smem);           // [2][BF]
-  int* s_idx = reinterpret_cast<int*>(smem + 2 * BF * sizeof(float));  // [kv][TM]
+  unsigned char* s_b = smem;                             // [2][BBYTES]
+  int* s_idx = reinterpret_cast<int*>(smem + 2 * BBYTES);              // [kv][TM]
   int* s_row = s_idx + kv * TM;                                        // [TM] output row of each tile slot (-1: none)
   unsigned* s_mask = reinterpret_cast<unsigned*>(s_row + TM);          // [1] offsets active in this block
 
@@ -273,7 +315,12 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
     _Pragma("unroll") for (int u = 0; u < BLD; ++u) {                                              \
       const int f = tid + u * 256;                                                                 \
       if (NFRAG % 256 == 0 || f < NFRAG) {                                                         \
-        _Pragma("unroll") for (int j = 0; j < V; ++j) s_b[(BUF) * BF + f * V + j] = breg[u][j];    \
+        if constexpr (OT == VC_OPERAND_F32) {                                                      \
+          float* d_ = reinterpret_cast<float*>(s_b + (BUF) * BBYTES) + f * V;                      \
+          _Pragma("unroll") for (int j = 0; j < V; ++j) d_[j] = breg[u][j];                        \
+        } else {                                                                                   \
+          *reinterpret_cast<u32x2*>(s_b + (BUF) * BBYTES + f * 8) = Pack4<OT == VC_OPERAND_F32 ? VC_OPERAND_F16 : OT>::cvt(breg[u]); \
+        }                                                                                          \
       }                                                                                            \
     }                                                                                              \
   } while (0)
@@ -296,17 +343,35 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
   // waits: the MFMAs never wait for the loads issued in their own half-trip.
 #define VC_MFMA(A, ACT, BUF)                                                                       \
   do {                                                                                             \
-    const float* __restrict__ B_ = s_b + (BUF) * BF;                                               \
-    float b[NCH][NT][V];                                                                           \
-    _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                             \
-        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                          \
-            VecLoad<V>::ld(B_ + ((ch * NT + nt) * 64 + lane) * V, b[ch][nt]);                      \
-    _Pragma("unroll") for (int t = 0; t < RT; ++t) {                                               \
-      if (ACT[t]) {                                                                                \
-        _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                         \
+    if constexpr (OT == VC_OPERAND_F32) {                                                          \
+      const float* __restrict__ B_ = reinterpret_cast<const float*>(s_b + (BUF) * BBYTES);         \
+      float b[NCH][NT][V];                                                                         \
+      _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
+          _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                        \
+              VecLoad<V>::ld(B_ + ((ch * NT + nt) * 64 + lane) * V, b[ch][nt]);                    \
+      _Pragma("unroll") for (int t = 0; t < RT; ++t) {                                             \
+        if (ACT[t]) {                                                                              \
+          _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                       \
+              _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                    \
+                  _Pragma("unroll") for (int j = 0; j < V; ++j)                                    \
+                      acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[t][ch][j], b[ch][nt][j], acc[t][nt], 0, 0, 0); \
+        }                                                                                          \
+      }                                                                                            \
+    } else {                                                                                       \
+      constexpr int OT_ = (OT == VC_OPERAND_F32) ? VC_OPERAND_F16 : OT;                            \
+      const unsigned char* __restrict__ B_ = s_b + (BUF) * BBYTES;                                 \
+      u32x2 b[NCH][NT];                                                                            \
+      _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
+          _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                        \
+              b[ch][nt] = *reinterpret_cast<const u32x2*>(B_ + ((ch * NT + nt) * 64 + lane) * 8);  \
+      _Pragma("unroll") for (int t = 0; t < RT; ++t) {                                             \
+        if (ACT[t]) {                                                                              \
+          _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch) {                                     \
+            const u32x2 ah = Pack4<OT_>::cvt(A[t][ch]);                                            \
             _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                      \
-                _Pragma("unroll") for (int j = 0; j < V; ++j)                                      \
-                    acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[t][ch][j], b[ch][nt][j], acc[t][nt], 0, 0, 0); \
+                acc[t][nt] = mfma16<OT_>(ah, b[ch][nt], acc[t][nt]);                               \
+          }                                                                                        \
+        }                                                                                          \
       }                                                                                            \
     }                                                                                              \
   } while (0)
@@ -367,7 +432,49 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
 // Operand vectorisation: lane (i, q) loads VA = CI/16 contiguous input channels [VA*i, VA*i+VA) of pair q's input row and
 // VB = CO/16 contiguous output channels of its dy row with ONE vector load each and issues VA x VB MFMAs per 4 pairs;
 // tile (ja, jb) therefore holds dW[ci = VA*m + ja][co = VB*n + jb] (a fixed permutation of the M / N dimensions).
-template <int CI, int CO>
+template <int CI, int CO, int OT>
+__device__ __forceinline__ void bw_group16(const float* __restrict__ x, const float* __restrict__ dy, const int* qi,
+                                           const int* qo, int npairs, int i, int q, bool a_ok, bool b_ok,
+                                           f32x4 (&acc)[(CI >= 16) ? CI / 16 : 1][(CO >= 16) ? CO / 16 : 1]) {
+  constexpr int VA = (CI >= 16) ? CI / 16 : 1, VB = (CO >= 16) ? CO / 16 : 1;
+  constexpr int OT_ = (OT == VC_OPERAND_F32) ? VC_OPERAND_F16 : OT;
+  float a[4][VA], b[4][VB];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int slot = q * 4 + r;
+    const bool ok = slot < npairs;
+    const int pin = ok ? qi[slot] : 0, pout = ok ? qo[slot] : 0;
+    if (ok && a_ok) VecLoad<VA>::ld(x + (int64_t)pin * CI + VA * i, a[r]);
+    else {
+#pragma unroll
+      for (int j = 0; j < VA; ++j) a[r][j] = 0.f;
+    }
+    if (ok && b_ok) VecLoad<VB>::ld(dy + (int64_t)pout * CO + VB * i, b[r]);
+    else {
+#pragma unroll
+      for (int j = 0; j < VB; ++j) b[r][j] = 0.f;
+    }
+  }
+  u32x2 ah[VA], bh[VB];
+#pragma unroll
+  for (int j = 0; j < VA; ++j) {
+    const float t[4] = {a[0][j], a[1][j], a[2][j], a[3][j]};
+    ah[j] = Pack4<OT_>::cvt(t);
+  }
+#pragma unroll
+  for (int j = 0; j < VB; ++j) {
+    const float t[4] = {b[0][j], b[1][j], b[2][j], b[3][j]};
+    bh[j] = Pack4<OT_>::cvt(t);
+  }
+#pragma unroll
+  for (int ja = 0; ja < VA; ++ja)
+#pragma unroll
+    for (int jb = 0; jb < VB; ++jb) acc[ja][jb] = mfma16<OT_>(ah[ja], bh[jb], acc[ja][jb]);
+}
+
+// OT != VC_OPERAND_F32: 16 pairs per MFMA step (v_mfma_f32_16x16x16_{f16,bf16}); lane (i, q) loads the rows of the 4 pairs
+// 4q..4q+3 of the group and packs, per channel, those 4 values (rounded to 16 bit) into one operand.
+template <int CI, int CO, int OT>
 __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                          const int32_t* __restrict__ tbl, int64_t n_out, int kv,
                                                          int64_t rows_per_block, int nsplit, int legacy_order,
@@ -375,6 +482,7 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
   constexpr int VA = (CI >= 16) ? CI / 16 : 1, VB = (CO >= 16) ? CO / 16 : 1;
   constexpr int MA = (CI >= 16) ? 16 : CI, NB = (CO >= 16) ? 16 : CO;  // lanes of the tile that carry data
   constexpr int U = (VA * VB >= 8) ? 2 : 4;                            // groups of 4 pairs gathered per iteration
+  constexpr int GP = (OT == VC_OPERAND_F32) ? 4 : 16;                  // pairs per MFMA K-step
   __shared__ int q_in[4][136];
   __shared__ int q_out[4][136];
   __shared__ float red[CI * CO];
@@ -423,41 +531,76 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
     if (valid) { qi[qlen + pos] = v; qo[qlen + pos] = (int)r; }
     qlen += __popcll(m);
     __builtin_amdgcn_wave_barrier();
-    const int ng = qlen >> 2;
-    int g = 0;
-    for (; g + U <= ng; g += U) {
-      float a[U][VA], b[U][VB];
+    if constexpr (OT == VC_OPERAND_F32) {
+      const int ng = qlen >> 2;
+      int g = 0;
+      for (; g + U <= ng; g += U) {
+        float a[U][VA], b[U][VB];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int pin = qi[(g + u) * 4 + q], pout = qo[(g + u) * 4 + q];
-        if (a_ok) VecLoad<VA>::ld(x + (int64_t)pin * CI + VA * i, a[u]);
-        else {
+        for (int u = 0; u < U; ++u) {
+          const int pin = qi[(g + u) * 4 + q], pout = qo[(g + u) * 4 + q];
+          if (a_ok) VecLoad<VA>::ld(x + (int64_t)pin * CI + VA * i, a[u]);
+          else {
 #pragma unroll
-          for (int j = 0; j < VA; ++j) a[u][j] = 0.f;
+            for (int j = 0; j < VA; ++j) a[u][j] = 0.f;
+          }
+          if (b_ok) VecLoad<VB>::ld(dy + (int64_t)pout * CO + VB * i, b[u]);
+          else {
+#pragma unroll
+            for (int j = 0; j < VB; ++j) b[u][j] = 0.f;
+          }
         }
-        if (b_ok) VecLoad<VB>::ld(dy + (int64_t)pout * CO + VB * i, b[u]);
-        else {
 #pragma unroll
-          for (int j = 0; j < VB; ++j) b[u][j] = 0.f;
-        }
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int ja = 0; ja < VA; ++ja)
+#pragma unroll
+            for (int jb = 0; jb < VB; ++jb)
+              acc[ja][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][ja], b[u][jb], acc[ja][jb], 0, 0, 0);
       }
+      for (; g < ng; ++g) {
+        const int pin = qi[g * 4 + q], pout = qo[g * 4 + q];
+        float a[VA], b[VB];
+        if (a_ok) VecLoad<VA>::ld(x + (int64_t)pin * CI + VA * i, a);
+        else {
 #pragma unroll
-      for (int u = 0; u < U; ++u)
+          for (int j = 0; j < VA; ++j) a[j] = 0.f;
+        }
+        if (b_ok) VecLoad<VB>::ld(dy + (int64_t)pout * CO + VB * i, b);
+        else {
+#pragma unroll
+          for (int j = 0; j < VB; ++j) b[j] = 0.f;
+        }
 #pragma unroll
         for (int ja = 0; ja < VA; ++ja)
 #pragma unroll
           for (int jb = 0; jb < VB; ++jb)
-            acc[ja][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][ja], b[u][jb], acc[ja][jb], 0, 0, 0);
+            acc[ja][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ja], b[jb], acc[ja][jb], 0, 0, 0);
+      }
+    } else {
+      const int ng = qlen >> 4;
+      for (int g = 0; g < ng; ++g) bw_group16<CI, CO, OT>(x, dy, qi + g * 16, qo + g * 16, 16, i, q, a_ok, b_ok, acc);
     }
-    for (; g < ng; ++g) {
-      const int pin = qi[g * 4 + q], pout = qo[g * 4 + q];
+    const int rem = qlen & (GP - 1);
+    const int done = qlen - rem;
+    int t1 = 0, t2 = 0;
+    if (lane < rem) { t1 = qi[done + lane]; t2 = qo[done + lane]; }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < rem) { qi[lane] = t1; qo[lane] = t2; }
+    qlen = rem;
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (qlen > 0) {  // tail group, padded with zero operands
+    if constexpr (OT == VC_OPERAND_F32) {
+      const bool ok = q < qlen;
+      const int pin = ok ? qi[q] : 0, pout = ok ? qo[q] : 0;
       float a[VA], b[VB];
-      if (a_ok) VecLoad<VA>::ld(x + (int64_t)pin * CI + VA * i, a);
+      if (ok && a_ok) VecLoad<VA>::ld(x + (int64_t)pin * CI + VA * i, a);
       else {
 #pragma unroll
         for (int j = 0; j < VA; ++j) a[j] = 0.f;
       }
-      if (b_ok) VecLoad<VB>::ld(dy + (int64_t)pout * CO + VB * i, b);
+      if (ok && b_ok) VecLoad<VB>::ld(dy + (int64_t)pout * CO + VB * i, b);
       else {
 #pragma unroll
         for (int j = 0; j < VB; ++j) b[j] = 0.f;
@@ -467,34 +610,9 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
 #pragma unroll
         for (int jb = 0; jb < VB; ++jb)
           acc[ja][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ja], b[jb], acc[ja][jb], 0, 0, 0);
+    } else {
+      bw_group16<CI, CO, OT>(x, dy, qi, qo, qlen, i, q, a_ok, b_ok, acc);
     }
-    const int rem = qlen - ng * 4;
-    int t1 = 0, t2 = 0;
-    if (lane < rem) { t1 = qi[ng * 4 + lane]; t2 = qo[ng * 4 + lane]; }
-    __builtin_amdgcn_wave_barrier();
-    if (lane < rem) { qi[lane] = t1; qo[lane] = t2; }
-    qlen = rem;
-    __builtin_amdgcn_wave_barrier();
-  }
-  if (qlen > 0) {  // tail group, padded with zero operands
-    const bool ok = q < qlen;
-    const int pin = ok ? qi[q] : 0, pout = ok ? qo[q] : 0;
-    float a[VA], b[VB];
-    if (ok && a_ok) VecLoad<VA>::ld(x + (int64_t)pin * CI + VA * i, a);
-    else {
-#pragma unroll
-      for (int j = 0; j < VA; ++j) a[j] = 0.f;
-    }
-    if (ok && b_ok) VecLoad<VB>::ld(dy + (int64_t)pout * CO + VB * i, b);
-    else {
-#pragma unroll
-      for (int j = 0; j < VB; ++j) b[j] = 0.f;
-    }
-#pragma unroll
-    for (int ja = 0; ja < VA; ++ja)
-#pragma unroll
-      for (int jb = 0; jb < VB; ++jb)
-        acc[ja][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ja], b[jb], acc[ja][jb], 0, 0, 0);
   }
 
   // fixed-order cross-wave reduction through LDS (wave 0 stores, waves 1..3 add in order)
@@ -624,7 +742,8 @@ int g_conv_rt = 0;             // v2 row tiles per wave: 1 (64 rows/block) | 2 (
 
 template <int CK, int CN, bool BWD>
 static int launch_gg(const float* src, const float* src_centre, int64_t n_src, const int32_t* tbl, const float* w,
-                     float* out, const int32_t* rep, const int32_t* order, int64_t n_out, int kv, int centre, int mirror, hipStream_t st) {
+                     float* out, const int32_t* rep, const int32_t* order, int64_t n_out, int kv, int centre, int mirror, int ot,
+                       hipStream_t st) {
   const int64_t rows_per_block = 4 * kRT * 16;
   if (g_conv_variant == 2 && kv <= 32 && n_src * CK * 4 < (1LL << 31)) {
     constexpr int V = (CK >= 16) ? 4 : CK / 4;
@@ -634,12 +753,27 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
     // rows per block = 64 * rt.  Measured (tools/kbench.py): rt = 1 wins or ties everywhere -- the kernel is bound by
     // L2 latency / occupancy, not by the W_k re-staging traffic: a variant looping 2/4/8 row tiles per staged W_k (W
     // traffic and barriers / RT) was 5-60 % SLOWER because of its lower occupancy, and was removed.
-    const int rt = (g_conv_rt == 2) ? 2 : 1;
-    const size_t lds = (size_t)2 * NCH * NT * 64 * V * sizeof(float) + (size_t)(kv + 1) * 64 * rt * sizeof(int) + 16;
+    // 16-bit operands: only where both channel counts are >= 16 (the 4/8-channel layers are bandwidth-bound and stay fp32)
+    const bool half_ops = (ot != VC_OPERAND_F32) && CK >= 16 && CN >= 16;
+    const int rt = (g_conv_rt == 2 && !half_ops) ? 2 : 1;
+    const size_t lds = (size_t)2 * NCH * NT * 64 * V * (half_ops ? 2 : sizeof(float)) +
+                       (size_t)(kv + 1) * 64 * rt * sizeof(int) + 16;
     const dim3 grid((unsigned)cdiv(n_out, (int64_t)64 * rt));
 #define VC_ARGS src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror
-    if (rt == 2) hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 2>), grid, dim3(256), lds, st, VC_ARGS);
-    else hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 1>), grid, dim3(256), lds, st, VC_ARGS);
+    if constexpr (CK >= 16 && CN >= 16) {
+      if (half_ops && ot == VC_OPERAND_F16) {
+        hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 1, VC_OPERAND_F16>), grid, dim3(256), lds, st, VC_ARGS);
+        VC_CHECK_LAUNCH("gather_gemm_v2_kernel<f16>");
+        return VC_OK;
+      }
+      if (half_ops) {
+        hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 1, VC_OPERAND_BF16>), grid, dim3(256), lds, st, VC_ARGS);
+        VC_CHECK_LAUNCH("gather_gemm_v2_kernel<bf16>");
+        return VC_OK;
+      }
+    }
+    if (rt == 2) hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 2, VC_OPERAND_F32>), grid, dim3(256), lds, st, VC_ARGS);
+    else hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 1, VC_OPERAND_F32>), grid, dim3(256), lds, st, VC_ARGS);
 #undef VC_ARGS
     VC_CHECK_LAUNCH("gather_gemm_v2_kernel");
     return VC_OK;
@@ -652,13 +786,14 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
 
 template <int CK, bool BWD>
 static int dispatch_cn(int cn, const float* src, const float* src_centre, int64_t n_src, const int32_t* tbl, const float* w, float* out,
-                       const int32_t* rep, const int32_t* order, int64_t n_out, int kv, int centre, int mirror, hipStream_t st) {
+                       const int32_t* rep, const int32_t* order, int64_t n_out, int kv, int centre, int mirror, int ot,
+                       hipStream_t st) {
   switch (cn) {
-    case 4: return launch_gg<CK, 4, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, st);
-    case 8: return launch_gg<CK, 8, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, st);
-    case 16: return launch_gg<CK, 16, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, st);
-    case 32: return launch_gg<CK, 32, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, st);
-    case 64: return launch_gg<CK, 64, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, st);
+    case 4: return launch_gg<CK, 4, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, st);
+    case 8: return launch_gg<CK, 8, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, st);
+    case 16: return launch_gg<CK, 16, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, st);
+    case 32: return launch_gg<CK, 32, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, st);
+    case 64: return launch_gg<CK, 64, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, st);
   }
   set_error("gather-GEMM: unsupported output channel count %d (supported: 4,8,16,32,64)", cn);
   return VC_EINVAL;
@@ -666,13 +801,14 @@ static int dispatch_cn(int cn, const float* src, const float* src_centre, int64_
 
 template <bool BWD>
 static int dispatch_ck(int ck, int cn, const float* src, const float* src_centre, int64_t n_src, const int32_t* tbl, const float* w,
-                       float* out, const int32_t* rep, const int32_t* order, int64_t n_out, int kv, int centre, int mirror, hipStream_t st) {
+                       float* out, const int32_t* rep, const int32_t* order, int64_t n_out, int kv, int centre, int mirror, int ot,
+                       hipStream_t st) {
   switch (ck) {
-    case 4: return dispatch_cn<4, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, st);
-    case 8: return dispatch_cn<8, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, st);
-    case 16: return dispatch_cn<16, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, st);
-    case 32: return dispatch_cn<32, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, st);
-    case 64: return dispatch_cn<64, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, st);
+    case 4: return dispatch_cn<4, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, st);
+    case 8: return dispatch_cn<8, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, st);
+    case 16: return dispatch_cn<16, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, st);
+    case 32: return dispatch_cn<32, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, st);
+    case 64: return dispatch_cn<64, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, st);
   }
   set_error("gather-GEMM: unsupported source channel count %d (supported: 4,8,16,32,64)", ck);
   return VC_EINVAL;
@@ -703,13 +839,24 @@ static inline void bw_split(int64_t n_out, int kv, int cin, int cout, int& nspli
 
 template <int CI, int CO>
 static int launch_bw(const float* x, const float* dy, const int32_t* tbl, int64_t n_out, int kv, float* dweight,
-                     float* partial, hipStream_t st) {
+                     float* partial, int ot, hipStream_t st) {
   int nsplit;
   int64_t rpb;
   bw_split(n_out, kv, CI, CO, nsplit, rpb);
   const unsigned nblocks = g_bw_legacy_order ? (unsigned)(nsplit * kv) : (unsigned)(cdiv(nsplit, 8) * 8 * kv);
-  hipLaunchKernelGGL((bwd_weight_kernel<CI, CO>), dim3(nblocks), dim3(256), 0, st, x, dy, tbl, n_out, kv, rpb, nsplit,
-                     g_bw_legacy_order, partial);
+#define VC_ARGS x, dy, tbl, n_out, kv, rpb, nsplit, g_bw_legacy_order, partial
+  bool launched = false;
+  if constexpr (CI >= 16 && CO >= 16) {  // 16-bit operands only where both channel counts are >= 16 (as in the gather-GEMM)
+    if (ot == VC_OPERAND_F16) {
+      hipLaunchKernelGGL((bwd_weight_kernel<CI, CO, VC_OPERAND_F16>), dim3(nblocks), dim3(256), 0, st, VC_ARGS);
+      launched = true;
+    } else if (ot == VC_OPERAND_BF16) {
+      hipLaunchKernelGGL((bwd_weight_kernel<CI, CO, VC_OPERAND_BF16>), dim3(nblocks), dim3(256), 0, st, VC_ARGS);
+      launched = true;
+    }
+  }
+  if (!launched) hipLaunchKernelGGL((bwd_weight_kernel<CI, CO, VC_OPERAND_F32>), dim3(nblocks), dim3(256), 0, st, VC_ARGS);
+#undef VC_ARGS
   VC_CHECK_LAUNCH("bwd_weight_kernel");
   const int total = kv * CI * CO;
   hipLaunchKernelGGL(bwd_weight_reduce_kernel, dim3((unsigned)cdiv(total, 64)), dim3(256), 0, st, partial, nsplit, kv,
@@ -720,13 +867,13 @@ static int launch_bw(const float* x, const float* dy, const int32_t* tbl, int64_
 
 template <int CI>
 static int dispatch_bw_co(int co, const float* x, const float* dy, const int32_t* tbl, int64_t n_out, int kv,
-                          float* dweight, float* partial, hipStream_t st) {
+                          float* dweight, float* partial, int ot, hipStream_t st) {
   switch (co) {
-    case 4: return launch_bw<CI, 4>(x, dy, tbl, n_out, kv, dweight, partial, st);
-    case 8: return launch_bw<CI, 8>(x, dy, tbl, n_out, kv, dweight, partial, st);
-    case 16: return launch_bw<CI, 16>(x, dy, tbl, n_out, kv, dweight, partial, st);
-    case 32: return launch_bw<CI, 32>(x, dy, tbl, n_out, kv, dweight, partial, st);
-    case 64: return launch_bw<CI, 64>(x, dy, tbl, n_out, kv, dweight, partial, st);
+    case 4: return launch_bw<CI, 4>(x, dy, tbl, n_out, kv, dweight, partial, ot, st);
+    case 8: return launch_bw<CI, 8>(x, dy, tbl, n_out, kv, dweight, partial, ot, st);
+    case 16: return launch_bw<CI, 16>(x, dy, tbl, n_out, kv, dweight, partial, ot, st);
+    case 32: return launch_bw<CI, 32>(x, dy, tbl, n_out, kv, dweight, partial, ot, st);
+    case 64: return launch_bw<CI, 64>(x, dy, tbl, n_out, kv, dweight, partial, ot, st);
   }
   set_error("bwd-weight: unsupported output channel count %d", co);
   return VC_EINVAL;
@@ -750,23 +897,26 @@ int vc_debug_set(const char* key, int value) {
 }
 
 int vc_conv_forward(const float* x, int64_t n_in, const int32_t* pair_fwd, int64_t n_out, int kv, const float* weight,
-                    int cin, int cout, const int32_t* row_order, float* y, void* stream) {
+                    int cin, int cout, const int32_t* row_order, int operand_type, float* y, void* stream) {
   VC_REQUIRE(n_in >= 0 && n_out >= 0 && kv >= 1 && weight, "vc_conv_forward: null/invalid argument");
   if (n_out == 0) return VC_OK;
   VC_REQUIRE(pair_fwd && y && (x || n_in == 0), "vc_conv_forward: null argument");
+  VC_REQUIRE(operand_type >= VC_OPERAND_F32 && operand_type <= VC_OPERAND_BF16, "vc_conv_forward: unknown operand_type");
   return dispatch_ck<false>(cin, cout, x, nullptr, n_in, pair_fwd, weight, y, nullptr, row_order, n_out, kv, -1, 0,
-                            (hipStream_t)stream);
+                            operand_type, (hipStream_t)stream);
 }
 
 int vc_conv_backward_input(const float* dy, const float* dy_centre, int64_t n_src, const int32_t* tbl, int64_t n_in,
                            int kv, const float* weight, int cin, int cout, int mirror, int centre, const int32_t* rep,
-                           const int32_t* row_order, float* dx, void* stream) {
+                           const int32_t* row_order, int operand_type, float* dx, void* stream) {
   VC_REQUIRE(n_src >= 0 && n_in >= 0 && kv >= 1 && weight, "vc_conv_backward_input: null/invalid argument");
   if (n_in == 0) return VC_OK;
   VC_REQUIRE(tbl && dx && (dy || n_src == 0), "vc_conv_backward_input: null argument");
   VC_REQUIRE(centre >= -1 && centre < kv, "vc_conv_backward_input: centre out of range");
+  VC_REQUIRE(operand_type >= VC_OPERAND_F32 && operand_type <= VC_OPERAND_BF16,
+             "vc_conv_backward_input: unknown operand_type");
   return dispatch_ck<true>(cout, cin, dy, dy_centre, n_src, tbl, weight, dx, rep, row_order, n_in, kv, centre,
-                           mirror ? 1 : 0, (hipStream_t)stream);
+                           mirror ? 1 : 0, operand_type, (hipStream_t)stream);
 }
 
 size_t vc_conv_backward_weight_workspace_bytes(int64_t n_out, int kv, int cin, int cout) {
@@ -776,8 +926,10 @@ size_t vc_conv_backward_weight_workspace_bytes(int64_t n_out, int kv, int cin, i
 }
 
 int vc_conv_backward_weight(const float* x, const float* dy, const int32_t* pair_fwd, int64_t n_out, int kv, int cin,
-                            int cout, float* dweight, void* ws, size_t ws_bytes, void* stream) {
+                            int cout, int operand_type, float* dweight, void* ws, size_t ws_bytes, void* stream) {
   VC_REQUIRE(n_out >= 0 && kv >= 1 && dweight && ws, "vc_conv_backward_weight: null/invalid argument");
+  VC_REQUIRE(operand_type >= VC_OPERAND_F32 && operand_type <= VC_OPERAND_BF16,
+             "vc_conv_backward_weight: unknown operand_type");
   hipStream_t st = (hipStream_t)stream;
   if (ws_bytes < vc_conv_backward_weight_workspace_bytes(n_out, kv, cin, cout)) {
     set_error("vc_conv_backward_weight: workspace too small");
@@ -790,11 +942,11 @@ int vc_conv_backward_weight(const float* x, const float* dy, const int32_t* pair
   VC_REQUIRE(x && dy && pair_fwd, "vc_conv_backward_weight: null argument");
   float* partial = (float*)ws;
   switch (cin) {
-    case 4: return dispatch_bw_co<4>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, st);
-    case 8: return dispatch_bw_co<8>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, st);
-    case 16: return dispatch_bw_co<16>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, st);
-    case 32: return dispatch_bw_co<32>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, st);
-    case 64: return dispatch_bw_co<64>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, st);
+    case 4: return dispatch_bw_co<4>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st);
+    case 8: return dispatch_bw_co<8>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st);
+    case 16: return dispatch_bw_co<16>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st);
+    case 32: return dispatch_bw_co<32>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st);
+    case 64: return dispatch_bw_co<64>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st);
   }
   set_error("bwd-weight: unsupported input channel count %d", cin);
   return VC_EINVAL;

@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256) hash_insert_kernel(const int32_t* __restr
   int b, z, y, x;
   load_coord(indices, i, ndim, b, z, y, x);
   uint64_t key = (((uint64_t)b * D + z) * H + y) * W + x;
-  uint64_t slot = mix64(key) & mask;
+  uint64_t slot = coord_slot(key, mask);
   for (;;) {
     unsigned long long prev = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)kEmptyKey,
                                         (unsigned long long)key);
@@ -59,40 +59,44 @@ __global__ void __launch_bounds__(256) hash_insert_kernel(const int32_t* __restr
       atomicMax(&vals[slot], (int)i);  // duplicate rule: highest row wins
       return;
     }
-    slot = (slot + 1) & mask;
+    slot = coord_next(slot, mask);
   }
 }
 
 // ------------------------------------------------------------------------------------------ K4 subm rulebook
+// Block = 64 consecutive rows x 4 offset groups: thread (r, kg) probes offsets kg, kg+4, ... of row r.  All offsets of a row
+// range are handled by ONE block (the old grid had the offset as blockIdx.y, i.e. the whole coordinate list was streamed
+// from HBM once per offset and neighbouring offsets of a row never shared a cache); each table write is 64 consecutive ints.
 __global__ void __launch_bounds__(256) subm_rulebook_kernel(const int32_t* __restrict__ indices, int64_t n, int ndim,
                                                             int D, int H, int W, int kz, int ky, int kx, int dz,
                                                             int dy, int dx, const uint64_t* __restrict__ keys,
                                                             const int32_t* __restrict__ vals, uint64_t mask,
                                                             int32_t* __restrict__ pair, int32_t* __restrict__ rep) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
   if (i >= n) return;
-  const int k = blockIdx.y;
+  const int kg = threadIdx.x >> 6;
   const int kv = kz * ky * kx;
   const int centre = ((kz / 2) * ky + ky / 2) * kx + kx / 2;
   int b, z, y, x;
   load_coord(indices, i, ndim, b, z, y, x);
-  if (k == centre) {
-    pair[(int64_t)k * n + i] = (int32_t)i;
-    if (rep) {
-      uint64_t key = (((uint64_t)b * D + z) * H + y) * W + x;
-      rep[i] = hash_lookup(keys, vals, mask, key);
+  for (int k = kg; k < kv; k += 4) {
+    if (k == centre) {
+      pair[(int64_t)k * n + i] = (int32_t)i;
+      if (rep) {
+        uint64_t key = (((uint64_t)b * D + z) * H + y) * W + x;
+        rep[i] = hash_lookup(keys, vals, mask, key);
+      }
+      continue;
     }
-    return;
+    const int oz = k / (ky * kx), oy = (k / kx) % ky, ox = k % kx;
+    const int nz = z + (oz - kz / 2) * dz, ny = y + (oy - ky / 2) * dy, nx = x + (ox - kx / 2) * dx;
+    int r = -1;
+    if (nz >= 0 && nz < D && ny >= 0 && ny < H && nx >= 0 && nx < W) {
+      uint64_t key = (((uint64_t)b * D + nz) * H + ny) * W + nx;
+      r = hash_lookup(keys, vals, mask, key);
+    }
+    pair[(int64_t)k * n + i] = r;
   }
-  (void)kv;
-  const int oz = k / (ky * kx), oy = (k / kx) % ky, ox = k % kx;
-  const int nz = z + (oz - kz / 2) * dz, ny = y + (oy - ky / 2) * dy, nx = x + (ox - kx / 2) * dx;
-  int r = -1;
-  if (nz >= 0 && nz < D && ny >= 0 && ny < H && nx >= 0 && nx < W) {
-    uint64_t key = (((uint64_t)b * D + nz) * H + ny) * W + nx;
-    r = hash_lookup(keys, vals, mask, key);
-  }
-  pair[(int64_t)k * n + i] = r;
 }
 
 // ------------------------------------------------------------------------------------------ K5 strided rulebook
@@ -115,14 +119,30 @@ __device__ __forceinline__ int64_t sp_candidate(const SpGeom& g, int b, int z, i
   return (((int64_t)b * g.Do + qz) * g.Ho + qy) * g.Wo + qx;
 }
 
+// Same block shape as subm_rulebook_kernel (64 rows x 4 offset groups).  For one offset the 64 lanes of a wave are 64
+// x-consecutive rows whose candidate cells mostly fall into the SAME 64-cell bitmap word: a segmented OR-scan over the wave
+// merges them and only the last lane of each run issues the atomic (same-address L2 atomics serialise).
 __global__ void __launch_bounds__(256) sp_mark_kernel(const int32_t* __restrict__ indices, int64_t n, int ndim,
                                                       SpGeom g, unsigned long long* __restrict__ bitmap) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  int b, z, y, x;
-  load_coord(indices, i, ndim, b, z, y, x);
-  int64_t L = sp_candidate(g, b, z, y, x, blockIdx.y);
-  if (L >= 0) atomicOr(&bitmap[L >> 6], 1ULL << (L & 63));
+  const int lane = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  const bool live = i < n;
+  int b = 0, z = 0, y = 0, x = 0;
+  if (live) load_coord(indices, i, ndim, b, z, y, x);
+  const int kv = g.k[0] * g.k[1] * g.k[2];
+  for (int k = kg; k < kv; k += 4) {
+    const int64_t L = live ? sp_candidate(g, b, z, y, x, k) : -1;
+    long long w = (L >= 0) ? (long long)(L >> 6) : (long long)(-1 - lane);  // invalid lanes never match anything
+    unsigned long long bits = (L >= 0) ? (1ULL << (L & 63)) : 0ULL;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const long long ow = __shfl_up(w, off, 64);
+      const unsigned long long ob = __shfl_up(bits, off, 64);
+      if (lane >= off && ow == w) bits |= ob;
+    }
+    const long long nw = __shfl_down(w, 1, 64);
+    if (L >= 0 && (lane == 63 || nw != w)) atomicOr(&bitmap[w], bits);
+  }
 }
 
 __global__ void __launch_bounds__(256) sp_blocksum_kernel(const unsigned long long* __restrict__ bitmap,
@@ -226,19 +246,22 @@ __global__ void __launch_bounds__(256) sp_pairs_kernel(const int32_t* __restrict
                                                        const uint32_t* __restrict__ prefix, int64_t n_out,
                                                        int32_t* __restrict__ pair_fwd,
                                                        int32_t* __restrict__ pair_bwd) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);  // 64 rows x 4 offset groups, as sp_mark_kernel
   if (i >= n) return;
-  const int k = blockIdx.y;
+  const int kg = threadIdx.x >> 6;
   int b, z, y, x;
   load_coord(indices, i, ndim, b, z, y, x);
-  int64_t L = sp_candidate(g, b, z, y, x, k);
-  int o = -1;
-  if (L >= 0) {
-    unsigned long long w = bitmap[L >> 6];
-    o = (int)prefix[L >> 6] + __popcll(w & ((1ULL << (L & 63)) - 1ULL));
-    atomicMax(&pair_fwd[(int64_t)k * n_out + o], (int)i);  // duplicate inputs: highest row wins
+  const int kv = g.k[0] * g.k[1] * g.k[2];
+  for (int k = kg; k < kv; k += 4) {
+    const int64_t L = sp_candidate(g, b, z, y, x, k);
+    int o = -1;
+    if (L >= 0) {
+      unsigned long long w = bitmap[L >> 6];
+      o = (int)prefix[L >> 6] + __popcll(w & ((1ULL << (L & 63)) - 1ULL));
+      atomicMax(&pair_fwd[(int64_t)k * n_out + o], (int)i);  // duplicate inputs: highest row wins
+    }
+    pair_bwd[(int64_t)k * n + i] = o;
   }
-  pair_bwd[(int64_t)k * n + i] = o;
 }
 
 // ------------------------------------------------------------------------------------------ K9 projection
@@ -568,13 +591,13 @@ extern "C" {
 const char* vc_version(void) { return "virconv_hip 0.1 (gfx950)"; }
 const char* vc_last_error(void) { return g_err; }
 
-size_t vc_hash_workspace_bytes(int64_t n) { return (size_t)hash_capacity(n < 0 ? 0 : n) * 12; }
+size_t vc_hash_workspace_bytes(int64_t n) { return (size_t)coord_hash_capacity(n < 0 ? 0 : n) * 12; }
 
 int vc_hash_build(const int32_t* indices, int64_t n, int ndim, const int32_t* shape, void* ws, size_t ws_bytes,
                   void* stream) {
   VC_REQUIRE(ndim == 2 || ndim == 3, "vc_hash_build: ndim must be 2 or 3 (got %d)", ndim);
   VC_REQUIRE(n >= 0 && ws && shape && (indices || n == 0), "vc_hash_build: null argument");
-  const uint64_t cap = hash_capacity(n);
+  const uint64_t cap = coord_hash_capacity(n);
   if (ws_bytes < cap * 12) { set_error("vc_hash_build: workspace %zu < %llu", ws_bytes, (unsigned long long)cap * 12); return VC_ECAPACITY; }
   hipStream_t st = (hipStream_t)stream;
   VC_CHECK_HIP(hipMemsetAsync(ws, 0xFF, cap * 12, st));
@@ -594,14 +617,14 @@ int vc_subm_rulebook(const int32_t* indices, int64_t n, int ndim, const int32_t*
   VC_REQUIRE(ndim == 2 || ndim == 3, "vc_subm_rulebook: ndim must be 2 or 3");
   VC_REQUIRE(n >= 0 && ws && shape && ksize && (n == 0 || (indices && pair_fwd)), "vc_subm_rulebook: null argument");
   if (n == 0) return VC_OK;
-  const uint64_t cap = hash_capacity(n);
+  const uint64_t cap = coord_hash_capacity(n);
   if (ws_bytes < cap * 12) { set_error("vc_subm_rulebook: workspace too small"); return VC_ECAPACITY; }
   Dims d = make_dims(ndim, shape);
   Kern3 g = make_kern(ndim, ksize, nullptr, nullptr, dilation);
   for (int a = 0; a < 3; ++a) VC_REQUIRE(g.k[a] % 2 == 1, "vc_subm_rulebook: kernel sizes must be odd");
   const uint64_t* keys = (const uint64_t*)ws;
   const int32_t* vals = (const int32_t*)(keys + cap);
-  hipLaunchKernelGGL(subm_rulebook_kernel, dim3((unsigned)cdiv(n, 256), g.kv), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(subm_rulebook_kernel, dim3((unsigned)cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream,
                      indices, n, ndim, d.D, d.H, d.W, g.k[0], g.k[1], g.k[2], g.d[0], g.d[1], g.d[2], keys, vals,
                      cap - 1, pair_fwd, rep_out);
   VC_CHECK_LAUNCH("subm_rulebook_kernel");
@@ -650,7 +673,7 @@ int vc_spconv_mark_count(const int32_t* indices, int64_t n, int ndim, int batch_
   Kern3 k = make_kern(ndim, ksize, stride_, padding, dilation);
   SpGeom g = make_spgeom(o, k);
   if (n > 0) {
-    hipLaunchKernelGGL(sp_mark_kernel, dim3((unsigned)cdiv(n, 256), k.kv), dim3(256), 0, st, indices, n, ndim, g, bitmap);
+    hipLaunchKernelGGL(sp_mark_kernel, dim3((unsigned)cdiv(n, 64)), dim3(256), 0, st, indices, n, ndim, g, bitmap);
     VC_CHECK_LAUNCH("sp_mark_kernel");
   }
   hipLaunchKernelGGL(sp_blocksum_kernel, dim3((unsigned)nb), dim3(256), 0, st, bitmap, nwords, blocksum);
@@ -685,7 +708,7 @@ int vc_spconv_emit_pairs(const int32_t* indices, int64_t n, int ndim, int batch_
   VC_CHECK_LAUNCH("sp_emit_kernel");
   if (n_out > 0) VC_CHECK_HIP(hipMemsetAsync(pair_fwd, 0xFF, (size_t)k.kv * n_out * 4, st));
   if (n > 0) {
-    hipLaunchKernelGGL(sp_pairs_kernel, dim3((unsigned)cdiv(n, 256), k.kv), dim3(256), 0, st, indices, n, ndim, g,
+    hipLaunchKernelGGL(sp_pairs_kernel, dim3((unsigned)cdiv(n, 64)), dim3(256), 0, st, indices, n, ndim, g,
                        bitmap, prefix, n_out, pair_fwd, pair_bwd);
     VC_CHECK_LAUNCH("sp_pairs_kernel");
   }

@@ -123,8 +123,8 @@ class SparseConvFunction(torch.autograd.Function):
         ctx.rb, ctx.inverse = rb, inverse
         ctx.save_for_backward(features, weight)
         if inverse:
-            return be.conv_forward(features, weight, rb.pair_bwd, order=rb.order_bwd)
-        return be.conv_forward(features, weight, rb.pair_fwd, order=rb.order_fwd)
+            return be.conv_forward(features, weight, rb.pair_bwd, order=rb.order_bwd, operand=MFMA_OPERAND)
+        return be.conv_forward(features, weight, rb.pair_fwd, order=rb.order_fwd, operand=MFMA_OPERAND)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -148,20 +148,22 @@ def _conv_backward(rb: "Rulebook", inverse: bool, features, weight, grad_out, ne
         side.wait_stream(main)
         alive = []  # scratch + operands of the side-stream launch stay referenced until the join
         dw = be.conv_backward_weight(features, grad_out, tbl_w, tuple(weight.shape), stream=side.cuda_stream,
-                                     keep_alive=alive)
+                                     keep_alive=alive, operand=MFMA_OPERAND)
     if need_dx:
         if inverse:
-            dx = be.conv_backward_input(grad_out, weight, rb.pair_fwd, rb.n_out, mirror=False, order=rb.order_fwd)
+            dx = be.conv_backward_input(grad_out, weight, rb.pair_fwd, rb.n_out, mirror=False, order=rb.order_fwd,
+                                        operand=MFMA_OPERAND)
         elif rb.kind == "subm":
             dx = be.conv_backward_input(grad_out, weight, rb.pair_fwd, rb.n_in, mirror=True, centre=rb.centre, rep=rb.rep,
-                                        order=rb.order_bwd)
+                                        order=rb.order_bwd, operand=MFMA_OPERAND)
         else:
-            dx = be.conv_backward_input(grad_out, weight, rb.pair_bwd, rb.n_in, mirror=False, order=rb.order_bwd)
+            dx = be.conv_backward_input(grad_out, weight, rb.pair_bwd, rb.n_in, mirror=False, order=rb.order_bwd,
+                                        operand=MFMA_OPERAND)
     if side is not None:
         main.wait_stream(side)
         del alive
     elif need_dw:
-        dw = be.conv_backward_weight(features, grad_out, tbl_w, tuple(weight.shape))
+        dw = be.conv_backward_weight(features, grad_out, tbl_w, tuple(weight.shape), operand=MFMA_OPERAND)
     return dx, dw
 
 
@@ -172,8 +174,8 @@ class ConvBNReLUFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, rb, inverse, running_mean, running_var, nbt, momentum, eps, relu):
         be = get_backend()
-        y_raw = (be.conv_forward(x, weight, rb.pair_bwd, order=rb.order_bwd) if inverse
-                 else be.conv_forward(x, weight, rb.pair_fwd, order=rb.order_fwd))
+        y_raw = (be.conv_forward(x, weight, rb.pair_bwd, order=rb.order_bwd, operand=MFMA_OPERAND) if inverse
+                 else be.conv_forward(x, weight, rb.pair_fwd, order=rb.order_fwd, operand=MFMA_OPERAND))
         y, mean, var = be.bn_forward(y_raw, gamma, beta, running_mean, running_var, True, momentum, eps, relu,
                                      num_batches_tracked=nbt)
         ctx.rb, ctx.inverse, ctx.cfg = rb, inverse, (float(eps), bool(relu))
@@ -204,6 +206,9 @@ OVERLAP_WEIGHT_GRAD = True
 #          issued work 2.3x (measured: s3.down bwd 197 -> 85 us) and a 1024-row window is enough
 #   "all"  every table (measured: strided forward -25 %, SubM +-0 -- the sort costs more than it saves there)
 #   "none" natural order everywhere
+# MFMA operand type of the conv kernels: "f32" (exact, default, the parity path) | "f16" | "bf16" (BASELINE configs[4]:
+# "fp16 MFMA contraction"; tensors stay fp32, operands are rounded in registers, accumulation is fp32)
+MFMA_OPERAND = os.environ.get("VIRCONV_MFMA_OPERAND", "f32")
 ROW_ORDER = os.environ.get("VIRCONV_ROW_ORDER", "bwd")
 ROW_ORDER_WINDOW = int(os.environ.get("VIRCONV_ROW_ORDER_WINDOW", "2048"))
 _SIDE_STREAMS = {}
