@@ -9,4 +9,5 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/f
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/f1/write -o x -- python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline > $R/gpurun_out/f1/p_write.log 2>&1
 cd $R
 find gpurun_out/f1 -name "*kernel_trace.csv" -delete
+timeout 100 python tools/kbench.py > gpurun_out/f1/kbench.txt 2>&1
 tail -n 3 gpurun_out/f1/t.log

@@ -43,20 +43,36 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int* total, int* 
 }
 
 // ------------------------------------------------------------------------------------------ K3 hash build
+// Rows of the image-space (2-D) tensors repeat coordinates massively (every voxel outside the camera frustum clamps onto a
+// border pixel), and equal keys sit in consecutive rows: a segmented max-scan over the wave folds each run of equal keys
+// into its last lane, which does the one CAS + atomicMax for the run (same-address atomics serialise in L2).
 __global__ void __launch_bounds__(256) hash_insert_kernel(const int32_t* __restrict__ indices, int64_t n, int ndim,
                                                           int D, int H, int W, uint64_t* __restrict__ keys,
                                                           int32_t* __restrict__ vals, uint64_t mask) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  int b, z, y, x;
-  load_coord(indices, i, ndim, b, z, y, x);
-  uint64_t key = (((uint64_t)b * D + z) * H + y) * W + x;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool live = i < n;
+  uint64_t key = kEmptyKey - 1 - (uint64_t)lane;  // dead lanes: distinct, never equal to a real key
+  if (live) {
+    int b, z, y, x;
+    load_coord(indices, i, ndim, b, z, y, x);
+    key = (((uint64_t)b * D + z) * H + y) * W + x;
+  }
+  int row = live ? (int)i : -1;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint64_t ok = __shfl_up((unsigned long long)key, off, 64);
+    const int orow = __shfl_up(row, off, 64);
+    if (lane >= off && ok == key) row = max(row, orow);
+  }
+  const uint64_t nk = __shfl_down((unsigned long long)key, 1, 64);
+  if (!live || (lane != 63 && nk == key)) return;  // not the tail of its run
   uint64_t slot = coord_slot(key, mask);
   for (;;) {
     unsigned long long prev = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)kEmptyKey,
                                         (unsigned long long)key);
     if (prev == kEmptyKey || prev == key) {
-      atomicMax(&vals[slot], (int)i);  // duplicate rule: highest row wins
+      atomicMax(&vals[slot], row);  // duplicate rule: highest row wins
       return;
     }
     slot = coord_next(slot, mask);
@@ -132,8 +148,15 @@ __global__ void __launch_bounds__(256) sp_mark_kernel(const int32_t* __restrict_
   const int kv = g.k[0] * g.k[1] * g.k[2];
   for (int k = kg; k < kv; k += 4) {
     const int64_t L = live ? sp_candidate(g, b, z, y, x, k) : -1;
-    long long w = (L >= 0) ? (long long)(L >> 6) : (long long)(-1 - lane);  // invalid lanes never match anything
-    unsigned long long bits = (L >= 0) ? (1ULL << (L & 63)) : 0ULL;
+    const bool valid = L >= 0;
+    // lanes without a candidate (for stride 2 every other x) adopt the word of the nearest valid lane below them, so that
+    // the lanes of one word form ONE contiguous run whose last lane flushes it
+    const unsigned long long vm = __ballot(valid);
+    const unsigned long long below = vm & ((lane == 63) ? ~0ULL : ((2ULL << lane) - 1ULL));
+    const int src = below ? 63 - __clzll((long long)below) : lane;
+    const long long w0 = valid ? (long long)(L >> 6) : (long long)(-1 - lane);
+    const long long w = __shfl(w0, src, 64);
+    unsigned long long bits = valid ? (1ULL << (L & 63)) : 0ULL;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const long long ow = __shfl_up(w, off, 64);
@@ -141,7 +164,7 @@ __global__ void __launch_bounds__(256) sp_mark_kernel(const int32_t* __restrict_
       if (lane >= off && ow == w) bits |= ob;
     }
     const long long nw = __shfl_down(w, 1, 64);
-    if (L >= 0 && (lane == 63 || nw != w)) atomicOr(&bitmap[w], bits);
+    if (bits != 0ULL && (lane == 63 || nw != w)) atomicOr(&bitmap[w], bits);
   }
 }
 
