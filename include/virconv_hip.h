@@ -197,6 +197,37 @@ int vc_bn_relu_backward(const float* x, const float* dy, int dy_stride, int dy_c
                         const float* mean, const float* var, const float* gamma, const float* beta, float eps,
                         int relu, float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
 
+/* ================================================================================================ RoI grid pooling
+ * the operators that consume multi_scale_3d_features['x_conv3'/'x_conv4'] right after the backbone
+ * (pcdet/models/roi_heads/ted_head.py:450-650 -> pointnet2_stack/voxel_pool_modules.py:70-130).
+ *
+ * Voxel index: occupancy bitmap + coordinate hash over the (N, 4) [b, z, y, x] indices of a sparse tensor.  Replaces the
+ * dense (B, Z, Y, X) int32 volume of generate_voxel2pinds (pcdet/utils/spconv_utils.py:4-21).                        */
+size_t vc_voxel_index_workspace_bytes(int64_t n, int batch_size, const int32_t* host_spatial_shape /* [Z, Y, X] */);
+int vc_voxel_index_build(const int32_t* indices, int64_t n, int batch_size, const int32_t* host_spatial_shape, void* ws,
+                         size_t ws_bytes, void* stream);
+
+/* Voxel query: for query m (metric position new_xyz[m], voxel coordinate new_coords[m] = [b, z, y, x]) the first `nsample`
+ * voxels, in dz, dy, dx ascending scan order over [-range, +range]^3, whose centre xyz[row] lies within `radius`.
+ * idx (m, nsample) int32 = rows of `xyz` (GLOBAL rows, as the reference kernel writes them); unused slots repeat the
+ * first hit; empty_mask[m] = 1 and a zero row when nothing was found (the post-processing of VoxelQuery.forward is
+ * included).  x_range <= 31.  Replaces voxel_query_wrapper_stack (pointnet2_stack/src/voxel_query.cpp:25-41,
+ * voxel_query_gpu.cu:10-113, voxel_query_utils.py:12-46).                                                            */
+int vc_voxel_query(const void* ws, size_t ws_bytes, int64_t n, int batch_size, const int32_t* host_spatial_shape,
+                   const float* xyz, const float* new_xyz, const int32_t* new_coords, int64_t m, int z_range, int y_range,
+                   int x_range, float radius, int nsample, int32_t* idx, uint8_t* empty_mask, void* stream);
+
+/* out[m, c, s] = features[start(batch of m) + idx[m, s], c]  (idx batch-LOCAL, as the reference's stacked layout) and its
+ * transpose (scatter-add with fp32 atomics, like the reference).  Argument order follows group_points_wrapper_stack /
+ * group_points_grad_wrapper_stack (pointnet2_stack/src/group_points.cpp, group_points_gpu.cu:15-118,
+ * pointnet2_utils.py:48-105).  grad_features is zeroed by the call.                                                   */
+int vc_group_points(int batch_size, int64_t m, int c, int nsample, const float* features,
+                    const int32_t* features_batch_cnt, const int32_t* idx, const int32_t* idx_batch_cnt, float* out,
+                    void* stream);
+int vc_group_points_grad(int batch_size, int64_t m, int c, int64_t n, int nsample, const float* grad_out,
+                         const int32_t* idx, const int32_t* idx_batch_cnt, const int32_t* features_batch_cnt,
+                         float* grad_features, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

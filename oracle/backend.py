@@ -11,7 +11,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from . import geometry, sparse_ref
+from . import geometry, pooling_ref, sparse_ref
 
 
 def _np(t: torch.Tensor) -> np.ndarray:
@@ -110,6 +110,22 @@ class OracleBackend:
         idx = indices.long()
         sl = (idx[:, 0], slice(None)) + tuple(idx[:, a + 1] for a in range(idx.shape[1] - 1))
         return dense[sl].contiguous()
+
+    # ------------------------------------------------------------------ RoI grid pooling
+    def voxel_index_build(self, indices, batch_size, spatial_shape):
+        return torch.from_numpy(pooling_ref.voxel2pinds(_np(indices), int(batch_size), spatial_shape))  # dense volume
+
+    def voxel_query(self, ws, n, batch_size, spatial_shape, xyz, new_xyz, new_coords, max_range, radius, nsample):
+        idx, empty = pooling_ref.voxel_query(max_range, radius, nsample, _np(xyz), _np(new_xyz), _np(new_coords), _np(ws))
+        return torch.from_numpy(idx), torch.from_numpy(empty)
+
+    def group_points(self, features, features_batch_cnt, idx, idx_batch_cnt):
+        return torch.from_numpy(pooling_ref.group_points(_np(features), _np(features_batch_cnt), _np(idx),
+                                                         _np(idx_batch_cnt)))
+
+    def group_points_grad(self, grad_out, idx, idx_batch_cnt, features_batch_cnt, n):
+        return torch.from_numpy(pooling_ref.group_points_grad(_np(grad_out), _np(idx), _np(idx_batch_cnt),
+                                                              _np(features_batch_cnt), int(n)))
 
     # ------------------------------------------------------------------ voxelise + MeanVFE
     def voxelize_mean(self, points, pc_range, voxel_size, max_points, max_voxels, vfe_max_last):

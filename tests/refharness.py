@@ -93,3 +93,45 @@ class Calib:
 def make_reference_calib(calib_dict):
     from pcdet.utils.calibration_kitti import Calibration
     return Calibration(dict(calib_dict))
+
+
+# ------------------------------------------------------------------------------------------------ RoI grid pooling
+def import_reference_voxel_pool():
+    """-> (voxel_pool_modules, spconv_utils, common_utils) of the REFERENCE, unmodified, with its compiled extension
+    `pointnet2_stack_cuda` replaced by the CPU oracle (oracle/pooling_ref.py) and torch.cuda.{Int,Float}Tensor mapped to
+    CPU constructors (the wrappers allocate their outputs with them: voxel_query_utils.py:33, pointnet2_utils.py:77,97)."""
+    assert available(), "reference tree not present"
+    import numpy as np
+    import torch
+    from oracle import pooling_ref
+    import_reference_backbone()  # facade + stubs + sys.path
+    ext = sys.modules["pcdet.ops.pointnet2.pointnet2_stack.pointnet2_stack_cuda"]
+
+    def voxel_query_wrapper(M, Z, Y, X, nsample, radius, z_range, y_range, x_range, new_xyz, xyz, new_coords,
+                            point_indices, idx):
+        out, empty = pooling_ref.voxel_query((z_range, y_range, x_range), radius, nsample, xyz.numpy(), new_xyz.numpy(),
+                                             new_coords.numpy(), point_indices.numpy())
+        out = out.copy()
+        out[empty, 0] = -1  # raw kernel output: `if (cnt == 0) idx[0] = -1` on a zero-initialised row
+        idx.copy_(torch.from_numpy(out))
+        return 1
+
+    def group_points_wrapper(B, M, C, nsample, features, features_batch_cnt, idx, idx_batch_cnt, output):
+        output.copy_(torch.from_numpy(pooling_ref.group_points(features.detach().numpy(), features_batch_cnt.numpy(),
+                                                               idx.numpy(), idx_batch_cnt.numpy())))
+        return 1
+
+    def group_points_grad_wrapper(B, M, C, N, nsample, grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features):
+        grad_features.copy_(torch.from_numpy(pooling_ref.group_points_grad(
+            grad_out.numpy(), idx.numpy(), idx_batch_cnt.numpy(), features_batch_cnt.numpy(), N)))
+        return 1
+
+    ext.voxel_query_wrapper = voxel_query_wrapper
+    ext.group_points_wrapper = group_points_wrapper
+    ext.group_points_grad_wrapper = group_points_grad_wrapper
+    torch.cuda.IntTensor = lambda *shape: torch.zeros(*shape, dtype=torch.int32)
+    torch.cuda.FloatTensor = lambda *shape: torch.zeros(*shape, dtype=torch.float32)
+    vpm = importlib.import_module("pcdet.ops.pointnet2.pointnet2_stack.voxel_pool_modules")
+    su = importlib.import_module("pcdet.utils.spconv_utils")
+    cu = importlib.import_module("pcdet.utils.common_utils")
+    return vpm, su, cu

@@ -32,6 +32,11 @@ SIGNATURES = {
     "vc_spconv_emit_pairs": (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _I64, _P, _P, _P, _P]),
     "vc_conv_forward": (_I, [_P, _I64, _P, _I64, _I, _P, _I, _I, _P, _I, _P, _P]),
     "vc_conv_backward_input": (_I, [_P, _P, _I64, _P, _I64, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
+    "vc_voxel_index_workspace_bytes": (_SZ, [_I64, _I, _P]),
+    "vc_voxel_index_build": (_I, [_P, _I64, _I, _P, _P, _SZ, _P]),
+    "vc_voxel_query": (_I, [_P, _SZ, _I64, _I, _P, _P, _P, _P, _I64, _I, _I, _I, _F, _I, _P, _P, _P]),
+    "vc_group_points": (_I, [_I, _I64, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "vc_group_points_grad": (_I, [_I, _I64, _I, _I64, _I, _P, _P, _P, _P, _P, _P]),
     "vc_row_order": (_I, [_P, _I64, _I, _P, _I, _I, _P, _P]),
     "vc_conv_backward_weight_workspace_bytes": (_SZ, [_I64, _I, _I, _I]),
     "vc_conv_backward_weight": (_I, [_P, _P, _P, _I64, _I, _I, _I, _I, _P, _P, _SZ, _P]),

@@ -216,6 +216,58 @@ class HipBackend:
             keep_alive.extend((ws, x, dy, pair_fwd))
         return dw
 
+    # ------------------------------------------------------------------ RoI grid pooling
+    def voxel_index_build(self, indices: torch.Tensor, batch_size: int, spatial_shape) -> torch.Tensor:
+        """Occupancy bitmap + coordinate hash over (N, 4) [b, z, y, x] -> opaque workspace tensor (vc_voxel_index_build)."""
+        indices = _need(indices, torch.int32, "indices")
+        assert indices.shape[1] == 4 and len(spatial_shape) == 3
+        shp = i32arr(spatial_shape)
+        nbytes = self.lib.vc_voxel_index_workspace_bytes(indices.shape[0], int(batch_size), shp)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=indices.device)
+        check(self.lib.vc_voxel_index_build(_ptr(indices), indices.shape[0], int(batch_size), shp, _ptr(ws), nbytes,
+                                            _stream()), "vc_voxel_index_build")
+        return ws
+
+    def voxel_query(self, ws: torch.Tensor, n: int, batch_size: int, spatial_shape, xyz: torch.Tensor,
+                    new_xyz: torch.Tensor, new_coords: torch.Tensor, max_range, radius: float, nsample: int):
+        xyz = _need(xyz, torch.float32, "xyz")
+        new_xyz = _need(new_xyz, torch.float32, "new_xyz")
+        new_coords = _need(new_coords, torch.int32, "new_coords")
+        m = new_coords.shape[0]
+        assert xyz.shape == (n, 3) and new_xyz.shape == (m, 3) and new_coords.shape[1] == 4
+        idx = torch.empty((m, nsample), dtype=torch.int32, device=xyz.device)
+        empty = torch.empty((m,), dtype=torch.uint8, device=xyz.device)
+        zr, yr, xr = (int(v) for v in max_range)
+        check(self.lib.vc_voxel_query(_ptr(ws), ws.numel(), n, int(batch_size), i32arr(spatial_shape), _ptr(xyz),
+                                      _ptr(new_xyz), _ptr(new_coords), m, zr, yr, xr, float(radius), int(nsample),
+                                      _ptr(idx), _ptr(empty), _stream()), "vc_voxel_query")
+        return idx, empty.bool()
+
+    def group_points(self, features: torch.Tensor, features_batch_cnt: torch.Tensor, idx: torch.Tensor,
+                     idx_batch_cnt: torch.Tensor) -> torch.Tensor:
+        features = _need(features, torch.float32, "features")
+        idx = _need(idx, torch.int32, "idx")
+        fbc = _need(features_batch_cnt, torch.int32, "features_batch_cnt")
+        ibc = _need(idx_batch_cnt, torch.int32, "idx_batch_cnt")
+        m, nsample = idx.shape
+        c = features.shape[1]
+        out = torch.empty((m, c, nsample), dtype=torch.float32, device=features.device)
+        check(self.lib.vc_group_points(ibc.shape[0], m, c, nsample, _ptr(features), _ptr(fbc), _ptr(idx), _ptr(ibc),
+                                       _ptr(out), _stream()), "vc_group_points")
+        return out
+
+    def group_points_grad(self, grad_out: torch.Tensor, idx: torch.Tensor, idx_batch_cnt: torch.Tensor,
+                          features_batch_cnt: torch.Tensor, n: int) -> torch.Tensor:
+        grad_out = _need(grad_out, torch.float32, "grad_out")
+        idx = _need(idx, torch.int32, "idx")
+        fbc = _need(features_batch_cnt, torch.int32, "features_batch_cnt")
+        ibc = _need(idx_batch_cnt, torch.int32, "idx_batch_cnt")
+        m, c, nsample = grad_out.shape
+        gf = torch.empty((n, c), dtype=torch.float32, device=grad_out.device)
+        check(self.lib.vc_group_points_grad(ibc.shape[0], m, c, n, nsample, _ptr(grad_out), _ptr(idx), _ptr(ibc), _ptr(fbc),
+                                            _ptr(gf), _stream()), "vc_group_points_grad")
+        return gf
+
     # ------------------------------------------------------------------ projection / discard / dense
     def project_uv(self, indices: torch.Tensor, calib: torch.Tensor, trans: Optional[torch.Tensor], batch_size: int,
                    stride: int, want_depth: bool = False):

@@ -21,6 +21,7 @@ SOURCES = {
     "index_kernels.hip": ["-ffp-contract=off"],
     "conv_kernels.hip": [],
     "bn_kernels.hip": [],
+    "pool_kernels.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 
