@@ -27,9 +27,9 @@ def _batch(g, device):
     return b
 
 
-def _run_and_check(device, mode):
+def _run_and_check(device, mode, plan_ahead=True):
     g = load_golden("virconv_8x_ref.npz")
-    model = VirConv8x(CFG_8X, input_channels=8, grid_size=GRID).to(device)
+    model = VirConv8x(dict(CFG_8X, PLAN_AHEAD=plan_ahead), input_channels=8, grid_size=GRID).to(device)
     fill_parameters(model, 11)
     model.train(mode == "train")
     with torch.no_grad():
@@ -58,12 +58,39 @@ def test_state_dict_layout():
     assert len(keys) == 186 and "conv_input.0.weight" in keys and "conv2.0.0.weight" in keys and "vir_conv4.d2_conv2.1.bias" in keys
 
 
+@pytest.mark.parametrize("plan_ahead", [True, False])
 @pytest.mark.parametrize("mode", ["eval", "train"])
-def test_8x_oracle_backend_matches_reference(oracle_backend, mode):
-    _run_and_check("cpu", mode)
+def test_8x_oracle_backend_matches_reference(oracle_backend, mode, plan_ahead):
+    _run_and_check("cpu", mode, plan_ahead)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("plan_ahead", [True, False])
 @pytest.mark.parametrize("mode", ["eval", "train"])
-def test_8x_hip_matches_reference(hip_backend, mode):
-    _run_and_check("cuda", mode)
+def test_8x_hip_matches_reference(hip_backend, mode, plan_ahead):
+    _run_and_check("cuda", mode, plan_ahead)
+
+
+@pytest.mark.gpu
+def test_8x_train_step_with_layer_discard_plan_equals_inline(hip_backend):
+    """Train mode with the spconv-1.x layer discard on (injected permutations): the plan-ahead path and the inline path
+    give bit-identical outputs and gradients (same kernels, same order; only where the geometry is built differs)."""
+    g = load_golden("virconv_8x_ref.npz")
+    res = []
+    for plan_ahead in (True, False):
+        cfg = dict(CFG_8X, PLAN_AHEAD=plan_ahead, LAYER_DISCARD_MODE="spconv1_inplace")
+        model = VirConv8x(cfg, input_channels=8, grid_size=GRID).cuda()
+        fill_parameters(model, 11)
+        model.train()
+        b = _batch(g, "cuda")
+        torch.manual_seed(7)   # the discard permutations are drawn with torch.randperm in both paths, in the same order
+        out = model(b)
+        loss = sum((out["encoded_spconv_tensor" + r].features.sum() + out["multi_scale_3d_features_mm" + r]["x_conv4"].features.sum())
+                   for r in ("", "1", "2"))
+        loss.backward()
+        res.append((out["multi_scale_3d_features_mm"]["x_conv4"].features.detach().clone(),
+                    {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    assert torch.equal(res[0][0], res[1][0])
+    assert res[0][1].keys() == res[1][1].keys()
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k

@@ -61,6 +61,7 @@ def main():
             loc[empty] = 0
             t_g = timeit(lambda: be.group_points(feats, cnt, loc, new_cnt), args.iters)
             go = torch.randn((m, 32, 16), generator=g).to(dev)
+            go[empty] = 0                                                    # the module zeroes emptied balls (keep mask)
             t_b = timeit(lambda: be.group_points_grad(go, loc, new_cnt, cnt, n), args.iters)
             gbytes = m * 16 * 32 * 4 * 2 / 1e9                               # rows read + (M, C, nsample) written
             print(f"{name:8s} {n:7d} {m:7d} | {t_index:9.1f} | {str(rng):>9s} {t_q:9.1f} {100 * float(empty.float().mean()):8.1f} "

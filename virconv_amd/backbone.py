@@ -191,6 +191,76 @@ def _plan_stream(device):
     return _PLAN_STREAMS[key]
 
 
+class _PlanScope:
+    """Run the geometry plan on the high-priority side stream (see VirConvL8x.build_plan) and hand the result to the main
+    stream.  CPU tensors: a no-op scope."""
+
+    def __init__(self, ref_tensor, batch_dict):
+        self.on_gpu = ref_tensor.is_cuda
+        if self.on_gpu:
+            self.main = torch.cuda.current_stream()
+            self.side = _plan_stream(ref_tensor.device)
+            ready = batch_dict.get("inputs_ready_event")
+            if ready is not None:
+                self.side.wait_event(ready)  # inputs were produced before this event: no need to wait for the stream tail
+            else:
+                self.side.wait_stream(self.main)
+            self.ctx = torch.cuda.stream(self.side)
+        else:
+            import contextlib
+            self.ctx = contextlib.nullcontext()
+
+    def __enter__(self):
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc)
+
+    def publish(self, plan):
+        if self.on_gpu:
+            self.main.wait_stream(self.side)
+            _record_stream(plan, self.main)
+        return plan
+
+
+def _draw_keep(rate, n, batch_dict, tag, device):
+    """Rows kept by layer_voxel_discard: the first floor(n * (1 - rate)) entries of a permutation (injected or drawn)."""
+    n_keep = int(n * (1 - rate))
+    inj = batch_dict.get("layer_discard_keep")
+    if inj is not None:
+        keep = inj[tag].to(device=device, dtype=torch.int64)
+        assert keep.shape[0] == n_keep, f"injected keep has {keep.shape[0]} rows, expected {n_keep}"
+        return keep
+    return torch.randperm(n, device=device)[:n_keep]
+
+
+def _plan_nrconv_chain(blocks, in_idx, shape, batch_size, calib, trans_param, discard_tags, rate, batch_dict):
+    """Plans of consecutive NRConvBlocks (+ the layer discard after a block when its tag is not None)."""
+    stages = []
+    for (blk, stride), tag in zip(blocks, discard_tags):
+        p = blk.plan(in_idx, shape, batch_size, calib, stride, trans_param)
+        in_idx, shape = p["out_indices"], p["out_shape"]
+        p["keep"] = None
+        if tag is not None:
+            keep = _draw_keep(rate, in_idx.shape[0], batch_dict, tag, in_idx.device)
+            _, in_idx = ops.get_backend().gather_rows(None, in_idx, keep)
+            p["keep"], p["kept_indices"] = keep, in_idx
+        stages.append(p)
+    return stages, in_idx, shape
+
+
+def _run_nrconv_chain(blocks, stages, x, batch_size, calib, trans_param):
+    outs = []
+    for (blk, stride), p in zip(blocks, stages):
+        x = blk(x, batch_size, calib, stride, None, trans_param, plan=p)
+        if p["keep"] is not None:
+            f = ops.GatherRowsFunction.apply(x.features, p["keep"])
+            x = spconv.SparseConvTensor(f, p["kept_indices"], x.spatial_shape, batch_size)
+        outs.append(x)
+    return outs
+
+
 class VirConvL8x(nn.Module):
     """VirConv-L backbone: one stream over fused LiDAR+virtual voxels (spconv_backbone.py:538-699)."""
 
@@ -227,15 +297,6 @@ class VirConvL8x(nn.Module):
     def _discard_active(self):
         return self.training and self.layer_discard_mode != "spconv2_noop" and self.layer_discard_rate != 0
 
-    def _draw_keep(self, n, batch_dict, tag, device):
-        n_keep = int(n * (1 - self.layer_discard_rate))
-        inj = batch_dict.get("layer_discard_keep")
-        if inj is not None:
-            keep = inj[tag].to(device=device, dtype=torch.int64)
-            assert keep.shape[0] == n_keep, f"injected keep has {keep.shape[0]} rows, expected {n_keep}"
-            return keep
-        return torch.randperm(n, device=device)[:n_keep]
-
     def _discard(self, sp, batch_dict, tag):
         if not self._discard_active():
             return sp
@@ -250,40 +311,17 @@ class VirConvL8x(nn.Module):
         whole backbone depend on coordinates only, so they are built first -- on a side stream, where the four
         data-dependent size reads (one per strided conv) only wait for a few short index kernels instead of draining
         the feature work queued on the main stream.  The feature pass that follows is free of host syncs."""
-        on_gpu = coords.is_cuda
-        if on_gpu:
-            main = torch.cuda.current_stream()
-            side = _plan_stream(coords.device)
-            ready = batch_dict.get("inputs_ready_event")
-            if ready is not None:
-                side.wait_event(ready)  # inputs were produced before this event: no need to wait for the stream tail
-            else:
-                side.wait_stream(main)
-            ctx = torch.cuda.stream(side)
-        else:
-            import contextlib
-            ctx = contextlib.nullcontext()
         blocks = [(self.vir_conv1, 1), (self.vir_conv2, 2), (self.vir_conv3, 4), (self.vir_conv4, 8)]
-        with ctx:
-            idx, shape, stages = coords.int(), list(self.sparse_shape), []
-            in_idx = idx
-            for bi, (blk, stride) in enumerate(blocks):
-                p = blk.plan(in_idx, shape, batch_size, calib, stride, trans_param)
-                in_idx, shape = p["out_indices"], p["out_shape"]
-                p["keep"] = None
-                if bi < 3 and self._discard_active():
-                    keep = self._draw_keep(in_idx.shape[0], batch_dict, f"x_conv{bi + 1}{rid}", in_idx.device)
-                    _, in_idx = ops.get_backend().gather_rows(None, in_idx, keep)
-                    p["keep"], p["kept_indices"] = keep, in_idx
-                stages.append(p)
+        active = self._discard_active()
+        tags = [f"x_conv{bi + 1}{rid}" if (bi < 3 and active) else None for bi in range(4)]
+        with _PlanScope(coords, batch_dict) as scope:
+            idx = coords.int()
+            stages, in_idx, shape = _plan_nrconv_chain(blocks, idx, list(self.sparse_shape), batch_size, calib, trans_param,
+                                                       tags, self.layer_discard_rate, batch_dict)
             co = self.conv_out[0]
             rb_out = ops.build_sparse_rulebook(in_idx, shape, batch_size, co.kernel_size, co.stride, co.padding, co.dilation)
             plan = {"in_indices": idx, "stages": stages, "conv_out": {co.indice_key: rb_out}}
-        if not on_gpu:
-            return plan
-        main.wait_stream(side)
-        _record_stream(plan, main)
-        return plan
+        return scope.publish(plan)
 
     def forward(self, batch_dict):
         if "transform_param" in batch_dict:
@@ -310,14 +348,8 @@ class VirConvL8x(nn.Module):
             if self.plan_ahead:
                 plan = self.build_plan(coords, batch_size, calib, trans_param, batch_dict, rid)
                 x = spconv.SparseConvTensor(feats, plan["in_indices"], self.sparse_shape, batch_size)
-                outs = []
                 blocks = [(self.vir_conv1, 1), (self.vir_conv2, 2), (self.vir_conv3, 4), (self.vir_conv4, 8)]
-                for (blk, stride), p in zip(blocks, plan["stages"]):
-                    x = blk(x, batch_size, calib, stride, None, trans_param, plan=p)
-                    if p["keep"] is not None:
-                        f = ops.GatherRowsFunction.apply(x.features, p["keep"])
-                        x = spconv.SparseConvTensor(f, p["kept_indices"], x.spatial_shape, batch_size)
-                    outs.append(x)
+                outs = _run_nrconv_chain(blocks, plan["stages"], x, batch_size, calib, trans_param)
                 x1, x2, x3, x4 = outs
                 x4.indice_dict.update(plan["conv_out"])
                 out = self.conv_out(x4)
@@ -360,6 +392,7 @@ class VirConv8x(nn.Module):
         self.layer_discard_mode = _cfg_get(model_cfg, "LAYER_DISCARD_MODE", "spconv1_inplace")
         assert self.layer_discard_mode in ("spconv1_inplace", "spconv2_noop")
         self.mm = bool(_cfg_get(model_cfg, "MM", False))
+        self.plan_ahead = bool(_cfg_get(model_cfg, "PLAN_AHEAD", True))
         nf = _cfg_get(model_cfg, "NUM_FILTERS")
         norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
         self.sparse_shape = [int(v) for v in (np.asarray(grid_size)[::-1] + [1, 0, 0])]
@@ -419,60 +452,166 @@ class VirConv8x(nn.Module):
         x4 = self.conv4(x3)
         return x1, x2, x3, x4, self.conv_out(x4)
 
+    def _discard_active(self):
+        return self.training and self.layer_discard_mode != "spconv2_noop" and self.layer_discard_rate != 0
+
     def _discard(self, sp, batch_dict, tag):
-        if not self.training or self.layer_discard_mode == "spconv2_noop" or self.layer_discard_rate == 0:
+        if not self._discard_active():
             return sp
         inj = batch_dict.get("layer_discard_keep")
         return layer_voxel_discard(sp, self.layer_discard_rate, None if inj is None else inj[tag])
+
+    # ---- geometry plan (same idea as VirConvL8x.build_plan): every rulebook of both streams, the eval-time slab splits and
+    # the discard permutations are functions of the coordinates only and are built first, on the plan stream
+    def _plan_lidar(self, idx, shape, batch_size):
+        """{indice_key: Rulebook} of the LiDAR stream + the coordinates of x3, x4 and the output."""
+        rbs = {}
+        first = self.conv_input[0]
+        rbs[first.indice_key] = ops.build_subm_rulebook(idx, shape, first.kernel_size, first.dilation, False)
+        cur, cur_shape, coords = idx, list(shape), {}
+        for name, seq in (("x2", self.conv2), ("x3", self.conv3), ("x4", self.conv4)):
+            down, subm = seq[0][0], seq[1][0]
+            rb = ops.build_sparse_rulebook(cur, cur_shape, batch_size, down.kernel_size, down.stride, down.padding, down.dilation)
+            rbs[down.indice_key] = rb
+            cur, cur_shape = rb.out_indices, list(rb.out_shape)
+            rbs[subm.indice_key] = ops.build_subm_rulebook(cur, cur_shape, subm.kernel_size, subm.dilation, False)
+            coords[name] = (cur, cur_shape)
+        co = self.conv_out[0]
+        rb = ops.build_sparse_rulebook(cur, cur_shape, batch_size, co.kernel_size, co.stride, co.padding, co.dilation)
+        rbs[co.indice_key] = rb
+        coords["out"] = (rb.out_indices, list(rb.out_shape))
+        return rbs, coords
+
+    @staticmethod
+    def _plan_split(indices, shape, i):
+        """Geometry half of decompose_tensor: kept rows and shifted coordinates of slab i."""
+        w = shape[2]
+        begin, end = i * (w // 4), (i + 1) * (w // 4)
+        x = indices[:, 3]
+        keep = torch.nonzero((begin < x) & (x < end)).squeeze(1)
+        idx = indices[keep].clone()
+        idx[:, 3] -= begin
+        return keep, idx.int(), [shape[0], shape[1], shape[2] // 4]
+
+    def build_plan(self, batch_dict, rids, batch_size, calib):
+        ref = batch_dict["voxel_coords"]
+        plan = {"lidar": {}, "split": {}, "mm": {}}
+        with _PlanScope(ref, batch_dict) as scope:
+            if self.training:
+                for rid in rids:
+                    idx = batch_dict["voxel_coords" + rid].int()
+                    rbs, _ = self._plan_lidar(idx, self.sparse_shape, batch_size)
+                    plan["lidar"][rid] = (idx, rbs)
+            else:
+                coords = []
+                for i, rid in enumerate(rids):
+                    c = batch_dict["voxel_coords" + rid].clone()
+                    c[:, 3] += i * self.sparse_shape[2]
+                    coords.append(c)
+                idx = torch.cat(coords).int()
+                new_shape = [self.sparse_shape[0], self.sparse_shape[1], self.sparse_shape[2] * 4]
+                rbs, co = self._plan_lidar(idx, new_shape, batch_size)
+                plan["lidar"]["cat"] = (idx, rbs, new_shape)
+                for i, rid in enumerate(rids):
+                    plan["split"][rid] = {k: self._plan_split(co[k][0], co[k][1], i) for k in ("x3", "x4", "out")}
+            if self.mm:
+                blocks = [(self.vir_conv1, 1), (self.vir_conv2, 2), (self.vir_conv3, 4), (self.vir_conv4, 8)]
+                active = self._discard_active()
+                for i, rid in enumerate(rids):
+                    idx = batch_dict["voxel_coords_mm" + rid].int()
+                    keep0 = None
+                    if active:  # the MM stream also discards its input (spconv_backbone.py:488-489)
+                        keep0 = _draw_keep(self.layer_discard_rate, idx.shape[0], batch_dict, f"mm_input{rid}", idx.device)
+                        _, idx = ops.get_backend().gather_rows(None, idx, keep0)
+                    trans_param = batch_dict.get("aug_param")
+                    if "transform_param" in batch_dict:
+                        trans_param = batch_dict["transform_param"][:, i, :]
+                    tags = [f"mm_x_conv{bi + 1}{rid}" if (bi < 3 and active) else None for bi in range(4)]
+                    stages, _, _ = _plan_nrconv_chain(blocks, idx, list(self.sparse_shape), batch_size, calib, trans_param,
+                                                      tags, self.layer_discard_rate, batch_dict)
+                    plan["mm"][rid] = {"keep0": keep0, "in_indices": idx, "stages": stages, "trans_param": trans_param}
+        return scope.publish(plan)
+
+    @staticmethod
+    def _apply_split(tensor, split, batch_size):
+        keep, idx, shape = split
+        feats = ops.GatherRowsFunction.apply(tensor.features, keep) if tensor.features.is_cuda else tensor.features[keep]
+        return spconv.SparseConvTensor(feats, idx, shape, batch_size)
 
     def forward(self, batch_dict):
         rot_num = batch_dict["transform_param"].shape[1] if "transform_param" in batch_dict else 1
         batch_size = batch_dict["batch_size"]
         strides = {"x_conv1": 1, "x_conv2": 2, "x_conv3": 4, "x_conv4": 8}
         rids = ["" if i == 0 else str(i) for i in range(rot_num)]
+        calib = None
+        if self.mm:
+            calib = batch_dict["calib"]
+            if not torch.is_tensor(calib):
+                calib = ops.calib_tensor(calib, batch_dict["voxel_features_mm"].device)
+        plan = self.build_plan(batch_dict, rids, batch_size, calib) if self.plan_ahead else None
 
         if self.training:
             for rid in rids:
-                sp = spconv.SparseConvTensor(batch_dict["voxel_features" + rid], batch_dict["voxel_coords" + rid].int(),
-                                             self.sparse_shape, batch_size)
+                if plan is not None:
+                    idx, rbs = plan["lidar"][rid]
+                    sp = spconv.SparseConvTensor(batch_dict["voxel_features" + rid], idx, self.sparse_shape, batch_size,
+                                                 indice_dict=dict(rbs))
+                else:
+                    sp = spconv.SparseConvTensor(batch_dict["voxel_features" + rid], batch_dict["voxel_coords" + rid].int(),
+                                                 self.sparse_shape, batch_size)
                 x1, x2, x3, x4, out = self._lidar_stream(sp)
                 batch_dict.update({"encoded_spconv_tensor" + rid: out, "encoded_spconv_tensor_stride" + rid: 8,
                                    "multi_scale_3d_features" + rid: {"x_conv1": x1, "x_conv2": x2, "x_conv3": x3, "x_conv4": x4},
                                    "multi_scale_3d_strides" + rid: dict(strides)})
         else:
-            feats, coords = [], []
-            for i, rid in enumerate(rids):
-                c = batch_dict["voxel_coords" + rid].clone()
-                c[:, 3] += i * self.sparse_shape[2]
-                feats.append(batch_dict["voxel_features" + rid])
-                coords.append(c)
-            new_shape = [self.sparse_shape[0], self.sparse_shape[1], self.sparse_shape[2] * 4]
-            sp = spconv.SparseConvTensor(torch.cat(feats, 0), torch.cat(coords).int(), new_shape, batch_size)
+            feats = torch.cat([batch_dict["voxel_features" + rid] for rid in rids], 0)
+            if plan is not None:
+                idx, rbs, new_shape = plan["lidar"]["cat"]
+                sp = spconv.SparseConvTensor(feats, idx, new_shape, batch_size, indice_dict=dict(rbs))
+            else:
+                coords = []
+                for i, rid in enumerate(rids):
+                    c = batch_dict["voxel_coords" + rid].clone()
+                    c[:, 3] += i * self.sparse_shape[2]
+                    coords.append(c)
+                new_shape = [self.sparse_shape[0], self.sparse_shape[1], self.sparse_shape[2] * 4]
+                sp = spconv.SparseConvTensor(feats, torch.cat(coords).int(), new_shape, batch_size)
             x1, x2, x3, x4, out = self._lidar_stream(sp)
             for i, rid in enumerate(rids):
+                if plan is not None:
+                    sp_ = plan["split"][rid]
+                    o, s3, s4 = (self._apply_split(out, sp_["out"], batch_size), self._apply_split(x3, sp_["x3"], batch_size),
+                                 self._apply_split(x4, sp_["x4"], batch_size))
+                else:
+                    o, s3, s4 = (self.decompose_tensor(out, i, batch_size), self.decompose_tensor(x3, i, batch_size),
+                                 self.decompose_tensor(x4, i, batch_size))
                 batch_dict.update({
-                    "encoded_spconv_tensor" + rid: self.decompose_tensor(out, i, batch_size),
+                    "encoded_spconv_tensor" + rid: o,
                     "encoded_spconv_tensor_stride" + rid: 8,
-                    "multi_scale_3d_features" + rid: {"x_conv1": None, "x_conv2": None,
-                                                      "x_conv3": self.decompose_tensor(x3, i, batch_size),
-                                                      "x_conv4": self.decompose_tensor(x4, i, batch_size)},
+                    "multi_scale_3d_features" + rid: {"x_conv1": None, "x_conv2": None, "x_conv3": s3, "x_conv4": s4},
                     "multi_scale_3d_strides" + rid: dict(strides)})
 
         if self.mm:
-            calib = batch_dict["calib"]
-            if not torch.is_tensor(calib):
-                calib = ops.calib_tensor(calib, batch_dict["voxel_features_mm"].device)
+            blocks = [(self.vir_conv1, 1), (self.vir_conv2, 2), (self.vir_conv3, 4), (self.vir_conv4, 8)]
             for i, rid in enumerate(rids):
-                sp = spconv.SparseConvTensor(batch_dict["voxel_features_mm" + rid], batch_dict["voxel_coords_mm" + rid].int(),
-                                             self.sparse_shape, batch_size)
-                sp = self._discard(sp, batch_dict, f"mm_input{rid}")  # the MM stream also discards its input (:488-489)
-                trans_param = batch_dict.get("aug_param")
-                if "transform_param" in batch_dict:
-                    trans_param = batch_dict["transform_param"][:, i, :]
-                m1 = self._discard(self.vir_conv1(sp, batch_size, calib, 1, None, trans_param), batch_dict, f"mm_x_conv1{rid}")
-                m2 = self._discard(self.vir_conv2(m1, batch_size, calib, 2, None, trans_param), batch_dict, f"mm_x_conv2{rid}")
-                m3 = self._discard(self.vir_conv3(m2, batch_size, calib, 4, None, trans_param), batch_dict, f"mm_x_conv3{rid}")
-                m4 = self.vir_conv4(m3, batch_size, calib, 8, None, trans_param)
+                if plan is not None:
+                    pm = plan["mm"][rid]
+                    f = batch_dict["voxel_features_mm" + rid]
+                    if pm["keep0"] is not None:
+                        f = ops.GatherRowsFunction.apply(f, pm["keep0"])
+                    sp = spconv.SparseConvTensor(f, pm["in_indices"], self.sparse_shape, batch_size)
+                    m1, m2, m3, m4 = _run_nrconv_chain(blocks, pm["stages"], sp, batch_size, calib, pm["trans_param"])
+                else:
+                    sp = spconv.SparseConvTensor(batch_dict["voxel_features_mm" + rid],
+                                                 batch_dict["voxel_coords_mm" + rid].int(), self.sparse_shape, batch_size)
+                    sp = self._discard(sp, batch_dict, f"mm_input{rid}")  # the MM stream also discards its input (:488-489)
+                    trans_param = batch_dict.get("aug_param")
+                    if "transform_param" in batch_dict:
+                        trans_param = batch_dict["transform_param"][:, i, :]
+                    m1 = self._discard(self.vir_conv1(sp, batch_size, calib, 1, None, trans_param), batch_dict, f"mm_x_conv1{rid}")
+                    m2 = self._discard(self.vir_conv2(m1, batch_size, calib, 2, None, trans_param), batch_dict, f"mm_x_conv2{rid}")
+                    m3 = self._discard(self.vir_conv3(m2, batch_size, calib, 4, None, trans_param), batch_dict, f"mm_x_conv3{rid}")
+                    m4 = self.vir_conv4(m3, batch_size, calib, 8, None, trans_param)
                 batch_dict.update({"encoded_spconv_tensor_stride_mm" + rid: 8,
                                    "multi_scale_3d_features_mm" + rid: {"x_conv1": m1, "x_conv2": m2, "x_conv3": m3, "x_conv4": m4},
                                    "multi_scale_3d_strides" + rid: dict(strides)})

@@ -160,10 +160,23 @@ __global__ void __launch_bounds__(256) group_points_kernel(int B, int64_t m, int
     } else {
       for (int e = lane; e < cw * nsample; e += 64) tile[(e / nsample) * ld + e % nsample] = blk[e];
       __builtin_amdgcn_wave_barrier();
-      for (int s = 0; s < nsample; ++s) {
+      // consecutive samples that repeat a row (the unused slots of a ball all hold its first hit) are summed in registers
+      // and flushed with one atomic; exact zeros (the gradient of an emptied ball) are not sent at all -- with the
+      // reference's kernel those are tens of thousands of same-address atomics on row 0
+      int64_t cur = start + id[0];
+      float acc = (lane < cw) ? tile[lane * ld] : 0.f;
+      for (int s = 1; s < nsample; ++s) {
         const int64_t row = start + id[s];
-        if (lane < cw) atomicAdd(&features[row * C + c0 + lane], tile[lane * ld + s]);
+        const float v = (lane < cw) ? tile[lane * ld + s] : 0.f;
+        if (row != cur) {
+          if (lane < cw && acc != 0.f) atomicAdd(&features[cur * C + c0 + lane], acc);
+          cur = row;
+          acc = v;
+        } else {
+          acc += v;
+        }
       }
+      if (lane < cw && acc != 0.f) atomicAdd(&features[cur * C + c0 + lane], acc);
     }
     __builtin_amdgcn_wave_barrier();
   }
