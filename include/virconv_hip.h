@@ -114,6 +114,20 @@ int vc_conv_backward_input(const float* dy, const float* dy_centre, int64_t n_sr
                            int64_t n_in, int kv, const float* weight, int cin, int cout, int mirror, int centre,
                            const int32_t* rep, const int32_t* row_order, int operand_type, float* dx, void* stream);
 
+/* Forward conv with a BatchNorm epilogue (fp32 operands; query vc_conv_epilogue_supported for the shape first):
+ *   VC_EPI_STATS   training: besides y the kernel writes per-64-row-block, per-channel (sum, sum of squares) to
+ *                  stats_partial [ceil(n_out/64)][2][cout] (vc_conv_stats_partial_floats floats) for vc_bn_stats_from_partial
+ *                  -- the statistics pass no longer re-reads y;
+ *   VC_EPI_AFFINE  eval: y = relu?(conv * (gamma / sqrt(var + eps)) + (beta - mean * gamma / sqrt(var + eps))) in the store,
+ *                  i.e. conv + BatchNorm1d(eval) + ReLU (spconv_backbone.py:101-105) as ONE launch.                     */
+typedef enum vc_epilogue { VC_EPI_NONE = 0, VC_EPI_STATS = 1, VC_EPI_AFFINE = 2 } vc_epilogue;
+int vc_conv_epilogue_supported(int64_t n_in, int cin, int cout, int kv, int operand_type);
+size_t vc_conv_stats_partial_floats(int64_t n_out, int cout);
+int vc_conv_forward_epilogue(const float* x, int64_t n_in, const int32_t* pair_fwd, int64_t n_out, int kv,
+                             const float* weight, int cin, int cout, const int32_t* row_order, int epilogue,
+                             float* stats_partial, const float* mean, const float* var, const float* gamma,
+                             const float* beta, float eps, int relu, float* y, void* stream);
+
 /* Row permutation that makes the gather-GEMM's 16-row tiles homogeneous: within each window of `window` (1024 | 2048 |
  * 4096) consecutive rows of `tbl` (KV, n) the rows are stably sorted by their active-offset bit mask (bit k set <=> tbl[k, r] >= 0; rows with
  * rep[r] != r count as {centre} only, matching the duplicate-pixel backward).  kv <= 32.  order (n) int32.
@@ -191,6 +205,10 @@ size_t vc_bn_workspace_bytes(int64_t n, int c);
 int vc_bn_stats(const float* x, int64_t n, int c, float* mean, float* var, float* running_mean /*nullable*/,
                 float* running_var /*nullable*/, int64_t* num_batches_tracked /*nullable, += 1*/, float momentum,
                 void* ws, size_t ws_bytes, void* stream);
+/* statistics from the per-block partial sums of vc_conv_forward_epilogue(VC_EPI_STATS): same outputs as vc_bn_stats */
+int vc_bn_stats_from_partial(const float* partial, int64_t nblocks, int64_t n, int c, float* mean, float* var,
+                             float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                             void* stream);
 int vc_bn_apply_relu(const float* x, int64_t n, int c, const float* mean, const float* var, const float* gamma,
                      const float* beta, float eps, int relu, float* y, int y_stride, int y_col0, void* stream);
 int vc_bn_relu_backward(const float* x, const float* dy, int dy_stride, int dy_col0, int64_t n, int c,

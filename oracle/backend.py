@@ -54,6 +54,9 @@ class OracleBackend:
         x, weight = self._operands(operand, weight.shape[-1], weight.shape[0], x, weight)
         return sparse_ref.conv_forward(x, weight, _np(pair_fwd))
 
+    def conv_epilogue_supported(self, n_in, cin, cout, kv, operand="f32"):
+        return False  # fused epilogues are a product optimisation; the oracle always takes the plain path
+
     def conv_backward_input(self, dy, weight, tbl, n_in, mirror, centre=-1, rep=None, order=None, operand="f32"):
         """dX of the three conv flavours, in the product's calling convention (include/virconv_hip.h).
 

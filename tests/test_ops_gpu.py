@@ -442,3 +442,58 @@ def test_reduced_operand_is_ignored_below_16_channels(hip_backend):
                            hip_backend.conv_backward_input(g, w, pair, n, mirror=True, operand="f16"))
         assert torch.equal(hip_backend.conv_backward_weight(x, g, pair, tuple(w.shape)),
                            hip_backend.conv_backward_weight(x, g, pair, tuple(w.shape), operand="bf16"))
+
+
+# ------------------------------------------------------------------------------------------------ conv epilogues (BN fusion)
+@pytest.mark.parametrize("cin,cout", [(8, 8), (16, 32), (64, 32), (64, 64)])
+def test_conv_stats_epilogue_gives_the_same_conv_and_batchnorm_statistics(hip_backend, cin, cout):
+    rng = np.random.default_rng(cin + 3 * cout)
+    idx = _indices3(31, 5000)
+    n = idx.shape[0]
+    it = torch.from_numpy(idx).cuda()
+    x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.standard_normal((cout, 3, 3, 3, cin)) / 5).astype(np.float32)).cuda()
+    pair, _ = hip_backend.subm_rulebook(it, SHAPE3, (3, 3, 3), (1, 1, 1), want_rep=False)
+    assert hip_backend.conv_epilogue_supported(n, cin, cout, 27)
+    y_ref = hip_backend.conv_forward(x, w, pair)
+    for order in (None, hip_backend.row_order(pair)):
+        y, partial = hip_backend.conv_forward_stats(x, w, pair, order=order)
+        assert torch.equal(y, y_ref)                                       # the epilogue never changes the conv output
+        p = partial.view(-1, 2, cout).double()
+        yd = y_ref.double()
+        np.testing.assert_allclose(p[:, 0].sum(0).cpu().numpy(), yd.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+        np.testing.assert_allclose(p[:, 1].sum(0).cpu().numpy(), (yd * yd).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    g, b = torch.rand(cout).cuda() + 0.5, torch.randn(cout).cuda()
+    rm1, rv1, rm2, rv2 = torch.zeros(cout).cuda(), torch.ones(cout).cuda(), torch.zeros(cout).cuda(), torch.ones(cout).cuda()
+    n1, n2 = torch.zeros((), dtype=torch.int64).cuda(), torch.zeros((), dtype=torch.int64).cuda()
+    y, partial = hip_backend.conv_forward_stats(x, w, pair)
+    o1, m1, v1 = hip_backend.bn_forward(y, g, b, rm1, rv1, True, 0.01, 1e-3, True, num_batches_tracked=n1, partial=partial)
+    o2, m2, v2 = hip_backend.bn_forward(y, g, b, rm2, rv2, True, 0.01, 1e-3, True, num_batches_tracked=n2)
+    assert int(n1) == 1 and int(n2) == 1
+    for a, c in ((m1, m2), (v1, v2), (rm1, rm2), (rv1, rv2), (o1, o2)):
+        assert float((a - c).abs().max()) <= 1e-5 * max(1.0, float(c.abs().max()))
+    # bit-stable: the per-block sums and the finalize order are fixed
+    y2, partial2 = hip_backend.conv_forward_stats(x, w, pair)
+    assert torch.equal(partial, partial2)
+
+
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("cin,cout", [(8, 8), (32, 16), (64, 64)])
+def test_conv_affine_epilogue_equals_conv_then_eval_batchnorm(hip_backend, cin, cout, relu):
+    rng = np.random.default_rng(cin * 5 + cout)
+    idx = _indices3(32, 4000)
+    n = idx.shape[0]
+    x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.standard_normal((cout, 3, 3, 3, cin)) / 5).astype(np.float32)).cuda()
+    pair, _ = hip_backend.subm_rulebook(torch.from_numpy(idx).cuda(), SHAPE3, (3, 3, 3), (1, 1, 1), want_rep=False)
+    g, b = torch.rand(cout).cuda() + 0.5, torch.randn(cout).cuda()
+    mean, var = torch.randn(cout).cuda() * 0.2, torch.rand(cout).cuda() + 0.3
+    fused = hip_backend.conv_forward_affine(x, w, pair, None, mean, var, g, b, 1e-3, relu)
+    y = hip_backend.conv_forward(x, w, pair)
+    ref, _, _ = hip_backend.bn_forward(y, g, b, mean, var, False, 0.01, 1e-3, relu)
+    assert float((fused - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    yd = y.double()
+    exact = (yd - mean.double()) / torch.sqrt(var.double() + 1e-3) * g.double() + b.double()
+    if relu:
+        exact = exact.clamp_min(0)
+    assert float((fused.double() - exact).abs().max()) <= TOL * max(1.0, float(exact.abs().max()))

@@ -165,6 +165,42 @@ class HipBackend:
             self._trace_close(rec)
         return y
 
+    def conv_epilogue_supported(self, n_in: int, cin: int, cout: int, kv: int, operand: str = "f32") -> bool:
+        return bool(self.lib.vc_conv_epilogue_supported(n_in, cin, cout, kv, OPERAND_TYPES[operand]))
+
+    def conv_forward_stats(self, x: torch.Tensor, weight: torch.Tensor, pair_fwd: torch.Tensor,
+                           order: Optional[torch.Tensor] = None):
+        """Forward conv that also emits the per-block BatchNorm partial sums (VC_EPI_STATS) -> (y_raw, partial)."""
+        x = _need(x, torch.float32, "features")
+        weight = _need(weight, torch.float32, "weight")
+        pair_fwd = _need(pair_fwd, torch.int32, "pair_fwd")
+        kv, n_out = pair_fwd.shape
+        cout, cin = weight.shape[0], weight.shape[-1]
+        y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+        partial = torch.empty((self.lib.vc_conv_stats_partial_floats(n_out, cout),), dtype=torch.float32, device=x.device)
+        rec = self._trace_open(pair_fwd, x.shape[0], cin, cout) if self._traced("fwd", cin, cout) else None
+        check(self.lib.vc_conv_forward_epilogue(_ptr(x), x.shape[0], _ptr(pair_fwd), n_out, kv, _ptr(weight), cin, cout,
+                                                _ptr(order), 1, _ptr(partial), None, None, None, None, 0.0, 0, _ptr(y),
+                                                _stream()), "vc_conv_forward_epilogue")
+        if rec is not None:
+            self._trace_close(rec)
+        return y, partial
+
+    def conv_forward_affine(self, x: torch.Tensor, weight: torch.Tensor, pair_fwd: torch.Tensor, order, mean, var, gamma,
+                            beta, eps: float, relu: bool) -> torch.Tensor:
+        """conv + eval-mode BatchNorm (+ReLU) in one launch (VC_EPI_AFFINE)."""
+        x = _need(x, torch.float32, "features")
+        weight = _need(weight, torch.float32, "weight")
+        pair_fwd = _need(pair_fwd, torch.int32, "pair_fwd")
+        kv, n_out = pair_fwd.shape
+        cout, cin = weight.shape[0], weight.shape[-1]
+        y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+        check(self.lib.vc_conv_forward_epilogue(_ptr(x), x.shape[0], _ptr(pair_fwd), n_out, kv, _ptr(weight), cin, cout,
+                                                _ptr(order), 2, None, _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta),
+                                                float(eps), 1 if relu else 0, _ptr(y), _stream()),
+              "vc_conv_forward_epilogue")
+        return y
+
     def conv_backward_input(self, dy: torch.Tensor, weight: torch.Tensor, tbl: torch.Tensor, n_in: int, mirror: bool,
                             centre: int = -1, rep: Optional[torch.Tensor] = None,
                             order: Optional[torch.Tensor] = None, operand: str = "f32") -> torch.Tensor:
@@ -359,8 +395,9 @@ class HipBackend:
     # ------------------------------------------------------------------ BatchNorm(+ReLU)
     def bn_forward(self, x: torch.Tensor, gamma, beta, running_mean, running_var, training: bool, momentum: float,
                    eps: float, relu: bool, out: Optional[torch.Tensor] = None, out_col0: int = 0,
-                   num_batches_tracked: Optional[torch.Tensor] = None):
-        """-> (y, mean, var).  `out` (N, Ctot) lets the result land at a column offset of a wider row (fused concat)."""
+                   num_batches_tracked: Optional[torch.Tensor] = None, partial: Optional[torch.Tensor] = None):
+        """-> (y, mean, var).  `out` (N, Ctot) lets the result land at a column offset of a wider row (fused concat).
+        `partial`: per-block sums from conv_forward_stats -- the statistics then need no pass over x."""
         x = _need(x, torch.float32, "features")
         n, c = x.shape
         dev = x.device
@@ -368,10 +405,17 @@ class HipBackend:
         if training:
             mean = torch.empty((c,), dtype=torch.float32, device=dev)
             var = torch.empty((c,), dtype=torch.float32, device=dev)
-            ws_bytes = self.lib.vc_bn_workspace_bytes(n, c)
-            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-            check(self.lib.vc_bn_stats(_ptr(x), n, c, _ptr(mean), _ptr(var), _ptr(running_mean), _ptr(running_var),
-                                       _ptr(num_batches_tracked), float(momentum), _ptr(ws), ws_bytes, st), "vc_bn_stats")
+            if partial is not None:
+                check(self.lib.vc_bn_stats_from_partial(_ptr(partial), partial.numel() // (2 * c), n, c, _ptr(mean),
+                                                        _ptr(var), _ptr(running_mean), _ptr(running_var),
+                                                        _ptr(num_batches_tracked), float(momentum), st),
+                      "vc_bn_stats_from_partial")
+            else:
+                ws_bytes = self.lib.vc_bn_workspace_bytes(n, c)
+                ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+                check(self.lib.vc_bn_stats(_ptr(x), n, c, _ptr(mean), _ptr(var), _ptr(running_mean), _ptr(running_var),
+                                           _ptr(num_batches_tracked), float(momentum), _ptr(ws), ws_bytes, st),
+                      "vc_bn_stats")
         else:
             mean, var = running_mean, running_var
         if out is None:

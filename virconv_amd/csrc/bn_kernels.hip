@@ -117,6 +117,37 @@ __global__ void __launch_bounds__(256) bn_stats_finalize_kernel(const double* __
   }
 }
 
+// statistics from the conv epilogue's per-block fp32 partials [nb][2][c] (sum, sum of squares): same outputs as above
+__global__ void __launch_bounds__(256) bn_stats_from_partial_kernel(const float* __restrict__ partial, int64_t nb, int64_t n,
+                                                                    int c, float* __restrict__ mean,
+                                                                    float* __restrict__ var,
+                                                                    float* __restrict__ running_mean,
+                                                                    float* __restrict__ running_var,
+                                                                    long long* __restrict__ num_batches_tracked,
+                                                                    float momentum) {
+  const int lane = threadIdx.x & 63;
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ch >= c) return;
+  if (num_batches_tracked && ch == 0 && lane == 0) *num_batches_tracked += 1;
+  double s = 0.0, ss = 0.0;
+  for (int64_t b = lane; b < nb; b += 64) {
+    s += (double)partial[(b * 2 + 0) * c + ch];
+    ss += (double)partial[(b * 2 + 1) * c + ch];
+  }
+  wave_sum2(s, ss);
+  if (lane != 0) return;
+  const double m = s / (double)n;
+  double v = ss / (double)n - m * m;
+  if (v < 0.0) v = 0.0;
+  mean[ch] = (float)m;
+  var[ch] = (float)v;
+  if (running_mean) running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)m;
+  if (running_var) {
+    const double unb = (n > 1) ? v * (double)n / (double)(n - 1) : v;
+    running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unb;
+  }
+}
+
 __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const double* __restrict__ partial, int nb, int c,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ sums /* [2][c]: dbeta, dgamma */) {
@@ -231,6 +262,16 @@ int vc_bn_stats(const float* x, int64_t n, int c, float* mean, float* var, float
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, partial, nb, n, c, mean, var,
                      running_mean, running_var, (long long*)num_batches_tracked, momentum);
   VC_CHECK_LAUNCH("bn_stats_finalize_kernel");
+  return VC_OK;
+}
+
+int vc_bn_stats_from_partial(const float* partial, int64_t nblocks, int64_t n, int c, float* mean, float* var,
+                             float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                             void* stream) {
+  VC_REQUIRE(c >= 1 && n >= 1 && nblocks >= 1 && partial && mean && var, "vc_bn_stats_from_partial: null/invalid argument");
+  hipLaunchKernelGGL(bn_stats_from_partial_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, nblocks, n,
+                     c, mean, var, running_mean, running_var, (long long*)num_batches_tracked, momentum);
+  VC_CHECK_LAUNCH("bn_stats_from_partial_kernel");
   return VC_OK;
 }
 

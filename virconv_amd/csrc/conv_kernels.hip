@@ -216,14 +216,31 @@ struct BufLoad<1> {
   }
 };
 
-template <int CK, int CN, bool BWD, int RT, int OT>
+// Epilogue of the forward conv (EPI): what happens to the accumulators besides the plain store
+//   VC_EPI_NONE    nothing
+//   VC_EPI_STATS   training-mode BatchNorm statistics: the block also writes, per output channel, the sum and the sum of
+//                  squares of ITS 64 rows to epi.partial[block][2][CN] (fixed in-block order: 4 accumulator rows, q lanes,
+//                  waves); the finalize kernel adds the blocks up in fp64.  Saves the read-back pass of bn_reduce.
+//   VC_EPI_AFFINE  eval-mode BatchNorm (+ReLU) folded into the store: y = acc * (gamma * istd) + (beta - mean * gamma * istd)
+struct ConvEpilogue {
+  float* partial;        // STATS
+  const float* mean;     // AFFINE (running statistics)
+  const float* var;
+  const float* gamma;
+  const float* beta;
+  float eps;
+  int relu;
+};
+
+template <int CK, int CN, bool BWD, int RT, int OT, int EPI>
 __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __restrict__ src,
                                                              const float* __restrict__ src_centre, int64_t n_src,
                                                              const int32_t* __restrict__ tbl,
                                                              const float* __restrict__ w, float* __restrict__ out,
                                                              const int32_t* __restrict__ rep,
                                                              const int32_t* __restrict__ order, int64_t n_out, int kv,
-                                                             int centre, int mirror) {
+                                                             int centre, int mirror, ConvEpilogue epi) {
+  static_assert(EPI == VC_EPI_NONE || (!BWD && RT == 1), "epilogues exist for the 64-row forward kernel only");
   constexpr int V = (CK >= 16) ? 4 : CK / 4;
   constexpr int NCH = CK / (4 * V);
   constexpr int NT = (CN + 15) / 16;
@@ -409,6 +426,43 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
 #undef VC_STORE_B
 #undef VC_GATHER_A
 
+  if constexpr (EPI == VC_EPI_STATS) {
+    // rows beyond n_out gathered nothing, their accumulators are exact zeros: no masking needed
+    float* s_red = reinterpret_cast<float*>(s_b);  // [4 waves][2][NT*16]; W images are dead after the barrier below
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float sm = ((acc[0][nt][0] + acc[0][nt][1]) + acc[0][nt][2]) + acc[0][nt][3];
+      float sq = ((acc[0][nt][0] * acc[0][nt][0] + acc[0][nt][1] * acc[0][nt][1]) + acc[0][nt][2] * acc[0][nt][2]) +
+                 acc[0][nt][3] * acc[0][nt][3];
+      sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
+      sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
+      if (q == 0) {
+        s_red[(wave * 2 + 0) * (NT * 16) + nt * 16 + i] = sm;
+        s_red[(wave * 2 + 1) * (NT * 16) + nt * 16 + i] = sq;
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * CN) {
+      const int which = tid / CN, n = tid - which * CN;
+      const float v = ((s_red[(0 * 2 + which) * (NT * 16) + n] + s_red[(1 * 2 + which) * (NT * 16) + n]) +
+                       s_red[(2 * 2 + which) * (NT * 16) + n]) + s_red[(3 * 2 + which) * (NT * 16) + n];
+      epi.partial[(lbid * 2 + which) * CN + n] = v;
+    }
+  }
+  float sc[NT], sh[NT];
+  if constexpr (EPI == VC_EPI_AFFINE) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 16 + i;
+      sc[nt] = 1.f; sh[nt] = 0.f;
+      if (n < CN) {
+        const float istd = 1.0f / sqrtf(epi.var[n] + epi.eps);
+        sc[nt] = (epi.gamma ? epi.gamma[n] : 1.f) * istd;
+        sh[nt] = (epi.beta ? epi.beta[n] : 0.f) - epi.mean[n] * sc[nt];
+      }
+    }
+  }
 #pragma unroll
   for (int t = 0; t < RT; ++t) {
     int64_t orow[4];
@@ -419,8 +473,14 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
       const int n = nt * 16 + i;
       if (n >= CN) continue;
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg)
-        if (orow[reg] >= 0) out[orow[reg] * CN + n] = acc[t][nt][reg];
+      for (int reg = 0; reg < 4; ++reg) {
+        float v = acc[t][nt][reg];
+        if constexpr (EPI == VC_EPI_AFFINE) {
+          v = v * sc[nt] + sh[nt];
+          if (epi.relu) v = fmaxf(v, 0.f);
+        }
+        if (orow[reg] >= 0) out[orow[reg] * CN + n] = v;
+      }
     }
   }
 }
@@ -743,7 +803,7 @@ int g_conv_rt = 0;             // v2 row tiles per wave: 1 (64 rows/block) | 2 (
 template <int CK, int CN, bool BWD>
 static int launch_gg(const float* src, const float* src_centre, int64_t n_src, const int32_t* tbl, const float* w,
                      float* out, const int32_t* rep, const int32_t* order, int64_t n_out, int kv, int centre, int mirror, int ot,
-                       hipStream_t st) {
+                       int epi_kind, const ConvEpilogue& epi, hipStream_t st) {
   const int64_t rows_per_block = 4 * kRT * 16;
   if (g_conv_variant == 2 && kv <= 32 && n_src * CK * 4 < (1LL << 31)) {
     constexpr int V = (CK >= 16) ? 4 : CK / 4;
@@ -755,28 +815,43 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
     // traffic and barriers / RT) was 5-60 % SLOWER because of its lower occupancy, and was removed.
     // 16-bit operands: only where both channel counts are >= 16 (the 4/8-channel layers are bandwidth-bound and stay fp32)
     const bool half_ops = (ot != VC_OPERAND_F32) && CK >= 16 && CN >= 16;
-    const int rt = (g_conv_rt == 2 && !half_ops) ? 2 : 1;
+    const int rt = (g_conv_rt == 2 && !half_ops && epi_kind == VC_EPI_NONE) ? 2 : 1;
     const size_t lds = (size_t)2 * NCH * NT * 64 * V * (half_ops ? 2 : sizeof(float)) +
                        (size_t)(kv + 1) * 64 * rt * sizeof(int) + 16;
     const dim3 grid((unsigned)cdiv(n_out, (int64_t)64 * rt));
-#define VC_ARGS src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror
+#define VC_ARGS src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, epi
+    if constexpr (!BWD) {
+      if (epi_kind != VC_EPI_NONE) {
+        if (half_ops) { set_error("gather-GEMM: epilogues are implemented for fp32 operands only"); return VC_EINVAL; }
+        if (epi_kind == VC_EPI_STATS)
+          hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, false, 1, VC_OPERAND_F32, VC_EPI_STATS>), grid, dim3(256), lds, st, VC_ARGS);
+        else
+          hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, false, 1, VC_OPERAND_F32, VC_EPI_AFFINE>), grid, dim3(256), lds, st, VC_ARGS);
+        VC_CHECK_LAUNCH("gather_gemm_v2_kernel<epilogue>");
+        return VC_OK;
+      }
+    }
     if constexpr (CK >= 16 && CN >= 16) {
       if (half_ops && ot == VC_OPERAND_F16) {
-        hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 1, VC_OPERAND_F16>), grid, dim3(256), lds, st, VC_ARGS);
+        hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 1, VC_OPERAND_F16, VC_EPI_NONE>), grid, dim3(256), lds, st, VC_ARGS);
         VC_CHECK_LAUNCH("gather_gemm_v2_kernel<f16>");
         return VC_OK;
       }
       if (half_ops) {
-        hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 1, VC_OPERAND_BF16>), grid, dim3(256), lds, st, VC_ARGS);
+        hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 1, VC_OPERAND_BF16, VC_EPI_NONE>), grid, dim3(256), lds, st, VC_ARGS);
         VC_CHECK_LAUNCH("gather_gemm_v2_kernel<bf16>");
         return VC_OK;
       }
     }
-    if (rt == 2) hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 2, VC_OPERAND_F32>), grid, dim3(256), lds, st, VC_ARGS);
-    else hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 1, VC_OPERAND_F32>), grid, dim3(256), lds, st, VC_ARGS);
+    if (rt == 2) hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 2, VC_OPERAND_F32, VC_EPI_NONE>), grid, dim3(256), lds, st, VC_ARGS);
+    else hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 1, VC_OPERAND_F32, VC_EPI_NONE>), grid, dim3(256), lds, st, VC_ARGS);
 #undef VC_ARGS
     VC_CHECK_LAUNCH("gather_gemm_v2_kernel");
     return VC_OK;
+  }
+  if (epi_kind != VC_EPI_NONE) {
+    set_error("gather-GEMM: epilogue requested on the fallback kernel (query vc_conv_epilogue_supported first)");
+    return VC_EINVAL;
   }
   hipLaunchKernelGGL((gather_gemm_kernel<CK, CN, BWD, kRT>), dim3((unsigned)cdiv(n_out, rows_per_block)), dim3(256), 0,
                      st, src, src_centre, tbl, w, out, rep, n_out, kv, centre, mirror);
@@ -787,13 +862,13 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
 template <int CK, bool BWD>
 static int dispatch_cn(int cn, const float* src, const float* src_centre, int64_t n_src, const int32_t* tbl, const float* w, float* out,
                        const int32_t* rep, const int32_t* order, int64_t n_out, int kv, int centre, int mirror, int ot,
-                       hipStream_t st) {
+                       int epi_kind, const ConvEpilogue& epi, hipStream_t st) {
   switch (cn) {
-    case 4: return launch_gg<CK, 4, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, st);
-    case 8: return launch_gg<CK, 8, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, st);
-    case 16: return launch_gg<CK, 16, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, st);
-    case 32: return launch_gg<CK, 32, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, st);
-    case 64: return launch_gg<CK, 64, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, st);
+    case 4: return launch_gg<CK, 4, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, st);
+    case 8: return launch_gg<CK, 8, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, st);
+    case 16: return launch_gg<CK, 16, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, st);
+    case 32: return launch_gg<CK, 32, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, st);
+    case 64: return launch_gg<CK, 64, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, st);
   }
   set_error("gather-GEMM: unsupported output channel count %d (supported: 4,8,16,32,64)", cn);
   return VC_EINVAL;
@@ -802,13 +877,13 @@ static int dispatch_cn(int cn, const float* src, const float* src_centre, int64_
 template <bool BWD>
 static int dispatch_ck(int ck, int cn, const float* src, const float* src_centre, int64_t n_src, const int32_t* tbl, const float* w,
                        float* out, const int32_t* rep, const int32_t* order, int64_t n_out, int kv, int centre, int mirror, int ot,
-                       hipStream_t st) {
+                       int epi_kind, const ConvEpilogue& epi, hipStream_t st) {
   switch (ck) {
-    case 4: return dispatch_cn<4, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, st);
-    case 8: return dispatch_cn<8, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, st);
-    case 16: return dispatch_cn<16, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, st);
-    case 32: return dispatch_cn<32, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, st);
-    case 64: return dispatch_cn<64, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, st);
+    case 4: return dispatch_cn<4, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, st);
+    case 8: return dispatch_cn<8, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, st);
+    case 16: return dispatch_cn<16, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, st);
+    case 32: return dispatch_cn<32, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, st);
+    case 64: return dispatch_cn<64, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, st);
   }
   set_error("gather-GEMM: unsupported source channel count %d (supported: 4,8,16,32,64)", ck);
   return VC_EINVAL;
@@ -903,7 +978,34 @@ int vc_conv_forward(const float* x, int64_t n_in, const int32_t* pair_fwd, int64
   VC_REQUIRE(pair_fwd && y && (x || n_in == 0), "vc_conv_forward: null argument");
   VC_REQUIRE(operand_type >= VC_OPERAND_F32 && operand_type <= VC_OPERAND_BF16, "vc_conv_forward: unknown operand_type");
   return dispatch_ck<false>(cin, cout, x, nullptr, n_in, pair_fwd, weight, y, nullptr, row_order, n_out, kv, -1, 0,
-                            operand_type, (hipStream_t)stream);
+                            operand_type, VC_EPI_NONE, ConvEpilogue{}, (hipStream_t)stream);
+}
+
+int vc_conv_epilogue_supported(int64_t n_in, int cin, int cout, int kv, int operand_type) {
+  (void)cout;
+  return (g_conv_variant == 2 && kv <= 32 && n_in * (int64_t)cin * 4 < (1LL << 31) && operand_type == VC_OPERAND_F32) ? 1 : 0;
+}
+
+size_t vc_conv_stats_partial_floats(int64_t n_out, int cout) {
+  if (n_out < 0 || cout < 1) return 0;
+  return (size_t)cdiv(n_out, 64) * 2 * cout;
+}
+
+int vc_conv_forward_epilogue(const float* x, int64_t n_in, const int32_t* pair_fwd, int64_t n_out, int kv, const float* weight,
+                             int cin, int cout, const int32_t* row_order, int epilogue, float* stats_partial,
+                             const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                             int relu, float* y, void* stream) {
+  VC_REQUIRE(n_in >= 0 && n_out >= 0 && kv >= 1 && weight, "vc_conv_forward_epilogue: null/invalid argument");
+  VC_REQUIRE(epilogue == VC_EPI_STATS || epilogue == VC_EPI_AFFINE, "vc_conv_forward_epilogue: unknown epilogue %d", epilogue);
+  if (n_out == 0) return VC_OK;
+  VC_REQUIRE(pair_fwd && y && (x || n_in == 0), "vc_conv_forward_epilogue: null argument");
+  VC_REQUIRE(epilogue != VC_EPI_STATS || stats_partial, "vc_conv_forward_epilogue: stats_partial is null");
+  VC_REQUIRE(epilogue != VC_EPI_AFFINE || (mean && var), "vc_conv_forward_epilogue: mean/var are null");
+  VC_REQUIRE(vc_conv_epilogue_supported(n_in, cin, cout, kv, VC_OPERAND_F32),
+             "vc_conv_forward_epilogue: not available for this shape (vc_conv_epilogue_supported)");
+  ConvEpilogue e{stats_partial, mean, var, gamma, beta, eps, relu};
+  return dispatch_ck<false>(cin, cout, x, nullptr, n_in, pair_fwd, weight, y, nullptr, row_order, n_out, kv, -1, 0,
+                            VC_OPERAND_F32, epilogue, e, (hipStream_t)stream);
 }
 
 int vc_conv_backward_input(const float* dy, const float* dy_centre, int64_t n_src, const int32_t* tbl, int64_t n_in,
@@ -916,7 +1018,7 @@ int vc_conv_backward_input(const float* dy, const float* dy_centre, int64_t n_sr
   VC_REQUIRE(operand_type >= VC_OPERAND_F32 && operand_type <= VC_OPERAND_BF16,
              "vc_conv_backward_input: unknown operand_type");
   return dispatch_ck<true>(cout, cin, dy, dy_centre, n_src, tbl, weight, dx, rep, row_order, n_in, kv, centre,
-                           mirror ? 1 : 0, operand_type, (hipStream_t)stream);
+                           mirror ? 1 : 0, operand_type, VC_EPI_NONE, ConvEpilogue{}, (hipStream_t)stream);
 }
 
 size_t vc_conv_backward_weight_workspace_bytes(int64_t n_out, int kv, int cin, int cout) {

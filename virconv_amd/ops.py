@@ -174,10 +174,17 @@ class ConvBNReLUFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, rb, inverse, running_mean, running_var, nbt, momentum, eps, relu):
         be = get_backend()
-        y_raw = (be.conv_forward(x, weight, rb.pair_bwd, order=rb.order_bwd, operand=MFMA_OPERAND) if inverse
-                 else be.conv_forward(x, weight, rb.pair_fwd, order=rb.order_fwd, operand=MFMA_OPERAND))
-        y, mean, var = be.bn_forward(y_raw, gamma, beta, running_mean, running_var, True, momentum, eps, relu,
-                                     num_batches_tracked=nbt)
+        tbl, order = (rb.pair_bwd, rb.order_bwd) if inverse else (rb.pair_fwd, rb.order_fwd)
+        if FUSE_BN_STATS and MFMA_OPERAND == "f32" and be.conv_epilogue_supported(x.shape[0], weight.shape[-1],
+                                                                                  weight.shape[0], rb.kv):
+            # the conv epilogue emits the per-block (sum, sum of squares): the statistics need no pass over y_raw
+            y_raw, partial = be.conv_forward_stats(x, weight, tbl, order=order)
+            y, mean, var = be.bn_forward(y_raw, gamma, beta, running_mean, running_var, True, momentum, eps, relu,
+                                         num_batches_tracked=nbt, partial=partial)
+        else:
+            y_raw = be.conv_forward(x, weight, tbl, order=order, operand=MFMA_OPERAND)
+            y, mean, var = be.bn_forward(y_raw, gamma, beta, running_mean, running_var, True, momentum, eps, relu,
+                                         num_batches_tracked=nbt)
         ctx.rb, ctx.inverse, ctx.cfg = rb, inverse, (float(eps), bool(relu))
         ctx.save_for_backward(x, weight, y_raw, mean, var, gamma, beta)
         return y
@@ -200,7 +207,23 @@ def conv_bn_relu(x: torch.Tensor, weight: torch.Tensor, rb: "Rulebook", inverse:
                                     bn.momentum, bn.eps, relu)
 
 
+def conv_bn_relu_eval(x: torch.Tensor, weight: torch.Tensor, rb: "Rulebook", inverse: bool, bn: torch.nn.BatchNorm1d,
+                      relu: bool) -> Optional[torch.Tensor]:
+    """Inference: conv + BatchNorm1d(running statistics) (+ReLU) as ONE kernel launch, or None when not applicable (the
+    caller then runs the two modules one after the other)."""
+    be = get_backend()
+    if not (FUSE_BN_EVAL and MFMA_OPERAND == "f32" and x.is_cuda and x.shape[0] != 0 and bn.track_running_stats
+            and be.conv_epilogue_supported(x.shape[0], weight.shape[-1], weight.shape[0], rb.kv)):
+        return None
+    tbl, order = (rb.pair_bwd, rb.order_bwd) if inverse else (rb.pair_fwd, rb.order_fwd)
+    return be.conv_forward_affine(x.detach(), weight.detach(), tbl, order, bn.running_mean, bn.running_var,
+                                  None if bn.weight is None else bn.weight.detach(),
+                                  None if bn.bias is None else bn.bias.detach(), bn.eps, relu)
+
+
 OVERLAP_WEIGHT_GRAD = True
+FUSE_BN_STATS = os.environ.get("VIRCONV_FUSE_BN_STATS", "1") != "0"   # training: BN partial sums in the conv epilogue
+FUSE_BN_EVAL = os.environ.get("VIRCONV_FUSE_BN_EVAL", "1") != "0"     # inference: BN(+ReLU) folded into the conv store
 # vc_row_order permutations computed with the rulebooks (tile-homogeneity hint for the gather-GEMM; results identical).
 #   "bwd"  (default) strided convs' backward-input tables only: their active sets are parity classes, sorting cuts the
 #          issued work 2.3x (measured: s3.down bwd 197 -> 85 us) and a 1024-row window is enough

@@ -80,11 +80,18 @@ class SparseConvolution(SparseModule):
         return self.bias is None
 
     def forward(self, x: SparseConvTensor, fuse_bn=None, fuse_relu: bool = False) -> SparseConvTensor:
+        """`fuse_bn` (set by SparseSequential): the BatchNorm1d that follows this conv, folded into the same operator --
+        training mode: one autograd node, statistics from the conv epilogue; eval mode without grad: one kernel launch."""
         assert isinstance(x, SparseConvTensor)
         assert x.features.shape[1] == self.in_channels, "channel size mismatch"
         assert len(x.spatial_shape) == self.ndim
         rb = self._rulebook(x)
-        if fuse_bn is not None:
+        if fuse_bn is not None and not fuse_bn.training:
+            feats = ops.conv_bn_relu_eval(x.features, self.weight, rb, self.inverse, fuse_bn, fuse_relu)
+            if feats is None:  # not applicable: plain conv, then the modules themselves
+                feats = ops.sparse_conv(x.features, self.weight, rb, self.inverse)
+                feats = ops.bn_relu(feats, fuse_bn, fuse_relu)
+        elif fuse_bn is not None:
             feats = ops.conv_bn_relu(x.features, self.weight, rb, self.inverse, fuse_bn, fuse_relu)
         else:
             feats = ops.sparse_conv(x.features, self.weight, rb, self.inverse)

@@ -67,9 +67,11 @@ class SparseSequential(SparseModule):
             if is_spconv_module(module):
                 assert isinstance(input, SparseConvTensor)
                 nxt = mods[k + 1] if k + 1 < len(mods) else None
+                eval_fusable = (nxt is not None and not nxt.training and not torch.is_grad_enabled())
                 if (self.fuse_bn_relu and getattr(module, "fusable_with_bn", False) and type(nxt) is nn.BatchNorm1d
-                        and nxt.training and nxt.affine and nxt.track_running_stats and nxt.momentum is not None
-                        and input.features.is_cuda and input.features.shape[0] != 0 and nxt.num_features % 4 == 0):
+                        and (nxt.training or eval_fusable) and nxt.affine and nxt.track_running_stats
+                        and nxt.momentum is not None and input.features.is_cuda and input.features.shape[0] != 0
+                        and nxt.num_features % 4 == 0):
                     relu = k + 2 < len(mods) and type(mods[k + 2]) is nn.ReLU
                     input = module(input, fuse_bn=nxt, fuse_relu=relu)   # conv + BN (+ ReLU) as one autograd node
                     k += 3 if relu else 2
