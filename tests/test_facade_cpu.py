@@ -151,3 +151,26 @@ def test_permutation_invariance_of_input_rows(oracle_backend):
     assert torch.equal(y0.indices, y1.indices)
     assert torch.allclose(y0.features, y1.features, atol=1e-5)
     assert torch.allclose(s0.features[perm], s1.features, atol=1e-5)  # SubM keeps the caller's row order
+
+
+@pytest.mark.parametrize("bins,seed", [(2, 0), (10, 1), (10, 2), (4, 3)])
+def test_device_input_point_discard_equals_the_numpy_restatement(bins, seed):
+    """virconv_amd.data.input_point_discard_device (torch ops, any device) against the numpy version (which tests/
+    test_oracle_cpu.py pins to the reference's own dataset.py) for the same injected per-bin permutations."""
+    from virconv_amd import data
+    fr = synth.make_frame(seed)
+    pts = fr["points_virtual"]
+    perms = {}
+
+    def perm_np(n):
+        perms.setdefault(n, np.random.default_rng(100 + n).permutation(n))
+        return perms[n]
+
+    ref = data.input_point_discard(pts, bin_num=bins, rate=0.8, permutation=perm_np)
+    got = data.input_point_discard_device(torch.from_numpy(pts), bin_num=bins, rate=0.8,
+                                          permutation=lambda n: torch.from_numpy(perm_np(n)))
+    np.testing.assert_array_equal(got.numpy(), ref)
+    assert abs(ref.shape[0] - 0.2 * pts.shape[0]) < 0.2 * pts.shape[0]
+    fused = data.prepare_frame_device(torch.from_numpy(fr["points_lidar"]), torch.from_numpy(pts), training=(bins == 2),
+                                      permutation=lambda n: torch.from_numpy(perm_np(n)))
+    assert fused.shape[1] == 8 and torch.equal(fused[:fr["points_lidar"].shape[0]], torch.from_numpy(fr["points_lidar"]))

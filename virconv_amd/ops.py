@@ -222,7 +222,9 @@ def conv_bn_relu_eval(x: torch.Tensor, weight: torch.Tensor, rb: "Rulebook", inv
 
 
 OVERLAP_WEIGHT_GRAD = True
-FUSE_BN_STATS = os.environ.get("VIRCONV_FUSE_BN_STATS", "1") != "0"   # training: BN partial sums in the conv epilogue
+# training: BN partial sums in the conv epilogue.  Measured A/B on the bench step: 7.21-7.24 ms with, 7.07 ms without -- the
+# saved read-back pass (0.14 ms) is paid back by the epilogue's two extra barriers and a 10x longer finalize; off by default.
+FUSE_BN_STATS = os.environ.get("VIRCONV_FUSE_BN_STATS", "0") != "0"
 FUSE_BN_EVAL = os.environ.get("VIRCONV_FUSE_BN_EVAL", "1") != "0"     # inference: BN(+ReLU) folded into the conv store
 # vc_row_order permutations computed with the rulebooks (tile-homogeneity hint for the gather-GEMM; results identical).
 #   "bwd"  (default) strided convs' backward-input tables only: their active sets are parity classes, sorting cuts the
