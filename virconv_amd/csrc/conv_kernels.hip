@@ -735,7 +735,16 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x
   float m = 0.f;
   const int64_t n4 = n >> 2;
   const float4* x4 = reinterpret_cast<const float4*>(x);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {  // 4 independent 16-byte loads in flight per thread
+    const float4 v0 = x4[i], v1 = x4[i + stride], v2 = x4[i + 2 * stride], v3 = x4[i + 3 * stride];
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w))));
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w))));
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v2.x), fabsf(v2.y)), fmaxf(fabsf(v2.z), fabsf(v2.w))));
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v3.x), fabsf(v3.y)), fmaxf(fabsf(v3.z), fabsf(v3.w))));
+  }
+  for (; i < n4; i += stride) {
     const float4 v = x4[i];
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
@@ -791,8 +800,13 @@ __global__ void __launch_bounds__(256) group_sum_convert_kernel(const long long*
                                                                 float* __restrict__ grp) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
-  const double scale = gs_scale(*absmax);
-  grp[e] = (scale > 0.0) ? (float)((double)acc[e] / scale) : 0.f;
+  // the scale is a power of two: multiplying by its exact inverse 2^(e-40) equals the division bit for bit (an fp64 divide per
+  // element made this kernel ALU-bound)
+  const float am = __uint_as_float(*absmax);
+  if (!(am > 0.f) || !isfinite(am)) { grp[e] = 0.f; return; }
+  int ex;
+  frexpf(am, &ex);
+  grp[e] = (float)((double)acc[e] * ldexp(1.0, ex - 40));
 }
 
 // --------------------------------------------------------------------------------------------- dispatch

@@ -42,6 +42,15 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int* total, int* 
   return base + inc - v;
 }
 
+// Kernel-offset decode table of a block: entry k = oz | oy << 8 | ox << 16.  These index kernels were bound by integer
+// division (ten runtime div/mod per candidate, 27 candidates per row); the decode now costs one LDS read and the stride
+// division a shift.  Must be called by every thread of the block (contains a barrier).
+__device__ __forceinline__ void fill_offset_table(int* tbl, int kz, int ky, int kx) {
+  const int kv = kz * ky * kx;
+  for (int k = threadIdx.x; k < kv; k += blockDim.x) tbl[k] = (k / (ky * kx)) | (((k / kx) % ky) << 8) | ((k % kx) << 16);
+  __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------ K3 hash build
 // Rows of the image-space (2-D) tensors repeat coordinates massively (every voxel outside the camera frustum clamps onto a
 // border pixel), and equal keys sit in consecutive rows: a segmented max-scan over the wave folds each run of equal keys
@@ -88,6 +97,8 @@ __global__ void __launch_bounds__(256) subm_rulebook_kernel(const int32_t* __res
                                                             int dy, int dx, const uint64_t* __restrict__ keys,
                                                             const int32_t* __restrict__ vals, uint64_t mask,
                                                             int32_t* __restrict__ pair, int32_t* __restrict__ rep) {
+  __shared__ int s_off[128];
+  fill_offset_table(s_off, kz, ky, kx);
   const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
   if (i >= n) return;
   const int kg = threadIdx.x >> 6;
@@ -104,7 +115,8 @@ __global__ void __launch_bounds__(256) subm_rulebook_kernel(const int32_t* __res
       }
       continue;
     }
-    const int oz = k / (ky * kx), oy = (k / kx) % ky, ox = k % kx;
+    const int off = s_off[k];
+    const int oz = off & 255, oy = (off >> 8) & 255, ox = off >> 16;
     const int nz = z + (oz - kz / 2) * dz, ny = y + (oy - ky / 2) * dy, nx = x + (ox - kx / 2) * dx;
     int r = -1;
     if (nz >= 0 && nz < D && ny >= 0 && ny < H && nx >= 0 && nx < W) {
@@ -122,15 +134,27 @@ static constexpr int kWordsPerBlock = 256 * kWordsPerThread;
 struct SpGeom {
   int Do, Ho, Wo;
   int k[3], s[3], p[3], d[3];
+  int sh[3];  // log2(stride) when the stride is a power of two (always, in this model), else -1
 };
 
-// candidate output cell (linear, 64-bit) of input row coordinate (b,z,y,x) through kernel offset k, or -1
-__device__ __forceinline__ int64_t sp_candidate(const SpGeom& g, int b, int z, int y, int x, int k) {
-  const int oz = k / (g.k[1] * g.k[2]), oy = (k / g.k[2]) % g.k[1], ox = k % g.k[2];
+__device__ __forceinline__ bool sp_div(int t, int s, int sh, int& q) {
+  if (sh >= 0) {
+    if (t & (s - 1)) return false;
+    q = t >> sh;
+    return true;
+  }
+  if (t % s) return false;
+  q = t / s;
+  return true;
+}
+
+// candidate output cell (linear, 64-bit) of input row coordinate (b,z,y,x) through kernel offset `off` (table entry), or -1
+__device__ __forceinline__ int64_t sp_candidate(const SpGeom& g, int b, int z, int y, int x, int off) {
+  const int oz = off & 255, oy = (off >> 8) & 255, ox = off >> 16;
   const int tz = z + g.p[0] - oz * g.d[0], ty = y + g.p[1] - oy * g.d[1], tx = x + g.p[2] - ox * g.d[2];
   if (tz < 0 || ty < 0 || tx < 0) return -1;
-  if (tz % g.s[0] || ty % g.s[1] || tx % g.s[2]) return -1;
-  const int qz = tz / g.s[0], qy = ty / g.s[1], qx = tx / g.s[2];
+  int qz, qy, qx;
+  if (!sp_div(tz, g.s[0], g.sh[0], qz) || !sp_div(ty, g.s[1], g.sh[1], qy) || !sp_div(tx, g.s[2], g.sh[2], qx)) return -1;
   if (qz >= g.Do || qy >= g.Ho || qx >= g.Wo) return -1;
   return (((int64_t)b * g.Do + qz) * g.Ho + qy) * g.Wo + qx;
 }
@@ -140,6 +164,8 @@ __device__ __forceinline__ int64_t sp_candidate(const SpGeom& g, int b, int z, i
 // merges them and only the last lane of each run issues the atomic (same-address L2 atomics serialise).
 __global__ void __launch_bounds__(256) sp_mark_kernel(const int32_t* __restrict__ indices, int64_t n, int ndim,
                                                       SpGeom g, unsigned long long* __restrict__ bitmap) {
+  __shared__ int s_off[128];
+  fill_offset_table(s_off, g.k[0], g.k[1], g.k[2]);
   const int lane = threadIdx.x & 63, kg = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 64 + lane;
   const bool live = i < n;
@@ -147,7 +173,7 @@ __global__ void __launch_bounds__(256) sp_mark_kernel(const int32_t* __restrict_
   if (live) load_coord(indices, i, ndim, b, z, y, x);
   const int kv = g.k[0] * g.k[1] * g.k[2];
   for (int k = kg; k < kv; k += 4) {
-    const int64_t L = live ? sp_candidate(g, b, z, y, x, k) : -1;
+    const int64_t L = live ? sp_candidate(g, b, z, y, x, s_off[k]) : -1;
     const bool valid = L >= 0;
     // lanes without a candidate (for stride 2 every other x) adopt the word of the nearest valid lane below them, so that
     // the lanes of one word form ONE contiguous run whose last lane flushes it
@@ -269,6 +295,8 @@ __global__ void __launch_bounds__(256) sp_pairs_kernel(const int32_t* __restrict
                                                        const uint32_t* __restrict__ prefix, int64_t n_out,
                                                        int32_t* __restrict__ pair_fwd,
                                                        int32_t* __restrict__ pair_bwd) {
+  __shared__ int s_off[128];
+  fill_offset_table(s_off, g.k[0], g.k[1], g.k[2]);
   const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);  // 64 rows x 4 offset groups, as sp_mark_kernel
   if (i >= n) return;
   const int kg = threadIdx.x >> 6;
@@ -276,7 +304,7 @@ __global__ void __launch_bounds__(256) sp_pairs_kernel(const int32_t* __restrict
   load_coord(indices, i, ndim, b, z, y, x);
   const int kv = g.k[0] * g.k[1] * g.k[2];
   for (int k = kg; k < kv; k += 4) {
-    const int64_t L = sp_candidate(g, b, z, y, x, k);
+    const int64_t L = sp_candidate(g, b, z, y, x, s_off[k]);
     int o = -1;
     if (L >= 0) {
       unsigned long long w = bitmap[L >> 6];
@@ -384,7 +412,8 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restric
   const int c4 = c >> 2;
   int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= n_keep * c4) return;
-  int64_t j = t / c4;
+  // c4 is a power of two for every layer of this model: shift instead of a 64-bit division per float4
+  int64_t j = ((c4 & (c4 - 1)) == 0) ? (t >> (__ffs(c4) - 1)) : (t / c4);
   int q = (int)(t - j * c4);
   int64_t src = keep[j];
   reinterpret_cast<float4*>(feat_out)[j * c4 + q] = reinterpret_cast<const float4*>(feat)[src * c4 + q];
@@ -409,26 +438,49 @@ __global__ void __launch_bounds__(256) scatter_rows_kernel(const float* __restri
   const int c4 = c >> 2;
   int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= n_keep * c4) return;
-  int64_t j = t / c4;
+  int64_t j = ((c4 & (c4 - 1)) == 0) ? (t >> (__ffs(c4) - 1)) : (t / c4);
   int q = (int)(t - j * c4);
   reinterpret_cast<float4*>(gin)[keep[j] * c4 + q] = reinterpret_cast<const float4*>(gout)[j * c4 + q];
 }
 
 // ------------------------------------------------------------------------------------------ K10 dense
+// Block = 64 rows x all channels.  The rows are read (written) as whole coalesced rows through an LDS tile, each row's
+// dense base offset is computed once, and every wave instruction touches 64 rows of ONE channel plane (x-adjacent rows are
+// adjacent there).  The first version used a thread per (channel, row): a 64-bit division per element and one 4-byte
+// access per 256-byte feature row -- 444 MB fetched per launch for 16 MB of features (PMC).
 template <bool TO_DENSE>
 __global__ void __launch_bounds__(256) dense_kernel(float* __restrict__ feat, const int32_t* __restrict__ indices,
                                                     int64_t n, int c, int ndim, int D, int H, int W,
                                                     float* __restrict__ dense) {
-  // thread per (channel, row) with rows fastest: consecutive threads hit consecutive rows of one channel plane
-  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= n * c) return;
-  int ch = (int)(t / n);
-  int64_t i = t - (int64_t)ch * n;
-  int b, z, y, x;
-  load_coord(indices, i, ndim, b, z, y, x);
-  int64_t off = ((((int64_t)b * c + ch) * D + z) * H + y) * W + x;
-  if (TO_DENSE) dense[off] = feat[i * c + ch];
-  else feat[i * c + ch] = dense[off];
+  extern __shared__ float d_tile[];                       // [64][c + 1] floats, then 64 int64 base offsets
+  const int ld = c + 1;
+  int64_t* s_base = reinterpret_cast<int64_t*>(d_tile + 64 * ld + ((64 * ld) & 1));
+  const int64_t row0 = (int64_t)blockIdx.x * 64;
+  const int rows = (int)min((int64_t)64, n - row0);
+  const int64_t plane = (int64_t)D * H * W;
+  if (threadIdx.x < rows) {
+    int b, z, y, x;
+    load_coord(indices, row0 + threadIdx.x, ndim, b, z, y, x);
+    s_base[threadIdx.x] = (((int64_t)b * c * D + z) * H + y) * W + x;   // offset of channel 0
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (TO_DENSE) {
+    for (int r = wave; r < rows; r += 4)
+      for (int col = lane; col < c; col += 64) d_tile[r * ld + col] = feat[(row0 + r) * c + col];
+  }
+  __syncthreads();
+  if (lane < rows) {
+    const int64_t base = s_base[lane];
+    for (int ch = wave; ch < c; ch += 4) {
+      if (TO_DENSE) dense[base + ch * plane] = d_tile[lane * ld + ch];
+      else d_tile[lane * ld + ch] = dense[base + ch * plane];
+    }
+  }
+  if (!TO_DENSE) {
+    __syncthreads();
+    for (int r = wave; r < rows; r += 4)
+      for (int col = lane; col < c; col += 64) feat[(row0 + r) * c + col] = d_tile[r * ld + col];
+  }
 }
 
 // ------------------------------------------------------------------------------------------ generic int scan (flags)
@@ -644,6 +696,7 @@ int vc_subm_rulebook(const int32_t* indices, int64_t n, int ndim, const int32_t*
   if (ws_bytes < cap * 12) { set_error("vc_subm_rulebook: workspace too small"); return VC_ECAPACITY; }
   Dims d = make_dims(ndim, shape);
   Kern3 g = make_kern(ndim, ksize, nullptr, nullptr, dilation);
+  VC_REQUIRE(g.kv <= 128, "vc_subm_rulebook: kernel volume %d > 128", g.kv);
   for (int a = 0; a < 3; ++a) VC_REQUIRE(g.k[a] % 2 == 1, "vc_subm_rulebook: kernel sizes must be odd");
   const uint64_t* keys = (const uint64_t*)ws;
   const int32_t* vals = (const int32_t*)(keys + cap);
@@ -673,7 +726,15 @@ size_t vc_spconv_workspace_bytes(int batch_size, int ndim, const int32_t* out_sh
 static inline SpGeom make_spgeom(const Dims& o, const Kern3& k) {
   SpGeom g;
   g.Do = o.D; g.Ho = o.H; g.Wo = o.W;
-  for (int a = 0; a < 3; ++a) { g.k[a] = k.k[a]; g.s[a] = k.s[a]; g.p[a] = k.p[a]; g.d[a] = k.d[a]; }
+  for (int a = 0; a < 3; ++a) {
+    g.k[a] = k.k[a]; g.s[a] = k.s[a]; g.p[a] = k.p[a]; g.d[a] = k.d[a];
+    g.sh[a] = -1;
+    if (k.s[a] > 0 && (k.s[a] & (k.s[a] - 1)) == 0) {
+      int sh = 0;
+      while ((1 << sh) < k.s[a]) ++sh;
+      g.sh[a] = sh;
+    }
+  }
   return g;
 }
 
@@ -694,6 +755,7 @@ int vc_spconv_mark_count(const int32_t* indices, int64_t n, int ndim, int batch_
   int32_t* blocksum = (int32_t*)(prefix + nwords);
   VC_CHECK_HIP(hipMemsetAsync(bitmap, 0, nwords * 8, st));
   Kern3 k = make_kern(ndim, ksize, stride_, padding, dilation);
+  VC_REQUIRE(k.kv <= 128, "strided rulebook: kernel volume %d > 128", k.kv);
   SpGeom g = make_spgeom(o, k);
   if (n > 0) {
     hipLaunchKernelGGL(sp_mark_kernel, dim3((unsigned)cdiv(n, 64)), dim3(256), 0, st, indices, n, ndim, g, bitmap);
@@ -723,6 +785,7 @@ int vc_spconv_emit_pairs(const int32_t* indices, int64_t n, int ndim, int batch_
   uint32_t* prefix = (uint32_t*)(bitmap + nwords);
   const int32_t* blocksum = (const int32_t*)(prefix + nwords);
   Kern3 k = make_kern(ndim, ksize, stride_, padding, dilation);
+  VC_REQUIRE(k.kv <= 128, "strided rulebook: kernel volume %d > 128", k.kv);
   SpGeom g = make_spgeom(o, k);
   hipLaunchKernelGGL(sp_prefix_kernel, dim3((unsigned)nb), dim3(256), 0, st, bitmap, nwords, blocksum, prefix);
   VC_CHECK_LAUNCH("sp_prefix_kernel");
@@ -800,7 +863,9 @@ int vc_to_dense(const float* features, const int32_t* indices, int64_t n, int c,
   if (n == 0) return VC_OK;
   VC_REQUIRE(features && indices && dense, "vc_to_dense: null argument");
   Dims d = make_dims(ndim, shape);
-  hipLaunchKernelGGL(dense_kernel<true>, dim3((unsigned)cdiv(n * c, 256)), dim3(256), 0, (hipStream_t)stream,
+  const size_t lds = (size_t)64 * (c + 1) * sizeof(float) + 64 * sizeof(int64_t) + 8;
+  VC_REQUIRE(lds <= 64 * 1024, "vc_to_dense: channel count %d too large", c);
+  hipLaunchKernelGGL(dense_kernel<true>, dim3((unsigned)cdiv(n, 64)), dim3(256), lds, (hipStream_t)stream,
                      const_cast<float*>(features), indices, n, c, ndim, d.D, d.H, d.W, dense);
   VC_CHECK_LAUNCH("dense_kernel<to>");
   return VC_OK;
@@ -812,7 +877,9 @@ int vc_from_dense(const float* dense, const int32_t* indices, int64_t n, int c, 
   if (n == 0) return VC_OK;
   VC_REQUIRE(features && indices && dense, "vc_from_dense: null argument");
   Dims d = make_dims(ndim, shape);
-  hipLaunchKernelGGL(dense_kernel<false>, dim3((unsigned)cdiv(n * c, 256)), dim3(256), 0, (hipStream_t)stream, features,
+  const size_t lds = (size_t)64 * (c + 1) * sizeof(float) + 64 * sizeof(int64_t) + 8;
+  VC_REQUIRE(lds <= 64 * 1024, "vc_from_dense: channel count %d too large", c);
+  hipLaunchKernelGGL(dense_kernel<false>, dim3((unsigned)cdiv(n, 64)), dim3(256), lds, (hipStream_t)stream, features,
                      indices, n, c, ndim, d.D, d.H, d.W, const_cast<float*>(dense));
   VC_CHECK_LAUNCH("dense_kernel<from>");
   return VC_OK;
