@@ -106,24 +106,50 @@ __global__ void __launch_bounds__(256) subm_rulebook_kernel(const int32_t* __res
   const int centre = ((kz / 2) * ky + ky / 2) * kx + kx / 2;
   int b, z, y, x;
   load_coord(indices, i, ndim, b, z, y, x);
-  for (int k = kg; k < kv; k += 4) {
-    if (k == centre) {
-      pair[(int64_t)k * n + i] = (int32_t)i;
-      if (rep) {
-        uint64_t key = (((uint64_t)b * D + z) * H + y) * W + x;
-        rep[i] = hash_lookup(keys, vals, mask, key);
+  // Offsets in batches of 8 per thread: the first probe of every offset of the batch is issued before any is resolved (most
+  // lookups end at their first slot, hit or empty), so a thread has up to 8 independent loads in flight instead of one chain.
+  for (int k0 = kg; k0 < kv; k0 += 32) {
+    uint64_t key[8], slot[8], found[8];
+    bool ok[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + 4 * j;
+      ok[j] = false;
+      key[j] = 0; slot[j] = 0; found[j] = kEmptyKey;
+      if (k >= kv || k == centre) continue;
+      const int off = s_off[k];
+      const int oz = off & 255, oy = (off >> 8) & 255, ox = off >> 16;
+      const int nz = z + (oz - kz / 2) * dz, ny = y + (oy - ky / 2) * dy, nx = x + (ox - kx / 2) * dx;
+      if (nz >= 0 && nz < D && ny >= 0 && ny < H && nx >= 0 && nx < W) {
+        ok[j] = true;
+        key[j] = (((uint64_t)b * D + nz) * H + ny) * W + nx;
+        slot[j] = coord_slot(key[j], mask);
+        found[j] = keys[slot[j]];
       }
-      continue;
     }
-    const int off = s_off[k];
-    const int oz = off & 255, oy = (off >> 8) & 255, ox = off >> 16;
-    const int nz = z + (oz - kz / 2) * dz, ny = y + (oy - ky / 2) * dy, nx = x + (ox - kx / 2) * dx;
-    int r = -1;
-    if (nz >= 0 && nz < D && ny >= 0 && ny < H && nx >= 0 && nx < W) {
-      uint64_t key = (((uint64_t)b * D + nz) * H + ny) * W + nx;
-      r = hash_lookup(keys, vals, mask, key);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + 4 * j;
+      if (k >= kv) continue;
+      if (k == centre) {
+        pair[(int64_t)k * n + i] = (int32_t)i;
+        if (rep) {
+          const uint64_t kk = (((uint64_t)b * D + z) * H + y) * W + x;
+          rep[i] = hash_lookup(keys, vals, mask, kk);
+        }
+        continue;
+      }
+      int r = -1;
+      if (ok[j]) {
+        uint64_t sl = slot[j], f = found[j];
+        while (f != key[j] && f != kEmptyKey) {  // rare: collision chain
+          sl = coord_next(sl, mask);
+          f = keys[sl];
+        }
+        if (f == key[j]) r = vals[sl];
+      }
+      pair[(int64_t)k * n + i] = r;
     }
-    pair[(int64_t)k * n + i] = r;
   }
 }
 
