@@ -117,9 +117,22 @@ __global__ void __launch_bounds__(256) bn_stats_finalize_kernel(const double* __
   if (ch >= c) return;
   if (num_batches_tracked && ch == 0 && lane == 0) *num_batches_tracked += 1;
   double s = 0.0, ss = 0.0;
-  for (int b = lane; b < nb; b += 64) {
-    s += partial[(int64_t)b * 2 * c + ch];
-    ss += partial[(int64_t)b * 2 * c + c + ch];
+  {  // same addition order as a plain loop; four trips' loads are issued together (the kernel was a chain of dependent loads)
+    int b = lane;
+    for (; b + 192 < nb; b += 256) {
+      double a[4], q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = partial[(int64_t)(b + 64 * u) * 2 * c + ch];
+        q[u] = partial[(int64_t)(b + 64 * u) * 2 * c + c + ch];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s += a[u]; ss += q[u]; }
+    }
+    for (; b < nb; b += 64) {
+      s += partial[(int64_t)b * 2 * c + ch];
+      ss += partial[(int64_t)b * 2 * c + c + ch];
+    }
   }
   wave_sum2(s, ss);
   if (lane != 0) return;
@@ -173,9 +186,22 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const double* __re
   const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ch >= c) return;
   double s = 0.0, ss = 0.0;
-  for (int b = lane; b < nb; b += 64) {
-    s += partial[(int64_t)b * 2 * c + ch];
-    ss += partial[(int64_t)b * 2 * c + c + ch];
+  {  // same addition order as a plain loop; four trips' loads are issued together (the kernel was a chain of dependent loads)
+    int b = lane;
+    for (; b + 192 < nb; b += 256) {
+      double a[4], q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = partial[(int64_t)(b + 64 * u) * 2 * c + ch];
+        q[u] = partial[(int64_t)(b + 64 * u) * 2 * c + c + ch];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s += a[u]; ss += q[u]; }
+    }
+    for (; b < nb; b += 64) {
+      s += partial[(int64_t)b * 2 * c + ch];
+      ss += partial[(int64_t)b * 2 * c + c + ch];
+    }
   }
   wave_sum2(s, ss);
   if (lane != 0) return;
