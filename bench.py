@@ -209,6 +209,15 @@ def main():
     if args.mode == "infer":
         return run_infer(args, model, batch, device, rank, world)
 
+    # Setup (untimed, not a step): a second of steady-state steps before the W warm-up steps (allocator, clocks).  Measured:
+    # this does NOT remove the first-process-on-a-fresh-box penalty (7.5 ms vs 6.7-7.0 ms for later processes on the same
+    # box, with or without 4 s of settling), whose cause is outside this process.
+    settle = float(os.environ.get("VIRCONV_SETTLE_SEC", "1.0"))
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < settle:
+        train_step(ddp, optimizer, batch, lw, grad_sync)
+        torch.cuda.synchronize()
+
     for _ in range(args.warmup):
         train_step(ddp, optimizer, batch, lw, grad_sync)
 
