@@ -221,7 +221,10 @@ def conv_bn_relu_eval(x: torch.Tensor, weight: torch.Tensor, rb: "Rulebook", inv
                                   None if bn.bias is None else bn.bias.detach(), bn.eps, relu)
 
 
-OVERLAP_WEIGHT_GRAD = os.environ.get("VIRCONV_OVERLAP_DW", "1") != "0"  # dW on a side stream under the backward-input conv
+# dW on a side stream under the backward-input conv.  Was worth 0.5 ms when the kernels left the chip half empty; since the
+# kernel work of this round it only adds two stream joins per layer on the host: 6.61-6.63 ms without vs 6.85-7.15 ms with
+# (three interleaved A/B pairs).  Off by default.
+OVERLAP_WEIGHT_GRAD = os.environ.get("VIRCONV_OVERLAP_DW", "0") != "0"
 # training: BN partial sums in the conv epilogue.  Measured A/B on the bench step: 7.21-7.24 ms with, 7.07 ms without -- the
 # saved read-back pass (0.14 ms) is paid back by the epilogue's two extra barriers and a 10x longer finalize; off by default.
 FUSE_BN_STATS = os.environ.get("VIRCONV_FUSE_BN_STATS", "0") != "0"
