@@ -125,8 +125,11 @@ def test_fullsize_backbone_eval_vs_oracle_and_deterministic(hip_backend, frame_b
     assert float((a.features.cpu() - b.features).abs().max()) < 1e-4 * max(1.0, float(b.features.abs().max()))
 
 
-def test_fullsize_train_step_gradients_are_bitwise_deterministic(hip_backend):
-    """Whole VirConv-L forward + backward (2-D branch, injected layer-discard permutations) twice: every gradient bit-equal."""
+@pytest.mark.parametrize("overlap_dw", [False, True])
+def test_fullsize_train_step_gradients_are_bitwise_deterministic(hip_backend, overlap_dw, monkeypatch):
+    """Whole VirConv-L forward + backward (2-D branch, injected layer-discard permutations) twice: every gradient bit-equal.
+    Also with the weight gradient on its side stream (off by default): that path once had a scratch-lifetime race."""
+    monkeypatch.setattr(ops, "OVERLAP_WEIGHT_GRAD", overlap_dw)
     b1 = bench.make_batch([0], torch.device("cuda", 0), training=True)
     torch.manual_seed(3)
     model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).cuda().train()
