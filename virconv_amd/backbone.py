@@ -139,7 +139,44 @@ class NRConvBlock(nn.Module):
         rb2 = ops.build_subm_rulebook(uv, self.IMAGE_SHAPE, self.d2_conv1[0].kernel_size, self.d2_conv1[0].dilation, True)
         return {"rb3d": rbs3, "uv": uv, "rb2d": {k2: rb2}, "out_indices": indices, "out_shape": shape}
 
+    @staticmethod
+    def _unit_is_plain(seq) -> bool:
+        """conv (no bias) -> BatchNorm1d -> ReLU, the only shape post_act_block builds."""
+        mods = list(seq._modules.values())
+        return (len(mods) == 3 and getattr(seq, "fuse_bn_relu", False) and getattr(mods[0], "fusable_with_bn", False)
+                and type(mods[1]) is nn.BatchNorm1d
+                and type(mods[2]) is nn.ReLU and mods[1].affine and mods[1].track_running_stats
+                and mods[1].momentum is not None and mods[1].num_features % 4 == 0)
+
+    def _unit(self, seq, feats, rb):
+        """One conv+BN+ReLU unit on a feature matrix with a ready rulebook -- what SparseSequential.forward does for this
+        module triple, minus the per-layer SparseConvTensor bookkeeping (the plan path knows every index structure)."""
+        conv, bn = seq[0], seq[1]
+        if bn.training:
+            return ops.conv_bn_relu(feats, conv.weight, rb, False, bn, True)
+        out = ops.conv_bn_relu_eval(feats, conv.weight, rb, False, bn, True) if not torch.is_grad_enabled() else None
+        if out is None:
+            out = ops.bn_relu(ops.sparse_conv(feats, conv.weight, rb, False), bn, True)
+        return out
+
+    def _forward_planned(self, sp_tensor, batch_size, plan):
+        kd, k3, k2 = self._keys()
+        f = sp_tensor.features
+        if self.stride > 1:
+            f = self._unit(self.down_layer, f, plan["rb3d"][kd])
+        rb3, rb2 = plan["rb3d"][k3], plan["rb2d"][k2]
+        f3 = self._unit(self.d3_conv2, self._unit(self.d3_conv1, f, rb3), rb3)
+        f2 = self._unit(self.d2_conv2, self._unit(self.d2_conv1, f3, rb2), rb2)
+        indice_dict = dict(sp_tensor.indice_dict)
+        indice_dict.update(plan["rb3d"])
+        return spconv.SparseConvTensor(torch.cat([f3, f2], -1), plan["out_indices"], plan["out_shape"], batch_size,
+                                       indice_dict=indice_dict)
+
     def forward(self, sp_tensor, batch_size, calib, stride, x_trans_train=None, trans_param=None, plan=None):
+        if (plan is not None and sp_tensor.features.is_cuda and sp_tensor.features.shape[0] != 0
+                and all(self._unit_is_plain(m) for m in ([self.down_layer] if self.stride > 1 else []) +
+                        [self.d3_conv1, self.d3_conv2, self.d2_conv1, self.d2_conv2])):
+            return self._forward_planned(sp_tensor, batch_size, plan)
         if plan is not None:
             sp_tensor.indice_dict.update(plan["rb3d"])
         if self.stride > 1:
