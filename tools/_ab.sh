@@ -1,10 +1,9 @@
 mkdir -p gpurun_out/ab
+timeout 900 python -m pytest tests -m gpu -q > gpurun_out/ab/t.log 2>&1
 run() { tag=$1; shift; env "$@" python bench.py --steps 40 --warmup 12 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$tag', d['ms_per_step'])" >> gpurun_out/ab/res.txt; }
-run warm X=1
-run overlap1 VIRCONV_OVERLAP_DW=1
-run nooverlap1 VIRCONV_OVERLAP_DW=0
-run overlap2 VIRCONV_OVERLAP_DW=1
-run nooverlap2 VIRCONV_OVERLAP_DW=0
-run overlap3 VIRCONV_OVERLAP_DW=1
-run nooverlap3 VIRCONV_OVERLAP_DW=0
-cat gpurun_out/ab/res.txt
+run a X=1
+run b X=1
+run c X=1
+python bench.py --mode infer --batch-size 1 --steps 100 --warmup 20 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('infer1', d['ms_per_step'])" >> gpurun_out/ab/res.txt
+python bench.py --mode infer --batch-size 4 --steps 60 --warmup 20 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('infer4', d['ms_per_step'])" >> gpurun_out/ab/res.txt
+tail -3 gpurun_out/ab/t.log; cat gpurun_out/ab/res.txt

@@ -42,6 +42,9 @@ def short(name: str) -> str:
 
 def stats_summary(path: str, steps: int, out_md: str, title: str) -> None:
     rows = list(csv.DictReader(open(path)))
+    once = [int(r["Calls"]) for r in rows if "dense_kernel<true>" in r["Name"]]  # launched exactly once per train step
+    if once:
+        steps = once[0]  # counts the settle / warm-up / timed steps alike, whatever their number was
     tot = sum(float(r["TotalDurationNs"]) for r in rows) / steps / 1e6
     calls = sum(int(r["Calls"]) for r in rows) / steps
     fam = defaultdict(float)
