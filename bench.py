@@ -180,6 +180,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
     device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
+    numa = parallel.bind_to_gpu_numa(device.index)  # one process per GPU, on the cores next to that GPU
     be = ops.get_backend()
     ops.MFMA_OPERAND = args.operand
 
@@ -262,7 +263,7 @@ def main():
                                "NRConv 2-D branch on, synthetic KITTI frames (20k LiDAR + 60k virtual points, input "
                                "discard 0.8, <=40000 voxels/frame)",
                    "frames_per_gpu": bs, "global_batch": bs * world, "voxels_rank0": int(batch["voxel_features"].shape[0]),
-                   "parallelism": f"dp{world}"},
+                   "parallelism": f"dp{world}", "cpu_affinity": numa},
         "roofline": roof,
     }
     if world == 1 and not args.no_cpu_baseline:

@@ -111,3 +111,17 @@ def test_shard_frames():
     shards = [parallel.shard_frames(ids, r, 4) for r in range(4)]
     assert sorted(sum(shards, [])) == ids and all(len(s) == 2 for s in shards)
     assert parallel.shard_frames(ids, 0, 1) == ids
+
+
+def test_numa_binding_helpers_are_safe_without_a_gpu(monkeypatch):
+    """bind_to_gpu_numa is best effort: it must never raise and must honour VIRCONV_NUMA_BIND=0; the cpulist parser handles
+    the kernel's 'a-b,c' syntax."""
+    from virconv_amd import parallel
+    assert parallel._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert parallel._parse_cpulist("") == set()
+    before = os.sched_getaffinity(0)
+    msg = parallel.bind_to_gpu_numa(0)
+    assert isinstance(msg, str) and os.sched_getaffinity(0) <= before
+    os.sched_setaffinity(0, before)
+    monkeypatch.setenv("VIRCONV_NUMA_BIND", "0")
+    assert parallel.bind_to_gpu_numa(0) == "off"

@@ -167,6 +167,22 @@ def _conv_backward(rb: "Rulebook", inverse: bool, features, weight, grad_out, ne
     return dx, dw
 
 
+def _as_wide_rows(g: torch.Tensor):
+    """(tensor, first column) such that tensor[:, col : col + C] == g, WITHOUT copying when g is a column slice of a wider
+    row-major matrix (what the backward of the NRConv concat hands to its two producers).  The BN backward kernels take a row
+    stride and a column offset, so the `.contiguous()` copy of every such slice can be skipped."""
+    if g.is_contiguous():
+        return g, 0
+    n, c = g.shape
+    rs = g.stride(0)
+    if (g.dim() == 2 and g.stride(1) == 1 and rs > c and rs % 4 == 0 and c % 4 == 0 and g.is_cuda):
+        col0 = g.storage_offset() % rs
+        start = g.storage_offset() - col0
+        if col0 % 4 == 0 and col0 + c <= rs and g.untyped_storage().nbytes() >= (start + n * rs) * g.element_size():
+            return torch.as_strided(g, (n, rs), (rs, 1), start), col0
+    return g.contiguous(), 0
+
+
 class ConvBNReLUFunction(torch.autograd.Function):
     """conv -> training-mode BatchNorm1d -> (ReLU) as ONE autograd node (half the Python/autograd overhead of the two
     separate nodes; same kernels, same numerics)."""
@@ -194,7 +210,8 @@ class ConvBNReLUFunction(torch.autograd.Function):
         be = get_backend()
         x, weight, y_raw, mean, var, gamma, beta = ctx.saved_tensors
         eps, relu = ctx.cfg
-        d_raw, dgamma, dbeta = be.bn_backward(y_raw, grad_out.contiguous(), 0, mean, var, gamma, beta, eps, relu)
+        wide, col0 = _as_wide_rows(grad_out)
+        d_raw, dgamma, dbeta = be.bn_backward(y_raw, wide, col0, mean, var, gamma, beta, eps, relu)
         dx, dw = _conv_backward(ctx.rb, ctx.inverse, x, weight, d_raw, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None
 

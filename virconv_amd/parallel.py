@@ -30,6 +30,56 @@ def init_distributed(backend: str = None) -> tuple:
     return rank, local_rank, world
 
 
+def _parse_cpulist(text: str):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def bind_to_gpu_numa(device_index: int = 0) -> str:
+    """Pin this process to the CPU cores of the NUMA node its GPU hangs off (one process per GPU: the launch/doorbell path
+    and the pinned count reads should not cross the socket interconnect).  Best effort, never raises.  The GPU is found by
+    its PCI address (torch device properties) or, failing that, as the device_index-th GPU node of the KFD topology that this
+    container may read.  VIRCONV_NUMA_BIND=0 disables it.  -> a short description for logs."""
+    if os.environ.get("VIRCONV_NUMA_BIND", "1") == "0":
+        return "off"
+    try:
+        import glob
+        cpulist = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            addr = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            path = f"/sys/bus/pci/devices/{addr}/local_cpulist"
+            if os.path.exists(path):
+                cpulist = open(path).read()
+        except Exception:
+            cpulist = None
+        if cpulist is None:
+            minors = []
+            for node in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*"), key=lambda p: int(p.rsplit("/", 1)[1])):
+                try:
+                    props = dict(line.split()[:2] for line in open(node + "/properties") if line.strip())
+                except OSError:
+                    continue  # another tenant's GPU
+                if int(props.get("simd_count", "0")) > 0:
+                    minors.append(int(props["drm_render_minor"]))
+            if device_index < len(minors):
+                cpulist = open(f"/sys/class/drm/renderD{minors[device_index]}/device/local_cpulist").read()
+        if not cpulist or not cpulist.strip():
+            return "unknown topology"
+        want = _parse_cpulist(cpulist) & os.sched_getaffinity(0)
+        if not want:
+            return "no local cpu in the allowed set"
+        os.sched_setaffinity(0, want)
+        return f"bound to {len(want)} cpus of the GPU's NUMA node ({cpulist.strip()})"
+    except Exception as e:  # pragma: no cover - topology files differ between kernels / containers
+        return f"not bound ({type(e).__name__})"
+
+
 def shard_frames(frame_ids: Sequence[int], rank: int, world: int) -> List[int]:
     """Round-robin frame sharding (what DistributedSampler does without shuffling, datasets/__init__.py:66-71)."""
     return [f for k, f in enumerate(frame_ids) if k % world == rank]
