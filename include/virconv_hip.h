@@ -150,7 +150,10 @@ int vc_conv_backward_weight(const float* x, const float* dy, const int32_t* pair
  * 64-bit fixed point scaled by the tensor's max |dy| (integer adds are associative), then rounded once to fp32.       */
 size_t vc_group_sum_workspace_bytes(int64_t n, int c);
 int vc_group_sum(const float* dy, const int32_t* rep, int64_t n, int c, float* dy_grp, void* ws, size_t ws_bytes,
-                 void* stream);
+                 int prepared, void* stream);
+/* Optional two-step form that saves the max|dy| pass: vc_group_sum_prepare zeroes `ws`; the kernel that PRODUCES dy then
+ * leaves max|dy| in the first word of ws (vc_bn_relu_backward's absmax_out = ws); vc_group_sum(..., prepared = 1).        */
+int vc_group_sum_prepare(void* ws, size_t ws_bytes, int64_t n, int c, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ K9 projection
  * Voxel index -> image pixel index.  Replaces index2points + index2uv +
@@ -213,7 +216,8 @@ int vc_bn_apply_relu(const float* x, int64_t n, int c, const float* mean, const 
                      const float* beta, float eps, int relu, float* y, int y_stride, int y_col0, void* stream);
 int vc_bn_relu_backward(const float* x, const float* dy, int dy_stride, int dy_col0, int64_t n, int c,
                         const float* mean, const float* var, const float* gamma, const float* beta, float eps,
-                        int relu, float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+                        int relu, float* dx, float* dgamma, float* dbeta, unsigned* absmax_out /* nullable, zeroed by
+                        the caller: receives max|dx| as float bits */, void* ws, size_t ws_bytes, void* stream);
 
 /* ================================================================================================ RoI grid pooling
  * the operators that consume multi_scale_3d_features['x_conv3'/'x_conv4'] right after the backbone

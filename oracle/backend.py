@@ -57,7 +57,8 @@ class OracleBackend:
     def conv_epilogue_supported(self, n_in, cin, cout, kv, operand="f32"):
         return False  # fused epilogues are a product optimisation; the oracle always takes the plain path
 
-    def conv_backward_input(self, dy, weight, tbl, n_in, mirror, centre=-1, rep=None, order=None, operand="f32"):
+    def conv_backward_input(self, dy, weight, tbl, n_in, mirror, centre=-1, rep=None, order=None, operand="f32",
+                            group_ws=None):
         """dX of the three conv flavours, in the product's calling convention (include/virconv_hip.h).
 
         SubM (mirror=True, tbl = pair_fwd): the EXACT transpose of the forward gather,
@@ -160,7 +161,7 @@ class OracleBackend:
             y = torch.relu(y)
         return y, mean, var
 
-    def bn_backward(self, x, dy, dy_col0, mean, var, gamma, beta, eps, relu):
+    def bn_backward(self, x, dy, dy_col0, mean, var, gamma, beta, eps, relu, absmax_ws=None):
         n, c = x.shape
         dy = dy[:, dy_col0:dy_col0 + c]
         istd = 1.0 / torch.sqrt(var + eps)

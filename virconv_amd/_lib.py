@@ -45,7 +45,8 @@ SIGNATURES = {
     "vc_conv_backward_weight_workspace_bytes": (_SZ, [_I64, _I, _I, _I]),
     "vc_conv_backward_weight": (_I, [_P, _P, _P, _I64, _I, _I, _I, _I, _P, _P, _SZ, _P]),
     "vc_group_sum_workspace_bytes": (_SZ, [_I64, _I]),
-    "vc_group_sum": (_I, [_P, _P, _I64, _I, _P, _P, _SZ, _P]),
+    "vc_group_sum": (_I, [_P, _P, _I64, _I, _P, _P, _SZ, _I, _P]),
+    "vc_group_sum_prepare": (_I, [_P, _SZ, _I64, _I, _P]),
     "vc_project_prepare": (_I, [_P, _P, _I, _P, _P]),
     "vc_project_uv": (_I, [_P, _I64, _P, _I, _I, _P, _P, _P]),
     "vc_gather_rows": (_I, [_P, _P, _I, _I, _P, _I64, _P, _P, _P]),
@@ -57,7 +58,7 @@ SIGNATURES = {
     "vc_bn_workspace_bytes": (_SZ, [_I64, _I]),
     "vc_bn_stats": (_I, [_P, _I64, _I, _P, _P, _P, _P, _P, _F, _P, _SZ, _P]),
     "vc_bn_apply_relu": (_I, [_P, _I64, _I, _P, _P, _P, _P, _F, _I, _P, _I, _I, _P]),
-    "vc_bn_relu_backward": (_I, [_P, _P, _I, _I, _I64, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _SZ, _P]),
+    "vc_bn_relu_backward": (_I, [_P, _P, _I, _I, _I64, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _SZ, _P]),
 }
 
 _lib = None

@@ -203,7 +203,9 @@ class HipBackend:
 
     def conv_backward_input(self, dy: torch.Tensor, weight: torch.Tensor, tbl: torch.Tensor, n_in: int, mirror: bool,
                             centre: int = -1, rep: Optional[torch.Tensor] = None,
-                            order: Optional[torch.Tensor] = None, operand: str = "f32") -> torch.Tensor:
+                            order: Optional[torch.Tensor] = None, operand: str = "f32",
+                            group_ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`group_ws`: workspace from group_sum_prepare whose header already holds max|dy| (left there by bn_backward)."""
         dy = _need(dy, torch.float32, "grad_out")
         weight = _need(weight, torch.float32, "weight")
         tbl = _need(tbl, torch.int32, "pair table")
@@ -216,9 +218,10 @@ class HipBackend:
             rep = _need(rep, torch.int32, "rep")
             grp = torch.empty_like(dy)
             gws_bytes = self.lib.vc_group_sum_workspace_bytes(dy.shape[0], cout)
-            gws = torch.empty((gws_bytes,), dtype=torch.uint8, device=dy.device)
-            check(self.lib.vc_group_sum(_ptr(dy), _ptr(rep), dy.shape[0], cout, _ptr(grp), _ptr(gws), gws_bytes, _stream()),
-                  "vc_group_sum")
+            gws = group_ws if group_ws is not None else torch.empty((gws_bytes,), dtype=torch.uint8, device=dy.device)
+            assert gws.numel() >= gws_bytes
+            check(self.lib.vc_group_sum(_ptr(dy), _ptr(rep), dy.shape[0], cout, _ptr(grp), _ptr(gws), gws_bytes,
+                                        1 if group_ws is not None else 0, _stream()), "vc_group_sum")
             src, src_centre = grp, dy
         rec = self._trace_open(tbl, dy.shape[0], cout, cin) if self._traced("bwd", cout, cin) else None
         check(self.lib.vc_conv_backward_input(_ptr(src), _ptr(src_centre), dy.shape[0], _ptr(tbl), n_in, kv, _ptr(weight),
@@ -425,7 +428,15 @@ class HipBackend:
                                         1 if relu else 0, _ptr(out), out.shape[1], out_col0, st), "vc_bn_apply_relu")
         return out, mean, var
 
-    def bn_backward(self, x, dy, dy_col0, mean, var, gamma, beta, eps: float, relu: bool):
+    def group_sum_prepare(self, n: int, c: int, device) -> torch.Tensor:
+        """Zeroed group-sum workspace; hand it to bn_backward(absmax_ws=...) and then to conv_backward_input(group_ws=...)."""
+        nbytes = self.lib.vc_group_sum_workspace_bytes(n, c)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        check(self.lib.vc_group_sum_prepare(_ptr(ws), nbytes, n, c, _stream()), "vc_group_sum_prepare")
+        return ws
+
+    def bn_backward(self, x, dy, dy_col0, mean, var, gamma, beta, eps: float, relu: bool,
+                    absmax_ws: Optional[torch.Tensor] = None):
         x = _need(x, torch.float32, "features")
         dy = _need(dy, torch.float32, "grad_out")
         n, c = x.shape
@@ -437,5 +448,5 @@ class HipBackend:
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
         check(self.lib.vc_bn_relu_backward(_ptr(x), _ptr(dy), dy.shape[1], dy_col0, n, c, _ptr(mean), _ptr(var), _ptr(gamma),
                                            _ptr(beta), float(eps), 1 if relu else 0, _ptr(dx), _ptr(dgamma), _ptr(dbeta),
-                                           _ptr(ws), ws_bytes, _stream()), "vc_bn_relu_backward")
+                                           _ptr(absmax_ws), _ptr(ws), ws_bytes, _stream()), "vc_bn_relu_backward")
         return dx, dgamma, dbeta

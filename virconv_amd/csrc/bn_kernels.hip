@@ -316,7 +316,9 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_pow2_kernel(const float* __rest
                                                              const float* __restrict__ mean, const float* __restrict__ var,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float eps, int relu, const float* __restrict__ sums,
-                                                             float* __restrict__ dx) {
+                                                             float* __restrict__ dx, unsigned* __restrict__ absmax_out) {
+  __shared__ float s_max[4];
+  float amax = 0.f;
   const int c4 = 1 << lg_c4, R = 256 >> lg_c4;
   const int cq = threadIdx.x & (c4 - 1), rt = threadIdx.x >> lg_c4;
   const float inv_n = 1.0f / (float)n;
@@ -354,8 +356,20 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_pow2_kernel(const float* __rest
       float d = ds[j];
       if (relu && !(xh * g[j] + bt[j] > 0.f)) d = 0.f;
       o[j] = g[j] * istd[j] * (d - s0[j] * inv_n - xh * s1[j] * inv_n);
+      amax = fmaxf(amax, fabsf(o[j]));
     }
     *reinterpret_cast<float4*>(dx + r * c + cq * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  // max |dx| of the whole tensor for the consumer's fixed-point group sum (saves it a pass over dx): one atomic per block
+  if (absmax_out != nullptr) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      amax = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+      if (amax > 0.f) atomicMax(absmax_out, __float_as_uint(amax));
+    }
   }
 }
 
@@ -442,7 +456,7 @@ int vc_bn_apply_relu(const float* x, int64_t n, int c, const float* mean, const 
 
 int vc_bn_relu_backward(const float* x, const float* dy, int dy_stride, int dy_col0, int64_t n, int c, const float* mean,
                         const float* var, const float* gamma, const float* beta, float eps, int relu, float* dx,
-                        float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream) {
+                        float* dgamma, float* dbeta, unsigned* absmax_out, void* ws, size_t ws_bytes, void* stream) {
   VC_REQUIRE(bn_c_ok(c), "vc_bn_relu_backward: unsupported channel count %d", c);
   VC_REQUIRE(dy_stride >= c && dy_stride % 4 == 0 && dy_col0 % 4 == 0 && dy_col0 + c <= dy_stride,
              "vc_bn_relu_backward: bad stride arguments");
@@ -463,8 +477,9 @@ int vc_bn_relu_backward(const float* x, const float* dy, int dy_stride, int dy_c
   if (lg >= 0) {
     const int rows_per_block = (256 >> lg) * kBnRowsPerThread;
     hipLaunchKernelGGL(bn_bwd_dx_pow2_kernel, dim3((unsigned)cdiv(n, rows_per_block)), dim3(256), 0, st, x, dy, dy_stride,
-                       dy_col0, n, c, lg, mean, var, gamma, beta, eps, relu, sums, dx);
+                       dy_col0, n, c, lg, mean, var, gamma, beta, eps, relu, sums, dx, absmax_out);
   } else {
+    VC_REQUIRE(absmax_out == nullptr, "vc_bn_relu_backward: absmax_out needs a power-of-two channel count");
     hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3((unsigned)cdiv(n * (c / 4), 256)), dim3(256), 0, st, x, dy, dy_stride,
                        dy_col0, n, c, mean, var, gamma, beta, eps, relu, sums, dx);
   }

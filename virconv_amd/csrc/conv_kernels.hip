@@ -1106,8 +1106,15 @@ size_t vc_group_sum_workspace_bytes(int64_t n, int c) {
   return (size_t)n * c * sizeof(long long) + 64;
 }
 
+int vc_group_sum_prepare(void* ws, size_t ws_bytes, int64_t n, int c, void* stream) {
+  VC_REQUIRE(n >= 0 && c > 0 && ws, "vc_group_sum_prepare: null/invalid argument");
+  if (ws_bytes < vc_group_sum_workspace_bytes(n, c)) { set_error("vc_group_sum_prepare: workspace too small"); return VC_ECAPACITY; }
+  VC_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)n * c * sizeof(long long) + 64, (hipStream_t)stream));
+  return VC_OK;
+}
+
 int vc_group_sum(const float* dy, const int32_t* rep, int64_t n, int c, float* dy_grp, void* ws, size_t ws_bytes,
-                 void* stream) {
+                 int prepared, void* stream) {
   VC_REQUIRE(n >= 0 && c > 0, "vc_group_sum: invalid argument");
   if (n == 0) return VC_OK;
   VC_REQUIRE(dy && rep && dy_grp && ws, "vc_group_sum: null argument");
@@ -1116,11 +1123,13 @@ int vc_group_sum(const float* dy, const int32_t* rep, int64_t n, int c, float* d
   unsigned* absmax = (unsigned*)ws;                 // [0..63] header, then the int64 accumulators
   long long* acc = (long long*)((char*)ws + 64);
   const int64_t total = n * c;
-  VC_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)total * sizeof(long long) + 64, st));
-  int64_t nb = cdiv(total, 256 * 16);
-  if (nb > 512) nb = 512;
-  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)nb), dim3(256), 0, st, dy, total, absmax);
-  VC_CHECK_LAUNCH("absmax_kernel");
+  if (!prepared) {  // prepared: vc_group_sum_prepare zeroed ws and the producer of dy (vc_bn_relu_backward) left max|dy| in it
+    VC_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)total * sizeof(long long) + 64, st));
+    int64_t nb = cdiv(total, 256 * 16);
+    if (nb > 512) nb = 512;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)nb), dim3(256), 0, st, dy, total, absmax);
+    VC_CHECK_LAUNCH("absmax_kernel");
+  }
   hipLaunchKernelGGL(group_sum_fixed_kernel, dim3((unsigned)cdiv(cdiv(n, kGsRows) * c, 256)), dim3(256), 0, st, dy, rep, n, c,
                      absmax, acc);
   VC_CHECK_LAUNCH("group_sum_fixed_kernel");

@@ -134,7 +134,8 @@ class SparseConvFunction(torch.autograd.Function):
         return dx, dw, None, None
 
 
-def _conv_backward(rb: "Rulebook", inverse: bool, features, weight, grad_out, need_dx: bool, need_dw: bool):
+def _conv_backward(rb: "Rulebook", inverse: bool, features, weight, grad_out, need_dx: bool, need_dw: bool,
+                   group_ws=None):
     """dX and dW of one sparse conv.  dW and dX are independent and both latency-bound: dW runs on a side stream
     underneath dX and is joined before returning (autograd / DDP hooks only ever see completed gradients)."""
     be = get_backend()
@@ -155,7 +156,7 @@ def _conv_backward(rb: "Rulebook", inverse: bool, features, weight, grad_out, ne
                                         operand=MFMA_OPERAND)
         elif rb.kind == "subm":
             dx = be.conv_backward_input(grad_out, weight, rb.pair_fwd, rb.n_in, mirror=True, centre=rb.centre, rep=rb.rep,
-                                        order=rb.order_bwd, operand=MFMA_OPERAND)
+                                        order=rb.order_bwd, operand=MFMA_OPERAND, group_ws=group_ws)
         else:
             dx = be.conv_backward_input(grad_out, weight, rb.pair_bwd, rb.n_in, mirror=False, order=rb.order_bwd,
                                         operand=MFMA_OPERAND)
@@ -211,8 +212,16 @@ class ConvBNReLUFunction(torch.autograd.Function):
         x, weight, y_raw, mean, var, gamma, beta = ctx.saved_tensors
         eps, relu = ctx.cfg
         wide, col0 = _as_wide_rows(grad_out)
-        d_raw, dgamma, dbeta = be.bn_backward(y_raw, wide, col0, mean, var, gamma, beta, eps, relu)
-        dx, dw = _conv_backward(ctx.rb, ctx.inverse, x, weight, d_raw, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        rb, gws = ctx.rb, None
+        if (rb.rep is not None and not ctx.inverse and rb.kind == "subm" and ctx.needs_input_grad[0]
+                and hasattr(be, "group_sum_prepare") and y_raw.is_cuda
+                and (y_raw.shape[1] & (y_raw.shape[1] - 1)) == 0):
+            # duplicate-pixel conv: its backward group-sums d_raw in fixed point and needs max|d_raw|; the BN backward
+            # kernel that writes d_raw leaves it in the (pre-zeroed) group-sum workspace: one pass over d_raw less
+            gws = be.group_sum_prepare(y_raw.shape[0], y_raw.shape[1], y_raw.device)
+        d_raw, dgamma, dbeta = be.bn_backward(y_raw, wide, col0, mean, var, gamma, beta, eps, relu, absmax_ws=gws)
+        dx, dw = _conv_backward(rb, ctx.inverse, x, weight, d_raw, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                group_ws=gws)
         return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
