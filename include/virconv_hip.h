@@ -173,6 +173,9 @@ int vc_project_uv(const int32_t* indices, int64_t n, const float* params, int ba
 int vc_gather_rows(const float* features, const int32_t* indices, int c, int icols, const int64_t* keep,
                    int64_t n_keep, float* features_out, int32_t* indices_out, void* stream);
 /* grad_in[keep[j], :] = grad_out[j, :], other rows zero (keep indices are unique).                              */
+/* keep[i] = P_seed(i), i < n_keep, for a pseudo-random permutation P_seed of [0, n) (4-round Feistel + cycle walking): the
+ * rows layer_voxel_discard keeps, `perm[:n_keep]` (spconv_backbone.py:137-141), without sorting n random keys.          */
+int vc_random_keep(int64_t n, int64_t n_keep, uint64_t seed, int64_t* keep, void* stream);
 int vc_scatter_rows(const float* grad_out, int c, const int64_t* keep, int64_t n_keep, int64_t n_in,
                     float* grad_in, void* stream);
 

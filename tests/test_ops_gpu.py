@@ -497,3 +497,34 @@ def test_conv_affine_epilogue_equals_conv_then_eval_batchnorm(hip_backend, cin, 
     if relu:
         exact = exact.clamp_min(0)
     assert float((fused.double() - exact).abs().max()) <= TOL * max(1.0, float(exact.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------ random keep (layer discard)
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 1000, 65536, 65537, 310351])
+def test_random_keep_is_a_permutation_prefix(hip_backend, n):
+    full = hip_backend.random_keep(n, n, 1234, "cuda").cpu().numpy()
+    np.testing.assert_array_equal(np.sort(full), np.arange(n))                       # a bijection of range(n)
+    n_keep = int(n * 0.9)
+    part = hip_backend.random_keep(n, n_keep, 1234, "cuda").cpu().numpy()
+    np.testing.assert_array_equal(part, full[:n_keep])                                # any prefix of the SAME permutation
+    again = hip_backend.random_keep(n, n_keep, 1234, "cuda").cpu().numpy()
+    np.testing.assert_array_equal(part, again)                                        # a function of the seed only
+    if n > 100:
+        other = hip_backend.random_keep(n, n, 99, "cuda").cpu().numpy()
+        assert (other != full).mean() > 0.9
+        # rough uniformity: the kept rows of a 50 % prefix are spread over the index range, not clustered
+        half = full[: n // 2]
+        quart = np.histogram(half, bins=4, range=(0, n))[0] / (n // 2)
+        assert np.all(np.abs(quart - 0.25) < 0.05), quart
+        assert abs(np.corrcoef(np.arange(n), full)[0, 1]) < 0.05                      # no trend between position and value
+
+
+def test_layer_discard_draws_through_the_fast_generator_and_follows_the_torch_seed(hip_backend):
+    from virconv_amd import backbone
+    torch.manual_seed(5)
+    a = backbone.draw_random_keep(5000, 4500, "cuda")
+    torch.manual_seed(5)
+    b = backbone.draw_random_keep(5000, 4500, "cuda")
+    c = backbone.draw_random_keep(5000, 4500, "cuda")
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert a.dtype == torch.int64 and a.unique().numel() == 4500 and int(a.max()) < 5000 and int(a.min()) >= 0

@@ -1,9 +1,7 @@
 mkdir -p gpurun_out/ab
-run() { tag=$1; shift; env "$@" python bench.py --steps 40 --warmup 12 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$tag', d['ms_per_step'], d['config'].get('cpu_affinity'))" >> gpurun_out/ab/res.txt; }
-python -c "import os; a=sorted(os.sched_getaffinity(0)); print('affinity', len(a), a[:4], a[-4:])" >> gpurun_out/ab/res.txt
-run first_bind VIRCONV_NUMA_BIND=1
-run second_nobind VIRCONV_NUMA_BIND=0
-run third_bind VIRCONV_NUMA_BIND=1
-run fourth_nobind VIRCONV_NUMA_BIND=0
-run fifth_bind VIRCONV_NUMA_BIND=1
-cat gpurun_out/ab/res.txt
+timeout 900 python -m pytest tests -m gpu -q -x > gpurun_out/ab/t.log 2>&1
+run() { tag=$1; shift; env "$@" python bench.py --steps 40 --warmup 12 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$tag', d['ms_per_step'])" >> gpurun_out/ab/res.txt; }
+run a X=1
+run b X=1
+run c X=1
+tail -3 gpurun_out/ab/t.log; cat gpurun_out/ab/res.txt

@@ -41,6 +41,7 @@ SIGNATURES = {
     "vc_conv_stats_partial_floats": (_SZ, [_I64, _I]),
     "vc_conv_forward_epilogue": (_I, [_P, _I64, _P, _I64, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _F, _I, _P, _P]),
     "vc_bn_stats_from_partial": (_I, [_P, _I64, _I64, _I, _P, _P, _P, _P, _P, _F, _P]),
+    "vc_random_keep": (_I, [_I64, _I64, C.c_uint64, _P, _P]),
     "vc_row_order": (_I, [_P, _I64, _I, _P, _I, _I, _P, _P]),
     "vc_conv_backward_weight_workspace_bytes": (_SZ, [_I64, _I, _I, _I]),
     "vc_conv_backward_weight": (_I, [_P, _P, _P, _I64, _I, _I, _I, _I, _P, _P, _SZ, _P]),

@@ -22,8 +22,13 @@ import numpy as np
 import torch
 from torch import nn
 
+import os
+
 from . import ops
 from . import spconv
+
+# layer discard: draw the kept rows with vc_random_keep (point-wise pseudo-random permutation) instead of torch.randperm
+FAST_RANDOM_KEEP = os.environ.get("VIRCONV_FAST_RANDOM_KEEP", "1") != "0"
 
 
 def _cfg_get(cfg, key, default=None):
@@ -73,6 +78,16 @@ def post_act_block2d(in_channels, out_channels, kernel_size, indice_key=None, st
     return spconv.SparseSequential(conv, norm_fn(out_channels), relu)
 
 
+def draw_random_keep(n: int, n_keep: int, device) -> torch.Tensor:
+    """perm[:n_keep] of a random permutation of the n rows.  On the GPU the permutation is evaluated point-wise by
+    vc_random_keep, seeded from torch's CPU generator (so torch.manual_seed reproduces it); torch.randperm otherwise."""
+    be = ops.get_backend()
+    if FAST_RANDOM_KEEP and torch.device(device).type == "cuda" and hasattr(be, "random_keep"):
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        return be.random_keep(n, n_keep, seed, device)
+    return torch.randperm(n, device=device)[:n_keep]
+
+
 def layer_voxel_discard(sp: spconv.SparseConvTensor, rate: float, keep: Optional[torch.Tensor] = None):
     """StVD layer discard (spconv_backbone.py:134-147), spconv-1.x semantics: keep rows ``perm[:int(N*(1-rate))]`` in
     permuted order.  ``keep`` injects the permutation prefix (tests / benchmarks); otherwise a device randperm is drawn
@@ -82,7 +97,7 @@ def layer_voxel_discard(sp: spconv.SparseConvTensor, rate: float, keep: Optional
     n = sp.features.shape[0]
     n_keep = int(n * (1 - rate))
     if keep is None:
-        keep = torch.randperm(n, device=sp.features.device)[:n_keep]
+        keep = draw_random_keep(n, n_keep, sp.features.device)
     else:
         keep = keep.to(sp.features.device)
         assert keep.shape[0] == n_keep, f"injected keep has {keep.shape[0]} rows, expected int({n}*(1-{rate}))={n_keep}"
@@ -269,7 +284,7 @@ def _draw_keep(rate, n, batch_dict, tag, device):
         keep = inj[tag].to(device=device, dtype=torch.int64)
         assert keep.shape[0] == n_keep, f"injected keep has {keep.shape[0]} rows, expected {n_keep}"
         return keep
-    return torch.randperm(n, device=device)[:n_keep]
+    return draw_random_keep(n, n_keep, device)
 
 
 def _plan_nrconv_chain(blocks, in_idx, shape, batch_size, calib, trans_param, discard_tags, rate, batch_dict):

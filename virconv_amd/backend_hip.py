@@ -347,6 +347,12 @@ class HipBackend:
                                       _stream()), "vc_gather_rows")
         return fo, io
 
+    def random_keep(self, n: int, n_keep: int, seed: int, device) -> torch.Tensor:
+        """perm[:n_keep] of a pseudo-random permutation of range(n), evaluated point-wise on the device (vc_random_keep)."""
+        keep = torch.empty((n_keep,), dtype=torch.int64, device=device)
+        check(self.lib.vc_random_keep(n, n_keep, seed & 0xFFFFFFFFFFFFFFFF, _ptr(keep), _stream()), "vc_random_keep")
+        return keep
+
     def scatter_rows(self, grad_out: torch.Tensor, keep: torch.Tensor, n_in: int) -> torch.Tensor:
         grad_out = _need(grad_out, torch.float32, "grad_out")
         keep = _need(keep, torch.int64, "keep")

@@ -469,6 +469,40 @@ __global__ void __launch_bounds__(256) scatter_rows_kernel(const float* __restri
   reinterpret_cast<float4*>(gin)[keep[j] * c4 + q] = reinterpret_cast<const float4*>(gout)[j * c4 + q];
 }
 
+// ------------------------------------------------------------------------------------------ K2 random keep (layer discard)
+// layer_voxel_discard keeps perm[:n_keep] of a random permutation of the N rows (spconv_backbone.py:134-147).  torch.randperm
+// on the device is a radix sort of N random keys (9 launches, 0.1 ms for 3e5 rows, three times per step); a pseudo-random
+// PERMUTATION can be evaluated point-wise instead: a 4-round Feistel network over 2h bits (2^(2h) >= N, < 4N) is a bijection
+// of [0, 2^(2h)), and cycle-walking (re-encrypt until the value is < N) restricts it to a bijection of [0, N).  keep[i] is
+// that permutation at i: distinct rows, any prefix length, one thread per kept row, no sort.
+__device__ __forceinline__ uint32_t feistel_round(uint32_t r, uint32_t key) {
+  uint32_t v = r ^ key;
+  v ^= v >> 16; v *= 0x85ebca6bu; v ^= v >> 13; v *= 0xc2b2ae35u; v ^= v >> 16;
+  return v;
+}
+
+__global__ void __launch_bounds__(256) random_keep_kernel(int64_t n, int64_t n_keep, uint64_t seed, int half_bits,
+                                                          int64_t* __restrict__ keep) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_keep) return;
+  const uint32_t mask = (half_bits >= 32) ? 0xffffffffu : ((1u << half_bits) - 1u);
+  uint32_t k[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) k[r] = (uint32_t)(mix64(seed + 0x9e3779b97f4a7c15ULL * (uint64_t)(r + 1)) >> 16);
+  uint64_t x = (uint64_t)i;
+  do {
+    uint32_t l = (uint32_t)(x >> half_bits) & mask, rr = (uint32_t)x & mask;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t t = l ^ (feistel_round(rr, k[r]) & mask);
+      l = rr;
+      rr = t;
+    }
+    x = ((uint64_t)l << half_bits) | rr;
+  } while (x >= (uint64_t)n);
+  keep[i] = (int64_t)x;
+}
+
 // ------------------------------------------------------------------------------------------ K10 dense
 // Block = 64 rows x all channels.  The rows are read (written) as whole coalesced rows through an LDS tile, each row's
 // dense base offset is computed once, and every wave instruction touches 64 rows of ONE channel plane (x-adjacent rows are
@@ -998,6 +1032,19 @@ int vc_row_order(const int32_t* tbl, int64_t n, int kv, const int32_t* rep, int 
       return VC_EINVAL;
   }
   VC_CHECK_LAUNCH("row_order_kernel");
+  return VC_OK;
+}
+
+int vc_random_keep(int64_t n, int64_t n_keep, uint64_t seed, int64_t* keep, void* stream) {
+  VC_REQUIRE(n >= 0 && n_keep >= 0 && n_keep <= n, "vc_random_keep: need 0 <= n_keep <= n");
+  if (n_keep == 0) return VC_OK;
+  VC_REQUIRE(keep, "vc_random_keep: null argument");
+  int half = 1;
+  while (half < 31 && (1ULL << (2 * half)) < (uint64_t)n) ++half;
+  VC_REQUIRE((1ULL << (2 * half)) >= (uint64_t)n, "vc_random_keep: n too large");
+  hipLaunchKernelGGL(random_keep_kernel, dim3((unsigned)cdiv(n_keep, 256)), dim3(256), 0, (hipStream_t)stream, n, n_keep,
+                     seed, half, keep);
+  VC_CHECK_LAUNCH("random_keep_kernel");
   return VC_OK;
 }
 
