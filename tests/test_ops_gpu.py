@@ -528,3 +528,34 @@ def test_layer_discard_draws_through_the_fast_generator_and_follows_the_torch_se
     c = backbone.draw_random_keep(5000, 4500, "cuda")
     assert torch.equal(a, b) and not torch.equal(a, c)
     assert a.dtype == torch.int64 and a.unique().numel() == 4500 and int(a.max()) < 5000 and int(a.min()) >= 0
+
+
+# ------------------------------------------------------------------------------------------------ fallback kernel
+@pytest.mark.parametrize("cin,cout", [(8, 8), (16, 32), (64, 32), (64, 64)])
+def test_fallback_gather_gemm_kernel_matches_the_default_one(hip_backend, cin, cout):
+    """gather_gemm_kernel (v1: per-wave loads, no LDS staging) is what runs when a source exceeds 2 GiB (32-bit buffer
+    offsets) or KV > 32.  Forced here through vc_debug_set: same k order and MFMA sequence => bit-identical results."""
+    rng = np.random.default_rng(cin + cout)
+    idx = _indices3(41, 4000)
+    n = idx.shape[0]
+    it = torch.from_numpy(idx).cuda()
+    x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.standard_normal((cout, 3, 3, 3, cin)) / 10).astype(np.float32)).cuda()
+    g = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32)).cuda()
+    pair, _ = hip_backend.subm_rulebook(it, SHAPE3, (3, 3, 3), (1, 1, 1), want_rep=False)
+    oi, _, pf, pb = hip_backend.sparse_rulebook(it, SHAPE3, 2, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1))
+    go = torch.from_numpy(rng.standard_normal((oi.shape[0], cout)).astype(np.float32)).cuda()
+
+    def run():
+        return (hip_backend.conv_forward(x, w, pair), hip_backend.conv_backward_input(g, w, pair, n, mirror=True),
+                hip_backend.conv_forward(x, w, pf), hip_backend.conv_backward_input(go, w, pb, n, mirror=False))
+
+    ref = run()
+    assert hip_backend.lib.vc_debug_set(b"conv_variant", 1) == 0
+    try:
+        assert not hip_backend.conv_epilogue_supported(n, cin, cout, 27)      # epilogues exist for the default kernel only
+        alt = run()
+    finally:
+        assert hip_backend.lib.vc_debug_set(b"conv_variant", 2) == 0
+    for a, b in zip(ref, alt):
+        assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))
