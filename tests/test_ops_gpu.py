@@ -559,3 +559,28 @@ def test_fallback_gather_gemm_kernel_matches_the_default_one(hip_backend, cin, c
         assert hip_backend.lib.vc_debug_set(b"conv_variant", 2) == 0
     for a, b in zip(ref, alt):
         assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))
+
+
+@pytest.mark.parametrize("win", [1024, 2048, 4096])
+@pytest.mark.parametrize("distinct", [1, 5, 100, 128, 129, 400])
+def test_row_order_counting_and_bitonic_paths_agree_with_a_stable_sort(hip_backend, win, distinct):
+    """Windows with <= 128 distinct masks take the ballot/prefix counting sort, the others the LDS bitonic network; both must
+    equal numpy's stable argsort of the masks inside each window (synthetic tables with a controlled number of masks)."""
+    rng = np.random.default_rng(distinct)
+    n, kv = 3 * win + 77, 27
+    palette = rng.choice(1 << 20, size=distinct, replace=False).astype(np.int64)
+    masks = palette[rng.integers(0, distinct, n)]
+    pair = np.where((masks[None, :] >> np.arange(kv)[:, None]) & 1, 7, -1).astype(np.int32)
+    order = hip_backend.row_order(torch.from_numpy(pair).cuda(), window=win).cpu().numpy()
+    want = np.concatenate([s + np.argsort(masks[s:s + win], kind="stable") for s in range(0, n, win)])
+    np.testing.assert_array_equal(order, want.astype(np.int32))
+
+
+def test_row_order_of_a_strided_backward_table_is_a_stable_mask_sort(hip_backend):
+    idx = _indices3(51, 6000)
+    _, _, _, pb = hip_backend.sparse_rulebook(torch.from_numpy(idx).cuda(), SHAPE3, 2, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1))
+    m = _masks(pb.cpu().numpy())
+    assert len(np.unique(m)) < 128                       # parity classes (+ boundaries): the counting path
+    order = hip_backend.row_order(pb, window=2048).cpu().numpy()
+    want = np.concatenate([s + np.argsort(m[s:s + 2048], kind="stable") for s in range(0, m.shape[0], 2048)])
+    np.testing.assert_array_equal(order, want.astype(np.int32))

@@ -676,43 +676,147 @@ __global__ void vox_count_kernel(const int32_t* total, int max_voxels, int32_t* 
 // union is 21 offsets against 15 per row for the stage-3 SubM convs, 18 against 5 for the strided convs and 27 against
 // 3.4 for their backward.  This kernel sorts the rows of each window of WIN consecutive rows by their active-offset
 // bit mask (stable: ties keep ascending row order), in LDS, one block per window; windows keep the gathers L2-local.
+//
+// Two paths, chosen per window.  COUNTING path (the common one: the strided backward tables have a handful of distinct masks
+// per window -- parity classes of the input coordinate): the distinct masks go into a 128-slot LDS hash set, each gets its
+// rank by value, every 64-row chunk counts its rows per class with ballots (the lead lane of a class broadcasts it, the
+// lanes of the class take popcount-below as their rank inside the chunk), an exclusive scan over [class][chunk] gives the
+// bases, and every row writes itself to base + rank: a stable counting sort with ~10 block barriers.  BITONIC path (more
+// than 128 distinct masks in the window, or KV = 32): the 66-stage LDS bitonic network on (mask << 32 | row) keys.
+static constexpr int kOrdSlots = 128;
+static constexpr unsigned kOrdEmpty = 0xffffffffu;
+
 template <int WIN, int THREADS>
 __global__ void __launch_bounds__(THREADS) row_order_kernel(const int32_t* __restrict__ tbl, int64_t n, int kv,
                                                             const int32_t* __restrict__ rep, int centre,
                                                             int32_t* __restrict__ order) {
-  __shared__ unsigned long long keys[WIN];
+  static_assert(WIN == 4 * THREADS && THREADS % 64 == 0, "4 rows per thread");
+  constexpr int CH = WIN / 64;                        // 64-row chunks per window
+  constexpr int NCNT = kOrdSlots * CH;                // [class][chunk] counters; == 8 * THREADS
+  __shared__ unsigned long long raw[WIN];             // bitonic keys, or the counters of the counting path (NCNT ints)
+  __shared__ unsigned s_hash[kOrdSlots];
+  __shared__ int s_rank[kOrdSlots];
+  __shared__ int s_wave[THREADS / 64];
+  __shared__ int s_overflow;
+  int* cnt = reinterpret_cast<int*>(raw);
   const int64_t base = (int64_t)blockIdx.x * WIN;
-  for (int j = threadIdx.x; j < WIN; j += THREADS) {
-    const int64_t r = base + j;
-    unsigned long long key = ~0ULL;  // padding sorts last
-    if (r < n) {
-      unsigned m = 0u;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  unsigned m[4];
+  bool valid[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t r = base + u * THREADS + threadIdx.x;
+    valid[u] = r < n;
+    m[u] = 0u;
+    if (valid[u]) {
       if (rep != nullptr && rep[r] != (int32_t)r) {
-        m = (centre >= 0) ? (1u << centre) : 0u;     // duplicate-pixel rows only ever use the centre offset
+        m[u] = (centre >= 0) ? (1u << centre) : 0u;   // duplicate-pixel rows only ever use the centre offset
       } else {
-        for (int k = 0; k < kv; ++k) m |= (tbl[(int64_t)k * n + r] >= 0 ? 1u : 0u) << k;
+        for (int k = 0; k < kv; ++k) m[u] |= (tbl[(int64_t)k * n + r] >= 0 ? 1u : 0u) << k;
       }
-      key = ((unsigned long long)m << 32) | (unsigned)j;
     }
-    keys[j] = key;
+  }
+  for (int j = threadIdx.x; j < kOrdSlots; j += THREADS) s_hash[j] = kOrdEmpty;
+  if (threadIdx.x == 0) s_overflow = (kv >= 32) ? 1 : 0;   // a full 32-bit mask would collide with the empty marker
+  __syncthreads();
+  int slot[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    slot[u] = -1;
+    if (!valid[u] || kv >= 32) continue;
+    unsigned h = (m[u] * 0x9e3779b1u) >> 25;          // 7 bits
+    for (int probe = 0; probe < kOrdSlots; ++probe) {
+      const unsigned old = atomicCAS(&s_hash[h], kOrdEmpty, m[u]);
+      if (old == kOrdEmpty || old == m[u]) { slot[u] = (int)h; break; }
+      h = (h + 1) & (kOrdSlots - 1);
+    }
+    if (slot[u] < 0) s_overflow = 1;                  // benign race: every writer stores 1
   }
   __syncthreads();
-  for (int size = 2; size <= WIN; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+
+  if (s_overflow) {  // ---------------------------------------------------------------- bitonic path (block-uniform)
 #pragma unroll
-      for (int t = threadIdx.x; t < WIN / 2; t += THREADS) {
-        const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
-        const int hi = lo | stride;
-        const bool up = (lo & size) == 0;
-        const unsigned long long a = keys[lo], b = keys[hi];
-        if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+    for (int u = 0; u < 4; ++u) {
+      const int j = u * THREADS + threadIdx.x;
+      raw[j] = valid[u] ? (((unsigned long long)m[u] << 32) | (unsigned)j) : ~0ULL;   // padding sorts last
+    }
+    __syncthreads();
+    for (int size = 2; size <= WIN; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+        for (int t = threadIdx.x; t < WIN / 2; t += THREADS) {
+          const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+          const int hi = lo | stride;
+          const bool up = (lo & size) == 0;
+          const unsigned long long a = raw[lo], b = raw[hi];
+          if ((a > b) == up) { raw[lo] = b; raw[hi] = a; }
+        }
+        __syncthreads();
       }
-      __syncthreads();
+    }
+    for (int j = threadIdx.x; j < WIN; j += THREADS) {
+      const int64_t r = base + j;
+      if (r < n) order[r] = (int32_t)(base + (int64_t)(raw[j] & 0xffffffffULL));
+    }
+    return;
+  }
+
+  // ---------------------------------------------------------------------------------- counting path
+  for (int j = threadIdx.x; j < kOrdSlots; j += THREADS) {   // rank of every distinct mask by value
+    const unsigned v = s_hash[j];
+    int rk = -1;
+    if (v != kOrdEmpty) {
+      rk = 0;
+      for (int t = 0; t < kOrdSlots; ++t) rk += (s_hash[t] < v) ? 1 : 0;   // empty slots are 0xffffffff: never smaller
+    }
+    s_rank[j] = rk;
+  }
+  for (int j = threadIdx.x; j < NCNT; j += THREADS) cnt[j] = 0;
+  __syncthreads();
+  int cls[4], rin[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    cls[u] = valid[u] ? s_rank[slot[u]] : -1;
+    rin[u] = 0;
+    const int chunk = u * (THREADS / 64) + wave;      // rows u*THREADS + wave*64 .. +63: 64 consecutive rows
+    unsigned long long remaining = __ballot(valid[u]);
+    while (remaining) {
+      const int lead = __ffsll((long long)remaining) - 1;
+      const int c = __shfl(cls[u], lead, 64);
+      const unsigned long long mm = __ballot(valid[u] && cls[u] == c);
+      if (valid[u] && cls[u] == c) rin[u] = __popcll(mm & ((1ULL << lane) - 1ULL));
+      if (lane == lead) cnt[c * CH + chunk] = __popcll(mm);
+      remaining &= ~mm;
     }
   }
-  for (int j = threadIdx.x; j < WIN; j += THREADS) {
-    const int64_t r = base + j;
-    if (r < n) order[r] = (int32_t)(base + (int64_t)(keys[j] & 0xffffffffULL));
+  __syncthreads();
+  {  // exclusive scan of cnt[0 .. NCNT) in place: 8 consecutive entries per thread, wave scan, cross-wave offsets
+    const int e0 = threadIdx.x * 8;
+    int v[8], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] = cnt[e0 + j]; sum += v[j]; }
+    int inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += o;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_wave[w];
+    int run = woff + inc - sum;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { cnt[e0 + j] = run; run += v[j]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (!valid[u]) continue;
+    const int chunk = u * (THREADS / 64) + wave;
+    const int pos = cnt[cls[u] * CH + chunk] + rin[u];
+    order[base + pos] = (int32_t)(base + u * THREADS + threadIdx.x);
   }
 }
 
