@@ -713,7 +713,13 @@ __global__ void __launch_bounds__(THREADS) row_order_kernel(const int32_t* __res
       if (rep != nullptr && rep[r] != (int32_t)r) {
         m[u] = (centre >= 0) ? (1u << centre) : 0u;   // duplicate-pixel rows only ever use the centre offset
       } else {
-        for (int k = 0; k < kv; ++k) m[u] |= (tbl[(int64_t)k * n + r] >= 0 ? 1u : 0u) << k;
+        for (int k0 = 0; k0 < kv; k0 += 9) {          // 9 table entries in flight per trip (one dependent load per trip made
+          int v[9];                                   // the mask build the longest part of this kernel)
+#pragma unroll
+          for (int j = 0; j < 9; ++j) v[j] = (k0 + j < kv) ? tbl[(int64_t)(k0 + j) * n + r] : -1;
+#pragma unroll
+          for (int j = 0; j < 9; ++j) m[u] |= (v[j] >= 0 ? 1u : 0u) << ((k0 + j) & 31);
+        }
       }
     }
   }
