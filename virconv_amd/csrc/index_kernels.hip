@@ -726,18 +726,32 @@ __global__ void __launch_bounds__(THREADS) row_order_kernel(const int32_t* __res
   for (int j = threadIdx.x; j < kOrdSlots; j += THREADS) s_hash[j] = kOrdEmpty;
   if (threadIdx.x == 0) s_overflow = (kv >= 32) ? 1 : 0;   // a full 32-bit mask would collide with the empty marker
   __syncthreads();
+  // insert the distinct masks: per 64-row chunk the lanes holding the same mask elect a leader (ballot loop), only the leader
+  // does the LDS CAS and broadcasts the slot -- thousands of same-address LDS atomics per window were the longest part
   int slot[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     slot[u] = -1;
-    if (!valid[u] || kv >= 32) continue;
-    unsigned h = (m[u] * 0x9e3779b1u) >> 25;          // 7 bits
-    for (int probe = 0; probe < kOrdSlots; ++probe) {
-      const unsigned old = atomicCAS(&s_hash[h], kOrdEmpty, m[u]);
-      if (old == kOrdEmpty || old == m[u]) { slot[u] = (int)h; break; }
-      h = (h + 1) & (kOrdSlots - 1);
+    if (kv >= 32) continue;
+    unsigned long long remaining = __ballot(valid[u]);
+    while (remaining) {
+      const int lead = __ffsll((long long)remaining) - 1;
+      const unsigned mv = (unsigned)__shfl((int)m[u], lead, 64);
+      const unsigned long long same = __ballot(valid[u] && m[u] == mv);
+      int found = -1;
+      if (lane == lead) {
+        unsigned h = (mv * 0x9e3779b1u) >> 25;        // 7 bits
+        for (int probe = 0; probe < kOrdSlots; ++probe) {
+          const unsigned old = atomicCAS(&s_hash[h], kOrdEmpty, mv);
+          if (old == kOrdEmpty || old == mv) { found = (int)h; break; }
+          h = (h + 1) & (kOrdSlots - 1);
+        }
+        if (found < 0) s_overflow = 1;                // benign race: every writer stores 1
+      }
+      found = __shfl(found, lead, 64);
+      if (valid[u] && m[u] == mv) slot[u] = found;
+      remaining &= ~same;
     }
-    if (slot[u] < 0) s_overflow = 1;                  // benign race: every writer stores 1
   }
   __syncthreads();
 
