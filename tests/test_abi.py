@@ -57,6 +57,40 @@ def test_host_side_queries_and_argument_validation_without_gpu():
         _lib.check(st, "vc_gather_rows")
 
 
+def test_new_entry_points_validate_their_arguments_without_gpu():
+    """Every check below fails BEFORE any HIP call, so it runs in the build container (no device)."""
+    import ctypes
+    lib = _lib.load()
+    dummy = ctypes.c_void_p(64)  # never dereferenced on the host
+    shp = _lib.i32arr([21, 400, 352])
+    # row order: window and kernel-volume limits
+    assert lib.vc_row_order(dummy, 10, 27, None, -1, 512, dummy, None) == _lib.VC_EINVAL and b"window" in lib.vc_last_error()
+    assert lib.vc_row_order(dummy, 10, 33, None, -1, 1024, dummy, None) == _lib.VC_EINVAL
+    assert lib.vc_row_order(None, 0, 27, None, -1, 1024, None, None) == _lib.VC_OK          # empty table: nothing to do
+    # conv epilogues / operand types
+    assert lib.vc_conv_forward(dummy, 4, dummy, 4, 27, dummy, 8, 8, None, 7, dummy, None) == _lib.VC_EINVAL
+    assert b"operand_type" in lib.vc_last_error()
+    assert lib.vc_conv_forward_epilogue(dummy, 4, dummy, 4, 27, dummy, 8, 8, None, 5, None, None, None, None, None, 0.0, 0,
+                                        dummy, None) == _lib.VC_EINVAL
+    assert lib.vc_conv_forward_epilogue(dummy, 4, dummy, 4, 27, dummy, 8, 8, None, 1, None, None, None, None, None, 0.0, 0,
+                                        dummy, None) == _lib.VC_EINVAL and b"stats_partial" in lib.vc_last_error()
+    assert lib.vc_conv_epilogue_supported(1000, 64, 32, 27, 0) == 1 and lib.vc_conv_epilogue_supported(1000, 64, 32, 27, 1) == 0
+    assert lib.vc_conv_epilogue_supported(1 << 24, 64, 32, 27, 0) == 0                      # source >= 2 GiB: fallback kernel
+    assert lib.vc_conv_stats_partial_floats(130, 32) == 3 * 2 * 32
+    # RoI grid pooling
+    assert lib.vc_voxel_index_workspace_bytes(1000, 2, shp) > 2 * 21 * 400 * 352 // 8
+    assert lib.vc_voxel_query(dummy, 1 << 30, 10, 2, shp, dummy, dummy, dummy, 5, 1, 1, 32, 1.0, 4, dummy, dummy, None) == _lib.VC_EINVAL
+    assert b"x_range" in lib.vc_last_error()
+    assert lib.vc_voxel_query(dummy, 16, 10, 2, shp, dummy, dummy, dummy, 5, 1, 1, 1, 1.0, 4, dummy, dummy, None) == _lib.VC_ECAPACITY
+    assert lib.vc_group_points(1, 5, 0, 4, dummy, dummy, dummy, dummy, dummy, None) == _lib.VC_EINVAL
+    # layer discard
+    assert lib.vc_random_keep(10, 11, 1, dummy, None) == _lib.VC_EINVAL
+    assert lib.vc_random_keep(10, 0, 1, None, None) == _lib.VC_OK
+    # group sum
+    assert lib.vc_group_sum_workspace_bytes(100, 16) == 100 * 16 * 8 + 64
+    assert lib.vc_group_sum_prepare(dummy, 8, 100, 16, None) == _lib.VC_ECAPACITY
+
+
 def test_product_has_no_cpu_path():
     import torch
     from virconv_amd.backend_hip import HipBackend
