@@ -199,6 +199,14 @@ int vc_voxelize_mean(const float* points, int64_t p, int f, const float* host_ra
                      int max_points, int max_voxels, int vfe_max_last, void* ws, size_t ws_bytes,
                      float* features, int32_t* coords, int32_t* num_points, int32_t* n_voxels_dev, void* stream);
 
+/* Un-fused form with the reference's exact return protocol: voxels (max_voxels, max_points, f) zero-padded, slot j = the
+ * j-th point (input order) of the cell; coords / num_points / *n_voxels_dev as above.  This is what
+ * Point2VoxelCPU3d.point_to_voxel hands to VoxelGeneratorWrapper.generate (data_processor.py:53-58), which MeanVFE then
+ * reduces (mean_vfe.py:39-49).  Same workspace as vc_voxelize_mean.                                                */
+int vc_voxelize(const float* points, int64_t p, int f, const float* host_range, const float* host_vsize,
+                int max_points, int max_voxels, void* ws, size_t ws_bytes, float* voxels, int32_t* coords,
+                int32_t* num_points, int32_t* n_voxels_dev, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ K11 BN(+ReLU)
  * Per-channel batch statistics over the N active rows and the fused normalise(+ReLU) pass -- the
  * nn.BatchNorm1d(eps=1e-3, momentum=0.01) + nn.ReLU that follow every conv (spconv_backbone.py:101-105,160).

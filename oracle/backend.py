@@ -137,6 +137,10 @@ class OracleBackend:
         feats = geometry.mean_vfe(vox, num, "max" if vfe_max_last else None)
         return torch.from_numpy(feats), torch.from_numpy(coords), torch.from_numpy(num)
 
+    def voxelize(self, points, pc_range, voxel_size, max_points, max_voxels):
+        vox, coords, num = geometry.voxelize(_np(points), voxel_size, pc_range, max_points, max_voxels)
+        return torch.from_numpy(vox), torch.from_numpy(coords), torch.from_numpy(num)
+
     # ------------------------------------------------------------------ BatchNorm(+ReLU)
     def bn_forward(self, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, out=None, out_col0=0,
                    num_batches_tracked=None):

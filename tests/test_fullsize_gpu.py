@@ -205,3 +205,164 @@ def test_fullsize_train_step_reduced_operands_within_declared_tolerance(hip_back
     b = torch.cat([g32[k].reshape(-1) for k in g32]).double()
     cos = float((a @ b) / (a.norm() * b.norm()))
     assert cos >= (0.99 if operand == "f16" else 0.9), cos
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Parity at the BENCHMARKED configuration (BASELINE configs[2] exactly as bench.py runs it: train mode, layer discard
+# `spconv1_inplace` 0.1 with injected keep indices, plan-ahead, fused conv+BN+ReLU nodes, full-size frames, bs 2):
+# HIP vs the CPU oracle -- indices bit-exact at every scale, features <= 1e-4, EVERY parameter gradient <= 1e-4 * max
+# with an element-wise atol/rtol check beside it.  spconv_backbone.py:609-699 (forward), :134-147 (layer discard).
+def _elementwise_close(a: np.ndarray, b: np.ndarray, rtol: float, atol: float):
+    """Element-wise |a - b| <= atol + rtol * |b| (what the max-normalised metric cannot see: small-magnitude channels)."""
+    bad = np.abs(a - b) > atol + rtol * np.abs(b)
+    return float(bad.mean()), float(np.abs(a - b).max())
+
+
+def _bench_loss(out, lw, mm=False):
+    loss = (out["encoded_spconv_tensor"].dense() * lw["dense"]).sum()
+    for name, t in out["multi_scale_3d_features"].items():
+        loss = loss + (t.features * lw[name]).sum()
+    if mm:
+        for name, t in out["multi_scale_3d_features_mm"].items():
+            loss = loss + (t.features * lw[name]).sum() * 0.5
+    return loss
+
+
+def _train_pass(model, batch, lw, mm=False):
+    model.zero_grad(set_to_none=True)
+    bd = dict(batch)
+    for k in ("voxel_features", "voxel_features_mm"):
+        if k in bd:
+            bd[k] = bd[k].clone()
+    out = model(bd)
+    loss = _bench_loss(out, lw, mm)
+    loss.backward()
+    res = {}
+    for name, t in out["multi_scale_3d_features"].items():
+        res[name] = (t.features.detach().cpu().numpy(), t.indices.cpu().numpy())
+    if mm:
+        for name, t in out["multi_scale_3d_features_mm"].items():
+            res["mm_" + name] = (t.features.detach().cpu().numpy(), t.indices.cpu().numpy())
+    t = out["encoded_spconv_tensor"]
+    res["out"] = (t.features.detach().cpu().numpy(), t.indices.cpu().numpy())
+    grads = {k: p.grad.detach().cpu().numpy() for k, p in model.named_parameters()}
+    return float(loss.detach()), res, grads
+
+
+def _record_discards(monkeypatch):
+    """Record every layer-discard permutation prefix the backbone draws (tag -> keep), so that the second backend can be
+    fed exactly the same keeps through batch_dict['layer_discard_keep'] (the reference draws them with numpy's global RNG,
+    spconv_backbone.py:137-141: parity needs them injected)."""
+    from virconv_amd import backbone as bb
+    rec = {}
+    orig = bb._draw_keep
+
+    def recording(rate, n, batch_dict, tag, device):
+        keep = orig(rate, n, batch_dict, tag, device)
+        rec[tag] = keep.detach().cpu().clone()
+        return keep
+
+    monkeypatch.setattr(bb, "_draw_keep", recording)
+    return rec
+
+
+def _compare_train(ref, got, feat_tol=1e-4, grad_tol=1e-4):
+    (l_o, out_o, g_o), (l_h, out_h, g_h) = ref, got
+    assert abs(l_h - l_o) <= 1e-4 * max(1.0, abs(l_o)), (l_h, l_o)
+    for name in out_o:
+        np.testing.assert_array_equal(out_h[name][1], out_o[name][1], err_msg=f"{name}: indices differ")
+        fo, fh = out_o[name][0], out_h[name][0]
+        err = np.abs(fh - fo).max()
+        assert err <= feat_tol * max(1.0, np.abs(fo).max()), (name, err)
+        frac, _ = _elementwise_close(fh, fo, rtol=1e-3, atol=1e-4)
+        assert frac == 0.0, (name, frac)
+    worst = ("", 0.0)
+    for k in g_o:
+        scale = max(float(np.abs(g_o[k]).max()), 1e-6)
+        err = float(np.abs(g_h[k] - g_o[k]).max()) / scale
+        if err > worst[1]:
+            worst = (k, err)
+        assert err <= grad_tol, (k, err)
+        # element-wise beside the max-normalised bound: tiny entries of BN-normalised gradients (cancellation) are allowed
+        # atol = 1e-4 of the tensor's own max, everything else must agree to rtol 2e-3
+        frac, _ = _elementwise_close(g_h[k], g_o[k], rtol=2e-3, atol=1e-4 * scale)
+        assert frac == 0.0, (k, frac)
+    return worst
+
+
+def test_fullsize_benchmarked_train_config_vs_oracle(hip_backend, monkeypatch):
+    """configs[2] as bench.py runs it (MODEL_CFG incl. spconv1_inplace discard 0.1, train mode, plan-ahead, bs 2 full-size
+    frames): outputs AND every parameter gradient against the oracle."""
+    dev = torch.device("cuda", 0)
+    batch = bench.make_batch([0, 1], dev, training=True)
+    assert batch["voxel_features"].shape[0] > 50000
+    lw = bench.make_loss_weights(dev)
+    torch.manual_seed(11)
+    model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).to(dev).train()
+    assert model.plan_ahead and model._discard_active()
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+    rec = _record_discards(monkeypatch)
+    cpu_model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).train()
+    cpu_model.load_state_dict(state)
+    bc = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    lwc = {k: v.cpu() for k, v in lw.items()}
+    torch.manual_seed(5)
+    with ops.use_backend(OracleBackend()):
+        ref = _train_pass(cpu_model, bc, lwc)
+    assert set(rec) == {"x_conv1", "x_conv2", "x_conv3"}
+    keeps = dict(rec)
+
+    bh = dict(batch)
+    bh["layer_discard_keep"] = {k: v.to(dev) for k, v in keeps.items()}
+    got = _train_pass(model, bh, lw)
+    # the discard really happened (x_conv1 is returned AFTER its discard: 90 % of the input rows, permuted order)
+    n0 = batch["voxel_features"].shape[0]
+    assert got[1]["x_conv1"][0].shape[0] == int(n0 * 0.9)
+    worst = _compare_train(ref, got)
+    print(f"[parity configs[2]] loss {got[0]:.6f} vs {ref[0]:.6f}; worst relative gradient error {worst[1]:.2e} ({worst[0]})")
+    # BN running statistics after the step (momentum update fused into the stats kernel)
+    sd_h, sd_o = model.state_dict(), cpu_model.state_dict()
+    for k in sd_o:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            a, b = sd_h[k].cpu().numpy(), sd_o[k].numpy()
+            assert np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(b).max()), k
+        if k.endswith("num_batches_tracked"):
+            assert int(sd_h[k]) == int(sd_o[k]) == 1
+
+
+def test_fullsize_virconv8x_train_vs_oracle(hip_backend, monkeypatch):
+    """BASELINE configs[3] backbone shape: VirConv8x (LiDAR stream + MM stream), train, bs 2, 16 000 + 16 000 voxels per
+    frame, layer discard 0.15 (injected), plan-ahead: outputs and every gradient vs the oracle.
+    spconv_backbone.py:339-535."""
+    import importlib
+    sys_path_tools = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__file__)), "tools")
+    import sys
+    if sys_path_tools not in sys.path:
+        sys.path.insert(0, sys_path_tools)
+    bench8x = importlib.import_module("bench8x")
+    from virconv_amd.backbone import VirConv8x
+    dev = torch.device("cuda", 0)
+    batch = bench8x.make_batch(2, dev)
+    assert batch["voxel_features"].shape[0] == 32000 and batch["voxel_features_mm"].shape[0] == 32000
+    cfg = dict(NAME="VirConv8x", NUM_FILTERS=[16, 32, 64, 64], RETURN_NUM_FEATURES_AS_DICT=True, OUT_FEATURES=64,
+               LAYER_DISCARD_RATE=0.15, LAYER_DISCARD_MODE="spconv1_inplace", MM=True)
+    lw = bench.make_loss_weights(dev)
+    torch.manual_seed(12)
+    model = VirConv8x(cfg, 8, synth.GRID_SIZE).to(dev).train()
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+    rec = _record_discards(monkeypatch)
+    cpu_model = VirConv8x(cfg, 8, synth.GRID_SIZE).train()
+    cpu_model.load_state_dict(state)
+    bc = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    lwc = {k: v.cpu() for k, v in lw.items()}
+    torch.manual_seed(6)
+    with ops.use_backend(OracleBackend()):
+        ref = _train_pass(cpu_model, bc, lwc, mm=True)
+    assert set(rec) == {"mm_input", "mm_x_conv1", "mm_x_conv2", "mm_x_conv3"}
+    bh = dict(batch)
+    bh["layer_discard_keep"] = {k: v.to(dev) for k, v in rec.items()}
+    got = _train_pass(model, bh, lw, mm=True)
+    worst = _compare_train(ref, got)
+    print(f"[parity configs[3] backbone] loss {got[0]:.6f} vs {ref[0]:.6f}; worst relative gradient error {worst[1]:.2e} ({worst[0]})")

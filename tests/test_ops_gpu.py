@@ -584,3 +584,40 @@ def test_row_order_of_a_strided_backward_table_is_a_stable_mask_sort(hip_backend
     order = hip_backend.row_order(pb, window=2048).cpu().numpy()
     want = np.concatenate([s + np.argsort(m[s:s + 2048], kind="stable") for s in range(0, m.shape[0], 2048)])
     np.testing.assert_array_equal(order, want.astype(np.int32))
+
+
+@pytest.mark.parametrize("max_voxels", [40000, 3000])
+def test_point_to_voxel_reference_wrapper_protocol_on_hip(hip_backend, max_voxels):
+    """the voxeliser side of the boundary.  The body of the reference's VoxelGeneratorWrapper.generate
+    (data_processor.py:53-58, restated here because /root/reference is absent on the GPU box; the build-container test
+    tests/test_reference_composition.py runs the unmodified wrapper itself):
+        voxel_output = gen.point_to_voxel(tv.from_numpy(points)); voxels = tv_voxels.numpy() ...
+    through the facade's Point2VoxelCPU3d + cumm.tensorview shim on HIP: zero-padded (M, 5, F) voxels, coords, counts
+    bit-exact vs the oracle (incl. out-of-range points, cells with > 5 points, the max_voxels cap)."""
+    from virconv_amd import spconv as facade
+    facade.install(force=True)
+    import cumm.tensorview as tv
+    from spconv.utils import Point2VoxelCPU3d
+    fr = synth.make_frame(23, n_lidar=6000, n_virtual=9000)
+    pts = np.concatenate([fr["points_lidar"], fr["points_virtual"]])
+    crowd = np.tile(pts[500:501], (9, 1))  # 9 more points in one existing cell: only the first 5 (input order) are kept
+    crowd[:, 3] = np.arange(9, dtype=np.float32)
+    out_of_range = np.array([[-1.0, 0, 0, 0, 0, 0, 0, 2], [10, 45.0, 0, 0, 0, 0, 0, 2], [10, 0, 1.5, 0, 0, 0, 0, 1]], np.float32)
+    pts = np.concatenate([pts[:100], out_of_range, pts[100:], crowd]).astype(np.float32)
+    gen = Point2VoxelCPU3d(vsize_xyz=list(synth.VOXEL_SIZE), coors_range_xyz=synth.POINT_CLOUD_RANGE, num_point_features=8,
+                           max_num_points_per_voxel=5, max_num_voxels=max_voxels)
+    tv_voxels, tv_coordinates, tv_num_points = gen.point_to_voxel(tv.from_numpy(pts))
+    voxels, coordinates, num_points = tv_voxels.numpy(), tv_coordinates.numpy(), tv_num_points.numpy()
+    vref, cref, nref = geometry.voxelize(pts, synth.VOXEL_SIZE, synth.POINT_CLOUD_RANGE, 5, max_voxels)
+    assert voxels.shape == vref.shape and voxels.shape[1:] == (5, 8)
+    np.testing.assert_array_equal(coordinates, cref)
+    np.testing.assert_array_equal(num_points, nref)
+    np.testing.assert_array_equal(voxels, vref)
+    assert nref.max() == 5 and (max_voxels != 3000 or cref.shape[0] == 3000)
+    # MeanVFE('max') (mean_vfe.py:39-49) on that output == the fused voxeliser
+    f, c, n = gen.point_to_voxel_mean(pts)
+    np.testing.assert_array_equal(c.cpu().numpy(), cref)
+    np.testing.assert_allclose(f.cpu().numpy(), geometry.mean_vfe(vref, nref, "max"), rtol=0, atol=1e-6)
+    # empty input
+    ev, ec, en = gen.point_to_voxel(tv.from_numpy(np.zeros((0, 8), np.float32)))
+    assert ev.numpy().shape == (0, 5, 8) and ec.numpy().shape == (0, 3) and en.numpy().shape == (0,)

@@ -46,3 +46,39 @@ def test_reference_backbone_runs_unmodified_on_facade_and_matches_ours():
     b.load_state_dict(sa, strict=True)
     from pcdet.utils.spconv_utils import find_all_spconv_keys
     assert len(find_all_spconv_keys(b)) == 20  # the checkpoint-loader's discovery (detector3d_template.py:358) sees our convs
+
+
+def test_reference_voxel_generator_wrapper_and_meanvfe_run_unmodified_on_the_facade():
+    """`spconv.utils.Point2VoxelCPU3d` is part of the drop-in boundary.  The reference's UNMODIFIED
+    VoxelGeneratorWrapper (data_processor.py:14-59: cumm.tensorview protocol, spconv-2 branch) and MeanVFE
+    (mean_vfe.py:39-49) are driven through the facade (oracle operators here; tests/test_ops_gpu.py does the same
+    protocol on HIP) and must reproduce the oracle voxeliser + MeanVFE bit for bit."""
+    import importlib
+    from easydict import EasyDict
+    from oracle import geometry
+    from oracle.backend import OracleBackend
+    from virconv_amd import data, ops, synth
+    refharness.import_reference_backbone()  # install() facade + cumm shim + stubs + sys.path
+    dp = importlib.import_module("pcdet.datasets.processor.data_processor")
+    assert dp.tv is not None, "the cumm.tensorview shim was not picked up by the reference's data_processor"
+    fr = synth.make_frame(3)
+    pts = data.prepare_frame(fr["points_lidar"], fr["points_virtual"], True, rng=np.random.default_rng(10_003))
+    with ops.use_backend(OracleBackend()):
+        gen = dp.VoxelGeneratorWrapper(vsize_xyz=list(synth.VOXEL_SIZE), coors_range_xyz=synth.POINT_CLOUD_RANGE,
+                                       num_point_features=8, max_num_points_per_voxel=5, max_num_voxels=40000)
+        assert gen.spconv_ver == 2
+        voxels, coords, num = gen.generate(pts)
+    assert isinstance(voxels, np.ndarray) and voxels.shape[1:] == (5, 8) and voxels.dtype == np.float32
+    vref, cref, nref = geometry.voxelize(pts, synth.VOXEL_SIZE, synth.POINT_CLOUD_RANGE, 5, 40000)
+    np.testing.assert_array_equal(voxels, vref)
+    np.testing.assert_array_equal(coords, cref)
+    np.testing.assert_array_equal(num, nref)
+    # reference MeanVFE('max') on the wrapper's output == the fused voxeliser's features
+    mv = importlib.import_module("pcdet.models.backbones_3d.vfe.mean_vfe")
+    vfe = mv.MeanVFE(EasyDict(MODEL="max"), num_point_features=8)
+    bd = vfe({"voxels": torch.from_numpy(voxels), "voxel_num_points": torch.from_numpy(num)})
+    with ops.use_backend(OracleBackend()):
+        from virconv_amd.spconv.utils import Point2VoxelCPU3d
+        f, c, n = Point2VoxelCPU3d(list(synth.VOXEL_SIZE), synth.POINT_CLOUD_RANGE, 8, 5, 40000).point_to_voxel_mean(pts)
+    np.testing.assert_array_equal(c.numpy(), coords)
+    np.testing.assert_allclose(bd["voxel_features"].numpy(), f.numpy(), rtol=0, atol=1e-6)

@@ -56,6 +56,7 @@ SIGNATURES = {
     "vc_from_dense": (_I, [_P, _P, _I64, _I, _I, _I, _P, _P, _P]),
     "vc_voxelize_workspace_bytes": (_SZ, [_I64, _I]),
     "vc_voxelize_mean": (_I, [_P, _I64, _I, _P, _P, _I, _I, _I, _P, _SZ, _P, _P, _P, _P, _P]),
+    "vc_voxelize": (_I, [_P, _I64, _I, _P, _P, _I, _I, _P, _SZ, _P, _P, _P, _P, _P]),
     "vc_bn_workspace_bytes": (_SZ, [_I64, _I]),
     "vc_bn_stats": (_I, [_P, _I64, _I, _P, _P, _P, _P, _P, _F, _P, _SZ, _P]),
     "vc_bn_apply_relu": (_I, [_P, _I64, _I, _P, _P, _P, _P, _F, _I, _P, _I, _I, _P]),

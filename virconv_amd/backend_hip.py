@@ -401,6 +401,24 @@ class HipBackend:
         m = self._read_count(nv)
         return feats[:m], coords[:m], num[:m]
 
+    def voxelize(self, points: torch.Tensor, pc_range, voxel_size, max_points: int, max_voxels: int):
+        """Un-fused voxeliser with the reference's return protocol (vc_voxelize): zero-padded voxels (M, max_points, F),
+        coords (M, 3) [z, y, x], num_points (M,) -- what Point2VoxelCPU3d.point_to_voxel returns (data_processor.py:53-58)."""
+        points = _need(points, torch.float32, "points")
+        p, f = points.shape
+        dev = points.device
+        ws_bytes = self.lib.vc_voxelize_workspace_bytes(p, max_points)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        voxels = torch.empty((max_voxels, max_points, f), dtype=torch.float32, device=dev)
+        coords = torch.empty((max_voxels, 3), dtype=torch.int32, device=dev)
+        num = torch.empty((max_voxels,), dtype=torch.int32, device=dev)
+        nv = torch.zeros((1,), dtype=torch.int32, device=dev)
+        check(self.lib.vc_voxelize(_ptr(points), p, f, f32arr(pc_range), f32arr(voxel_size), max_points, max_voxels,
+                                   _ptr(ws), ws_bytes, _ptr(voxels), _ptr(coords), _ptr(num), _ptr(nv), _stream()),
+              "vc_voxelize")
+        m = self._read_count(nv)
+        return voxels[:m], coords[:m], num[:m]
+
     # ------------------------------------------------------------------ BatchNorm(+ReLU)
     def bn_forward(self, x: torch.Tensor, gamma, beta, running_mean, running_var, training: bool, momentum: float,
                    eps: float, relu: bool, out: Optional[torch.Tensor] = None, out_col0: int = 0,

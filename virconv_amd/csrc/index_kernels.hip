@@ -666,6 +666,29 @@ __global__ void __launch_bounds__(256) vox_reduce_kernel(const float* __restrict
   if (ch == 0) num_points[vid] = cnt;
 }
 
+// Un-fused variant: the zero-padded (M, maxp, F) voxel tensor of Point2VoxelCPU3d.point_to_voxel (data_processor.py:53-58);
+// slot j of voxel v holds the j-th point (input order) that fell into the cell, unused slots are zeros.
+__global__ void __launch_bounds__(256) vox_fill_kernel(const float* __restrict__ points, int f, int maxp,
+                                                       const int32_t* __restrict__ cellvid,
+                                                       const int32_t* __restrict__ slots, int64_t cap,
+                                                       float* __restrict__ voxels, int32_t* __restrict__ num_points) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= cap * f) return;
+  int64_t s = t / f;
+  int ch = (int)(t - s * f);
+  int vid = cellvid[s];
+  if (vid < 0) return;
+  const int32_t* sl = slots + s * maxp;
+  int cnt = 0;
+  for (int j = 0; j < maxp; ++j) {
+    int pi = sl[j];
+    float val = 0.0f;
+    if (pi != 0x7fffffff) { val = points[(int64_t)pi * f + ch]; ++cnt; }
+    voxels[((int64_t)vid * maxp + j) * f + ch] = val;
+  }
+  if (ch == 0) num_points[vid] = cnt;
+}
+
 __global__ void vox_count_kernel(const int32_t* total, int max_voxels, int32_t* n_voxels) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *n_voxels = min(*total, max_voxels);
 }
@@ -1078,12 +1101,14 @@ size_t vc_voxelize_workspace_bytes(int64_t p, int max_points) {
   return (size_t)(cap * (8 + 4 + 4 + 4 * (uint64_t)max_points) + (uint64_t)p * 8 + (nb + 1) * 4 + 64);
 }
 
-int vc_voxelize_mean(const float* points, int64_t p, int f, const float* range, const float* vsize, int max_points,
-                     int max_voxels, int vfe_max_last, void* ws, size_t ws_bytes, float* features, int32_t* coords,
-                     int32_t* num_points, int32_t* n_voxels_dev, void* stream) {
+// fused = true : `out` = per-voxel mean features (max_voxels, f)            (vc_voxelize_mean)
+// fused = false: `out` = zero-padded voxels (max_voxels, max_points, f)     (vc_voxelize)
+static int voxelize_impl(bool fused, const float* points, int64_t p, int f, const float* range, const float* vsize,
+                         int max_points, int max_voxels, int vfe_max_last, void* ws, size_t ws_bytes, float* features,
+                         int32_t* coords, int32_t* num_points, int32_t* n_voxels_dev, void* stream) {
   VC_REQUIRE(p >= 0 && f >= 3 && range && vsize && max_points >= 1 && max_voxels >= 1 && ws && features && coords &&
-                 num_points && n_voxels_dev && (points || p == 0), "vc_voxelize_mean: null/invalid argument");
-  if (ws_bytes < vc_voxelize_workspace_bytes(p, max_points)) { set_error("vc_voxelize_mean: workspace too small"); return VC_ECAPACITY; }
+                 num_points && n_voxels_dev && (points || p == 0), "vc_voxelize: null/invalid argument");
+  if (ws_bytes < vc_voxelize_workspace_bytes(p, max_points)) { set_error("vc_voxelize: workspace too small"); return VC_ECAPACITY; }
   hipStream_t st = (hipStream_t)stream;
   const uint64_t cap = hash_capacity(p);
   const int64_t nb = cdiv(p > 0 ? p : 1, 256);
@@ -1123,11 +1148,31 @@ int vc_voxelize_mean(const float* points, int64_t p, int f, const float* range, 
     hipLaunchKernelGGL(vox_assign_kernel, dim3((unsigned)nb), dim3(256), 0, st, points, f, g, pslot, flag, blocksum, p,
                        max_voxels, cellvid, coords);
     VC_CHECK_LAUNCH("vox_assign_kernel");
-    hipLaunchKernelGGL(vox_reduce_kernel, dim3((unsigned)cdiv((int64_t)cap * f, 256)), dim3(256), 0, st, points, f,
-                       max_points, cellvid, slots, (int64_t)cap, vfe_max_last, features, num_points);
-    VC_CHECK_LAUNCH("vox_reduce_kernel");
+    if (fused) {
+      hipLaunchKernelGGL(vox_reduce_kernel, dim3((unsigned)cdiv((int64_t)cap * f, 256)), dim3(256), 0, st, points, f,
+                         max_points, cellvid, slots, (int64_t)cap, vfe_max_last, features, num_points);
+      VC_CHECK_LAUNCH("vox_reduce_kernel");
+    } else {
+      hipLaunchKernelGGL(vox_fill_kernel, dim3((unsigned)cdiv((int64_t)cap * f, 256)), dim3(256), 0, st, points, f,
+                         max_points, cellvid, slots, (int64_t)cap, features, num_points);
+      VC_CHECK_LAUNCH("vox_fill_kernel");
+    }
   }
   return VC_OK;
+}
+
+int vc_voxelize_mean(const float* points, int64_t p, int f, const float* range, const float* vsize, int max_points,
+                     int max_voxels, int vfe_max_last, void* ws, size_t ws_bytes, float* features, int32_t* coords,
+                     int32_t* num_points, int32_t* n_voxels_dev, void* stream) {
+  return voxelize_impl(true, points, p, f, range, vsize, max_points, max_voxels, vfe_max_last, ws, ws_bytes, features,
+                       coords, num_points, n_voxels_dev, stream);
+}
+
+int vc_voxelize(const float* points, int64_t p, int f, const float* range, const float* vsize, int max_points,
+                int max_voxels, void* ws, size_t ws_bytes, float* voxels, int32_t* coords, int32_t* num_points,
+                int32_t* n_voxels_dev, void* stream) {
+  return voxelize_impl(false, points, p, f, range, vsize, max_points, max_voxels, 0, ws, ws_bytes, voxels, coords,
+                       num_points, n_voxels_dev, stream);
 }
 
 int vc_row_order(const int32_t* tbl, int64_t n, int kv, const int32_t* rep, int centre, int window, int32_t* order,
