@@ -207,6 +207,36 @@ int vc_voxelize(const float* points, int64_t p, int f, const float* host_range, 
                 int max_points, int max_voxels, void* ws, size_t ws_bytes, float* voxels, int32_t* coords,
                 int32_t* num_points, int32_t* n_voxels_dev, void* stream);
 
+/* ------------------------------------------------------------------------------------------------ a2 input point discard
+ * StVD input discard of the virtual points, bin-based (pcdet/datasets/dataset.py:120-189 partition + input_point_discard):
+ * bins of width max_dis/bin_num over x, far -> near; the running retain test on the bin counts picks `position`; the nearest
+ * `position` bins holding more than per_bin = int((int(p*(1-rate)) - distant_acc) / (position + 1e-4)) points keep
+ * perm_i[:per_bin] of them (in that order), the other bins keep everything in input order; output = bins far -> near.
+ *   points      (p, f) float32, or float16 when points_are_f16 (the layout of the depth-completion .npy files,
+ *               tools/PENet/vis_utils.py:148-152; kitti_dataset_mm.py:70-73 widens them with .astype(float32))
+ *   rate, max_dis  as Python floats (double): the reference evaluates 1 - rate, N * retain and the ratio test in float64
+ *   host_perms  NULL, or a HOST array of bin_num DEVICE pointers: entry i = the permutation of [0, count_i) the reference
+ *               would draw for bin i with np.random.permutation (parity tests inject it); a NULL entry / NULL array draws a
+ *               point-wise pseudo-random permutation from `seed` (Feistel network + cycle walking, as vc_random_keep)
+ *   out         (p, f) float32 capacity; the first *n_out_dev rows are the result (device-side count, no host sync)   */
+size_t vc_input_discard_workspace_bytes(int64_t p);
+int vc_input_discard(const void* points, int points_are_f16, int64_t p, int f, int bin_num, double rate, double max_dis,
+                     const int64_t* const* host_perms, uint64_t seed, void* ws, size_t ws_bytes, float* out,
+                     int32_t* n_out_dev, void* stream);
+
+/* Fused data front-end: raw LiDAR points + raw virtual points -> input discard (above) -> LiDAR-first
+ * concatenation (dataset.py:270-294; data_processor.py:152-155 LIDAR_FIRST) -> optional `points[:, 3] /= intensity_div`
+ * (dataset.py:292; 0 = off) -> first-touch voxeliser + MeanVFE (vc_voxelize_mean).  One call, no host synchronisation:
+ * the kept-point count stays on the device (the voxeliser runs over the whole capacity, unused rows are out-of-range
+ * sentinels placed after every real point).  *n_points_dev (nullable) = p_lidar + kept virtual points.               */
+size_t vc_frontend_workspace_bytes(int64_t p_lidar, int64_t p_virtual, int f, int max_points);
+int vc_frontend_voxelize_mean(const float* lidar, int64_t p_lidar, const void* virt, int virt_is_f16, int64_t p_virtual,
+                              int f, int bin_num, double rate, double max_dis, const int64_t* const* host_perms,
+                              uint64_t seed, float intensity_div, const float* host_range, const float* host_vsize,
+                              int max_points, int max_voxels, int vfe_max_last, void* ws, size_t ws_bytes, float* features,
+                              int32_t* coords, int32_t* num_points, int32_t* n_voxels_dev, int32_t* n_points_dev,
+                              void* stream);
+
 /* ------------------------------------------------------------------------------------------------ K11 BN(+ReLU)
  * Per-channel batch statistics over the N active rows and the fused normalise(+ReLU) pass -- the
  * nn.BatchNorm1d(eps=1e-3, momentum=0.01) + nn.ReLU that follow every conv (spconv_backbone.py:101-105,160).

@@ -141,6 +141,25 @@ class OracleBackend:
         vox, coords, num = geometry.voxelize(_np(points), voxel_size, pc_range, max_points, max_voxels)
         return torch.from_numpy(vox), torch.from_numpy(coords), torch.from_numpy(num)
 
+    # ------------------------------------------------------------------ input point discard + fused front-end
+    def input_discard(self, points, bin_num, rate, max_dis=60.0, perms=None, seed=0, sync=True):
+        """oracle/geometry.input_point_discard with per-bin injected permutations ({bin: perm}); bins without one draw from
+        a numpy generator seeded with `seed`."""
+        pts = _np(points).astype(np.float32)
+        out = geometry.input_point_discard_binned(pts, bin_num, rate, max_dis, perms, np.random.default_rng(seed))
+        return torch.from_numpy(out), torch.tensor([out.shape[0]], dtype=torch.int32)
+
+    def frontend_voxelize_mean(self, lidar, virtual, bin_num, rate, pc_range, voxel_size, max_points, max_voxels,
+                               vfe_max_last, max_dis=60.0, perms=None, seed=0, intensity_div=0.0, sync=True):
+        virt, _ = self.input_discard(virtual, bin_num, rate, max_dis, perms, seed)
+        pts = np.concatenate([_np(lidar).astype(np.float32), _np(virt)])
+        if intensity_div:
+            pts[:, 3] /= np.float32(intensity_div)
+        f, c, n = self.voxelize_mean(torch.from_numpy(pts), pc_range, voxel_size, max_points, max_voxels, vfe_max_last)
+        if sync:
+            return f, c, n
+        return f, c, n, torch.tensor([f.shape[0], pts.shape[0]], dtype=torch.int32)
+
     # ------------------------------------------------------------------ BatchNorm(+ReLU)
     def bn_forward(self, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, out=None, out_col0=0,
                    num_batches_tracked=None):

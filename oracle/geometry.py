@@ -140,6 +140,27 @@ def input_point_discard(points: np.ndarray, bin_num: int = 2, rate: float = 0.8,
     return np.concatenate(parts)
 
 
+def input_point_discard_binned(points: np.ndarray, bin_num: int, rate: float, max_dis: float = 60, perms=None,
+                               rng: Optional[np.random.Generator] = None) -> np.ndarray:
+    """input_point_discard (dataset.py:172-189) with the permutations injected PER BIN: ``perms[i]`` (i = bin id, 0 = nearest)
+    is what ``np.random.permutation(count_i)`` would have returned for bin i; bins without an entry draw from ``rng``.
+    Same arithmetic as input_point_discard above (which takes one callable for all bins)."""
+    retain = 1 - rate
+    parts, pos, distant_acc = partition(points, num=bin_num, max_dis=max_dis, rate=retain)
+    out_n = int(points.shape[0] * retain)
+    per_bin = int((out_n - distant_acc) / (pos + 0.0001))
+    for j in range(len(parts) - pos, len(parts)):
+        if parts[j].shape[0] > per_bin:
+            i = bin_num - 1 - j
+            r = None if perms is None else (perms.get(i) if isinstance(perms, dict) else perms[i])
+            if r is None:
+                r = (rng or np.random.default_rng()).permutation(parts[j].shape[0])
+            r = np.asarray(r.cpu() if hasattr(r, "cpu") else r).astype(np.int64)
+            assert r.shape[0] == parts[j].shape[0]
+            parts[j] = parts[j][r[:max(per_bin, 0)]]
+    return np.concatenate(parts)
+
+
 def layer_voxel_discard(features: np.ndarray, indices: np.ndarray, rate: float, permutation: np.ndarray):
     """spconv_backbone.py:134-147, spconv-1.x (in-place) behaviour: rows permutation[:int(N*(1-rate))]."""
     if rate == 0:

@@ -108,3 +108,26 @@ def test_no_product_module_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_front_end_entry_points_validate_their_arguments_without_gpu():
+    """vc_voxelize / vc_input_discard / vc_frontend_voxelize_mean: every check below fails before any HIP call."""
+    import ctypes
+    lib = _lib.load()
+    dummy = ctypes.c_void_p(64)
+    rng, vs = _lib.f32arr([0, -40, -3, 70.4, 40, 1]), _lib.f32arr([0.05, 0.05, 0.05])
+    assert lib.vc_input_discard_workspace_bytes(60000) > 60000 * 4 and lib.vc_input_discard_workspace_bytes(-1) == 0
+    assert lib.vc_frontend_workspace_bytes(20000, 60000, 8, 5) > lib.vc_voxelize_workspace_bytes(80000, 5)
+    # bin count out of range / bad rate / missing count pointer / odd fp16 feature count / short workspace
+    assert lib.vc_input_discard(dummy, 0, 10, 8, 17, 0.8, 60.0, None, 0, dummy, 1 << 20, dummy, dummy, None) == _lib.VC_EINVAL
+    assert b"bin_num" in lib.vc_last_error()
+    assert lib.vc_input_discard(dummy, 0, 10, 8, 2, 1.0, 60.0, None, 0, dummy, 1 << 20, dummy, dummy, None) == _lib.VC_EINVAL
+    assert lib.vc_input_discard(dummy, 0, 10, 8, 2, 0.8, 60.0, None, 0, dummy, 1 << 20, dummy, None, None) == _lib.VC_EINVAL
+    assert lib.vc_input_discard(dummy, 1, 10, 7, 2, 0.8, 60.0, None, 0, dummy, 1 << 20, dummy, dummy, None) == _lib.VC_EINVAL
+    assert lib.vc_input_discard(dummy, 0, 10, 8, 2, 0.8, 60.0, None, 0, dummy, 16, dummy, dummy, None) == _lib.VC_ECAPACITY
+    assert lib.vc_voxelize(None, 10, 8, rng, vs, 5, 100, dummy, 1 << 20, dummy, dummy, dummy, dummy, None) == _lib.VC_EINVAL
+    assert lib.vc_voxelize(dummy, 10, 8, rng, vs, 5, 100, dummy, 16, dummy, dummy, dummy, dummy, None) == _lib.VC_ECAPACITY
+    assert lib.vc_frontend_voxelize_mean(None, 10, dummy, 0, 10, 8, 2, 0.8, 60.0, None, 0, 0.0, rng, vs, 5, 100, 1, dummy,
+                                         1 << 24, dummy, dummy, dummy, dummy, None, None) == _lib.VC_EINVAL
+    assert lib.vc_frontend_voxelize_mean(dummy, 10, dummy, 0, 10, 8, 2, 0.8, 60.0, None, 0, 0.0, rng, vs, 5, 100, 1, dummy,
+                                         16, dummy, dummy, dummy, dummy, None, None) == _lib.VC_ECAPACITY

@@ -154,23 +154,46 @@ def test_permutation_invariance_of_input_rows(oracle_backend):
 
 
 @pytest.mark.parametrize("bins,seed", [(2, 0), (10, 1), (10, 2), (4, 3)])
-def test_device_input_point_discard_equals_the_numpy_restatement(bins, seed):
-    """virconv_amd.data.input_point_discard_device (torch ops, any device) against the numpy version (which tests/
-    test_oracle_cpu.py pins to the reference's own dataset.py) for the same injected per-bin permutations."""
+def test_front_end_host_logic_on_the_oracle_backend(oracle_backend, bins, seed):
+    """Host side of the device front-end (virconv_amd.data.input_point_discard_device / frontend_voxelize / frontend_batch)
+    on the oracle operators: per-bin injected permutations reproduce the reference-pinned numpy discard, and the fused call
+    equals discard -> LiDAR-first concat -> voxeliser + MeanVFE done step by step.  (The HIP kernels behind the same calls
+    are checked bit-exactly in tests/test_ops_gpu.py.)"""
+    from oracle import geometry
     from virconv_amd import data
     fr = synth.make_frame(seed)
-    pts = fr["points_virtual"]
-    perms = {}
+    pts, lidar = fr["points_virtual"], fr["points_lidar"]
+    store = {}
 
     def perm_np(n):
-        perms.setdefault(n, np.random.default_rng(100 + n).permutation(n))
-        return perms[n]
+        store.setdefault(n, np.random.default_rng(100 + n).permutation(n))
+        return store[n]
 
     ref = data.input_point_discard(pts, bin_num=bins, rate=0.8, permutation=perm_np)
-    got = data.input_point_discard_device(torch.from_numpy(pts), bin_num=bins, rate=0.8,
-                                          permutation=lambda n: torch.from_numpy(perm_np(n)))
+    parts, _, _ = data.partition(pts, num=bins, rate=1 - 0.8)
+    perms = {bins - 1 - j: torch.from_numpy(perm_np(parts[j].shape[0])) for j in range(len(parts))}
+    got = data.input_point_discard_device(torch.from_numpy(pts), bin_num=bins, rate=0.8, perms=perms)
     np.testing.assert_array_equal(got.numpy(), ref)
-    assert abs(ref.shape[0] - 0.2 * pts.shape[0]) < 0.2 * pts.shape[0]
-    fused = data.prepare_frame_device(torch.from_numpy(fr["points_lidar"]), torch.from_numpy(pts), training=(bins == 2),
-                                      permutation=lambda n: torch.from_numpy(perm_np(n)))
-    assert fused.shape[1] == 8 and torch.equal(fused[:fr["points_lidar"].shape[0]], torch.from_numpy(fr["points_lidar"]))
+    if bins in (2, 10):
+        training = bins == 2
+        f, c, n = data.frontend_voxelize(torch.from_numpy(lidar), torch.from_numpy(pts), training, synth.POINT_CLOUD_RANGE,
+                                         synth.VOXEL_SIZE, perms=perms)
+        fused = np.concatenate([lidar, ref]).astype(np.float32)
+        vox, cref, nref = geometry.voxelize(fused, synth.VOXEL_SIZE, synth.POINT_CLOUD_RANGE, 5, 40000)
+        np.testing.assert_array_equal(c.numpy(), cref)
+        np.testing.assert_array_equal(n.numpy(), nref)
+        np.testing.assert_allclose(f.numpy(), geometry.mean_vfe(vox, nref, "max"), rtol=0, atol=1e-6)
+        bf, bc = data.frontend_batch([(torch.from_numpy(lidar), torch.from_numpy(pts))] * 2, training, synth.POINT_CLOUD_RANGE,
+                                     synth.VOXEL_SIZE, seed=3)
+        assert bc.shape[1] == 4 and bf.shape[0] == bc.shape[0] and set(bc[:, 0].tolist()) == {0, 1}
+
+
+def test_front_end_refuses_host_tensors_on_the_product_backend():
+    """No CPU path in the product: the HIP backend raises on host tensors instead of computing on the CPU."""
+    from virconv_amd import _lib, backend_hip
+    be = backend_hip.HipBackend()
+    with pytest.raises(_lib.VirConvError):
+        be.input_discard(torch.zeros((10, 8)), 2, 0.8)
+    with pytest.raises(_lib.VirConvError):
+        be.frontend_voxelize_mean(torch.zeros((10, 8)), torch.zeros((10, 8)), 2, 0.8, synth.POINT_CLOUD_RANGE, synth.VOXEL_SIZE,
+                                  5, 100, True)

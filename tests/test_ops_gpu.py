@@ -621,3 +621,113 @@ def test_point_to_voxel_reference_wrapper_protocol_on_hip(hip_backend, max_voxel
     # empty input
     ev, ec, en = gen.point_to_voxel(tv.from_numpy(np.zeros((0, 8), np.float32)))
     assert ev.numpy().shape == (0, 5, 8) and ec.numpy().shape == (0, 3) and en.numpy().shape == (0,)
+
+
+# ------------------------------------------------------------------------------------------------ a2 / f2: data front-end
+def _bin_perms(pts, bins, rate=0.8, max_dis=60.0):
+    """The permutations np.random.permutation would hand to the reference, keyed by bin id (0 = nearest)."""
+    from virconv_amd import data
+    parts, _, _ = data.partition(pts, num=bins, max_dis=max_dis, rate=1 - rate)
+    return {bins - 1 - j: np.random.default_rng(1000 + 17 * j + parts[j].shape[0]).permutation(parts[j].shape[0])
+            for j in range(len(parts))}
+
+
+@pytest.mark.parametrize("bins,seed,half", [(2, 0, False), (10, 1, False), (10, 2, True), (4, 3, False), (16, 4, True), (1, 5, False)])
+def test_input_point_discard_kernel_bit_exact_under_injected_permutations(hip_backend, bins, seed, half):
+    """vc_input_discard vs oracle/geometry.input_point_discard_binned (pinned to the reference's own dataset.py:120-189 in
+    tests/test_oracle_cpu.py) with the per-bin permutations injected: the same rows, in the same order, bit for bit --
+    float32 points and the float16 rows of the depth-completion .npy files (widened exactly like .astype(float32))."""
+    fr = synth.make_frame(seed)
+    pts = fr["points_virtual"]
+    if half:
+        pts = pts.astype(np.float16).astype(np.float32)
+    perms = _bin_perms(pts, bins)
+    ref = geometry.input_point_discard_binned(pts, bins, 0.8, 60.0, perms)
+    dev_pts = torch.from_numpy(pts.astype(np.float16) if half else pts).cuda()
+    got, n_out = hip_backend.input_discard(dev_pts, bins, 0.8, 60.0, perms={b: torch.from_numpy(p) for b, p in perms.items()})
+    assert int(n_out.item()) == ref.shape[0]
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+def test_input_point_discard_kernel_edge_cases(hip_backend):
+    """x < 0 belongs to no bin, points on a bin edge, an empty input, fewer points than bins, a rate of 0 (nothing dropped)."""
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-5, 75, size=(5000, 8)).astype(np.float32)
+    pts[:40, 0] = np.repeat(np.array([0.0, 6.0, 30.0, 59.999996, 60.0, 54.0, -0.0, -1e-7], np.float32), 5)
+    for bins in (2, 10):
+        perms = _bin_perms(pts, bins)
+        ref = geometry.input_point_discard_binned(pts, bins, 0.8, 60.0, perms)
+        got, _ = hip_backend.input_discard(torch.from_numpy(pts).cuda(), bins, 0.8, 60.0,
+                                           perms={b: torch.from_numpy(p) for b, p in perms.items()})
+        np.testing.assert_array_equal(got.cpu().numpy(), ref)
+    e, n = hip_backend.input_discard(torch.zeros((0, 8)).cuda(), 2, 0.8)
+    assert e.shape == (0, 8) and int(n.item()) == 0
+    few = pts[100:103]
+    ref = geometry.input_point_discard_binned(few, 10, 0.8, 60.0, _bin_perms(few, 10))
+    got, _ = hip_backend.input_discard(torch.from_numpy(few).cuda(), 10, 0.8, perms={b: torch.from_numpy(p) for b, p in _bin_perms(few, 10).items()})
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+    ref0 = geometry.input_point_discard_binned(pts, 2, 0.0, 60.0, _bin_perms(pts, 2, rate=0.0))
+    got0, _ = hip_backend.input_discard(torch.from_numpy(pts).cuda(), 2, 0.0)
+    np.testing.assert_array_equal(got0.cpu().numpy(), ref0)
+
+
+def test_input_point_discard_kernel_own_generator(hip_backend):
+    """Without injected permutations each reduced bin keeps per_bin DISTINCT points of that bin (a permutation prefix), the
+    kept-whole bins are untouched, the total equals the reference's count, and the draw follows the seed."""
+    fr = synth.make_frame(7)
+    pts = fr["points_virtual"]
+    for bins in (2, 10):
+        ref = geometry.input_point_discard_binned(pts, bins, 0.8, 60.0, _bin_perms(pts, bins))
+        a, _ = hip_backend.input_discard(torch.from_numpy(pts).cuda(), bins, 0.8, seed=11)
+        b, _ = hip_backend.input_discard(torch.from_numpy(pts).cuda(), bins, 0.8, seed=11)
+        c, _ = hip_backend.input_discard(torch.from_numpy(pts).cuda(), bins, 0.8, seed=12)
+        assert torch.equal(a, b) and not torch.equal(a, c) and a.shape[0] == ref.shape[0] == c.shape[0]
+        a = a.cpu().numpy()
+        inter = 60.0 / bins
+        bin_of = lambda x: np.minimum(np.floor(x / np.float32(inter)).astype(np.int64), bins - 1)
+        np.testing.assert_array_equal(bin_of(a[:, 0]), bin_of(ref[:, 0]))        # same bin layout, far -> near
+        src = {r.tobytes() for r in pts}
+        rows = [r.tobytes() for r in a]
+        assert len(set(rows)) == len(rows) and set(rows) <= src                   # distinct rows of the input
+        keep_whole = np.array([r.tobytes() for r in ref]) == np.array(rows)
+        assert keep_whole.mean() > 0.05                                           # the far bins are identical (kept whole)
+
+
+@pytest.mark.parametrize("training,half", [(True, False), (False, True)])
+def test_fused_front_end_equals_the_step_by_step_reference_pipeline(hip_backend, training, half):
+    """vc_frontend_voxelize_mean (ONE call: discard + LiDAR-first concat + intensity /= 10 + voxeliser + MeanVFE) against the
+    oracle pipeline dataset.py:270-294 -> data_processor.py:128-187 -> mean_vfe.py:39-49 on the same injected permutations."""
+    from virconv_amd import data
+    fr = synth.make_frame(9)
+    lidar, virt = fr["points_lidar"], fr["points_virtual"]
+    if half:
+        virt = virt.astype(np.float16).astype(np.float32)
+    bins = 2 if training else 10
+    perms = _bin_perms(virt, bins)
+    kept = geometry.input_point_discard_binned(virt, bins, 0.8, 60.0, perms)
+    fused = np.concatenate([lidar, kept]).astype(np.float32)
+    fused[:, 3] /= np.float32(10)
+    vox, cref, nref = geometry.voxelize(fused, synth.VOXEL_SIZE, synth.POINT_CLOUD_RANGE, 5, 40000)
+    fref = geometry.mean_vfe(vox, nref, "max")
+    dv = torch.from_numpy(virt.astype(np.float16) if half else virt).cuda()
+    f, c, n = data.frontend_voxelize(torch.from_numpy(lidar).cuda(), dv, training, synth.POINT_CLOUD_RANGE, synth.VOXEL_SIZE,
+                                     perms={b: torch.from_numpy(p) for b, p in perms.items()}, intensity_div=10.0)
+    np.testing.assert_array_equal(c.cpu().numpy(), cref)
+    np.testing.assert_array_equal(n.cpu().numpy(), nref)
+    np.testing.assert_allclose(f.cpu().numpy(), fref, rtol=0, atol=1e-6)
+    # the batched form: all launches queued, one count read
+    bf, bc = data.frontend_batch([(torch.from_numpy(lidar).cuda(), dv)] * 2, training, synth.POINT_CLOUD_RANGE, synth.VOXEL_SIZE, seed=5)
+    assert bc.shape[1] == 4 and bf.shape[0] == bc.shape[0] and sorted(set(bc[:, 0].tolist())) == [0, 1]
+
+
+def test_load_virtual_points_reads_the_fp16_npy_layout(hip_backend, tmp_path):
+    from virconv_amd import data
+    fr = synth.make_frame(2)
+    arr = fr["points_virtual"].astype(np.float16)           # tools/PENet/vis_utils.py:148-152 writes float16 (P, 8)
+    path = str(tmp_path / "000002.npy")
+    np.save(path, arr)
+    t = data.load_virtual_points(path, "cuda")
+    assert t.dtype == torch.float16 and t.is_cuda and t.shape == arr.shape
+    np.testing.assert_array_equal(t.cpu().numpy(), arr)
+    out = data.input_point_discard_device(t, bin_num=2, rate=0.8, seed=1)
+    assert out.dtype == torch.float32 and 0 < out.shape[0] < arr.shape[0]

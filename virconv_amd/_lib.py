@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("VIRCONV_LIB", os.path.join(_HERE, "libvirconv_hip.so"
 OPERAND_TYPES = {"f32": 0, "f16": 1, "bf16": 2}  # vc_operand (include/virconv_hip.h)
 VC_OK, VC_EINVAL, VC_ECAPACITY, VC_EHIP = 0, -1, -2, -3
 
-_P, _I64, _I, _SZ, _F = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_float
+_P, _I64, _I, _SZ, _F, _D = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_float, C.c_double
 
 # name -> (restype, argtypes); must list every symbol of include/virconv_hip.h (checked by tests/test_abi.py)
 SIGNATURES = {
@@ -57,6 +57,11 @@ SIGNATURES = {
     "vc_voxelize_workspace_bytes": (_SZ, [_I64, _I]),
     "vc_voxelize_mean": (_I, [_P, _I64, _I, _P, _P, _I, _I, _I, _P, _SZ, _P, _P, _P, _P, _P]),
     "vc_voxelize": (_I, [_P, _I64, _I, _P, _P, _I, _I, _P, _SZ, _P, _P, _P, _P, _P]),
+    "vc_input_discard_workspace_bytes": (_SZ, [_I64]),
+    "vc_input_discard": (_I, [_P, _I, _I64, _I, _I, _D, _D, _P, C.c_uint64, _P, _SZ, _P, _P, _P]),
+    "vc_frontend_workspace_bytes": (_SZ, [_I64, _I64, _I, _I]),
+    "vc_frontend_voxelize_mean": (_I, [_P, _I64, _P, _I, _I64, _I, _I, _D, _D, _P, C.c_uint64, _F, _P, _P, _I, _I, _I, _P, _SZ,
+                                       _P, _P, _P, _P, _P, _P]),
     "vc_bn_workspace_bytes": (_SZ, [_I64, _I]),
     "vc_bn_stats": (_I, [_P, _I64, _I, _P, _P, _P, _P, _P, _F, _P, _SZ, _P]),
     "vc_bn_apply_relu": (_I, [_P, _I64, _I, _P, _P, _P, _P, _F, _I, _P, _I, _I, _P]),

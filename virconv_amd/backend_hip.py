@@ -419,6 +419,82 @@ class HipBackend:
         m = self._read_count(nv)
         return voxels[:m], coords[:m], num[:m]
 
+    # ------------------------------------------------------------------ input point discard + fused front-end
+    @staticmethod
+    def _perm_table(perms, bin_num: int, device):
+        """perms: None | {bin: int64 tensor} | sequence of bin_num entries -> (ctypes host array of device pointers, keep-alive)."""
+        if perms is None:
+            return None, []
+        import ctypes
+        arr = (ctypes.c_void_p * bin_num)()
+        alive = []
+        for b in range(bin_num):
+            t = perms.get(b) if isinstance(perms, dict) else perms[b]
+            if t is None:
+                arr[b] = None
+                continue
+            t = torch.as_tensor(t).to(device=device, dtype=torch.int64).contiguous()
+            alive.append(t)
+            arr[b] = t.data_ptr()
+        return arr, alive
+
+    def input_discard(self, points: torch.Tensor, bin_num: int, rate: float, max_dis: float = 60.0, perms=None,
+                      seed: int = 0, sync: bool = True):
+        """StVD input point discard (vc_input_discard; dataset.py:120-189).  points (P, F) float32 or float16.
+        -> (out (P, F) float32 capacity buffer, n_out device int32[1]); with sync=True the buffer is sliced to its
+        n_out rows (one count read)."""
+        if not points.is_cuda:
+            raise _lib.VirConvError("input_discard: expected a CUDA/HIP tensor; virconv_amd has no CPU path")
+        assert points.dtype in (torch.float32, torch.float16) and points.dim() == 2
+        points = points.contiguous()
+        p, f = points.shape
+        dev = points.device
+        ws_bytes = self.lib.vc_input_discard_workspace_bytes(p)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        out = torch.empty((p, f), dtype=torch.float32, device=dev)
+        n_out = torch.zeros((1,), dtype=torch.int32, device=dev)
+        tbl, alive = self._perm_table(perms, bin_num, dev)
+        check(self.lib.vc_input_discard(_ptr(points), 1 if points.dtype == torch.float16 else 0, p, f, int(bin_num),
+                                        float(rate), float(max_dis), tbl, seed & 0xFFFFFFFFFFFFFFFF, _ptr(ws), ws_bytes,
+                                        _ptr(out), _ptr(n_out), _stream()), "vc_input_discard")
+        del alive  # the launches are ordered on the stream; torch's allocator keeps the blocks stream-ordered
+        if not sync:
+            return out, n_out
+        return out[:self._read_count(n_out)], n_out
+
+    def frontend_voxelize_mean(self, lidar: torch.Tensor, virtual: torch.Tensor, bin_num: int, rate: float, pc_range,
+                               voxel_size, max_points: int, max_voxels: int, vfe_max_last: bool, max_dis: float = 60.0,
+                               perms=None, seed: int = 0, intensity_div: float = 0.0, sync: bool = True):
+        """Fused data front-end (vc_frontend_voxelize_mean): raw LiDAR (Pl, F) f32 + raw virtual (Pv, F) f32|f16 ->
+        input discard -> LiDAR-first concat -> voxeliser + MeanVFE.  -> (features, coords, num_points[, n_voxels dev])."""
+        lidar = _need(lidar, torch.float32, "lidar points")
+        if not virtual.is_cuda:
+            raise _lib.VirConvError("frontend_voxelize_mean: expected CUDA/HIP tensors; virconv_amd has no CPU path")
+        assert virtual.dtype in (torch.float32, torch.float16)
+        virtual = virtual.contiguous()
+        pl, f = lidar.shape
+        pv = virtual.shape[0]
+        assert virtual.shape[1] == f
+        dev = lidar.device
+        ws_bytes = self.lib.vc_frontend_workspace_bytes(pl, pv, f, max_points)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        feats = torch.zeros((max_voxels, f), dtype=torch.float32, device=dev)
+        coords = torch.zeros((max_voxels, 3), dtype=torch.int32, device=dev)
+        num = torch.zeros((max_voxels,), dtype=torch.int32, device=dev)
+        nv = torch.zeros((2,), dtype=torch.int32, device=dev)
+        tbl, alive = self._perm_table(perms, bin_num, dev)
+        check(self.lib.vc_frontend_voxelize_mean(_ptr(lidar), pl, _ptr(virtual), 1 if virtual.dtype == torch.float16 else 0,
+                                                 pv, f, int(bin_num), float(rate), float(max_dis), tbl,
+                                                 seed & 0xFFFFFFFFFFFFFFFF, float(intensity_div), f32arr(pc_range),
+                                                 f32arr(voxel_size), max_points, max_voxels, 1 if vfe_max_last else 0,
+                                                 _ptr(ws), ws_bytes, _ptr(feats), _ptr(coords), _ptr(num), _ptr(nv[:1]),
+                                                 _ptr(nv[1:]), _stream()), "vc_frontend_voxelize_mean")
+        del alive
+        if not sync:
+            return feats, coords, num, nv
+        m = self._read_count(nv[:1])
+        return feats[:m], coords[:m], num[:m]
+
     # ------------------------------------------------------------------ BatchNorm(+ReLU)
     def bn_forward(self, x: torch.Tensor, gamma, beta, running_mean, running_var, training: bool, momentum: float,
                    eps: float, relu: bool, out: Optional[torch.Tensor] = None, out_col0: int = 0,

@@ -22,6 +22,7 @@ SOURCES = {
     "conv_kernels.hip": [],
     "bn_kernels.hip": [],
     "pool_kernels.hip": ["-ffp-contract=off"],
+    "frontend_kernels.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 

@@ -91,6 +91,38 @@ __device__ __forceinline__ uint64_t mix64(uint64_t k) {
 
 static constexpr uint64_t kEmptyKey = ~0ULL;
 
+// Point-wise pseudo-random PERMUTATION of [0, n): 4-round Feistel network over 2*half_bits bits (2^(2h) >= n) + cycle walking
+// (re-encrypt until the value is < n).  A bijection of [0, n) that can be evaluated at any index without sorting n keys.
+// Used by the layer discard (vc_random_keep) and the input point discard (vc_input_discard).
+__device__ __forceinline__ uint32_t feistel_round(uint32_t r, uint32_t key) {
+  uint32_t v = r ^ key;
+  v ^= v >> 16; v *= 0x85ebca6bu; v ^= v >> 13; v *= 0xc2b2ae35u; v ^= v >> 16;
+  return v;
+}
+__device__ __forceinline__ int feistel_half_bits(uint64_t n) {
+  int half = 1;
+  while (half < 31 && (1ULL << (2 * half)) < n) ++half;
+  return half;
+}
+__device__ __forceinline__ uint64_t feistel_perm(uint64_t i, uint64_t n, int half_bits, uint64_t seed) {
+  const uint32_t mask = (half_bits >= 32) ? 0xffffffffu : ((1u << half_bits) - 1u);
+  uint32_t k[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) k[r] = (uint32_t)(mix64(seed + 0x9e3779b97f4a7c15ULL * (uint64_t)(r + 1)) >> 16);
+  uint64_t x = i;
+  do {
+    uint32_t l = (uint32_t)(x >> half_bits) & mask, rr = (uint32_t)x & mask;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t t = l ^ (feistel_round(rr, k[r]) & mask);
+      l = rr;
+      rr = t;
+    }
+    x = ((uint64_t)l << half_bits) | rr;
+  } while (x >= n);
+  return x;
+}
+
 // Coordinate hash (K3), workspace = [keys: cap x u64][vals: cap x i32].  LOCALITY-PRESERVING: the key is the linear
 // voxel index (x fastest); the 8 keys of an aligned x-octet map to 8 CONSECUTIVE slots (one 64-byte run of `keys`), only
 // the octet id is scrambled, and a collision jumps a whole octet (slot + 8), which keeps the low bits.  The rulebook

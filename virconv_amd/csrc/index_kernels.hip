@@ -475,32 +475,11 @@ __global__ void __launch_bounds__(256) scatter_rows_kernel(const float* __restri
 // PERMUTATION can be evaluated point-wise instead: a 4-round Feistel network over 2h bits (2^(2h) >= N, < 4N) is a bijection
 // of [0, 2^(2h)), and cycle-walking (re-encrypt until the value is < N) restricts it to a bijection of [0, N).  keep[i] is
 // that permutation at i: distinct rows, any prefix length, one thread per kept row, no sort.
-__device__ __forceinline__ uint32_t feistel_round(uint32_t r, uint32_t key) {
-  uint32_t v = r ^ key;
-  v ^= v >> 16; v *= 0x85ebca6bu; v ^= v >> 13; v *= 0xc2b2ae35u; v ^= v >> 16;
-  return v;
-}
-
 __global__ void __launch_bounds__(256) random_keep_kernel(int64_t n, int64_t n_keep, uint64_t seed, int half_bits,
                                                           int64_t* __restrict__ keep) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n_keep) return;
-  const uint32_t mask = (half_bits >= 32) ? 0xffffffffu : ((1u << half_bits) - 1u);
-  uint32_t k[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) k[r] = (uint32_t)(mix64(seed + 0x9e3779b97f4a7c15ULL * (uint64_t)(r + 1)) >> 16);
-  uint64_t x = (uint64_t)i;
-  do {
-    uint32_t l = (uint32_t)(x >> half_bits) & mask, rr = (uint32_t)x & mask;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint32_t t = l ^ (feistel_round(rr, k[r]) & mask);
-      l = rr;
-      rr = t;
-    }
-    x = ((uint64_t)l << half_bits) | rr;
-  } while (x >= (uint64_t)n);
-  keep[i] = (int64_t)x;
+  keep[i] = (int64_t)feistel_perm((uint64_t)i, (uint64_t)n, half_bits, seed);
 }
 
 // ------------------------------------------------------------------------------------------ K10 dense

@@ -5,9 +5,12 @@
                         (dataset.py:270-294, data_processor.py:152-155)
   voxelize_batch        GPU voxeliser + fused MeanVFE per frame (vc_voxelize_mean), collated with the batch index
                         prepended (dataset.py:315-367 collate_batch)
-  input_point_discard_device / prepare_frame_device
-                        the same discard on a torch tensor that is already on the GPU (raw points in,
-                        voxel features out, nothing on the host but one 10-int histogram read) -- device-agnostic torch ops
+  input_point_discard_device
+                        the same discard as a hand-written HIP path (vc_input_discard) on points already on the GPU
+  frontend_voxelize / frontend_batch
+                        SURVEY §8f rank 2: raw LiDAR + raw (fp16) virtual points in, voxel features out, ONE C-ABI call per
+                        frame (vc_frontend_voxelize_mean: discard + LiDAR-first concat + voxeliser + MeanVFE), no host sync
+                        inside; load_virtual_points reads the fp16 .npy the offline depth completion wrote
 """
 from __future__ import annotations
 
@@ -59,52 +62,62 @@ def prepare_frame(points_lidar: np.ndarray, points_virtual: np.ndarray, training
 
 
 def input_point_discard_device(points: torch.Tensor, bin_num: int = 2, rate: float = 0.8, max_dis: float = 60.0,
-                               permutation: Optional[Callable[[int], torch.Tensor]] = None) -> torch.Tensor:
-    """input_point_discard (dataset.py:120-189) on a tensor that lives on any device; one host read (the bin histogram).
+                               perms=None, seed: Optional[int] = None) -> torch.Tensor:
+    """input_point_discard (dataset.py:120-189) of points that already live on the GPU: the hand-written HIP path
+    (vc_input_discard -- ballot histogram, scanned stable ranks, per-bin point-wise permutation), one count read.
 
-    Same output as the numpy version for the same per-bin permutations: bins far -> near, reduced bins keep
-    ``permutation(n_i)[:per_bin]`` of their points (in that order), the others keep all points in input order.
-    ``permutation(n) -> int64 tensor`` defaults to a device ``torch.randperm``."""
-    retain = 1 - rate
-    total = points.shape[0]
-    inter = max_dis / bin_num
-    x = points[:, 0]
-    # bin of a point: i with inter*i <= x < inter*(i+1); the last bin is open-ended; x < 0 belongs to no bin (-1).
-    # Compared like the reference does: x against the python-float products inter*i, in float64
-    edges = torch.tensor([inter * i for i in range(bin_num)], dtype=torch.float64, device=points.device)
-    b = (torch.bucketize(x.to(torch.float64), edges, right=True) - 1).to(torch.int64)
-    counts = torch.bincount(b[b >= 0], minlength=bin_num).cpu().tolist()                      # the one host read
-    acc, position, distant_acc = 0, bin_num - 1, 0
-    for j in range(bin_num):                                                                  # far -> near
-        i = bin_num - j - 1
-        acc += counts[i]
-        if (acc + i * counts[i]) / total < retain:
-            position, distant_acc = i, acc
-    position = max(position, 0)
-    per_bin = int((int(total * retain) - distant_acc) / (position + 0.0001))
-    # stable sort by (far -> near): rows of bin i become one contiguous, input-ordered run
-    key = torch.where(b >= 0, (bin_num - 1) - b, torch.full_like(b, bin_num))
-    order = torch.sort(key, stable=True)[1]
-    runs, start = [], 0
-    for j in range(bin_num):
-        i = bin_num - j - 1
-        n_i = counts[i]
-        rows = order[start:start + n_i]
-        start += n_i
-        if j >= bin_num - position and n_i > per_bin:                                        # parts[len - pos:], reduced
-            perm = permutation(n_i) if permutation is not None else torch.randperm(n_i, device=points.device)
-            rows = rows[perm.to(device=rows.device, dtype=torch.int64)[:per_bin]]
-        runs.append(rows)
-    keep = torch.cat(runs) if runs else order[:0]
-    return points.index_select(0, keep)
+    ``points`` (P, F) float32 or float16 (the dtype of the depth-completion ``.npy`` files).  ``perms`` injects the per-bin
+    permutations ``{bin: int64 tensor}`` (bin 0 = nearest; what the reference draws with ``np.random.permutation``) --
+    with them the result equals the numpy version bit for bit; without, each reduced bin draws a pseudo-random permutation
+    from ``seed`` (default: torch's CPU generator, so ``torch.manual_seed`` reproduces it)."""
+    if seed is None:
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    out, _ = ops.get_backend().input_discard(points, bin_num, rate, max_dis, perms=perms, seed=seed, sync=True)
+    return out
 
 
-def prepare_frame_device(points_lidar: torch.Tensor, points_virtual: torch.Tensor, training: bool, discard_rate: float = 0.8,
-                         permutation: Optional[Callable[[int], torch.Tensor]] = None) -> torch.Tensor:
-    """prepare_frame on device tensors: (P, 8) float32, LiDAR rows first."""
-    virt = input_point_discard_device(points_virtual, bin_num=2 if training else 10, rate=discard_rate,
-                                      permutation=permutation)
-    return torch.cat([points_lidar, virt]).float()
+def load_virtual_points(path: str, device="cuda") -> torch.Tensor:
+    """One frame of depth-completed virtual points as the offline stage wrote it: an ``.npy`` of (P, 8) float16
+    ``[x, y, z, intensity, r/3, g/3, b/3, flag]`` (tools/PENet/vis_utils.py:148-152; read by kitti_dataset_mm.py:70-73 as
+    ``np.load(f).astype(np.float32)``).  The half-precision rows go to the GPU as they are (half the PCIe bytes) through a
+    pinned staging buffer; vc_input_discard / vc_frontend_voxelize_mean widen them on load, which is exactly ``astype``."""
+    arr = np.load(path, mmap_mode="r")
+    assert arr.ndim == 2 and arr.dtype in (np.float16, np.float32), (arr.shape, arr.dtype)
+    host = torch.from_numpy(np.ascontiguousarray(arr))
+    if torch.device(device).type == "cuda":
+        host = host.pin_memory()
+    return host.to(device, non_blocking=True)
+
+
+def frontend_voxelize(points_lidar: torch.Tensor, points_virtual: torch.Tensor, training: bool, pc_range, voxel_size,
+                      max_points: int = 5, max_voxels: int = 40000, vfe_max_last: bool = True, discard_rate: float = 0.8,
+                      perms=None, seed: Optional[int] = None, intensity_div: float = 0.0, sync: bool = True):
+    """The whole per-frame data front-end of the non-LATER_FUSION configs (VirConv-L) in ONE call on the device
+    (vc_frontend_voxelize_mean): input discard (2 bins train / 10 bins test, dataset.py:276-278) -> LiDAR-first concat
+    (dataset.py:290-292, data_processor.py:152-155) -> voxeliser + MeanVFE.  -> (features, coords [z, y, x], num_points)."""
+    if seed is None:
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    return ops.get_backend().frontend_voxelize_mean(points_lidar, points_virtual, 2 if training else 10, discard_rate,
+                                                    pc_range, voxel_size, max_points, max_voxels, vfe_max_last,
+                                                    perms=perms, seed=seed, intensity_div=intensity_div, sync=sync)
+
+
+def frontend_batch(frames, training: bool, pc_range, voxel_size, max_points: int = 5, max_voxels: int = 40000,
+                   vfe_max_last: bool = True, discard_rate: float = 0.8, seed: Optional[int] = None):
+    """collate_batch (dataset.py:315-367) over frontend_voxelize: frames = [(lidar (Pl, 8), virtual (Pv, 8)), ...] device
+    tensors -> voxel_features (N, F), voxel_coords (N, 4) i32 [b, z, y, x].  The per-frame launches are all queued before the
+    first count is read, so the host waits once, not once per frame."""
+    be = ops.get_backend()
+    if seed is None:
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    pend = [be.frontend_voxelize_mean(l, v, 2 if training else 10, discard_rate, pc_range, voxel_size, max_points, max_voxels,
+                                      vfe_max_last, seed=seed + 7919 * b, sync=False) for b, (l, v) in enumerate(frames)]
+    feats, coords = [], []
+    counts = torch.stack([p[3][0] for p in pend]).cpu().tolist() if pend and pend[0][3].is_cuda else [int(p[3][0]) for p in pend]
+    for b, ((f, c, _, _), m) in enumerate(zip(pend, counts)):
+        feats.append(f[:m])
+        coords.append(torch.cat([torch.full((m, 1), b, dtype=torch.int32, device=c.device), c[:m]], dim=1))
+    return torch.cat(feats), torch.cat(coords)
 
 
 def voxelize_batch(frames: Sequence[np.ndarray], pc_range, voxel_size, max_points: int = 5, max_voxels: int = 40000,
