@@ -107,24 +107,32 @@ int vc_spconv_emit_pairs(const int32_t* indices, int64_t n, int ndim, int batch_
  *   row_order (optional, NULL = natural order): a permutation of [0, n_out) from vc_row_order; tile slot s computes output
  *   row row_order[s].  A pure scheduling hint -- results are bit-identical with and without it.
  * Replaces spconv ops.implicit_gemm / indice_conv fwd and bwd-input (autograd of spconv_backbone.py:89-125).   */
+/*   flags: VC_CONV_SORTED_ROWS -- the rows of `tbl` AND the rows they point to are both in ascending coordinate order (true
+ *   for every SubM conv on a tensor produced by a strided conv, forward and backward): the three dx-offsets of one (dz, dy)
+ *   then gather one nearly contiguous run of source rows per 16-row tile, and the kernel stages that run through LDS ("LDS
+ *   staging of the per-kernel-offset feature gathers") instead of gathering L2 -> registers per offset; runs that do not fit
+ *   the 32-row window gather directly.  Like row_order a pure performance hint: results are bit-identical either way.    */
+typedef enum vc_conv_flags { VC_CONV_SORTED_ROWS = 1 } vc_conv_flags;
 int vc_conv_forward(const float* x, int64_t n_in, const int32_t* pair_fwd, int64_t n_out, int kv,
-                    const float* weight, int cin, int cout, const int32_t* row_order, int operand_type, float* y,
-                    void* stream);
+                    const float* weight, int cin, int cout, const int32_t* row_order, int operand_type, int flags,
+                    float* y, void* stream);
 int vc_conv_backward_input(const float* dy, const float* dy_centre, int64_t n_src, const int32_t* tbl,
                            int64_t n_in, int kv, const float* weight, int cin, int cout, int mirror, int centre,
-                           const int32_t* rep, const int32_t* row_order, int operand_type, float* dx, void* stream);
+                           const int32_t* rep, const int32_t* row_order, int operand_type, int flags, float* dx,
+                           void* stream);
 
 /* Forward conv with a BatchNorm epilogue (fp32 operands; query vc_conv_epilogue_supported for the shape first):
- *   VC_EPI_STATS   training: besides y the kernel writes per-64-row-block, per-channel (sum, sum of squares) to
- *                  stats_partial [ceil(n_out/64)][2][cout] (vc_conv_stats_partial_floats floats) for vc_bn_stats_from_partial
- *                  -- the statistics pass no longer re-reads y;
+ *   VC_EPI_STATS   training: besides y the kernel writes per-channel (sum, sum of squares) partial rows [rows][2][cout] --
+ *                  one per 64-row block, or one per 16-row wave tile on the LDS-window kernel (no barrier in the epilogue);
+ *                  vc_conv_stats_partial_floats gives the size for the same (shape, flags) -- for vc_bn_stats_from_partial:
+ *                  the statistics pass no longer re-reads y;
  *   VC_EPI_AFFINE  eval: y = relu?(conv * (gamma / sqrt(var + eps)) + (beta - mean * gamma / sqrt(var + eps))) in the store,
  *                  i.e. conv + BatchNorm1d(eval) + ReLU (spconv_backbone.py:101-105) as ONE launch.                     */
 typedef enum vc_epilogue { VC_EPI_NONE = 0, VC_EPI_STATS = 1, VC_EPI_AFFINE = 2 } vc_epilogue;
 int vc_conv_epilogue_supported(int64_t n_in, int cin, int cout, int kv, int operand_type);
-size_t vc_conv_stats_partial_floats(int64_t n_out, int cout);
+size_t vc_conv_stats_partial_floats(int64_t n_in, int64_t n_out, int cin, int cout, int kv, int flags);
 int vc_conv_forward_epilogue(const float* x, int64_t n_in, const int32_t* pair_fwd, int64_t n_out, int kv,
-                             const float* weight, int cin, int cout, const int32_t* row_order, int epilogue,
+                             const float* weight, int cin, int cout, const int32_t* row_order, int epilogue, int flags,
                              float* stats_partial, const float* mean, const float* var, const float* gamma,
                              const float* beta, float eps, int relu, float* y, void* stream);
 

@@ -50,7 +50,7 @@ class OracleBackend:
         dt = {"f16": torch.float16, "bf16": torch.bfloat16}[operand]
         return [t.to(dt).to(t.dtype) for t in ts]
 
-    def conv_forward(self, x, weight, pair_fwd, order=None, operand="f32"):
+    def conv_forward(self, x, weight, pair_fwd, order=None, operand="f32", sorted_rows=False):
         x, weight = self._operands(operand, weight.shape[-1], weight.shape[0], x, weight)
         return sparse_ref.conv_forward(x, weight, _np(pair_fwd))
 
@@ -58,7 +58,7 @@ class OracleBackend:
         return False  # fused epilogues are a product optimisation; the oracle always takes the plain path
 
     def conv_backward_input(self, dy, weight, tbl, n_in, mirror, centre=-1, rep=None, order=None, operand="f32",
-                            group_ws=None):
+                            group_ws=None, sorted_rows=False):
         """dX of the three conv flavours, in the product's calling convention (include/virconv_hip.h).
 
         SubM (mirror=True, tbl = pair_fwd): the EXACT transpose of the forward gather,

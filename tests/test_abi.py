@@ -49,7 +49,7 @@ def test_host_side_queries_and_argument_validation_without_gpu():
     # invalid arguments are rejected with a status code + message, never exit()/abort (include/virconv_hip.h)
     st = lib.vc_hash_build(None, 10, 5, _lib.i32arr([1, 2, 3]), None, 0, None)
     assert st == _lib.VC_EINVAL and b"ndim" in lib.vc_last_error()
-    st = lib.vc_conv_forward(None, 0, None, 10, 27, None, 8, 8, None, 0, None, None)
+    st = lib.vc_conv_forward(None, 0, None, 10, 27, None, 8, 8, None, 0, 0, None, None)
     assert st == _lib.VC_EINVAL
     st = lib.vc_gather_rows(None, None, 7, 4, None, 0, None, None, None)
     assert st == _lib.VC_EINVAL and b"multiple of 4" in lib.vc_last_error()
@@ -68,15 +68,18 @@ def test_new_entry_points_validate_their_arguments_without_gpu():
     assert lib.vc_row_order(dummy, 10, 33, None, -1, 1024, dummy, None) == _lib.VC_EINVAL
     assert lib.vc_row_order(None, 0, 27, None, -1, 1024, None, None) == _lib.VC_OK          # empty table: nothing to do
     # conv epilogues / operand types
-    assert lib.vc_conv_forward(dummy, 4, dummy, 4, 27, dummy, 8, 8, None, 7, dummy, None) == _lib.VC_EINVAL
+    assert lib.vc_conv_forward(dummy, 4, dummy, 4, 27, dummy, 8, 8, None, 7, 0, dummy, None) == _lib.VC_EINVAL
     assert b"operand_type" in lib.vc_last_error()
-    assert lib.vc_conv_forward_epilogue(dummy, 4, dummy, 4, 27, dummy, 8, 8, None, 5, None, None, None, None, None, 0.0, 0,
+    assert lib.vc_conv_forward_epilogue(dummy, 4, dummy, 4, 27, dummy, 8, 8, None, 5, 0, None, None, None, None, None, 0.0, 0,
                                         dummy, None) == _lib.VC_EINVAL
-    assert lib.vc_conv_forward_epilogue(dummy, 4, dummy, 4, 27, dummy, 8, 8, None, 1, None, None, None, None, None, 0.0, 0,
+    assert lib.vc_conv_forward_epilogue(dummy, 4, dummy, 4, 27, dummy, 8, 8, None, 1, 0, None, None, None, None, None, 0.0, 0,
                                         dummy, None) == _lib.VC_EINVAL and b"stats_partial" in lib.vc_last_error()
     assert lib.vc_conv_epilogue_supported(1000, 64, 32, 27, 0) == 1 and lib.vc_conv_epilogue_supported(1000, 64, 32, 27, 1) == 0
     assert lib.vc_conv_epilogue_supported(1 << 24, 64, 32, 27, 0) == 0                      # source >= 2 GiB: fallback kernel
-    assert lib.vc_conv_stats_partial_floats(130, 32) == 3 * 2 * 32
+    assert lib.vc_conv_stats_partial_floats(130, 130, 8, 32, 27, 0) == 3 * 2 * 32
+    # the LDS-window kernel (sorted-rows hint, >= 16 source channels) writes one partial row per 16-row wave tile
+    assert lib.vc_conv_stats_partial_floats(130, 130, 32, 32, 27, 1) == 3 * 4 * 2 * 32
+    assert lib.vc_conv_stats_partial_floats(130, 130, 8, 32, 27, 1) == 3 * 2 * 32
     # RoI grid pooling
     assert lib.vc_voxel_index_workspace_bytes(1000, 2, shp) > 2 * 21 * 400 * 352 // 8
     assert lib.vc_voxel_query(dummy, 1 << 30, 10, 2, shp, dummy, dummy, dummy, 5, 1, 1, 32, 1.0, 4, dummy, dummy, None) == _lib.VC_EINVAL

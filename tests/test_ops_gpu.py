@@ -731,3 +731,140 @@ def test_load_virtual_points_reads_the_fp16_npy_layout(hip_backend, tmp_path):
     np.testing.assert_array_equal(t.cpu().numpy(), arr)
     out = data.input_point_discard_device(t, bin_num=2, rate=0.8, seed=1)
     assert out.dtype == torch.float32 and 0 < out.shape[0] < arr.shape[0]
+
+
+# ------------------------------------------------------------------------------------------------ LDS row-window gather-GEMM (v3)
+def _sorted_scene(seed=41, bs=2):
+    """Coordinate-SORTED active set with surface-like occupancy (what the SubM convs of stages 2-4 see): the output of a
+    stride-2 conv over voxelised synthetic frames."""
+    from virconv_amd import data
+    feats, coords = [], []
+    for b in range(bs):
+        fr = synth.make_frame(seed + b, n_lidar=6000, n_virtual=9000)
+        pts = np.concatenate([fr["points_lidar"], fr["points_virtual"]])
+        _, c, _ = geometry.voxelize(pts, synth.VOXEL_SIZE, synth.POINT_CLOUD_RANGE, 5, 40000)
+        coords.append(np.concatenate([np.full((c.shape[0], 1), b, np.int32), c], 1))
+    idx = np.concatenate(coords)
+    oi, osh, _, _ = sparse_ref.sparse_rulebook(idx, [81, 1600, 1408], bs, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+    return oi, list(osh)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 16), (16, 32), (64, 32), (32, 64), (32, 32), (64, 64), (16, 8), (64, 4)])
+def test_window_gather_gemm_is_bit_identical_to_the_direct_kernel_and_matches_the_oracle(hip_backend, cin, cout):
+    """VC_CONV_SORTED_ROWS (LDS row windows, per-wave, with the direct-gather fall-back for runs that do not fit) is a pure
+    scheduling choice: forward and backward-input are bit-identical to the direct kernel, and within 1e-4 of the oracle."""
+    rng = np.random.default_rng(100 * cin + cout)
+    idx, shape = _sorted_scene()
+    n = idx.shape[0]
+    assert n > 20000
+    it = torch.from_numpy(idx).cuda()
+    pair, _ = hip_backend.subm_rulebook(it, shape, (3, 3, 3), (1, 1, 1), want_rep=False)
+    x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).cuda()
+    g = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.standard_normal((cout, 3, 3, 3, cin)) / 5).astype(np.float32)).cuda()
+    y_dir = hip_backend.conv_forward(x, w, pair)
+    y_win = hip_backend.conv_forward(x, w, pair, sorted_rows=True)
+    assert torch.equal(y_win, y_dir)
+    assert torch.equal(y_win, hip_backend.conv_forward(x, w, pair, sorted_rows=True))      # run-to-run bit-stable
+    dx_dir = hip_backend.conv_backward_input(g, w, pair, n, mirror=True)
+    dx_win = hip_backend.conv_backward_input(g, w, pair, n, mirror=True, sorted_rows=True)
+    assert torch.equal(dx_win, dx_dir)
+    pref = sparse_ref.subm_rulebook(idx, shape, (3, 3, 3))
+    yref = sparse_ref.conv_forward(x.cpu().double(), w.cpu().double(), pref)
+    assert _rel_err(y_win.cpu().numpy(), yref.numpy()) < TOL
+    np.testing.assert_allclose(y_win.cpu().numpy(), yref.numpy(), rtol=1e-3, atol=1e-4)   # element-wise beside the max-norm
+    dxref, _ = sparse_ref.conv_backward(torch.zeros((n, cin), dtype=torch.float64), w.cpu().double(), pref, g.cpu().double())
+    assert _rel_err(dx_win.cpu().numpy(), dxref.numpy()) < TOL
+    np.testing.assert_allclose(dx_win.cpu().numpy(), dxref.numpy(), rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("case", ["permuted", "tiny", "ragged", "kv9", "kv3", "strided_pairs"])
+def test_window_gather_gemm_hint_is_safe_on_any_table(hip_backend, case):
+    """The hint is only a hint: row orders that give no contiguous runs (every (tile, group) falls back to direct gathers),
+    1 / 15 / 65 rows, 2-D (KV = 9) and (3,1,1) (KV = 3) kernels, a strided conv's table -- always the direct kernel's bits."""
+    rng = np.random.default_rng(7)
+    cin, cout = 32, 32
+    if case in ("permuted", "tiny", "ragged"):
+        idx, shape = _sorted_scene(43, 1)
+        if case == "permuted":
+            idx = idx[rng.permutation(idx.shape[0])]
+        elif case == "tiny":
+            idx = idx[:1]
+        else:
+            idx = idx[:65 + 15]
+        it = torch.from_numpy(np.ascontiguousarray(idx)).cuda()
+        pair, _ = hip_backend.subm_rulebook(it, shape, (3, 3, 3), (1, 1, 1), want_rep=False)
+        n_in = n_out = idx.shape[0]
+        ksz = (3, 3, 3)
+    elif case == "kv9":
+        idx = _indices2(5, 6000, dup=False)
+        idx = idx[np.lexsort((idx[:, 2], idx[:, 1], idx[:, 0]))]
+        pair, _ = hip_backend.subm_rulebook(torch.from_numpy(np.ascontiguousarray(idx)).cuda(), (160, 60), (3, 3), (1, 1), want_rep=False)
+        n_in = n_out = idx.shape[0]
+        ksz = (3, 3)
+    else:
+        idx, shape = _sorted_scene(44, 1)
+        it = torch.from_numpy(idx).cuda()
+        if case == "kv3":
+            oi, osh, pair, _ = hip_backend.sparse_rulebook(it, shape, 1, (3, 1, 1), (2, 1, 1), (0, 0, 0), (1, 1, 1))
+            ksz = (3, 1, 1)
+        else:
+            oi, osh, pair, _ = hip_backend.sparse_rulebook(it, shape, 1, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1))
+            ksz = (3, 3, 3)
+        n_in, n_out = idx.shape[0], oi.shape[0]
+    x = torch.from_numpy(rng.standard_normal((n_in, cin)).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.standard_normal((cout,) + ksz + (cin,)) / 5).astype(np.float32)).cuda()
+    y_dir = hip_backend.conv_forward(x, w, pair)
+    y_win = hip_backend.conv_forward(x, w, pair, sorted_rows=True)
+    assert y_win.shape == (n_out, cout) and torch.equal(y_win, y_dir)
+    yref = sparse_ref.conv_forward(x.cpu().double(), w.cpu().double(), pair.cpu().numpy())
+    assert _rel_err(y_win.cpu().numpy(), yref.numpy()) < TOL
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (64, 32), (32, 64)])
+def test_window_gather_gemm_epilogues(hip_backend, cin, cout):
+    """BatchNorm epilogues of the window kernel: per-WAVE partial statistics (no barrier) feed the same mean / var as the
+    pass over y; the folded eval-mode BN(+ReLU) equals conv-then-BN."""
+    rng = np.random.default_rng(cin + 7 * cout)
+    idx, shape = _sorted_scene(45, 1)
+    n = idx.shape[0]
+    it = torch.from_numpy(idx).cuda()
+    pair, _ = hip_backend.subm_rulebook(it, shape, (3, 3, 3), (1, 1, 1), want_rep=False)
+    x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.standard_normal((cout, 3, 3, 3, cin)) / 5).astype(np.float32)).cuda()
+    y_ref = hip_backend.conv_forward(x, w, pair)
+    y, partial = hip_backend.conv_forward_stats(x, w, pair, sorted_rows=True)
+    assert torch.equal(y, y_ref)
+    p = partial.view(-1, 2, cout).double()
+    assert p.shape[0] == 4 * ((n + 63) // 64)                       # one partial row per 16-row wave tile
+    yd = y_ref.double()
+    np.testing.assert_allclose(p[:, 0].sum(0).cpu().numpy(), yd.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(p[:, 1].sum(0).cpu().numpy(), (yd * yd).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    g, b = torch.rand(cout).cuda() + 0.5, torch.randn(cout).cuda()
+    rm1, rv1, rm2, rv2 = torch.zeros(cout).cuda(), torch.ones(cout).cuda(), torch.zeros(cout).cuda(), torch.ones(cout).cuda()
+    o1, m1, v1 = hip_backend.bn_forward(y, g, b, rm1, rv1, True, 0.01, 1e-3, True, partial=partial)
+    o2, m2, v2 = hip_backend.bn_forward(y, g, b, rm2, rv2, True, 0.01, 1e-3, True)
+    for a, c in ((m1, m2), (v1, v2), (rm1, rm2), (rv1, rv2), (o1, o2)):
+        assert float((a - c).abs().max()) <= 1e-5 * max(1.0, float(c.abs().max()))
+    _, partial2 = hip_backend.conv_forward_stats(x, w, pair, sorted_rows=True)
+    assert torch.equal(partial, partial2)
+    mean, var = torch.randn(cout).cuda() * 0.2, torch.rand(cout).cuda() + 0.3
+    fused = hip_backend.conv_forward_affine(x, w, pair, None, mean, var, g, b, 1e-3, True, sorted_rows=True)
+    assert torch.equal(fused, hip_backend.conv_forward_affine(x, w, pair, None, mean, var, g, b, 1e-3, True))
+
+
+def test_backbone_marks_sorted_tables_and_uses_the_window_kernel(hip_backend):
+    """The geometry plan tags the SubM rulebooks of stages 2-4 (rows = output of a strided conv: ascending order)."""
+    import bench
+    from virconv_amd.backbone import VirConvL8x
+    batch = bench.make_batch([0], torch.device("cuda", 0), training=False)
+    model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).cuda().eval()
+    plan = model.build_plan(batch["voxel_coords"], 1, batch["calib"], None, batch)
+    flags = [[rb.sorted_rows for rb in st["rb3d"].values()] for st in plan["stages"]]
+    assert flags[0] == [False]                                   # stage 1: first-touch order
+    assert all(f == [False, True] for f in flags[1:])            # strided conv table, then the SubM table on its sorted output
+    assert not any(rb.sorted_rows for st in plan["stages"] for rb in st["rb2d"].values())
+    for st in plan["stages"][1:]:
+        oi = st["out_indices"].long()
+        lin = ((oi[:, 0] * st["out_shape"][0] + oi[:, 1]) * st["out_shape"][1] + oi[:, 2]) * st["out_shape"][2] + oi[:, 3]
+        assert bool((lin[1:] > lin[:-1]).all())

@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--rt", type=int, default=0, help="v2 row tiles per wave (vc_debug_set conv_rt); 0 = heuristic")
     ap.add_argument("--operand", default="f32", choices=["f32", "f16", "bf16"], help="MFMA operand type")
     ap.add_argument("--bw-legacy", action="store_true", help="offset-major block order in the weight-gradient kernel")
+    ap.add_argument("--no-window", action="store_true", help="never use the LDS row-window gather-GEMM (A/B)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     be = ops.get_backend()
@@ -113,11 +114,12 @@ def main():
         flops = 2.0 * pairs * cin * cout
         byts = 4.0 * (rb.n_in * cin + rb.n_out * cout + kv * cin * cout) + 4.0 * kv * rb.n_out
         res = {}
+        srt = rb.sorted_rows and not args.no_window
         if args.only in ("all", "fwd"):
-            res["fwd"] = timeit(lambda: be.conv_forward(x, w, rb.pair_fwd, order=rb.order_fwd, operand=args.operand), args.iters)
+            res["fwd"] = timeit(lambda: be.conv_forward(x, w, rb.pair_fwd, order=rb.order_fwd, operand=args.operand, sorted_rows=srt), args.iters)
         if args.only in ("all", "bwd"):
             if rb.kind == "subm":
-                res["bwd"] = timeit(lambda: be.conv_backward_input(dy, w, rb.pair_fwd, rb.n_in, True, rb.centre, rb.rep, order=rb.order_bwd, operand=args.operand), args.iters)
+                res["bwd"] = timeit(lambda: be.conv_backward_input(dy, w, rb.pair_fwd, rb.n_in, True, rb.centre, rb.rep, order=rb.order_bwd, operand=args.operand, sorted_rows=srt), args.iters)
             else:
                 res["bwd"] = timeit(lambda: be.conv_backward_input(dy, w, rb.pair_bwd, rb.n_in, False, order=rb.order_bwd, operand=args.operand), args.iters)
         if args.only in ("all", "dw"):
@@ -127,7 +129,7 @@ def main():
             return flops / (us * 1e-6) / 1e12
 
         f, b, d = res.get("fwd"), res.get("bwd"), res.get("dw")
-        line = f"{name:34s} {rb.n_in:7d} {rb.n_out:7d} {pairs / max(rb.n_out, 1):5.2f} | "
+        line = f"{name + (' [win]' if srt else ''):34s} {rb.n_in:7d} {rb.n_out:7d} {pairs / max(rb.n_out, 1):5.2f} | "
         line += (f"{f:8.1f} {tf(f):6.2f} {100 * tf(f) / PEAK:5.1f} {byts / (f * 1e-6) / 1e9:6.0f} | " if f else " " * 34 + "| ")
         line += (f"{b:8.1f} {tf(b):6.2f} {100 * tf(b) / PEAK:5.1f} | " if b else " " * 23 + "| ")
         line += (f"{d:8.1f} {tf(d):6.2f} {100 * tf(d) / PEAK:5.1f}" if d else "")

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VIRCONV_LIB", os.path.join(_HERE, "libvirconv_hip.so"))  # override: A/B builds only
 
 OPERAND_TYPES = {"f32": 0, "f16": 1, "bf16": 2}  # vc_operand (include/virconv_hip.h)
+CONV_SORTED_ROWS = 1                              # vc_conv_flags
 VC_OK, VC_EINVAL, VC_ECAPACITY, VC_EHIP = 0, -1, -2, -3
 
 _P, _I64, _I, _SZ, _F, _D = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_float, C.c_double
@@ -30,16 +31,16 @@ SIGNATURES = {
     "vc_spconv_workspace_bytes": (_SZ, [_I, _I, _P]),
     "vc_spconv_mark_count": (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P, _P]),
     "vc_spconv_emit_pairs": (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _I64, _P, _P, _P, _P]),
-    "vc_conv_forward": (_I, [_P, _I64, _P, _I64, _I, _P, _I, _I, _P, _I, _P, _P]),
-    "vc_conv_backward_input": (_I, [_P, _P, _I64, _P, _I64, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
+    "vc_conv_forward": (_I, [_P, _I64, _P, _I64, _I, _P, _I, _I, _P, _I, _I, _P, _P]),
+    "vc_conv_backward_input": (_I, [_P, _P, _I64, _P, _I64, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
     "vc_voxel_index_workspace_bytes": (_SZ, [_I64, _I, _P]),
     "vc_voxel_index_build": (_I, [_P, _I64, _I, _P, _P, _SZ, _P]),
     "vc_voxel_query": (_I, [_P, _SZ, _I64, _I, _P, _P, _P, _P, _I64, _I, _I, _I, _F, _I, _P, _P, _P]),
     "vc_group_points": (_I, [_I, _I64, _I, _I, _P, _P, _P, _P, _P, _P]),
     "vc_group_points_grad": (_I, [_I, _I64, _I, _I64, _I, _P, _P, _P, _P, _P, _P]),
     "vc_conv_epilogue_supported": (_I, [_I64, _I, _I, _I, _I]),
-    "vc_conv_stats_partial_floats": (_SZ, [_I64, _I]),
-    "vc_conv_forward_epilogue": (_I, [_P, _I64, _P, _I64, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _F, _I, _P, _P]),
+    "vc_conv_stats_partial_floats": (_SZ, [_I64, _I64, _I, _I, _I, _I]),
+    "vc_conv_forward_epilogue": (_I, [_P, _I64, _P, _I64, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _F, _I, _P, _P]),
     "vc_bn_stats_from_partial": (_I, [_P, _I64, _I64, _I, _P, _P, _P, _P, _P, _F, _P]),
     "vc_random_keep": (_I, [_I64, _I64, C.c_uint64, _P, _P]),
     "vc_row_order": (_I, [_P, _I64, _I, _P, _I, _I, _P, _P]),

@@ -10,8 +10,9 @@ What is different from running the reference file on the facade (which also work
   * the two 3-D SubM convs of a block share one rulebook (same coordinates; the reference gives them different
     indice_keys :186,199 and rebuilds), likewise the two 2-D convs
   * BatchNorm1d+ReLU run as a fused two-pass HIP op
-  * layer discard (StVD) is a real device gather with injectable keep indices; ``LAYER_DISCARD_MODE`` selects the
-    spconv-1.x in-place behaviour (paper) or the spconv-2.x silent no-op
+  * layer discard (StVD): ``LAYER_DISCARD_MODE`` selects the spconv-2.x silent no-op (the default: what the reference does
+    under its required spconv version) or the spconv-1.x in-place behaviour of the paper -- then a real device
+    gather with injectable keep indices
 """
 from __future__ import annotations
 
@@ -322,7 +323,10 @@ class VirConvL8x(nn.Module):
         self.return_num_features_as_dict = _cfg_get(model_cfg, "RETURN_NUM_FEATURES_AS_DICT", False)
         self.out_features = _cfg_get(model_cfg, "OUT_FEATURES", 64)
         self.layer_discard_rate = _cfg_get(model_cfg, "LAYER_DISCARD_RATE", 0.0)
-        self.layer_discard_mode = _cfg_get(model_cfg, "LAYER_DISCARD_MODE", "spconv1_inplace")
+        # default = what the reference does under its required spconv 2.x: layer_voxel_discard rebinds a local and returns
+        # None, i.e. NO discard -- the released checkpoints were trained that way.  "spconv1_inplace" is the
+        # opt-in paper / spconv-1.x behaviour (a real discard).
+        self.layer_discard_mode = _cfg_get(model_cfg, "LAYER_DISCARD_MODE", "spconv2_noop")
         assert self.layer_discard_mode in ("spconv1_inplace", "spconv2_noop")
         self.plan_ahead = bool(_cfg_get(model_cfg, "PLAN_AHEAD", True))
         num_filters = _cfg_get(model_cfg, "NUM_FILTERS")
@@ -441,7 +445,10 @@ class VirConv8x(nn.Module):
         self.return_num_features_as_dict = _cfg_get(model_cfg, "RETURN_NUM_FEATURES_AS_DICT", False)
         self.out_features = _cfg_get(model_cfg, "OUT_FEATURES", 64)
         self.layer_discard_rate = _cfg_get(model_cfg, "LAYER_DISCARD_RATE", 0.0)
-        self.layer_discard_mode = _cfg_get(model_cfg, "LAYER_DISCARD_MODE", "spconv1_inplace")
+        # default = what the reference does under its required spconv 2.x: layer_voxel_discard rebinds a local and returns
+        # None, i.e. NO discard -- the released checkpoints were trained that way.  "spconv1_inplace" is the
+        # opt-in paper / spconv-1.x behaviour (a real discard).
+        self.layer_discard_mode = _cfg_get(model_cfg, "LAYER_DISCARD_MODE", "spconv2_noop")
         assert self.layer_discard_mode in ("spconv1_inplace", "spconv2_noop")
         self.mm = bool(_cfg_get(model_cfg, "MM", False))
         self.plan_ahead = bool(_cfg_get(model_cfg, "PLAN_AHEAD", True))

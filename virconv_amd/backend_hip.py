@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import OPERAND_TYPES, check, i32arr, f32arr
+from ._lib import CONV_SORTED_ROWS, OPERAND_TYPES, check, i32arr, f32arr
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -150,7 +150,9 @@ class HipBackend:
         return order
 
     def conv_forward(self, x: torch.Tensor, weight: torch.Tensor, pair_fwd: torch.Tensor,
-                     order: Optional[torch.Tensor] = None, operand: str = "f32") -> torch.Tensor:
+                     order: Optional[torch.Tensor] = None, operand: str = "f32", sorted_rows: bool = False) -> torch.Tensor:
+        """`sorted_rows`: VC_CONV_SORTED_ROWS hint (table rows and the rows they gather are in ascending coordinate order):
+        the kernel stages the gathers through LDS row windows.  Results are bit-identical with and without it."""
         x = _need(x, torch.float32, "features")
         weight = _need(weight, torch.float32, "weight")
         pair_fwd = _need(pair_fwd, torch.int32, "pair_fwd")
@@ -160,7 +162,8 @@ class HipBackend:
         y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
         rec = self._trace_open(pair_fwd, x.shape[0], cin, cout) if self._traced("fwd", cin, cout) else None
         check(self.lib.vc_conv_forward(_ptr(x), x.shape[0], _ptr(pair_fwd), n_out, kv, _ptr(weight), cin, cout,
-                                       _ptr(order), OPERAND_TYPES[operand], _ptr(y), _stream()), "vc_conv_forward")
+                                       _ptr(order), OPERAND_TYPES[operand], CONV_SORTED_ROWS if sorted_rows else 0, _ptr(y),
+                                       _stream()), "vc_conv_forward")
         if rec is not None:
             self._trace_close(rec)
         return y
@@ -169,7 +172,7 @@ class HipBackend:
         return bool(self.lib.vc_conv_epilogue_supported(n_in, cin, cout, kv, OPERAND_TYPES[operand]))
 
     def conv_forward_stats(self, x: torch.Tensor, weight: torch.Tensor, pair_fwd: torch.Tensor,
-                           order: Optional[torch.Tensor] = None):
+                           order: Optional[torch.Tensor] = None, sorted_rows: bool = False):
         """Forward conv that also emits the per-block BatchNorm partial sums (VC_EPI_STATS) -> (y_raw, partial)."""
         x = _need(x, torch.float32, "features")
         weight = _need(weight, torch.float32, "weight")
@@ -177,17 +180,19 @@ class HipBackend:
         kv, n_out = pair_fwd.shape
         cout, cin = weight.shape[0], weight.shape[-1]
         y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
-        partial = torch.empty((self.lib.vc_conv_stats_partial_floats(n_out, cout),), dtype=torch.float32, device=x.device)
+        flags = CONV_SORTED_ROWS if sorted_rows else 0
+        partial = torch.empty((self.lib.vc_conv_stats_partial_floats(x.shape[0], n_out, cin, cout, kv, flags),),
+                              dtype=torch.float32, device=x.device)
         rec = self._trace_open(pair_fwd, x.shape[0], cin, cout) if self._traced("fwd", cin, cout) else None
         check(self.lib.vc_conv_forward_epilogue(_ptr(x), x.shape[0], _ptr(pair_fwd), n_out, kv, _ptr(weight), cin, cout,
-                                                _ptr(order), 1, _ptr(partial), None, None, None, None, 0.0, 0, _ptr(y),
-                                                _stream()), "vc_conv_forward_epilogue")
+                                                _ptr(order), 1, flags, _ptr(partial), None, None, None, None, 0.0, 0,
+                                                _ptr(y), _stream()), "vc_conv_forward_epilogue")
         if rec is not None:
             self._trace_close(rec)
         return y, partial
 
     def conv_forward_affine(self, x: torch.Tensor, weight: torch.Tensor, pair_fwd: torch.Tensor, order, mean, var, gamma,
-                            beta, eps: float, relu: bool) -> torch.Tensor:
+                            beta, eps: float, relu: bool, sorted_rows: bool = False) -> torch.Tensor:
         """conv + eval-mode BatchNorm (+ReLU) in one launch (VC_EPI_AFFINE)."""
         x = _need(x, torch.float32, "features")
         weight = _need(weight, torch.float32, "weight")
@@ -196,15 +201,16 @@ class HipBackend:
         cout, cin = weight.shape[0], weight.shape[-1]
         y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
         check(self.lib.vc_conv_forward_epilogue(_ptr(x), x.shape[0], _ptr(pair_fwd), n_out, kv, _ptr(weight), cin, cout,
-                                                _ptr(order), 2, None, _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta),
-                                                float(eps), 1 if relu else 0, _ptr(y), _stream()),
+                                                _ptr(order), 2, CONV_SORTED_ROWS if sorted_rows else 0, None, _ptr(mean),
+                                                _ptr(var), _ptr(gamma), _ptr(beta), float(eps), 1 if relu else 0, _ptr(y),
+                                                _stream()),
               "vc_conv_forward_epilogue")
         return y
 
     def conv_backward_input(self, dy: torch.Tensor, weight: torch.Tensor, tbl: torch.Tensor, n_in: int, mirror: bool,
                             centre: int = -1, rep: Optional[torch.Tensor] = None,
                             order: Optional[torch.Tensor] = None, operand: str = "f32",
-                            group_ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+                            group_ws: Optional[torch.Tensor] = None, sorted_rows: bool = False) -> torch.Tensor:
         """`group_ws`: workspace from group_sum_prepare whose header already holds max|dy| (left there by bn_backward)."""
         dy = _need(dy, torch.float32, "grad_out")
         weight = _need(weight, torch.float32, "weight")
@@ -226,7 +232,8 @@ class HipBackend:
         rec = self._trace_open(tbl, dy.shape[0], cout, cin) if self._traced("bwd", cout, cin) else None
         check(self.lib.vc_conv_backward_input(_ptr(src), _ptr(src_centre), dy.shape[0], _ptr(tbl), n_in, kv, _ptr(weight),
                                               cin, cout, 1 if mirror else 0, centre if rep is not None else -1,
-                                              _ptr(rep), _ptr(order), OPERAND_TYPES[operand], _ptr(dx), _stream()),
+                                              _ptr(rep), _ptr(order), OPERAND_TYPES[operand],
+                                              CONV_SORTED_ROWS if sorted_rows else 0, _ptr(dx), _stream()),
               "vc_conv_backward_input")
         if rec is not None:
             self._trace_close(rec)

@@ -43,16 +43,24 @@ def _stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    # A/B builds (developer only): VIRCONV_LIB_OUT=<path> VIRCONV_HIPCC_EXTRA="-DVC_V2_SCHED=0" python -m virconv_amd.build
+    # writes a second library that tools/kbench.py can load through VIRCONV_LIB=<path>
+    out, extra_env = os.environ.get("VIRCONV_LIB_OUT"), os.environ.get("VIRCONV_HIPCC_EXTRA", "").split()
+    if out:
+        return _build_to(out, os.path.join(HERE, "build_ab"), extra_env, verbose)
     if not force and not _stale():
         return LIB
+    return _build_to(LIB, os.path.join(HERE, "build"), extra_env, verbose)
+
+
+def _build_to(LIB: str, objdir: str, extra_env, verbose: bool) -> str:
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
 
     def compile_one(item):
         src, extra = item
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *COMMON, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *COMMON, *extra, *extra_env, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print("[virconv_amd.build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

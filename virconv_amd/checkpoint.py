@@ -28,24 +28,34 @@ def find_all_spconv_keys(model: nn.Module, prefix: str = "") -> Set[str]:
     return keys
 
 
-def adapt_spconv_weight(val: torch.Tensor, want_shape: torch.Size) -> torch.Tensor:
+def adapt_spconv_weight(val: torch.Tensor, want_shape: torch.Size, source_layout: str = "auto") -> torch.Tensor:
     """Return `val` re-laid out to `want_shape` = (Cout, *k, Cin) if it is a known foreign layout, else `val` itself.
 
-    (*k, Cin, Cout)  spconv 1.x  -> move the last axis to the front.  (The reference additionally tries a plain
-    transpose(-1, -2) because ITS live layout depends on the installed spconv build; ours is fixed, so the only foreign
-    on-disk layout is spconv 1.x's.)
+    On-disk layouts of spconv conv weights (detector3d_template.py:358-370):
+      (Cout, *k, Cin)   spconv 2.x implicit-GEMM builds -- ours; released VirConv checkpoints
+      (*k, Cin, Cout)   spconv 1.x              -> move the last axis to the front         ('spconv1')
+      (*k, Cout, Cin)   spconv 2.x "native"     -> move the second-to-last axis to the front ('native')
+    The two foreign layouts have the same shape when Cin == Cout; `source_layout='auto'` then assumes spconv 1.x (the case
+    the reference's loader is written for), pass 'native' to override.  (The reference's transpose(-1, -2) branch serves a
+    LIVE model in native layout; our live layout is fixed.)
     """
+    assert source_layout in ("auto", "spconv1", "native")
     if tuple(val.shape) == tuple(want_shape) or val.dim() != len(want_shape) or val.dim() < 3:
         return val
     nd = val.dim()
-    v1 = val.permute(nd - 1, *range(nd - 1))                       # (*k,Cin,Cout) -> (Cout,*k,Cin)
-    if tuple(v1.shape) == tuple(want_shape):
-        return v1.contiguous()
+    cands = []
+    if source_layout in ("auto", "spconv1"):
+        cands.append(val.permute(nd - 1, *range(nd - 1)))                    # (*k,Cin,Cout) -> (Cout,*k,Cin)
+    if source_layout in ("auto", "native"):
+        cands.append(val.permute(nd - 2, *range(nd - 2), nd - 1))            # (*k,Cout,Cin) -> (Cout,*k,Cin)
+    for v in cands:
+        if tuple(v.shape) == tuple(want_shape):
+            return v.contiguous()
     return val
 
 
-def load_state_dict_adapted(model: nn.Module, state_disk: Dict[str, torch.Tensor], *, strict: bool = True
-                            ) -> Tuple[Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:
+def load_state_dict_adapted(model: nn.Module, state_disk: Dict[str, torch.Tensor], *, strict: bool = True,
+                            source_layout: str = "auto") -> Tuple[Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:
     """Load `state_disk` into `model` the way Detector3DTemplate._load_state_dict does.
 
     Returns (live state_dict after the update, the subset that was actually taken from disk).  Keys missing from the model
@@ -59,7 +69,7 @@ def load_state_dict_adapted(model: nn.Module, state_disk: Dict[str, torch.Tensor
         if key not in live:
             continue
         if key in conv_keys and live[key].shape != val.shape:
-            val = adapt_spconv_weight(val, live[key].shape)
+            val = adapt_spconv_weight(val, live[key].shape, source_layout)
         if live[key].shape == val.shape:
             taken[key] = val
     if strict:

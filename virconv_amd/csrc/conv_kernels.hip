@@ -20,6 +20,11 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ int g_xcd_swizzle_off = 0;  // developer switch (tools/kbench.py --no-xcd)
+// v2 MFMA phase: 1 = all B fragments of an offset are read before its first MFMA and consecutive MFMAs alternate between
+// the output-column accumulators (round 2); 0 = the round-1 order (kept for A/B builds: hipcc -DVC_V2_SCHED=0)
+#ifndef VC_V2_SCHED
+#define VC_V2_SCHED 1
+#endif
 
 // Reduced-precision MFMA operands (BASELINE configs[4]: "fp16 MFMA contraction"): features / gradients / weights stay fp32
 // in HBM, are rounded (RNE) to fp16 or bf16 in registers right before the MFMA, products are exact and accumulate in fp32.
@@ -366,12 +371,20 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
       _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
           _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                        \
               VecLoad<V>::ld(B_ + ((ch * NT + nt) * 64 + lane) * V, b[ch][nt]);                    \
+      if (VC_V2_SCHED && NCH * NT <= 8) __builtin_amdgcn_sched_barrier(0);                         \
       _Pragma("unroll") for (int t = 0; t < RT; ++t) {                                             \
         if (ACT[t]) {                                                                              \
-          _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                       \
-              _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                    \
-                  _Pragma("unroll") for (int j = 0; j < V; ++j)                                    \
-                      acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[t][ch][j], b[ch][nt][j], acc[t][nt], 0, 0, 0); \
+          if constexpr (VC_V2_SCHED != 0) {                                                        \
+            _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                     \
+                _Pragma("unroll") for (int j = 0; j < V; ++j)                                      \
+                    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                              \
+                        acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[t][ch][j], b[ch][nt][j], acc[t][nt], 0, 0, 0); \
+          } else {                                                                                 \
+            _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                     \
+                _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                  \
+                    _Pragma("unroll") for (int j = 0; j < V; ++j)                                  \
+                        acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[t][ch][j], b[ch][nt][j], acc[t][nt], 0, 0, 0); \
+          }                                                                                        \
         }                                                                                          \
       }                                                                                            \
     } else {                                                                                       \
@@ -481,6 +494,294 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
         }
         if (orow[reg] >= 0) out[orow[reg] * CN + n] = v;
       }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------- K6/K7 v3 (LDS row windows)
+// The gather-GEMM for tables whose rows are in ascending coordinate order (the SubM convs of stages 2-4, forward and
+// backward-input): the feature gathers are staged through LDS instead of going L2 -> VGPR per kernel offset.
+//
+// Why it works (tests/analysis_tile_window.py, oracle rulebooks of a synthetic KITTI frame): rows are sorted by (b, z, y, x), so
+// the source rows that the three dx-offsets of one (dz, dy) group gather for a 16-row MFMA tile form ONE nearly contiguous run
+// -- median span 16-18 rows, <= 32 rows for 97.4-98.1 % of the (tile, group) pairs -- and every row of the run is gathered
+// 1.6-2.5 times.  Per (wave, group) the run [lo, lo + span) is loaded ONCE with fully coalesced 16-byte loads (whole 64/128/256-
+// byte rows, 4/8/16 rows per wave instruction), parked in registers while the previous group computes (the registers are the
+// second buffer: no LDS double buffering, no block barrier -- the window is private to the wave), written to the wave's LDS
+// window (row stride CK*4 + 16 bytes: conflict-free ds_read_b128 for the MFMA fragment pattern) and the A fragments of the
+// three offsets are read from there; index -1 reads a zero row.  A (tile, group) whose span exceeds the window gathers
+// directly (buffer loads, as v2).
+//
+// MFMA phase (also what v2 got wrong, visible in its ISA: every B fragment was read into the same four registers and
+// waited for, eight exposed LDS latencies per offset, and the four MFMAs of a K-chunk were issued back to back on ONE
+// accumulator, 40-cycle dependent latency instead of the 32-cycle issue rate): all fragments of a stage are read first
+// (sched_barrier), then the MFMAs alternate between the NT accumulators.
+//
+// W_k staging (per offset, double-buffered, one block barrier per offset) and the XCD-aware block mapping are v2's.
+// EPI == VC_EPI_STATS here writes one partial row per WAVE (16 output rows): no extra barrier in the epilogue.
+static constexpr int kWinRows = 32;
+
+// full-wave integer min / max on the DPP crossbar (row_shr 1/2/4/8 scans a 16-lane row, row_bcast:15 / :31 chain the rows; the
+// result is lane 63's): seven VALU instructions and no LDS round trip -- __shfl_xor lowers to ds_bpermute + a wait per step,
+// six exposed LDS latencies per reduction.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_shift(int identity, int v) {
+  return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROWMASK, 0xf, false);
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+  constexpr int id = 0x7fffffff;
+  v = min(v, dpp_shift<0x111, 0xf>(id, v));
+  v = min(v, dpp_shift<0x112, 0xf>(id, v));
+  v = min(v, dpp_shift<0x114, 0xf>(id, v));
+  v = min(v, dpp_shift<0x118, 0xf>(id, v));
+  v = min(v, dpp_shift<0x142, 0xa>(id, v));
+  v = min(v, dpp_shift<0x143, 0xc>(id, v));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+  constexpr int id = (int)0x80000000;
+  v = max(v, dpp_shift<0x111, 0xf>(id, v));
+  v = max(v, dpp_shift<0x112, 0xf>(id, v));
+  v = max(v, dpp_shift<0x114, 0xf>(id, v));
+  v = max(v, dpp_shift<0x118, 0xf>(id, v));
+  v = max(v, dpp_shift<0x142, 0xa>(id, v));
+  v = max(v, dpp_shift<0x143, 0xc>(id, v));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+template <int CK, int CN, bool BWD, int EPI>
+__global__ void __launch_bounds__(256) gather_gemm_v3_kernel(const float* __restrict__ src, int64_t n_src,
+                                                             const int32_t* __restrict__ tbl,
+                                                             const float* __restrict__ w, float* __restrict__ out,
+                                                             int64_t n_out, int kv, int mirror, ConvEpilogue epi) {
+  static_assert(CK >= 16 && CK % 16 == 0, "the window kernel moves 16-byte chunks of whole rows");
+  static_assert(EPI == VC_EPI_NONE || !BWD, "epilogues exist for the forward kernel only");
+  constexpr int V = 4;
+  constexpr int NCH = CK / 16;
+  constexpr int NT = (CN + 15) / 16;
+  constexpr int NFRAG = NCH * NT * 64;
+  constexpr int BF = NFRAG * V;                 // floats of one W_k image
+  constexpr int BLD = (NFRAG + 255) / 256;
+  constexpr int WS = CK + 4;                    // window row stride in floats (16-byte pad)
+  constexpr int LPR = CK / 4;                   // lanes (16-byte chunks) per row
+  constexpr int RPI = 64 / LPR;                 // rows per wave load instruction
+  constexpr int NWI = kWinRows / RPI;           // load instructions of a full window
+  constexpr int NSTG = (NCH * NT > 8) ? 2 : 1;  // fragment stages per offset (register budget: <= 8 B fragments in flight)
+  constexpr int CPS = NCH / NSTG;               // K-chunks per stage
+  static_assert(NCH % NSTG == 0, "stage split");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* s_b = reinterpret_cast<float*>(smem);                                  // [2][BF]
+  int* s_idx = reinterpret_cast<int*>(s_b + 2 * BF);                            // [kv][64]
+  float* s_win = reinterpret_cast<float*>(s_idx + kv * 64);                     // [4][(kWinRows + 1) * WS]
+  unsigned* s_mask = reinterpret_cast<unsigned*>(s_win + 4 * (kWinRows + 1) * WS);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  int64_t lbid;
+  {
+    const unsigned nb = gridDim.x, bid = blockIdx.x, xcd = bid & 7u, qd = nb >> 3, rm = nb & 7u;
+    lbid = (int64_t)(xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    if (g_xcd_swizzle_off) lbid = bid;
+  }
+  const int64_t brow0 = lbid * 64;
+  const __amdgpu_buffer_rsrc_t rs_src =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)(n_src * CK * 4), 0x00020000);
+  float* win = s_win + wave * ((kWinRows + 1) * WS);
+
+  if (tid == 0) s_mask[0] = 0u;
+  for (int c = lane; c < WS; c += 64) win[kWinRows * WS + c] = 0.f;  // the zero row (index -1 reads it)
+  __syncthreads();
+  {  // phase 0: the block's slice of the pair table -> LDS, active-offset mask
+    const int r = tid & 63;
+    const bool inb = brow0 + r < n_out;
+    for (int k = tid >> 6; k < kv; k += 4) {
+      const int v = inb ? tbl[(int64_t)k * n_out + brow0 + r] : -1;
+      s_idx[k * 64 + r] = v;
+      if (__ballot(v >= 0) != 0ULL && lane == 0) atomicOr(&s_mask[0], 1u << k);
+    }
+  }
+  __syncthreads();
+  unsigned bmask = (unsigned)__builtin_amdgcn_readfirstlane((int)s_mask[0]);
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (bmask != 0u) {
+    float breg[BLD][V];
+    f32x4 wreg[NWI];
+#pragma unroll
+    for (int c = 0; c < NWI; ++c) wreg[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#define VC3_LOAD_B(K)                                                                              \
+  do {                                                                                             \
+    const int kw_ = mirror ? (kv - 1 - (K)) : (K);                                                 \
+    _Pragma("unroll") for (int u = 0; u < BLD; ++u) {                                              \
+      const int f = tid + u * 256;                                                                 \
+      if (NFRAG % 256 == 0 || f < NFRAG) {                                                         \
+        const int fl = f & 63, nt_ = (f >> 6) % NT, ch_ = (f >> 6) / NT;                           \
+        const int n_ = nt_ * 16 + (fl & 15), kk0 = ch_ * 16 + (fl >> 4) * 4;                       \
+        if (CN % 16 == 0 || n_ < CN) {                                                             \
+          if (!BWD) {                                                                              \
+            VecLoad<V>::ld(w + ((int64_t)n_ * kv + kw_) * CK + kk0, breg[u]);                      \
+          } else {                                                                                 \
+            _Pragma("unroll") for (int j = 0; j < V; ++j)                                          \
+                breg[u][j] = w[((int64_t)(kk0 + j) * kv + kw_) * CN + n_];                         \
+          }                                                                                        \
+        } else {                                                                                   \
+          _Pragma("unroll") for (int j = 0; j < V; ++j) breg[u][j] = 0.f;                          \
+        }                                                                                          \
+      }                                                                                            \
+    }                                                                                              \
+  } while (0)
+
+    // group g = offsets 3g .. 3g+2 (the dx triple of one (dz, dy)); gmask bit g = the block visits the group
+    unsigned gmask = 0u;
+    for (int g = 0; g * 3 < kv; ++g)
+      if ((bmask >> (3 * g)) & 7u) gmask |= 1u << g;
+    // span of the rows group G gathers for this wave's tile -> (lo, span); span = 0 when nothing is gathered or it does not fit
+#define VC3_ANALYSE(G, LO, SPAN)                                                                   \
+  do {                                                                                             \
+    const int ko_ = 3 * (G) + q;                                                                   \
+    const int v_ = (q < 3 && ko_ < kv) ? s_idx[ko_ * 64 + wave * 16 + i] : -1;                     \
+    const int mn_ = wave_min_i32((v_ >= 0) ? v_ : 0x7fffffff);                                     \
+    const int mx_ = wave_max_i32(v_);                                                              \
+    const int sp_ = (mx_ >= 0) ? (mx_ - mn_ + 1) : 0;                                              \
+    LO = mn_;                                                                                      \
+    SPAN = (sp_ <= kWinRows) ? sp_ : 0;                                                            \
+  } while (0)
+
+    // coalesced load of rows [LO, LO + SPAN) into wreg: instruction c moves rows LO + c*RPI .. + RPI-1, lane = (row, 16-B
+    // chunk).  Straight-line code: an instruction whose rows lie beyond the span gets an out-of-range offset -- the buffer
+    // bounds check answers it with zeros without touching memory -- so there is no branch and no register merge per load.
+#define VC3_ISSUE(LO, SPAN)                                                                        \
+  do {                                                                                             \
+    const unsigned off0_ = ((unsigned)(LO) + (unsigned)(lane / LPR)) * (unsigned)(CK * 4) + (unsigned)(lane % LPR) * 16u; \
+    _Pragma("unroll") for (int c = 0; c < NWI; ++c) {                                              \
+      const unsigned o_ = (c * RPI < (SPAN)) ? off0_ + (unsigned)(c * RPI * CK * 4) : 0xfffffff0u; \
+      wreg[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, (int)o_, 0, 0)); \
+    }                                                                                              \
+  } while (0)
+
+    int pre_g = __ffs((int)gmask) - 1, pre_lo, pre_span;  // window parked in wreg (span 0: nothing fits / nothing gathered)
+    VC3_ANALYSE(pre_g, pre_lo, pre_span);
+    VC3_ISSUE(pre_lo, pre_span);
+    int cur_g = -1, cur_lo = 0, cur_ok = 0;                // window now in LDS
+
+    int k = __ffs((int)bmask) - 1;
+    bmask &= bmask - 1;
+    VC3_LOAD_B(k);
+    int p = 0;
+    for (;;) {
+      // ---- W_k: registers -> LDS image p, visible after the barrier (which also retires every read of image p^1)
+#pragma unroll
+      for (int u = 0; u < BLD; ++u) {
+        const int f = tid + u * 256;
+        if (NFRAG % 256 == 0 || f < NFRAG)
+          *reinterpret_cast<f32x4*>(s_b + p * BF + f * V) = f32x4{breg[u][0], breg[u][1], breg[u][2], breg[u][3]};
+      }
+      __syncthreads();
+      const int knext = (bmask != 0u) ? (__ffs((int)bmask) - 1) : -1;
+      bmask &= bmask - 1;
+      if (knext >= 0) VC3_LOAD_B(knext);  // in flight under this offset's MFMAs
+
+      // ---- group switch (wave-local): parked rows -> LDS window, then start the load of the next visited group's rows
+      const int g = k / 3;
+      if (g != cur_g) {  // pre_g == g: the prefetch always targets the next visited group
+        __builtin_amdgcn_wave_barrier();  // the previous group's fragment reads are issued before the window is overwritten
+#pragma unroll
+        for (int c = 0; c < NWI; ++c)
+          *reinterpret_cast<f32x4*>(win + (c * RPI + lane / LPR) * WS + (lane % LPR) * 4) = wreg[c];
+        __builtin_amdgcn_wave_barrier();  // LDS serves a wave's accesses in order: the reads below see these writes
+        cur_g = g; cur_lo = pre_lo; cur_ok = pre_span > 0;
+        const unsigned rest = gmask & ~((2u << g) - 1u);  // groups after g
+        pre_g = (rest != 0u) ? (__ffs((int)rest) - 1) : g;
+        VC3_ANALYSE(pre_g, pre_lo, pre_span);
+        if (rest == 0u) pre_span = 0;      // nothing left to prefetch: every load below is answered by the bounds check
+        VC3_ISSUE(pre_lo, pre_span);
+      }
+
+      // ---- this wave's 16 rows x offset k.  Two separate code paths: the window path must not contain a VMEM-sourced
+      // register (hipcc would put `s_waitcnt vmcnt(small)` in front of its MFMAs and drain the parked prefetches with it).
+      const int id = s_idx[k * 64 + wave * 16 + i];
+      if (__ballot(id >= 0) != 0ULL) {  // wave-uniform
+        const float* __restrict__ B_ = s_b + p * BF;
+#define VC3_STAGE(SG, ALOAD)                                                                       \
+  do {                                                                                             \
+    f32x4 a[CPS], b[CPS][NT];                                                                      \
+    _Pragma("unroll") for (int c = 0; c < CPS; ++c) a[c] = ALOAD((SG) * CPS + c);                  \
+    _Pragma("unroll") for (int c = 0; c < CPS; ++c)                                                \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                          \
+            b[c][nt] = *reinterpret_cast<const f32x4*>(B_ + ((((SG) * CPS + c) * NT + nt) * 64 + lane) * 4); \
+    __builtin_amdgcn_sched_barrier(0); /* every fragment read of the stage is issued before its first MFMA */ \
+    _Pragma("unroll") for (int c = 0; c < CPS; ++c)                                                \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                              \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) /* alternate accumulators: no dependent back-to-back MFMAs */ \
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[c][nt][j], acc[nt], 0, 0, 0); \
+  } while (0)
+        if (cur_ok) {
+          const float* arow = win + ((id >= 0) ? (id - cur_lo) : kWinRows) * WS + q * 4;
+#define VC3_A_LDS(CH) (*reinterpret_cast<const f32x4*>(arow + (CH) * 16))
+#pragma unroll
+          for (int sg = 0; sg < NSTG; ++sg) VC3_STAGE(sg, VC3_A_LDS);
+#undef VC3_A_LDS
+        } else {
+          const unsigned goff = (unsigned)id * (unsigned)(CK * 4) + (unsigned)(q * 16);  // id = -1 wraps out of range -> zeros
+#define VC3_A_GLB(CH) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, (int)(goff + (unsigned)((CH) * 64)), 0, 0))
+#pragma unroll
+          for (int sg = 0; sg < NSTG; ++sg) VC3_STAGE(sg, VC3_A_GLB);
+#undef VC3_A_GLB
+        }
+#undef VC3_STAGE
+      }
+      if (knext < 0) break;
+      k = knext;
+      p ^= 1;
+    }
+#undef VC3_LOAD_B
+#undef VC3_ANALYSE
+#undef VC3_ISSUE
+  }
+
+  if constexpr (EPI == VC_EPI_STATS) {
+    // per-WAVE partial sums (16 rows): rows beyond n_out gathered nothing (exact zeros); fixed order: 4 accumulator rows,
+    // then the q lanes; no LDS, no barrier
+    float* prow = epi.partial + ((lbid * 4 + wave) * 2) * CN;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float sm = ((acc[nt][0] + acc[nt][1]) + acc[nt][2]) + acc[nt][3];
+      float sq = ((acc[nt][0] * acc[nt][0] + acc[nt][1] * acc[nt][1]) + acc[nt][2] * acc[nt][2]) + acc[nt][3] * acc[nt][3];
+      sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
+      sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
+      const int n = nt * 16 + i;
+      if (q == 0 && n < CN) { prow[n] = sm; prow[CN + n] = sq; }
+    }
+  }
+  float sc[NT], sh[NT];
+  if constexpr (EPI == VC_EPI_AFFINE) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 16 + i;
+      sc[nt] = 1.f; sh[nt] = 0.f;
+      if (n < CN) {
+        const float istd = 1.0f / sqrtf(epi.var[n] + epi.eps);
+        sc[nt] = (epi.gamma ? epi.gamma[n] : 1.f) * istd;
+        sh[nt] = (epi.beta ? epi.beta[n] : 0.f) - epi.mean[n] * sc[nt];
+      }
+    }
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = nt * 16 + i;
+    if (n >= CN) continue;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int64_t r = brow0 + wave * 16 + q * 4 + reg;
+      float v = acc[nt][reg];
+      if constexpr (EPI == VC_EPI_AFFINE) {
+        v = v * sc[nt] + sh[nt];
+        if (epi.relu) v = fmaxf(v, 0.f);
+      }
+      if (r < n_out) out[r * CN + n] = v;
     }
   }
 }
@@ -847,11 +1148,44 @@ static constexpr int kRT = 2;  // 32 rows per wave, 128 rows per 256-thread bloc
 int g_conv_variant = 2;        // 1 = gather_gemm_kernel (per-wave loads), 2 = gather_gemm_v2_kernel (LDS-staged, pipelined)
 int g_conv_rt = 0;             // v2 row tiles per wave: 1 (64 rows/block) | 2 (128 rows/block) | 0 = heuristic
 
+int g_conv_window = 1;         // 0 = never take the LDS-window kernel (A/B measurements)
+
+// the LDS row-window kernel (v3) serves: fp32 operands, >= 16 source channels, natural row order, no duplicate-pixel rule,
+// tables the caller flags as coordinate-sorted (VC_CONV_SORTED_ROWS)
+template <int CK>
+static inline bool use_window_kernel(int flags, int ot, const int32_t* rep, const int32_t* order, int64_t n_src, int kv,
+                                     const float* src_centre) {
+  return CK >= 16 && g_conv_window && g_conv_variant == 2 && (flags & VC_CONV_SORTED_ROWS) && ot == VC_OPERAND_F32 &&
+         rep == nullptr && order == nullptr && src_centre == nullptr && kv <= 32 && n_src * CK * 4 < (1LL << 31);
+}
+
 template <int CK, int CN, bool BWD>
 static int launch_gg(const float* src, const float* src_centre, int64_t n_src, const int32_t* tbl, const float* w,
                      float* out, const int32_t* rep, const int32_t* order, int64_t n_out, int kv, int centre, int mirror, int ot,
-                       int epi_kind, const ConvEpilogue& epi, hipStream_t st) {
+                       int epi_kind, const ConvEpilogue& epi, int flags, hipStream_t st) {
   const int64_t rows_per_block = 4 * kRT * 16;
+  if constexpr (CK >= 16) {
+    if (use_window_kernel<CK>(flags, ot, rep, order, n_src, kv, src_centre)) {
+      constexpr int NCH = CK / 16, NT = (CN + 15) / 16;
+      const size_t lds = (size_t)2 * NCH * NT * 64 * 4 * sizeof(float) + (size_t)kv * 64 * sizeof(int) +
+                         (size_t)4 * (kWinRows + 1) * (CK + 4) * sizeof(float) + 16;
+      const dim3 grid((unsigned)cdiv(n_out, 64));
+#define VC_ARGS3 src, n_src, tbl, w, out, n_out, kv, mirror, epi
+      if constexpr (!BWD) {
+        if (epi_kind == VC_EPI_STATS)
+          hipLaunchKernelGGL((gather_gemm_v3_kernel<CK, CN, false, VC_EPI_STATS>), grid, dim3(256), lds, st, VC_ARGS3);
+        else if (epi_kind == VC_EPI_AFFINE)
+          hipLaunchKernelGGL((gather_gemm_v3_kernel<CK, CN, false, VC_EPI_AFFINE>), grid, dim3(256), lds, st, VC_ARGS3);
+        else
+          hipLaunchKernelGGL((gather_gemm_v3_kernel<CK, CN, false, VC_EPI_NONE>), grid, dim3(256), lds, st, VC_ARGS3);
+      } else {
+        hipLaunchKernelGGL((gather_gemm_v3_kernel<CK, CN, true, VC_EPI_NONE>), grid, dim3(256), lds, st, VC_ARGS3);
+      }
+#undef VC_ARGS3
+      VC_CHECK_LAUNCH("gather_gemm_v3_kernel");
+      return VC_OK;
+    }
+  }
   if (g_conv_variant == 2 && kv <= 32 && n_src * CK * 4 < (1LL << 31)) {
     constexpr int V = (CK >= 16) ? 4 : CK / 4;
     constexpr int NCH = CK / (4 * V);
@@ -909,13 +1243,13 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
 template <int CK, bool BWD>
 static int dispatch_cn(int cn, const float* src, const float* src_centre, int64_t n_src, const int32_t* tbl, const float* w, float* out,
                        const int32_t* rep, const int32_t* order, int64_t n_out, int kv, int centre, int mirror, int ot,
-                       int epi_kind, const ConvEpilogue& epi, hipStream_t st) {
+                       int epi_kind, const ConvEpilogue& epi, int flags, hipStream_t st) {
   switch (cn) {
-    case 4: return launch_gg<CK, 4, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, st);
-    case 8: return launch_gg<CK, 8, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, st);
-    case 16: return launch_gg<CK, 16, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, st);
-    case 32: return launch_gg<CK, 32, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, st);
-    case 64: return launch_gg<CK, 64, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, st);
+    case 4: return launch_gg<CK, 4, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, flags, st);
+    case 8: return launch_gg<CK, 8, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, flags, st);
+    case 16: return launch_gg<CK, 16, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, flags, st);
+    case 32: return launch_gg<CK, 32, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, flags, st);
+    case 64: return launch_gg<CK, 64, BWD>(src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, flags, st);
   }
   set_error("gather-GEMM: unsupported output channel count %d (supported: 4,8,16,32,64)", cn);
   return VC_EINVAL;
@@ -924,13 +1258,13 @@ static int dispatch_cn(int cn, const float* src, const float* src_centre, int64_
 template <bool BWD>
 static int dispatch_ck(int ck, int cn, const float* src, const float* src_centre, int64_t n_src, const int32_t* tbl, const float* w,
                        float* out, const int32_t* rep, const int32_t* order, int64_t n_out, int kv, int centre, int mirror, int ot,
-                       int epi_kind, const ConvEpilogue& epi, hipStream_t st) {
+                       int epi_kind, const ConvEpilogue& epi, int flags, hipStream_t st) {
   switch (ck) {
-    case 4: return dispatch_cn<4, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, st);
-    case 8: return dispatch_cn<8, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, st);
-    case 16: return dispatch_cn<16, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, st);
-    case 32: return dispatch_cn<32, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, st);
-    case 64: return dispatch_cn<64, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, st);
+    case 4: return dispatch_cn<4, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, flags, st);
+    case 8: return dispatch_cn<8, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, flags, st);
+    case 16: return dispatch_cn<16, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, flags, st);
+    case 32: return dispatch_cn<32, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, flags, st);
+    case 64: return dispatch_cn<64, BWD>(cn, src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, ot, epi_kind, epi, flags, st);
   }
   set_error("gather-GEMM: unsupported source channel count %d (supported: 4,8,16,32,64)", ck);
   return VC_EINVAL;
@@ -1010,6 +1344,7 @@ extern "C" {
 int vc_debug_set(const char* key, int value) {
   if (key && !strcmp(key, "conv_variant")) { g_conv_variant = value; return VC_OK; }
   if (key && !strcmp(key, "conv_rt")) { g_conv_rt = value; return VC_OK; }
+  if (key && !strcmp(key, "conv_window")) { g_conv_window = value; return VC_OK; }
   if (key && !strcmp(key, "bw_legacy_order")) { g_bw_legacy_order = value; return VC_OK; }
   if (key && !strcmp(key, "xcd_swizzle_off")) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_swizzle_off), &value, sizeof(int)) == hipSuccess ? VC_OK : VC_EHIP;
@@ -1019,13 +1354,13 @@ int vc_debug_set(const char* key, int value) {
 }
 
 int vc_conv_forward(const float* x, int64_t n_in, const int32_t* pair_fwd, int64_t n_out, int kv, const float* weight,
-                    int cin, int cout, const int32_t* row_order, int operand_type, float* y, void* stream) {
+                    int cin, int cout, const int32_t* row_order, int operand_type, int flags, float* y, void* stream) {
   VC_REQUIRE(n_in >= 0 && n_out >= 0 && kv >= 1 && weight, "vc_conv_forward: null/invalid argument");
   if (n_out == 0) return VC_OK;
   VC_REQUIRE(pair_fwd && y && (x || n_in == 0), "vc_conv_forward: null argument");
   VC_REQUIRE(operand_type >= VC_OPERAND_F32 && operand_type <= VC_OPERAND_BF16, "vc_conv_forward: unknown operand_type");
   return dispatch_ck<false>(cin, cout, x, nullptr, n_in, pair_fwd, weight, y, nullptr, row_order, n_out, kv, -1, 0,
-                            operand_type, VC_EPI_NONE, ConvEpilogue{}, (hipStream_t)stream);
+                            operand_type, VC_EPI_NONE, ConvEpilogue{}, flags, (hipStream_t)stream);
 }
 
 int vc_conv_epilogue_supported(int64_t n_in, int cin, int cout, int kv, int operand_type) {
@@ -1033,13 +1368,23 @@ int vc_conv_epilogue_supported(int64_t n_in, int cin, int cout, int kv, int oper
   return (g_conv_variant == 2 && kv <= 32 && n_in * (int64_t)cin * 4 < (1LL << 31) && operand_type == VC_OPERAND_F32) ? 1 : 0;
 }
 
-size_t vc_conv_stats_partial_floats(int64_t n_out, int cout) {
+static bool stats_per_wave(int64_t n_in, int cin, int kv, int flags) {
+  switch (cin) {
+    case 16: return use_window_kernel<16>(flags, VC_OPERAND_F32, nullptr, nullptr, n_in, kv, nullptr);
+    case 32: return use_window_kernel<32>(flags, VC_OPERAND_F32, nullptr, nullptr, n_in, kv, nullptr);
+    case 64: return use_window_kernel<64>(flags, VC_OPERAND_F32, nullptr, nullptr, n_in, kv, nullptr);
+  }
+  return false;
+}
+
+size_t vc_conv_stats_partial_floats(int64_t n_in, int64_t n_out, int cin, int cout, int kv, int flags) {
   if (n_out < 0 || cout < 1) return 0;
-  return (size_t)cdiv(n_out, 64) * 2 * cout;
+  // one partial row (sum, sum of squares per channel) per 64-row block, or per 16-row wave tile on the LDS-window kernel
+  return (size_t)cdiv(n_out, 64) * (stats_per_wave(n_in, cin, kv, flags) ? 4 : 1) * 2 * cout;
 }
 
 int vc_conv_forward_epilogue(const float* x, int64_t n_in, const int32_t* pair_fwd, int64_t n_out, int kv, const float* weight,
-                             int cin, int cout, const int32_t* row_order, int epilogue, float* stats_partial,
+                             int cin, int cout, const int32_t* row_order, int epilogue, int flags, float* stats_partial,
                              const float* mean, const float* var, const float* gamma, const float* beta, float eps,
                              int relu, float* y, void* stream) {
   VC_REQUIRE(n_in >= 0 && n_out >= 0 && kv >= 1 && weight, "vc_conv_forward_epilogue: null/invalid argument");
@@ -1052,12 +1397,12 @@ int vc_conv_forward_epilogue(const float* x, int64_t n_in, const int32_t* pair_f
              "vc_conv_forward_epilogue: not available for this shape (vc_conv_epilogue_supported)");
   ConvEpilogue e{stats_partial, mean, var, gamma, beta, eps, relu};
   return dispatch_ck<false>(cin, cout, x, nullptr, n_in, pair_fwd, weight, y, nullptr, row_order, n_out, kv, -1, 0,
-                            VC_OPERAND_F32, epilogue, e, (hipStream_t)stream);
+                            VC_OPERAND_F32, epilogue, e, flags, (hipStream_t)stream);
 }
 
 int vc_conv_backward_input(const float* dy, const float* dy_centre, int64_t n_src, const int32_t* tbl, int64_t n_in,
                            int kv, const float* weight, int cin, int cout, int mirror, int centre, const int32_t* rep,
-                           const int32_t* row_order, int operand_type, float* dx, void* stream) {
+                           const int32_t* row_order, int operand_type, int flags, float* dx, void* stream) {
   VC_REQUIRE(n_src >= 0 && n_in >= 0 && kv >= 1 && weight, "vc_conv_backward_input: null/invalid argument");
   if (n_in == 0) return VC_OK;
   VC_REQUIRE(tbl && dx && (dy || n_src == 0), "vc_conv_backward_input: null argument");
@@ -1065,7 +1410,7 @@ int vc_conv_backward_input(const float* dy, const float* dy_centre, int64_t n_sr
   VC_REQUIRE(operand_type >= VC_OPERAND_F32 && operand_type <= VC_OPERAND_BF16,
              "vc_conv_backward_input: unknown operand_type");
   return dispatch_ck<true>(cout, cin, dy, dy_centre, n_src, tbl, weight, dx, rep, row_order, n_in, kv, centre,
-                           mirror ? 1 : 0, operand_type, VC_EPI_NONE, ConvEpilogue{}, (hipStream_t)stream);
+                           mirror ? 1 : 0, operand_type, VC_EPI_NONE, ConvEpilogue{}, flags, (hipStream_t)stream);
 }
 
 size_t vc_conv_backward_weight_workspace_bytes(int64_t n_out, int kv, int cin, int cout) {

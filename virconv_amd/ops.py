@@ -70,6 +70,9 @@ class Rulebook:
     # optional scheduling hints (vc_row_order): permutations of the columns of pair_fwd / of the backward-input table
     order_fwd: Optional[torch.Tensor] = None
     order_bwd: Optional[torch.Tensor] = None
+    # SubM rulebook over rows that are in ascending coordinate order (the output of a strided conv): the gather-GEMM may
+    # stage its gathers through LDS row windows (VC_CONV_SORTED_ROWS)
+    sorted_rows: bool = False
 
     @property
     def kv(self) -> int:
@@ -88,6 +91,8 @@ def build_subm_rulebook(indices: torch.Tensor, spatial_shape, ksize, dilation=1,
     n = indices.shape[0]
     rb = Rulebook("subm", pair, None, rep if allow_duplicates else None, n, n, indices, indices, shape, shape, ks,
                   (1,) * ndim, tuple(k // 2 for k in ks), dl)
+    # strided-conv outputs are emitted in ascending (b, z, y, x) order and tagged below; a SubM conv on them reads a sorted table
+    rb.sorted_rows = bool(WINDOW_GATHER and getattr(indices, "_vc_sorted", False) and not allow_duplicates)
     if ROW_ORDER == "all" and rb.kv <= 32:
         be = get_backend()
         rb.order_fwd = be.row_order(pair, window=ROW_ORDER_WINDOW)
@@ -103,6 +108,7 @@ def build_sparse_rulebook(indices: torch.Tensor, spatial_shape, batch_size: int,
     pd, dl = ntuple(padding, ndim), ntuple(dilation, ndim)
     shape = tuple(int(s) for s in spatial_shape)
     out_idx, out_shape, pf, pb = get_backend().sparse_rulebook(indices, shape, int(batch_size), ks, st, pd, dl)
+    out_idx._vc_sorted = True  # ascending linear order by construction (bitmap rank); see build_subm_rulebook
     rb = Rulebook("sparse", pf, pb, None, indices.shape[0], out_idx.shape[0], indices, out_idx, shape,
                   tuple(int(s) for s in out_shape), ks, st, pd, dl)
     if ROW_ORDER in ("bwd", "all") and 8 < rb.kv <= 32:
@@ -124,7 +130,8 @@ class SparseConvFunction(torch.autograd.Function):
         ctx.save_for_backward(features, weight)
         if inverse:
             return be.conv_forward(features, weight, rb.pair_bwd, order=rb.order_bwd, operand=MFMA_OPERAND)
-        return be.conv_forward(features, weight, rb.pair_fwd, order=rb.order_fwd, operand=MFMA_OPERAND)
+        return be.conv_forward(features, weight, rb.pair_fwd, order=rb.order_fwd, operand=MFMA_OPERAND,
+                               sorted_rows=rb.sorted_rows)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -156,7 +163,8 @@ def _conv_backward(rb: "Rulebook", inverse: bool, features, weight, grad_out, ne
                                         operand=MFMA_OPERAND)
         elif rb.kind == "subm":
             dx = be.conv_backward_input(grad_out, weight, rb.pair_fwd, rb.n_in, mirror=True, centre=rb.centre, rep=rb.rep,
-                                        order=rb.order_bwd, operand=MFMA_OPERAND, group_ws=group_ws)
+                                        order=rb.order_bwd, operand=MFMA_OPERAND, group_ws=group_ws,
+                                        sorted_rows=rb.sorted_rows)
         else:
             dx = be.conv_backward_input(grad_out, weight, rb.pair_bwd, rb.n_in, mirror=False, order=rb.order_bwd,
                                         operand=MFMA_OPERAND)
@@ -195,11 +203,12 @@ class ConvBNReLUFunction(torch.autograd.Function):
         if FUSE_BN_STATS and MFMA_OPERAND == "f32" and be.conv_epilogue_supported(x.shape[0], weight.shape[-1],
                                                                                   weight.shape[0], rb.kv):
             # the conv epilogue emits the per-block (sum, sum of squares): the statistics need no pass over y_raw
-            y_raw, partial = be.conv_forward_stats(x, weight, tbl, order=order)
+            y_raw, partial = be.conv_forward_stats(x, weight, tbl, order=order, sorted_rows=rb.sorted_rows and not inverse)
             y, mean, var = be.bn_forward(y_raw, gamma, beta, running_mean, running_var, True, momentum, eps, relu,
                                          num_batches_tracked=nbt, partial=partial)
         else:
-            y_raw = be.conv_forward(x, weight, tbl, order=order, operand=MFMA_OPERAND)
+            y_raw = be.conv_forward(x, weight, tbl, order=order, operand=MFMA_OPERAND,
+                                    sorted_rows=rb.sorted_rows and not inverse)
             y, mean, var = be.bn_forward(y_raw, gamma, beta, running_mean, running_var, True, momentum, eps, relu,
                                          num_batches_tracked=nbt)
         ctx.rb, ctx.inverse, ctx.cfg = rb, inverse, (float(eps), bool(relu))
@@ -244,7 +253,8 @@ def conv_bn_relu_eval(x: torch.Tensor, weight: torch.Tensor, rb: "Rulebook", inv
     tbl, order = (rb.pair_bwd, rb.order_bwd) if inverse else (rb.pair_fwd, rb.order_fwd)
     return be.conv_forward_affine(x.detach(), weight.detach(), tbl, order, bn.running_mean, bn.running_var,
                                   None if bn.weight is None else bn.weight.detach(),
-                                  None if bn.bias is None else bn.bias.detach(), bn.eps, relu)
+                                  None if bn.bias is None else bn.bias.detach(), bn.eps, relu,
+                                  sorted_rows=rb.sorted_rows and not inverse)
 
 
 # dW on a side stream under the backward-input conv.  Was worth 0.5 ms when the kernels left the chip half empty; since the
@@ -263,6 +273,8 @@ FUSE_BN_EVAL = os.environ.get("VIRCONV_FUSE_BN_EVAL", "1") != "0"     # inferenc
 # MFMA operand type of the conv kernels: "f32" (exact, default, the parity path) | "f16" | "bf16" (BASELINE configs[4]:
 # "fp16 MFMA contraction"; tensors stay fp32, operands are rounded in registers, accumulation is fp32)
 MFMA_OPERAND = os.environ.get("VIRCONV_MFMA_OPERAND", "f32")
+# LDS row-window gather-GEMM for SubM convs on coordinate-sorted rows (VC_CONV_SORTED_ROWS hint); 0 = always the direct gathers
+WINDOW_GATHER = os.environ.get("VIRCONV_WINDOW_GATHER", "1") != "0"
 ROW_ORDER = os.environ.get("VIRCONV_ROW_ORDER", "bwd")
 ROW_ORDER_WINDOW = int(os.environ.get("VIRCONV_ROW_ORDER_WINDOW", "2048"))
 _SIDE_STREAMS = {}
@@ -339,7 +351,16 @@ class BNReLUFunction(torch.autograd.Function):
         x, mean, var, gamma, beta = ctx.saved_tensors
         training, eps, relu = ctx.cfg
         if not training:
-            raise NotImplementedError("virconv_amd: backward through eval-mode BatchNorm is not supported")
+            # frozen statistics (fine-tuning with BatchNorm in eval mode, input-gradient probes): mean / var are constants, so
+            # dx = dy * gamma / sqrt(var + eps) behind the ReLU mask; rare path, plain tensor ops
+            istd = torch.rsqrt(var + eps)
+            xh = (x - mean) * istd
+            g = grad_out
+            if relu:
+                g = torch.where(xh * gamma + beta > 0, g, torch.zeros_like(g))
+            dgamma = (g * xh).sum(0) if ctx.needs_input_grad[1] else None
+            dbeta = g.sum(0) if ctx.needs_input_grad[2] else None
+            return g * (gamma * istd), dgamma, dbeta, None, None, None, None, None, None, None
         dx, dgamma, dbeta = be.bn_backward(x, grad_out.contiguous(), 0, mean, var, gamma, beta, eps, relu)
         return dx, dgamma, dbeta, None, None, None, None, None, None, None
 

@@ -124,7 +124,12 @@ class FlatGradAllReduce:
     def __call__(self) -> None:
         if not self.active:
             return
-        grads = [p.grad for p in self.params if p.grad is not None]
+        # every rank packs EVERY parameter (zeros where this rank produced no gradient -- an empty stream, a skipped
+        # block): the flat buffer has the same layout on all ranks, like DDP's buckets
+        for p in self.params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        grads = [p.grad for p in self.params]
         if not grads:
             return
         flat = torch.cat([g.reshape(-1) for g in grads])
