@@ -9,6 +9,11 @@ One process per GPU.  A "step" = one pass of the hot path over one batch: BASELI
 shard across ranks with no data-path collective, the only exchange is the DDP gradient all-reduce (RCCL).  Inputs
 (voxel features/coords, calib, aug params) are resident in HBM before the timed region; weak scaling (4 frames per GPU).
 
+`--gpus N` without a torch.distributed.run environment re-launches itself under it (one rank per GPU, 127.0.0.1 rendezvous).
+`--model 8x` = BASELINE configs[3]'s backbone (VirConv8x: LiDAR stream + virtual-point stream, bs 2 per GPU, 16 000 + 16 000
+voxels per frame, layer discard 0.15); `--frontend` puts the per-frame data front-end (input point discard + LiDAR-first
+voxeliser + MeanVFE from raw device-resident points, virtual points as the fp16 of the .npy files) inside the timed step.
+
 Rank 0 prints ONE JSON line: metric/value/unit/..., plus
   "roofline":     the dominant kernel (gather-GEMM forward/backward-input family, fp32 MFMA) -- achieved algorithmic
                   TFLOP/s from HIP events bracketing every launch of the traced instantiation inside the timed steps
@@ -64,6 +69,50 @@ def make_batch(frame_seeds, device, training=True):
     }
 
 
+def make_raw_frames(frame_seeds, device):
+    """Raw per-frame points resident on the device, as the dataset hands them over BEFORE the front-end: LiDAR (Pl, 8) fp32
+    and the depth-completed virtual points (Pv, 8) in the fp16 of their .npy files."""
+    raw, calibs, augs = [], [], []
+    for s in frame_seeds:
+        fr = synth.make_frame(s)
+        raw.append((torch.from_numpy(fr["points_lidar"]).to(device),
+                    torch.from_numpy(fr["points_virtual"].astype(np.float16)).to(device)))
+        calibs.append(fr["calib"])
+        augs.append(fr["aug_param"])
+    return raw, {"batch_size": len(frame_seeds), "calib": ops.calib_tensor(calibs, device),
+                 "aug_param": torch.from_numpy(np.stack(augs)).to(device)}
+
+
+def front_end(raw, base, training=True):
+    """The data front-end on the GPU: one fused call per frame (vc_frontend_voxelize_mean), one count read per batch."""
+    feats, coords = data.frontend_batch(raw, training, synth.POINT_CLOUD_RANGE, synth.VOXEL_SIZE, 5, 40000, True)
+    bd = dict(base)
+    bd["voxel_features"], bd["voxel_coords"] = feats, coords.float()
+    return bd
+
+
+MODEL_CFG_8X = dict(NAME="VirConv8x", NUM_FILTERS=[16, 32, 64, 64], RETURN_NUM_FEATURES_AS_DICT=True, OUT_FEATURES=64,
+                    LAYER_DISCARD_RATE=0.15, LAYER_DISCARD_MODE="spconv1_inplace", MM=True)
+
+
+def make_batch_8x(frame_seeds, device):
+    """VirConv-T/S backbone input (VirConv-T.yaml:9,119-122): a LiDAR-only voxel set and a fused (MM) voxel set per frame,
+    16 000 voxels each at most."""
+    lidar, mm, calibs, augs = [], [], [], []
+    for s in frame_seeds:
+        fr = synth.make_frame(s)
+        rng = np.random.default_rng(10_000 + s)
+        lidar.append(fr["points_lidar"])
+        mm.append(data.prepare_frame(fr["points_lidar"], fr["points_virtual"], training=True, rng=rng))
+        calibs.append(fr["calib"])
+        augs.append(fr["aug_param"])
+    f, c, _ = data.voxelize_batch(lidar, synth.POINT_CLOUD_RANGE, synth.VOXEL_SIZE, 5, 16000, True, device)
+    fm, cm, _ = data.voxelize_batch(mm, synth.POINT_CLOUD_RANGE, synth.VOXEL_SIZE, 5, 16000, True, device)
+    return {"batch_size": len(frame_seeds), "voxel_features": f, "voxel_coords": c.float(), "voxel_features_mm": fm,
+            "voxel_coords_mm": cm.float(), "calib": ops.calib_tensor(calibs, device),
+            "aug_param": torch.from_numpy(np.stack(augs)).to(device)}
+
+
 def make_loss_weights(device):
     g = torch.Generator(device="cpu").manual_seed(1234)
     w = {"dense": torch.randn((1, 64, 4, 200, 176), generator=g).to(device) * 0.01}
@@ -72,15 +121,22 @@ def make_loss_weights(device):
     return w
 
 
-def train_step(model, optimizer, batch, lw, grad_sync=None):
-    """fwd + bwd + Adam.  loss = (out.dense()*G).sum() + sum_i (x_conv_i.features * g_i).sum()  (heads out of scope)."""
+def train_step(model, optimizer, batch, lw, grad_sync=None, raw=None):
+    """fwd + bwd + Adam.  loss = (out.dense()*G).sum() + sum_i (x_conv_i.features * g_i).sum()  (heads out of scope).
+    `raw`: run the data front-end on the raw points first (the --frontend workload); `batch` then only carries calib / aug."""
     optimizer.zero_grad(set_to_none=True)
-    bd = dict(batch)
-    bd["voxel_features"] = batch["voxel_features"].clone()  # the backbone zeroes RGB in place
+    if raw is not None:
+        bd = front_end(raw, batch)
+    else:
+        bd = dict(batch)
+        bd["voxel_features"] = batch["voxel_features"].clone()  # the backbone zeroes RGB in place
     out = model(bd)
     loss = (out["encoded_spconv_tensor"].dense() * lw["dense"]).sum()
     for name, t in out["multi_scale_3d_features"].items():
         loss = loss + (t.features * lw[name]).sum()
+    if "multi_scale_3d_features_mm" in out:
+        for name, t in out["multi_scale_3d_features_mm"].items():
+            loss = loss + (t.features * lw[name]).sum()
     loss.backward()
     if grad_sync is not None:
         grad_sync()  # data-parallel exchange: one flat RCCL all-reduce of the gradients
@@ -151,7 +207,7 @@ def _pmc_traffic(tdir, tck, tcn):
     """HBM bytes per launch of the traced kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected in separate
     runs of this same command and corrected as MI355X_MICROARCH.md prescribes; summary committed under profiles/).
     PMC counters cannot be read from inside the process, so the number comes from that file; None if absent."""
-    path = os.path.join(ROOT, "profiles", f"r01_traffic_gather_gemm_{tck}_{tcn}_{tdir}.json")
+    path = os.path.join(ROOT, "profiles", f"r02_traffic_gather_gemm_{tck}_{tcn}_{tdir}.json")
     try:
         with open(path) as f:
             return float(json.load(f)["hbm_bytes_per_launch_corrected"])
@@ -173,10 +229,27 @@ def main():
                          "bf16 = BASELINE configs[4] 'fp16 MFMA contraction' experiment (fp32 tensors, fp32 accumulate), "
                          "reported with its own dtype and a 16-bit MFMA peak, never as the headline number")
     ap.add_argument("--trace", default="fwd,64,32", help="gather-GEMM instantiation timed for the roofline: dir,CK,CN")
+    ap.add_argument("--model", default="L", choices=["L", "8x"],
+                    help="L = VirConvL8x, BASELINE configs[2] (default, the headline); 8x = VirConv8x (LiDAR + virtual-point "
+                         "streams), the backbone of BASELINE configs[3], bs 2 per GPU unless --batch-size is given")
+    ap.add_argument("--frontend", action="store_true",
+                    help="include the GPU data front-end (input point discard + LiDAR-first voxeliser + MeanVFE from raw "
+                         "device-resident points) in every timed step (model L)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     rank, local_rank, world = parallel.init_distributed()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N ranks, or run without a launcher)"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
     device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
@@ -184,11 +257,24 @@ def main():
     be = ops.get_backend()
     ops.MFMA_OPERAND = args.operand
 
+    if args.model == "8x" and "--batch-size" not in " ".join(sys.argv):
+        args.batch_size = 2                                        # VirConv-T.yaml: bs 2 per GPU
+    assert not (args.frontend and (args.model != "L" or args.mode != "train")), "--frontend is a train-mode VirConv-L workload"
     bs = args.batch_size
     seeds = parallel.shard_frames(list(range(bs * world)), rank, world)
-    batch = make_batch(seeds, device, training=True)
+    raw = None
     torch.manual_seed(0)
-    model = VirConvL8x(MODEL_CFG, input_channels=8, grid_size=synth.GRID_SIZE).to(device)
+    if args.model == "8x":
+        from virconv_amd.backbone import VirConv8x
+        batch = make_batch_8x(seeds, device)
+        model = VirConv8x(MODEL_CFG_8X, input_channels=8, grid_size=synth.GRID_SIZE).to(device)
+    else:
+        batch = make_batch(seeds, device, training=True)
+        if args.frontend:
+            raw, base = make_raw_frames(seeds, device)
+            n_vox = int(batch["voxel_features"].shape[0])
+            batch = base
+        model = VirConvL8x(MODEL_CFG, input_channels=8, grid_size=synth.GRID_SIZE).to(device)
     model.train()
     use_torch_ddp = os.environ.get("VIRCONV_TORCH_DDP") == "1"   # stock DistributedDataParallel instead (slower here)
     ddp = parallel.wrap_ddp(model, device) if use_torch_ddp else model
@@ -216,11 +302,11 @@ def main():
     settle = float(os.environ.get("VIRCONV_SETTLE_SEC", "1.0"))
     t_settle = time.perf_counter()
     while time.perf_counter() - t_settle < settle:
-        train_step(ddp, optimizer, batch, lw, grad_sync)
+        train_step(ddp, optimizer, batch, lw, grad_sync, raw)
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        train_step(ddp, optimizer, batch, lw, grad_sync)
+        train_step(ddp, optimizer, batch, lw, grad_sync, raw)
 
     tdir, tck, tcn = args.trace.split(",")
     be.trace_begin(tdir, int(tck), int(tcn))
@@ -228,7 +314,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        train_step(ddp, optimizer, batch, lw, grad_sync)
+        train_step(ddp, optimizer, batch, lw, grad_sync, raw)
     torch.cuda.synchronize()
     parallel.barrier()
     dt = time.perf_counter() - t0
@@ -248,21 +334,34 @@ def main():
         peak = MFMA_F32_PEAK_TFLOPS if args.operand == "f32" else MFMA_16BIT_PEAK_TFLOPS
         roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": _pmc_traffic(tdir, tck, tcn) if args.operand == "f32" else None,
-                "kernel": f"gather_gemm_v2_kernel<CK={tck},CN={tcn},BWD={'true' if tdir == 'bwd' else 'false'},RT=1>",
+                "kernel": (f"gather_gemm_v3_kernel<CK={tck},CN={tcn},BWD={'true' if tdir == 'bwd' else 'false'}> (LDS row windows)"
+                           if all(e["windowed"] for e in trace) else
+                           f"gather_gemm_v2_kernel<CK={tck},CN={tcn},BWD={'true' if tdir == 'bwd' else 'false'},RT=1>"),
                 "launches": n_launch, "avg_us": round(t_ms / n_launch * 1e3, 2),
                 "algorithmic_gflop_per_launch": round(flops / n_launch / 1e9, 4),
                 "algorithmic_mb_per_launch": round(byts / n_launch / 1e6, 3),
                 "hbm_frac_of_algorithmic_bytes": round(byts / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    if args.model == "8x":
+        metric = "KITTI frames/sec (fwd+bwd) VirConv8x backbone (VirConv-T/S)"
+        workload = ("BASELINE configs[3] backbone: VirConv8x (LiDAR stream + virtual-point MM stream) train step (fwd+bwd+Adam), "
+                    "train mode, layer discard 0.15, bs 2 per GPU, <=16000 LiDAR + <=16000 fused voxels per frame; the "
+                    "cascade refinement head is out of scope (SURVEY 8f)")
+    else:
+        metric = "KITTI frames/sec (fwd+bwd) VirConv-L backbone"
+        workload = ("BASELINE configs[2]: VirConv-L train step (fwd+bwd+Adam), train mode, layer discard 0.1, NRConv 2-D branch "
+                    "on, synthetic KITTI frames (20k LiDAR + 60k virtual points, input discard 0.8, <=40000 voxels/frame)")
+        if args.frontend:
+            workload += ("; PLUS the GPU data front-end inside every timed step: input point discard (HIP) + LiDAR-first "
+                         "voxeliser + MeanVFE from raw device-resident points (virtual points fp16)")
     res = {
-        "metric": "KITTI frames/sec (fwd+bwd) VirConv-L backbone", "value": round(frames / dt, 3), "unit": "frames/s",
+        "metric": metric, "value": round(frames / dt, 3), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.operand == "f32" else f"{args.operand} MFMA operands, f32 accumulate, f32 tensors",
         "data": "synthetic",
-        "config": {"workload": "BASELINE configs[2]: VirConv-L train step (fwd+bwd+Adam), train mode, layer discard 0.1, "
-                               "NRConv 2-D branch on, synthetic KITTI frames (20k LiDAR + 60k virtual points, input "
-                               "discard 0.8, <=40000 voxels/frame)",
-                   "frames_per_gpu": bs, "global_batch": bs * world, "voxels_rank0": int(batch["voxel_features"].shape[0]),
+        "config": {"workload": workload,
+                   "frames_per_gpu": bs, "global_batch": bs * world,
+                   "voxels_rank0": n_vox if args.frontend else int(batch["voxel_features"].shape[0]),
                    "parallelism": f"dp{world}", "cpu_affinity": numa},
         "roofline": roof,
     }

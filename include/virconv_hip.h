@@ -160,7 +160,10 @@ size_t vc_group_sum_workspace_bytes(int64_t n, int c);
 int vc_group_sum(const float* dy, const int32_t* rep, int64_t n, int c, float* dy_grp, void* ws, size_t ws_bytes,
                  int prepared, void* stream);
 /* Optional two-step form that saves the max|dy| pass: vc_group_sum_prepare zeroes `ws`; the kernel that PRODUCES dy then
- * leaves max|dy| in the first word of ws (vc_bn_relu_backward's absmax_out = ws); vc_group_sum(..., prepared = 1).        */
+ * leaves max|dy| in the first word of ws (vc_bn_relu_backward's absmax_out = ws); vc_group_sum(..., prepared = 1).
+ * prepared = 2: `ws` is a PERSISTENT buffer (>= vc_group_sum_workspace_bytes of the largest layer) that the caller zeroed
+ * ONCE; the first word holds max|dy| as above, and the call hands the accumulators back all-zero (the convert kernel clears
+ * what it reads) -- no 8*n*c-byte memset per layer.                                                                     */
 int vc_group_sum_prepare(void* ws, size_t ws_bytes, int64_t n, int c, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ K9 projection
@@ -260,13 +263,40 @@ int vc_bn_stats(const float* x, int64_t n, int c, float* mean, float* var, float
 /* statistics from the per-block partial sums of vc_conv_forward_epilogue(VC_EPI_STATS): same outputs as vc_bn_stats */
 int vc_bn_stats_from_partial(const float* partial, int64_t nblocks, int64_t n, int c, float* mean, float* var,
                              float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
-                             void* stream);
+                             void* ws /* nullable: vc_bn_workspace_bytes; enables the coalesced two-stage reduce */,
+                             size_t ws_bytes, void* stream);
 int vc_bn_apply_relu(const float* x, int64_t n, int c, const float* mean, const float* var, const float* gamma,
                      const float* beta, float eps, int relu, float* y, int y_stride, int y_col0, void* stream);
 int vc_bn_relu_backward(const float* x, const float* dy, int dy_stride, int dy_col0, int64_t n, int c,
                         const float* mean, const float* var, const float* gamma, const float* beta, float eps,
-                        int relu, float* dx, float* dgamma, float* dbeta, unsigned* absmax_out /* nullable, zeroed by
-                        the caller: receives max|dx| as float bits */, void* ws, size_t ws_bytes, void* stream);
+                        int relu, float* dx, float* dgamma, float* dbeta, unsigned* absmax_out /* nullable: receives
+                        max|dx| as float bits (cleared by the call itself) */, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ post_act_block
+ * conv (no bias) -> BatchNorm1d(training) -> ReLU, the unit every conv of the backbone is wrapped in (spconv_backbone.py:86-107
+ * post_act_block, :110-131 post_act_block2d), forward and backward as ONE call each.  Host-side composition of the entry
+ * points above (same launches, same order, bit-identical results); exists to take the per-launch Python cost (~16 us) off a
+ * ~380-launch train step.
+ *   forward : y_raw = conv(x);  batch statistics -> mean, var (+ running stats, num_batches_tracked);
+ *             y[:, y_col0 : y_col0 + cout] = relu?((y_raw - mean) * rsqrt(var + eps) * gamma + beta)   (row stride y_stride:
+ *             the channel concat of NRConvBlock is written in place)
+ *   backward: dy (row stride dy_stride, column dy_col0) -> d_raw (BatchNorm + ReLU backward), dgamma, dbeta; dx = conv^T(d_raw)
+ *             through tbl_dx (SubM: pair_fwd, mirror = 1; strided: pair_bwd, mirror = 0; duplicate-pixel 2-D convs: rep /
+ *             centre + the persistent group-sum accumulator `group_acc`, see vc_group_sum prepared = 2); dw = weight gradient. */
+size_t vc_post_act_block_forward_workspace_bytes(int64_t n_in, int64_t n_out, int kv, int cin, int cout, int flags);
+int vc_post_act_block_forward(const float* x, int64_t n_in, const int32_t* pair_fwd, int64_t n_out, int kv,
+                              const float* weight, int cin, int cout, const int32_t* row_order, int operand_type, int flags,
+                              const float* gamma, const float* beta, float* running_mean, float* running_var,
+                              int64_t* num_batches_tracked, float momentum, float eps, int relu, float* y_raw, float* y,
+                              int y_stride, int y_col0, float* mean, float* var, void* ws, size_t ws_bytes, void* stream);
+size_t vc_post_act_block_backward_workspace_bytes(int64_t n_out, int kv, int cin, int cout);
+int vc_post_act_block_backward(const float* x, int64_t n_in, const float* y_raw, int64_t n_out, const float* dy,
+                               int dy_stride, int dy_col0, const float* mean, const float* var, const float* gamma,
+                               const float* beta, float eps, int relu, const int32_t* pair_fwd, const int32_t* tbl_dx,
+                               int64_t n_dx, int mirror, int centre, const int32_t* rep, const int32_t* row_order_dx, int kv,
+                               const float* weight, int cin, int cout, int operand_type, int flags, int need_dx, int need_dw,
+                               float* d_raw, float* dx, float* dw, float* dgamma, float* dbeta, void* group_acc,
+                               size_t group_acc_bytes, void* ws, size_t ws_bytes, void* stream);
 
 /* ================================================================================================ RoI grid pooling
  * the operators that consume multi_scale_3d_features['x_conv3'/'x_conv4'] right after the backbone

@@ -868,3 +868,30 @@ def test_backbone_marks_sorted_tables_and_uses_the_window_kernel(hip_backend):
         oi = st["out_indices"].long()
         lin = ((oi[:, 0] * st["out_shape"][0] + oi[:, 1]) * st["out_shape"][1] + oi[:, 2]) * st["out_shape"][2] + oi[:, 3]
         assert bool((lin[1:] > lin[:-1]).all())
+
+
+@pytest.mark.parametrize("wdma,winrows", [(1, 32), (0, 24), (1, 24)])
+@pytest.mark.parametrize("cin,cout", [(16, 16), (64, 32), (32, 64), (64, 64)])
+def test_window_gather_gemm_pipeline_variants_keep_the_bits(hip_backend, wdma, winrows, cin, cout):
+    """The experiment switches of the window kernel (W images through the LDS-DMA engine; 24-row windows) are scheduling
+    variants: forward and backward-input stay bit-identical to the direct kernel, on sorted and on permuted tables."""
+    rng = np.random.default_rng(cin * 3 + cout + wdma)
+    idx, shape = _sorted_scene(47, 1)
+    lib = hip_backend.lib
+    try:
+        assert lib.vc_debug_set(b"conv_wdma", wdma) == 0 and lib.vc_debug_set(b"conv_winrows", winrows) == 0
+        for permute in (False, True):
+            ii = idx[rng.permutation(idx.shape[0])] if permute else idx
+            n = ii.shape[0]
+            it = torch.from_numpy(np.ascontiguousarray(ii)).cuda()
+            pair, _ = hip_backend.subm_rulebook(it, shape, (3, 3, 3), (1, 1, 1), want_rep=False)
+            x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).cuda()
+            g = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32)).cuda()
+            w = torch.from_numpy((rng.standard_normal((cout, 3, 3, 3, cin)) / 5).astype(np.float32)).cuda()
+            for _ in range(2):
+                assert torch.equal(hip_backend.conv_forward(x, w, pair, sorted_rows=True), hip_backend.conv_forward(x, w, pair))
+                assert torch.equal(hip_backend.conv_backward_input(g, w, pair, n, mirror=True, sorted_rows=True),
+                                   hip_backend.conv_backward_input(g, w, pair, n, mirror=True))
+    finally:
+        lib.vc_debug_set(b"conv_wdma", 0)
+        lib.vc_debug_set(b"conv_winrows", 32)

@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--operand", default="f32", choices=["f32", "f16", "bf16"], help="MFMA operand type")
     ap.add_argument("--bw-legacy", action="store_true", help="offset-major block order in the weight-gradient kernel")
     ap.add_argument("--no-window", action="store_true", help="never use the LDS row-window gather-GEMM (A/B)")
+    ap.add_argument("--wdma", type=int, default=0, help="window kernel: W images through the LDS-DMA engine (vc_debug_set conv_wdma)")
+    ap.add_argument("--winrows", type=int, default=32, help="window kernel: rows per wave window, 32 | 24 (vc_debug_set conv_winrows)")
+    ap.add_argument("--layers", default="", help="comma-separated substrings: only time layers whose name contains one of them")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     be = ops.get_backend()
@@ -56,6 +59,7 @@ def main():
         assert be.lib.vc_debug_set(b"conv_variant", args.variant) == 0
     assert be.lib.vc_debug_set(b"conv_rt", args.rt) == 0
     assert be.lib.vc_debug_set(b"bw_legacy_order", 1 if args.bw_legacy else 0) == 0
+    assert be.lib.vc_debug_set(b"conv_wdma", args.wdma) == 0 and be.lib.vc_debug_set(b"conv_winrows", args.winrows) == 0
     torch.zeros(1, device=dev)
     assert be.lib.vc_debug_set(b"xcd_swizzle_off", 1 if args.no_xcd else 0) == 0
     batch = bench.make_batch(list(range(args.bs)), dev, training=True)
@@ -106,6 +110,8 @@ def main():
           f"{'bwd us':>8s} {'TF':>6s} {'%pk':>5s} | {'dW us':>8s} {'TF':>6s} {'%pk':>5s}")
     tot = {"fwd": 0.0, "bwd": 0.0, "dw": 0.0, "flops": 0.0}
     for name, rb, cin, cout in layers:
+        if args.layers and not any(t in name for t in args.layers.split(",")):
+            continue
         kv = rb.kv
         x = torch.randn((rb.n_in, cin), generator=g).to(dev)
         w = (torch.randn((cout, kv, cin), generator=g) / np.sqrt(kv * cin)).to(dev).reshape((cout,) + tuple(rb.ksize) + (cin,))
@@ -133,7 +139,7 @@ def main():
         line += (f"{f:8.1f} {tf(f):6.2f} {100 * tf(f) / PEAK:5.1f} {byts / (f * 1e-6) / 1e9:6.0f} | " if f else " " * 34 + "| ")
         line += (f"{b:8.1f} {tf(b):6.2f} {100 * tf(b) / PEAK:5.1f} | " if b else " " * 23 + "| ")
         line += (f"{d:8.1f} {tf(d):6.2f} {100 * tf(d) / PEAK:5.1f}" if d else "")
-        if ops.ROW_ORDER != "none":
+        if ops.ROW_ORDER != "none" and not args.layers:
             line += f" | ord {timeit(lambda: be.row_order(rb.pair_fwd, window=ops.ROW_ORDER_WINDOW), args.iters):6.1f}"
         print(line)
         for k in ("fwd", "bwd", "dw"):

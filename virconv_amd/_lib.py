@@ -41,7 +41,7 @@ SIGNATURES = {
     "vc_conv_epilogue_supported": (_I, [_I64, _I, _I, _I, _I]),
     "vc_conv_stats_partial_floats": (_SZ, [_I64, _I64, _I, _I, _I, _I]),
     "vc_conv_forward_epilogue": (_I, [_P, _I64, _P, _I64, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _F, _I, _P, _P]),
-    "vc_bn_stats_from_partial": (_I, [_P, _I64, _I64, _I, _P, _P, _P, _P, _P, _F, _P]),
+    "vc_bn_stats_from_partial": (_I, [_P, _I64, _I64, _I, _P, _P, _P, _P, _P, _F, _P, _SZ, _P]),
     "vc_random_keep": (_I, [_I64, _I64, C.c_uint64, _P, _P]),
     "vc_row_order": (_I, [_P, _I64, _I, _P, _I, _I, _P, _P]),
     "vc_conv_backward_weight_workspace_bytes": (_SZ, [_I64, _I, _I, _I]),
@@ -63,6 +63,12 @@ SIGNATURES = {
     "vc_frontend_workspace_bytes": (_SZ, [_I64, _I64, _I, _I]),
     "vc_frontend_voxelize_mean": (_I, [_P, _I64, _P, _I, _I64, _I, _I, _D, _D, _P, C.c_uint64, _F, _P, _P, _I, _I, _I, _P, _SZ,
                                        _P, _P, _P, _P, _P, _P]),
+    "vc_post_act_block_forward_workspace_bytes": (_SZ, [_I64, _I64, _I, _I, _I, _I]),
+    "vc_post_act_block_forward": (_I, [_P, _I64, _P, _I64, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P,
+                                       _I, _I, _P, _P, _P, _SZ, _P]),
+    "vc_post_act_block_backward_workspace_bytes": (_SZ, [_I64, _I, _I, _I]),
+    "vc_post_act_block_backward": (_I, [_P, _I64, _P, _I64, _P, _I, _I, _P, _P, _P, _P, _F, _I, _P, _P, _I64, _I, _I, _P, _P,
+                                        _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _P]),
     "vc_bn_workspace_bytes": (_SZ, [_I64, _I]),
     "vc_bn_stats": (_I, [_P, _I64, _I, _P, _P, _P, _P, _P, _F, _P, _SZ, _P]),
     "vc_bn_apply_relu": (_I, [_P, _I64, _I, _P, _P, _P, _P, _F, _I, _P, _I, _I, _P]),

@@ -61,20 +61,20 @@ class HipBackend:
         torch.cuda.synchronize()
         out = []
         for e in log:
-            pairs = int(e["pairs"].item())
+            pairs = int((e["tbl"] >= 0).sum().item())  # counted here, after the timed region (the table was kept alive)
             kv, ck, cn = e["kv"], e["ck"], e["cn"]
             out.append({"ms": e["start"].elapsed_time(e["end"]), "flops": 2.0 * pairs * ck * cn,
                         "bytes": 4.0 * (e["n_src"] * ck + e["n_out"] * cn + kv * ck * cn) + 4.0 * kv * e["n_out"],
-                        "pairs": pairs, "n_out": e["n_out"]})
+                        "pairs": pairs, "n_out": e["n_out"], "windowed": e["windowed"]})
         return out
 
     def _traced(self, direction, ck, cn):
         return self._trace is not None and self._trace == (direction, ck, cn)
 
-    def _trace_open(self, tbl, n_src, ck, cn):
+    def _trace_open(self, tbl, n_src, ck, cn, windowed=False):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        rec = {"pairs": (tbl >= 0).sum(), "kv": tbl.shape[0], "n_out": tbl.shape[1], "n_src": n_src, "ck": ck, "cn": cn,
-               "start": ev0, "end": ev1}
+        rec = {"tbl": tbl, "kv": tbl.shape[0], "n_out": tbl.shape[1], "n_src": n_src, "ck": ck, "cn": cn,
+               "start": ev0, "end": ev1, "windowed": bool(windowed)}
         ev0.record()
         return rec
 
@@ -160,7 +160,8 @@ class HipBackend:
         cout, cin = weight.shape[0], weight.shape[-1]
         assert weight.numel() == cout * kv * cin and x.shape[1] == cin
         y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
-        rec = self._trace_open(pair_fwd, x.shape[0], cin, cout) if self._traced("fwd", cin, cout) else None
+        rec = self._trace_open(pair_fwd, x.shape[0], cin, cout, sorted_rows and cin >= 16 and operand == "f32" and order is None) \
+            if self._traced("fwd", cin, cout) else None
         check(self.lib.vc_conv_forward(_ptr(x), x.shape[0], _ptr(pair_fwd), n_out, kv, _ptr(weight), cin, cout,
                                        _ptr(order), OPERAND_TYPES[operand], CONV_SORTED_ROWS if sorted_rows else 0, _ptr(y),
                                        _stream()), "vc_conv_forward")
@@ -183,7 +184,8 @@ class HipBackend:
         flags = CONV_SORTED_ROWS if sorted_rows else 0
         partial = torch.empty((self.lib.vc_conv_stats_partial_floats(x.shape[0], n_out, cin, cout, kv, flags),),
                               dtype=torch.float32, device=x.device)
-        rec = self._trace_open(pair_fwd, x.shape[0], cin, cout) if self._traced("fwd", cin, cout) else None
+        rec = self._trace_open(pair_fwd, x.shape[0], cin, cout, sorted_rows and cin >= 16 and order is None) \
+            if self._traced("fwd", cin, cout) else None
         check(self.lib.vc_conv_forward_epilogue(_ptr(x), x.shape[0], _ptr(pair_fwd), n_out, kv, _ptr(weight), cin, cout,
                                                 _ptr(order), 1, flags, _ptr(partial), None, None, None, None, 0.0, 0,
                                                 _ptr(y), _stream()), "vc_conv_forward_epilogue")
@@ -229,7 +231,8 @@ class HipBackend:
             check(self.lib.vc_group_sum(_ptr(dy), _ptr(rep), dy.shape[0], cout, _ptr(grp), _ptr(gws), gws_bytes,
                                         1 if group_ws is not None else 0, _stream()), "vc_group_sum")
             src, src_centre = grp, dy
-        rec = self._trace_open(tbl, dy.shape[0], cout, cin) if self._traced("bwd", cout, cin) else None
+        rec = self._trace_open(tbl, dy.shape[0], cout, cin, sorted_rows and cout >= 16 and operand == "f32" and order is None
+                               and rep is None) if self._traced("bwd", cout, cin) else None
         check(self.lib.vc_conv_backward_input(_ptr(src), _ptr(src_centre), dy.shape[0], _ptr(tbl), n_in, kv, _ptr(weight),
                                               cin, cout, 1 if mirror else 0, centre if rep is not None else -1,
                                               _ptr(rep), _ptr(order), OPERAND_TYPES[operand],
@@ -516,9 +519,11 @@ class HipBackend:
             mean = torch.empty((c,), dtype=torch.float32, device=dev)
             var = torch.empty((c,), dtype=torch.float32, device=dev)
             if partial is not None:
+                ws_bytes = self.lib.vc_bn_workspace_bytes(n, c)
+                ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
                 check(self.lib.vc_bn_stats_from_partial(_ptr(partial), partial.numel() // (2 * c), n, c, _ptr(mean),
                                                         _ptr(var), _ptr(running_mean), _ptr(running_var),
-                                                        _ptr(num_batches_tracked), float(momentum), st),
+                                                        _ptr(num_batches_tracked), float(momentum), _ptr(ws), ws_bytes, st),
                       "vc_bn_stats_from_partial")
             else:
                 ws_bytes = self.lib.vc_bn_workspace_bytes(n, c)
@@ -534,6 +539,93 @@ class HipBackend:
         check(self.lib.vc_bn_apply_relu(_ptr(x), n, c, _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), float(eps),
                                         1 if relu else 0, _ptr(out), out.shape[1], out_col0, st), "vc_bn_apply_relu")
         return out, mean, var
+
+    # ------------------------------------------------------------------ post_act_block (conv + BN + ReLU) as one call each way
+    def _group_acc(self, nbytes: int, device) -> torch.Tensor:
+        """Persistent all-zero int64 accumulator of the duplicate-pixel group sum (vc_group_sum prepared = 2): zeroed when it
+        is (re)allocated, handed back all-zero by every call."""
+        buf = getattr(self, "_gacc", None)
+        if buf is None or buf.numel() < nbytes or buf.device != torch.device(device):
+            buf = torch.zeros((int(nbytes * 1.25) + 4096,), dtype=torch.uint8, device=device)
+            self._gacc = buf
+        return buf
+
+    def post_act_block_forward(self, x, weight, tbl, order, operand: str, sorted_rows: bool, gamma, beta, running_mean,
+                               running_var, nbt, momentum: float, eps: float, relu: bool):
+        """conv -> training-mode BatchNorm1d -> (ReLU) in ONE C-ABI call (vc_post_act_block_forward).
+        -> (y, y_raw, mean, var)"""
+        x = _need(x, torch.float32, "features")
+        weight = _need(weight, torch.float32, "weight")
+        kv, n_out = tbl.shape
+        cout, cin = weight.shape[0], weight.shape[-1]
+        dev = x.device
+        flags = CONV_SORTED_ROWS if sorted_rows else 0
+        y_raw = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
+        y = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
+        stats = torch.empty((2, cout), dtype=torch.float32, device=dev)
+        ws_bytes = self.lib.vc_post_act_block_forward_workspace_bytes(x.shape[0], n_out, kv, cin, cout, flags)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        traced = self._traced("fwd", cin, cout)
+        rec = self._trace_open(tbl, x.shape[0], cin, cout, sorted_rows and cin >= 16 and operand == "f32" and order is None) \
+            if traced else None
+        if rec is not None:
+            # the roofline trace brackets the conv launch alone: run the unit's three operators one by one for this layer
+            if rec["windowed"]:
+                part = torch.empty((self.lib.vc_conv_stats_partial_floats(x.shape[0], n_out, cin, cout, kv, flags),),
+                                   dtype=torch.float32, device=dev)
+                check(self.lib.vc_conv_forward_epilogue(_ptr(x), x.shape[0], _ptr(tbl), n_out, kv, _ptr(weight), cin, cout,
+                                                        None, 1, flags, _ptr(part), None, None, None, None, 0.0, 0,
+                                                        _ptr(y_raw), _stream()), "vc_conv_forward_epilogue")
+                self._trace_close(rec)
+                check(self.lib.vc_bn_stats_from_partial(_ptr(part), part.numel() // (2 * cout), n_out, cout, _ptr(stats[0]),
+                                                        _ptr(stats[1]), _ptr(running_mean), _ptr(running_var), _ptr(nbt),
+                                                        float(momentum), _ptr(ws), ws_bytes, _stream()), "vc_bn_stats_from_partial")
+            else:
+                check(self.lib.vc_conv_forward(_ptr(x), x.shape[0], _ptr(tbl), n_out, kv, _ptr(weight), cin, cout, _ptr(order),
+                                               OPERAND_TYPES[operand], flags, _ptr(y_raw), _stream()), "vc_conv_forward")
+                self._trace_close(rec)
+                check(self.lib.vc_bn_stats(_ptr(y_raw), n_out, cout, _ptr(stats[0]), _ptr(stats[1]), _ptr(running_mean),
+                                           _ptr(running_var), _ptr(nbt), float(momentum), _ptr(ws), ws_bytes, _stream()),
+                      "vc_bn_stats")
+            check(self.lib.vc_bn_apply_relu(_ptr(y_raw), n_out, cout, _ptr(stats[0]), _ptr(stats[1]), _ptr(gamma), _ptr(beta),
+                                            float(eps), 1 if relu else 0, _ptr(y), cout, 0, _stream()), "vc_bn_apply_relu")
+            return y, y_raw, stats[0], stats[1]
+        check(self.lib.vc_post_act_block_forward(_ptr(x), x.shape[0], _ptr(tbl), n_out, kv, _ptr(weight), cin, cout,
+                                                 _ptr(order), OPERAND_TYPES[operand], flags, _ptr(gamma), _ptr(beta),
+                                                 _ptr(running_mean), _ptr(running_var), _ptr(nbt), float(momentum),
+                                                 float(eps), 1 if relu else 0, _ptr(y_raw), _ptr(y), cout, 0,
+                                                 _ptr(stats[0]), _ptr(stats[1]), _ptr(ws), ws_bytes, _stream()),
+              "vc_post_act_block_forward")
+        return y, y_raw, stats[0], stats[1]
+
+    def post_act_block_backward(self, x, weight, y_raw, dy_wide, dy_col0: int, mean, var, gamma, beta, eps: float, relu: bool,
+                                pair_fwd, tbl_dx, n_dx: int, mirror: bool, centre: int, rep, order_dx, operand: str,
+                                sorted_rows: bool, need_dx: bool, need_dw: bool):
+        """BatchNorm+ReLU backward -> (group sum) -> backward-input conv -> weight gradient in ONE C-ABI call.
+        -> (dx | None, dw | None, dgamma, dbeta)"""
+        kv, n_out = pair_fwd.shape
+        cout, cin = weight.shape[0], weight.shape[-1]
+        dev = x.device
+        flags = CONV_SORTED_ROWS if sorted_rows else 0
+        d_raw = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
+        dx = torch.empty((n_dx, cin), dtype=torch.float32, device=dev) if need_dx else None
+        dw = torch.empty(tuple(weight.shape), dtype=torch.float32, device=dev) if need_dw else None
+        dgb = torch.empty((2, cout), dtype=torch.float32, device=dev)
+        ws_bytes = self.lib.vc_post_act_block_backward_workspace_bytes(n_out, kv, cin, cout)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        gacc, gacc_bytes = None, 0
+        if rep is not None and need_dx:
+            gacc_bytes = self.lib.vc_group_sum_workspace_bytes(n_out, cout)
+            gacc = self._group_acc(gacc_bytes, dev)
+        check(self.lib.vc_post_act_block_backward(_ptr(x), x.shape[0], _ptr(y_raw), n_out, _ptr(dy_wide), dy_wide.shape[1],
+                                                  dy_col0, _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), float(eps),
+                                                  1 if relu else 0, _ptr(pair_fwd), _ptr(tbl_dx), n_dx, 1 if mirror else 0,
+                                                  centre, _ptr(rep), _ptr(order_dx), kv, _ptr(weight), cin, cout,
+                                                  OPERAND_TYPES[operand], flags, 1 if need_dx else 0, 1 if need_dw else 0,
+                                                  _ptr(d_raw), _ptr(dx), _ptr(dw), _ptr(dgb[0]), _ptr(dgb[1]), _ptr(gacc),
+                                                  gacc.numel() if gacc is not None else 0, _ptr(ws), ws_bytes, _stream()),
+              "vc_post_act_block_backward")
+        return dx, dw, dgb[0], dgb[1]
 
     def group_sum_prepare(self, n: int, c: int, device) -> torch.Tensor:
         """Zeroed group-sum workspace; hand it to bn_backward(absmax_ws=...) and then to conv_backward_input(group_ws=...)."""

@@ -23,6 +23,7 @@ SOURCES = {
     "bn_kernels.hip": [],
     "pool_kernels.hip": ["-ffp-contract=off"],
     "frontend_kernels.hip": ["-ffp-contract=off"],
+    "unit.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 

@@ -15,8 +15,10 @@ __global__ void __launch_bounds__(256) bn_reduce_kernel(const float* __restrict_
                                                         const float* __restrict__ mean, const float* __restrict__ var,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float eps, int relu, int64_t rows_per_block,
-                                                        double* __restrict__ partial) {
+                                                        double* __restrict__ partial, unsigned* __restrict__ zero_word) {
   __shared__ double lds[256 * 8];
+  // the max|dx| word bn_bwd_dx_pow2_kernel (the next launch on this stream) accumulates into with atomicMax: cleared here
+  if (zero_word != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0u;
   const int c4 = c >> 2;
   const int R = 256 / c4;           // row-threads per block (power of two)
   const int cq = threadIdx.x % c4;  // which float4 of the row
@@ -176,6 +178,36 @@ __global__ void __launch_bounds__(256) bn_stats_from_partial_kernel(const float*
   if (running_var) {
     const double unb = (n > 1) ? v * (double)n / (double)(n - 1) : v;
     running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unb;
+  }
+}
+
+// First stage for MANY conv-epilogue partial rows (one per 16-row wave tile on the LDS-window kernel: N/16 rows): block g adds
+// up a contiguous slab of rows with fully coalesced reads (a row = 2c consecutive floats; thread = (row sub-index, column)),
+// fp64 accumulation, fixed order, and writes ONE fp64 partial row in the [g][2][c] layout of bn_stats_finalize_kernel.
+__global__ void __launch_bounds__(256) bn_partial_reduce_kernel(const float* __restrict__ partial, int64_t nb,
+                                                                int64_t rows_per_block, int c,
+                                                                double* __restrict__ dpartial) {
+  __shared__ double lds[256];
+  const int c2 = 2 * c;
+  const int RS = 256 / c2;  // row sub-threads (c2 <= 256, power of two)
+  const int col = threadIdx.x % c2, rs = threadIdx.x / c2;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, nb);
+  double acc = 0.0;
+  if (rs < RS) {
+    int64_t r = r0 + rs;
+    for (; r + 3 * (int64_t)RS < r1; r += 4 * (int64_t)RS) {  // four loads in flight, consumed in row order
+      const float v0 = partial[r * c2 + col], v1 = partial[(r + RS) * c2 + col];
+      const float v2 = partial[(r + 2 * RS) * c2 + col], v3 = partial[(r + 3 * RS) * c2 + col];
+      acc += (double)v0; acc += (double)v1; acc += (double)v2; acc += (double)v3;
+    }
+    for (; r < r1; r += RS) acc += (double)partial[r * c2 + col];
+  }
+  lds[threadIdx.x] = acc;
+  __syncthreads();
+  if (rs == 0) {
+    double t = lds[col];
+    for (int u = 1; u < RS; ++u) t += lds[u * c2 + col];
+    dpartial[(int64_t)blockIdx.x * c2 + col] = t;
   }
 }
 
@@ -417,7 +449,7 @@ int vc_bn_stats(const float* x, int64_t n, int c, float* mean, float* var, float
   double* partial = (double*)ws;
   hipLaunchKernelGGL((bn_reduce_kernel<false>), dim3(nb), dim3(256), 0, st, x, (const float*)nullptr, 0, 0, n, c,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f, 0,
-                     rpb, partial);
+                     rpb, partial, (unsigned*)nullptr);
   VC_CHECK_LAUNCH("bn_reduce_kernel<stats>");
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, partial, nb, n, c, mean, var,
                      running_mean, running_var, (long long*)num_batches_tracked, momentum);
@@ -427,9 +459,23 @@ int vc_bn_stats(const float* x, int64_t n, int c, float* mean, float* var, float
 
 int vc_bn_stats_from_partial(const float* partial, int64_t nblocks, int64_t n, int c, float* mean, float* var,
                              float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
-                             void* stream) {
+                             void* ws, size_t ws_bytes, void* stream) {
   VC_REQUIRE(c >= 1 && n >= 1 && nblocks >= 1 && partial && mean && var, "vc_bn_stats_from_partial: null/invalid argument");
-  hipLaunchKernelGGL(bn_stats_from_partial_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, nblocks, n,
+  hipStream_t st = (hipStream_t)stream;
+  if (nblocks > 512 && ws != nullptr && 2 * c <= 256 && (c & (c - 1)) == 0) {
+    // many partial rows: coalesced slab reduce to <= 256 fp64 rows, then the ordinary finalize
+    if (ws_bytes < vc_bn_workspace_bytes(n, c)) { set_error("vc_bn_stats_from_partial: workspace too small"); return VC_ECAPACITY; }
+    const int64_t rpb = cdiv(nblocks, 256);
+    const int g = (int)cdiv(nblocks, rpb);
+    double* dpartial = (double*)ws;
+    hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(g), dim3(256), 0, st, partial, nblocks, rpb, c, dpartial);
+    VC_CHECK_LAUNCH("bn_partial_reduce_kernel");
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, dpartial, g, n, c, mean, var,
+                       running_mean, running_var, (long long*)num_batches_tracked, momentum);
+    VC_CHECK_LAUNCH("bn_stats_finalize_kernel");
+    return VC_OK;
+  }
+  hipLaunchKernelGGL(bn_stats_from_partial_kernel, dim3((c + 3) / 4), dim3(256), 0, st, partial, nblocks, n,
                      c, mean, var, running_mean, running_var, (long long*)num_batches_tracked, momentum);
   VC_CHECK_LAUNCH("bn_stats_from_partial_kernel");
   return VC_OK;
@@ -469,7 +515,7 @@ int vc_bn_relu_backward(const float* x, const float* dy, int dy_stride, int dy_c
   double* partial = (double*)ws;
   float* sums = (float*)(partial + (size_t)kMaxBnBlocks * 2 * c);
   hipLaunchKernelGGL((bn_reduce_kernel<true>), dim3(nb), dim3(256), 0, st, x, dy, dy_stride, dy_col0, n, c, mean, var,
-                     gamma, beta, eps, relu, rpb, partial);
+                     gamma, beta, eps, relu, rpb, partial, absmax_out);
   VC_CHECK_LAUNCH("bn_reduce_kernel<bwd>");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, partial, nb, c, dgamma, dbeta, sums);
   VC_CHECK_LAUNCH("bn_bwd_finalize_kernel");

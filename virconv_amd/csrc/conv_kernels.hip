@@ -20,10 +20,13 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ int g_xcd_swizzle_off = 0;  // developer switch (tools/kbench.py --no-xcd)
-// v2 MFMA phase: 1 = all B fragments of an offset are read before its first MFMA and consecutive MFMAs alternate between
-// the output-column accumulators (round 2); 0 = the round-1 order (kept for A/B builds: hipcc -DVC_V2_SCHED=0)
+// v2 MFMA phase order.  0 (default) = the round-1 order: hipcc reads each B fragment right before its four MFMAs, 68 VGPRs,
+// 6 waves per SIMD.  1 = every B fragment of an offset read before its first MFMA + accumulator-alternating MFMAs: better
+// per-wave code but 97 VGPRs / 4 waves per SIMD, and MEASURED SLOWER (s3.d3_conv1 64->32 forward 242 vs 208 us,
+// profiles/r02_kbench_variants.txt): this kernel waits ~2 us for every W_k it requested one iteration earlier, and only
+// resident waves hide that.  Kept for A/B builds (hipcc -DVC_V2_SCHED=1).
 #ifndef VC_V2_SCHED
-#define VC_V2_SCHED 1
+#define VC_V2_SCHED 0
 #endif
 
 // Reduced-precision MFMA operands (BASELINE configs[4]: "fp16 MFMA contraction"): features / gradients / weights stay fp32
@@ -519,7 +522,7 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
 //
 // W_k staging (per offset, double-buffered, one block barrier per offset) and the XCD-aware block mapping are v2's.
 // EPI == VC_EPI_STATS here writes one partial row per WAVE (16 output rows): no extra barrier in the epilogue.
-static constexpr int kWinRows = 32;
+static constexpr int kWinRowsDefault = 32;
 
 // full-wave integer min / max on the DPP crossbar (row_shr 1/2/4/8 scans a 16-lane row, row_bcast:15 / :31 chain the rows; the
 // result is lane 63's): seven VALU instructions and no LDS round trip -- __shfl_xor lowers to ds_bpermute + a wait per step,
@@ -549,13 +552,16 @@ __device__ __forceinline__ int wave_max_i32(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
-template <int CK, int CN, bool BWD, int EPI>
+template <int CK, int CN, bool BWD, int EPI, bool WDMA, int WINROWS>
 __global__ void __launch_bounds__(256) gather_gemm_v3_kernel(const float* __restrict__ src, int64_t n_src,
                                                              const int32_t* __restrict__ tbl,
                                                              const float* __restrict__ w, float* __restrict__ out,
                                                              int64_t n_out, int kv, int mirror, ConvEpilogue epi) {
   static_assert(CK >= 16 && CK % 16 == 0, "the window kernel moves 16-byte chunks of whole rows");
   static_assert(EPI == VC_EPI_NONE || !BWD, "epilogues exist for the forward kernel only");
+  static_assert(!WDMA || CN % 16 == 0, "the LDS-DMA weight pipeline cannot zero-fill padded output columns");
+  constexpr int kWinRows = WINROWS;             // rows of the per-wave LDS window (+ one zero row)
+  constexpr int NSLOT = WDMA ? 3 : 2;           // W images in LDS
   constexpr int V = 4;
   constexpr int NCH = CK / 16;
   constexpr int NT = (CN + 15) / 16;
@@ -565,13 +571,14 @@ __global__ void __launch_bounds__(256) gather_gemm_v3_kernel(const float* __rest
   constexpr int WS = CK + 4;                    // window row stride in floats (16-byte pad)
   constexpr int LPR = CK / 4;                   // lanes (16-byte chunks) per row
   constexpr int RPI = 64 / LPR;                 // rows per wave load instruction
-  constexpr int NWI = kWinRows / RPI;           // load instructions of a full window
+  constexpr int NWI = (kWinRows + RPI - 1) / RPI;  // load instructions of a full window
+  constexpr int NDMA = BWD ? BF / 256 : BLD;    // LDS-DMA instructions per wave and W image (4-byte / 16-byte granules)
   constexpr int NSTG = (NCH * NT > 8) ? 2 : 1;  // fragment stages per offset (register budget: <= 8 B fragments in flight)
   constexpr int CPS = NCH / NSTG;               // K-chunks per stage
   static_assert(NCH % NSTG == 0, "stage split");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* s_b = reinterpret_cast<float*>(smem);                                  // [2][BF]
-  int* s_idx = reinterpret_cast<int*>(s_b + 2 * BF);                            // [kv][64]
+  float* s_b = reinterpret_cast<float*>(smem);                                  // [NSLOT][BF]
+  int* s_idx = reinterpret_cast<int*>(s_b + NSLOT * BF);                        // [kv][64]
   float* s_win = reinterpret_cast<float*>(s_idx + kv * 64);                     // [4][(kWinRows + 1) * WS]
   unsigned* s_mask = reinterpret_cast<unsigned*>(s_win + 4 * (kWinRows + 1) * WS);
 
@@ -607,12 +614,12 @@ __global__ void __launch_bounds__(256) gather_gemm_v3_kernel(const float* __rest
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (bmask != 0u) {
-    float breg[BLD][V];
+    float bregA[BLD][V], bregB[BLD][V];  // W images in flight: loaded two offsets ahead, written to LDS one offset ahead
     f32x4 wreg[NWI];
 #pragma unroll
     for (int c = 0; c < NWI; ++c) wreg[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#define VC3_LOAD_B(K)                                                                              \
+#define VC3_LOAD_B(K, BR)                                                                          \
   do {                                                                                             \
     const int kw_ = mirror ? (kv - 1 - (K)) : (K);                                                 \
     _Pragma("unroll") for (int u = 0; u < BLD; ++u) {                                              \
@@ -622,13 +629,13 @@ __global__ void __launch_bounds__(256) gather_gemm_v3_kernel(const float* __rest
         const int n_ = nt_ * 16 + (fl & 15), kk0 = ch_ * 16 + (fl >> 4) * 4;                       \
         if (CN % 16 == 0 || n_ < CN) {                                                             \
           if (!BWD) {                                                                              \
-            VecLoad<V>::ld(w + ((int64_t)n_ * kv + kw_) * CK + kk0, breg[u]);                      \
+            VecLoad<V>::ld(w + ((int64_t)n_ * kv + kw_) * CK + kk0, BR[u]);                      \
           } else {                                                                                 \
             _Pragma("unroll") for (int j = 0; j < V; ++j)                                          \
-                breg[u][j] = w[((int64_t)(kk0 + j) * kv + kw_) * CN + n_];                         \
+                BR[u][j] = w[((int64_t)(kk0 + j) * kv + kw_) * CN + n_];                         \
           }                                                                                        \
         } else {                                                                                   \
-          _Pragma("unroll") for (int j = 0; j < V; ++j) breg[u][j] = 0.f;                          \
+          _Pragma("unroll") for (int j = 0; j < V; ++j) BR[u][j] = 0.f;                          \
         }                                                                                          \
       }                                                                                            \
     }                                                                                              \
@@ -667,30 +674,26 @@ __global__ void __launch_bounds__(256) gather_gemm_v3_kernel(const float* __rest
     VC3_ISSUE(pre_lo, pre_span);
     int cur_g = -1, cur_lo = 0, cur_ok = 0;                // window now in LDS
 
-    int k = __ffs((int)bmask) - 1;
-    bmask &= bmask - 1;
-    VC3_LOAD_B(k);
-    int p = 0;
-    for (;;) {
-      // ---- W_k: registers -> LDS image p, visible after the barrier (which also retires every read of image p^1)
-#pragma unroll
-      for (int u = 0; u < BLD; ++u) {
-        const int f = tid + u * 256;
-        if (NFRAG % 256 == 0 || f < NFRAG)
-          *reinterpret_cast<f32x4*>(s_b + p * BF + f * V) = f32x4{breg[u][0], breg[u][1], breg[u][2], breg[u][3]};
-      }
-      __syncthreads();
-      const int knext = (bmask != 0u) ? (__ffs((int)bmask) - 1) : -1;
-      bmask &= bmask - 1;
-      if (knext >= 0) VC3_LOAD_B(knext);  // in flight under this offset's MFMAs
+#define VC3_STORE_B(P, BR)                                                                         \
+  do {                                                                                             \
+    _Pragma("unroll") for (int u = 0; u < BLD; ++u) {                                              \
+      const int f = tid + u * 256;                                                                 \
+      if (NFRAG % 256 == 0 || f < NFRAG)                                                           \
+        *reinterpret_cast<f32x4*>(s_b + (P) * BF + f * V) = f32x4{BR[u][0], BR[u][1], BR[u][2], BR[u][3]}; \
+    }                                                                                              \
+  } while (0)
 
+    // one offset for this wave, in two parts: the group switch (wave-local: parked rows -> LDS window, then the request for the
+    // next visited group's rows) and the MFMA phase on W image `p`
+    auto switch_group = [&](const int k) __attribute__((always_inline)) {
       // ---- group switch (wave-local): parked rows -> LDS window, then start the load of the next visited group's rows
       const int g = k / 3;
       if (g != cur_g) {  // pre_g == g: the prefetch always targets the next visited group
         __builtin_amdgcn_wave_barrier();  // the previous group's fragment reads are issued before the window is overwritten
 #pragma unroll
         for (int c = 0; c < NWI; ++c)
-          *reinterpret_cast<f32x4*>(win + (c * RPI + lane / LPR) * WS + (lane % LPR) * 4) = wreg[c];
+          if (kWinRows % RPI == 0 || c * RPI + lane / LPR < kWinRows)  // a partial last instruction must not touch the zero row
+            *reinterpret_cast<f32x4*>(win + (c * RPI + lane / LPR) * WS + (lane % LPR) * 4) = wreg[c];
         __builtin_amdgcn_wave_barrier();  // LDS serves a wave's accesses in order: the reads below see these writes
         cur_g = g; cur_lo = pre_lo; cur_ok = pre_span > 0;
         const unsigned rest = gmask & ~((2u << g) - 1u);  // groups after g
@@ -700,6 +703,8 @@ __global__ void __launch_bounds__(256) gather_gemm_v3_kernel(const float* __rest
         VC3_ISSUE(pre_lo, pre_span);
       }
 
+    };
+    auto mfma_phase = [&](const int k, const int p) __attribute__((always_inline)) {
       // ---- this wave's 16 rows x offset k.  Two separate code paths: the window path must not contain a VMEM-sourced
       // register (hipcc would put `s_waitcnt vmcnt(small)` in front of its MFMAs and drain the parked prefetches with it).
       const int id = s_idx[k * 64 + wave * 16 + i];
@@ -733,10 +738,98 @@ __global__ void __launch_bounds__(256) gather_gemm_v3_kernel(const float* __rest
         }
 #undef VC3_STAGE
       }
-      if (knext < 0) break;
-      k = knext;
-      p ^= 1;
+    };
+
+    int k = __ffs((int)bmask) - 1;
+    bmask &= bmask - 1;
+    int k1 = (bmask != 0u) ? (__ffs((int)bmask) - 1) : -1;
+    bmask &= bmask - 1;
+    if constexpr (WDMA) {
+      // W pipeline on the LDS-DMA engine (global_load_lds: HBM/L2 -> LDS, no registers): the image of offset n+2 is requested
+      // at iteration n into slot (n+2) % 3 and nobody waits for it before the bottom of iteration n+1 -- two MFMA phases of
+      // flight.  Each wave waits for ITS part of image n+1 (a counted vmcnt: the DMAs of image n+2 stay in flight), the
+      // barrier at the top of iteration n+1 then publishes the whole image and retires every read of image n (slot reuse is
+      // three iterations away).  hipcc's own bookkeeping would drain the queue at every barrier, hence the raw barrier.
+#define VC3_DMA_B(K, SLOT)                                                                         \
+  do {                                                                                             \
+    const int kw_ = mirror ? (kv - 1 - (K)) : (K);                                                 \
+    if constexpr (!BWD) {                                                                          \
+      _Pragma("unroll") for (int u = 0; u < BLD; ++u) {                                            \
+        const int f0 = __builtin_amdgcn_readfirstlane(u * 256 + wave * 64);                        \
+        if (NFRAG % 256 == 0 || f0 < NFRAG) {                                                      \
+          const int f = f0 + lane;                                                                 \
+          const int fl = f & 63, nt_ = (f >> 6) % NT, ch_ = (f >> 6) / NT;                         \
+          const int n_ = nt_ * 16 + (fl & 15), kk0 = ch_ * 16 + (fl >> 4) * 4;                     \
+          __builtin_amdgcn_global_load_lds(                                                        \
+              (const __attribute__((address_space(1))) void*)(w + ((int64_t)n_ * kv + kw_) * CK + kk0), \
+              (__attribute__((address_space(3))) void*)(s_b + (SLOT) * BF + f0 * 4), 16, 0, 0);    \
+        }                                                                                          \
+      }                                                                                            \
+    } else {                                                                                       \
+      _Pragma("unroll") for (int e = 0; e < BF / 256; ++e) {                                       \
+        const int fi0 = __builtin_amdgcn_readfirstlane((e * 4 + wave) * 64);                       \
+        const int fi = fi0 + lane, f = fi >> 2, j = fi & 3;                                        \
+        const int fl = f & 63, nt_ = (f >> 6) % NT, ch_ = (f >> 6) / NT;                           \
+        const int n_ = nt_ * 16 + (fl & 15), kk = ch_ * 16 + (fl >> 4) * 4 + j;                    \
+        __builtin_amdgcn_global_load_lds(                                                          \
+            (const __attribute__((address_space(1))) void*)(w + ((int64_t)kk * kv + kw_) * CN + n_), \
+            (__attribute__((address_space(3))) void*)(s_b + (SLOT) * BF + fi0), 4, 0, 0);          \
+      }                                                                                            \
+    }                                                                                              \
+  } while (0)
+      static_assert(BWD ? (BF % 256 == 0) : true, "whole 256-byte granules per wave");
+      VC3_DMA_B(k, 0);
+      if (k1 >= 0) VC3_DMA_B(k1, 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      int slot = 0;
+      for (;;) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int k2 = (bmask != 0u) ? (__ffs((int)bmask) - 1) : -1;
+        bmask &= bmask - 1;
+        switch_group(k);
+        const int slot2 = (slot >= 1) ? slot - 1 : 2;  // (slot + 2) % 3
+        if (k2 >= 0) VC3_DMA_B(k2, slot2);
+        mfma_phase(k, slot);
+        if (k1 < 0) break;
+        if (k2 >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        k = k1; k1 = k2; slot = (slot == 2) ? 0 : slot + 1;
+      }
+#undef VC3_DMA_B
+    } else {
+    // W pipeline through registers: the image of offset n+2 is REQUESTED at the top of iteration n (into the register set that
+    // iteration n-1 emptied), and the image of offset n+1 is WRITTEN to its LDS slot at the bottom of iteration n, after this
+    // offset's MFMAs.  (hipcc turns the counted wait in front of that write into vmcnt(0) across the loop back edge, so the
+    // effective flight time is one MFMA phase, as in v2.)  One barrier per offset: it publishes slot p and retires every read
+    // of slot p^1.
+    VC3_LOAD_B(k, bregA);
+    VC3_STORE_B(0, bregA);
+    if (k1 >= 0) VC3_LOAD_B(k1, bregB);
+    int p = 0;
+    for (;;) {
+      // ---- even iteration: request W_{n+2} into set A (emptied at the bottom of iteration n-1), publish W_{n+1} from set B
+      __syncthreads();
+      int k2 = (bmask != 0u) ? (__ffs((int)bmask) - 1) : -1;
+      bmask &= bmask - 1;
+      if (k2 >= 0) VC3_LOAD_B(k2, bregA);
+      switch_group(k);
+      mfma_phase(k, p);
+      if (k1 < 0) break;
+      VC3_STORE_B(p ^ 1, bregB);
+      k = k1; k1 = k2; p ^= 1;
+      // ---- odd iteration: the same with the register sets swapped
+      __syncthreads();
+      k2 = (bmask != 0u) ? (__ffs((int)bmask) - 1) : -1;
+      bmask &= bmask - 1;
+      if (k2 >= 0) VC3_LOAD_B(k2, bregB);
+      switch_group(k);
+      mfma_phase(k, p);
+      if (k1 < 0) break;
+      VC3_STORE_B(p ^ 1, bregA);
+      k = k1; k1 = k2; p ^= 1;
     }
+    }
+#undef VC3_STORE_B
 #undef VC3_LOAD_B
 #undef VC3_ANALYSE
 #undef VC3_ISSUE
@@ -1129,18 +1222,22 @@ __global__ void __launch_bounds__(256) group_sum_fixed_kernel(const float* __res
   atomicAdd((unsigned long long*)&acc_out[(int64_t)cur * c + ch], (unsigned long long)acc);
 }
 
-__global__ void __launch_bounds__(256) group_sum_convert_kernel(const long long* __restrict__ acc, int64_t total,
+__global__ void __launch_bounds__(256) group_sum_convert_kernel(long long* __restrict__ acc, int64_t total,
                                                                 const unsigned* __restrict__ absmax,
-                                                                float* __restrict__ grp) {
+                                                                float* __restrict__ grp, int rezero) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   // the scale is a power of two: multiplying by its exact inverse 2^(e-40) equals the division bit for bit (an fp64 divide per
   // element made this kernel ALU-bound)
   const float am = __uint_as_float(*absmax);
+  const long long a = acc[e];
+  // persistent accumulator (prepared = 2): every element is read by exactly this thread, which hands it back cleared -- the
+  // buffer is all-zero again for the next layer without a memset of 8*N*C bytes (8 of them per train step before)
+  if (rezero) acc[e] = 0;
   if (!(am > 0.f) || !isfinite(am)) { grp[e] = 0.f; return; }
   int ex;
   frexpf(am, &ex);
-  grp[e] = (float)((double)acc[e] * ldexp(1.0, ex - 40));
+  grp[e] = (float)((double)a * ldexp(1.0, ex - 40));
 }
 
 // --------------------------------------------------------------------------------------------- dispatch
@@ -1149,6 +1246,8 @@ int g_conv_variant = 2;        // 1 = gather_gemm_kernel (per-wave loads), 2 = g
 int g_conv_rt = 0;             // v2 row tiles per wave: 1 (64 rows/block) | 2 (128 rows/block) | 0 = heuristic
 
 int g_conv_window = 1;         // 0 = never take the LDS-window kernel (A/B measurements)
+int g_conv_wdma = 0;           // 1 = W images through the LDS-DMA engine in the window kernel
+int g_conv_winrows = 32;       // 24 = smaller per-wave windows (one more block per CU at 64 channels)
 
 // the LDS row-window kernel (v3) serves: fp32 operands, >= 16 source channels, natural row order, no duplicate-pixel rule,
 // tables the caller flags as coordinate-sorted (VC_CONV_SORTED_ROWS)
@@ -1167,20 +1266,28 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
   if constexpr (CK >= 16) {
     if (use_window_kernel<CK>(flags, ot, rep, order, n_src, kv, src_centre)) {
       constexpr int NCH = CK / 16, NT = (CN + 15) / 16;
-      const size_t lds = (size_t)2 * NCH * NT * 64 * 4 * sizeof(float) + (size_t)kv * 64 * sizeof(int) +
-                         (size_t)4 * (kWinRows + 1) * (CK + 4) * sizeof(float) + 16;
+      // experiment switches (vc_debug_set): conv_wdma = W images through the LDS-DMA engine, conv_winrows = 24-row windows
+      const bool wdma = g_conv_wdma && CN % 16 == 0 && epi_kind == VC_EPI_NONE;
+      const int winrows = (g_conv_winrows == 24 && epi_kind == VC_EPI_NONE) ? 24 : 32;
+      const size_t lds = (size_t)(wdma ? 3 : 2) * NCH * NT * 64 * 4 * sizeof(float) + (size_t)kv * 64 * sizeof(int) +
+                         (size_t)4 * (winrows + 1) * (CK + 4) * sizeof(float) + 16;
       const dim3 grid((unsigned)cdiv(n_out, 64));
 #define VC_ARGS3 src, n_src, tbl, w, out, n_out, kv, mirror, epi
-      if constexpr (!BWD) {
-        if (epi_kind == VC_EPI_STATS)
-          hipLaunchKernelGGL((gather_gemm_v3_kernel<CK, CN, false, VC_EPI_STATS>), grid, dim3(256), lds, st, VC_ARGS3);
-        else if (epi_kind == VC_EPI_AFFINE)
-          hipLaunchKernelGGL((gather_gemm_v3_kernel<CK, CN, false, VC_EPI_AFFINE>), grid, dim3(256), lds, st, VC_ARGS3);
-        else
-          hipLaunchKernelGGL((gather_gemm_v3_kernel<CK, CN, false, VC_EPI_NONE>), grid, dim3(256), lds, st, VC_ARGS3);
-      } else {
-        hipLaunchKernelGGL((gather_gemm_v3_kernel<CK, CN, true, VC_EPI_NONE>), grid, dim3(256), lds, st, VC_ARGS3);
+#define VC_L3(B_, E_, D_, R_) hipLaunchKernelGGL((gather_gemm_v3_kernel<CK, CN, B_, E_, D_, R_>), grid, dim3(256), lds, st, VC_ARGS3)
+      if (epi_kind == VC_EPI_NONE) {
+        if constexpr (CN % 16 == 0) {
+          if (wdma && winrows == 24) VC_L3(BWD, VC_EPI_NONE, true, 24);
+          else if (wdma) VC_L3(BWD, VC_EPI_NONE, true, 32);
+          else if (winrows == 24) VC_L3(BWD, VC_EPI_NONE, false, 24);
+          else VC_L3(BWD, VC_EPI_NONE, false, 32);
+        } else {
+          VC_L3(BWD, VC_EPI_NONE, false, 32);
+        }
+      } else if constexpr (!BWD) {
+        if (epi_kind == VC_EPI_STATS) VC_L3(false, VC_EPI_STATS, false, 32);
+        else VC_L3(false, VC_EPI_AFFINE, false, 32);
       }
+#undef VC_L3
 #undef VC_ARGS3
       VC_CHECK_LAUNCH("gather_gemm_v3_kernel");
       return VC_OK;
@@ -1345,6 +1452,8 @@ int vc_debug_set(const char* key, int value) {
   if (key && !strcmp(key, "conv_variant")) { g_conv_variant = value; return VC_OK; }
   if (key && !strcmp(key, "conv_rt")) { g_conv_rt = value; return VC_OK; }
   if (key && !strcmp(key, "conv_window")) { g_conv_window = value; return VC_OK; }
+  if (key && !strcmp(key, "conv_wdma")) { g_conv_wdma = value; return VC_OK; }
+  if (key && !strcmp(key, "conv_winrows")) { g_conv_winrows = value; return VC_OK; }
   if (key && !strcmp(key, "bw_legacy_order")) { g_bw_legacy_order = value; return VC_OK; }
   if (key && !strcmp(key, "xcd_swizzle_off")) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_swizzle_off), &value, sizeof(int)) == hipSuccess ? VC_OK : VC_EHIP;
@@ -1478,7 +1587,8 @@ int vc_group_sum(const float* dy, const int32_t* rep, int64_t n, int c, float* d
   hipLaunchKernelGGL(group_sum_fixed_kernel, dim3((unsigned)cdiv(cdiv(n, kGsRows) * c, 256)), dim3(256), 0, st, dy, rep, n, c,
                      absmax, acc);
   VC_CHECK_LAUNCH("group_sum_fixed_kernel");
-  hipLaunchKernelGGL(group_sum_convert_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, acc, total, absmax, dy_grp);
+  hipLaunchKernelGGL(group_sum_convert_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, acc, total, absmax, dy_grp,
+                     prepared == 2 ? 1 : 0);
   VC_CHECK_LAUNCH("group_sum_convert_kernel");
   return VC_OK;
 }

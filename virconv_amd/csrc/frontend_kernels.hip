@@ -214,7 +214,7 @@ static int input_discard_impl(const void* points, int is_half, int64_t p, int f,
                               hipStream_t st) {
   VC_REQUIRE(p >= 0 && f >= 1 && bin_num >= 1 && bin_num <= kMaxBins, "vc_input_discard: invalid p / f / bin_num (1..16)");
   VC_REQUIRE(rate >= 0.0 && rate < 1.0 && max_dis > 0.0, "vc_input_discard: need 0 <= rate < 1 and max_dis > 0");
-  VC_REQUIRE(ws && out && (points || p == 0), "vc_input_discard: null argument");
+  VC_REQUIRE(ws && (out || p == 0) && (points || p == 0), "vc_input_discard: null argument");
   VC_REQUIRE(!is_half || f % 2 == 0, "vc_input_discard: fp16 points need an even feature count");
   if (ws_bytes < discard_ws_bytes(p)) { set_error("vc_input_discard: workspace too small"); return VC_ECAPACITY; }
   DiscardHeader* hdr = (DiscardHeader*)ws;

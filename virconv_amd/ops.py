@@ -193,22 +193,28 @@ def _as_wide_rows(g: torch.Tensor):
 
 
 class ConvBNReLUFunction(torch.autograd.Function):
-    """conv -> training-mode BatchNorm1d -> (ReLU) as ONE autograd node (half the Python/autograd overhead of the two
-    separate nodes; same kernels, same numerics)."""
+    """conv -> training-mode BatchNorm1d -> (ReLU) as ONE autograd node; on the HIP backend each direction is ONE C-ABI call
+    (vc_post_act_block_forward / _backward: the unit of spconv_backbone.py:86-131), same kernels, same numerics."""
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, rb, inverse, running_mean, running_var, nbt, momentum, eps, relu):
         be = get_backend()
         tbl, order = (rb.pair_bwd, rb.order_bwd) if inverse else (rb.pair_fwd, rb.order_fwd)
-        if FUSE_BN_STATS and MFMA_OPERAND == "f32" and be.conv_epilogue_supported(x.shape[0], weight.shape[-1],
-                                                                                  weight.shape[0], rb.kv):
+        srt = rb.sorted_rows and not inverse
+        ctx.unit_call = (FUSED_UNIT_CALLS and hasattr(be, "post_act_block_forward") and x.is_cuda and tbl.shape[1] > 0
+                         and weight.shape[0] in (4, 8, 16, 32, 64, 128) and gamma is not None and beta is not None
+                         and running_mean is not None and not OVERLAP_WEIGHT_GRAD)
+        if ctx.unit_call:
+            y, y_raw, mean, var = be.post_act_block_forward(x, weight, tbl, order, MFMA_OPERAND, srt, gamma, beta,
+                                                            running_mean, running_var, nbt, momentum, eps, relu)
+        elif FUSE_BN_STATS and MFMA_OPERAND == "f32" and be.conv_epilogue_supported(x.shape[0], weight.shape[-1],
+                                                                                    weight.shape[0], rb.kv):
             # the conv epilogue emits the per-block (sum, sum of squares): the statistics need no pass over y_raw
-            y_raw, partial = be.conv_forward_stats(x, weight, tbl, order=order, sorted_rows=rb.sorted_rows and not inverse)
+            y_raw, partial = be.conv_forward_stats(x, weight, tbl, order=order, sorted_rows=srt)
             y, mean, var = be.bn_forward(y_raw, gamma, beta, running_mean, running_var, True, momentum, eps, relu,
                                          num_batches_tracked=nbt, partial=partial)
         else:
-            y_raw = be.conv_forward(x, weight, tbl, order=order, operand=MFMA_OPERAND,
-                                    sorted_rows=rb.sorted_rows and not inverse)
+            y_raw = be.conv_forward(x, weight, tbl, order=order, operand=MFMA_OPERAND, sorted_rows=srt)
             y, mean, var = be.bn_forward(y_raw, gamma, beta, running_mean, running_var, True, momentum, eps, relu,
                                          num_batches_tracked=nbt)
         ctx.rb, ctx.inverse, ctx.cfg = rb, inverse, (float(eps), bool(relu))
@@ -222,15 +228,27 @@ class ConvBNReLUFunction(torch.autograd.Function):
         eps, relu = ctx.cfg
         wide, col0 = _as_wide_rows(grad_out)
         rb, gws = ctx.rb, None
-        if (rb.rep is not None and not ctx.inverse and rb.kind == "subm" and ctx.needs_input_grad[0]
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if ctx.unit_call:
+            inverse = ctx.inverse
+            if inverse:        # inverse conv: forward walked pair_bwd, its transpose walks pair_fwd
+                tbl_w, tbl_dx, n_dx, mirror, order_dx, rep, centre = rb.pair_bwd, rb.pair_fwd, rb.n_out, False, rb.order_fwd, None, -1
+            elif rb.kind == "subm":
+                tbl_w, tbl_dx, n_dx, mirror, order_dx, rep, centre = rb.pair_fwd, rb.pair_fwd, rb.n_in, True, rb.order_bwd, rb.rep, rb.centre
+            else:
+                tbl_w, tbl_dx, n_dx, mirror, order_dx, rep, centre = rb.pair_fwd, rb.pair_bwd, rb.n_in, False, rb.order_bwd, None, -1
+            dx, dw, dgamma, dbeta = be.post_act_block_backward(
+                x, weight, y_raw, wide, col0, mean, var, gamma, beta, eps, relu, tbl_w, tbl_dx, n_dx, mirror, centre, rep,
+                order_dx, MFMA_OPERAND, rb.sorted_rows and rb.kind == "subm" and not inverse, need_dx, need_dw)
+            return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None
+        if (rb.rep is not None and not ctx.inverse and rb.kind == "subm" and need_dx
                 and hasattr(be, "group_sum_prepare") and y_raw.is_cuda
                 and (y_raw.shape[1] & (y_raw.shape[1] - 1)) == 0):
             # duplicate-pixel conv: its backward group-sums d_raw in fixed point and needs max|d_raw|; the BN backward
             # kernel that writes d_raw leaves it in the (pre-zeroed) group-sum workspace: one pass over d_raw less
             gws = be.group_sum_prepare(y_raw.shape[0], y_raw.shape[1], y_raw.device)
         d_raw, dgamma, dbeta = be.bn_backward(y_raw, wide, col0, mean, var, gamma, beta, eps, relu, absmax_ws=gws)
-        dx, dw = _conv_backward(rb, ctx.inverse, x, weight, d_raw, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                group_ws=gws)
+        dx, dw = _conv_backward(rb, ctx.inverse, x, weight, d_raw, need_dx, need_dw, group_ws=gws)
         return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
@@ -265,6 +283,8 @@ OVERLAP_WEIGHT_GRAD = os.environ.get("VIRCONV_OVERLAP_DW", "0") != "0"
 # saved read-back pass (0.14 ms) is paid back by the epilogue's two extra barriers and a 10x longer finalize; off by default.
 FUSE_BN_STATS = os.environ.get("VIRCONV_FUSE_BN_STATS", "0") != "0"
 FUSE_BN_EVAL = os.environ.get("VIRCONV_FUSE_BN_EVAL", "1") != "0"     # inference: BN(+ReLU) folded into the conv store
+# training: a conv+BN+ReLU unit is ONE C-ABI call per direction (vc_post_act_block_forward / _backward) instead of 4-9 calls
+FUSED_UNIT_CALLS = os.environ.get("VIRCONV_FUSED_UNIT_CALLS", "1") != "0"
 # vc_row_order permutations computed with the rulebooks (tile-homogeneity hint for the gather-GEMM; results identical).
 #   "bwd"  (default) strided convs' backward-input tables only: their active sets are parity classes, sorting cuts the
 #          issued work 2.3x (measured: s3.down bwd 197 -> 85 us) and a 1024-row window is enough
