@@ -895,3 +895,53 @@ def test_window_gather_gemm_pipeline_variants_keep_the_bits(hip_backend, wdma, w
     finally:
         lib.vc_debug_set(b"conv_wdma", 0)
         lib.vc_debug_set(b"conv_winrows", 32)
+
+
+# ------------------------------------------------------------------------------------------------ post_act_block as one call
+@pytest.mark.parametrize("kind", ["subm_sorted", "subm_first_touch", "strided", "subm2d_dup"])
+def test_post_act_block_calls_equal_the_operator_by_operator_path(hip_backend, kind, monkeypatch):
+    """vc_post_act_block_forward / _backward are host-side compositions of the single operators: outputs, BatchNorm
+    statistics, running statistics and every gradient are bit-identical to issuing the operators one by one (the duplicate-
+    pixel conv uses the persistent, self-clearing group-sum accumulator: also run twice)."""
+    from torch import nn
+    rng = np.random.default_rng(3)
+    cin, cout = 32, 16
+    if kind == "subm2d_dup":
+        idx = _indices2(9, 20000, dup=True)
+        it = torch.from_numpy(idx).cuda()
+        rb = ops.build_subm_rulebook(it, (160, 60), (3, 3), 1, allow_duplicates=True)
+        wshape = (cout, 3, 3, cin)
+    else:
+        idx, shape = _sorted_scene(51, 1)
+        if kind == "subm_first_touch":
+            idx = idx[rng.permutation(idx.shape[0])]
+        it = torch.from_numpy(np.ascontiguousarray(idx)).cuda()
+        if kind == "subm_sorted":
+            it._vc_sorted = True
+        if kind == "strided":
+            rb = ops.build_sparse_rulebook(it, shape, 1, (3, 3, 3), (2, 2, 2), (1, 1, 1), 1)
+        else:
+            rb = ops.build_subm_rulebook(it, shape, (3, 3, 3), 1, False)
+        assert rb.sorted_rows == (kind == "subm_sorted")
+        wshape = (cout, 3, 3, 3, cin)
+    x0 = torch.from_numpy(rng.standard_normal((rb.n_in, cin)).astype(np.float32)).cuda()
+    w0 = torch.from_numpy((rng.standard_normal(wshape) / 5).astype(np.float32)).cuda()
+    g = torch.from_numpy(rng.standard_normal((rb.n_out, cout + 8)).astype(np.float32)).cuda()
+
+    def run(fused):
+        monkeypatch.setattr(ops, "FUSED_UNIT_CALLS", fused)
+        bn = nn.BatchNorm1d(cout, eps=1e-3, momentum=0.01).cuda().train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, cout)); bn.bias.copy_(torch.linspace(-0.2, 0.2, cout))
+        x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+        y = ops.conv_bn_relu(x, w, rb, False, bn, True)
+        wide = torch.cat([y, torch.zeros((rb.n_out, 8), device="cuda")], 1)   # the consumer is a concat: strided grad slices
+        (wide * g).sum().backward()
+        return [y.detach(), x.grad, w.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone(),
+                bn.num_batches_tracked.clone()]
+
+    ref = run(False)
+    for _ in range(2):
+        got = run(True)
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)
