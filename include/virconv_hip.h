@@ -197,6 +197,13 @@ int vc_to_dense(const float* features, const int32_t* indices, int64_t n, int c,
                 const int32_t* host_spatial_shape, float* dense, void* stream);
 int vc_from_dense(const float* dense, const int32_t* indices, int64_t n, int c, int ndim, int batch_size,
                   const int32_t* host_spatial_shape, float* features, void* stream);
+/* Write-once form of .dense() for HeightCompression (height_compression.py:27-31: encoded_spconv_tensor.dense() viewed as
+ * (B, C*D, H, W), the BEV map the 2-D backbone reads): `dense` need NOT be zero-filled -- a row-id volume in `ws`
+ * (batch * prod(shape) int32) decides per cell, and every element of `dense` is written exactly once (zeros where no voxel is
+ * active), coalesced along x.  Same result as zero-fill + vc_to_dense (highest row wins on duplicate coordinates).          */
+size_t vc_to_dense_fill_workspace_bytes(int batch_size, int ndim, const int32_t* host_spatial_shape);
+int vc_to_dense_fill(const float* features, const int32_t* indices, int64_t n, int c, int ndim, int batch_size,
+                     const int32_t* host_spatial_shape, float* dense, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ K1 voxelize + a3 MeanVFE
  * First-touch voxelisation of one frame's points with the mean (+ 'max' on the last channel) fused

@@ -853,10 +853,12 @@ def test_window_gather_gemm_epilogues(hip_backend, cin, cout):
     assert torch.equal(fused, hip_backend.conv_forward_affine(x, w, pair, None, mean, var, g, b, 1e-3, True))
 
 
-def test_backbone_marks_sorted_tables_and_uses_the_window_kernel(hip_backend):
-    """The geometry plan tags the SubM rulebooks of stages 2-4 (rows = output of a strided conv: ascending order)."""
+def test_backbone_marks_sorted_tables_and_uses_the_window_kernel(hip_backend, monkeypatch):
+    """With VIRCONV_WINDOW_GATHER on, the geometry plan tags the SubM rulebooks of stages 2-4 (rows = output of a strided conv:
+    ascending order)."""
     import bench
     from virconv_amd.backbone import VirConvL8x
+    monkeypatch.setattr(ops, "WINDOW_GATHER", True)
     batch = bench.make_batch([0], torch.device("cuda", 0), training=False)
     model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).cuda().eval()
     plan = model.build_plan(batch["voxel_coords"], 1, batch["calib"], None, batch)
@@ -918,6 +920,7 @@ def test_post_act_block_calls_equal_the_operator_by_operator_path(hip_backend, k
         it = torch.from_numpy(np.ascontiguousarray(idx)).cuda()
         if kind == "subm_sorted":
             it._vc_sorted = True
+            monkeypatch.setattr(ops, "WINDOW_GATHER", True)
         if kind == "strided":
             rb = ops.build_sparse_rulebook(it, shape, 1, (3, 3, 3), (2, 2, 2), (1, 1, 1), 1)
         else:
@@ -930,6 +933,9 @@ def test_post_act_block_calls_equal_the_operator_by_operator_path(hip_backend, k
 
     def run(fused):
         monkeypatch.setattr(ops, "FUSED_UNIT_CALLS", fused)
+        # on a sorted table the unit call takes its BatchNorm statistics from the window kernel's per-wave partial sums: the
+        # operator-by-operator reference has to do the same to be bit-comparable (a pass over y_raw rounds differently)
+        monkeypatch.setattr(ops, "FUSE_BN_STATS", kind == "subm_sorted")
         bn = nn.BatchNorm1d(cout, eps=1e-3, momentum=0.01).cuda().train()
         with torch.no_grad():
             bn.weight.copy_(torch.linspace(0.5, 1.5, cout)); bn.bias.copy_(torch.linspace(-0.2, 0.2, cout))
@@ -945,3 +951,40 @@ def test_post_act_block_calls_equal_the_operator_by_operator_path(hip_backend, k
         got = run(True)
         for a, b in zip(ref, got):
             assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------ f3: write-once dense / HeightCompression
+@pytest.mark.parametrize("c,shape,bs", [(64, (4, 200, 176), 2), (16, (5, 33, 70), 3), (8, (21, 64, 48), 2)])
+def test_write_once_dense_equals_zero_fill_plus_scatter(hip_backend, c, shape, bs, monkeypatch):
+    """vc_to_dense_fill (no zero-fill of the output, every element written once) against the oracle's dense() and against
+    the scatter form; HeightCompression's (B, C*D, H, W) view on top of it (height_compression.py:27-31)."""
+    from virconv_amd import backend_hip, spconv
+    from virconv_amd.backbone import HeightCompression
+    rng = np.random.default_rng(c)
+    idx = synth.small_scene_indices(5, 3000, shape, bs)
+    f = rng.standard_normal((idx.shape[0], c)).astype(np.float32)
+    ft, it = torch.from_numpy(f).cuda(), torch.from_numpy(idx).cuda()
+    junk = torch.full((bs, c) + shape, float("nan"), device="cuda")   # park NaNs in the allocator's free blocks
+    del junk
+    monkeypatch.setattr(backend_hip, "DENSE_WRITE_ONCE", True)
+    d1 = hip_backend.to_dense(ft, it, shape, bs)
+    monkeypatch.setattr(backend_hip, "DENSE_WRITE_ONCE", False)
+    d0 = hip_backend.to_dense(ft, it, shape, bs)
+    assert torch.equal(d1, d0)
+    np.testing.assert_array_equal(d1.cpu().numpy(), sparse_ref.to_dense(torch.from_numpy(f), idx, shape, bs).numpy())
+    monkeypatch.setattr(backend_hip, "DENSE_WRITE_ONCE", True)
+    sp = spconv.SparseConvTensor(ft.clone().requires_grad_(True), it, shape, bs)
+    bd = HeightCompression()({"encoded_spconv_tensor": sp, "encoded_spconv_tensor_stride": 8})
+    bev = bd["spatial_features"]
+    assert bev.shape == (bs, c * shape[0], shape[1], shape[2]) and torch.equal(bev.reshape(d1.shape), d1)
+    g = torch.randn_like(bev)
+    (bev * g).sum().backward()
+    gref = g.reshape(d1.shape)[it[:, 0].long(), :, it[:, 1].long(), it[:, 2].long(), it[:, 3].long()]
+    assert torch.equal(sp.features.grad, gref)
+
+
+def test_write_once_dense_duplicate_coordinates_last_row_wins(hip_backend):
+    idx = _indices2(3, 5000, dup=True)
+    f = np.random.default_rng(0).standard_normal((idx.shape[0], 16)).astype(np.float32)
+    d = hip_backend.to_dense(torch.from_numpy(f).cuda(), torch.from_numpy(idx).cuda(), (160, 60), 2)
+    np.testing.assert_array_equal(d.cpu().numpy(), sparse_ref.to_dense(torch.from_numpy(f), idx, (160, 60), 2).numpy())

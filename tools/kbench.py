@@ -49,10 +49,12 @@ def main():
     ap.add_argument("--operand", default="f32", choices=["f32", "f16", "bf16"], help="MFMA operand type")
     ap.add_argument("--bw-legacy", action="store_true", help="offset-major block order in the weight-gradient kernel")
     ap.add_argument("--no-window", action="store_true", help="never use the LDS row-window gather-GEMM (A/B)")
+    ap.add_argument("--window", action="store_true", help="use the LDS row-window gather-GEMM where the table is sorted (A/B)")
     ap.add_argument("--wdma", type=int, default=0, help="window kernel: W images through the LDS-DMA engine (vc_debug_set conv_wdma)")
     ap.add_argument("--winrows", type=int, default=32, help="window kernel: rows per wave window, 32 | 24 (vc_debug_set conv_winrows)")
     ap.add_argument("--layers", default="", help="comma-separated substrings: only time layers whose name contains one of them")
     args = ap.parse_args()
+    ops.WINDOW_GATHER = bool(args.window)
     dev = torch.device("cuda", 0)
     be = ops.get_backend()
     if args.variant:

@@ -42,7 +42,7 @@ def short(name: str) -> str:
 
 def stats_summary(path: str, steps: int, out_md: str, title: str) -> None:
     rows = list(csv.DictReader(open(path)))
-    once = [int(r["Calls"]) for r in rows if "dense_kernel<true>" in r["Name"]]  # launched exactly once per train step
+    once = [int(r["Calls"]) for r in rows if "dense_kernel<true>" in r["Name"] or "dense_fill_kernel" in r["Name"]]  # once per step
     if once:
         steps = once[0]  # counts the settle / warm-up / timed steps alike, whatever their number was
     tot = sum(float(r["TotalDurationNs"]) for r in rows) / steps / 1e6

@@ -55,6 +55,8 @@ SIGNATURES = {
     "vc_scatter_rows": (_I, [_P, _I, _P, _I64, _I64, _P, _P]),
     "vc_to_dense": (_I, [_P, _P, _I64, _I, _I, _I, _P, _P, _P]),
     "vc_from_dense": (_I, [_P, _P, _I64, _I, _I, _I, _P, _P, _P]),
+    "vc_to_dense_fill_workspace_bytes": (_SZ, [_I, _I, _P]),
+    "vc_to_dense_fill": (_I, [_P, _P, _I64, _I, _I, _I, _P, _P, _P, _SZ, _P]),
     "vc_voxelize_workspace_bytes": (_SZ, [_I64, _I]),
     "vc_voxelize_mean": (_I, [_P, _I64, _I, _P, _P, _I, _I, _I, _P, _SZ, _P, _P, _P, _P, _P]),
     "vc_voxelize": (_I, [_P, _I64, _I, _P, _P, _I, _I, _P, _SZ, _P, _P, _P, _P, _P]),

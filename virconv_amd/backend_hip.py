@@ -15,6 +15,12 @@ from . import _lib
 from ._lib import CONV_SORTED_ROWS, OPERAND_TYPES, check, i32arr, f32arr
 
 
+import os
+
+# .dense() / HeightCompression as a write-once fill (vc_to_dense_fill) instead of zero-fill + scatter; "0" = the scatter form
+DENSE_WRITE_ONCE = os.environ.get("VIRCONV_DENSE_WRITE_ONCE", "1") != "0"
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -377,10 +383,20 @@ class HipBackend:
         indices = _need(indices, torch.int32, "indices")
         n, c = features.shape
         ndim = indices.shape[1] - 1
+        shp = i32arr(spatial_shape)
+        ws_bytes = self.lib.vc_to_dense_fill_workspace_bytes(batch_size, ndim, shp)
+        if DENSE_WRITE_ONCE and ws_bytes <= (1 << 30) and c <= 128:
+            # write-once fill (vc_to_dense_fill): no zero-fill of the (B, C, *spatial) output, one coalesced pass
+            dense = torch.empty((batch_size, c) + tuple(int(s) for s in spatial_shape), dtype=torch.float32,
+                                device=features.device)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=features.device)
+            check(self.lib.vc_to_dense_fill(_ptr(features), _ptr(indices), n, c, ndim, batch_size, shp, _ptr(dense), _ptr(ws),
+                                            ws_bytes, _stream()), "vc_to_dense_fill")
+            return dense
         dense = torch.zeros((batch_size, c) + tuple(int(s) for s in spatial_shape), dtype=torch.float32,
                             device=features.device)
-        check(self.lib.vc_to_dense(_ptr(features), _ptr(indices), n, c, ndim, batch_size, i32arr(spatial_shape),
-                                   _ptr(dense), _stream()), "vc_to_dense")
+        check(self.lib.vc_to_dense(_ptr(features), _ptr(indices), n, c, ndim, batch_size, shp, _ptr(dense), _stream()),
+              "vc_to_dense")
         return dense
 
     def from_dense(self, dense: torch.Tensor, indices: torch.Tensor, spatial_shape, batch_size: int) -> torch.Tensor:

@@ -19,7 +19,10 @@ ARCH = "gfx950"
 # per-source extra flags: the index kernels must not contract mul+add (bit-exact integer outputs vs the oracle)
 SOURCES = {
     "index_kernels.hip": ["-ffp-contract=off"],
-    "conv_kernels.hip": [],
+    # MFMA accumulators in VGPRs (gfx950 has a unified register file): hipcc's default keeps them in AGPRs and shuttles them with
+    # v_accvgpr_read/write around every branch (48 moves in the hot loop of gather_gemm_v2<64,32>) -- 68 VGPR + 12 AGPR -> 68 VGPR,
+    # 6 -> 7 waves per SIMD, and these kernels' throughput follows their occupancy
+    "conv_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
     "bn_kernels.hip": [],
     "pool_kernels.hip": ["-ffp-contract=off"],
     "frontend_kernels.hip": ["-ffp-contract=off"],

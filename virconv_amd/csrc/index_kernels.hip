@@ -522,6 +522,59 @@ __global__ void __launch_bounds__(256) dense_kernel(float* __restrict__ feat, co
   }
 }
 
+// ------------------------------------------------------------------------------------------ K10 dense, write-once (f3)
+// HeightCompression (height_compression.py:27-31) = .dense() + a free view (B, C, D, H, W) -> (B, C*D, H, W).  The scatter form
+// above needs the whole dense tensor zero-filled first (36 MB per frame at (64, 4, 200, 176), written twice where a voxel
+// lands).  Write-once form: (1) a row-id volume (B*D*H*W int32, 0.56 MB per frame) takes row+1 at every active cell (atomicMax:
+// the highest row wins on duplicate coordinates, the "last write wins" of spconv's scatter); (2) one block per 64 x-consecutive
+// cells of a (b, z, y) line gathers the rows of its occupied cells through LDS and writes all C channel planes of the tile,
+// zeros where nothing is active: every dense element is written exactly once, coalesced along x, and no memset of the output.
+__global__ void __launch_bounds__(256) dense_rowid_kernel(const int32_t* __restrict__ indices, int64_t n, int ndim, int D,
+                                                          int H, int W, int32_t* __restrict__ rowid) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  int b, z, y, x;
+  load_coord(indices, r, ndim, b, z, y, x);
+  atomicMax(&rowid[(((int64_t)b * D + z) * H + y) * W + x], (int)(r + 1));
+}
+
+__global__ void __launch_bounds__(256) dense_fill_kernel(const float* __restrict__ feat, const int32_t* __restrict__ rowid,
+                                                         int c, int D, int H, int W, int tiles_per_line,
+                                                         float* __restrict__ dense) {
+  extern __shared__ float f_tile[];                 // [64][c + 1]
+  __shared__ int s_rid[64];
+  __shared__ int s_any;
+  const int ld = c + 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t line = blockIdx.x / tiles_per_line;  // (b*D + z)*H + y
+  const int x0 = (int)(blockIdx.x - line * tiles_per_line) * 64;
+  const int cells = min(64, W - x0);
+  if (threadIdx.x == 0) s_any = 0;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int rid = (threadIdx.x < cells) ? rowid[line * W + x0 + threadIdx.x] : 0;
+    s_rid[threadIdx.x] = rid;
+    if (rid != 0) s_any = 1;
+  }
+  __syncthreads();
+  const int64_t zy = line % ((int64_t)D * H);        // z*H + y
+  const int64_t b = line / ((int64_t)D * H);
+  const int64_t plane = (int64_t)D * H * W;
+  float* out = dense + (b * c * D) * (int64_t)H * W + zy * W + x0;   // channel 0 of this tile; channel ch at + ch * plane
+  if (s_any == 0) {  // most tiles: nothing active
+    if (lane < cells)
+      for (int ch = wave; ch < c; ch += 4) out[ch * plane + lane] = 0.f;
+    return;
+  }
+  for (int cell = wave; cell < cells; cell += 4) {   // a wave copies one row (coalesced) per trip
+    const int rid = s_rid[cell];
+    for (int col = lane; col < c; col += 64) f_tile[cell * ld + col] = rid ? feat[(int64_t)(rid - 1) * c + col] : 0.f;
+  }
+  __syncthreads();
+  if (lane < cells)
+    for (int ch = wave; ch < c; ch += 4) out[ch * plane + lane] = f_tile[lane * ld + ch];
+}
+
 // ------------------------------------------------------------------------------------------ generic int scan (flags)
 __global__ void __launch_bounds__(256) flag_blocksum_kernel(const int32_t* __restrict__ flags, int64_t n,
                                                             int32_t* __restrict__ blocksum) {
@@ -1054,6 +1107,36 @@ int vc_to_dense(const float* features, const int32_t* indices, int64_t n, int c,
   hipLaunchKernelGGL(dense_kernel<true>, dim3((unsigned)cdiv(n, 64)), dim3(256), lds, (hipStream_t)stream,
                      const_cast<float*>(features), indices, n, c, ndim, d.D, d.H, d.W, dense);
   VC_CHECK_LAUNCH("dense_kernel<to>");
+  return VC_OK;
+}
+
+size_t vc_to_dense_fill_workspace_bytes(int batch_size, int ndim, const int32_t* shape) {
+  if ((ndim != 2 && ndim != 3) || !shape || batch_size < 1) return 0;
+  Dims d = make_dims(ndim, shape);
+  return (size_t)batch_size * d.D * d.H * d.W * sizeof(int32_t);
+}
+
+int vc_to_dense_fill(const float* features, const int32_t* indices, int64_t n, int c, int ndim, int batch_size,
+                     const int32_t* shape, float* dense, void* ws, size_t ws_bytes, void* stream) {
+  VC_REQUIRE((ndim == 2 || ndim == 3) && shape && c > 0 && batch_size >= 1 && dense && ws, "vc_to_dense_fill: invalid argument");
+  VC_REQUIRE(n == 0 || (features && indices), "vc_to_dense_fill: null argument");
+  if (ws_bytes < vc_to_dense_fill_workspace_bytes(batch_size, ndim, shape)) { set_error("vc_to_dense_fill: workspace too small"); return VC_ECAPACITY; }
+  Dims d = make_dims(ndim, shape);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t lines = (int64_t)batch_size * d.D * d.H;
+  const int tiles = (int)cdiv(d.W, 64);
+  VC_REQUIRE(lines * tiles < (1LL << 31) && n < (1LL << 31) - 1, "vc_to_dense_fill: tensor too large");
+  const size_t lds = (size_t)64 * (c + 1) * sizeof(float);
+  VC_REQUIRE(lds <= 60 * 1024, "vc_to_dense_fill: channel count %d too large", c);
+  int32_t* rowid = (int32_t*)ws;
+  VC_CHECK_HIP(hipMemsetAsync(rowid, 0, vc_to_dense_fill_workspace_bytes(batch_size, ndim, shape), st));
+  if (n > 0) {
+    hipLaunchKernelGGL(dense_rowid_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, indices, n, ndim, d.D, d.H, d.W, rowid);
+    VC_CHECK_LAUNCH("dense_rowid_kernel");
+  }
+  hipLaunchKernelGGL(dense_fill_kernel, dim3((unsigned)(lines * tiles)), dim3(256), lds, st, features, rowid, c, d.D, d.H, d.W,
+                     tiles, dense);
+  VC_CHECK_LAUNCH("dense_fill_kernel");
   return VC_OK;
 }
 

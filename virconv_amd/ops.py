@@ -293,8 +293,11 @@ FUSED_UNIT_CALLS = os.environ.get("VIRCONV_FUSED_UNIT_CALLS", "1") != "0"
 # MFMA operand type of the conv kernels: "f32" (exact, default, the parity path) | "f16" | "bf16" (BASELINE configs[4]:
 # "fp16 MFMA contraction"; tensors stay fp32, operands are rounded in registers, accumulation is fp32)
 MFMA_OPERAND = os.environ.get("VIRCONV_MFMA_OPERAND", "f32")
-# LDS row-window gather-GEMM for SubM convs on coordinate-sorted rows (VC_CONV_SORTED_ROWS hint); 0 = always the direct gathers
-WINDOW_GATHER = os.environ.get("VIRCONV_WINDOW_GATHER", "1") != "0"
+# LDS row-window gather-GEMM for SubM convs on coordinate-sorted rows (VC_CONV_SORTED_ROWS hint).  Built, parity-tested and
+# MEASURED SLOWER than the direct gathers on MI355X (s3.d3_conv1 64->32 forward 243-273 us vs 210 us: the per-wave windows cost
+# LDS, LDS costs resident waves, and these kernels' throughput follows their occupancy -- profiles/r02_kbench_variants.txt,
+# r02_pmc_conv_variants.md).  Off by default; "1" turns it on (tools/kbench.py measures both).
+WINDOW_GATHER = os.environ.get("VIRCONV_WINDOW_GATHER", "0") != "0"
 ROW_ORDER = os.environ.get("VIRCONV_ROW_ORDER", "bwd")
 ROW_ORDER_WINDOW = int(os.environ.get("VIRCONV_ROW_ORDER_WINDOW", "2048"))
 _SIDE_STREAMS = {}
@@ -346,6 +349,12 @@ class ToDenseFunction(torch.autograd.Function):
     def backward(ctx, grad_dense):
         (indices,) = ctx.saved_tensors
         shape, bs = ctx.meta
+        if grad_dense.dim() >= 3 and grad_dense.shape[0] > 1 and grad_dense.stride(0) == 0:
+            # a gradient that is the same for every sample (broadcast along the batch axis): gather from ONE sample's planes
+            # instead of materialising batch_size copies of them
+            idx0 = indices.clone()
+            idx0[:, 0] = 0
+            return get_backend().from_dense(grad_dense[:1].contiguous(), idx0, shape, 1), None, None, None
         return get_backend().from_dense(grad_dense.contiguous(), indices, shape, bs), None, None, None
 
 
