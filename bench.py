@@ -131,8 +131,7 @@ def train_step(model, optimizer, batch, lw, grad_sync=None, raw=None):
         bd = dict(batch)
         bd["voxel_features"] = batch["voxel_features"].clone()  # the backbone zeroes RGB in place
     out = model(bd)
-    # (dense * G).sum() as a contraction: the same value without materialising the 36 MB-per-frame product
-    loss = torch.einsum("bcdhw,cdhw->", out["encoded_spconv_tensor"].dense(), lw["dense"][0])
+    loss = (out["encoded_spconv_tensor"].dense() * lw["dense"]).sum()
     for name, t in out["multi_scale_3d_features"].items():
         loss = loss + (t.features * lw[name]).sum()
     if "multi_scale_3d_features_mm" in out:

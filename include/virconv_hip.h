@@ -122,10 +122,9 @@ int vc_conv_backward_input(const float* dy, const float* dy_centre, int64_t n_sr
                            void* stream);
 
 /* Forward conv with a BatchNorm epilogue (fp32 operands; query vc_conv_epilogue_supported for the shape first):
- *   VC_EPI_STATS   training: besides y the kernel writes per-channel (sum, sum of squares) partial rows [rows][2][cout] --
- *                  one per 64-row block, or one per 16-row wave tile on the LDS-window kernel (no barrier in the epilogue);
- *                  vc_conv_stats_partial_floats gives the size for the same (shape, flags) -- for vc_bn_stats_from_partial:
- *                  the statistics pass no longer re-reads y;
+ *   VC_EPI_STATS   training: besides y the kernel writes per-channel (sum, sum of squares) partial rows [rows][2][cout], one
+ *                  per 16-row wave tile (no barrier in the epilogue); vc_conv_stats_partial_floats gives the size -- for
+ *                  vc_bn_stats_from_partial: the statistics pass reads 1/8 of the bytes of y instead of y;
  *   VC_EPI_AFFINE  eval: y = relu?(conv * (gamma / sqrt(var + eps)) + (beta - mean * gamma / sqrt(var + eps))) in the store,
  *                  i.e. conv + BatchNorm1d(eval) + ReLU (spconv_backbone.py:101-105) as ONE launch.                     */
 typedef enum vc_epilogue { VC_EPI_NONE = 0, VC_EPI_STATS = 1, VC_EPI_AFFINE = 2 } vc_epilogue;
@@ -143,6 +142,12 @@ int vc_conv_forward_epilogue(const float* x, int64_t n_in, const int32_t* pair_f
  * one LDS bitonic sort per window and never changes results.                                                      */
 int vc_row_order(const int32_t* tbl, int64_t n, int kv, const int32_t* rep, int centre, int window, int32_t* order,
                  void* stream);
+
+/* Row order for the backward-input of a duplicate-coordinate SubM conv: a stable partition of [0, n) with the representative
+ * rows (rep[r] == r: the only ones that own non-centre taps) first.  Tiles of the second part issue one offset instead of the
+ * tile union.  Pass the result as row_order of vc_conv_backward_input; like every row order it never changes results.      */
+size_t vc_rep_order_workspace_bytes(int64_t n);
+int vc_rep_order(const int32_t* rep, int64_t n, int32_t* order, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ K8 weight gradient
  * dW[:, k, :] = sum_o dy[o, :]^T (outer) x[pair_fwd[k, o], :]; wave-ballot compaction of the active pairs, MFMA
@@ -303,7 +308,9 @@ int vc_post_act_block_backward(const float* x, int64_t n_in, const float* y_raw,
                                int64_t n_dx, int mirror, int centre, const int32_t* rep, const int32_t* row_order_dx, int kv,
                                const float* weight, int cin, int cout, int operand_type, int flags, int need_dx, int need_dw,
                                float* d_raw, float* dx, float* dw, float* dgamma, float* dbeta, void* group_acc,
-                               size_t group_acc_bytes, void* ws, size_t ws_bytes, void* stream);
+                               size_t group_acc_bytes, void* ws, size_t ws_bytes,
+                               void* side_stream /* nullable hipStream_t: the weight gradient runs on it underneath the
+                               backward-input conv; forked and joined inside the call */, void* stream);
 
 /* ================================================================================================ RoI grid pooling
  * the operators that consume multi_scale_3d_features['x_conv3'/'x_conv4'] right after the backbone

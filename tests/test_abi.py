@@ -76,10 +76,9 @@ def test_new_entry_points_validate_their_arguments_without_gpu():
                                         dummy, None) == _lib.VC_EINVAL and b"stats_partial" in lib.vc_last_error()
     assert lib.vc_conv_epilogue_supported(1000, 64, 32, 27, 0) == 1 and lib.vc_conv_epilogue_supported(1000, 64, 32, 27, 1) == 0
     assert lib.vc_conv_epilogue_supported(1 << 24, 64, 32, 27, 0) == 0                      # source >= 2 GiB: fallback kernel
-    assert lib.vc_conv_stats_partial_floats(130, 130, 8, 32, 27, 0) == 3 * 2 * 32
-    # the LDS-window kernel (sorted-rows hint, >= 16 source channels) writes one partial row per 16-row wave tile
+    # one partial row (sum, sum of squares) per 16-row wave tile: 4 per 64-row block
+    assert lib.vc_conv_stats_partial_floats(130, 130, 8, 32, 27, 0) == 3 * 4 * 2 * 32
     assert lib.vc_conv_stats_partial_floats(130, 130, 32, 32, 27, 1) == 3 * 4 * 2 * 32
-    assert lib.vc_conv_stats_partial_floats(130, 130, 8, 32, 27, 1) == 3 * 2 * 32
     # RoI grid pooling
     assert lib.vc_voxel_index_workspace_bytes(1000, 2, shp) > 2 * 21 * 400 * 352 // 8
     assert lib.vc_voxel_query(dummy, 1 << 30, 10, 2, shp, dummy, dummy, dummy, 5, 1, 1, 32, 1.0, 4, dummy, dummy, None) == _lib.VC_EINVAL

@@ -933,9 +933,9 @@ def test_post_act_block_calls_equal_the_operator_by_operator_path(hip_backend, k
 
     def run(fused):
         monkeypatch.setattr(ops, "FUSED_UNIT_CALLS", fused)
-        # on a sorted table the unit call takes its BatchNorm statistics from the window kernel's per-wave partial sums: the
-        # operator-by-operator reference has to do the same to be bit-comparable (a pass over y_raw rounds differently)
-        monkeypatch.setattr(ops, "FUSE_BN_STATS", kind == "subm_sorted")
+        # the unit call takes its BatchNorm statistics from the conv epilogue's per-wave partial sums: the operator-by-operator
+        # reference has to do the same to be bit-comparable (a pass over y_raw rounds differently)
+        monkeypatch.setattr(ops, "FUSE_BN_STATS", True)
         bn = nn.BatchNorm1d(cout, eps=1e-3, momentum=0.01).cuda().train()
         with torch.no_grad():
             bn.weight.copy_(torch.linspace(0.5, 1.5, cout)); bn.bias.copy_(torch.linspace(-0.2, 0.2, cout))
@@ -946,8 +946,10 @@ def test_post_act_block_calls_equal_the_operator_by_operator_path(hip_backend, k
         return [y.detach(), x.grad, w.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone(),
                 bn.num_batches_tracked.clone()]
 
+    from virconv_amd import backend_hip
     ref = run(False)
-    for _ in range(2):
+    for overlap in (False, True, True):   # the weight gradient forked onto a side stream inside the call: same bits
+        monkeypatch.setattr(backend_hip, "UNIT_OVERLAP_DW", overlap)
         got = run(True)
         for a, b in zip(ref, got):
             assert torch.equal(a, b)
@@ -988,3 +990,26 @@ def test_write_once_dense_duplicate_coordinates_last_row_wins(hip_backend):
     f = np.random.default_rng(0).standard_normal((idx.shape[0], 16)).astype(np.float32)
     d = hip_backend.to_dense(torch.from_numpy(f).cuda(), torch.from_numpy(idx).cuda(), (160, 60), 2)
     np.testing.assert_array_equal(d.cpu().numpy(), sparse_ref.to_dense(torch.from_numpy(f), idx, (160, 60), 2).numpy())
+
+
+def test_rep_order_is_a_stable_partition_and_never_changes_the_duplicate_pixel_backward(hip_backend):
+    """vc_rep_order: representatives (rep[r] == r) first, both parts in ascending row order; the backward-input of the
+    duplicate-pixel conv gives the same bits with and without it."""
+    rng = np.random.default_rng(12)
+    shape = (160, 60)
+    idx = _indices2(13, 30000, dup=True)
+    n = idx.shape[0]
+    it = torch.from_numpy(idx).cuda()
+    pair, rep = hip_backend.subm_rulebook(it, shape, (3, 3), (1, 1), want_rep=True)
+    order = hip_backend.rep_order(rep)
+    r = rep.cpu().numpy()
+    is_rep = r == np.arange(n)
+    exp = np.concatenate([np.nonzero(is_rep)[0], np.nonzero(~is_rep)[0]])
+    np.testing.assert_array_equal(order.cpu().numpy(), exp)
+    assert 0.05 < is_rep.mean() < 0.95
+    w = torch.from_numpy((rng.standard_normal((32, 3, 3, 32)) / 17).astype(np.float32)).cuda()
+    g = torch.from_numpy(rng.standard_normal((n, 32)).astype(np.float32)).cuda()
+    a = hip_backend.conv_backward_input(g, w, pair, n, mirror=True, centre=4, rep=rep)
+    b = hip_backend.conv_backward_input(g, w, pair, n, mirror=True, centre=4, rep=rep, order=order)
+    assert torch.equal(a, b)
+    assert hip_backend.rep_order(rep[:0]).shape == (0,)

@@ -44,6 +44,8 @@ SIGNATURES = {
     "vc_bn_stats_from_partial": (_I, [_P, _I64, _I64, _I, _P, _P, _P, _P, _P, _F, _P, _SZ, _P]),
     "vc_random_keep": (_I, [_I64, _I64, C.c_uint64, _P, _P]),
     "vc_row_order": (_I, [_P, _I64, _I, _P, _I, _I, _P, _P]),
+    "vc_rep_order_workspace_bytes": (_SZ, [_I64]),
+    "vc_rep_order": (_I, [_P, _I64, _P, _P, _SZ, _P]),
     "vc_conv_backward_weight_workspace_bytes": (_SZ, [_I64, _I, _I, _I]),
     "vc_conv_backward_weight": (_I, [_P, _P, _P, _I64, _I, _I, _I, _I, _P, _P, _SZ, _P]),
     "vc_group_sum_workspace_bytes": (_SZ, [_I64, _I]),
@@ -70,7 +72,7 @@ SIGNATURES = {
                                        _I, _I, _P, _P, _P, _SZ, _P]),
     "vc_post_act_block_backward_workspace_bytes": (_SZ, [_I64, _I, _I, _I]),
     "vc_post_act_block_backward": (_I, [_P, _I64, _P, _I64, _P, _I, _I, _P, _P, _P, _P, _F, _I, _P, _P, _I64, _I, _I, _P, _P,
-                                        _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _P]),
+                                        _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _P, _P]),
     "vc_bn_workspace_bytes": (_SZ, [_I64, _I]),
     "vc_bn_stats": (_I, [_P, _I64, _I, _P, _P, _P, _P, _P, _F, _P, _SZ, _P]),
     "vc_bn_apply_relu": (_I, [_P, _I64, _I, _P, _P, _P, _P, _F, _I, _P, _I, _I, _P]),

@@ -17,6 +17,8 @@ from ._lib import CONV_SORTED_ROWS, OPERAND_TYPES, check, i32arr, f32arr
 
 import os
 
+# weight gradient of a conv+BN+ReLU unit on a side stream underneath its backward-input conv (fork / join inside the C call)
+UNIT_OVERLAP_DW = os.environ.get("VIRCONV_UNIT_OVERLAP_DW", "0") != "0"
 # .dense() / HeightCompression as a write-once fill (vc_to_dense_fill) instead of zero-fill + scatter; "0" = the scatter form
 DENSE_WRITE_ONCE = os.environ.get("VIRCONV_DENSE_WRITE_ONCE", "1") != "0"
 
@@ -153,6 +155,16 @@ class HipBackend:
         order = torch.empty((n,), dtype=torch.int32, device=tbl.device)
         check(self.lib.vc_row_order(_ptr(tbl), n, kv, _ptr(rep), centre if rep is not None else -1, window, _ptr(order),
                                     _stream()), "vc_row_order")
+        return order
+
+    def rep_order(self, rep: torch.Tensor) -> torch.Tensor:
+        """(n,) int32 stable partition of the rows, representatives (rep[r] == r) first (vc_rep_order)."""
+        rep = _need(rep, torch.int32, "rep")
+        n = rep.shape[0]
+        order = torch.empty((n,), dtype=torch.int32, device=rep.device)
+        ws_bytes = self.lib.vc_rep_order_workspace_bytes(n)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=rep.device)
+        check(self.lib.vc_rep_order(_ptr(rep), n, _ptr(order), _ptr(ws), ws_bytes, _stream()), "vc_rep_order")
         return order
 
     def conv_forward(self, x: torch.Tensor, weight: torch.Tensor, pair_fwd: torch.Tensor,
@@ -566,6 +578,13 @@ class HipBackend:
             self._gacc = buf
         return buf
 
+    def _side_stream(self, device) -> int:
+        st = getattr(self, "_side", None)
+        if st is None or st.device != torch.device(device):
+            st = torch.cuda.Stream(device=device)
+            self._side = st
+        return st.cuda_stream
+
     def post_act_block_forward(self, x, weight, tbl, order, operand: str, sorted_rows: bool, gamma, beta, running_mean,
                                running_var, nbt, momentum: float, eps: float, relu: bool):
         """conv -> training-mode BatchNorm1d -> (ReLU) in ONE C-ABI call (vc_post_act_block_forward).
@@ -639,7 +658,8 @@ class HipBackend:
                                                   centre, _ptr(rep), _ptr(order_dx), kv, _ptr(weight), cin, cout,
                                                   OPERAND_TYPES[operand], flags, 1 if need_dx else 0, 1 if need_dw else 0,
                                                   _ptr(d_raw), _ptr(dx), _ptr(dw), _ptr(dgb[0]), _ptr(dgb[1]), _ptr(gacc),
-                                                  gacc.numel() if gacc is not None else 0, _ptr(ws), ws_bytes, _stream()),
+                                                  gacc.numel() if gacc is not None else 0, _ptr(ws), ws_bytes,
+                                                  self._side_stream(dev) if UNIT_OVERLAP_DW else None, _stream()),
               "vc_post_act_block_backward")
         return dx, dw, dgb[0], dgb[1]
 

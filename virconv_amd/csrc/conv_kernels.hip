@@ -226,9 +226,9 @@ struct BufLoad<1> {
 
 // Epilogue of the forward conv (EPI): what happens to the accumulators besides the plain store
 //   VC_EPI_NONE    nothing
-//   VC_EPI_STATS   training-mode BatchNorm statistics: the block also writes, per output channel, the sum and the sum of
-//                  squares of ITS 64 rows to epi.partial[block][2][CN] (fixed in-block order: 4 accumulator rows, q lanes,
-//                  waves); the finalize kernel adds the blocks up in fp64.  Saves the read-back pass of bn_reduce.
+//   VC_EPI_STATS   training-mode BatchNorm statistics: every WAVE also writes, per output channel, the sum and the sum of
+//                  squares of its 16 rows to epi.partial[block * 4 + wave][2][CN] (fixed order: 4 accumulator rows, q lanes);
+//                  vc_bn_stats_from_partial adds them up in fp64.  Saves the read-back pass of bn_reduce.
 //   VC_EPI_AFFINE  eval-mode BatchNorm (+ReLU) folded into the store: y = acc * (gamma * istd) + (beta - mean * gamma * istd)
 struct ConvEpilogue {
   float* partial;        // STATS
@@ -443,9 +443,10 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
 #undef VC_GATHER_A
 
   if constexpr (EPI == VC_EPI_STATS) {
-    // rows beyond n_out gathered nothing, their accumulators are exact zeros: no masking needed
-    float* s_red = reinterpret_cast<float*>(s_b);  // [4 waves][2][NT*16]; W images are dead after the barrier below
-    __syncthreads();
+    // per-WAVE partial sums (the wave's 16 rows): rows beyond n_out gathered nothing, their accumulators are exact zeros; fixed
+    // order (4 accumulator rows, then the q lanes), no LDS and no barrier -- the block-level reduce this replaces cost two
+    // barriers per block and made the fused statistics slower than the pass over y they save (round 1)
+    float* prow = epi.partial + ((lbid * 4 + wave) * 2) * CN;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       float sm = ((acc[0][nt][0] + acc[0][nt][1]) + acc[0][nt][2]) + acc[0][nt][3];
@@ -453,17 +454,8 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
                  acc[0][nt][3] * acc[0][nt][3];
       sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
       sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
-      if (q == 0) {
-        s_red[(wave * 2 + 0) * (NT * 16) + nt * 16 + i] = sm;
-        s_red[(wave * 2 + 1) * (NT * 16) + nt * 16 + i] = sq;
-      }
-    }
-    __syncthreads();
-    if (tid < 2 * CN) {
-      const int which = tid / CN, n = tid - which * CN;
-      const float v = ((s_red[(0 * 2 + which) * (NT * 16) + n] + s_red[(1 * 2 + which) * (NT * 16) + n]) +
-                       s_red[(2 * 2 + which) * (NT * 16) + n]) + s_red[(3 * 2 + which) * (NT * 16) + n];
-      epi.partial[(lbid * 2 + which) * CN + n] = v;
+      const int n = nt * 16 + i;
+      if (q == 0 && n < CN) { prow[n] = sm; prow[CN + n] = sq; }
     }
   }
   float sc[NT], sh[NT];
@@ -1477,19 +1469,11 @@ int vc_conv_epilogue_supported(int64_t n_in, int cin, int cout, int kv, int oper
   return (g_conv_variant == 2 && kv <= 32 && n_in * (int64_t)cin * 4 < (1LL << 31) && operand_type == VC_OPERAND_F32) ? 1 : 0;
 }
 
-static bool stats_per_wave(int64_t n_in, int cin, int kv, int flags) {
-  switch (cin) {
-    case 16: return use_window_kernel<16>(flags, VC_OPERAND_F32, nullptr, nullptr, n_in, kv, nullptr);
-    case 32: return use_window_kernel<32>(flags, VC_OPERAND_F32, nullptr, nullptr, n_in, kv, nullptr);
-    case 64: return use_window_kernel<64>(flags, VC_OPERAND_F32, nullptr, nullptr, n_in, kv, nullptr);
-  }
-  return false;
-}
-
 size_t vc_conv_stats_partial_floats(int64_t n_in, int64_t n_out, int cin, int cout, int kv, int flags) {
+  (void)n_in; (void)cin; (void)kv; (void)flags;
   if (n_out < 0 || cout < 1) return 0;
-  // one partial row (sum, sum of squares per channel) per 64-row block, or per 16-row wave tile on the LDS-window kernel
-  return (size_t)cdiv(n_out, 64) * (stats_per_wave(n_in, cin, kv, flags) ? 4 : 1) * 2 * cout;
+  // one partial row (sum, sum of squares per channel) per 16-row wave tile: 4 per 64-row block, direct and window kernel alike
+  return (size_t)cdiv(n_out, 64) * 4 * 2 * cout;
 }
 
 int vc_conv_forward_epilogue(const float* x, int64_t n_in, const int32_t* pair_fwd, int64_t n_out, int kv, const float* weight,

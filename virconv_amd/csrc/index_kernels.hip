@@ -586,6 +586,35 @@ __global__ void __launch_bounds__(256) flag_blocksum_kernel(const int32_t* __res
   if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
 }
 
+// ------------------------------------------------------------------------------------------ representative-first row order
+// Backward-input of a duplicate-pixel SubM conv (2-D image-space branch): only representative rows (rep[r] == r) own
+// non-centre taps, every other row takes the centre tap alone -- and only 19-53 % of the rows are representatives.  In natural
+// order a 16-row tile mixes both kinds, so it issues the union (up to 9 offsets) for rows that need one.  A stable partition
+// "representatives first" makes the tiles homogeneous: the tiles of the second part issue ONE offset.  (vc_row_order's mask
+// sort gives the same split but is a per-window LDS sort; this is one flag scan.)
+__global__ void __launch_bounds__(256) rep_flag_blocksum_kernel(const int32_t* __restrict__ rep, int64_t n,
+                                                                int32_t* __restrict__ blocksum) {
+  __shared__ int lds[4];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int v = (i < n && rep[i] == (int32_t)i) ? 1 : 0;
+  int tot;
+  block_exclusive_scan_256(v, &tot, lds);
+  if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(256) rep_partition_kernel(const int32_t* __restrict__ rep, int64_t n,
+                                                            const int32_t* __restrict__ blocksum, int64_t nb,
+                                                            int32_t* __restrict__ order) {
+  __shared__ int lds[4];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int v = (i < n && rep[i] == (int32_t)i) ? 1 : 0;
+  int tot;
+  const int rank = block_exclusive_scan_256(v, &tot, lds) + blocksum[blockIdx.x];  // representatives before row i
+  if (i >= n) return;
+  const int n_rep = blocksum[nb];
+  order[v ? rank : n_rep + (int)(i - rank)] = (int32_t)i;
+}
+
 // ------------------------------------------------------------------------------------------ K1 voxelise + MeanVFE
 struct VoxGeom {
   float minx, miny, minz, vx, vy, vz;
@@ -1235,6 +1264,25 @@ int vc_voxelize(const float* points, int64_t p, int f, const float* range, const
                 int32_t* n_voxels_dev, void* stream) {
   return voxelize_impl(false, points, p, f, range, vsize, max_points, max_voxels, 0, ws, ws_bytes, voxels, coords,
                        num_points, n_voxels_dev, stream);
+}
+
+size_t vc_rep_order_workspace_bytes(int64_t n) { return n < 0 ? 0 : (size_t)(cdiv(n > 0 ? n : 1, 256) + 1) * sizeof(int32_t); }
+
+int vc_rep_order(const int32_t* rep, int64_t n, int32_t* order, void* ws, size_t ws_bytes, void* stream) {
+  VC_REQUIRE(n >= 0 && n < (1LL << 31), "vc_rep_order: invalid row count");
+  if (n == 0) return VC_OK;
+  VC_REQUIRE(rep && order && ws, "vc_rep_order: null argument");
+  if (ws_bytes < vc_rep_order_workspace_bytes(n)) { set_error("vc_rep_order: workspace too small"); return VC_ECAPACITY; }
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nb = cdiv(n, 256);
+  int32_t* blocksum = (int32_t*)ws;
+  hipLaunchKernelGGL(rep_flag_blocksum_kernel, dim3((unsigned)nb), dim3(256), 0, st, rep, n, blocksum);
+  VC_CHECK_LAUNCH("rep_flag_blocksum_kernel");
+  hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(256), 0, st, blocksum, nb, blocksum + nb, (int32_t*)nullptr);
+  VC_CHECK_LAUNCH("scan_blocksums_kernel");
+  hipLaunchKernelGGL(rep_partition_kernel, dim3((unsigned)nb), dim3(256), 0, st, rep, n, blocksum, nb, order);
+  VC_CHECK_LAUNCH("rep_partition_kernel");
+  return VC_OK;
 }
 
 int vc_row_order(const int32_t* tbl, int64_t n, int kv, const int32_t* rep, int centre, int window, int32_t* order,

@@ -18,7 +18,7 @@ extern "C" {
 size_t vc_post_act_block_forward_workspace_bytes(int64_t n_in, int64_t n_out, int kv, int cin, int cout, int flags) {
   if (n_in < 0 || n_out < 0 || cin < 1 || cout < 1 || kv < 1) return 0;
   return al256(vc_bn_workspace_bytes(n_out, cout)) +
-         al256(vc_conv_stats_partial_floats(n_in, n_out, cin, cout, kv, flags | VC_CONV_SORTED_ROWS) * sizeof(float)) + 256;
+         al256(vc_conv_stats_partial_floats(n_in, n_out, cin, cout, kv, flags) * sizeof(float)) + 256;
 }
 
 int vc_post_act_block_forward(const float* x, int64_t n_in, const int32_t* pair_fwd, int64_t n_out, int kv,
@@ -35,13 +35,11 @@ int vc_post_act_block_forward(const float* x, int64_t n_in, const int32_t* pair_
   const size_t bn_bytes = vc_bn_workspace_bytes(n_out, cout);
   float* partial = (float*)(bn_ws + al256(bn_bytes));
   int rc;
-  // BatchNorm statistics: from the conv epilogue where that is free (the LDS-window kernel writes per-wave partials without an
-  // extra barrier), else from a pass over y_raw (the block-level epilogue of the direct kernel costs two barriers per block
-  // and measured slower than the pass it saves)
+  // BatchNorm statistics from the conv epilogue (per-wave partial sums, no extra barrier) wherever the epilogue kernels serve
+  // the shape; else from a pass over y_raw
   const size_t pf = vc_conv_stats_partial_floats(n_in, n_out, cin, cout, kv, flags);
-  const bool per_wave = pf == (size_t)cdiv(n_out, 64) * 4 * 2 * cout;
-  if (per_wave && operand_type == VC_OPERAND_F32 && row_order == nullptr) {
-    rc = vc_conv_forward_epilogue(x, n_in, pair_fwd, n_out, kv, weight, cin, cout, nullptr, VC_EPI_STATS, flags, partial,
+  if (operand_type == VC_OPERAND_F32 && vc_conv_epilogue_supported(n_in, cin, cout, kv, VC_OPERAND_F32)) {
+    rc = vc_conv_forward_epilogue(x, n_in, pair_fwd, n_out, kv, weight, cin, cout, row_order, VC_EPI_STATS, flags, partial,
                                   nullptr, nullptr, nullptr, nullptr, 0.f, 0, y_raw, stream);
     if (rc != VC_OK) return rc;
     rc = vc_bn_stats_from_partial(partial, (int64_t)(pf / (2 * (size_t)cout)), n_out, cout, mean, var, running_mean,
@@ -66,13 +64,26 @@ size_t vc_post_act_block_backward_workspace_bytes(int64_t n_out, int kv, int cin
  * n_dx output rows (= the conv's INPUT rows); pair_fwd is always the forward table (n_out columns) for the weight gradient.
  * rep / centre: duplicate-pixel rule of the 2-D SubM convs (NULL / -1 otherwise); group_acc: the persistent all-zero int64
  * accumulator of vc_group_sum(prepared = 2) (required when rep != NULL).                                                  */
+// fork/join events for the optional side-stream weight gradient (created once per host thread; no device memory)
+static hipEvent_t* unit_events() {
+  static thread_local hipEvent_t ev[2] = {nullptr, nullptr};
+  if (ev[0] == nullptr) {
+    if (hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess) {
+      ev[0] = ev[1] = nullptr;
+      return nullptr;
+    }
+  }
+  return ev;
+}
+
 int vc_post_act_block_backward(const float* x, int64_t n_in, const float* y_raw, int64_t n_out, const float* dy,
                                int dy_stride, int dy_col0, const float* mean, const float* var, const float* gamma,
                                const float* beta, float eps, int relu, const int32_t* pair_fwd, const int32_t* tbl_dx,
                                int64_t n_dx, int mirror, int centre, const int32_t* rep, const int32_t* row_order_dx, int kv,
                                const float* weight, int cin, int cout, int operand_type, int flags, int need_dx, int need_dw,
                                float* d_raw, float* dx, float* dw, float* dgamma, float* dbeta, void* group_acc,
-                               size_t group_acc_bytes, void* ws, size_t ws_bytes, void* stream) {
+                               size_t group_acc_bytes, void* ws, size_t ws_bytes, void* side_stream, void* stream) {
   VC_REQUIRE(n_out >= 1 && x && y_raw && dy && mean && var && d_raw && dgamma && dbeta && ws && pair_fwd && weight,
              "vc_post_act_block_backward: null/invalid argument");
   VC_REQUIRE(!need_dx || (tbl_dx && dx), "vc_post_act_block_backward: need_dx without table / output");
@@ -94,6 +105,19 @@ int vc_post_act_block_backward(const float* x, int64_t n_in, const float* y_raw,
   int rc = vc_bn_relu_backward(y_raw, dy, dy_stride, dy_col0, n_out, cout, mean, var, gamma, beta, eps, relu, d_raw, dgamma,
                                dbeta, dup ? (unsigned*)group_acc : nullptr, bn_ws, bn_bytes, stream);
   if (rc != VC_OK) return rc;
+  // dW and dX both only read d_raw and are independent: with a side stream the weight gradient runs underneath the
+  // backward-input conv (fork after the BatchNorm backward, join before returning -- the caller's stream-ordered allocator may
+  // then recycle every buffer of this call).  Both kernels are latency-bound at ~50 % of the matrix pipes on their own.
+  hipEvent_t* ev = (side_stream && need_dx && need_dw) ? unit_events() : nullptr;
+  bool forked = false;
+  if (ev != nullptr) {
+    VC_CHECK_HIP(hipEventRecord(ev[0], (hipStream_t)stream));
+    VC_CHECK_HIP(hipStreamWaitEvent((hipStream_t)side_stream, ev[0], 0));
+    rc = vc_conv_backward_weight(x, d_raw, pair_fwd, n_out, kv, cin, cout, operand_type, dw, dw_ws, dw_bytes, side_stream);
+    if (rc != VC_OK) return rc;
+    VC_CHECK_HIP(hipEventRecord(ev[1], (hipStream_t)side_stream));
+    forked = true;
+  }
   if (need_dx) {
     const float* src = d_raw;
     const float* src_centre = nullptr;
@@ -107,7 +131,9 @@ int vc_post_act_block_backward(const float* x, int64_t n_in, const float* y_raw,
                                 dup ? rep : nullptr, row_order_dx, operand_type, flags, dx, stream);
     if (rc != VC_OK) return rc;
   }
-  if (need_dw) {
+  if (forked) {
+    VC_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, ev[1], 0));
+  } else if (need_dw) {
     rc = vc_conv_backward_weight(x, d_raw, pair_fwd, n_out, kv, cin, cout, operand_type, dw, dw_ws, dw_bytes, stream);
     if (rc != VC_OK) return rc;
   }

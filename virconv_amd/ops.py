@@ -93,6 +93,9 @@ def build_subm_rulebook(indices: torch.Tensor, spatial_shape, ksize, dilation=1,
                   (1,) * ndim, tuple(k // 2 for k in ks), dl)
     # strided-conv outputs are emitted in ascending (b, z, y, x) order and tagged below; a SubM conv on them reads a sorted table
     rb.sorted_rows = bool(WINDOW_GATHER and getattr(indices, "_vc_sorted", False) and not allow_duplicates)
+    if rb.rep is not None and REP_FIRST_ORDER and ROW_ORDER != "all" and hasattr(get_backend(), "rep_order") and indices.is_cuda:
+        # duplicate-pixel table: the backward-input walks representatives first (homogeneous tiles, see vc_rep_order)
+        rb.order_bwd = get_backend().rep_order(rb.rep)
     if ROW_ORDER == "all" and rb.kv <= 32:
         be = get_backend()
         rb.order_fwd = be.row_order(pair, window=ROW_ORDER_WINDOW)
@@ -299,6 +302,8 @@ MFMA_OPERAND = os.environ.get("VIRCONV_MFMA_OPERAND", "f32")
 # r02_pmc_conv_variants.md).  Off by default; "1" turns it on (tools/kbench.py measures both).
 WINDOW_GATHER = os.environ.get("VIRCONV_WINDOW_GATHER", "0") != "0"
 ROW_ORDER = os.environ.get("VIRCONV_ROW_ORDER", "bwd")
+# duplicate-pixel (2-D) SubM tables: backward-input in representative-first row order (vc_rep_order); "0" = natural order
+REP_FIRST_ORDER = os.environ.get("VIRCONV_REP_FIRST_ORDER", "1") != "0"
 ROW_ORDER_WINDOW = int(os.environ.get("VIRCONV_ROW_ORDER_WINDOW", "2048"))
 _SIDE_STREAMS = {}
 
