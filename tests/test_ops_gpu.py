@@ -997,7 +997,7 @@ def test_rep_order_is_a_stable_partition_and_never_changes_the_duplicate_pixel_b
     duplicate-pixel conv gives the same bits with and without it."""
     rng = np.random.default_rng(12)
     shape = (160, 60)
-    idx = _indices2(13, 30000, dup=True)
+    idx = _indices2(13, 4000, dup=True)
     n = idx.shape[0]
     it = torch.from_numpy(idx).cuda()
     pair, rep = hip_backend.subm_rulebook(it, shape, (3, 3), (1, 1), want_rep=True)

@@ -302,8 +302,10 @@ MFMA_OPERAND = os.environ.get("VIRCONV_MFMA_OPERAND", "f32")
 # r02_pmc_conv_variants.md).  Off by default; "1" turns it on (tools/kbench.py measures both).
 WINDOW_GATHER = os.environ.get("VIRCONV_WINDOW_GATHER", "0") != "0"
 ROW_ORDER = os.environ.get("VIRCONV_ROW_ORDER", "bwd")
-# duplicate-pixel (2-D) SubM tables: backward-input in representative-first row order (vc_rep_order); "0" = natural order
-REP_FIRST_ORDER = os.environ.get("VIRCONV_REP_FIRST_ORDER", "1") != "0"
+# duplicate-pixel (2-D) SubM tables: backward-input in representative-first row order (vc_rep_order).  Measured: no gain (2-D
+# backward-input 316 vs 303 us per pass, train step 6.21 vs 6.17 ms) -- those launches are dominated by the group-sum machinery
+# and the gathers, not by padded MFMAs.  Off by default.
+REP_FIRST_ORDER = os.environ.get("VIRCONV_REP_FIRST_ORDER", "0") != "0"
 ROW_ORDER_WINDOW = int(os.environ.get("VIRCONV_ROW_ORDER_WINDOW", "2048"))
 _SIDE_STREAMS = {}
 
