@@ -84,10 +84,25 @@ def make_raw_frames(frame_seeds, device):
 
 
 def front_end(raw, base, training=True):
-    """The data front-end on the GPU: one fused call per frame (vc_frontend_voxelize_mean), one count read per batch."""
-    feats, coords = data.frontend_batch(raw, training, synth.POINT_CLOUD_RANGE, synth.VOXEL_SIZE, 5, 40000, True)
+    """The data front-end on the GPU: one fused call per frame (vc_frontend_voxelize_mean), one count read per batch.  It
+    runs on the backbone's high-priority geometry stream: its count read then waits for a few short kernels, not for the
+    previous step's backward that is still queued on the main stream (the host keeps its run-ahead)."""
+    from virconv_amd.backbone import _plan_stream
+    dev = raw[0][0].device
+    main, side = torch.cuda.current_stream(), _plan_stream(dev)
+    ready = base.get("inputs_ready_event")
+    if ready is not None:
+        side.wait_event(ready)
+    else:
+        side.wait_stream(main)
+    with torch.cuda.stream(side):
+        feats, coords = data.frontend_batch(raw, training, synth.POINT_CLOUD_RANGE, synth.VOXEL_SIZE, 5, 40000, True)
+        coords = coords.float()
+    main.wait_stream(side)
+    feats.record_stream(main)
+    coords.record_stream(main)
     bd = dict(base)
-    bd["voxel_features"], bd["voxel_coords"] = feats, coords.float()
+    bd["voxel_features"], bd["voxel_coords"] = feats, coords
     return bd
 
 

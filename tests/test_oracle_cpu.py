@@ -218,6 +218,36 @@ def test_index2uv_equals_reference_torch_code(stride):
 
 
 @needs_ref
+def test_projection_mismatch_rate_on_a_full_frame_vs_reference_torch_code():
+    """the golden fixtures pick seeds on which the reference's torch projection and the oracle's agree on
+    every row; here the mismatch RATE is measured on a whole synthetic frame (all four strides, with and without augmentation)
+    and bounded.  A mismatch is a pixel coordinate that differs by one because torch's fused multiply-adds and the oracle's
+    one-rounding-per-op float32 arithmetic land on different sides of an integer boundary; it can only move a
+    row to the neighbouring pixel, never further."""
+    ref = refharness.import_reference_backbone()
+    from pcdet.datasets.augmentor.X_transform import X_TRANS
+    fr = synth.make_frame(0)
+    pts = np.concatenate([fr["points_lidar"], fr["points_virtual"][::3]])
+    _, coords, _ = geometry.voxelize(pts, synth.VOXEL_SIZE, synth.POINT_CLOUD_RANGE, 5, 40000)
+    assert coords.shape[0] > 30000
+    calibs = [fr["calib"]]
+    rc = [refharness.make_reference_calib(c) for c in calibs]
+    worst, total, bad = 0.0, 0, 0
+    for stride in (1, 2, 4, 8):
+        idx = np.unique(np.concatenate([np.zeros((coords.shape[0], 1), np.int32), coords // stride], 1), axis=0).astype(np.int32)
+        for tp in (fr["aug_param"][None].astype(np.float32), None):
+            uv_ref, _ = ref.index2uv(torch.from_numpy(idx), 1, rc, stride, X_TRANS(),
+                                     None if tp is None else torch.from_numpy(tp.copy()))
+            uv, _ = geometry.index2uv(idx, 1, calibs, stride, tp)
+            d = np.abs(uv_ref.numpy().astype(np.int64) - uv.astype(np.int64))
+            assert d.max() <= 1                       # a boundary case moves a row by at most one pixel
+            rate = float((d.max(axis=1) > 0).mean())
+            worst, total, bad = max(worst, rate), total + idx.shape[0], bad + int((d.max(axis=1) > 0).sum())
+    print(f"projection mismatch vs the reference torch code: {bad} of {total} rows ({bad / total:.2e}); worst case {worst:.2e}")
+    assert worst <= 1e-3 and bad / total <= 5e-4
+
+
+@needs_ref
 def test_mean_vfe_equals_reference_module():
     refharness.import_reference_backbone()
     from pcdet.models.backbones_3d.vfe.mean_vfe import MeanVFE

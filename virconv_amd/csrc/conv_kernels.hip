@@ -24,7 +24,9 @@ __device__ int g_xcd_swizzle_off = 0;  // developer switch (tools/kbench.py --no
 // 6 waves per SIMD.  1 = every B fragment of an offset read before its first MFMA + accumulator-alternating MFMAs: better
 // per-wave code but 97 VGPRs / 4 waves per SIMD, and MEASURED SLOWER (s3.d3_conv1 64->32 forward 242 vs 208 us,
 // profiles/r02_kbench_variants.txt): this kernel waits ~2 us for every W_k it requested one iteration earlier, and only
-// resident waves hide that.  Kept for A/B builds (hipcc -DVC_V2_SCHED=1).
+// resident waves hide that.  Kept for A/B builds (hipcc -DVC_V2_SCHED=1).  2 = only the MFMA ORDER of 1 (consecutive MFMAs
+// alternate between the output-column accumulators, no back-to-back dependent pair and its 8-cycle pipe bubble), fragment
+// reads left where hipcc wants them: same register count as 0 and the same time (bench 6.12-6.17 ms/step both).
 #ifndef VC_V2_SCHED
 #define VC_V2_SCHED 0
 #endif
@@ -374,7 +376,7 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
       _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
           _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                        \
               VecLoad<V>::ld(B_ + ((ch * NT + nt) * 64 + lane) * V, b[ch][nt]);                    \
-      if (VC_V2_SCHED && NCH * NT <= 8) __builtin_amdgcn_sched_barrier(0);                         \
+      if (VC_V2_SCHED == 1 && NCH * NT <= 8) __builtin_amdgcn_sched_barrier(0);                    \
       _Pragma("unroll") for (int t = 0; t < RT; ++t) {                                             \
         if (ACT[t]) {                                                                              \
           if constexpr (VC_V2_SCHED != 0) {                                                        \
@@ -980,6 +982,10 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
     if constexpr (OT == VC_OPERAND_F32) {
       const int ng = qlen >> 2;
       int g = 0;
+      // U groups of 4 pairs per trip: request, wait, 16 MFMAs.  A software-pipelined version (ping-pong register sets, the rows of
+      // trip t+1 requested before the MFMAs of trip t, counted vmcnt waits) was MEASURED SLOWER: 84 instead of 70 VGPRs for
+      // <64,32> = 5 instead of 7 waves per SIMD, dW total 1251 vs 1110 us per step (gpurun r2i) -- like the gather-GEMM, this
+      // kernel hides its gather latency with resident waves, not with per-wave prefetch.
       for (; g + U <= ng; g += U) {
         float a[U][VA], b[U][VB];
 #pragma unroll
