@@ -323,6 +323,8 @@ def main():
     for _ in range(args.warmup):
         train_step(ddp, optimizer, batch, lw, grad_sync, raw)
 
+    if os.environ.get("VIRCONV_PASS_DW_MAIN_TAIL"):   # schedule experiment, see virconv_amd/csrc/pass.hip
+        assert be.lib.vc_debug_set(b"pass_dw_main_tail", int(os.environ["VIRCONV_PASS_DW_MAIN_TAIL"])) == 0
     tdir, tck, tcn = args.trace.split(",")
     be.trace_begin(tdir, int(tck), int(tcn))
     parallel.barrier()

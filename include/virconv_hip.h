@@ -312,6 +312,67 @@ int vc_post_act_block_backward(const float* x, int64_t n_in, const float* y_raw,
                                void* side_stream /* nullable hipStream_t: the weight gradient runs on it underneath the
                                backward-input conv; forked and joined inside the call */, void* stream);
 
+/* ------------------------------------------------------------------------------------------------ feature pass
+ * The feature pass of a whole backbone -- every post_act_block, the NRConvBlock channel concat (spconv_backbone.py:207-229)
+ * and the layer discard gathers (:134-147) of VirConvL8x.forward (:609-699) -- as ONE call forward and ONE call backward
+ * (the reverse-mode sweep that spconv's autograd Functions + torch's engine perform node by node, train_utils.py:47).
+ * Pure host-side composition of the entry points above: same kernels, same order, bit-identical results.  What it removes
+ * is the per-node host cost (Python autograd node + ctypes + allocator round trips, ~25 us per launch against ~4 us for the
+ * launch itself), which bounds a ~370-launch train step on the host; all intermediate tensors live in ONE caller-provided
+ * arena per direction (bump-allocated, 256-B aligned; layout is a pure function of the program and the row counts).
+ *
+ * A program is a list of ops over numbered row-major float32 buffers (rows x cols):
+ *   VC_PASS_UNIT   dst[:, dst_col0 : dst_col0 + cout] = post_act_block(unit, table)(src)     (src dense: cols == cin)
+ *   VC_PASS_COPY   dst[:, dst_col0 : dst_col0 + cols(src)] = src                               (channel concat, written in place)
+ *   VC_PASS_GATHER dst = src[keeps[keep], :]                                                   (layer discard)
+ * Buffer 0.. may be `external` (caller memory, e.g. the input features); all others are carved from the arena and their
+ * byte offsets are reported so the caller can hand some of them out (x_conv1..4, the encoded tensor).
+ * Backward: gradients arriving from outside per buffer (`ext_grads[b]`, dense rows x cols, or NULL) are propagated in
+ * reverse op order; a buffer's gradient is the sum of its consumers' contributions (column slices are consumed as strided
+ * views, two contributions are added by one kernel); parameter gradients are written to the units' dweight/dgamma/dbeta
+ * (zero-filled when no gradient reaches a unit).  Weight gradients run on `side_stream` underneath the backward-input
+ * chain and are joined once at the end.                                                                               */
+typedef enum vc_pass_kind { VC_PASS_UNIT = 1, VC_PASS_COPY = 2, VC_PASS_GATHER = 3 } vc_pass_kind;
+typedef struct vc_pass_unit {    /* one post_act_block: conv weight (Cout, *k, Cin), BatchNorm1d parameters/state, gradient outputs */
+  const float* weight; const float* gamma; const float* beta;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;
+  float* dweight; float* dgamma; float* dbeta;           /* vc_pass_backward outputs (NULL: not wanted) */
+  int32_t cin, cout; float momentum, eps;
+} vc_pass_unit;
+typedef struct vc_pass_table {   /* one rulebook (vc_subm_rulebook / vc_spconv_emit_pairs outputs + hints) */
+  const int32_t* pair_fwd; const int32_t* pair_bwd /* strided only */; const int32_t* rep /* duplicate-pixel rule or NULL */;
+  const int32_t* order_fwd; const int32_t* order_bwd;     /* vc_row_order hints or NULL */
+  int64_t n_in, n_out; int32_t kv, subm, centre, sorted_rows;
+} vc_pass_table;
+typedef struct vc_pass_buf { int64_t rows; int32_t cols; int32_t external; void* ptr /* external only */; } vc_pass_buf;
+typedef struct vc_pass_op { int32_t kind, src, dst, dst_col0, unit, table, keep, relu; } vc_pass_op;
+typedef struct vc_pass_program {
+  const vc_pass_op* ops; int32_t n_ops;
+  const vc_pass_buf* bufs; int32_t n_bufs;
+  const vc_pass_unit* units; int32_t n_units;
+  const vc_pass_table* tables; int32_t n_tables;
+  const int64_t* const* keeps; int32_t n_keeps;
+  int32_t training;        /* 1: batch statistics (+ running-stat update), backward available; 0: running statistics */
+  int32_t operand_type;    /* vc_operand */
+} vc_pass_program;
+size_t vc_pass_forward_arena_bytes(const vc_pass_program* prog);
+int vc_pass_forward(const vc_pass_program* prog, void* arena, size_t arena_bytes,
+                    int64_t* buf_offsets /* n_bufs: byte offset of every arena buffer, -1 for external ones */, void* stream);
+size_t vc_pass_backward_arena_bytes(const vc_pass_program* prog, const float* const* ext_grads, int need_input_grad);
+int vc_pass_backward(const vc_pass_program* prog, const void* fwd_arena, size_t fwd_arena_bytes,
+                     const float* const* ext_grads /* n_bufs */, float* input_grad /* gradient of buffer 0 or NULL */,
+                     void* group_acc, size_t group_acc_bytes /* persistent accumulator of vc_group_sum(prepared = 2) */,
+                     void* arena, size_t arena_bytes, void* side_stream /* nullable */, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ kernel timing
+ * Brackets every launch of ONE gather-GEMM instantiation (direction: 0 forward, 1 backward-input; ck, cn = its gathered /
+ * produced channel counts) with HIP events on the launch stream, inside whatever call issues it (vc_conv_*,
+ * vc_post_act_block_*, vc_pass_*), and counts the table's active pairs on the device right after it (outside the
+ * bracket).  bench.py's roofline figure comes from here.  `dev_pairs`: device int64[max_records], caller-owned.        */
+typedef struct vc_trace_record { float ms; int32_t kv, ck, cn, windowed; int64_t n_src, n_out, pairs; } vc_trace_record;
+int vc_trace_begin(int direction, int ck, int cn, int max_records, int64_t* dev_pairs);
+int vc_trace_end(vc_trace_record* out, int capacity, int* n_records /* synchronises the traced events */);
+
 /* ================================================================================================ RoI grid pooling
  * the operators that consume multi_scale_3d_features['x_conv3'/'x_conv4'] right after the backbone
  * (pcdet/models/roi_heads/ted_head.py:450-650 -> pointnet2_stack/voxel_pool_modules.py:70-130).

@@ -133,3 +133,68 @@ def test_front_end_entry_points_validate_their_arguments_without_gpu():
                                          1 << 24, dummy, dummy, dummy, dummy, None, None) == _lib.VC_EINVAL
     assert lib.vc_frontend_voxelize_mean(dummy, 10, dummy, 0, 10, 8, 2, 0.8, 60.0, None, 0, 0.0, rng, vs, 5, 100, 1, dummy,
                                          16, dummy, dummy, dummy, dummy, None, None) == _lib.VC_ECAPACITY
+
+
+def _tiny_pass_program(n=100, cin=8, cout=16, n_out=None, training=1):
+    """One post_act_block on fake (never dereferenced) device pointers: enough for the host-side layout / validation code."""
+    import ctypes as C
+    n_out = n if n_out is None else n_out
+    fake = 0x10000
+    ops = (_lib.PassOp * 1)()
+    ops[0].kind, ops[0].src, ops[0].dst, ops[0].dst_col0, ops[0].unit, ops[0].table, ops[0].relu = _lib.PASS_UNIT, 0, 1, 0, 0, 0, 1
+    bufs = (_lib.PassBuf * 2)()
+    bufs[0].rows, bufs[0].cols, bufs[0].external, bufs[0].ptr = n, cin, 1, fake
+    bufs[1].rows, bufs[1].cols = n_out, cout
+    units = (_lib.PassUnit * 1)()
+    u = units[0]
+    u.weight = u.gamma = u.beta = u.running_mean = u.running_var = fake
+    u.cin, u.cout, u.momentum, u.eps = cin, cout, 0.01, 1e-3
+    tables = (_lib.PassTable * 1)()
+    t = tables[0]
+    t.pair_fwd, t.n_in, t.n_out, t.kv, t.subm, t.centre = fake, n, n, 27, 1, 13
+    prog = _lib.PassProgram()
+    prog.ops, prog.n_ops, prog.bufs, prog.n_bufs = ops, 1, bufs, 2
+    prog.units, prog.n_units, prog.tables, prog.n_tables = units, 1, tables, 1
+    prog.keeps, prog.n_keeps, prog.training, prog.operand_type = None, 0, training, 0
+    return prog, (ops, bufs, units, tables)
+
+
+def test_feature_pass_layout_and_validation_without_gpu():
+    """vc_pass_*: the arena layout and the program checks are host code -- exercised here on fake pointers (no launch)."""
+    import ctypes as C
+    lib = _lib.load()
+    prog, keep = _tiny_pass_program()
+    fwd = lib.vc_pass_forward_arena_bytes(C.byref(prog))
+    # output buffer + y_raw (kept for the backward) + statistics + the unit's scratch
+    assert fwd >= 2 * 100 * 16 * 4 + 2 * 16 * 4 + lib.vc_post_act_block_forward_workspace_bytes(100, 100, 27, 8, 16, 0)
+    ext = (C.c_void_p * 2)()
+    assert lib.vc_pass_backward_arena_bytes(C.byref(prog), ext, 0) > 0          # no gradient arrives: scratch only
+    ext[1] = 0x20000
+    b1 = lib.vc_pass_backward_arena_bytes(C.byref(prog), ext, 0)
+    b2 = lib.vc_pass_backward_arena_bytes(C.byref(prog), ext, 1)
+    assert b1 >= 100 * 16 * 4 + lib.vc_conv_backward_weight_workspace_bytes(100, 27, 8, 16)   # d_raw + weight-gradient partials
+    assert b2 >= b1 + 100 * 8 * 4                                                  # + dx of the first unit
+    # running statistics: smaller forward arena (no y_raw kept), no backward
+    prog_e, keep_e = _tiny_pass_program(training=0)
+    assert 0 < lib.vc_pass_forward_arena_bytes(C.byref(prog_e)) < fwd
+    assert lib.vc_pass_backward_arena_bytes(C.byref(prog_e), ext, 0) == 0
+    assert lib.vc_pass_backward(C.byref(prog_e), 0x1000, 1 << 30, ext, None, None, 0, 0x1000, 1 << 30, None, None) == _lib.VC_EINVAL
+    assert b"running statistics" in lib.vc_last_error()
+    # shape disagreements are caught before anything is launched
+    bad, keep_b = _tiny_pass_program(n_out=90)
+    assert lib.vc_pass_forward_arena_bytes(C.byref(bad)) == 0 and b"shapes disagree" in lib.vc_last_error()
+    assert lib.vc_pass_forward(C.byref(bad), 0x1000, 1 << 30, None, None) == _lib.VC_EINVAL
+    bad, keep_b = _tiny_pass_program()
+    keep_b[0][0].dst_col0 = 2
+    assert lib.vc_pass_forward_arena_bytes(C.byref(bad)) == 0 and b"multiple of 4" in lib.vc_last_error()
+    bad, keep_b = _tiny_pass_program()
+    keep_b[0][0].kind = 9
+    assert lib.vc_pass_forward(C.byref(bad), 0x1000, 1 << 30, None, None) == _lib.VC_EINVAL and b"unknown kind" in lib.vc_last_error()
+    assert lib.vc_pass_forward(None, None, 0, None, None) == _lib.VC_EINVAL
+    # arena too small
+    assert lib.vc_pass_forward(C.byref(prog), 0x1000, 16, None, None) == _lib.VC_ECAPACITY
+    # kernel timing facility: argument checks; ending a trace that never began is a no-op
+    n = C.c_int(-1)
+    assert lib.vc_trace_end(None, 0, C.byref(n)) == _lib.VC_OK and n.value == 0
+    assert lib.vc_trace_begin(2, 64, 32, 16, 0x1000) == _lib.VC_EINVAL
+    assert lib.vc_trace_begin(0, 64, 32, 16, None) == _lib.VC_EINVAL

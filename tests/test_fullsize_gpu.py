@@ -412,3 +412,84 @@ def test_fullsize_virconv8x_train_vs_oracle(hip_backend, monkeypatch):
     n_flip, rel_h, rel_o = _compare_train(ref64, ref32, got, "virconv_8x_configs3")
     print(f"[parity configs[3] backbone] loss {got[0]:.6f} vs {ref64[0]:.6f}; gradient vector: |hip - f64| / |f64| = {rel_h:.2e} "
           f"(fp32 oracle: {rel_o:.2e}); tensors with an isolated ReLU flip: {n_flip}")
+
+
+@pytest.mark.parametrize("discard", ["spconv1_inplace", "spconv2_noop"])
+def test_native_feature_pass_equals_the_node_by_node_path(hip_backend, discard, monkeypatch):
+    """vc_pass_forward / vc_pass_backward (the whole VirConvL8x chain as one native call per direction, ONE autograd node) issue
+    the same kernels in the same order as the node-by-node path: outputs, every parameter gradient, the input gradient and
+    the BatchNorm running statistics are bit-equal; eval mode (running statistics, affine epilogue) likewise."""
+    from virconv_amd import feature_pass
+    dev = torch.device("cuda", 0)
+    batch = bench.make_batch([0, 1], dev, training=True)
+    lw = bench.make_loss_weights(dev)
+    cfg = dict(bench.MODEL_CFG)
+    cfg["LAYER_DISCARD_MODE"] = discard
+    torch.manual_seed(21)
+    model = VirConvL8x(cfg, 8, synth.GRID_SIZE).to(dev).train()
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    rec = _record_discards(monkeypatch)
+    calls = []
+    orig_run = feature_pass.run
+    monkeypatch.setattr(feature_pass, "run", lambda *a, **k: (calls.append(1), orig_run(*a, **k))[1])
+
+    def one(native, keeps, training=True, want_input_grad=False):
+        monkeypatch.setattr(feature_pass, "NATIVE_PASS", native)
+        model.load_state_dict(state)
+        model.train(training)
+        model.zero_grad(set_to_none=True)
+        bd = dict(batch)
+        leaf = batch["voxel_features"].clone().requires_grad_(want_input_grad)
+        # the backbone zeroes the RGB columns in place (spconv_backbone.py:636): not allowed on a leaf that requires grad
+        bd["voxel_features"] = leaf * 1.0 if want_input_grad else leaf
+        if keeps:
+            bd["layer_discard_keep"] = keeps
+        with torch.set_grad_enabled(training):
+            out = model(bd)
+            loss = _bench_loss(out, lw)
+        res = {n: t.features.detach().clone() for n, t in out["multi_scale_3d_features"].items()}
+        res["out"] = out["encoded_spconv_tensor"].features.detach().clone()
+        idx = {n: t.indices.clone() for n, t in out["multi_scale_3d_features"].items()}
+        grads = {}
+        if training:
+            loss.backward()
+            grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+            if want_input_grad:
+                grads["__input__"] = leaf.grad.detach().clone()
+        return float(loss.detach()), res, idx, grads, {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    torch.manual_seed(5)
+    ref = one(False, None)
+    keeps = {k: v.to(dev) for k, v in rec.items()}
+    assert (len(keeps) == 3) == (discard == "spconv1_inplace")
+    n_calls = len(calls)
+    got = one(True, keeps)
+    assert len(calls) == n_calls + 1, "the native pass did not run"
+    assert ref[0] == got[0]
+    for k in ref[1]:
+        assert torch.equal(ref[1][k], got[1][k]), k
+    for k in ref[2]:
+        assert torch.equal(ref[2][k], got[2][k]), k
+    assert set(ref[3]) == set(got[3])
+    for k in ref[3]:
+        assert torch.equal(ref[3][k], got[3][k]), k
+    for k in ref[4]:
+        assert torch.equal(ref[4][k], got[4][k]), k
+    # with a gradient for the input features (not needed by the detector, supported by the sweep)
+    ref_i, got_i = one(False, keeps, want_input_grad=True), one(True, keeps, want_input_grad=True)
+    assert torch.equal(ref_i[3]["__input__"], got_i[3]["__input__"]) and float(ref_i[3]["__input__"].abs().max()) > 0
+    for k in ref_i[3]:
+        assert torch.equal(ref_i[3][k], got_i[3][k]), k
+    # frozen parameters get no gradient (and cost no weight-gradient launch)
+    model.vir_conv2.d3_conv1[0].weight.requires_grad_(False)
+    fr = one(True, keeps)
+    model.vir_conv2.d3_conv1[0].weight.requires_grad_(True)
+    assert "vir_conv2.d3_conv1.0.weight" not in fr[3]
+    for k in ref[3]:
+        if k != "vir_conv2.d3_conv1.0.weight":
+            assert torch.equal(ref[3][k], fr[3][k]), k
+    # eval mode: running statistics, conv + BN + ReLU folded into one launch per unit
+    e_ref, e_got = one(False, None, training=False), one(True, None, training=False)
+    assert e_ref[0] == e_got[0]
+    for k in e_ref[1]:
+        assert torch.equal(e_ref[1][k], e_got[1][k]), k

@@ -836,7 +836,7 @@ def test_window_gather_gemm_epilogues(hip_backend, cin, cout):
     y, partial = hip_backend.conv_forward_stats(x, w, pair, sorted_rows=True)
     assert torch.equal(y, y_ref)
     p = partial.view(-1, 2, cout).double()
-    assert p.shape[0] == 4 * ((n + 63) // 64)                       # one partial row per 16-row wave tile
+    assert p.shape[0] in (4 * ((n + 63) // 64), 8 * ((n + 127) // 128))   # one partial row per 16-row wave tile (4- or 8-wave blocks)
     yd = y_ref.double()
     np.testing.assert_allclose(p[:, 0].sum(0).cpu().numpy(), yd.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
     np.testing.assert_allclose(p[:, 1].sum(0).cpu().numpy(), (yd * yd).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)

@@ -73,11 +73,56 @@ SIGNATURES = {
     "vc_post_act_block_backward_workspace_bytes": (_SZ, [_I64, _I, _I, _I]),
     "vc_post_act_block_backward": (_I, [_P, _I64, _P, _I64, _P, _I, _I, _P, _P, _P, _P, _F, _I, _P, _P, _I64, _I, _I, _P, _P,
                                         _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _P, _P]),
+    "vc_pass_forward_arena_bytes": (_SZ, [_P]),
+    "vc_pass_forward": (_I, [_P, _P, _SZ, _P, _P]),
+    "vc_pass_backward_arena_bytes": (_SZ, [_P, _P, _I]),
+    "vc_pass_backward": (_I, [_P, _P, _SZ, _P, _P, _P, _SZ, _P, _SZ, _P, _P]),
+    "vc_trace_begin": (_I, [_I, _I, _I, _I, _P]),
+    "vc_trace_end": (_I, [_P, _I, _P]),
     "vc_bn_workspace_bytes": (_SZ, [_I64, _I]),
     "vc_bn_stats": (_I, [_P, _I64, _I, _P, _P, _P, _P, _P, _F, _P, _SZ, _P]),
     "vc_bn_apply_relu": (_I, [_P, _I64, _I, _P, _P, _P, _P, _F, _I, _P, _I, _I, _P]),
     "vc_bn_relu_backward": (_I, [_P, _P, _I, _I, _I64, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _SZ, _P]),
 }
+
+
+
+# ---- structs of the feature pass / kernel timing (include/virconv_hip.h: vc_pass_*, vc_trace_record)
+PASS_UNIT, PASS_COPY, PASS_GATHER = 1, 2, 3
+
+
+class PassUnit(C.Structure):
+    _fields_ = [("weight", _P), ("gamma", _P), ("beta", _P), ("running_mean", _P), ("running_var", _P),
+                ("num_batches_tracked", _P), ("dweight", _P), ("dgamma", _P), ("dbeta", _P),
+                ("cin", C.c_int32), ("cout", C.c_int32), ("momentum", _F), ("eps", _F)]
+
+
+class PassTable(C.Structure):
+    _fields_ = [("pair_fwd", _P), ("pair_bwd", _P), ("rep", _P), ("order_fwd", _P), ("order_bwd", _P),
+                ("n_in", _I64), ("n_out", _I64), ("kv", C.c_int32), ("subm", C.c_int32), ("centre", C.c_int32),
+                ("sorted_rows", C.c_int32)]
+
+
+class PassBuf(C.Structure):
+    _fields_ = [("rows", _I64), ("cols", C.c_int32), ("external", C.c_int32), ("ptr", _P)]
+
+
+class PassOp(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("src", C.c_int32), ("dst", C.c_int32), ("dst_col0", C.c_int32), ("unit", C.c_int32),
+                ("table", C.c_int32), ("keep", C.c_int32), ("relu", C.c_int32)]
+
+
+class PassProgram(C.Structure):
+    _fields_ = [("ops", C.POINTER(PassOp)), ("n_ops", C.c_int32), ("bufs", C.POINTER(PassBuf)), ("n_bufs", C.c_int32),
+                ("units", C.POINTER(PassUnit)), ("n_units", C.c_int32), ("tables", C.POINTER(PassTable)),
+                ("n_tables", C.c_int32), ("keeps", C.POINTER(_P)), ("n_keeps", C.c_int32), ("training", C.c_int32),
+                ("operand_type", C.c_int32)]
+
+
+class TraceRecord(C.Structure):
+    _fields_ = [("ms", _F), ("kv", C.c_int32), ("ck", C.c_int32), ("cn", C.c_int32), ("windowed", C.c_int32),
+                ("n_src", _I64), ("n_out", _I64), ("pairs", _I64)]
+
 
 _lib = None
 

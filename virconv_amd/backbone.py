@@ -25,7 +25,7 @@ from torch import nn
 
 import os
 
-from . import ops
+from . import feature_pass, ops
 from . import spconv
 
 # layer discard: draw the kept rows with vc_random_keep (point-wise pseudo-random permutation) instead of torch.randperm
@@ -403,12 +403,30 @@ class VirConvL8x(nn.Module):
 
             if self.plan_ahead:
                 plan = self.build_plan(coords, batch_size, calib, trans_param, batch_dict, rid)
-                x = spconv.SparseConvTensor(feats, plan["in_indices"], self.sparse_shape, batch_size)
-                blocks = [(self.vir_conv1, 1), (self.vir_conv2, 2), (self.vir_conv3, 4), (self.vir_conv4, 8)]
-                outs = _run_nrconv_chain(blocks, plan["stages"], x, batch_size, calib, trans_param)
-                x1, x2, x3, x4 = outs
-                x4.indice_dict.update(plan["conv_out"])
-                out = self.conv_out(x4)
+                native = feature_pass.run(self, feats, plan) if feature_pass.usable(self, feats, plan) else None
+                if native is not None:
+                    # the whole chain below as ONE native call per direction (virconv_amd/feature_pass.py): same kernels, same order
+                    xs, idict = [], {}
+                    for st, f in zip(plan["stages"], native[:4]):
+                        idict = dict(idict)
+                        idict.update(st["rb3d"])
+                        kept = st["keep"] is not None
+                        xs.append(spconv.SparseConvTensor(f, st["kept_indices"] if kept else st["out_indices"], st["out_shape"],
+                                                          batch_size, indice_dict={} if kept else idict))
+                        if kept:
+                            idict = {}
+                    x1, x2, x3, x4 = xs
+                    x4.indice_dict.update(plan["conv_out"])
+                    rb_out = plan["conv_out"][self.conv_out[0].indice_key]
+                    out = spconv.SparseConvTensor(native[4], rb_out.out_indices, list(rb_out.out_shape), batch_size,
+                                                  indice_dict=x4.indice_dict)
+                else:
+                    x = spconv.SparseConvTensor(feats, plan["in_indices"], self.sparse_shape, batch_size)
+                    blocks = [(self.vir_conv1, 1), (self.vir_conv2, 2), (self.vir_conv3, 4), (self.vir_conv4, 8)]
+                    outs = _run_nrconv_chain(blocks, plan["stages"], x, batch_size, calib, trans_param)
+                    x1, x2, x3, x4 = outs
+                    x4.indice_dict.update(plan["conv_out"])
+                    out = self.conv_out(x4)
             else:
                 x0 = spconv.SparseConvTensor(feats, coords.int(), self.sparse_shape, batch_size)
                 x1 = self.vir_conv1(x0, batch_size, calib, 1, None, trans_param)

@@ -15,6 +15,7 @@ from . import _lib
 from ._lib import CONV_SORTED_ROWS, OPERAND_TYPES, check, i32arr, f32arr
 
 
+import ctypes
 import os
 
 # weight gradient of a conv+BN+ReLU unit on a side stream underneath its backward-input conv (fork / join inside the C call)
@@ -51,44 +52,47 @@ class HipBackend:
         self.lib = _lib.load()
         self._pinned = None
         self._pin_ev = None
-        self._trace = None      # (direction, CK, CN) of the gather-GEMM instantiation being timed, or None
-        self._trace_log = []
+        self._trace_cap, self._trace_pairs = 0, None
+        if os.environ.get("VIRCONV_CONV_NW"):   # waves per block of the direct gather-GEMM (4 | 8), see conv_kernels.hip
+            check(self.lib.vc_debug_set(b"conv_nw", int(os.environ["VIRCONV_CONV_NW"])), "vc_debug_set")
 
     # ------------------------------------------------------------------ kernel timing for bench.py's roofline
-    def trace_begin(self, direction: str, ck: int, cn: int) -> None:
-        """Bracket every launch of gather_gemm_kernel<CK, CN, BWD=(direction=='bwd')> with HIP events on the current
-        stream and log its algorithmic flops / bytes (SURVEY §8d formulas)."""
+    native_pass = True   # vc_pass_forward / vc_pass_backward are available (virconv_amd/feature_pass.py)
+
+    @staticmethod
+    def stream() -> int:
+        return _stream()
+
+    @staticmethod
+    def unit_overlap_dw() -> bool:
+        return UNIT_OVERLAP_DW
+
+    def trace_begin(self, direction: str, ck: int, cn: int, max_records: int = 4096) -> None:
+        """Bracket every launch of the gather-GEMM instantiation <CK, CN, BWD=(direction=='bwd')> with HIP events on its launch
+        stream, INSIDE the library (vc_trace_begin): whichever call issues the launch -- an operator, a post_act_block unit or
+        the whole feature pass -- is timed as it runs in the product path.  The active pairs of each traced table are counted
+        on the device right after the launch (outside the bracket)."""
         assert direction in ("fwd", "bwd")
-        self._trace = (direction, int(ck), int(cn))
-        self._trace_log = []
+        self._trace_pairs = torch.zeros((max_records,), dtype=torch.int64, device="cuda")
+        check(self.lib.vc_trace_begin(0 if direction == "fwd" else 1, int(ck), int(cn), int(max_records),
+                                      _ptr(self._trace_pairs)), "vc_trace_begin")
+        self._trace_cap = int(max_records)
 
     def trace_end(self):
-        log, self._trace, self._trace_log = self._trace_log, None, []
-        if not log:
+        """-> [{ms, flops, bytes, pairs, n_out, windowed}] per traced launch (algorithmic figures: SURVEY 8d formulas)."""
+        cap = getattr(self, "_trace_cap", 0)
+        if not cap:
             return []
-        torch.cuda.synchronize()
+        recs = (_lib.TraceRecord * cap)()
+        n = ctypes.c_int(0)
+        check(self.lib.vc_trace_end(recs, cap, ctypes.byref(n)), "vc_trace_end")
+        self._trace_cap, self._trace_pairs = 0, None
         out = []
-        for e in log:
-            pairs = int((e["tbl"] >= 0).sum().item())  # counted here, after the timed region (the table was kept alive)
-            kv, ck, cn = e["kv"], e["ck"], e["cn"]
-            out.append({"ms": e["start"].elapsed_time(e["end"]), "flops": 2.0 * pairs * ck * cn,
-                        "bytes": 4.0 * (e["n_src"] * ck + e["n_out"] * cn + kv * ck * cn) + 4.0 * kv * e["n_out"],
-                        "pairs": pairs, "n_out": e["n_out"], "windowed": e["windowed"]})
+        for r in recs[:n.value]:
+            out.append({"ms": r.ms, "flops": 2.0 * r.pairs * r.ck * r.cn,
+                        "bytes": 4.0 * (r.n_src * r.ck + r.n_out * r.cn + r.kv * r.ck * r.cn) + 4.0 * r.kv * r.n_out,
+                        "pairs": int(r.pairs), "n_out": int(r.n_out), "windowed": bool(r.windowed)})
         return out
-
-    def _traced(self, direction, ck, cn):
-        return self._trace is not None and self._trace == (direction, ck, cn)
-
-    def _trace_open(self, tbl, n_src, ck, cn, windowed=False):
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        rec = {"tbl": tbl, "kv": tbl.shape[0], "n_out": tbl.shape[1], "n_src": n_src, "ck": ck, "cn": cn,
-               "start": ev0, "end": ev1, "windowed": bool(windowed)}
-        ev0.record()
-        return rec
-
-    def _trace_close(self, rec):
-        rec["end"].record()
-        self._trace_log.append(rec)
 
     def _read_count(self, dev_scalar: torch.Tensor) -> int:
         """Device int32 -> host: async copy into a pinned slot, then POLL the event.  (A blocking .item() goes through
@@ -178,13 +182,9 @@ class HipBackend:
         cout, cin = weight.shape[0], weight.shape[-1]
         assert weight.numel() == cout * kv * cin and x.shape[1] == cin
         y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
-        rec = self._trace_open(pair_fwd, x.shape[0], cin, cout, sorted_rows and cin >= 16 and operand == "f32" and order is None) \
-            if self._traced("fwd", cin, cout) else None
         check(self.lib.vc_conv_forward(_ptr(x), x.shape[0], _ptr(pair_fwd), n_out, kv, _ptr(weight), cin, cout,
                                        _ptr(order), OPERAND_TYPES[operand], CONV_SORTED_ROWS if sorted_rows else 0, _ptr(y),
                                        _stream()), "vc_conv_forward")
-        if rec is not None:
-            self._trace_close(rec)
         return y
 
     def conv_epilogue_supported(self, n_in: int, cin: int, cout: int, kv: int, operand: str = "f32") -> bool:
@@ -202,13 +202,9 @@ class HipBackend:
         flags = CONV_SORTED_ROWS if sorted_rows else 0
         partial = torch.empty((self.lib.vc_conv_stats_partial_floats(x.shape[0], n_out, cin, cout, kv, flags),),
                               dtype=torch.float32, device=x.device)
-        rec = self._trace_open(pair_fwd, x.shape[0], cin, cout, sorted_rows and cin >= 16 and order is None) \
-            if self._traced("fwd", cin, cout) else None
         check(self.lib.vc_conv_forward_epilogue(_ptr(x), x.shape[0], _ptr(pair_fwd), n_out, kv, _ptr(weight), cin, cout,
                                                 _ptr(order), 1, flags, _ptr(partial), None, None, None, None, 0.0, 0,
                                                 _ptr(y), _stream()), "vc_conv_forward_epilogue")
-        if rec is not None:
-            self._trace_close(rec)
         return y, partial
 
     def conv_forward_affine(self, x: torch.Tensor, weight: torch.Tensor, pair_fwd: torch.Tensor, order, mean, var, gamma,
@@ -249,15 +245,11 @@ class HipBackend:
             check(self.lib.vc_group_sum(_ptr(dy), _ptr(rep), dy.shape[0], cout, _ptr(grp), _ptr(gws), gws_bytes,
                                         1 if group_ws is not None else 0, _stream()), "vc_group_sum")
             src, src_centre = grp, dy
-        rec = self._trace_open(tbl, dy.shape[0], cout, cin, sorted_rows and cout >= 16 and operand == "f32" and order is None
-                               and rep is None) if self._traced("bwd", cout, cin) else None
         check(self.lib.vc_conv_backward_input(_ptr(src), _ptr(src_centre), dy.shape[0], _ptr(tbl), n_in, kv, _ptr(weight),
                                               cin, cout, 1 if mirror else 0, centre if rep is not None else -1,
                                               _ptr(rep), _ptr(order), OPERAND_TYPES[operand],
                                               CONV_SORTED_ROWS if sorted_rows else 0, _ptr(dx), _stream()),
               "vc_conv_backward_input")
-        if rec is not None:
-            self._trace_close(rec)
         return dx
 
     def conv_backward_weight(self, x: torch.Tensor, dy: torch.Tensor, pair_fwd: torch.Tensor, weight_shape,
@@ -581,7 +573,7 @@ class HipBackend:
     def _side_stream(self, device) -> int:
         st = getattr(self, "_side", None)
         if st is None or st.device != torch.device(device):
-            st = torch.cuda.Stream(device=device)
+            st = torch.cuda.Stream(device=device, priority=int(os.environ.get("VIRCONV_SIDE_PRIORITY", "0")))
             self._side = st
         return st.cuda_stream
 
@@ -600,31 +592,6 @@ class HipBackend:
         stats = torch.empty((2, cout), dtype=torch.float32, device=dev)
         ws_bytes = self.lib.vc_post_act_block_forward_workspace_bytes(x.shape[0], n_out, kv, cin, cout, flags)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-        traced = self._traced("fwd", cin, cout)
-        rec = self._trace_open(tbl, x.shape[0], cin, cout, sorted_rows and cin >= 16 and operand == "f32" and order is None) \
-            if traced else None
-        if rec is not None:
-            # the roofline trace brackets the conv launch alone: run the unit's three operators one by one for this layer
-            if rec["windowed"]:
-                part = torch.empty((self.lib.vc_conv_stats_partial_floats(x.shape[0], n_out, cin, cout, kv, flags),),
-                                   dtype=torch.float32, device=dev)
-                check(self.lib.vc_conv_forward_epilogue(_ptr(x), x.shape[0], _ptr(tbl), n_out, kv, _ptr(weight), cin, cout,
-                                                        None, 1, flags, _ptr(part), None, None, None, None, 0.0, 0,
-                                                        _ptr(y_raw), _stream()), "vc_conv_forward_epilogue")
-                self._trace_close(rec)
-                check(self.lib.vc_bn_stats_from_partial(_ptr(part), part.numel() // (2 * cout), n_out, cout, _ptr(stats[0]),
-                                                        _ptr(stats[1]), _ptr(running_mean), _ptr(running_var), _ptr(nbt),
-                                                        float(momentum), _ptr(ws), ws_bytes, _stream()), "vc_bn_stats_from_partial")
-            else:
-                check(self.lib.vc_conv_forward(_ptr(x), x.shape[0], _ptr(tbl), n_out, kv, _ptr(weight), cin, cout, _ptr(order),
-                                               OPERAND_TYPES[operand], flags, _ptr(y_raw), _stream()), "vc_conv_forward")
-                self._trace_close(rec)
-                check(self.lib.vc_bn_stats(_ptr(y_raw), n_out, cout, _ptr(stats[0]), _ptr(stats[1]), _ptr(running_mean),
-                                           _ptr(running_var), _ptr(nbt), float(momentum), _ptr(ws), ws_bytes, _stream()),
-                      "vc_bn_stats")
-            check(self.lib.vc_bn_apply_relu(_ptr(y_raw), n_out, cout, _ptr(stats[0]), _ptr(stats[1]), _ptr(gamma), _ptr(beta),
-                                            float(eps), 1 if relu else 0, _ptr(y), cout, 0, _stream()), "vc_bn_apply_relu")
-            return y, y_raw, stats[0], stats[1]
         check(self.lib.vc_post_act_block_forward(_ptr(x), x.shape[0], _ptr(tbl), n_out, kv, _ptr(weight), cin, cout,
                                                  _ptr(order), OPERAND_TYPES[operand], flags, _ptr(gamma), _ptr(beta),
                                                  _ptr(running_mean), _ptr(running_var), _ptr(nbt), float(momentum),

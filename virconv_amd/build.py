@@ -27,6 +27,7 @@ SOURCES = {
     "pool_kernels.hip": ["-ffp-contract=off"],
     "frontend_kernels.hip": ["-ffp-contract=off"],
     "unit.hip": [],
+    "pass.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 

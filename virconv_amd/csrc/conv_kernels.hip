@@ -9,6 +9,8 @@
 //   (64 contiguous bytes per gathered row across the 4 q-lanes) and feeds element j to MFMA step j; the weight
 //   fragment is permuted identically, so the K order inside a chunk is (j, q) -- a fixed order, results are
 //   run-to-run bit-stable.  fp32 MFMA is exact fp32 (bitwise an fmaf chain), so the 1e-4 parity bound holds.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace vc {
@@ -242,8 +244,8 @@ struct ConvEpilogue {
   int relu;
 };
 
-template <int CK, int CN, bool BWD, int RT, int OT, int EPI>
-__global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __restrict__ src,
+template <int CK, int CN, bool BWD, int RT, int OT, int EPI, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) gather_gemm_v2_kernel(const float* __restrict__ src,
                                                              const float* __restrict__ src_centre, int64_t n_src,
                                                              const int32_t* __restrict__ tbl,
                                                              const float* __restrict__ w, float* __restrict__ out,
@@ -254,11 +256,14 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
   constexpr int V = (CK >= 16) ? 4 : CK / 4;
   constexpr int NCH = CK / (4 * V);
   constexpr int NT = (CN + 15) / 16;
-  constexpr int TM = 64 * RT;                            // output rows per block: 4 waves x RT tiles of 16
+  // NW waves per block (4, or 8: the W_k image and its barrier are shared by twice the rows -- half the LDS per wave, which
+  // is what limits the occupancy of the 64-channel instantiations: 23.6 KB per 4-wave block = 6 waves per SIMD)
+  constexpr int NTHR = 64 * NW;
+  constexpr int TM = 16 * NW * RT;                       // output rows per block: NW waves x RT tiles of 16
   constexpr int NFRAG = NCH * NT * 64;                   // fragment vectors (V floats each) of one W_k image
   constexpr int BF = NFRAG * V;
   constexpr int BBYTES = BF * (OT == VC_OPERAND_F32 ? 4 : 2);  // one W_k image in LDS (fp32, or 16-bit operands)
-  constexpr int BLD = (NFRAG + 255) / 256;               // fragment vectors staged per thread
+  constexpr int BLD = (NFRAG + NTHR - 1) / NTHR;               // fragment vectors staged per thread
   static_assert(OT == VC_OPERAND_F32 || V == 4, "16-bit MFMA operands need >= 16 source channels");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* s_b = smem;                             // [2][BBYTES]
@@ -295,7 +300,7 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
     const int64_t row = inb ? (order ? (int64_t)order[brow0 + r] : brow0 + r) : -1;
     if (tid < TM) s_row[r] = (int)row;
     const bool centre_only = (rep != nullptr) && inb && (rep[row] != (int32_t)row);
-    for (int k = tid / TM; k < kv; k += 256 / TM) {
+    for (int k = tid / TM; k < kv; k += NTHR / TM) {
       int v = inb ? tbl[(int64_t)k * n_out + row] : -1;
       if (centre_only && k != centre) v = -1;
       s_idx[k * TM + r] = v;
@@ -319,8 +324,8 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
   do {                                                                                             \
     const int kw_ = mirror ? (kv - 1 - (K)) : (K);                                                 \
     _Pragma("unroll") for (int u = 0; u < BLD; ++u) {                                              \
-      const int f = tid + u * 256;                                                                 \
-      if (NFRAG % 256 == 0 || f < NFRAG) {                                                         \
+      const int f = tid + u * NTHR;                                                                \
+      if (NFRAG % NTHR == 0 || f < NFRAG) {                                                         \
         const int fl = f & 63, nt_ = (f >> 6) % NT, ch_ = (f >> 6) / NT;                           \
         const int n_ = nt_ * 16 + (fl & 15), kk0 = ch_ * 4 * V + (fl >> 4) * V;                    \
         if (CN % 16 == 0 || n_ < CN) {                                                             \
@@ -340,8 +345,8 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
 #define VC_STORE_B(BUF)                                                                            \
   do {                                                                                             \
     _Pragma("unroll") for (int u = 0; u < BLD; ++u) {                                              \
-      const int f = tid + u * 256;                                                                 \
-      if (NFRAG % 256 == 0 || f < NFRAG) {                                                         \
+      const int f = tid + u * NTHR;                                                                \
+      if (NFRAG % NTHR == 0 || f < NFRAG) {                                                         \
         if constexpr (OT == VC_OPERAND_F32) {                                                      \
           float* d_ = reinterpret_cast<float*>(s_b + (BUF) * BBYTES) + f * V;                      \
           _Pragma("unroll") for (int j = 0; j < V; ++j) d_[j] = breg[u][j];                        \
@@ -448,7 +453,7 @@ __global__ void __launch_bounds__(256) gather_gemm_v2_kernel(const float* __rest
     // per-WAVE partial sums (the wave's 16 rows): rows beyond n_out gathered nothing, their accumulators are exact zeros; fixed
     // order (4 accumulator rows, then the q lanes), no LDS and no barrier -- the block-level reduce this replaces cost two
     // barriers per block and made the fused statistics slower than the pass over y they save (round 1)
-    float* prow = epi.partial + ((lbid * 4 + wave) * 2) * CN;
+    float* prow = epi.partial + ((lbid * NW + wave) * 2) * CN;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       float sm = ((acc[0][nt][0] + acc[0][nt][1]) + acc[0][nt][2]) + acc[0][nt][3];
@@ -1238,11 +1243,62 @@ __global__ void __launch_bounds__(256) group_sum_convert_kernel(long long* __res
   grp[e] = (float)((double)a * ldexp(1.0, ex - 40));
 }
 
+// --------------------------------------------------------------------------------------------- kernel timing (vc_trace_*)
+__global__ void __launch_bounds__(256) count_pairs_kernel(const int32_t* __restrict__ tbl, int64_t total, int64_t* __restrict__ out) {
+  int64_t c = 0;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) c += tbl[e] >= 0 ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd((unsigned long long*)out, (unsigned long long)c);
+}
+
+struct TraceState {
+  bool on = false;
+  int dir = 0, ck = 0, cn = 0, cap = 0, n = 0;
+  int64_t* dev_pairs = nullptr;
+  hipEvent_t* ev = nullptr;  // 2 per record, created on first use, kept for the life of the process
+  int n_ev = 0;
+  vc_trace_record* rec = nullptr;
+};
+static TraceState g_trace;
+static bool g_last_windowed = false;  // set by launch_gg: the launch just issued was the LDS row-window kernel
+
+// -> record slot (its start event is on the stream) or -1
+static inline int trace_open(int dir, int ck, int cn, hipStream_t st) {
+  TraceState& T = g_trace;
+  if (!T.on || T.dir != dir || T.ck != ck || T.cn != cn || T.n >= T.cap) return -1;
+  const int i = T.n;
+  if (hipEventRecord(T.ev[2 * i], st) != hipSuccess) return -1;
+  return i;
+}
+static inline void trace_close(int i, const int32_t* tbl, int kv, int64_t n_src, int64_t n_out, hipStream_t st) {
+  TraceState& T = g_trace;
+  if (hipEventRecord(T.ev[2 * i + 1], st) != hipSuccess) return;
+  T.rec[i] = vc_trace_record{0.f, kv, T.ck, T.cn, g_last_windowed ? 1 : 0, n_src, n_out, 0};
+  int64_t nb = cdiv((int64_t)kv * n_out, 256 * 8);
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(count_pairs_kernel, dim3((unsigned)nb), dim3(256), 0, st, tbl, (int64_t)kv * n_out, T.dev_pairs + i);
+  (void)hipGetLastError();
+  T.n = i + 1;
+}
+
 // --------------------------------------------------------------------------------------------- dispatch
 static constexpr int kRT = 2;  // 32 rows per wave, 128 rows per 256-thread block
 int g_conv_variant = 2;        // 1 = gather_gemm_kernel (per-wave loads), 2 = gather_gemm_v2_kernel (LDS-staged, pipelined)
 int g_conv_rt = 0;             // v2 row tiles per wave: 1 (64 rows/block) | 2 (128 rows/block) | 0 = heuristic
 
+// Waves per block of the direct kernel where both channel counts are >= 16 (vc_debug_set conv_nw): 4 | 8 | 0 = per shape.
+// Measured on the VirConv-L layers (gpurun r2m, tools/kbench.py --nw): 8-wave blocks lift the LDS-bound occupancy of the
+// 64-channel instantiations from 6 to 8 waves per SIMD, yet only <CK=32, CN=64, backward-input> gets faster (235 -> 202 us,
+// 103 -> 96 us); the forward kernels tie (1207 vs 1210 us per pass) and the strided backward tables lose 5-7 %.
+int g_conv_nw = 0;
+static inline int conv_block_waves(int ck, int cn, bool bwd) {
+  if (ck < 16 || cn < 16) return 4;
+  if (g_conv_nw == 8) return 8;
+  if (g_conv_nw == 4) return 4;
+  return (bwd && ck == 32 && cn == 64) ? 8 : 4;
+}
 int g_conv_window = 1;         // 0 = never take the LDS-window kernel (A/B measurements)
 int g_conv_wdma = 0;           // 1 = W images through the LDS-DMA engine in the window kernel
 int g_conv_winrows = 32;       // 24 = smaller per-wave windows (one more block per CU at 64 channels)
@@ -1261,8 +1317,9 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
                      float* out, const int32_t* rep, const int32_t* order, int64_t n_out, int kv, int centre, int mirror, int ot,
                        int epi_kind, const ConvEpilogue& epi, int flags, hipStream_t st) {
   const int64_t rows_per_block = 4 * kRT * 16;
+  g_last_windowed = false;
   if constexpr (CK >= 16) {
-    if (use_window_kernel<CK>(flags, ot, rep, order, n_src, kv, src_centre)) {
+    if (conv_block_waves(CK, CN, BWD) == 4 && use_window_kernel<CK>(flags, ot, rep, order, n_src, kv, src_centre)) {
       constexpr int NCH = CK / 16, NT = (CN + 15) / 16;
       // experiment switches (vc_debug_set): conv_wdma = W images through the LDS-DMA engine, conv_winrows = 24-row windows
       const bool wdma = g_conv_wdma && CN % 16 == 0 && epi_kind == VC_EPI_NONE;
@@ -1288,6 +1345,7 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
 #undef VC_L3
 #undef VC_ARGS3
       VC_CHECK_LAUNCH("gather_gemm_v3_kernel");
+      g_last_windowed = true;
       return VC_OK;
     }
   }
@@ -1302,6 +1360,25 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
     // 16-bit operands: only where both channel counts are >= 16 (the 4/8-channel layers are bandwidth-bound and stay fp32)
     const bool half_ops = (ot != VC_OPERAND_F32) && CK >= 16 && CN >= 16;
     const int rt = (g_conv_rt == 2 && !half_ops && epi_kind == VC_EPI_NONE) ? 2 : 1;
+    if constexpr (CK >= 16 && CN >= 16) {
+      if (conv_block_waves(CK, CN, BWD) == 8 && !half_ops && rt == 1 && epi_kind != VC_EPI_AFFINE) {
+        // 8-wave blocks (128 rows): see the kernel's NW parameter
+        const size_t lds8 = (size_t)2 * NCH * NT * 64 * V * sizeof(float) + (size_t)(kv + 1) * 128 * sizeof(int) + 16;
+        const dim3 grid8((unsigned)cdiv(n_out, 128));
+        if constexpr (!BWD) {
+          if (epi_kind == VC_EPI_STATS) {
+            hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, false, 1, VC_OPERAND_F32, VC_EPI_STATS, 8>), grid8, dim3(512), lds8, st,
+                               src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, epi);
+            VC_CHECK_LAUNCH("gather_gemm_v2_kernel<stats, 8 waves>");
+            return VC_OK;
+          }
+        }
+        hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 1, VC_OPERAND_F32, VC_EPI_NONE, 8>), grid8, dim3(512), lds8, st,
+                           src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, epi);
+        VC_CHECK_LAUNCH("gather_gemm_v2_kernel<8 waves>");
+        return VC_OK;
+      }
+    }
     const size_t lds = (size_t)2 * NCH * NT * 64 * V * (half_ops ? 2 : sizeof(float)) +
                        (size_t)(kv + 1) * 64 * rt * sizeof(int) + 16;
     const dim3 grid((unsigned)cdiv(n_out, (int64_t)64 * rt));
@@ -1376,6 +1453,7 @@ static int dispatch_ck(int ck, int cn, const float* src, const float* src_centre
 }
 
 int g_bw_legacy_order = 0;      // debug: 1 = offset-major block order of the weight-gradient kernel
+extern int g_pass_dw_main_tail; // pass.hip
 static constexpr int kMaxSplit = 256;
 static constexpr size_t kMaxPartialBytes = 24u << 20;
 
@@ -1450,14 +1528,55 @@ int vc_debug_set(const char* key, int value) {
   if (key && !strcmp(key, "conv_variant")) { g_conv_variant = value; return VC_OK; }
   if (key && !strcmp(key, "conv_rt")) { g_conv_rt = value; return VC_OK; }
   if (key && !strcmp(key, "conv_window")) { g_conv_window = value; return VC_OK; }
+  if (key && !strcmp(key, "conv_nw")) { g_conv_nw = (value == 8 || value == 4) ? value : 0; return VC_OK; }
   if (key && !strcmp(key, "conv_wdma")) { g_conv_wdma = value; return VC_OK; }
   if (key && !strcmp(key, "conv_winrows")) { g_conv_winrows = value; return VC_OK; }
   if (key && !strcmp(key, "bw_legacy_order")) { g_bw_legacy_order = value; return VC_OK; }
+  if (key && !strcmp(key, "pass_dw_main_tail")) { g_pass_dw_main_tail = value; return VC_OK; }
   if (key && !strcmp(key, "xcd_swizzle_off")) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_swizzle_off), &value, sizeof(int)) == hipSuccess ? VC_OK : VC_EHIP;
   }
   set_error("vc_debug_set: unknown key");
   return VC_EINVAL;
+}
+
+int vc_trace_begin(int direction, int ck, int cn, int max_records, int64_t* dev_pairs) {
+  VC_REQUIRE((direction == 0 || direction == 1) && ck >= 1 && cn >= 1 && max_records >= 1 && dev_pairs,
+             "vc_trace_begin: invalid argument");
+  TraceState& T = g_trace;
+  T.on = false;
+  if (T.n_ev < 2 * max_records) {
+    hipEvent_t* ev = (hipEvent_t*)realloc(T.ev, sizeof(hipEvent_t) * 2 * (size_t)max_records);
+    vc_trace_record* rec = (vc_trace_record*)realloc(T.rec, sizeof(vc_trace_record) * (size_t)max_records);
+    if (!ev || !rec) { set_error("vc_trace_begin: out of host memory"); return VC_EINVAL; }
+    T.ev = ev;
+    T.rec = rec;
+    for (; T.n_ev < 2 * max_records; ++T.n_ev) VC_CHECK_HIP(hipEventCreate(&T.ev[T.n_ev]));
+  }
+  VC_CHECK_HIP(hipDeviceSynchronize());
+  VC_CHECK_HIP(hipMemset(dev_pairs, 0, sizeof(int64_t) * (size_t)max_records));
+  T.dir = direction; T.ck = ck; T.cn = cn; T.cap = max_records; T.n = 0; T.dev_pairs = dev_pairs;
+  T.on = true;
+  return VC_OK;
+}
+
+int vc_trace_end(vc_trace_record* out, int capacity, int* n_records) {
+  TraceState& T = g_trace;
+  VC_REQUIRE(n_records && (out || capacity == 0), "vc_trace_end: null argument");
+  *n_records = 0;
+  if (!T.on) return VC_OK;
+  T.on = false;
+  VC_CHECK_HIP(hipDeviceSynchronize());
+  const int n = T.n < capacity ? T.n : capacity;
+  for (int i = 0; i < n; ++i) {
+    float ms = 0.f;
+    VC_CHECK_HIP(hipEventElapsedTime(&ms, T.ev[2 * i], T.ev[2 * i + 1]));
+    out[i] = T.rec[i];
+    out[i].ms = ms;
+    VC_CHECK_HIP(hipMemcpy(&out[i].pairs, T.dev_pairs + i, sizeof(int64_t), hipMemcpyDeviceToHost));
+  }
+  *n_records = n;
+  return VC_OK;
 }
 
 int vc_conv_forward(const float* x, int64_t n_in, const int32_t* pair_fwd, int64_t n_out, int kv, const float* weight,
@@ -1466,8 +1585,11 @@ int vc_conv_forward(const float* x, int64_t n_in, const int32_t* pair_fwd, int64
   if (n_out == 0) return VC_OK;
   VC_REQUIRE(pair_fwd && y && (x || n_in == 0), "vc_conv_forward: null argument");
   VC_REQUIRE(operand_type >= VC_OPERAND_F32 && operand_type <= VC_OPERAND_BF16, "vc_conv_forward: unknown operand_type");
-  return dispatch_ck<false>(cin, cout, x, nullptr, n_in, pair_fwd, weight, y, nullptr, row_order, n_out, kv, -1, 0,
-                            operand_type, VC_EPI_NONE, ConvEpilogue{}, flags, (hipStream_t)stream);
+  const int tr = trace_open(0, cin, cout, (hipStream_t)stream);
+  const int rc = dispatch_ck<false>(cin, cout, x, nullptr, n_in, pair_fwd, weight, y, nullptr, row_order, n_out, kv, -1, 0,
+                                    operand_type, VC_EPI_NONE, ConvEpilogue{}, flags, (hipStream_t)stream);
+  if (tr >= 0) trace_close(tr, pair_fwd, kv, n_in, n_out, (hipStream_t)stream);
+  return rc;
 }
 
 int vc_conv_epilogue_supported(int64_t n_in, int cin, int cout, int kv, int operand_type) {
@@ -1476,9 +1598,11 @@ int vc_conv_epilogue_supported(int64_t n_in, int cin, int cout, int kv, int oper
 }
 
 size_t vc_conv_stats_partial_floats(int64_t n_in, int64_t n_out, int cin, int cout, int kv, int flags) {
-  (void)n_in; (void)cin; (void)kv; (void)flags;
+  (void)n_in; (void)kv; (void)flags;
   if (n_out < 0 || cout < 1) return 0;
-  // one partial row (sum, sum of squares per channel) per 16-row wave tile: 4 per 64-row block, direct and window kernel alike
+  // one partial row (sum, sum of squares per channel) per 16-row wave tile: 4 per 64-row block (8 per 128-row block), direct and
+  // window kernel alike
+  if (conv_block_waves(cin, cout, false) == 8) return (size_t)cdiv(n_out, 128) * 8 * 2 * cout;
   return (size_t)cdiv(n_out, 64) * 4 * 2 * cout;
 }
 
@@ -1495,8 +1619,11 @@ int vc_conv_forward_epilogue(const float* x, int64_t n_in, const int32_t* pair_f
   VC_REQUIRE(vc_conv_epilogue_supported(n_in, cin, cout, kv, VC_OPERAND_F32),
              "vc_conv_forward_epilogue: not available for this shape (vc_conv_epilogue_supported)");
   ConvEpilogue e{stats_partial, mean, var, gamma, beta, eps, relu};
-  return dispatch_ck<false>(cin, cout, x, nullptr, n_in, pair_fwd, weight, y, nullptr, row_order, n_out, kv, -1, 0,
-                            VC_OPERAND_F32, epilogue, e, flags, (hipStream_t)stream);
+  const int tr = trace_open(0, cin, cout, (hipStream_t)stream);
+  const int rc = dispatch_ck<false>(cin, cout, x, nullptr, n_in, pair_fwd, weight, y, nullptr, row_order, n_out, kv, -1, 0,
+                                    VC_OPERAND_F32, epilogue, e, flags, (hipStream_t)stream);
+  if (tr >= 0) trace_close(tr, pair_fwd, kv, n_in, n_out, (hipStream_t)stream);
+  return rc;
 }
 
 int vc_conv_backward_input(const float* dy, const float* dy_centre, int64_t n_src, const int32_t* tbl, int64_t n_in,
@@ -1508,8 +1635,11 @@ int vc_conv_backward_input(const float* dy, const float* dy_centre, int64_t n_sr
   VC_REQUIRE(centre >= -1 && centre < kv, "vc_conv_backward_input: centre out of range");
   VC_REQUIRE(operand_type >= VC_OPERAND_F32 && operand_type <= VC_OPERAND_BF16,
              "vc_conv_backward_input: unknown operand_type");
-  return dispatch_ck<true>(cout, cin, dy, dy_centre, n_src, tbl, weight, dx, rep, row_order, n_in, kv, centre,
-                           mirror ? 1 : 0, operand_type, VC_EPI_NONE, ConvEpilogue{}, flags, (hipStream_t)stream);
+  const int tr = trace_open(1, cout, cin, (hipStream_t)stream);
+  const int rc = dispatch_ck<true>(cout, cin, dy, dy_centre, n_src, tbl, weight, dx, rep, row_order, n_in, kv, centre,
+                                   mirror ? 1 : 0, operand_type, VC_EPI_NONE, ConvEpilogue{}, flags, (hipStream_t)stream);
+  if (tr >= 0) trace_close(tr, tbl, kv, n_src, n_in, (hipStream_t)stream);
+  return rc;
 }
 
 size_t vc_conv_backward_weight_workspace_bytes(int64_t n_out, int kv, int cin, int cout) {

@@ -1,0 +1,419 @@
+// Feature pass executor: the conv/BN/ReLU/concat/discard chain of a whole backbone forward in ONE C-ABI call, and its
+// reverse-mode sweep in ONE call (include/virconv_hip.h, "feature pass").  Reference path: VirConvL8x.forward
+// (pcdet/models/backbones_3d/spconv_backbone.py:609-699) -> NRConvBlock.forward (:207-229) -> post_act_block units (:86-131) and
+// layer_voxel_discard (:134-147); its backward is what torch's autograd engine does over spconv's Functions
+// (tools/train_utils/train_utils.py:47).  No new arithmetic: every launch goes through the operator entry points of this
+// library, in the same order as the node-by-node path, so results are bit-identical.  What this file owns is the HOST side of
+// a step: buffer layout in one arena per direction, the gradient bookkeeping of the reverse sweep, and the side-stream
+// schedule of the weight gradients.
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+namespace vc {
+
+static inline size_t al256p(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// dst[:, col0 : col0 + 4*c4] = src   (src dense (n, 4*c4); dst row stride ds floats)
+__global__ void __launch_bounds__(256) copy_cols_kernel(const float4* __restrict__ src, int64_t n, int c4, float* __restrict__ dst,
+                                                        int ds, int col0) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n * c4) return;
+  const int64_t r = (e < (1LL << 31)) ? (int64_t)((uint32_t)e / (uint32_t)c4) : e / c4;
+  const int j = (int)(e - r * c4);
+  *reinterpret_cast<float4*>(dst + r * ds + col0 + 4 * j) = src[e];
+}
+
+// out (dense n x 4*c4) = a[:, ac : ac + c] (+ b[:, bc : bc + c])    -- the sum of two gradient contributions of a buffer
+__global__ void __launch_bounds__(256) add_views_kernel(float4* out, int64_t n, int c4, const float* a, int as, int ac,
+                                                        const float* b, int bs, int bc) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n * c4) return;
+  const int64_t r = (e < (1LL << 31)) ? (int64_t)((uint32_t)e / (uint32_t)c4) : e / c4;
+  const int j = (int)(e - r * c4);
+  float4 v = *reinterpret_cast<const float4*>(a + r * as + ac + 4 * j);
+  if (b != nullptr) {
+    const float4 w = *reinterpret_cast<const float4*>(b + r * bs + bc + 4 * j);
+    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+  }
+  out[e] = v;
+}
+
+struct Bump {
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    const size_t o = off;
+    off += al256p(bytes);
+    return o;
+  }
+};
+
+static int check_program(const vc_pass_program* p) {
+  VC_REQUIRE(p && p->ops && p->bufs && p->units && p->tables && p->n_ops >= 1 && p->n_bufs >= 1, "vc_pass: null program field");
+  VC_REQUIRE(p->operand_type >= VC_OPERAND_F32 && p->operand_type <= VC_OPERAND_BF16, "vc_pass: unknown operand_type");
+  for (int b = 0; b < p->n_bufs; ++b) {
+    const vc_pass_buf& B = p->bufs[b];
+    VC_REQUIRE(B.rows >= 1 && B.cols >= 4 && B.cols % 4 == 0, "vc_pass: buffer %d has invalid shape (%lld x %d)", b, (long long)B.rows, B.cols);
+    VC_REQUIRE(!B.external || B.ptr, "vc_pass: external buffer %d without memory", b);
+  }
+  for (int i = 0; i < p->n_ops; ++i) {
+    const vc_pass_op& o = p->ops[i];
+    VC_REQUIRE(o.src >= 0 && o.src < p->n_bufs && o.dst >= 0 && o.dst < p->n_bufs && o.src != o.dst, "vc_pass: op %d: bad buffer id", i);
+    VC_REQUIRE(!p->bufs[o.dst].external, "vc_pass: op %d writes an external buffer", i);
+    const vc_pass_buf &S = p->bufs[o.src], &D = p->bufs[o.dst];
+    VC_REQUIRE(o.dst_col0 >= 0 && o.dst_col0 % 4 == 0, "vc_pass: op %d: dst_col0 must be a non-negative multiple of 4", i);
+    if (o.kind == VC_PASS_UNIT) {
+      VC_REQUIRE(o.unit >= 0 && o.unit < p->n_units && o.table >= 0 && o.table < p->n_tables, "vc_pass: op %d: bad unit/table id", i);
+      const vc_pass_unit& u = p->units[o.unit];
+      const vc_pass_table& t = p->tables[o.table];
+      VC_REQUIRE(u.weight && u.gamma && u.beta && u.running_mean && u.running_var, "vc_pass: unit %d: null parameter", o.unit);
+      VC_REQUIRE(t.pair_fwd && t.kv >= 1 && (t.subm || t.pair_bwd), "vc_pass: table %d: null pair table", o.table);
+      VC_REQUIRE(S.cols == u.cin && S.rows == t.n_in && D.rows == t.n_out && o.dst_col0 + u.cout <= D.cols,
+                 "vc_pass: op %d: unit/table/buffer shapes disagree (src %lld x %d, dst %lld x %d, table %lld -> %lld, %d -> %d channels)",
+                 i, (long long)S.rows, S.cols, (long long)D.rows, D.cols, (long long)t.n_in, (long long)t.n_out, u.cin, u.cout);
+      VC_REQUIRE(!t.subm || t.n_in == t.n_out, "vc_pass: table %d: submanifold table with n_in != n_out", o.table);
+    } else if (o.kind == VC_PASS_COPY) {
+      VC_REQUIRE(S.rows == D.rows && o.dst_col0 + S.cols <= D.cols, "vc_pass: op %d: copy shapes disagree", i);
+    } else if (o.kind == VC_PASS_GATHER) {
+      VC_REQUIRE(p->keeps && o.keep >= 0 && o.keep < p->n_keeps && p->keeps[o.keep], "vc_pass: op %d: bad keep id", i);
+      VC_REQUIRE(S.cols == D.cols && o.dst_col0 == 0 && D.rows <= S.rows, "vc_pass: op %d: gather shapes disagree", i);
+    } else {
+      set_error("vc_pass: op %d: unknown kind %d", i, o.kind);
+      return VC_EINVAL;
+    }
+  }
+  return VC_OK;
+}
+
+struct FwdLayout {
+  std::vector<int64_t> buf_off;            // arena offset of every buffer (-1: external)
+  std::vector<size_t> yraw_off, stats_off;  // per op (units, training only)
+  size_t scratch_off = 0, scratch_bytes = 0, total = 0;
+};
+
+static void fwd_layout(const vc_pass_program* p, FwdLayout& L) {
+  Bump bump;
+  L.buf_off.assign(p->n_bufs, -1);
+  for (int b = 0; b < p->n_bufs; ++b)
+    if (!p->bufs[b].external) L.buf_off[b] = (int64_t)bump.take((size_t)p->bufs[b].rows * p->bufs[b].cols * sizeof(float));
+  L.yraw_off.assign(p->n_ops, 0);
+  L.stats_off.assign(p->n_ops, 0);
+  size_t scratch = 256;
+  for (int i = 0; i < p->n_ops; ++i) {
+    const vc_pass_op& o = p->ops[i];
+    if (o.kind != VC_PASS_UNIT) continue;
+    const vc_pass_unit& u = p->units[o.unit];
+    const vc_pass_table& t = p->tables[o.table];
+    const int flags = t.sorted_rows ? VC_CONV_SORTED_ROWS : 0;
+    if (p->training) {
+      L.yraw_off[i] = bump.take((size_t)t.n_out * u.cout * sizeof(float));
+      L.stats_off[i] = bump.take((size_t)2 * u.cout * sizeof(float));
+      const size_t w = vc_post_act_block_forward_workspace_bytes(t.n_in, t.n_out, t.kv, u.cin, u.cout, flags);
+      if (w > scratch) scratch = w;
+    } else {
+      const size_t w = (size_t)t.n_out * u.cout * sizeof(float);  // y_raw of a unit the affine epilogue cannot serve
+      if (w > scratch) scratch = w;
+    }
+  }
+  L.scratch_off = bump.take(scratch);
+  L.scratch_bytes = scratch;
+  L.total = bump.off;
+}
+
+static inline float* buf_ptr(const vc_pass_program* p, const FwdLayout& L, const void* arena, int b) {
+  return p->bufs[b].external ? (float*)p->bufs[b].ptr : (float*)((char*)arena + L.buf_off[b]);
+}
+
+static hipEvent_t* pass_events() {
+  static thread_local hipEvent_t ev[2] = {nullptr, nullptr};
+  if (ev[0] == nullptr) {
+    if (hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess) {
+      ev[0] = ev[1] = nullptr;
+      return nullptr;
+    }
+  }
+  return ev;
+}
+
+static int launch_add_views(float* out, int64_t n, int c, const float* a, int as, int ac, const float* b, int bs, int bc,
+                            hipStream_t st) {
+  const int c4 = c / 4;
+  hipLaunchKernelGGL(add_views_kernel, dim3((unsigned)cdiv(n * c4, 256)), dim3(256), 0, st, (float4*)out, n, c4, a, as, ac, b,
+                     bs, bc);
+  VC_CHECK_LAUNCH("add_views_kernel");
+  return VC_OK;
+}
+
+// scheduling knob (vc_debug_set "pass_dw_main_tail"): the weight gradients of the LAST k units of the reverse sweep run on the
+// main stream after their backward-input conv instead of on the side stream.  The side stream's weight gradients trail the
+// main chain (they can only start after each unit's BatchNorm backward), so at the end of the sweep the main stream idles in
+// the join; moving the tail's weight gradients over fills that hole.
+int g_pass_dw_main_tail = 0;
+
+struct GradView {
+  const float* p;
+  int stride, col0;
+};
+
+// the reverse sweep; dry = only size the arena (no launches, no dereference)
+static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const float* const* ext_grads, float* input_grad,
+                          bool want_input_grad, void* group_acc, size_t group_acc_bytes, char* arena, size_t arena_bytes,
+                          hipStream_t side, hipStream_t st, bool dry, size_t* need_bytes) {
+  FwdLayout L;
+  fwd_layout(p, L);
+  Bump bump;
+  // shared scratch: BatchNorm partial sums (main stream), group-summed d_raw (main stream), weight-gradient partials (all weight
+  // gradients run in order on ONE stream, the side stream when there is one)
+  size_t bn_bytes = 256, grp_bytes = 256, dw_bytes = 256;
+  for (int i = 0; i < p->n_ops; ++i) {
+    const vc_pass_op& o = p->ops[i];
+    if (o.kind != VC_PASS_UNIT) continue;
+    const vc_pass_unit& u = p->units[o.unit];
+    const vc_pass_table& t = p->tables[o.table];
+    bn_bytes = std::max(bn_bytes, vc_bn_workspace_bytes(t.n_out, u.cout));
+    dw_bytes = std::max(dw_bytes, vc_conv_backward_weight_workspace_bytes(t.n_out, t.kv, u.cin, u.cout));
+    if (t.rep) grp_bytes = std::max(grp_bytes, (size_t)t.n_out * u.cout * sizeof(float));
+  }
+  const size_t bn_off = bump.take(bn_bytes), grp_off = bump.take(grp_bytes), dw_off = bump.take(dw_bytes),
+               dw2_off = bump.take(dw_bytes);
+  auto at = [&](size_t off) -> float* { return dry ? nullptr : (float*)(arena + off); };
+
+  std::vector<std::vector<GradView>> contrib(p->n_bufs);
+  std::vector<int> state(p->n_bufs, 0);  // 0 unresolved, 1 resolved to `res`, 2 no gradient reaches the buffer
+  std::vector<GradView> res(p->n_bufs);
+  const float* marker = (const float*)(uintptr_t)256;  // dry run: any non-null stand-in for "a contribution exists"
+  for (int b = 0; b < p->n_bufs; ++b)
+    if (ext_grads && ext_grads[b]) contrib[b].push_back({ext_grads[b], p->bufs[b].cols, 0});
+
+  auto resolve = [&](int b) -> int {
+    if (state[b]) return VC_OK;
+    auto& c = contrib[b];
+    if (c.empty()) { state[b] = 2; return VC_OK; }
+    if (c.size() == 1) { res[b] = c[0]; state[b] = 1; return VC_OK; }
+    const vc_pass_buf& B = p->bufs[b];
+    float* out = at(bump.take((size_t)B.rows * B.cols * sizeof(float)));
+    if (!dry) {
+      int rc = launch_add_views(out, B.rows, B.cols, c[0].p, c[0].stride, c[0].col0, c[1].p, c[1].stride, c[1].col0, st);
+      if (rc != VC_OK) return rc;
+      for (size_t k = 2; k < c.size(); ++k) {
+        rc = launch_add_views(out, B.rows, B.cols, out, B.cols, 0, c[k].p, c[k].stride, c[k].col0, st);
+        if (rc != VC_OK) return rc;
+      }
+    }
+    res[b] = {dry ? marker : out, B.cols, 0};
+    state[b] = 1;
+    return VC_OK;
+  };
+  auto wants_grad = [&](int b) { return !p->bufs[b].external || (b == 0 && want_input_grad); };
+
+  hipEvent_t* ev = (side != nullptr && !dry) ? pass_events() : nullptr;
+  bool forked = false;
+  int n_units_left = 0;  // units still ahead in the reverse sweep (for the main-tail schedule)
+  for (int i = 0; i < p->n_ops; ++i) n_units_left += p->ops[i].kind == VC_PASS_UNIT ? 1 : 0;
+
+  for (int i = p->n_ops - 1; i >= 0; --i) {
+    const vc_pass_op& o = p->ops[i];
+    int rc = resolve(o.dst);
+    if (rc != VC_OK) return rc;
+    const vc_pass_buf &S = p->bufs[o.src], &D = p->bufs[o.dst];
+    if (o.kind == VC_PASS_UNIT) {
+      const vc_pass_unit& u = p->units[o.unit];
+      const vc_pass_table& t = p->tables[o.table];
+      const size_t wbytes = (size_t)t.kv * u.cin * u.cout * sizeof(float);
+      const int units_left = n_units_left--;  // including this one
+      if (state[o.dst] == 2) {  // no gradient reaches this unit: its parameters get exact zeros
+        if (!dry) {
+          if (u.dweight) VC_CHECK_HIP(hipMemsetAsync(u.dweight, 0, wbytes, st));
+          if (u.dgamma) VC_CHECK_HIP(hipMemsetAsync(u.dgamma, 0, (size_t)u.cout * sizeof(float), st));
+          if (u.dbeta) VC_CHECK_HIP(hipMemsetAsync(u.dbeta, 0, (size_t)u.cout * sizeof(float), st));
+        }
+        continue;
+      }
+      const bool need_dx = wants_grad(o.src), need_dw = u.dweight != nullptr;
+      const bool dup = t.rep != nullptr && need_dx;
+      const bool on_side = ev != nullptr && units_left > g_pass_dw_main_tail;
+      float* d_raw = at(bump.take((size_t)t.n_out * u.cout * sizeof(float)));
+      float* dx = need_dx ? at(bump.take((size_t)t.n_in * u.cin * sizeof(float))) : nullptr;
+      float* dgb = (u.dgamma && u.dbeta) ? nullptr : at(bump.take((size_t)2 * u.cout * sizeof(float)));
+      if (need_dx) contrib[o.src].push_back({dry ? marker : dx, u.cin, 0});
+      if (dry) continue;
+      const GradView g = res[o.dst];
+      const float* x = buf_ptr(p, L, fwd_arena, o.src);
+      const float* y_raw = (const float*)((const char*)fwd_arena + L.yraw_off[i]);
+      const float* mean = (const float*)((const char*)fwd_arena + L.stats_off[i]);
+      const float* var = mean + u.cout;
+      if (dup) {
+        VC_REQUIRE(group_acc && group_acc_bytes >= vc_group_sum_workspace_bytes(t.n_out, u.cout) && (u.cout & (u.cout - 1)) == 0,
+                   "vc_pass_backward: duplicate-pixel table needs the persistent group-sum accumulator");
+      }
+      rc = vc_bn_relu_backward(y_raw, g.p, g.stride, g.col0 + o.dst_col0, t.n_out, u.cout, mean, var, u.gamma, u.beta, u.eps,
+                               o.relu, d_raw, u.dgamma ? u.dgamma : dgb, u.dbeta ? u.dbeta : dgb + u.cout,
+                               dup ? (unsigned*)group_acc : nullptr, arena + bn_off, bn_bytes, st);
+      if (rc != VC_OK) return rc;
+      if (need_dw && on_side) {  // fork: the weight gradient only reads x (forward arena) and d_raw (never rewritten in this call)
+        VC_CHECK_HIP(hipEventRecord(ev[0], st));
+        VC_CHECK_HIP(hipStreamWaitEvent(side, ev[0], 0));
+        forked = true;
+        rc = vc_conv_backward_weight(x, d_raw, t.pair_fwd, t.n_out, t.kv, u.cin, u.cout, p->operand_type, u.dweight,
+                                     arena + dw_off, dw_bytes, side);
+        if (rc != VC_OK) return rc;
+      }
+      if (need_dx) {
+        const float* src = d_raw;
+        const float* src_centre = nullptr;
+        if (dup) {
+          rc = vc_group_sum(d_raw, t.rep, t.n_out, u.cout, (float*)(arena + grp_off), group_acc, group_acc_bytes, 2, st);
+          if (rc != VC_OK) return rc;
+          src = (const float*)(arena + grp_off);
+          src_centre = d_raw;
+        }
+        const int flags = (t.sorted_rows && t.subm) ? VC_CONV_SORTED_ROWS : 0;
+        rc = vc_conv_backward_input(src, src_centre, t.n_out, t.subm ? t.pair_fwd : t.pair_bwd, t.n_in, t.kv, u.weight, u.cin,
+                                    u.cout, t.subm ? 1 : 0, dup ? t.centre : -1, dup ? t.rep : nullptr, t.order_bwd,
+                                    p->operand_type, flags, dx, st);
+        if (rc != VC_OK) return rc;
+      }
+      if (need_dw && !on_side) {  // main stream: its own partial-sum scratch (the side stream may still be using the shared one)
+        rc = vc_conv_backward_weight(x, d_raw, t.pair_fwd, t.n_out, t.kv, u.cin, u.cout, p->operand_type, u.dweight,
+                                     arena + dw2_off, dw_bytes, st);
+        if (rc != VC_OK) return rc;
+      }
+    } else if (o.kind == VC_PASS_COPY) {
+      if (state[o.dst] == 2 || !wants_grad(o.src)) continue;
+      contrib[o.src].push_back({res[o.dst].p, res[o.dst].stride, res[o.dst].col0 + o.dst_col0});
+    } else {  // VC_PASS_GATHER: scatter the kept rows back, zeros elsewhere
+      if (state[o.dst] == 2 || !wants_grad(o.src)) continue;
+      GradView g = res[o.dst];
+      if (g.stride != D.cols || g.col0 != 0) {
+        float* dense = at(bump.take((size_t)D.rows * D.cols * sizeof(float)));
+        if (!dry) {
+          rc = launch_add_views(dense, D.rows, D.cols, g.p, g.stride, g.col0, nullptr, 0, 0, st);
+          if (rc != VC_OK) return rc;
+        }
+        g = {dry ? marker : dense, D.cols, 0};
+      }
+      float* gs = at(bump.take((size_t)S.rows * S.cols * sizeof(float)));
+      contrib[o.src].push_back({dry ? marker : gs, S.cols, 0});
+      if (dry) continue;
+      rc = vc_scatter_rows(g.p, D.cols, p->keeps[o.keep], D.rows, S.rows, gs, st);
+      if (rc != VC_OK) return rc;
+    }
+  }
+  if (want_input_grad) {
+    int rc = resolve(0);
+    if (rc != VC_OK) return rc;
+    if (!dry) {
+      const vc_pass_buf& B = p->bufs[0];
+      if (state[0] == 2) VC_CHECK_HIP(hipMemsetAsync(input_grad, 0, (size_t)B.rows * B.cols * sizeof(float), st));
+      else {
+        rc = launch_add_views(input_grad, B.rows, B.cols, res[0].p, res[0].stride, res[0].col0, nullptr, 0, 0, st);
+        if (rc != VC_OK) return rc;
+      }
+    }
+  }
+  if (forked) {  // join: every weight gradient is complete before the caller's stream moves on (and may recycle the arenas)
+    VC_CHECK_HIP(hipEventRecord(ev[1], side));
+    VC_CHECK_HIP(hipStreamWaitEvent(st, ev[1], 0));
+  }
+  if (need_bytes) *need_bytes = bump.off;
+  if (!dry && bump.off > arena_bytes) {  // cannot happen when the caller sized the arena with the same arguments
+    set_error("vc_pass_backward: arena too small");
+    return VC_ECAPACITY;
+  }
+  return VC_OK;
+}
+
+}  // namespace vc
+
+using namespace vc;
+
+extern "C" {
+
+size_t vc_pass_forward_arena_bytes(const vc_pass_program* prog) {
+  if (check_program(prog) != VC_OK) return 0;
+  FwdLayout L;
+  fwd_layout(prog, L);
+  return L.total;
+}
+
+int vc_pass_forward(const vc_pass_program* p, void* arena, size_t arena_bytes, int64_t* buf_offsets, void* stream) {
+  int rc = check_program(p);
+  if (rc != VC_OK) return rc;
+  VC_REQUIRE(arena, "vc_pass_forward: null arena");
+  FwdLayout L;
+  fwd_layout(p, L);
+  if (arena_bytes < L.total) { set_error("vc_pass_forward: arena too small"); return VC_ECAPACITY; }
+  hipStream_t st = (hipStream_t)stream;
+  if (buf_offsets)
+    for (int b = 0; b < p->n_bufs; ++b) buf_offsets[b] = L.buf_off[b];
+  char* scratch = (char*)arena + L.scratch_off;
+  for (int i = 0; i < p->n_ops; ++i) {
+    const vc_pass_op& o = p->ops[i];
+    const vc_pass_buf &S = p->bufs[o.src], &D = p->bufs[o.dst];
+    const float* x = buf_ptr(p, L, arena, o.src);
+    float* y = buf_ptr(p, L, arena, o.dst);
+    if (o.kind == VC_PASS_UNIT) {
+      const vc_pass_unit& u = p->units[o.unit];
+      const vc_pass_table& t = p->tables[o.table];
+      const int flags = t.sorted_rows ? VC_CONV_SORTED_ROWS : 0;
+      if (p->training) {
+        float* y_raw = (float*)((char*)arena + L.yraw_off[i]);
+        float* mean = (float*)((char*)arena + L.stats_off[i]);
+        rc = vc_post_act_block_forward(x, t.n_in, t.pair_fwd, t.n_out, t.kv, u.weight, u.cin, u.cout, t.order_fwd,
+                                       p->operand_type, flags, u.gamma, u.beta, u.running_mean, u.running_var,
+                                       u.num_batches_tracked, u.momentum, u.eps, o.relu, y_raw, y, D.cols, o.dst_col0, mean,
+                                       mean + u.cout, scratch, L.scratch_bytes, stream);
+      } else if (D.cols == u.cout && p->operand_type == VC_OPERAND_F32 &&
+                 vc_conv_epilogue_supported(t.n_in, u.cin, u.cout, t.kv, VC_OPERAND_F32)) {
+        rc = vc_conv_forward_epilogue(x, t.n_in, t.pair_fwd, t.n_out, t.kv, u.weight, u.cin, u.cout, t.order_fwd, VC_EPI_AFFINE,
+                                      flags, nullptr, u.running_mean, u.running_var, u.gamma, u.beta, u.eps, o.relu, y, stream);
+      } else {
+        rc = vc_conv_forward(x, t.n_in, t.pair_fwd, t.n_out, t.kv, u.weight, u.cin, u.cout, t.order_fwd, p->operand_type, flags,
+                             (float*)scratch, stream);
+        if (rc != VC_OK) return rc;
+        rc = vc_bn_apply_relu((const float*)scratch, t.n_out, u.cout, u.running_mean, u.running_var, u.gamma, u.beta, u.eps,
+                              o.relu, y, D.cols, o.dst_col0, stream);
+      }
+    } else if (o.kind == VC_PASS_COPY) {
+      hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)cdiv(S.rows * (S.cols / 4), 256)), dim3(256), 0, st, (const float4*)x,
+                         S.rows, S.cols / 4, y, D.cols, o.dst_col0);
+      VC_CHECK_LAUNCH("copy_cols_kernel");
+      rc = VC_OK;
+    } else {
+      rc = vc_gather_rows(x, nullptr, S.cols, 0, p->keeps[o.keep], D.rows, y, nullptr, stream);
+    }
+    if (rc != VC_OK) return rc;
+  }
+  return VC_OK;
+}
+
+size_t vc_pass_backward_arena_bytes(const vc_pass_program* prog, const float* const* ext_grads, int need_input_grad) {
+  if (check_program(prog) != VC_OK || !prog->training) return 0;
+  size_t need = 0;
+  if (backward_sweep(prog, nullptr, ext_grads, nullptr, need_input_grad != 0, nullptr, 0, nullptr, 0, nullptr, nullptr, true,
+                     &need) != VC_OK)
+    return 0;
+  return need;
+}
+
+int vc_pass_backward(const vc_pass_program* p, const void* fwd_arena, size_t fwd_arena_bytes, const float* const* ext_grads,
+                     float* input_grad, void* group_acc, size_t group_acc_bytes, void* arena, size_t arena_bytes,
+                     void* side_stream, void* stream) {
+  int rc = check_program(p);
+  if (rc != VC_OK) return rc;
+  VC_REQUIRE(p->training, "vc_pass_backward: the program ran with running statistics (training = 0): no backward");
+  VC_REQUIRE(fwd_arena && arena && ext_grads, "vc_pass_backward: null argument");
+  FwdLayout L;
+  fwd_layout(p, L);
+  if (fwd_arena_bytes < L.total) { set_error("vc_pass_backward: forward arena smaller than the program's layout"); return VC_ECAPACITY; }
+  size_t need = 0;
+  rc = backward_sweep(p, nullptr, ext_grads, nullptr, input_grad != nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, true, &need);
+  if (rc != VC_OK) return rc;
+  if (arena_bytes < need) { set_error("vc_pass_backward: arena too small"); return VC_ECAPACITY; }
+  return backward_sweep(p, fwd_arena, ext_grads, input_grad, input_grad != nullptr, group_acc, group_acc_bytes, (char*)arena,
+                        arena_bytes, (hipStream_t)side_stream, (hipStream_t)stream, false, nullptr);
+}
+
+}  // extern "C"
