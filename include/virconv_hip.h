@@ -159,7 +159,8 @@ int vc_conv_backward_weight(const float* x, const float* dy, const int32_t* pair
                             void* stream);
 
 /* dy_grp[rep[i], :] = sum over the rows i sharing representative rep[i] of dy[i, :]  (rows that are nobody's
- * representative get 0).  Only used by the duplicate-coordinate SubM backward.  Bit-stable: the sum is carried in
+ * representative are NOT written: vc_conv_backward_input reads dy_grp at representatives only, and 47-81 % of the rows of
+ * the image-space tensors are not representatives).  Only used by the duplicate-coordinate SubM backward.  Bit-stable: the sum is carried in
  * 64-bit fixed point scaled by the tensor's max |dy| (integer adds are associative), then rounded once to fp32.       */
 size_t vc_group_sum_workspace_bytes(int64_t n, int c);
 int vc_group_sum(const float* dy, const int32_t* rep, int64_t n, int c, float* dy_grp, void* ws, size_t ws_bytes,

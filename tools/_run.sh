@@ -1,12 +1,8 @@
-mkdir -p gpurun_out/r2m
-VIRCONV_CONV_NW=8 timeout 600 python -m pytest tests/test_ops_gpu.py -m gpu -x -q -k "conv or subm or strided or post_act or epilogue" > gpurun_out/r2m/tests_nw8.log 2>&1
-tail -n 3 gpurun_out/r2m/tests_nw8.log
-timeout 200 python tools/kbench.py --only fwd --nw 4 > gpurun_out/r2m/kb_fwd_nw4.log 2>&1
-timeout 200 python tools/kbench.py --only fwd --nw 8 > gpurun_out/r2m/kb_fwd_nw8.log 2>&1
-timeout 200 python tools/kbench.py --only bwd --nw 4 > gpurun_out/r2m/kb_bwd_nw4.log 2>&1
-timeout 200 python tools/kbench.py --only bwd --nw 8 > gpurun_out/r2m/kb_bwd_nw8.log 2>&1
-grep -h TOTAL gpurun_out/r2m/kb_*.log
-timeout 200 python bench.py --steps 40 --warmup 10 --no-cpu-baseline 2>&1 | grep ms_per_step | cut -c1-170 > gpurun_out/r2m/bench_nw.txt
-VIRCONV_CONV_NW=8 timeout 200 python bench.py --steps 40 --warmup 10 --no-cpu-baseline 2>&1 | grep ms_per_step | cut -c1-170 >> gpurun_out/r2m/bench_nw.txt
-cat gpurun_out/r2m/bench_nw.txt
+mkdir -p gpurun_out/r2n
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r2n/tests.log 2>&1
+tail -n 4 gpurun_out/r2n/tests.log
+timeout 200 python bench.py --steps 40 --warmup 10 --no-cpu-baseline 2>&1 | grep ms_per_step > gpurun_out/r2n/bench.txt
+timeout 200 python bench.py --steps 40 --warmup 10 --no-cpu-baseline 2>&1 | grep ms_per_step >> gpurun_out/r2n/bench.txt
+cut -c1-170 gpurun_out/r2n/bench.txt
+timeout 100 python tools/step_phases.py > gpurun_out/r2n/phases.txt 2>&1; tail -n 1 gpurun_out/r2n/phases.txt
 echo finished
