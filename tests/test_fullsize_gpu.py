@@ -433,6 +433,8 @@ def test_native_feature_pass_equals_the_node_by_node_path(hip_backend, discard, 
     orig_run = feature_pass.run
     monkeypatch.setattr(feature_pass, "run", lambda *a, **k: (calls.append(1), orig_run(*a, **k))[1])
 
+    monkeypatch.setattr(feature_pass, "NATIVE_PASS_EVAL", True)   # the eval program is not the default (see feature_pass.usable)
+
     def one(native, keeps, training=True, want_input_grad=False):
         monkeypatch.setattr(feature_pass, "NATIVE_PASS", native)
         model.load_state_dict(state)

@@ -1,8 +1,9 @@
-mkdir -p gpurun_out/r2n
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r2n/tests.log 2>&1
-tail -n 4 gpurun_out/r2n/tests.log
-timeout 200 python bench.py --steps 40 --warmup 10 --no-cpu-baseline 2>&1 | grep ms_per_step > gpurun_out/r2n/bench.txt
-timeout 200 python bench.py --steps 40 --warmup 10 --no-cpu-baseline 2>&1 | grep ms_per_step >> gpurun_out/r2n/bench.txt
-cut -c1-170 gpurun_out/r2n/bench.txt
-timeout 100 python tools/step_phases.py > gpurun_out/r2n/phases.txt 2>&1; tail -n 1 gpurun_out/r2n/phases.txt
-echo finished
+mkdir -p gpurun_out/r2o
+python bench.py --mode infer --batch-size 1 2>&1 | grep '"value"' | cut -c1-175 > gpurun_out/r2o/lines.txt
+VIRCONV_NATIVE_PASS=0 python bench.py --mode infer --batch-size 1 2>&1 | grep '"value"' | cut -c1-175 >> gpurun_out/r2o/lines.txt
+python bench.py --mode infer --batch-size 4 2>&1 | grep '"value"' | cut -c1-175 >> gpurun_out/r2o/lines.txt
+python bench.py --model 8x --steps 40 --warmup 12 --no-cpu-baseline 2>&1 | grep '"value"' | cut -c1-175 >> gpurun_out/r2o/lines.txt
+VIRCONV_UNIT_OVERLAP_DW=0 python bench.py --model 8x --steps 40 --warmup 12 --no-cpu-baseline 2>&1 | grep '"value"' | cut -c1-175 >> gpurun_out/r2o/lines.txt
+python bench.py --steps 40 --warmup 12 --no-cpu-baseline 2>&1 | grep '"value"' | cut -c1-175 >> gpurun_out/r2o/lines.txt
+timeout 300 python -m pytest tests/test_fullsize_gpu.py -m gpu -x -q -k "native or determin or eval or rulebook" 2>&1 | tail -n 2 >> gpurun_out/r2o/lines.txt
+cat gpurun_out/r2o/lines.txt

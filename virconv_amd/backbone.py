@@ -137,23 +137,33 @@ class NRConvBlock(nn.Module):
         kd = self.down_layer[0].indice_key if self.stride > 1 else None
         return kd, k3, k2
 
-    def plan(self, indices, spatial_shape, batch_size, calib, stride, trans_param):
+    def begin_down(self, indices, spatial_shape, batch_size):
+        """Start the strided-conv rulebook of this block (None for a stride-1 block); `plan(..., pending=...)` finishes it."""
+        if self.stride <= 1:
+            return None
+        conv = self.down_layer[0]
+        return ops.begin_sparse_rulebook(indices, list(spatial_shape), batch_size, conv.kernel_size, conv.stride, conv.padding,
+                                         conv.dilation)
+
+    def plan(self, indices, spatial_shape, batch_size, calib, stride, trans_param, pending=None, after_down=None):
         """Build every index structure of the block from the input coordinates: the strided-conv rulebook (+ its output
-        coordinates), the shared 3-D SubM rulebook, the pixel coordinates and the shared 2-D SubM rulebook."""
+        coordinates), the shared 3-D SubM rulebook, the pixel coordinates and the shared 2-D SubM rulebook.
+        `pending`: the block's strided rulebook already begun (begin_down).  `after_down(indices, shape)`: called as soon as the
+        block's output coordinates exist -- the chain uses it to begin the NEXT strided rulebook, whose count read then
+        overlaps this block's SubM / projection / 2-D rulebook kernels."""
         kd, k3, k2 = self._keys()
         rbs3, shape = {}, list(spatial_shape)
         if self.stride > 1:
-            conv = self.down_layer[0]
-            rb = ops.build_sparse_rulebook(indices, shape, batch_size, conv.kernel_size, conv.stride, conv.padding,
-                                           conv.dilation)
+            rb = ops.finish_sparse_rulebook(pending if pending is not None else self.begin_down(indices, shape, batch_size))
             rbs3[kd] = rb
             indices, shape = rb.out_indices, list(rb.out_shape)
+        extra = after_down(indices, shape) if after_down is not None else None
         rbs3[k3] = ops.build_subm_rulebook(indices, shape, self.d3_conv1[0].kernel_size, self.d3_conv1[0].dilation, False)
         if trans_param is not None:
             trans_param = torch.as_tensor(trans_param, dtype=torch.float32, device=indices.device).reshape(batch_size, 3)
         uv = ops.project_uv(indices, calib, trans_param, batch_size, stride)
         rb2 = ops.build_subm_rulebook(uv, self.IMAGE_SHAPE, self.d2_conv1[0].kernel_size, self.d2_conv1[0].dilation, True)
-        return {"rb3d": rbs3, "uv": uv, "rb2d": {k2: rb2}, "out_indices": indices, "out_shape": shape}
+        return {"rb3d": rbs3, "uv": uv, "rb2d": {k2: rb2}, "out_indices": indices, "out_shape": shape, "after_down": extra}
 
     @staticmethod
     def _unit_is_plain(seq) -> bool:
@@ -288,19 +298,38 @@ def _draw_keep(rate, n, batch_dict, tag, device):
     return draw_random_keep(n, n_keep, device)
 
 
-def _plan_nrconv_chain(blocks, in_idx, shape, batch_size, calib, trans_param, discard_tags, rate, batch_dict):
-    """Plans of consecutive NRConvBlocks (+ the layer discard after a block when its tag is not None)."""
+def _plan_nrconv_chain(blocks, in_idx, shape, batch_size, calib, trans_param, discard_tags, rate, batch_dict, tail=None):
+    """Plans of consecutive NRConvBlocks (+ the layer discard after a block when its tag is not None).  `tail`: the strided
+    conv that follows the chain (conv_out), or None; its begun rulebook is returned as the fourth value.
+    Every strided rulebook needs ONE number on the host (its output row count).  The chain starts the next strided rulebook
+    as soon as the current block's output coordinates (and its discard) exist and only then issues the current block's SubM /
+    projection / 2-D rulebook kernels, so the count is on the host by the time it is needed."""
     stages = []
-    for (blk, stride), tag in zip(blocks, discard_tags):
-        p = blk.plan(in_idx, shape, batch_size, calib, stride, trans_param)
-        in_idx, shape = p["out_indices"], p["out_shape"]
-        p["keep"] = None
-        if tag is not None:
-            keep = _draw_keep(rate, in_idx.shape[0], batch_dict, tag, in_idx.device)
-            _, in_idx = ops.get_backend().gather_rows(None, in_idx, keep)
-            p["keep"], p["kept_indices"] = keep, in_idx
+    pending = blocks[0][0].begin_down(in_idx, shape, batch_size) if blocks else None
+    for i, ((blk, stride), tag) in enumerate(zip(blocks, discard_tags)):
+        nxt = blocks[i + 1][0] if i + 1 < len(blocks) else None
+
+        def after_down(idx, shp, tag=tag, nxt=nxt, last=(i + 1 == len(blocks))):
+            keep, kept = None, idx
+            if tag is not None:
+                keep = _draw_keep(rate, idx.shape[0], batch_dict, tag, idx.device)
+                _, kept = ops.get_backend().gather_rows(None, idx, keep)
+            if nxt is not None:
+                begun = nxt.begin_down(kept, shp, batch_size)
+            elif last and tail is not None:
+                begun = ops.begin_sparse_rulebook(kept, shp, batch_size, tail.kernel_size, tail.stride, tail.padding, tail.dilation)
+            else:
+                begun = None
+            return keep, kept, begun
+
+        p = blk.plan(in_idx, shape, batch_size, calib, stride, trans_param, pending=pending, after_down=after_down)
+        keep, kept, pending = p.pop("after_down")
+        in_idx, shape = kept, p["out_shape"]
+        p["keep"] = keep
+        if keep is not None:
+            p["kept_indices"] = kept
         stages.append(p)
-    return stages, in_idx, shape
+    return stages, in_idx, shape, pending
 
 
 def _run_nrconv_chain(blocks, stages, x, batch_size, calib, trans_param):
@@ -372,10 +401,10 @@ class VirConvL8x(nn.Module):
         tags = [f"x_conv{bi + 1}{rid}" if (bi < 3 and active) else None for bi in range(4)]
         with _PlanScope(coords, batch_dict) as scope:
             idx = coords.int()
-            stages, in_idx, shape = _plan_nrconv_chain(blocks, idx, list(self.sparse_shape), batch_size, calib, trans_param,
-                                                       tags, self.layer_discard_rate, batch_dict)
             co = self.conv_out[0]
-            rb_out = ops.build_sparse_rulebook(in_idx, shape, batch_size, co.kernel_size, co.stride, co.padding, co.dilation)
+            stages, in_idx, shape, begun = _plan_nrconv_chain(blocks, idx, list(self.sparse_shape), batch_size, calib,
+                                                              trans_param, tags, self.layer_discard_rate, batch_dict, tail=co)
+            rb_out = ops.finish_sparse_rulebook(begun)
             plan = {"in_indices": idx, "stages": stages, "conv_out": {co.indice_key: rb_out}}
         return scope.publish(plan)
 
@@ -604,8 +633,8 @@ class VirConv8x(nn.Module):
                     if "transform_param" in batch_dict:
                         trans_param = batch_dict["transform_param"][:, i, :]
                     tags = [f"mm_x_conv{bi + 1}{rid}" if (bi < 3 and active) else None for bi in range(4)]
-                    stages, _, _ = _plan_nrconv_chain(blocks, idx, list(self.sparse_shape), batch_size, calib, trans_param,
-                                                      tags, self.layer_discard_rate, batch_dict)
+                    stages, _, _, _ = _plan_nrconv_chain(blocks, idx, list(self.sparse_shape), batch_size, calib, trans_param,
+                                                         tags, self.layer_discard_rate, batch_dict)
                     plan["mm"][rid] = {"keep0": keep0, "in_indices": idx, "stages": stages, "trans_param": trans_param}
         return scope.publish(plan)
 

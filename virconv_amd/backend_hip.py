@@ -19,7 +19,11 @@ import ctypes
 import os
 
 # weight gradient of a conv+BN+ReLU unit on a side stream underneath its backward-input conv (fork / join inside the C call)
-UNIT_OVERLAP_DW = os.environ.get("VIRCONV_UNIT_OVERLAP_DW", "1") != "0"   # measured: 6.13-6.14 -> 6.02-6.09 ms/step
+# node-by-node path only (the feature pass has its own weight-gradient stream schedule, see csrc/pass.hip): fork the weight gradient
+# of a unit onto a side stream inside vc_post_act_block_backward.  Measured: VirConv-L bs 4 6.13-6.14 -> 6.02-6.09 ms/step, but
+# VirConv8x bs 2 (small tensors, host-bound) 5.98 -> 6.82 ms/step -- the fork/join pair per unit costs more host time than the
+# overlap returns.  Off by default.
+UNIT_OVERLAP_DW = os.environ.get("VIRCONV_UNIT_OVERLAP_DW", "0") != "0"
 # .dense() / HeightCompression as a write-once fill (vc_to_dense_fill) instead of zero-fill + scatter; "0" = the scatter form
 DENSE_WRITE_ONCE = os.environ.get("VIRCONV_DENSE_WRITE_ONCE", "1") != "0"
 
@@ -64,8 +68,10 @@ class HipBackend:
         return _stream()
 
     @staticmethod
-    def unit_overlap_dw() -> bool:
-        return UNIT_OVERLAP_DW
+    def pass_overlap_dw() -> bool:
+        """Feature pass: weight gradients on the side stream (joined once at the end of the sweep).  Measured on VirConv-L
+        bs 4: backward 3.87-3.98 ms without, 3.27-3.45 ms with (tools/step_phases.py)."""
+        return os.environ.get("VIRCONV_PASS_OVERLAP_DW", "1") != "0"
 
     def trace_begin(self, direction: str, ck: int, cn: int, max_records: int = 4096) -> None:
         """Bracket every launch of the gather-GEMM instantiation <CK, CN, BWD=(direction=='bwd')> with HIP events on its launch
@@ -127,29 +133,55 @@ class HipBackend:
                                         _ptr(pair), _ptr(rep), st), "vc_subm_rulebook")
         return pair, rep
 
-    def sparse_rulebook(self, indices: torch.Tensor, spatial_shape, batch_size: int, ksize, stride, padding, dilation):
-        """-> out_indices (M, ndim+1) int32 ascending, out_shape, pair_fwd (KV, M), pair_bwd (KV, N)."""
+    def sparse_rulebook_begin(self, indices: torch.Tensor, spatial_shape, batch_size: int, ksize, stride, padding, dilation):
+        """First half of a strided-conv rulebook: mark the output cells, count them, start the count's trip to the host.
+        The caller issues whatever other geometry kernels it has before `sparse_rulebook_finish` waits for the count -- the
+        one data-dependent size of a strided conv then costs no idle time on the plan stream."""
         indices = _need(indices, torch.int32, "indices")
         n, ndim = indices.shape[0], indices.shape[1] - 1
         out_shape = conv_out_shape(spatial_shape, ksize, stride, padding, dilation)
-        kv = int(np.prod(ksize))
         dev = indices.device
         oshp = i32arr(out_shape)
         ws_bytes = self.lib.vc_spconv_workspace_bytes(batch_size, ndim, oshp)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
         n_out_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
-        st = _stream()
         ks, sd, pd, dl = i32arr(ksize), i32arr(stride), i32arr(padding), i32arr(dilation)
         check(self.lib.vc_spconv_mark_count(_ptr(indices), n, ndim, batch_size, oshp, ks, sd, pd, dl, _ptr(ws), ws_bytes,
-                                            _ptr(n_out_dev), st), "vc_spconv_mark_count")
-        n_out = self._read_count(n_out_dev)  # the one host sync of a strided conv (data-dependent output size)
+                                            _ptr(n_out_dev), _stream()), "vc_spconv_mark_count")
+        if self._pinned is None:
+            self._pinned = torch.empty((16,), dtype=torch.int32).pin_memory()
+            self._pin_ev = torch.cuda.Event()
+        if getattr(self, "_pin_evs", None) is None:
+            self._pin_evs = [torch.cuda.Event() for _ in range(8)]
+            self._pin_next = 0
+        slot = 1 + self._pin_next % 8      # slot 0 belongs to _read_count
+        self._pin_next += 1
+        self._pinned[slot:slot + 1].copy_(n_out_dev, non_blocking=True)
+        ev = self._pin_evs[slot - 1]
+        ev.record()
+        return {"indices": indices, "n": n, "ndim": ndim, "batch_size": batch_size, "out_shape": out_shape, "oshp": oshp,
+                "geom": (ks, sd, pd, dl), "kv": int(np.prod(ksize)), "ws": ws, "ws_bytes": ws_bytes, "n_out_dev": n_out_dev,
+                "slot": slot, "event": ev}
+
+    def sparse_rulebook_finish(self, h):
+        """-> out_indices (M, ndim+1) int32 ascending, out_shape, pair_fwd (KV, M), pair_bwd (KV, N)."""
+        while not h["event"].query():
+            pass
+        n_out = int(self._pinned[h["slot"]])  # the one host sync of a strided conv (data-dependent output size)
+        indices, n, ndim, dev = h["indices"], h["n"], h["ndim"], h["indices"].device
+        ks, sd, pd, dl = h["geom"]
         out_indices = torch.empty((n_out, ndim + 1), dtype=torch.int32, device=dev)
-        pair_fwd = torch.empty((kv, n_out), dtype=torch.int32, device=dev)
-        pair_bwd = torch.empty((kv, n), dtype=torch.int32, device=dev)
-        check(self.lib.vc_spconv_emit_pairs(_ptr(indices), n, ndim, batch_size, oshp, ks, sd, pd, dl, _ptr(ws), ws_bytes,
-                                            n_out, _ptr(out_indices), _ptr(pair_fwd), _ptr(pair_bwd), st),
+        pair_fwd = torch.empty((h["kv"], n_out), dtype=torch.int32, device=dev)
+        pair_bwd = torch.empty((h["kv"], n), dtype=torch.int32, device=dev)
+        check(self.lib.vc_spconv_emit_pairs(_ptr(indices), n, ndim, h["batch_size"], h["oshp"], ks, sd, pd, dl, _ptr(h["ws"]),
+                                            h["ws_bytes"], n_out, _ptr(out_indices), _ptr(pair_fwd), _ptr(pair_bwd), _stream()),
               "vc_spconv_emit_pairs")
-        return out_indices, out_shape, pair_fwd, pair_bwd
+        return out_indices, h["out_shape"], pair_fwd, pair_bwd
+
+    def sparse_rulebook(self, indices: torch.Tensor, spatial_shape, batch_size: int, ksize, stride, padding, dilation):
+        """-> out_indices (M, ndim+1) int32 ascending, out_shape, pair_fwd (KV, M), pair_bwd (KV, N)."""
+        return self.sparse_rulebook_finish(self.sparse_rulebook_begin(indices, spatial_shape, batch_size, ksize, stride, padding,
+                                                                      dilation))
 
     # ------------------------------------------------------------------ convolution
     def row_order(self, tbl: torch.Tensor, rep: Optional[torch.Tensor] = None, centre: int = -1,

@@ -25,6 +25,7 @@ import torch
 from . import _lib, ops
 
 NATIVE_PASS = os.environ.get("VIRCONV_NATIVE_PASS", "1") != "0"
+NATIVE_PASS_EVAL = os.environ.get("VIRCONV_NATIVE_PASS_EVAL", "0") != "0"
 _CHANNELS = (4, 8, 16, 32, 64)
 
 
@@ -157,8 +158,15 @@ def usable(model, feats: torch.Tensor, plan) -> bool:
             return False
     if not all(unit_is_plain(s) and s[1].training == model.training for s in seqs):
         return False
-    if not model.training and torch.is_grad_enabled() and (feats.requires_grad or any(p.requires_grad for p in model.parameters())):
-        return False  # running statistics + gradients: the node-by-node path (eval-mode BatchNorm backward)
+    if not model.training:
+        # eval: the node-by-node path is already ONE launch per unit (BatchNorm folded into the conv store) and at bs 1 the step is
+        # bound by the geometry plan's count reads, not by the feature pass: measured 1.25 ms/frame (nodes) vs 1.31 ms (native
+        # pass, whose burst of launches competes with the next frame's plan kernels).  The native eval pass stays available
+        # (VIRCONV_NATIVE_PASS_EVAL=1, bit-equal, tested) but is not the default.
+        if not NATIVE_PASS_EVAL:
+            return False
+        if torch.is_grad_enabled() and (feats.requires_grad or any(p.requires_grad for p in model.parameters())):
+            return False  # running statistics + gradients: the node-by-node path (eval-mode BatchNorm backward)
     return True
 
 
@@ -282,7 +290,7 @@ class PassFunction(torch.autograd.Function):
             _lib.check(_lib.VC_EINVAL, "vc_pass_backward_arena_bytes")
         arena = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         gacc = be._group_acc(call.group_bytes, dev) if call.group_bytes else None
-        side = be._side_stream(dev) if be.unit_overlap_dw() else None
+        side = be._side_stream(dev) if be.pass_overlap_dw() else None
         _lib.check(lib.vc_pass_backward(prog, call.arena.data_ptr(), call.arena.numel(), ext, _ptr(gin), _ptr(gacc),
                                         gacc.numel() if gacc is not None else 0, arena.data_ptr(), nbytes, side, be.stream()),
                    "vc_pass_backward")

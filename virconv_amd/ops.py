@@ -105,21 +105,38 @@ def build_subm_rulebook(indices: torch.Tensor, spatial_shape, ksize, dilation=1,
     return rb
 
 
-def build_sparse_rulebook(indices: torch.Tensor, spatial_shape, batch_size: int, ksize, stride, padding, dilation=1) -> Rulebook:
+def begin_sparse_rulebook(indices: torch.Tensor, spatial_shape, batch_size: int, ksize, stride, padding, dilation=1):
+    """Start a strided-conv rulebook (output-cell marking + the count's trip to the host) and return a handle for
+    `finish_sparse_rulebook`: the geometry plan issues its other kernels in between, so the count read does not stall it."""
     ndim = indices.shape[1] - 1
     ks, st = ntuple(ksize, ndim), ntuple(stride, ndim)
     pd, dl = ntuple(padding, ndim), ntuple(dilation, ndim)
     shape = tuple(int(s) for s in spatial_shape)
-    out_idx, out_shape, pf, pb = get_backend().sparse_rulebook(indices, shape, int(batch_size), ks, st, pd, dl)
+    be = get_backend()
+    args = (indices, shape, int(batch_size), ks, st, pd, dl)
+    handle = be.sparse_rulebook_begin(*args) if hasattr(be, "sparse_rulebook_begin") else None
+    return {"args": args, "handle": handle}
+
+
+def finish_sparse_rulebook(pending) -> Rulebook:
+    indices, shape, batch_size, ks, st, pd, dl = pending["args"]
+    be = get_backend()
+    if pending["handle"] is not None:
+        out_idx, out_shape, pf, pb = be.sparse_rulebook_finish(pending["handle"])
+    else:
+        out_idx, out_shape, pf, pb = be.sparse_rulebook(indices, shape, batch_size, ks, st, pd, dl)
     out_idx._vc_sorted = True  # ascending linear order by construction (bitmap rank); see build_subm_rulebook
     rb = Rulebook("sparse", pf, pb, None, indices.shape[0], out_idx.shape[0], indices, out_idx, shape,
                   tuple(int(s) for s in out_shape), ks, st, pd, dl)
     if ROW_ORDER in ("bwd", "all") and 8 < rb.kv <= 32:
-        be = get_backend()
         rb.order_bwd = be.row_order(pb, window=ROW_ORDER_WINDOW)
         if ROW_ORDER == "all":
             rb.order_fwd = be.row_order(pf, window=ROW_ORDER_WINDOW)
     return rb
+
+
+def build_sparse_rulebook(indices: torch.Tensor, spatial_shape, batch_size: int, ksize, stride, padding, dilation=1) -> Rulebook:
+    return finish_sparse_rulebook(begin_sparse_rulebook(indices, spatial_shape, batch_size, ksize, stride, padding, dilation))
 
 
 class SparseConvFunction(torch.autograd.Function):
