@@ -323,8 +323,9 @@ def main():
     for _ in range(args.warmup):
         train_step(ddp, optimizer, batch, lw, grad_sync, raw)
 
-    if os.environ.get("VIRCONV_PASS_DW_MAIN_TAIL"):   # schedule experiment, see virconv_amd/csrc/pass.hip
-        assert be.lib.vc_debug_set(b"pass_dw_main_tail", int(os.environ["VIRCONV_PASS_DW_MAIN_TAIL"])) == 0
+    for env, key in (("VIRCONV_PASS_DW_MAIN_TAIL", b"pass_dw_main_tail"), ("VIRCONV_PASS_BWD_EPILOGUE", b"pass_bwd_epilogue")):
+        if os.environ.get(env):   # A/B switches of the feature pass, see virconv_amd/csrc/pass.hip
+            assert be.lib.vc_debug_set(key, int(os.environ[env])) == 0
     tdir, tck, tcn = args.trace.split(",")
     be.trace_begin(tdir, int(tck), int(tcn))
     parallel.barrier()

@@ -135,6 +135,21 @@ int vc_conv_forward_epilogue(const float* x, int64_t n_in, const int32_t* pair_f
                              float* stats_partial, const float* mean, const float* var, const float* gamma,
                              const float* beta, float eps, int relu, float* y, void* stream);
 
+/* Backward-input conv with an epilogue (fp32 operands; availability: vc_conv_epilogue_supported(n_src, cout, cin, kv, F32)):
+ *   dx = conv^T(dy) + addend[:, add_col0 : add_col0 + cin]      (addend optional: a second gradient contribution of the same
+ *        tensor given as a strided view, e.g. the NRConvBlock concat slice or the gradient arriving from a head)
+ *   and, when y_raw != NULL, the BatchNorm-backward sums of the unit that PRODUCED this conv's input (its pre-BatchNorm
+ *   output y_raw (n_in, cin), batch mean / var, gamma, beta, eps, relu):  per channel sum(d) and sum(d * xhat) with
+ *   d = dx masked by that unit's ReLU -- written as per-wave partial rows [rows][2][cin]
+ *   (vc_conv_bwd_stats_partial_floats floats), consumed by vc_bn_relu_backward_from_partial.  This removes the unit's own
+ *   reduction pass over (y_raw, dy) and the kernel that would add the two contributions.                               */
+size_t vc_conv_bwd_stats_partial_floats(int64_t n_in, int cin, int cout);
+int vc_conv_backward_input_epilogue(const float* dy, const float* dy_centre, int64_t n_src, const int32_t* tbl, int64_t n_in,
+                                    int kv, const float* weight, int cin, int cout, int mirror, int centre, const int32_t* rep,
+                                    const int32_t* row_order, int flags, const float* addend, int add_stride, int add_col0,
+                                    const float* y_raw, const float* mean, const float* var, const float* gamma,
+                                    const float* beta, float eps, int relu, float* stats_partial, float* dx, void* stream);
+
 /* Row permutation that makes the gather-GEMM's 16-row tiles homogeneous: within each window of `window` (1024 | 2048 |
  * 4096) consecutive rows of `tbl` (KV, n) the rows are stably sorted by their active-offset bit mask (bit k set <=> tbl[k, r] >= 0; rows with
  * rep[r] != r count as {centre} only, matching the duplicate-pixel backward).  kv <= 32.  order (n) int32.
@@ -284,6 +299,13 @@ int vc_bn_relu_backward(const float* x, const float* dy, int dy_stride, int dy_c
                         const float* mean, const float* var, const float* gamma, const float* beta, float eps,
                         int relu, float* dx, float* dgamma, float* dbeta, unsigned* absmax_out /* nullable: receives
                         max|dx| as float bits (cleared by the call itself) */, void* ws, size_t ws_bytes, void* stream);
+
+/* vc_bn_relu_backward with the two per-channel sums taken from the partial rows of vc_conv_backward_input_epilogue
+ * (`partial`: nblocks rows of [2][c] floats) instead of a reduction pass over (x, dy).                                   */
+int vc_bn_relu_backward_from_partial(const float* x, const float* dy, int dy_stride, int dy_col0, int64_t n, int c,
+                                     const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                                     int relu, const float* partial, int64_t nblocks, float* dx, float* dgamma, float* dbeta,
+                                     unsigned* absmax_out, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ post_act_block
  * conv (no bias) -> BatchNorm1d(training) -> ReLU, the unit every conv of the backbone is wrapped in (spconv_backbone.py:86-107

@@ -213,7 +213,11 @@ __global__ void __launch_bounds__(256) bn_partial_reduce_kernel(const float* __r
 
 __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const double* __restrict__ partial, int nb, int c,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              float* __restrict__ sums /* [2][c]: dbeta, dgamma */) {
+                                                              float* __restrict__ sums /* [2][c]: dbeta, dgamma */,
+                                                              unsigned* __restrict__ zero_word) {
+  // the max|dx| word the dx kernel (next launch on this stream) accumulates into: cleared here when the reduction pass that
+  // normally clears it did not run (sums taken from a conv epilogue)
+  if (zero_word != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0u;
   const int lane = threadIdx.x & 63;
   const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ch >= c) return;
@@ -517,7 +521,8 @@ int vc_bn_relu_backward(const float* x, const float* dy, int dy_stride, int dy_c
   hipLaunchKernelGGL((bn_reduce_kernel<true>), dim3(nb), dim3(256), 0, st, x, dy, dy_stride, dy_col0, n, c, mean, var,
                      gamma, beta, eps, relu, rpb, partial, absmax_out);
   VC_CHECK_LAUNCH("bn_reduce_kernel<bwd>");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, partial, nb, c, dgamma, dbeta, sums);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, partial, nb, c, dgamma, dbeta, sums,
+                     (unsigned*)nullptr);
   VC_CHECK_LAUNCH("bn_bwd_finalize_kernel");
   const int lg = bn_lg_c4(c);
   if (lg >= 0) {
@@ -529,6 +534,34 @@ int vc_bn_relu_backward(const float* x, const float* dy, int dy_stride, int dy_c
     hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3((unsigned)cdiv(n * (c / 4), 256)), dim3(256), 0, st, x, dy, dy_stride,
                        dy_col0, n, c, mean, var, gamma, beta, eps, relu, sums, dx);
   }
+  VC_CHECK_LAUNCH("bn_bwd_dx_kernel");
+  return VC_OK;
+}
+
+int vc_bn_relu_backward_from_partial(const float* x, const float* dy, int dy_stride, int dy_col0, int64_t n, int c,
+                                     const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                                     int relu, const float* fpartial, int64_t nblocks, float* dx, float* dgamma, float* dbeta,
+                                     unsigned* absmax_out, void* ws, size_t ws_bytes, void* stream) {
+  VC_REQUIRE(bn_c_ok(c) && 2 * c <= 256, "vc_bn_relu_backward_from_partial: unsupported channel count %d", c);
+  VC_REQUIRE(dy_stride >= c && dy_stride % 4 == 0 && dy_col0 % 4 == 0 && dy_col0 + c <= dy_stride,
+             "vc_bn_relu_backward_from_partial: bad stride arguments");
+  VC_REQUIRE(n >= 1 && nblocks >= 1 && x && dy && mean && var && dx && ws && fpartial,
+             "vc_bn_relu_backward_from_partial: null/invalid argument");
+  if (ws_bytes < vc_bn_workspace_bytes(n, c)) { set_error("vc_bn_relu_backward_from_partial: workspace too small"); return VC_ECAPACITY; }
+  hipStream_t st = (hipStream_t)stream;
+  double* partial = (double*)ws;
+  float* sums = (float*)(partial + (size_t)kMaxBnBlocks * 2 * c);
+  const int64_t rpb = cdiv(nblocks, 256);
+  const int g = (int)cdiv(nblocks, rpb);
+  hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(g), dim3(256), 0, st, fpartial, nblocks, rpb, c, partial);
+  VC_CHECK_LAUNCH("bn_partial_reduce_kernel");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, partial, g, c, dgamma, dbeta, sums, absmax_out);
+  VC_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+  const int lg = bn_lg_c4(c);
+  VC_REQUIRE(lg >= 0, "vc_bn_relu_backward_from_partial: channel count must be a power of two");
+  const int rows_per_block = (256 >> lg) * kBnRowsPerThread;
+  hipLaunchKernelGGL(bn_bwd_dx_pow2_kernel, dim3((unsigned)cdiv(n, rows_per_block)), dim3(256), 0, st, x, dy, dy_stride, dy_col0,
+                     n, c, lg, mean, var, gamma, beta, eps, relu, sums, dx, absmax_out);
   VC_CHECK_LAUNCH("bn_bwd_dx_kernel");
   return VC_OK;
 }

@@ -234,15 +234,24 @@ struct BufLoad<1> {
 //                  squares of its 16 rows to epi.partial[block * 4 + wave][2][CN] (fixed order: 4 accumulator rows, q lanes);
 //                  vc_bn_stats_from_partial adds them up in fp64.  Saves the read-back pass of bn_reduce.
 //   VC_EPI_AFFINE  eval-mode BatchNorm (+ReLU) folded into the store: y = acc * (gamma * istd) + (beta - mean * gamma * istd)
+//   VC_EPI_BWD     backward-input conv only: `addend` (optional, a second gradient contribution given as a strided view) is added
+//                  to the tile before it is stored, and (optional, y_raw != NULL) the BatchNorm-backward sums of the unit that
+//                  PRODUCED this conv's input -- sum(dy_masked), sum(dy_masked * xhat) per channel, per-wave partial rows as in
+//                  STATS -- are formed from the stored tile and that unit's pre-BatchNorm output: the unit's separate reduction
+//                  pass over (y_raw, dy) and the gradient-add kernel disappear
 struct ConvEpilogue {
-  float* partial;        // STATS
-  const float* mean;     // AFFINE (running statistics)
+  float* partial;        // STATS / BWD
+  const float* mean;     // AFFINE (running statistics) / BWD (batch statistics of the producing unit)
   const float* var;
   const float* gamma;
   const float* beta;
   float eps;
   int relu;
+  const float* y_raw = nullptr;    // BWD: pre-BatchNorm output of the producing unit, (rows of this launch) x CN
+  const float* addend = nullptr;   // BWD: out += addend[:, add_col0 : add_col0 + CN] (row stride add_stride)
+  int add_stride = 0, add_col0 = 0;
 };
+static constexpr int VC_EPI_BWD = 3;  // internal (not part of vc_epilogue: selected by vc_conv_backward_input_epilogue)
 
 template <int CK, int CN, bool BWD, int RT, int OT, int EPI, int NW = 4>
 __global__ void __launch_bounds__(64 * NW) gather_gemm_v2_kernel(const float* __restrict__ src,
@@ -252,7 +261,8 @@ __global__ void __launch_bounds__(64 * NW) gather_gemm_v2_kernel(const float* __
                                                              const int32_t* __restrict__ rep,
                                                              const int32_t* __restrict__ order, int64_t n_out, int kv,
                                                              int centre, int mirror, ConvEpilogue epi) {
-  static_assert(EPI == VC_EPI_NONE || (!BWD && RT == 1), "epilogues exist for the 64-row forward kernel only");
+  static_assert(EPI == VC_EPI_NONE || RT == 1, "epilogues exist for the one-tile-per-wave kernel only");
+  static_assert(EPI == VC_EPI_NONE || (EPI == VC_EPI_BWD) == BWD, "STATS / AFFINE: forward kernel; BWD: backward-input kernel");
   constexpr int V = (CK >= 16) ? 4 : CK / 4;
   constexpr int NCH = CK / (4 * V);
   constexpr int NT = (CN + 15) / 16;
@@ -478,6 +488,23 @@ __global__ void __launch_bounds__(64 * NW) gather_gemm_v2_kernel(const float* __
       }
     }
   }
+  // VC_EPI_BWD: per-channel constants of the producing unit's BatchNorm (the same expressions as bn_bwd_dx_*: identical xhat,
+  // identical ReLU mask) and the running sums of this lane's 4 rows
+  float b_mu[NT], b_istd[NT], b_g[NT], b_bt[NT], b_sa[NT], b_sb[NT];
+  const bool bwd_stats = (EPI == VC_EPI_BWD) && epi.y_raw != nullptr;
+  if constexpr (EPI == VC_EPI_BWD) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 16 + i;
+      b_mu[nt] = 0.f; b_istd[nt] = 0.f; b_g[nt] = 1.f; b_bt[nt] = 0.f; b_sa[nt] = 0.f; b_sb[nt] = 0.f;
+      if (bwd_stats && n < CN) {
+        b_mu[nt] = epi.mean[n];
+        b_istd[nt] = 1.0f / sqrtf(epi.var[n] + epi.eps);
+        b_g[nt] = epi.gamma ? epi.gamma[n] : 1.f;
+        b_bt[nt] = epi.beta ? epi.beta[n] : 0.f;
+      }
+    }
+  }
 #pragma unroll
   for (int t = 0; t < RT; ++t) {
     int64_t orow[4];
@@ -494,7 +521,32 @@ __global__ void __launch_bounds__(64 * NW) gather_gemm_v2_kernel(const float* __
           v = v * sc[nt] + sh[nt];
           if (epi.relu) v = fmaxf(v, 0.f);
         }
+        if constexpr (EPI == VC_EPI_BWD) {
+          if (orow[reg] >= 0) {
+            if (epi.addend != nullptr) v += epi.addend[orow[reg] * epi.add_stride + epi.add_col0 + n];
+            if (bwd_stats) {
+              const float xh = (epi.y_raw[orow[reg] * CN + n] - b_mu[nt]) * b_istd[nt];
+              float d = v;
+              if (epi.relu && !(xh * b_g[nt] + b_bt[nt] > 0.f)) d = 0.f;
+              b_sa[nt] += d;
+              b_sb[nt] += d * xh;
+            }
+          }
+        }
         if (orow[reg] >= 0) out[orow[reg] * CN + n] = v;
+      }
+    }
+  }
+  if constexpr (EPI == VC_EPI_BWD) {
+    if (bwd_stats) {  // per-WAVE partial row [2][CN]: (sum dy_masked, sum dy_masked * xhat), fixed order, no LDS, no barrier
+      float* prow = epi.partial + ((lbid * NW + wave) * 2) * CN;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float sa = b_sa[nt], sb = b_sb[nt];
+        sa += __shfl_xor(sa, 16, 64); sb += __shfl_xor(sb, 16, 64);
+        sa += __shfl_xor(sa, 32, 64); sb += __shfl_xor(sb, 32, 64);
+        const int n = nt * 16 + i;
+        if (q == 0 && n < CN) { prow[n] = sa; prow[CN + n] = sb; }
       }
     }
   }
@@ -1343,7 +1395,7 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
   const int64_t rows_per_block = 4 * kRT * 16;
   g_last_windowed = false;
   if constexpr (CK >= 16) {
-    if (conv_block_waves(CK, CN, BWD) == 4 && use_window_kernel<CK>(flags, ot, rep, order, n_src, kv, src_centre)) {
+    if (conv_block_waves(CK, CN, BWD) == 4 && epi_kind != VC_EPI_BWD && use_window_kernel<CK>(flags, ot, rep, order, n_src, kv, src_centre)) {
       constexpr int NCH = CK / 16, NT = (CN + 15) / 16;
       // experiment switches (vc_debug_set): conv_wdma = W images through the LDS-DMA engine, conv_winrows = 24-row windows
       const bool wdma = g_conv_wdma && CN % 16 == 0 && epi_kind == VC_EPI_NONE;
@@ -1397,6 +1449,14 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
             return VC_OK;
           }
         }
+        if constexpr (BWD) {
+          if (epi_kind == VC_EPI_BWD) {
+            hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, true, 1, VC_OPERAND_F32, VC_EPI_BWD, 8>), grid8, dim3(512), lds8, st,
+                               src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, epi);
+            VC_CHECK_LAUNCH("gather_gemm_v2_kernel<bwd epilogue, 8 waves>");
+            return VC_OK;
+          }
+        }
         hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 1, VC_OPERAND_F32, VC_EPI_NONE, 8>), grid8, dim3(512), lds8, st,
                            src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, epi);
         VC_CHECK_LAUNCH("gather_gemm_v2_kernel<8 waves>");
@@ -1407,6 +1467,14 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
                        (size_t)(kv + 1) * 64 * rt * sizeof(int) + 16;
     const dim3 grid((unsigned)cdiv(n_out, (int64_t)64 * rt));
 #define VC_ARGS src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, epi
+    if constexpr (BWD) {
+      if (epi_kind == VC_EPI_BWD) {
+        if (half_ops) { set_error("gather-GEMM: epilogues are implemented for fp32 operands only"); return VC_EINVAL; }
+        hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, true, 1, VC_OPERAND_F32, VC_EPI_BWD>), grid, dim3(256), lds, st, VC_ARGS);
+        VC_CHECK_LAUNCH("gather_gemm_v2_kernel<bwd epilogue>");
+        return VC_OK;
+      }
+    }
     if constexpr (!BWD) {
       if (epi_kind != VC_EPI_NONE) {
         if (half_ops) { set_error("gather-GEMM: epilogues are implemented for fp32 operands only"); return VC_EINVAL; }
@@ -1478,6 +1546,7 @@ static int dispatch_ck(int ck, int cn, const float* src, const float* src_centre
 
 int g_bw_legacy_order = 0;      // debug: 1 = offset-major block order of the weight-gradient kernel
 extern int g_pass_dw_main_tail; // pass.hip
+extern int g_pass_bwd_epilogue; // pass.hip
 static constexpr int kMaxSplit = 256;
 static constexpr size_t kMaxPartialBytes = 24u << 20;
 
@@ -1557,6 +1626,7 @@ int vc_debug_set(const char* key, int value) {
   if (key && !strcmp(key, "conv_winrows")) { g_conv_winrows = value; return VC_OK; }
   if (key && !strcmp(key, "bw_legacy_order")) { g_bw_legacy_order = value; return VC_OK; }
   if (key && !strcmp(key, "pass_dw_main_tail")) { g_pass_dw_main_tail = value; return VC_OK; }
+  if (key && !strcmp(key, "pass_bwd_epilogue")) { g_pass_bwd_epilogue = value; return VC_OK; }
   if (key && !strcmp(key, "xcd_swizzle_off")) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_swizzle_off), &value, sizeof(int)) == hipSuccess ? VC_OK : VC_EHIP;
   }
@@ -1662,6 +1732,38 @@ int vc_conv_backward_input(const float* dy, const float* dy_centre, int64_t n_sr
   const int tr = trace_open(1, cout, cin, (hipStream_t)stream);
   const int rc = dispatch_ck<true>(cout, cin, dy, dy_centre, n_src, tbl, weight, dx, rep, row_order, n_in, kv, centre,
                                    mirror ? 1 : 0, operand_type, VC_EPI_NONE, ConvEpilogue{}, flags, (hipStream_t)stream);
+  if (tr >= 0) trace_close(tr, tbl, kv, n_src, n_in, (hipStream_t)stream);
+  return rc;
+}
+
+size_t vc_conv_bwd_stats_partial_floats(int64_t n_in, int cin, int cout) {
+  if (n_in < 0 || cin < 1 || cout < 1) return 0;
+  // one partial row per 16-row wave tile of the backward-input kernel <CK = cout, CN = cin>
+  const int nw = conv_block_waves(cout, cin, true);
+  return (size_t)cdiv(n_in, 16 * nw) * nw * 2 * cin;
+}
+
+int vc_conv_backward_input_epilogue(const float* dy, const float* dy_centre, int64_t n_src, const int32_t* tbl, int64_t n_in,
+                                    int kv, const float* weight, int cin, int cout, int mirror, int centre, const int32_t* rep,
+                                    const int32_t* row_order, int flags, const float* addend, int add_stride, int add_col0,
+                                    const float* y_raw, const float* mean, const float* var, const float* gamma,
+                                    const float* beta, float eps, int relu, float* stats_partial, float* dx, void* stream) {
+  VC_REQUIRE(n_src >= 0 && n_in >= 1 && kv >= 1 && weight && tbl && dx && (dy || n_src == 0),
+             "vc_conv_backward_input_epilogue: null/invalid argument");
+  VC_REQUIRE(centre >= -1 && centre < kv, "vc_conv_backward_input_epilogue: centre out of range");
+  VC_REQUIRE(!addend || (add_stride >= cin && add_col0 >= 0 && add_col0 + cin <= add_stride),
+             "vc_conv_backward_input_epilogue: bad addend view");
+  VC_REQUIRE(!y_raw || (mean && var && stats_partial), "vc_conv_backward_input_epilogue: statistics requested without mean/var/partial");
+  VC_REQUIRE(vc_conv_epilogue_supported(n_src, cout, cin, kv, VC_OPERAND_F32),
+             "vc_conv_backward_input_epilogue: not available for this shape (vc_conv_epilogue_supported(n_src, cout, cin, kv))");
+  ConvEpilogue e{stats_partial, mean, var, gamma, beta, eps, relu};
+  e.y_raw = y_raw;
+  e.addend = addend;
+  e.add_stride = add_stride;
+  e.add_col0 = add_col0;
+  const int tr = trace_open(1, cout, cin, (hipStream_t)stream);
+  const int rc = dispatch_ck<true>(cout, cin, dy, dy_centre, n_src, tbl, weight, dx, rep, row_order, n_in, kv, centre,
+                                   mirror ? 1 : 0, VC_OPERAND_F32, VC_EPI_BWD, e, flags, (hipStream_t)stream);
   if (tr >= 0) trace_close(tr, tbl, kv, n_src, n_in, (hipStream_t)stream);
   return rc;
 }

@@ -151,6 +151,11 @@ static int launch_add_views(float* out, int64_t n, int c, const float* a, int as
 // main chain (they can only start after each unit's BatchNorm backward), so at the end of the sweep the main stream idles in
 // the join; moving the tail's weight gradients over fills that hole.
 int g_pass_dw_main_tail = 0;
+// vc_debug_set "pass_bwd_epilogue" (default 1): let the backward-input conv that delivers the LAST contribution to a buffer's
+// gradient add the earlier contribution in its epilogue and, when that buffer is the whole output of a unit, also form that
+// unit's BatchNorm-backward sums there (vc_conv_backward_input_epilogue): no gradient-add kernel, no reduction pass over
+// (y_raw, dy) for 15 of the 20 units of VirConvL8x.  0 = every unit reduces for itself (the node-by-node arithmetic).
+int g_pass_bwd_epilogue = 1;
 
 struct GradView {
   const float* p;
@@ -208,6 +213,20 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
   };
   auto wants_grad = [&](int b) { return !p->bufs[b].external || (b == 0 && want_input_grad); };
 
+  // who writes a buffer as a whole (a unit whose output IS the buffer) and who reads it first (forward order = the last
+  // contributor to its gradient in the reverse sweep)
+  std::vector<int> prod_unit(p->n_bufs, -1), first_cons(p->n_bufs, -1), n_writers(p->n_bufs, 0);
+  for (int i = 0; i < p->n_ops; ++i) {
+    const vc_pass_op& o = p->ops[i];
+    if (first_cons[o.src] < 0) first_cons[o.src] = i;
+    ++n_writers[o.dst];
+    if (o.kind == VC_PASS_UNIT && o.dst_col0 == 0 && p->bufs[o.dst].cols == p->units[o.unit].cout) prod_unit[o.dst] = i;
+  }
+  for (int b = 0; b < p->n_bufs; ++b)
+    if (n_writers[b] != 1) prod_unit[b] = -1;
+  struct FusedSums { const float* partial = nullptr; int64_t nblocks = 0; };
+  std::vector<FusedSums> fused(p->n_ops);  // per unit op: BatchNorm-backward sums delivered by a conv epilogue
+
   hipEvent_t* ev = (side != nullptr && !dry) ? pass_events() : nullptr;
   bool forked = false;
   int n_units_left = 0;  // units still ahead in the reverse sweep (for the main-tail schedule)
@@ -237,6 +256,26 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
       float* d_raw = at(bump.take((size_t)t.n_out * u.cout * sizeof(float)));
       float* dx = need_dx ? at(bump.take((size_t)t.n_in * u.cin * sizeof(float))) : nullptr;
       float* dgb = (u.dgamma && u.dbeta) ? nullptr : at(bump.take((size_t)2 * u.cout * sizeof(float)));
+      // epilogue fusion: this conv delivers the last contribution to the gradient of its source buffer
+      bool fold = false;
+      GradView addv{nullptr, 0, 0};
+      int cprod = -1;
+      float* fpart = nullptr;
+      if (need_dx && g_pass_bwd_epilogue && p->operand_type == VC_OPERAND_F32 && first_cons[o.src] == i &&
+          contrib[o.src].size() <= 1 && vc_conv_epilogue_supported(t.n_out, u.cout, u.cin, t.kv, VC_OPERAND_F32)) {
+        fold = true;
+        if (!contrib[o.src].empty()) {
+          addv = contrib[o.src][0];
+          contrib[o.src].clear();
+        }
+        cprod = prod_unit[o.src];
+        if (cprod >= 0) {
+          const size_t pf = vc_conv_bwd_stats_partial_floats(t.n_in, u.cin, u.cout);
+          fpart = at(bump.take(pf * sizeof(float)));
+          fused[cprod].partial = dry ? marker : fpart;
+          fused[cprod].nblocks = (int64_t)(pf / (2 * (size_t)u.cin));
+        }
+      }
       if (need_dx) contrib[o.src].push_back({dry ? marker : dx, u.cin, 0});
       if (dry) continue;
       const GradView g = res[o.dst];
@@ -248,9 +287,15 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
         VC_REQUIRE(group_acc && group_acc_bytes >= vc_group_sum_workspace_bytes(t.n_out, u.cout) && (u.cout & (u.cout - 1)) == 0,
                    "vc_pass_backward: duplicate-pixel table needs the persistent group-sum accumulator");
       }
-      rc = vc_bn_relu_backward(y_raw, g.p, g.stride, g.col0 + o.dst_col0, t.n_out, u.cout, mean, var, u.gamma, u.beta, u.eps,
-                               o.relu, d_raw, u.dgamma ? u.dgamma : dgb, u.dbeta ? u.dbeta : dgb + u.cout,
-                               dup ? (unsigned*)group_acc : nullptr, arena + bn_off, bn_bytes, st);
+      if (fused[i].partial != nullptr)
+        rc = vc_bn_relu_backward_from_partial(y_raw, g.p, g.stride, g.col0 + o.dst_col0, t.n_out, u.cout, mean, var, u.gamma,
+                                              u.beta, u.eps, o.relu, fused[i].partial, fused[i].nblocks, d_raw,
+                                              u.dgamma ? u.dgamma : dgb, u.dbeta ? u.dbeta : dgb + u.cout,
+                                              dup ? (unsigned*)group_acc : nullptr, arena + bn_off, bn_bytes, st);
+      else
+        rc = vc_bn_relu_backward(y_raw, g.p, g.stride, g.col0 + o.dst_col0, t.n_out, u.cout, mean, var, u.gamma, u.beta, u.eps,
+                                 o.relu, d_raw, u.dgamma ? u.dgamma : dgb, u.dbeta ? u.dbeta : dgb + u.cout,
+                                 dup ? (unsigned*)group_acc : nullptr, arena + bn_off, bn_bytes, st);
       if (rc != VC_OK) return rc;
       if (need_dw && on_side) {  // fork: the weight gradient only reads x (forward arena) and d_raw (never rewritten in this call)
         VC_CHECK_HIP(hipEventRecord(ev[0], st));
@@ -270,9 +315,26 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
           src_centre = d_raw;
         }
         const int flags = (t.sorted_rows && t.subm) ? VC_CONV_SORTED_ROWS : 0;
-        rc = vc_conv_backward_input(src, src_centre, t.n_out, t.subm ? t.pair_fwd : t.pair_bwd, t.n_in, t.kv, u.weight, u.cin,
-                                    u.cout, t.subm ? 1 : 0, dup ? t.centre : -1, dup ? t.rep : nullptr, t.order_bwd,
-                                    p->operand_type, flags, dx, st);
+        if (fold) {
+          const float *cy = nullptr, *cmean = nullptr, *cvar = nullptr, *cg = nullptr, *cb = nullptr;
+          float ceps = 0.f;
+          int crelu = 0;
+          if (cprod >= 0) {  // the unit that produced this conv's input: its BatchNorm-backward sums are formed in the epilogue
+            const vc_pass_unit& cu = p->units[p->ops[cprod].unit];
+            cy = (const float*)((const char*)fwd_arena + L.yraw_off[cprod]);
+            cmean = (const float*)((const char*)fwd_arena + L.stats_off[cprod]);
+            cvar = cmean + cu.cout;
+            cg = cu.gamma; cb = cu.beta; ceps = cu.eps; crelu = p->ops[cprod].relu;
+          }
+          rc = vc_conv_backward_input_epilogue(src, src_centre, t.n_out, t.subm ? t.pair_fwd : t.pair_bwd, t.n_in, t.kv, u.weight,
+                                               u.cin, u.cout, t.subm ? 1 : 0, dup ? t.centre : -1, dup ? t.rep : nullptr,
+                                               t.order_bwd, flags, addv.p, addv.stride, addv.col0, cy, cmean, cvar, cg, cb, ceps,
+                                               crelu, fpart, dx, st);
+        } else {
+          rc = vc_conv_backward_input(src, src_centre, t.n_out, t.subm ? t.pair_fwd : t.pair_bwd, t.n_in, t.kv, u.weight, u.cin,
+                                      u.cout, t.subm ? 1 : 0, dup ? t.centre : -1, dup ? t.rep : nullptr, t.order_bwd,
+                                      p->operand_type, flags, dx, st);
+        }
         if (rc != VC_OK) return rc;
       }
       if (need_dw && !on_side) {  // main stream: its own partial-sum scratch (the side stream may still be using the shared one)

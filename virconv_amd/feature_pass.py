@@ -111,8 +111,10 @@ def build_virconv_l_program(model, discard_active: bool, training: bool) -> _Pro
         cat = P.buf(2 * c, ("table_out", t3))
         P.ops.append((_lib.PASS_UNIT, cur, f1, 0, P.unit(blk.d3_conv1), t3, 0, 1))
         P.ops.append((_lib.PASS_UNIT, f1, f3, 0, P.unit(blk.d3_conv2), t3, 0, 1))
-        P.ops.append((_lib.PASS_COPY, f3, cat, 0, 0, 0, 0, 0))
+        # the first 2-D unit reads f3 BEFORE f3 is copied into the concat: in the reverse sweep the concat slice then arrives first
+        # and the unit's backward-input conv -- the last contributor to f3's gradient -- adds it in its epilogue
         P.ops.append((_lib.PASS_UNIT, f3, g1, 0, P.unit(blk.d2_conv1), t2, 0, 1))
+        P.ops.append((_lib.PASS_COPY, f3, cat, 0, 0, 0, 0, 0))
         if training:
             P.ops.append((_lib.PASS_UNIT, g1, cat, c, P.unit(blk.d2_conv2), t2, 0, 1))      # concat written in place
         else:
