@@ -53,8 +53,13 @@ def _worker(rank, world, port, out_dir, mode="ddp"):
     else:  # the exchange bench.py uses: one flat all-reduce of the packed gradients
         ddp, sync = model, parallel.FlatGradAllReduce(model)
     out = ddp(batch)
-    loss = out["encoded_spconv_tensor"].features.square().mean() + out["multi_scale_3d_features"]["x_conv2"].features.mean()
+    if mode == "flat_partial":   # a loss that leaves vir_conv3 / vir_conv4 / conv_out WITHOUT a gradient (p.grad is None)
+        loss = out["multi_scale_3d_features"]["x_conv2"].features.mean()
+    else:
+        loss = out["encoded_spconv_tensor"].features.square().mean() + out["multi_scale_3d_features"]["x_conv2"].features.mean()
     loss.backward()
+    if mode == "flat_partial":
+        assert model.conv_out[0].weight.grad is None and model.vir_conv2.d3_conv1[0].weight.grad is not None
     if sync is not None:
         sync()
     grads = {k: p.grad.clone() for k, p in model.named_parameters()}
@@ -125,3 +130,17 @@ def test_numa_binding_helpers_are_safe_without_a_gpu(monkeypatch):
     os.sched_setaffinity(0, before)
     monkeypatch.setenv("VIRCONV_NUMA_BIND", "0")
     assert parallel.bind_to_gpu_numa(0) == "off"
+
+
+@pytest.mark.timeout(600)
+def test_flat_allreduce_with_parameters_that_received_no_gradient(tmp_path):
+    """a parameter whose .grad is None must not change the size of the flat buffer on one rank only; the exchange
+    fills it with zeros on every rank (what DistributedDataParallel does for unused parameters)."""
+    world, port = 2, _free_port()
+    mp.start_processes(_worker, args=(world, port, str(tmp_path), "flat_partial"), nprocs=world, join=True, start_method="spawn")
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    for k in r0["grads"]:
+        assert torch.equal(r0["grads"][k], r1["grads"][k]), k
+    assert float(r0["grads"]["conv_out.0.weight"].abs().max()) == 0.0
+    assert float(r0["grads"]["vir_conv2.d3_conv1.0.weight"].abs().max()) > 0.0

@@ -522,3 +522,67 @@ def test_native_feature_pass_equals_the_node_by_node_path(hip_backend, discard, 
     assert e_ref[0] == e_got[0]
     for k in e_ref[1]:
         assert torch.equal(e_ref[1][k], e_got[1][k]), k
+
+
+def test_native_feature_pass_virconv8x_equals_the_node_by_node_path(hip_backend, monkeypatch):
+    """VirConv8x (training): the LiDAR stream and the virtual-point stream (input discard + NRConvBlocks + layer discards) each run
+    as one native call per direction.  Without the backward epilogue fusion: bit-equal to the node-by-node path; with it (the
+    default): forward bit-equal, gradients equal up to the summation order of the fused BatchNorm-backward sums."""
+    import importlib
+    import os
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    bench8x = importlib.import_module("bench8x")
+    from virconv_amd import feature_pass
+    from virconv_amd.backbone import VirConv8x
+    dev = torch.device("cuda", 0)
+    batch = bench8x.make_batch(2, dev)
+    cfg = dict(NAME="VirConv8x", NUM_FILTERS=[16, 32, 64, 64], RETURN_NUM_FEATURES_AS_DICT=True, OUT_FEATURES=64,
+               LAYER_DISCARD_RATE=0.15, LAYER_DISCARD_MODE="spconv1_inplace", MM=True)
+    lw = bench.make_loss_weights(dev)
+    torch.manual_seed(13)
+    model = VirConv8x(cfg, 8, synth.GRID_SIZE).to(dev).train()
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    rec = _record_discards(monkeypatch)
+    calls = []
+    for name in ("run_8x_lidar", "run_8x_mm"):
+        orig = getattr(feature_pass, name)
+        monkeypatch.setattr(feature_pass, name, lambda *a, _o=orig, _n=name, **k: (calls.append(_n), _o(*a, **k))[1])
+
+    def one(native, keeps):
+        monkeypatch.setattr(feature_pass, "NATIVE_PASS", native)
+        model.load_state_dict(state)
+        bd = dict(batch)
+        if keeps:
+            bd["layer_discard_keep"] = keeps
+        loss, res, grads = _train_pass(model, bd, lw, mm=True)
+        return loss, res, grads, {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    torch.manual_seed(7)
+    ref = one(False, None)
+    keeps = {k: v.to(dev) for k, v in rec.items()}
+    assert set(keeps) == {"mm_input", "mm_x_conv1", "mm_x_conv2", "mm_x_conv3"} and not calls
+    lib = hip_backend.lib
+    assert lib.vc_debug_set(b"pass_bwd_epilogue", 0) == 0
+    try:
+        got = one(True, keeps)
+    finally:
+        assert lib.vc_debug_set(b"pass_bwd_epilogue", 1) == 0
+    assert calls == ["run_8x_lidar", "run_8x_mm"], calls
+    assert ref[0] == got[0]
+    for k in ref[1]:
+        assert np.array_equal(ref[1][k][0], got[1][k][0]) and np.array_equal(ref[1][k][1], got[1][k][1]), k
+    assert set(ref[2]) == set(got[2])
+    for k in ref[2]:
+        assert np.array_equal(ref[2][k], got[2][k]), k
+    for k in ref[3]:
+        assert torch.equal(ref[3][k], got[3][k]), k
+    fused = one(True, keeps)
+    assert ref[0] == fused[0]
+    for k in ref[1]:
+        assert np.array_equal(ref[1][k][0], fused[1][k][0]), k
+    for k in ref[2]:
+        tol = 1e-5 * max(float(np.abs(ref[2][k]).max()), 1e-30)
+        assert float(np.abs(fused[2][k] - ref[2][k]).max()) <= tol, k

@@ -658,14 +658,25 @@ class VirConv8x(nn.Module):
 
         if self.training:
             for rid in rids:
+                native = None
                 if plan is not None:
                     idx, rbs = plan["lidar"][rid]
-                    sp = spconv.SparseConvTensor(batch_dict["voxel_features" + rid], idx, self.sparse_shape, batch_size,
-                                                 indice_dict=dict(rbs))
+                    f_in = batch_dict["voxel_features" + rid]
+                    if feature_pass.usable_8x(self, f_in, "lidar"):
+                        native = feature_pass.run_8x_lidar(self, f_in, rbs)   # the whole stream: one native call per direction
+                    sp = spconv.SparseConvTensor(f_in, idx, self.sparse_shape, batch_size, indice_dict=dict(rbs))
                 else:
                     sp = spconv.SparseConvTensor(batch_dict["voxel_features" + rid], batch_dict["voxel_coords" + rid].int(),
                                                  self.sparse_shape, batch_size)
-                x1, x2, x3, x4, out = self._lidar_stream(sp)
+                if native is not None:
+                    geo = [(idx, self.sparse_shape)] + [(rbs[seq[0][0].indice_key].out_indices, list(rbs[seq[0][0].indice_key].out_shape))
+                                                        for seq in (self.conv2, self.conv3, self.conv4)]
+                    rbo = rbs[self.conv_out[0].indice_key]
+                    geo.append((rbo.out_indices, list(rbo.out_shape)))
+                    x1, x2, x3, x4, out = [spconv.SparseConvTensor(f, gi, gs, batch_size, indice_dict=dict(rbs))
+                                           for f, (gi, gs) in zip(native, geo)]
+                else:
+                    x1, x2, x3, x4, out = self._lidar_stream(sp)
                 batch_dict.update({"encoded_spconv_tensor" + rid: out, "encoded_spconv_tensor_stride" + rid: 8,
                                    "multi_scale_3d_features" + rid: {"x_conv1": x1, "x_conv2": x2, "x_conv3": x3, "x_conv4": x4},
                                    "multi_scale_3d_strides" + rid: dict(strides)})
@@ -703,10 +714,16 @@ class VirConv8x(nn.Module):
                 if plan is not None:
                     pm = plan["mm"][rid]
                     f = batch_dict["voxel_features_mm" + rid]
-                    if pm["keep0"] is not None:
-                        f = ops.GatherRowsFunction.apply(f, pm["keep0"])
-                    sp = spconv.SparseConvTensor(f, pm["in_indices"], self.sparse_shape, batch_size)
-                    m1, m2, m3, m4 = _run_nrconv_chain(blocks, pm["stages"], sp, batch_size, calib, pm["trans_param"])
+                    native = feature_pass.run_8x_mm(self, f, pm) if feature_pass.usable_8x(self, f, "mm") else None
+                    if native is not None:   # input discard + the four NRConvBlocks + layer discards: one native call per direction
+                        m1, m2, m3, m4 = [spconv.SparseConvTensor(ft, st["kept_indices"] if st["keep"] is not None else st["out_indices"],
+                                                                  st["out_shape"], batch_size)
+                                          for ft, st in zip(native, pm["stages"])]
+                    else:
+                        if pm["keep0"] is not None:
+                            f = ops.GatherRowsFunction.apply(f, pm["keep0"])
+                        sp = spconv.SparseConvTensor(f, pm["in_indices"], self.sparse_shape, batch_size)
+                        m1, m2, m3, m4 = _run_nrconv_chain(blocks, pm["stages"], sp, batch_size, calib, pm["trans_param"])
                 else:
                     sp = spconv.SparseConvTensor(batch_dict["voxel_features_mm" + rid],
                                                  batch_dict["voxel_coords_mm" + rid].int(), self.sparse_shape, batch_size)

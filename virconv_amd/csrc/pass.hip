@@ -211,7 +211,16 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
     state[b] = 1;
     return VC_OK;
   };
-  auto wants_grad = [&](int b) { return !p->bufs[b].external || (b == 0 && want_input_grad); };
+  // which buffers carry a gradient at all: everything downstream of a unit (it has parameters), and pure data movement
+  // (copy / gather) of a buffer that does -- a discard of the raw input features, for instance, does not
+  std::vector<char> needs(p->n_bufs, 0);
+  needs[0] = want_input_grad ? 1 : 0;
+  for (int i = 0; i < p->n_ops; ++i) {
+    const vc_pass_op& o = p->ops[i];
+    if (o.kind == VC_PASS_UNIT) needs[o.dst] = 1;
+    else if (needs[o.src]) needs[o.dst] = 1;
+  }
+  auto wants_grad = [&](int b) { return needs[b] != 0; };
 
   // who writes a buffer as a whole (a unit whose output IS the buffer) and who reads it first (forward order = the last
   // contributor to its gradient in the reverse sweep)

@@ -41,8 +41,8 @@ class _Program:
         self.cols: List[int] = []         # per buffer
         self.rows_of: List[tuple] = []    # per buffer: ("in",) | ("table_out", t) | ("keep", k)
         self.units: List[tuple] = []      # (conv module, bn module)
-        self.n_tables = 0
-        self.n_keeps = 0
+        self.table_getters: List = []     # per table: ctx -> Rulebook   (ctx = whatever the model hands to run_program)
+        self.keep_getters: List = []      # per keep:  ctx -> int64 row indices
         self.outputs: List[int] = []      # buffer ids handed back to the caller
 
     def buf(self, cols: int, rows_of: tuple) -> int:
@@ -54,9 +54,52 @@ class _Program:
         self.units.append((seq[0], seq[1]))
         return len(self.units) - 1
 
-    def table(self) -> int:
-        self.n_tables += 1
-        return self.n_tables - 1
+    def table(self, getter) -> int:
+        self.table_getters.append(getter)
+        return len(self.table_getters) - 1
+
+    def keep(self, getter) -> int:
+        self.keep_getters.append(getter)
+        return len(self.keep_getters) - 1
+
+    def add_unit(self, seq, src: int, table: int, dst: Optional[int] = None, dst_col0: int = 0) -> int:
+        """Append one post_act_block; -> its output buffer (a new dense one unless `dst` is given)."""
+        if dst is None:
+            dst = self.buf(seq[0].weight.shape[0], ("table_out", table))
+        self.ops.append((_lib.PASS_UNIT, src, dst, dst_col0, self.unit(seq), table, 0, 1))
+        return dst
+
+    def add_gather(self, src: int, keep: int) -> int:
+        dst = self.buf(self.cols[src], ("keep", keep))
+        self.ops.append((_lib.PASS_GATHER, src, dst, 0, 0, 0, keep, 0))
+        return dst
+
+    def add_nrconv_chain(self, cur: int, blocks, discard_flags, training: bool, stage_of) -> int:
+        """The chain of NRConvBlocks (spconv_backbone.py:150-229) + the layer discard after a block whose flag is set; every
+        block's (post-discard) output is appended to `outputs`.  `stage_of(ctx, bi)` -> the block's plan dict."""
+        for bi, (blk, flag) in enumerate(zip(blocks, discard_flags)):
+            kd, k3, k2 = blk._keys()
+            if blk.stride > 1:
+                cur = self.add_unit(blk.down_layer, cur, self.table(lambda c, bi=bi, kd=kd: stage_of(c, bi)["rb3d"][kd]))
+            t3 = self.table(lambda c, bi=bi, k3=k3: stage_of(c, bi)["rb3d"][k3])
+            t2 = self.table(lambda c, bi=bi, k2=k2: stage_of(c, bi)["rb2d"][k2])
+            ch = blk.d3_conv1[0].weight.shape[0]
+            f3 = self.add_unit(blk.d3_conv2, self.add_unit(blk.d3_conv1, cur, t3), t3)
+            cat = self.buf(2 * ch, ("table_out", t3))
+            # the first 2-D unit reads f3 BEFORE f3 is copied into the concat: in the reverse sweep the concat slice then arrives
+            # first and the unit's backward-input conv -- the last contributor to f3's gradient -- adds it in its epilogue
+            g1 = self.add_unit(blk.d2_conv1, f3, t2, self.buf(ch, ("table_out", t3)))
+            self.ops.append((_lib.PASS_COPY, f3, cat, 0, 0, 0, 0, 0))
+            if training:
+                self.add_unit(blk.d2_conv2, g1, t2, cat, ch)                      # concat written in place
+            else:   # eval: one launch per unit (BatchNorm folded into the conv store, dense rows), both halves are copied
+                g2 = self.add_unit(blk.d2_conv2, g1, t2, self.buf(ch, ("table_out", t3)))
+                self.ops.append((_lib.PASS_COPY, g2, cat, ch, 0, 0, 0, 0))
+            cur = cat
+            if flag:
+                cur = self.add_gather(cat, self.keep(lambda c, bi=bi: stage_of(c, bi)["keep"]))
+            self.outputs.append(cur)
+        return cur
 
     def freeze(self):
         n = len(self.ops)
@@ -89,76 +132,76 @@ def unit_is_plain(seq) -> bool:
 def build_virconv_l_program(model, discard_active: bool, training: bool) -> _Program:
     """VirConvL8x: four NRConvBlocks (+ the layer discard after the first three in training) and conv_out.  Training: the
     second 2-D unit writes its half of the channel concat in place.  Eval: every unit is ONE launch (BatchNorm folded into the
-    conv store, which writes dense rows), so both halves are copied into the concat."""
+    conv store, which writes dense rows), so both halves are copied into the concat.  ctx = the geometry plan."""
     P = _Program()
     cur = P.buf(model.vir_conv1.d3_conv1[0].weight.shape[-1], ("in",))
-    P.plan_tables = []   # per table: (stage index | "conv_out", key kind)
-    P.plan_keeps = []    # per keep: stage index
-    for bi, blk in enumerate([model.vir_conv1, model.vir_conv2, model.vir_conv3, model.vir_conv4]):
-        if blk.stride > 1:
-            t = P.table()
-            P.plan_tables.append((bi, "down"))
-            u = P.unit(blk.down_layer)
-            d = P.buf(blk.down_layer[0].weight.shape[0], ("table_out", t))
-            P.ops.append((_lib.PASS_UNIT, cur, d, 0, u, t, 0, 1))
-            cur = d
-        t3, t2 = P.table(), P.table()
-        P.plan_tables += [(bi, "3d"), (bi, "2d")]
-        c = blk.d3_conv1[0].weight.shape[0]
-        f1 = P.buf(c, ("table_out", t3))
-        f3 = P.buf(c, ("table_out", t3))
-        g1 = P.buf(c, ("table_out", t3))
-        cat = P.buf(2 * c, ("table_out", t3))
-        P.ops.append((_lib.PASS_UNIT, cur, f1, 0, P.unit(blk.d3_conv1), t3, 0, 1))
-        P.ops.append((_lib.PASS_UNIT, f1, f3, 0, P.unit(blk.d3_conv2), t3, 0, 1))
-        # the first 2-D unit reads f3 BEFORE f3 is copied into the concat: in the reverse sweep the concat slice then arrives first
-        # and the unit's backward-input conv -- the last contributor to f3's gradient -- adds it in its epilogue
-        P.ops.append((_lib.PASS_UNIT, f3, g1, 0, P.unit(blk.d2_conv1), t2, 0, 1))
-        P.ops.append((_lib.PASS_COPY, f3, cat, 0, 0, 0, 0, 0))
-        if training:
-            P.ops.append((_lib.PASS_UNIT, g1, cat, c, P.unit(blk.d2_conv2), t2, 0, 1))      # concat written in place
-        else:
-            g2 = P.buf(c, ("table_out", t3))
-            P.ops.append((_lib.PASS_UNIT, g1, g2, 0, P.unit(blk.d2_conv2), t2, 0, 1))
-            P.ops.append((_lib.PASS_COPY, g2, cat, c, 0, 0, 0, 0))
-        cur = cat
-        if discard_active and bi < 3:
-            k = P.n_keeps
-            P.n_keeps += 1
-            P.plan_keeps.append(bi)
-            kept = P.buf(2 * c, ("keep", k))
-            P.ops.append((_lib.PASS_GATHER, cat, kept, 0, 0, 0, k, 0))
-            cur = kept
-        P.outputs.append(cur)
-    t = P.table()
-    P.plan_tables.append(("conv_out", None))
-    out = P.buf(model.conv_out[0].weight.shape[0], ("table_out", t))
-    P.ops.append((_lib.PASS_UNIT, cur, out, 0, P.unit(model.conv_out), t, 0, 1))
-    P.outputs.append(out)
+    blocks = [model.vir_conv1, model.vir_conv2, model.vir_conv3, model.vir_conv4]
+    cur = P.add_nrconv_chain(cur, blocks, [discard_active and bi < 3 for bi in range(4)], training,
+                             lambda plan, bi: plan["stages"][bi])
+    key = model.conv_out[0].indice_key
+    P.outputs.append(P.add_unit(model.conv_out, cur, P.table(lambda plan: plan["conv_out"][key])))
     return P.freeze()
 
 
-def _plan_table(model, plan, entry):
-    where, kind = entry
-    if where == "conv_out":
-        return plan["conv_out"][model.conv_out[0].indice_key]
-    blk = [model.vir_conv1, model.vir_conv2, model.vir_conv3, model.vir_conv4][where]
-    kd, k3, k2 = blk._keys()
-    st = plan["stages"][where]
-    return st["rb3d"][kd] if kind == "down" else (st["rb3d"][k3] if kind == "3d" else st["rb2d"][k2])
+def build_virconv8x_lidar_program(model) -> _Program:
+    """VirConv8x LiDAR stream (spconv_backbone.py:362-407): conv_input, conv1..conv4 (a strided unit + two SubM units sharing
+    one rulebook per stage), conv_out.  Outputs x_conv1..4 and the encoded tensor.  ctx = {indice_key: Rulebook}."""
+    P = _Program()
+    cur = P.buf(model.conv_input[0].weight.shape[-1], ("in",))
+    tables = {}
+
+    def tbl(seq):
+        key = seq[0].indice_key
+        if key not in tables:
+            tables[key] = P.table(lambda rbs, key=key: rbs[key])
+        return tables[key]
+
+    cur = P.add_unit(model.conv_input, cur, tbl(model.conv_input))
+    for stage in (model.conv1, model.conv2, model.conv3, model.conv4):
+        for unit in stage:
+            cur = P.add_unit(unit, cur, tbl(unit))
+        P.outputs.append(cur)
+    P.outputs.append(P.add_unit(model.conv_out, cur, tbl(model.conv_out)))
+    return P.freeze()
+
+
+def build_virconv8x_mm_program(model, discard_active: bool) -> _Program:
+    """VirConv8x virtual-point stream (spconv_backbone.py:444-535): the input discard (:488-489) and four NRConvBlocks with the
+    layer discard after the first three.  ctx = plan["mm"][rid]."""
+    P = _Program()
+    cur = P.buf(model.vir_conv1.d3_conv1[0].weight.shape[-1], ("in",))
+    if discard_active:
+        cur = P.add_gather(cur, P.keep(lambda pm: pm["keep0"]))
+    blocks = [model.vir_conv1, model.vir_conv2, model.vir_conv3, model.vir_conv4]
+    P.add_nrconv_chain(cur, blocks, [discard_active and bi < 3 for bi in range(4)], True, lambda pm, bi: pm["stages"][bi])
+    return P.freeze()
+
+
+def _units_ok(seqs, training: bool) -> bool:
+    return all(unit_is_plain(s) and s[1].training == training for s in seqs)
+
+
+def _backend_ok(feats: torch.Tensor) -> bool:
+    be = ops.get_backend()
+    return bool(NATIVE_PASS and ops.FUSED_UNIT_CALLS and not ops.OVERLAP_WEIGHT_GRAD and getattr(be, "native_pass", False)
+                and feats.is_cuda and feats.dtype == torch.float32 and feats.shape[0] > 0)
+
+
+def _nrconv_seqs(blocks):
+    seqs = []
+    for blk in blocks:
+        if blk.conv_depth:
+            return None
+        seqs += ([blk.down_layer] if blk.stride > 1 else []) + [blk.d3_conv1, blk.d3_conv2, blk.d2_conv1, blk.d2_conv2]
+    return seqs
 
 
 def usable(model, feats: torch.Tensor, plan) -> bool:
-    be = ops.get_backend()
-    if not (NATIVE_PASS and ops.FUSED_UNIT_CALLS and not ops.OVERLAP_WEIGHT_GRAD and getattr(be, "native_pass", False)
-            and feats.is_cuda and feats.dtype == torch.float32 and feats.shape[0] > 0):
+    """VirConvL8x: may this call take the native pass?"""
+    if not _backend_ok(feats):
         return False
-    seqs = [model.conv_out]
-    for blk in (model.vir_conv1, model.vir_conv2, model.vir_conv3, model.vir_conv4):
-        seqs += ([blk.down_layer] if blk.stride > 1 else []) + [blk.d3_conv1, blk.d3_conv2, blk.d2_conv1, blk.d2_conv2]
-        if blk.conv_depth:
-            return False
-    if not all(unit_is_plain(s) and s[1].training == model.training for s in seqs):
+    seqs = _nrconv_seqs([model.vir_conv1, model.vir_conv2, model.vir_conv3, model.vir_conv4])
+    if seqs is None or not _units_ok(seqs + [model.conv_out], model.training):
         return False
     if not model.training:
         # eval: the node-by-node path is already ONE launch per unit (BatchNorm folded into the conv store) and at bs 1 the step is
@@ -172,6 +215,17 @@ def usable(model, feats: torch.Tensor, plan) -> bool:
     return True
 
 
+def usable_8x(model, feats: torch.Tensor, stream: str) -> bool:
+    """VirConv8x, training mode only: the LiDAR stream ("lidar") or the virtual-point stream ("mm")."""
+    if not (model.training and _backend_ok(feats)):
+        return False
+    if stream == "lidar":
+        seqs = [model.conv_input, model.conv_out] + [u for st in (model.conv1, model.conv2, model.conv3, model.conv4) for u in st]
+    else:
+        seqs = _nrconv_seqs([model.vir_conv1, model.vir_conv2, model.vir_conv3, model.vir_conv4])
+    return seqs is not None and _units_ok(seqs, True)
+
+
 _PROGRAMS = weakref.WeakKeyDictionary()   # model -> {(discard_active, training): _Program}; kept off the module (deepcopy / pickle safe)
 
 
@@ -180,11 +234,11 @@ class _Call:
     __slots__ = ("prog", "c_prog", "c_bufs", "c_units", "c_tables", "c_keeps", "arena", "offsets", "keep_alive", "group_bytes")
 
 
-def _fill(model, P: _Program, feats, plan, training: bool) -> Optional[_Call]:
+def _fill(P: _Program, feats, ctx, training: bool) -> Optional[_Call]:
     call = _Call()
     call.prog = P
-    tables = [_plan_table(model, plan, e) for e in P.plan_tables]
-    keeps = [plan["stages"][bi]["keep"] for bi in P.plan_keeps]
+    tables = [g(ctx) for g in P.table_getters]
+    keeps = [g(ctx) for g in P.keep_getters]
     if any(rb.n_out <= 0 or rb.n_in <= 0 for rb in tables) or any(k is None or k.shape[0] == 0 for k in keeps):
         return None
     c_tables = (_lib.PassTable * len(tables))()
@@ -307,18 +361,39 @@ class PassFunction(torch.autograd.Function):
         return (gin, None, *grads)
 
 
-def run(model, feats: torch.Tensor, plan):
-    """-> [x_conv1, x_conv2, x_conv3, x_conv4, out] feature matrices, or None when this call cannot take the native pass."""
-    discard = model._discard_active()
-    cache = _PROGRAMS.setdefault(model, {})
-    key = (discard, bool(model.training))
-    P = cache.get(key)
-    if P is None:
-        P = cache[key] = build_virconv_l_program(model, discard, bool(model.training))
-    call = _fill(model, P, feats, plan, model.training)
+def _run_program(P: _Program, feats: torch.Tensor, ctx, training: bool):
+    call = _fill(P, feats, ctx, training)
     if call is None:
         return None
     params = []
     for conv, bn in P.units:
         params += [conv.weight, bn.weight, bn.bias]
     return PassFunction.apply(feats, call, *params)
+
+
+def _program(model, key, build):
+    cache = _PROGRAMS.setdefault(model, {})
+    P = cache.get(key)
+    if P is None:
+        P = cache[key] = build()
+    return P
+
+
+def run(model, feats: torch.Tensor, plan):
+    """VirConvL8x -> [x_conv1, x_conv2, x_conv3, x_conv4, out] feature matrices, or None when this call cannot take the native
+    pass (an empty tensor somewhere)."""
+    discard, training = model._discard_active(), bool(model.training)
+    P = _program(model, ("L", discard, training), lambda: build_virconv_l_program(model, discard, training))
+    return _run_program(P, feats, plan, training)
+
+
+def run_8x_lidar(model, feats: torch.Tensor, rbs):
+    """VirConv8x LiDAR stream (training) -> [x_conv1..4, out] feature matrices or None."""
+    return _run_program(_program(model, ("8x-lidar",), lambda: build_virconv8x_lidar_program(model)), feats, rbs, True)
+
+
+def run_8x_mm(model, feats: torch.Tensor, pm):
+    """VirConv8x virtual-point stream (training) -> [m1..m4] feature matrices (each after its layer discard) or None."""
+    discard = model._discard_active()
+    P = _program(model, ("8x-mm", discard), lambda: build_virconv8x_mm_program(model, discard))
+    return _run_program(P, feats, pm, True)
