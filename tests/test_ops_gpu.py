@@ -1013,3 +1013,44 @@ def test_rep_order_is_a_stable_partition_and_never_changes_the_duplicate_pixel_b
     b = hip_backend.conv_backward_input(g, w, pair, n, mirror=True, centre=4, rep=rep, order=order)
     assert torch.equal(a, b)
     assert hip_backend.rep_order(rep[:0]).shape == (0,)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout", [(20, 12), (68, 36), (8, 72), (6, 10)])
+def test_facade_handles_channel_counts_the_kernels_are_not_instantiated_for(hip_backend, cin, cout):
+    """channel counts outside {4, 8, 16, 32, 64} (e.g. NRConvBlock(conv_depth=True): 16 + 4 input channels,
+    spconv_backbone.py:172-173) are tiled into supported pieces with zero padding instead of failing: a SubM conv + BatchNorm1d +
+    ReLU unit of the façade, forward and backward, against the oracle."""
+    from oracle.backend import OracleBackend
+    from virconv_amd import spconv
+    rng = np.random.default_rng(5)
+    shape = [9, 40, 36]
+    n = 3000
+    lin = rng.choice(2 * shape[0] * shape[1] * shape[2], size=n, replace=False)
+    b, rem = np.divmod(lin, shape[0] * shape[1] * shape[2])
+    z, rem = np.divmod(rem, shape[1] * shape[2])
+    y, x = np.divmod(rem, shape[2])
+    idx = torch.from_numpy(np.stack([b, z, y, x], 1).astype(np.int32))
+    feats = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32))
+    g = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32))
+
+    def build():
+        torch.manual_seed(3)
+        seq = spconv.SparseSequential(spconv.SubMConv3d(cin, cout, 3, padding=1, bias=False, indice_key="k"),
+                                      torch.nn.BatchNorm1d(cout, eps=1e-3, momentum=0.01), torch.nn.ReLU())
+        return seq.train()
+
+    def run(seq, dev):
+        f = feats.to(dev).requires_grad_(True)
+        sp = spconv.SparseConvTensor(f, idx.to(dev), shape, 2)
+        out = seq(sp).features
+        (out * g.to(dev)).sum().backward()
+        return (out.detach().cpu(), f.grad.cpu(), seq[0].weight.grad.cpu(), seq[1].weight.grad.cpu(), seq[1].bias.grad.cpu(),
+                seq[1].running_mean.cpu().clone(), seq[1].running_var.cpu().clone())
+
+    with ops.use_backend(OracleBackend()):
+        ref = run(build(), "cpu")
+    got = run(build().cuda(), "cuda")
+    for a, b_, name in zip(got, ref, ("out", "dx", "dw", "dgamma", "dbeta", "running_mean", "running_var")):
+        tol = 2e-4 * max(1.0, float(b_.abs().max()))
+        assert float((a - b_).abs().max()) <= tol, (name, float((a - b_).abs().max()), tol)

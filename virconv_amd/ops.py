@@ -334,8 +334,38 @@ def _side_stream(device):
     return _SIDE_STREAMS[key]
 
 
+_CONV_CHANNELS = (4, 8, 16, 32, 64)        # channel counts the gather-GEMM / weight-gradient kernels are instantiated for
+_BN_CHANNELS = (4, 8, 16, 32, 64, 128)
+
+
+def _channel_pieces(c: int, sizes):
+    """[(first, last, padded)] covering range(c) with pieces of at most max(sizes) channels, each padded up to a supported size."""
+    out, a, top = [], 0, max(sizes)
+    while a < c:
+        b = min(c, a + top)
+        out.append((a, b, min(s for s in sizes if s >= b - a)))
+        a = b
+    return out
+
+
 def sparse_conv(features: torch.Tensor, weight: torch.Tensor, rb: Rulebook, inverse: bool = False) -> torch.Tensor:
-    return SparseConvFunction.apply(features, weight, rb, inverse)
+    """Sparse conv for ANY channel counts.  The kernels serve 4/8/16/32/64 channels on either side (every layer of the reference's
+    models); other counts (e.g. NRConvBlock(conv_depth=True): +4 input channels, spconv_backbone.py:172-173) are tiled into
+    supported pieces with zero padding -- same kernels, differentiable through the pad / slice / add ops around them."""
+    cout, cin = weight.shape[0], weight.shape[-1]
+    if (cin in _CONV_CHANNELS and cout in _CONV_CHANNELS) or not features.is_cuda:
+        return SparseConvFunction.apply(features, weight, rb, inverse)
+    F = torch.nn.functional
+    outs = []
+    for o0, o1, op in _channel_pieces(cout, _CONV_CHANNELS):
+        acc = None
+        for i0, i1, ip in _channel_pieces(cin, _CONV_CHANNELS):
+            x = F.pad(features[:, i0:i1], (0, ip - (i1 - i0)))
+            w = F.pad(weight[o0:o1, ..., i0:i1], (0, ip - (i1 - i0)) + (0, 0) * (weight.dim() - 2) + (0, op - (o1 - o0)))
+            y = SparseConvFunction.apply(x.contiguous(), w.contiguous(), rb, inverse)[:, :o1 - o0]
+            acc = y if acc is None else acc + y
+        outs.append(acc)
+    return outs[0] if len(outs) == 1 else torch.cat(outs, 1)
 
 
 class GatherRowsFunction(torch.autograd.Function):
@@ -426,7 +456,25 @@ def bn_relu(x: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool) -> torch.Tens
     rv = bn.running_var if bn.track_running_stats else None
     # num_batches_tracked is incremented inside the stats-finalize kernel (no extra launch)
     nbt = bn.num_batches_tracked if (training and bn.track_running_stats) else None
-    return BNReLUFunction.apply(x, bn.weight, bn.bias, rm, rv, training, momentum, bn.eps, relu, nbt)
+    c = x.shape[1]
+    if c in _BN_CHANNELS or not x.is_cuda or bn.weight is None:
+        return BNReLUFunction.apply(x, bn.weight, bn.bias, rm, rv, training, momentum, bn.eps, relu, nbt)
+    # any other channel count: BatchNorm is per channel, so it is applied piecewise on zero-padded channel slices (a padded
+    # channel has mean 0 / variance 0 and is cut off again); running statistics are updated on padded copies and written back
+    F = torch.nn.functional
+    outs = []
+    for k, (a, b, p_) in enumerate(_channel_pieces(c, _BN_CHANNELS)):
+        pad = (0, p_ - (b - a))
+        rm_p = F.pad(rm[a:b], pad) if rm is not None else None
+        rv_p = F.pad(rv[a:b], pad, value=1.0) if rv is not None else None
+        y = BNReLUFunction.apply(F.pad(x[:, a:b], pad).contiguous(), F.pad(bn.weight[a:b], pad), F.pad(bn.bias[a:b], pad), rm_p,
+                                 rv_p, training, momentum, bn.eps, relu, nbt if k == 0 else None)
+        if training and rm is not None:
+            with torch.no_grad():
+                rm[a:b].copy_(rm_p[:b - a])
+                rv[a:b].copy_(rv_p[:b - a])
+        outs.append(y[:, :b - a])
+    return outs[0] if len(outs) == 1 else torch.cat(outs, 1)
 
 
 def project_uv(indices, calib, trans, batch_size, stride):

@@ -77,7 +77,9 @@ class SparseConvolution(SparseModule):
 
     @property
     def fusable_with_bn(self) -> bool:
-        return self.bias is None
+        # the fused conv+BN(+ReLU) operators exist for the channel counts the kernels are instantiated for; anything else takes
+        # the generic (channel-tiled) ops.sparse_conv + ops.bn_relu
+        return self.bias is None and self.in_channels in ops._CONV_CHANNELS and self.out_channels in ops._CONV_CHANNELS
 
     def forward(self, x: SparseConvTensor, fuse_bn=None, fuse_relu: bool = False) -> SparseConvTensor:
         """`fuse_bn` (set by SparseSequential): the BatchNorm1d that follows this conv, folded into the same operator --

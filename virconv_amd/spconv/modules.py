@@ -83,7 +83,7 @@ class SparseSequential(SparseModule):
                 if input.indices.shape[0] != 0:
                     feats = input.features
                     fused = (self.fuse_bn_relu and type(module) is nn.BatchNorm1d and feats.is_cuda
-                             and module.affine and module.momentum is not None and feats.shape[1] % 4 == 0)
+                             and module.affine and module.momentum is not None)
                     if fused:
                         relu = k + 1 < len(mods) and type(mods[k + 1]) is nn.ReLU
                         input = input.replace_feature(ops.bn_relu(feats, module, relu))
