@@ -1041,7 +1041,7 @@ def test_facade_handles_channel_counts_the_kernels_are_not_instantiated_for(hip_
         return seq.train()
 
     def run(seq, dev):
-        f = feats.to(dev).requires_grad_(True)
+        f = feats.clone().to(dev).detach().requires_grad_(True)
         sp = spconv.SparseConvTensor(f, idx.to(dev), shape, 2)
         out = seq(sp).features
         (out * g.to(dev)).sum().backward()
