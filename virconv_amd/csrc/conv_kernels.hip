@@ -552,6 +552,288 @@ __global__ void __launch_bounds__(64 * NW) gather_gemm_v2_kernel(const float* __
   }
 }
 
+// --------------------------------------------------------------------------------------------- K6/K7 v4 (wave-autonomous)
+// Round 2, second design of the gather-GEMM for the MFMA-bound shapes (both channel counts multiples of 16).  v2's counters say
+// its matrix pipes are busy 56 % of the time although every resource it uses is far from saturated: each block walks its active
+// offsets in lock step (one barrier + one LDS-staged W_k image per offset, 32 MFMAs per wave between barriers), so a wave's
+// MFMA burst is short and every burst is gated by the slowest of four waves sitting on four different SIMDs.  v4 removes the
+// coupling instead of tuning it:
+//   * a workgroup is ONE wave that owns 64 consecutive output rows (4 MFMA row tiles): no block barrier anywhere;
+//   * W_k goes from L2 straight into the wave's registers in MFMA-fragment order (the canonical (Cout, KV, Cin) layout already
+//     gives a lane its fragment as contiguous 16 bytes; the transposed backward reads are dwords): the same L2 traffic per row
+//     as a 64-row block sharing one staged image, no LDS round trip; W_{k+1} is loaded while the four tiles of offset k
+//     compute (register ping-pong), i.e. one W_k load is amortised over up to 4 x 32 MFMAs of the same wave;
+//   * the gathers are pipelined at TILE granularity: while tile t of offset k runs its MFMAs, the rows of the next tile slot
+//     are in flight into the other A register set and the pair-table entries of the slot after that are being read from LDS;
+//     every load is unconditional (index -1 -> out-of-range buffer offset -> zeros), the body is straight-line code per
+//     offset pair, so hipcc keeps counted vmcnt waits;
+//   * consecutive MFMAs alternate between the output-column accumulators (no dependent back-to-back pair);
+//   * LDS holds only the wave's slice of the pair table (KV x 64 ints) -- 7 KB per wave.
+// Same arithmetic per output row as v2 (offsets ascending, K order (ch, j, q)): results are bit-identical to v2's.
+template <int NB>
+struct BufLoadS;
+template <>
+struct BufLoadS<4> {
+  static __device__ __forceinline__ void ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float* o) {
+    i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    o[0] = __int_as_float(v.x); o[1] = __int_as_float(v.y); o[2] = __int_as_float(v.z); o[3] = __int_as_float(v.w);
+  }
+};
+template <>
+struct BufLoadS<1> {
+  static __device__ __forceinline__ void ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float* o) {
+    o[0] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+  }
+};
+
+template <int CK, int CN, bool BWD, int EPI>
+__global__ void __launch_bounds__(64) gather_gemm_v4_kernel(const float* __restrict__ src,
+                                                            const float* __restrict__ src_centre, int64_t n_src,
+                                                            const int32_t* __restrict__ tbl,
+                                                            const float* __restrict__ w, float* __restrict__ out,
+                                                            const int32_t* __restrict__ rep,
+                                                            const int32_t* __restrict__ order, int64_t n_out, int kv,
+                                                            int centre, int mirror, ConvEpilogue epi) {
+  static_assert(CK % 16 == 0 && CN % 16 == 0, "v4 serves channel counts that are multiples of 16");
+  static_assert(EPI == VC_EPI_NONE || (EPI == VC_EPI_BWD) == BWD, "STATS / AFFINE: forward kernel; BWD: backward-input kernel");
+  constexpr int RT = 4, R = 64;
+  constexpr int NCH = CK / 16, NT = CN / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int* s_idx = reinterpret_cast<int*>(smem);  // [kv][64]
+  int* s_row = s_idx + kv * R;                // [64] output row of each slot (-1: none)
+
+  const int lane = threadIdx.x;
+  const int i = lane & 15, q = lane >> 4;
+  int64_t lbid;
+  {  // XCD-aware block -> row-range mapping (see v2)
+    const unsigned nb = gridDim.x, bid = blockIdx.x, xcd = bid & 7u, qd = nb >> 3, rm = nb & 7u;
+    lbid = (int64_t)(xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    if (g_xcd_swizzle_off) lbid = bid;
+  }
+  const int64_t brow0 = lbid * R;
+
+  const __amdgpu_buffer_rsrc_t rs_src =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)(n_src * CK * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_ctr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(src_centre ? src_centre : src), 0, (int)(n_src * CK * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, (int)(kv * CK * CN * 4), 0x00020000);
+
+  // ---- the wave's slice of the pair table -> LDS, per-tile active-offset masks (bit k of tm[t]: tile t owns offset k)
+  unsigned tm[RT] = {0u, 0u, 0u, 0u};
+  {
+    const bool inb = brow0 + lane < n_out;
+    const int64_t row = inb ? (order ? (int64_t)order[brow0 + lane] : brow0 + lane) : -1;
+    s_row[lane] = (int)row;
+    const bool centre_only = (rep != nullptr) && inb && (rep[row] != (int32_t)row);
+    for (int k0 = 0; k0 < kv; k0 += 9) {
+      int v[9];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) v[u] = (inb && k0 + u < kv) ? tbl[(int64_t)(k0 + u) * n_out + row] : -1;
+#pragma unroll
+      for (int u = 0; u < 9; ++u) {
+        if (k0 + u < kv) {
+          int x = v[u];
+          if (centre_only && k0 + u != centre) x = -1;
+          s_idx[(k0 + u) * R + lane] = x;
+          const unsigned long long b = __ballot(x >= 0);
+#pragma unroll
+          for (int t = 0; t < RT; ++t)
+            if ((b >> (16 * t)) & 0xFFFFull) tm[t] |= 1u << (k0 + u);
+        }
+      }
+    }
+  }
+  __syncthreads();  // one-wave workgroup: no s_barrier, only the LDS ordering
+  unsigned umask = tm[0] | tm[1] | tm[2] | tm[3];
+  umask = (unsigned)__builtin_amdgcn_readfirstlane((int)umask);
+
+  f32x4 acc[RT][NT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float B0[NCH][NT][4], B1[NCH][NT][4];
+  float A0[NCH][4], A1[NCH][4];
+
+  // per-lane byte offsets of the W fragments
+  //   forward : w[(n * kv + kw) * CK + ch*16 + q*4 .. +3],  n = nt*16 + i   -> voff[nt] + soff(kw) + imm(ch)
+  //   backward: w[((ch*16 + q*4 + j) * kv + kw) * CN + nt*16 + i]          -> voff + soff(ch, j, kw) + imm(nt)
+  unsigned wv[NT];
+  if constexpr (!BWD) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wv[nt] = (unsigned)(((nt * 16 + i) * kv * CK + q * 4) * 4);
+  } else {
+    wv[0] = (unsigned)((q * 4 * kv * CN + i) * 4);
+  }
+
+#define V4_LOAD_B(K, BX)                                                                           \
+  do {                                                                                             \
+    const int kw_ = mirror ? (kv - 1 - (K)) : (K);                                                 \
+    if constexpr (!BWD) {                                                                          \
+      const unsigned so_ = (unsigned)(kw_ * CK * 4);                                               \
+      _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
+          _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                        \
+              BufLoadS<4>::ld(rs_w, wv[nt] + (unsigned)(ch * 64), so_, BX[ch][nt]);                \
+    } else {                                                                                       \
+      _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                          \
+            const unsigned so_ = (unsigned)((((ch * 16 + j) * kv + kw_) * CN) * 4);                \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                      \
+                BufLoadS<1>::ld(rs_w, wv[0] + (unsigned)(nt * 64), so_, &BX[ch][nt][j]);           \
+          }                                                                                        \
+    }                                                                                              \
+  } while (0)
+
+#define V4_IDX(K, T) s_idx[(K) * R + (T) * 16 + i]
+
+#define V4_GATHER(K, ID, AX)                                                                       \
+  do {                                                                                             \
+    const __amdgpu_buffer_rsrc_t rs_ = ((K) == centre) ? rs_ctr : rs_src;                          \
+    const unsigned base_ = (unsigned)(ID) * (unsigned)(CK * 4) + (unsigned)(q * 16);               \
+    _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch) BufLoad<4>::ld(rs_, base_ + (unsigned)(ch * 64), AX[ch]); \
+  } while (0)
+
+#define V4_MFMA(T, K, AX, BX)                                                                      \
+  do {                                                                                             \
+    if ((tm[T] >> (K)) & 1u) {                                                                     \
+      _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j)                                            \
+              _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                    \
+                  acc[T][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(AX[ch][j], BX[ch][nt][j], acc[T][nt], 0, 0, 0); \
+    }                                                                                              \
+  } while (0)
+
+  // one offset KC (its W image in BC, tile 0's rows in A0, idg = table entries of tile 1), next offset KN
+#define V4_OFFSET(KC, KN, BC, BN)                                                                  \
+  do {                                                                                             \
+    V4_LOAD_B(KN, BN);                                                                             \
+    idn = V4_IDX(KC, 2); V4_GATHER(KC, idg, A1); V4_MFMA(0, KC, A0, BC); idg = idn;                \
+    idn = V4_IDX(KC, 3); V4_GATHER(KC, idg, A0); V4_MFMA(1, KC, A1, BC); idg = idn;                \
+    idn = V4_IDX(KN, 0); V4_GATHER(KC, idg, A1); V4_MFMA(2, KC, A0, BC); idg = idn;                \
+    idn = V4_IDX(KN, 1); V4_GATHER(KN, idg, A0); V4_MFMA(3, KC, A1, BC); idg = idn;                \
+  } while (0)
+
+#pragma unroll
+  for (int t = 0; t < RT; ++t) tm[t] = (unsigned)__builtin_amdgcn_readfirstlane((int)tm[t]);
+  if (umask != 0u) {
+    int kc = __ffs((int)umask) - 1, kn;
+    umask &= umask - 1;
+    int idg, idn;
+    V4_LOAD_B(kc, B0);
+    idg = V4_IDX(kc, 0);
+    V4_GATHER(kc, idg, A0);
+    idg = V4_IDX(kc, 1);
+    for (;;) {
+      const bool more0 = umask != 0u;
+      kn = more0 ? (__ffs((int)umask) - 1) : kc;
+      umask &= umask - 1;
+      V4_OFFSET(kc, kn, B0, B1);
+      if (!more0) break;
+      const bool more1 = umask != 0u;
+      kc = more1 ? (__ffs((int)umask) - 1) : kn;
+      umask &= umask - 1;
+      V4_OFFSET(kn, kc, B1, B0);
+      if (!more1) break;
+    }
+  }
+#undef V4_OFFSET
+#undef V4_MFMA
+#undef V4_GATHER
+#undef V4_IDX
+#undef V4_LOAD_B
+
+  // ---- epilogues: as v2, one partial row per 16-row tile (tile index = first row / 16)
+  if constexpr (EPI == VC_EPI_STATS) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      float* prow = epi.partial + ((lbid * RT + t) * 2) * CN;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float sm = ((acc[t][nt][0] + acc[t][nt][1]) + acc[t][nt][2]) + acc[t][nt][3];
+        float sq = ((acc[t][nt][0] * acc[t][nt][0] + acc[t][nt][1] * acc[t][nt][1]) + acc[t][nt][2] * acc[t][nt][2]) +
+                   acc[t][nt][3] * acc[t][nt][3];
+        sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
+        sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
+        const int n = nt * 16 + i;
+        if (q == 0) { prow[n] = sm; prow[CN + n] = sq; }
+      }
+    }
+  }
+  float sc[NT], sh[NT];
+  if constexpr (EPI == VC_EPI_AFFINE) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 16 + i;
+      const float istd = 1.0f / sqrtf(epi.var[n] + epi.eps);
+      sc[nt] = (epi.gamma ? epi.gamma[n] : 1.f) * istd;
+      sh[nt] = (epi.beta ? epi.beta[n] : 0.f) - epi.mean[n] * sc[nt];
+    }
+  }
+  float b_mu[NT], b_istd[NT], b_g[NT], b_bt[NT];
+  const bool bwd_stats = (EPI == VC_EPI_BWD) && epi.y_raw != nullptr;
+  if constexpr (EPI == VC_EPI_BWD) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 16 + i;
+      b_mu[nt] = 0.f; b_istd[nt] = 0.f; b_g[nt] = 1.f; b_bt[nt] = 0.f;
+      if (bwd_stats) {
+        b_mu[nt] = epi.mean[n];
+        b_istd[nt] = 1.0f / sqrtf(epi.var[n] + epi.eps);
+        b_g[nt] = epi.gamma ? epi.gamma[n] : 1.f;
+        b_bt[nt] = epi.beta ? epi.beta[n] : 0.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    int64_t orow[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) orow[reg] = s_row[t * 16 + q * 4 + reg];
+    float b_sa[NT], b_sb[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 16 + i;
+      b_sa[nt] = 0.f; b_sb[nt] = 0.f;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        float v = acc[t][nt][reg];
+        if constexpr (EPI == VC_EPI_AFFINE) {
+          v = v * sc[nt] + sh[nt];
+          if (epi.relu) v = fmaxf(v, 0.f);
+        }
+        if constexpr (EPI == VC_EPI_BWD) {
+          if (orow[reg] >= 0) {
+            if (epi.addend != nullptr) v += epi.addend[orow[reg] * epi.add_stride + epi.add_col0 + n];
+            if (bwd_stats) {
+              const float xh = (epi.y_raw[orow[reg] * CN + n] - b_mu[nt]) * b_istd[nt];
+              float d = v;
+              if (epi.relu && !(xh * b_g[nt] + b_bt[nt] > 0.f)) d = 0.f;
+              b_sa[nt] += d;
+              b_sb[nt] += d * xh;
+            }
+          }
+        }
+        if (orow[reg] >= 0) out[orow[reg] * CN + n] = v;
+      }
+    }
+    if constexpr (EPI == VC_EPI_BWD) {
+      if (bwd_stats) {
+        float* prow = epi.partial + ((lbid * RT + t) * 2) * CN;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          float sa = b_sa[nt], sb = b_sb[nt];
+          sa += __shfl_xor(sa, 16, 64); sb += __shfl_xor(sb, 16, 64);
+          sa += __shfl_xor(sa, 32, 64); sb += __shfl_xor(sb, 32, 64);
+          const int n = nt * 16 + i;
+          if (q == 0) { prow[n] = sa; prow[CN + n] = sb; }
+        }
+      }
+    }
+  }
+}
+
 // --------------------------------------------------------------------------------------------- K6/K7 v3 (LDS row windows)
 // The gather-GEMM for tables whose rows are in ascending coordinate order (the SubM convs of stages 2-4, forward and
 // backward-input): the feature gathers are staged through LDS instead of going L2 -> VGPR per kernel offset.
@@ -1369,8 +1651,18 @@ int g_conv_rt = 0;             // v2 row tiles per wave: 1 (64 rows/block) | 2 (
 // 64-channel instantiations from 6 to 8 waves per SIMD, yet only <CK=32, CN=64, backward-input> gets faster (235 -> 202 us,
 // 103 -> 96 us); the forward kernels tie (1207 vs 1210 us per pass) and the strided backward tables lose 5-7 %.
 int g_conv_nw = 0;
+// Wave-autonomous kernel (v4): vc_debug_set conv_v4 = 0 never | 1 every eligible shape (both channel counts multiples of 16,
+// fp32 operands) | 2 = per shape (the table below, from tools/kbench.py --v4 A/B runs)
+int g_conv_v4 = 2;
+static inline bool conv_use_v4(int ck, int cn, bool bwd) {
+  if (ck % 16 != 0 || cn % 16 != 0 || g_conv_v4 == 0) return false;
+  if (g_conv_v4 == 1) return true;
+  (void)bwd;
+  return false;  // no shape enabled until measured
+}
 static inline int conv_block_waves(int ck, int cn, bool bwd) {
   if (ck < 16 || cn < 16) return 4;
+  if (conv_use_v4(ck, cn, bwd)) return 4;  // 64 rows per workgroup: the same partial-row count as a 4-wave v2 block
   if (g_conv_nw == 8) return 8;
   if (g_conv_nw == 4) return 4;
   return (bwd && ck == 32 && cn == 64) ? 8 : 4;
@@ -1394,6 +1686,26 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
                        int epi_kind, const ConvEpilogue& epi, int flags, hipStream_t st) {
   const int64_t rows_per_block = 4 * kRT * 16;
   g_last_windowed = false;
+  if constexpr (CK % 16 == 0 && CN % 16 == 0) {
+    if (conv_use_v4(CK, CN, BWD) && ot == VC_OPERAND_F32 && kv <= 32 && n_src * CK * 4 < (1LL << 31) &&
+        (int64_t)kv * CK * CN * 4 < (1LL << 31)) {
+      const size_t lds4 = (size_t)(kv + 1) * 64 * sizeof(int);
+      const dim3 grid4((unsigned)cdiv(n_out, 64));
+#define VC_L4(E_) hipLaunchKernelGGL((gather_gemm_v4_kernel<CK, CN, BWD, E_>), grid4, dim3(64), lds4, st, src, src_centre, n_src, \
+                                     tbl, w, out, rep, order, n_out, kv, centre, mirror, epi)
+      bool done = true;
+      if (epi_kind == VC_EPI_NONE) VC_L4(VC_EPI_NONE);
+      else if (BWD && epi_kind == VC_EPI_BWD) { if constexpr (BWD) VC_L4(VC_EPI_BWD); }
+      else if (!BWD && epi_kind == VC_EPI_STATS) { if constexpr (!BWD) VC_L4(VC_EPI_STATS); }
+      else if (!BWD && epi_kind == VC_EPI_AFFINE) { if constexpr (!BWD) VC_L4(VC_EPI_AFFINE); }
+      else done = false;
+#undef VC_L4
+      if (done) {
+        VC_CHECK_LAUNCH("gather_gemm_v4_kernel");
+        return VC_OK;
+      }
+    }
+  }
   if constexpr (CK >= 16) {
     if (conv_block_waves(CK, CN, BWD) == 4 && epi_kind != VC_EPI_BWD && use_window_kernel<CK>(flags, ot, rep, order, n_src, kv, src_centre)) {
       constexpr int NCH = CK / 16, NT = (CN + 15) / 16;
@@ -1620,6 +1932,7 @@ extern "C" {
 int vc_debug_set(const char* key, int value) {
   if (key && !strcmp(key, "conv_variant")) { g_conv_variant = value; return VC_OK; }
   if (key && !strcmp(key, "conv_rt")) { g_conv_rt = value; return VC_OK; }
+  if (key && !strcmp(key, "conv_v4")) { g_conv_v4 = value; return VC_OK; }
   if (key && !strcmp(key, "conv_window")) { g_conv_window = value; return VC_OK; }
   if (key && !strcmp(key, "conv_nw")) { g_conv_nw = (value == 8 || value == 4) ? value : 0; return VC_OK; }
   if (key && !strcmp(key, "conv_wdma")) { g_conv_wdma = value; return VC_OK; }
