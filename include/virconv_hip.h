@@ -121,6 +121,20 @@ int vc_conv_backward_input(const float* dy, const float* dy_centre, int64_t n_sr
                            const int32_t* rep, const int32_t* row_order, int operand_type, int flags, float* dx,
                            void* stream);
 
+/* Fragment-ordered weight images.  The gather-GEMMs re-read W_k once per 64 output rows and kernel offset; from the canonical
+ * (Cout, KV, Cin) layout those reads run at a third of the rate of contiguous ones (a quad of lanes touches four weight rows
+ * KV*Cin*4 bytes apart; tools/ubench/gather_ubench.hip: 9.3 vs 30 TB/s).  vc_conv_pack_weights repacks up to 48 weight tensors
+ * in ONE launch into the order the MFMA B fragments are consumed in -- backward = 0: the image vc_conv_forward* reads,
+ * backward = 1: the transposed image vc_conv_backward_input* reads -- and registers (weight pointer, direction) -> image for the
+ * calling thread: conv launches that follow look their weight pointer up and read the image instead.  The caller owns the
+ * memory (vc_conv_packed_weight_floats floats per tensor; 0 = the shape takes no image, pass packed[i] = NULL), must repack
+ * after every weight update, and ends the association with vc_conv_clear_packed_weights.  Results are bit-identical with and
+ * without an image.  (spconv's implicit-GEMM path keeps a reordered filter copy the same way.)                            */
+size_t vc_conv_packed_weight_floats(int cin, int cout, int kv, int backward);
+int vc_conv_pack_weights(int n, const float* const* weights, const int* cin, const int* cout, const int* kv, int backward,
+                         float* const* packed, void* stream);
+int vc_conv_clear_packed_weights(void);
+
 /* Forward conv with a BatchNorm epilogue (fp32 operands; query vc_conv_epilogue_supported for the shape first):
  *   VC_EPI_STATS   training: besides y the kernel writes per-channel (sum, sum of squares) partial rows [rows][2][cout], one
  *                  per 16-row wave tile (no barrier in the epilogue); vc_conv_stats_partial_floats gives the size -- for

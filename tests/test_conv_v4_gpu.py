@@ -35,11 +35,33 @@ class _V4:
 
 
 def _both(lib, fn):
+    """ref = the LDS-staged kernel reading the canonical weight layout; got / again = the wave-autonomous kernel; every other
+    combination (either kernel with a fragment-ordered weight image) is compared with ref right here, bit for bit."""
+    def same(a, b):
+        if isinstance(a, (tuple, list)):
+            assert len(a) == len(b)
+            for x, y in zip(a, b):
+                same(x, y)
+        elif isinstance(a, dict):
+            for k in a:
+                same(a[k], b[k])
+        elif torch.is_tensor(a):
+            assert a.shape == b.shape and torch.equal(a, b)
     with _V4(lib, 0):
         ref = fn()
+        assert lib.vc_debug_set(b"conv_autopack", 1) == 0
+        try:
+            same(ref, fn())
+        finally:
+            assert lib.vc_debug_set(b"conv_autopack", 0) == 0
     with _V4(lib, 1):
         got = fn()
         again = fn()
+        assert lib.vc_debug_set(b"conv_autopack", 1) == 0
+        try:
+            same(got, fn())
+        finally:
+            assert lib.vc_debug_set(b"conv_autopack", 0) == 0
     return ref, got, again
 
 
@@ -169,7 +191,22 @@ def test_v4_whole_train_step_equals_v2(hip_backend, discard, monkeypatch):
         res["out"] = out["encoded_spconv_tensor"].features.detach().clone()
         return float(loss.detach()), res, {k: p.grad.detach().clone() for k, p in model.named_parameters()}
 
-    ref, got, again = _both(hip_backend.lib, one)
+    lib = hip_backend.lib
+    with _V4(lib, 0):
+        ref = one()                                   # v2, fragment-ordered weight images (the pass packs them)
+        assert lib.vc_debug_set(b"conv_packed", 0) == 0
+        try:
+            canon = one()                             # v2, canonical weight layout
+        finally:
+            assert lib.vc_debug_set(b"conv_packed", 1) == 0
+    assert ref[0] == canon[0]
+    for k in ref[1]:
+        assert torch.equal(ref[1][k], canon[1][k]), k
+    for k in ref[2]:
+        assert torch.equal(ref[2][k], canon[2][k]), k
+    with _V4(lib, 1):
+        got = one()
+        again = one()
     assert ref[0] == got[0]
     for k in ref[1]:
         assert torch.equal(ref[1][k], got[1][k]), k

@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--winrows", type=int, default=32, help="window kernel: rows per wave window, 32 | 24 (vc_debug_set conv_winrows)")
     ap.add_argument("--nw", type=int, default=0, help="direct kernel: waves per block 4 | 8 (vc_debug_set conv_nw); 0 = library default")
     ap.add_argument("--v4", type=int, default=-1, help="wave-autonomous gather-GEMM (vc_debug_set conv_v4): 0 never | 1 every eligible shape | 2 library table; -1 = leave the default")
+    ap.add_argument("--autopack", action="store_true", help="repack the weights into fragment order before every conv launch (vc_debug_set conv_autopack; the pack launch is inside the timing)")
     ap.add_argument("--layers", default="", help="comma-separated substrings: only time layers whose name contains one of them")
     args = ap.parse_args()
     ops.WINDOW_GATHER = bool(args.window)
@@ -68,6 +69,7 @@ def main():
         assert be.lib.vc_debug_set(b"conv_nw", args.nw) == 0
     if args.v4 >= 0:
         assert be.lib.vc_debug_set(b"conv_v4", args.v4) == 0
+    assert be.lib.vc_debug_set(b"conv_autopack", 1 if args.autopack else 0) == 0
     torch.zeros(1, device=dev)
     assert be.lib.vc_debug_set(b"xcd_swizzle_off", 1 if args.no_xcd else 0) == 0
     batch = bench.make_batch(list(range(args.bs)), dev, training=True)

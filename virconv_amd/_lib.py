@@ -38,6 +38,9 @@ SIGNATURES = {
     "vc_voxel_query": (_I, [_P, _SZ, _I64, _I, _P, _P, _P, _P, _I64, _I, _I, _I, _F, _I, _P, _P, _P]),
     "vc_group_points": (_I, [_I, _I64, _I, _I, _P, _P, _P, _P, _P, _P]),
     "vc_group_points_grad": (_I, [_I, _I64, _I, _I64, _I, _P, _P, _P, _P, _P, _P]),
+    "vc_conv_packed_weight_floats": (_SZ, [_I, _I, _I, _I]),
+    "vc_conv_pack_weights": (_I, [_I, _P, _P, _P, _P, _I, _P, _P]),
+    "vc_conv_clear_packed_weights": (_I, []),
     "vc_conv_epilogue_supported": (_I, [_I64, _I, _I, _I, _I]),
     "vc_conv_stats_partial_floats": (_SZ, [_I64, _I64, _I, _I, _I, _I]),
     "vc_conv_forward_epilogue": (_I, [_P, _I64, _P, _I64, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _F, _I, _P, _P]),

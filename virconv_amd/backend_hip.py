@@ -59,6 +59,8 @@ class HipBackend:
         self._trace_cap, self._trace_pairs = 0, None
         if os.environ.get("VIRCONV_CONV_NW"):   # waves per block of the direct gather-GEMM (4 | 8), see conv_kernels.hip
             check(self.lib.vc_debug_set(b"conv_nw", int(os.environ["VIRCONV_CONV_NW"])), "vc_debug_set")
+        if os.environ.get("VIRCONV_CONV_PACKED"):   # 0 = ignore the fragment-ordered weight images the pass executor registers (A/B)
+            check(self.lib.vc_debug_set(b"conv_packed", int(os.environ["VIRCONV_CONV_PACKED"])), "vc_debug_set")
         if os.environ.get("VIRCONV_CONV_V4"):   # wave-autonomous gather-GEMM: 0 never | 1 every eligible shape | 2 library table
             check(self.lib.vc_debug_set(b"conv_v4", int(os.environ["VIRCONV_CONV_V4"])), "vc_debug_set")
 

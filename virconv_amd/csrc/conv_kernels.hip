@@ -11,6 +11,8 @@
 //   run-to-run bit-stable.  fp32 MFMA is exact fp32 (bitwise an fmaf chain), so the 1e-4 parity bound holds.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace vc {
@@ -191,6 +193,54 @@ __global__ void __launch_bounds__(256) gather_gemm_kernel(const float* __restric
     }
 }
 
+// --------------------------------------------------------------------------------------------- fragment-ordered weight images
+// Measured (tools/ubench/gather_ubench.hip, MI355X): a wave that reads its W_k fragments from the canonical (Cout, KV, Cin) layout
+// moves 9.3 TB/s over the chip -- a quad of consecutive lanes touches four weight rows 27*Cin*4 bytes apart, and the vector
+// memory pipeline serves one cache line per quad and clock -- against 30 TB/s when every instruction reads 1 KB of contiguous
+// memory.  The gather-GEMMs re-read W_k once per 64 output rows and offset, 0.53 GB per launch of the 64 -> 32 SubM layer, i.e.
+// 57 us of the memory pipeline per launch against 17 us.  So the weights are repacked ONCE per step and direction into the order
+// the MFMA B fragments want (kernel offset k, 16-channel K chunk ch, 16-column N tile nt, lane, 4 floats):
+//   packed[(((k * NCH + ch) * NT + nt) * 64 + lane) * 4 + j] = Wsel(k)[ch*16 + (lane >> 4)*4 + j][nt*16 + (lane & 15)]
+// (columns >= CN are zero).  spconv's implicit-GEMM path also keeps a reordered copy of the filters; here it lives in caller
+// memory (vc_conv_pack_weights) and is looked up by the canonical weight pointer when a conv is launched.
+struct PackDesc {
+  const float* w;
+  float* dst;
+  int ck, cn, kv, bwd;
+};
+static constexpr int kMaxPack = 48;
+struct PackArgs {
+  PackDesc d[kMaxPack];
+};
+__global__ void __launch_bounds__(256) pack_weights_kernel(PackArgs a) {
+  const PackDesc d = a.d[blockIdx.y];
+  const int nch = d.ck / 16, nt_n = (d.cn + 15) / 16;
+  const int total = d.kv * nch * nt_n * 256;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int j = e & 3, lane = (e >> 2) & 63;
+    int f = e >> 8;
+    const int nt = f % nt_n; f /= nt_n;
+    const int ch = f % nch;
+    const int k = f / nch;
+    const int kk = ch * 16 + (lane >> 4) * 4 + j, n = nt * 16 + (lane & 15);
+    float v = 0.f;
+    if (n < d.cn) v = d.bwd ? d.w[((int64_t)kk * d.kv + k) * d.cn + n] : d.w[((int64_t)n * d.kv + k) * d.ck + kk];
+    d.dst[e] = v;
+  }
+}
+
+// canonical weight pointer -> fragment-ordered image (per thread: the pass executor registers before it launches and clears after)
+struct PackedEntry { const float* w; const float* packed; int bwd; };
+static thread_local PackedEntry g_packed[2 * kMaxPack];
+static thread_local int g_n_packed = 0;
+int g_conv_use_packed = 1;  // vc_debug_set conv_packed: 0 = ignore registered images (A/B)
+static inline const float* packed_lookup(const float* w, bool bwd) {
+  if (!g_conv_use_packed) return nullptr;
+  for (int i = 0; i < g_n_packed; ++i)
+    if (g_packed[i].w == w && g_packed[i].bwd == (bwd ? 1 : 0)) return g_packed[i].packed;
+  return nullptr;
+}
+
 // --------------------------------------------------------------------------------------------- K6/K7 v2 (pipelined)
 // Same math and the same fixed accumulation order as gather_gemm_kernel, restructured so that the matrix pipe is not
 // parked behind dependent loads:
@@ -253,7 +303,7 @@ struct ConvEpilogue {
 };
 static constexpr int VC_EPI_BWD = 3;  // internal (not part of vc_epilogue: selected by vc_conv_backward_input_epilogue)
 
-template <int CK, int CN, bool BWD, int RT, int OT, int EPI, int NW = 4>
+template <int CK, int CN, bool BWD, int RT, int OT, int EPI, int NW = 4, bool PK = false>
 __global__ void __launch_bounds__(64 * NW) gather_gemm_v2_kernel(const float* __restrict__ src,
                                                              const float* __restrict__ src_centre, int64_t n_src,
                                                              const int32_t* __restrict__ tbl,
@@ -262,6 +312,7 @@ __global__ void __launch_bounds__(64 * NW) gather_gemm_v2_kernel(const float* __
                                                              const int32_t* __restrict__ order, int64_t n_out, int kv,
                                                              int centre, int mirror, ConvEpilogue epi) {
   static_assert(EPI == VC_EPI_NONE || RT == 1, "epilogues exist for the one-tile-per-wave kernel only");
+  static_assert(!PK || (CK % 16 == 0 && OT == VC_OPERAND_F32), "packed weight images: fp32 operands, 16-channel K chunks");
   static_assert(EPI == VC_EPI_NONE || (EPI == VC_EPI_BWD) == BWD, "STATS / AFFINE: forward kernel; BWD: backward-input kernel");
   constexpr int V = (CK >= 16) ? 4 : CK / 4;
   constexpr int NCH = CK / (4 * V);
@@ -338,6 +389,9 @@ __global__ void __launch_bounds__(64 * NW) gather_gemm_v2_kernel(const float* __
       if (NFRAG % NTHR == 0 || f < NFRAG) {                                                         \
         const int fl = f & 63, nt_ = (f >> 6) % NT, ch_ = (f >> 6) / NT;                           \
         const int n_ = nt_ * 16 + (fl & 15), kk0 = ch_ * 4 * V + (fl >> 4) * V;                    \
+        if constexpr (PK) {  /* fragment-ordered image (vc_conv_pack_weights): 16 contiguous bytes per lane */ \
+          VecLoad<V>::ld(w + ((int64_t)kw_ * NFRAG + f) * V, breg[u]);                             \
+        } else                                                                                     \
         if (CN % 16 == 0 || n_ < CN) {                                                             \
           if (!BWD) {                                                                              \
             VecLoad<V>::ld(w + ((int64_t)n_ * kv + kw_) * CK + kk0, breg[u]);                      \
@@ -586,7 +640,7 @@ struct BufLoadS<1> {
   }
 };
 
-template <int CK, int CN, bool BWD, int EPI>
+template <int CK, int CN, bool BWD, int EPI, bool PK = false>
 __global__ void __launch_bounds__(64) gather_gemm_v4_kernel(const float* __restrict__ src,
                                                             const float* __restrict__ src_centre, int64_t n_src,
                                                             const int32_t* __restrict__ tbl,
@@ -661,7 +715,9 @@ __global__ void __launch_bounds__(64) gather_gemm_v4_kernel(const float* __restr
   //   forward : w[(n * kv + kw) * CK + ch*16 + q*4 .. +3],  n = nt*16 + i   -> voff[nt] + soff(kw) + imm(ch)
   //   backward: w[((ch*16 + q*4 + j) * kv + kw) * CN + nt*16 + i]          -> voff + soff(ch, j, kw) + imm(nt)
   unsigned wv[NT];
-  if constexpr (!BWD) {
+  if constexpr (PK) {
+    wv[0] = (unsigned)(lane * 16);
+  } else if constexpr (!BWD) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) wv[nt] = (unsigned)(((nt * 16 + i) * kv * CK + q * 4) * 4);
   } else {
@@ -671,7 +727,12 @@ __global__ void __launch_bounds__(64) gather_gemm_v4_kernel(const float* __restr
 #define V4_LOAD_B(K, BX)                                                                           \
   do {                                                                                             \
     const int kw_ = mirror ? (kv - 1 - (K)) : (K);                                                 \
-    if constexpr (!BWD) {                                                                          \
+    if constexpr (PK) {  /* fragment-ordered image: every instruction reads 1 KB of contiguous memory */ \
+      const unsigned so_ = (unsigned)(kw_ * (NCH * NT * 1024));                                    \
+      _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
+          _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                        \
+              BufLoadS<4>::ld(rs_w, wv[0], so_ + (unsigned)((ch * NT + nt) * 1024), BX[ch][nt]);   \
+    } else if constexpr (!BWD) {                                                                   \
       const unsigned so_ = (unsigned)(kw_ * CK * 4);                                               \
       _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
           _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                        \
@@ -1651,6 +1712,17 @@ int g_conv_rt = 0;             // v2 row tiles per wave: 1 (64 rows/block) | 2 (
 // 64-channel instantiations from 6 to 8 waves per SIMD, yet only <CK=32, CN=64, backward-input> gets faster (235 -> 202 us,
 // 103 -> 96 us); the forward kernels tie (1207 vs 1210 us per pass) and the strided backward tables lose 5-7 %.
 int g_conv_nw = 0;
+// developer switch conv_autopack (tools/kbench.py --autopack): the stand-alone conv entry points repack the weights into a
+// library-owned scratch right before the launch, so that a kernel can be timed with a fragment-ordered image without a pass
+// executor around it.  The product path never allocates: the pass executor packs into its caller-provided arena.
+int g_conv_autopack = 0;
+static constexpr size_t kAutopackBytes = (size_t)27 * 64 * 64 * sizeof(float);
+static float* autopack_scratch(bool bwd) {
+  static float* buf[2] = {nullptr, nullptr};
+  float*& b = buf[bwd ? 1 : 0];
+  if (b == nullptr && hipMalloc((void**)&b, kAutopackBytes) != hipSuccess) b = nullptr;
+  return b;
+}
 // Wave-autonomous kernel (v4): vc_debug_set conv_v4 = 0 never | 1 every eligible shape (both channel counts multiples of 16,
 // fp32 operands) | 2 = per shape (the table below, from tools/kbench.py --v4 A/B runs)
 int g_conv_v4 = 2;
@@ -1686,13 +1758,36 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
                        int epi_kind, const ConvEpilogue& epi, int flags, hipStream_t st) {
   const int64_t rows_per_block = 4 * kRT * 16;
   g_last_windowed = false;
+  // fragment-ordered weight image registered for this weight tensor and direction (vc_conv_pack_weights), or -- developer
+  // switch conv_autopack, for stand-alone kernel timing -- packed right here into a scratch the library owns
+  const float* wpk = nullptr;
+  if constexpr (CK % 16 == 0 && CN % 16 == 0) {
+    if (ot == VC_OPERAND_F32 && kv <= 32) {
+      wpk = packed_lookup(w, BWD);
+      if (wpk == nullptr && g_conv_autopack) {
+        float* scratch = autopack_scratch(BWD);
+        if (scratch != nullptr && (size_t)kv * CK * CN * sizeof(float) <= kAutopackBytes) {
+          PackArgs pa;
+          pa.d[0] = PackDesc{w, scratch, CK, CN, kv, BWD ? 1 : 0};
+          hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)cdiv((int64_t)kv * CK * CN, 1024), 1), dim3(256), 0, st, pa);
+          VC_CHECK_LAUNCH("pack_weights_kernel");
+          wpk = scratch;
+        }
+      }
+    }
+  }
   if constexpr (CK % 16 == 0 && CN % 16 == 0) {
     if (conv_use_v4(CK, CN, BWD) && ot == VC_OPERAND_F32 && kv <= 32 && n_src * CK * 4 < (1LL << 31) &&
         (int64_t)kv * CK * CN * 4 < (1LL << 31)) {
       const size_t lds4 = (size_t)(kv + 1) * 64 * sizeof(int);
       const dim3 grid4((unsigned)cdiv(n_out, 64));
-#define VC_L4(E_) hipLaunchKernelGGL((gather_gemm_v4_kernel<CK, CN, BWD, E_>), grid4, dim3(64), lds4, st, src, src_centre, n_src, \
-                                     tbl, w, out, rep, order, n_out, kv, centre, mirror, epi)
+#define VC_L4(E_)                                                                                                              \
+  do {                                                                                                                         \
+    if (wpk) hipLaunchKernelGGL((gather_gemm_v4_kernel<CK, CN, BWD, E_, true>), grid4, dim3(64), lds4, st, src, src_centre, n_src, \
+                                tbl, wpk, out, rep, order, n_out, kv, centre, mirror, epi);                                    \
+    else hipLaunchKernelGGL((gather_gemm_v4_kernel<CK, CN, BWD, E_, false>), grid4, dim3(64), lds4, st, src, src_centre, n_src, \
+                            tbl, w, out, rep, order, n_out, kv, centre, mirror, epi);                                          \
+  } while (0)
       bool done = true;
       if (epi_kind == VC_EPI_NONE) VC_L4(VC_EPI_NONE);
       else if (BWD && epi_kind == VC_EPI_BWD) { if constexpr (BWD) VC_L4(VC_EPI_BWD); }
@@ -1753,24 +1848,34 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
         // 8-wave blocks (128 rows): see the kernel's NW parameter
         const size_t lds8 = (size_t)2 * NCH * NT * 64 * V * sizeof(float) + (size_t)(kv + 1) * 128 * sizeof(int) + 16;
         const dim3 grid8((unsigned)cdiv(n_out, 128));
+#define VC_L8(B_, E_)                                                                                                          \
+  do {                                                                                                                         \
+    if constexpr (CN % 16 == 0) {                                                                                              \
+      if (wpk) {                                                                                                               \
+        hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, B_, 1, VC_OPERAND_F32, E_, 8, true>), grid8, dim3(512), lds8, st, src, \
+                           src_centre, n_src, tbl, wpk, out, rep, order, n_out, kv, centre, mirror, epi);                     \
+        break;                                                                                                                 \
+      }                                                                                                                        \
+    }                                                                                                                          \
+    hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, B_, 1, VC_OPERAND_F32, E_, 8, false>), grid8, dim3(512), lds8, st, src,  \
+                       src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, epi);                           \
+  } while (0)
         if constexpr (!BWD) {
           if (epi_kind == VC_EPI_STATS) {
-            hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, false, 1, VC_OPERAND_F32, VC_EPI_STATS, 8>), grid8, dim3(512), lds8, st,
-                               src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, epi);
+            VC_L8(false, VC_EPI_STATS);
             VC_CHECK_LAUNCH("gather_gemm_v2_kernel<stats, 8 waves>");
             return VC_OK;
           }
         }
         if constexpr (BWD) {
           if (epi_kind == VC_EPI_BWD) {
-            hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, true, 1, VC_OPERAND_F32, VC_EPI_BWD, 8>), grid8, dim3(512), lds8, st,
-                               src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, epi);
+            VC_L8(true, VC_EPI_BWD);
             VC_CHECK_LAUNCH("gather_gemm_v2_kernel<bwd epilogue, 8 waves>");
             return VC_OK;
           }
         }
-        hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 1, VC_OPERAND_F32, VC_EPI_NONE, 8>), grid8, dim3(512), lds8, st,
-                           src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, epi);
+        VC_L8(BWD, VC_EPI_NONE);
+#undef VC_L8
         VC_CHECK_LAUNCH("gather_gemm_v2_kernel<8 waves>");
         return VC_OK;
       }
@@ -1779,10 +1884,22 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
                        (size_t)(kv + 1) * 64 * rt * sizeof(int) + 16;
     const dim3 grid((unsigned)cdiv(n_out, (int64_t)64 * rt));
 #define VC_ARGS src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, epi
+#define VC_ARGS_PK src, src_centre, n_src, tbl, wpk, out, rep, order, n_out, kv, centre, mirror, epi
+    // fp32, one tile per wave, 4-wave blocks: the fragment-ordered weight image when there is one
+#define VC_L2(B_, E_)                                                                                                          \
+  do {                                                                                                                         \
+    if constexpr (CK % 16 == 0 && CN % 16 == 0) {                                                                              \
+      if (wpk) {                                                                                                               \
+        hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, B_, 1, VC_OPERAND_F32, E_, 4, true>), grid, dim3(256), lds, st, VC_ARGS_PK); \
+        break;                                                                                                                 \
+      }                                                                                                                        \
+    }                                                                                                                          \
+    hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, B_, 1, VC_OPERAND_F32, E_, 4, false>), grid, dim3(256), lds, st, VC_ARGS); \
+  } while (0)
     if constexpr (BWD) {
       if (epi_kind == VC_EPI_BWD) {
         if (half_ops) { set_error("gather-GEMM: epilogues are implemented for fp32 operands only"); return VC_EINVAL; }
-        hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, true, 1, VC_OPERAND_F32, VC_EPI_BWD>), grid, dim3(256), lds, st, VC_ARGS);
+        VC_L2(true, VC_EPI_BWD);
         VC_CHECK_LAUNCH("gather_gemm_v2_kernel<bwd epilogue>");
         return VC_OK;
       }
@@ -1790,10 +1907,8 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
     if constexpr (!BWD) {
       if (epi_kind != VC_EPI_NONE) {
         if (half_ops) { set_error("gather-GEMM: epilogues are implemented for fp32 operands only"); return VC_EINVAL; }
-        if (epi_kind == VC_EPI_STATS)
-          hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, false, 1, VC_OPERAND_F32, VC_EPI_STATS>), grid, dim3(256), lds, st, VC_ARGS);
-        else
-          hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, false, 1, VC_OPERAND_F32, VC_EPI_AFFINE>), grid, dim3(256), lds, st, VC_ARGS);
+        if (epi_kind == VC_EPI_STATS) VC_L2(false, VC_EPI_STATS);
+        else VC_L2(false, VC_EPI_AFFINE);
         VC_CHECK_LAUNCH("gather_gemm_v2_kernel<epilogue>");
         return VC_OK;
       }
@@ -1811,7 +1926,9 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
       }
     }
     if (rt == 2) hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 2, VC_OPERAND_F32, VC_EPI_NONE>), grid, dim3(256), lds, st, VC_ARGS);
-    else hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, BWD, 1, VC_OPERAND_F32, VC_EPI_NONE>), grid, dim3(256), lds, st, VC_ARGS);
+    else VC_L2(BWD, VC_EPI_NONE);
+#undef VC_L2
+#undef VC_ARGS_PK
 #undef VC_ARGS
     VC_CHECK_LAUNCH("gather_gemm_v2_kernel");
     return VC_OK;
@@ -1933,6 +2050,8 @@ int vc_debug_set(const char* key, int value) {
   if (key && !strcmp(key, "conv_variant")) { g_conv_variant = value; return VC_OK; }
   if (key && !strcmp(key, "conv_rt")) { g_conv_rt = value; return VC_OK; }
   if (key && !strcmp(key, "conv_v4")) { g_conv_v4 = value; return VC_OK; }
+  if (key && !strcmp(key, "conv_autopack")) { g_conv_autopack = value; return VC_OK; }
+  if (key && !strcmp(key, "conv_packed")) { g_conv_use_packed = value; return VC_OK; }
   if (key && !strcmp(key, "conv_window")) { g_conv_window = value; return VC_OK; }
   if (key && !strcmp(key, "conv_nw")) { g_conv_nw = (value == 8 || value == 4) ? value : 0; return VC_OK; }
   if (key && !strcmp(key, "conv_wdma")) { g_conv_wdma = value; return VC_OK; }
@@ -1983,6 +2102,39 @@ int vc_trace_end(vc_trace_record* out, int capacity, int* n_records) {
     VC_CHECK_HIP(hipMemcpy(&out[i].pairs, T.dev_pairs + i, sizeof(int64_t), hipMemcpyDeviceToHost));
   }
   *n_records = n;
+  return VC_OK;
+}
+
+size_t vc_conv_packed_weight_floats(int cin, int cout, int kv, int backward) {
+  const int ck = backward ? cout : cin, cn = backward ? cin : cout;
+  if (cin < 1 || cout < 1 || kv < 1 || kv > 32 || ck % 16 != 0 || cn % 16 != 0) return 0;  // shapes the gather-GEMMs take an image for
+  return (size_t)kv * ck * cn;
+}
+
+int vc_conv_pack_weights(int n, const float* const* weights, const int* cin, const int* cout, const int* kv, int backward,
+                         float* const* packed, void* stream) {
+  VC_REQUIRE(n >= 0 && n <= kMaxPack && (n == 0 || (weights && cin && cout && kv && packed)),
+             "vc_conv_pack_weights: null argument or more than %d tensors", kMaxPack);
+  PackArgs pa;
+  int m = 0, biggest = 0;
+  for (int i = 0; i < n; ++i) {
+    if (packed[i] == nullptr) continue;
+    const size_t fl = vc_conv_packed_weight_floats(cin[i], cout[i], kv[i], backward);
+    VC_REQUIRE(fl != 0 && weights[i], "vc_conv_pack_weights: tensor %d (%d -> %d, kv %d) takes no packed image", i, cin[i], cout[i], kv[i]);
+    VC_REQUIRE(g_n_packed < 2 * kMaxPack, "vc_conv_pack_weights: registry full (vc_conv_clear_packed_weights between passes)");
+    pa.d[m++] = PackDesc{weights[i], packed[i], backward ? cout[i] : cin[i], backward ? cin[i] : cout[i], kv[i], backward ? 1 : 0};
+    g_packed[g_n_packed++] = PackedEntry{weights[i], packed[i], backward ? 1 : 0};
+    biggest = std::max(biggest, (int)fl);
+  }
+  if (m == 0) return VC_OK;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<int64_t>(cdiv(biggest, 1024), 64), (unsigned)m), dim3(256), 0,
+                     (hipStream_t)stream, pa);
+  VC_CHECK_LAUNCH("pack_weights_kernel");
+  return VC_OK;
+}
+
+int vc_conv_clear_packed_weights(void) {
+  g_n_packed = 0;
   return VC_OK;
 }
 

@@ -89,6 +89,7 @@ static int check_program(const vc_pass_program* p) {
 struct FwdLayout {
   std::vector<int64_t> buf_off;            // arena offset of every buffer (-1: external)
   std::vector<size_t> yraw_off, stats_off;  // per op (units, training only)
+  std::vector<int64_t> wpk_off;             // per op: fragment-ordered weight image of the unit's conv (-1: the shape takes none)
   size_t scratch_off = 0, scratch_bytes = 0, total = 0;
 };
 
@@ -99,6 +100,7 @@ static void fwd_layout(const vc_pass_program* p, FwdLayout& L) {
     if (!p->bufs[b].external) L.buf_off[b] = (int64_t)bump.take((size_t)p->bufs[b].rows * p->bufs[b].cols * sizeof(float));
   L.yraw_off.assign(p->n_ops, 0);
   L.stats_off.assign(p->n_ops, 0);
+  L.wpk_off.assign(p->n_ops, -1);
   size_t scratch = 256;
   for (int i = 0; i < p->n_ops; ++i) {
     const vc_pass_op& o = p->ops[i];
@@ -106,6 +108,10 @@ static void fwd_layout(const vc_pass_program* p, FwdLayout& L) {
     const vc_pass_unit& u = p->units[o.unit];
     const vc_pass_table& t = p->tables[o.table];
     const int flags = t.sorted_rows ? VC_CONV_SORTED_ROWS : 0;
+    if (p->operand_type == VC_OPERAND_F32) {
+      const size_t pk = vc_conv_packed_weight_floats(u.cin, u.cout, t.kv, 0);
+      if (pk) L.wpk_off[i] = (int64_t)bump.take(pk * sizeof(float));
+    }
     if (p->training) {
       L.yraw_off[i] = bump.take((size_t)t.n_out * u.cout * sizeof(float));
       L.stats_off[i] = bump.take((size_t)2 * u.cout * sizeof(float));
@@ -123,6 +129,27 @@ static void fwd_layout(const vc_pass_program* p, FwdLayout& L) {
 
 static inline float* buf_ptr(const vc_pass_program* p, const FwdLayout& L, const void* arena, int b) {
   return p->bufs[b].external ? (float*)p->bufs[b].ptr : (float*)((char*)arena + L.buf_off[b]);
+}
+
+// Repack the conv weights of the units in `ops_idx` into fragment order (ONE launch) and register the images for the conv
+// launches of this call; `backward` selects the transposed image the backward-input kernels read.
+static int pack_unit_weights(const vc_pass_program* p, const std::vector<int>& ops_idx, const std::vector<float*>& dst, int backward,
+                             hipStream_t st) {
+  const int chunk = 48;
+  for (size_t b = 0; b < ops_idx.size(); b += chunk) {
+    const int n = (int)std::min<size_t>(chunk, ops_idx.size() - b);
+    const float* w[chunk];
+    float* d[chunk];
+    int ci[chunk], co[chunk], kv[chunk];
+    for (int j = 0; j < n; ++j) {
+      const vc_pass_op& o = p->ops[ops_idx[b + j]];
+      w[j] = p->units[o.unit].weight; d[j] = dst[b + j];
+      ci[j] = p->units[o.unit].cin; co[j] = p->units[o.unit].cout; kv[j] = p->tables[o.table].kv;
+    }
+    const int rc = vc_conv_pack_weights(n, w, ci, co, kv, backward, d, st);
+    if (rc != VC_OK) return rc;
+  }
+  return VC_OK;
 }
 
 static hipEvent_t* pass_events() {
@@ -184,6 +211,33 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
   const size_t bn_off = bump.take(bn_bytes), grp_off = bump.take(grp_bytes), dw_off = bump.take(dw_bytes),
                dw2_off = bump.take(dw_bytes);
   auto at = [&](size_t off) -> float* { return dry ? nullptr : (float*)(arena + off); };
+
+  // transposed fragment-ordered weight images for the backward-input convs (one pack launch for the whole sweep)
+  struct ClearPacked { bool on; ~ClearPacked() { if (on) vc_conv_clear_packed_weights(); } } clear_packed_on_exit{!dry};
+  if (p->operand_type == VC_OPERAND_F32) {
+    std::vector<char> needs0(p->n_bufs, 0);
+    needs0[0] = want_input_grad ? 1 : 0;
+    for (int i = 0; i < p->n_ops; ++i) {
+      const vc_pass_op& o = p->ops[i];
+      if (o.kind == VC_PASS_UNIT) needs0[o.dst] = 1;
+      else if (needs0[o.src]) needs0[o.dst] = 1;
+    }
+    std::vector<int> idx;
+    std::vector<float*> dst;
+    for (int i = 0; i < p->n_ops; ++i) {
+      const vc_pass_op& o = p->ops[i];
+      if (o.kind != VC_PASS_UNIT || !needs0[o.src]) continue;
+      const size_t pk = vc_conv_packed_weight_floats(p->units[o.unit].cin, p->units[o.unit].cout, p->tables[o.table].kv, 1);
+      if (!pk) continue;
+      idx.push_back(i);
+      dst.push_back(at(bump.take(pk * sizeof(float))));
+    }
+    if (!dry) {
+      vc_conv_clear_packed_weights();
+      const int rc = pack_unit_weights(p, idx, dst, 1, st);
+      if (rc != VC_OK) return rc;
+    }
+  }
 
   std::vector<std::vector<GradView>> contrib(p->n_bufs);
   std::vector<int> state(p->n_bufs, 0);  // 0 unresolved, 1 resolved to `res`, 2 no gradient reaches the buffer
@@ -420,6 +474,19 @@ int vc_pass_forward(const vc_pass_program* p, void* arena, size_t arena_bytes, i
   if (buf_offsets)
     for (int b = 0; b < p->n_bufs; ++b) buf_offsets[b] = L.buf_off[b];
   char* scratch = (char*)arena + L.scratch_off;
+  {  // fragment-ordered weight images for every conv whose shape takes one (conv_kernels.hip, "fragment-ordered weight images")
+    std::vector<int> idx;
+    std::vector<float*> dst;
+    for (int i = 0; i < p->n_ops; ++i)
+      if (p->ops[i].kind == VC_PASS_UNIT && L.wpk_off[i] >= 0) {
+        idx.push_back(i);
+        dst.push_back((float*)((char*)arena + L.wpk_off[i]));
+      }
+    vc_conv_clear_packed_weights();
+    rc = pack_unit_weights(p, idx, dst, 0, st);
+    if (rc != VC_OK) { vc_conv_clear_packed_weights(); return rc; }
+  }
+  struct ClearPacked { ~ClearPacked() { vc_conv_clear_packed_weights(); } } clear_packed_on_exit;
   for (int i = 0; i < p->n_ops; ++i) {
     const vc_pass_op& o = p->ops[i];
     const vc_pass_buf &S = p->bufs[o.src], &D = p->bufs[o.dst];
