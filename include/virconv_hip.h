@@ -157,7 +157,7 @@ int vc_conv_forward_epilogue(const float* x, int64_t n_in, const int32_t* pair_f
  *   d = dx masked by that unit's ReLU -- written as per-wave partial rows [rows][2][cin]
  *   (vc_conv_bwd_stats_partial_floats floats), consumed by vc_bn_relu_backward_from_partial.  This removes the unit's own
  *   reduction pass over (y_raw, dy) and the kernel that would add the two contributions.                               */
-size_t vc_conv_bwd_stats_partial_floats(int64_t n_in, int cin, int cout);
+size_t vc_conv_bwd_stats_partial_floats(int64_t n_in, int cin, int cout, int row_ordered /* the launch will take a row_order */);
 int vc_conv_backward_input_epilogue(const float* dy, const float* dy_centre, int64_t n_src, const int32_t* tbl, int64_t n_in,
                                     int kv, const float* weight, int cin, int cout, int mirror, int centre, const int32_t* rep,
                                     const int32_t* row_order, int flags, const float* addend, int add_stride, int add_col0,

@@ -22,7 +22,7 @@ def _rel_err(a, b):
 
 
 class _V4:
-    """with _V4(lib, 1): ... -- force the kernel choice, restore the library default (2 = per-shape table) afterwards"""
+    """with _V4(lib, 1): ... -- force the kernel choice, restore the library default (0 = the LDS-staged kernel) afterwards"""
 
     def __init__(self, lib, value):
         self.lib, self.value = lib, value
@@ -31,7 +31,7 @@ class _V4:
         assert self.lib.vc_debug_set(b"conv_v4", self.value) == 0
 
     def __exit__(self, *a):
-        assert self.lib.vc_debug_set(b"conv_v4", 2) == 0
+        assert self.lib.vc_debug_set(b"conv_v4", 0) == 0
 
 
 def _both(lib, fn):

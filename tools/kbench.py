@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--nw", type=int, default=0, help="direct kernel: waves per block 4 | 8 (vc_debug_set conv_nw); 0 = library default")
     ap.add_argument("--v4", type=int, default=-1, help="wave-autonomous gather-GEMM (vc_debug_set conv_v4): 0 never | 1 every eligible shape | 2 library table; -1 = leave the default")
     ap.add_argument("--autopack", action="store_true", help="repack the weights into fragment order before every conv launch (vc_debug_set conv_autopack; the pack launch is inside the timing)")
+    ap.add_argument("--ablate", type=int, default=0, help="v4 ablations (vc_debug_set conv_v4_ablate; wrong results): 1 no MFMA | 2 coalesced gathers | 3 W from one image | 4 = 2 + 3")
+    ap.add_argument("--pf", type=int, default=1, help="v4 gather prefetch distance (vc_debug_set conv_v4_pf): 1 | 2 | 4")
     ap.add_argument("--layers", default="", help="comma-separated substrings: only time layers whose name contains one of them")
     args = ap.parse_args()
     ops.WINDOW_GATHER = bool(args.window)
@@ -70,6 +72,8 @@ def main():
     if args.v4 >= 0:
         assert be.lib.vc_debug_set(b"conv_v4", args.v4) == 0
     assert be.lib.vc_debug_set(b"conv_autopack", 1 if args.autopack else 0) == 0
+    assert be.lib.vc_debug_set(b"conv_v4_ablate", args.ablate) == 0
+    assert be.lib.vc_debug_set(b"conv_v4_pf", args.pf) == 0
     torch.zeros(1, device=dev)
     assert be.lib.vc_debug_set(b"xcd_swizzle_off", 1 if args.no_xcd else 0) == 0
     batch = bench.make_batch(list(range(args.bs)), dev, training=True)

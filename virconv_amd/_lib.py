@@ -82,7 +82,7 @@ SIGNATURES = {
     "vc_pass_backward": (_I, [_P, _P, _SZ, _P, _P, _P, _SZ, _P, _SZ, _P, _P]),
     "vc_trace_begin": (_I, [_I, _I, _I, _I, _P]),
     "vc_trace_end": (_I, [_P, _I, _P]),
-    "vc_conv_bwd_stats_partial_floats": (_SZ, [_I64, _I, _I]),
+    "vc_conv_bwd_stats_partial_floats": (_SZ, [_I64, _I, _I, _I]),
     "vc_conv_backward_input_epilogue": (_I, [_P, _P, _I64, _P, _I64, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P, _P, _P,
                                              _P, _P, _F, _I, _P, _P, _P]),
     "vc_bn_relu_backward_from_partial": (_I, [_P, _P, _I, _I, _I64, _I, _P, _P, _P, _P, _F, _I, _P, _I64, _P, _P, _P, _P, _P,

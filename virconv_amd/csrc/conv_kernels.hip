@@ -640,7 +640,12 @@ struct BufLoadS<1> {
   }
 };
 
-template <int CK, int CN, bool BWD, int EPI, bool PK = false>
+// ABL (developer ablations, vc_debug_set conv_v4_ablate; results are WRONG for ABL != 0): 1 = the MFMAs replaced by a few FMAs
+// that keep every load alive, 2 = every gather reads the tile's own rows (coalesced, cache-resident), 3 = every W_k load reads
+// offset 0's image (cache-resident), 4 = 2 + 3
+// PF = gather prefetch distance: 1 = one tile slot ahead (two A register sets), 2 = two slots ahead (three sets), 4 = a whole
+// offset ahead (all four tiles of the next offset are in flight while the current offset computes: 2 x 4 sets)
+template <int CK, int CN, bool BWD, int EPI, bool PK = false, int ABL = 0, int PF = 1>
 __global__ void __launch_bounds__(64) gather_gemm_v4_kernel(const float* __restrict__ src,
                                                             const float* __restrict__ src_centre, int64_t n_src,
                                                             const int32_t* __restrict__ tbl,
@@ -710,6 +715,8 @@ __global__ void __launch_bounds__(64) gather_gemm_v4_kernel(const float* __restr
 
   float B0[NCH][NT][4], B1[NCH][NT][4];
   float A0[NCH][4], A1[NCH][4];
+  float A2[PF == 2 ? NCH : 1][4];                 // PF == 2: third register set
+  float AC[PF == 4 ? RT : 1][NCH][4], AN[PF == 4 ? RT : 1][NCH][4];  // PF == 4: current / next offset, all tiles
 
   // per-lane byte offsets of the W fragments
   //   forward : w[(n * kv + kw) * CK + ch*16 + q*4 .. +3],  n = nt*16 + i   -> voff[nt] + soff(kw) + imm(ch)
@@ -726,7 +733,7 @@ __global__ void __launch_bounds__(64) gather_gemm_v4_kernel(const float* __restr
 
 #define V4_LOAD_B(K, BX)                                                                           \
   do {                                                                                             \
-    const int kw_ = mirror ? (kv - 1 - (K)) : (K);                                                 \
+    const int kw_ = (ABL == 3 || ABL == 4) ? 0 : (mirror ? (kv - 1 - (K)) : (K));                  \
     if constexpr (PK) {  /* fragment-ordered image: every instruction reads 1 KB of contiguous memory */ \
       const unsigned so_ = (unsigned)(kw_ * (NCH * NT * 1024));                                    \
       _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
@@ -747,7 +754,8 @@ __global__ void __launch_bounds__(64) gather_gemm_v4_kernel(const float* __restr
     }                                                                                              \
   } while (0)
 
-#define V4_IDX(K, T) s_idx[(K) * R + (T) * 16 + i]
+#define V4_IDX(K, T) ((ABL == 2 || ABL == 4) ? (s_idx[(K) * R + (T) * 16 + i] >= 0 ? (int)(brow0 % n_src) + (T) * 16 + i : -1) \
+                                             : s_idx[(K) * R + (T) * 16 + i])
 
 #define V4_GATHER(K, ID, AX)                                                                       \
   do {                                                                                             \
@@ -761,8 +769,10 @@ __global__ void __launch_bounds__(64) gather_gemm_v4_kernel(const float* __restr
     if ((tm[T] >> (K)) & 1u) {                                                                     \
       _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
           _Pragma("unroll") for (int j = 0; j < 4; ++j)                                            \
-              _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                    \
-                  acc[T][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(AX[ch][j], BX[ch][nt][j], acc[T][nt], 0, 0, 0); \
+              _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                  \
+                if constexpr (ABL == 1) acc[T][nt][j] += AX[ch][j] * BX[ch][nt][j];                \
+                else acc[T][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(AX[ch][j], BX[ch][nt][j], acc[T][nt], 0, 0, 0); \
+              }                                                                                    \
     }                                                                                              \
   } while (0)
 
@@ -776,8 +786,68 @@ __global__ void __launch_bounds__(64) gather_gemm_v4_kernel(const float* __restr
     idn = V4_IDX(KN, 1); V4_GATHER(KN, idg, A0); V4_MFMA(3, KC, A1, BC); idg = idn;                \
   } while (0)
 
+  // PF == 2: tile 0's rows in AX, tile 1's in AY (possibly still in flight), idg = table entries of tile 2; the next offset
+  // starts with (AY, AZ, AX)
+#define V4_OFFSET3(KC, KN, BC, BN, AX, AY, AZ)                                                     \
+  do {                                                                                             \
+    V4_LOAD_B(KN, BN);                                                                             \
+    idn = V4_IDX(KC, 3); V4_GATHER(KC, idg, AZ); V4_MFMA(0, KC, AX, BC); idg = idn;                \
+    idn = V4_IDX(KN, 0); V4_GATHER(KC, idg, AX); V4_MFMA(1, KC, AY, BC); idg = idn;                \
+    idn = V4_IDX(KN, 1); V4_GATHER(KN, idg, AY); V4_MFMA(2, KC, AZ, BC); idg = idn;                \
+    idn = V4_IDX(KN, 2); V4_GATHER(KN, idg, AZ); V4_MFMA(3, KC, AX, BC); idg = idn;                \
+  } while (0)
+  // PF == 4: the four tiles of KC are in AXC, the four tiles of KN go to AXN
+#define V4_OFFSETD(KC, KN, BC, BN, AXC, AXN)                                                       \
+  do {                                                                                             \
+    V4_LOAD_B(KN, BN);                                                                             \
+    int id4_[RT];                                                                                  \
+    _Pragma("unroll") for (int t = 0; t < RT; ++t) id4_[t] = V4_IDX(KN, t);                        \
+    _Pragma("unroll") for (int t = 0; t < RT; ++t) V4_GATHER(KN, id4_[t], AXN[t]);                 \
+    V4_MFMA(0, KC, AXC[0], BC); V4_MFMA(1, KC, AXC[1], BC);                                        \
+    V4_MFMA(2, KC, AXC[2], BC); V4_MFMA(3, KC, AXC[3], BC);                                        \
+  } while (0)
+#define V4_NEXT(MORE, KNEW, KOLD)                                                                  \
+  const bool MORE = umask != 0u;                                                                   \
+  KNEW = MORE ? (__ffs((int)umask) - 1) : KOLD;                                                    \
+  umask &= umask - 1;
+
 #pragma unroll
   for (int t = 0; t < RT; ++t) tm[t] = (unsigned)__builtin_amdgcn_readfirstlane((int)tm[t]);
+  if constexpr (PF == 4) {
+    if (umask != 0u) {
+      int kc = __ffs((int)umask) - 1, kn;
+      umask &= umask - 1;
+      V4_LOAD_B(kc, B0);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) { const int id_ = V4_IDX(kc, t); V4_GATHER(kc, id_, AC[t]); }
+      for (;;) {
+        V4_NEXT(more0, kn, kc)
+        V4_OFFSETD(kc, kn, B0, B1, AC, AN);
+        if (!more0) break;
+        V4_NEXT(more1, kc, kn)
+        V4_OFFSETD(kn, kc, B1, B0, AN, AC);
+        if (!more1) break;
+      }
+    }
+  } else if constexpr (PF == 2) {
+    if (umask != 0u) {
+      int ka = __ffs((int)umask) - 1, kb;
+      umask &= umask - 1;
+      int idg, idn;
+      V4_LOAD_B(ka, B0);
+      idg = V4_IDX(ka, 0); V4_GATHER(ka, idg, A0);
+      idg = V4_IDX(ka, 1); V4_GATHER(ka, idg, A1);
+      idg = V4_IDX(ka, 2);
+      for (;;) {
+        { V4_NEXT(m0, kb, ka) V4_OFFSET3(ka, kb, B0, B1, A0, A1, A2); if (!m0) break; }
+        { V4_NEXT(m1, ka, kb) V4_OFFSET3(kb, ka, B1, B0, A1, A2, A0); if (!m1) break; }
+        { V4_NEXT(m2, kb, ka) V4_OFFSET3(ka, kb, B0, B1, A2, A0, A1); if (!m2) break; }
+        { V4_NEXT(m3, ka, kb) V4_OFFSET3(kb, ka, B1, B0, A0, A1, A2); if (!m3) break; }
+        { V4_NEXT(m4, kb, ka) V4_OFFSET3(ka, kb, B0, B1, A1, A2, A0); if (!m4) break; }
+        { V4_NEXT(m5, ka, kb) V4_OFFSET3(kb, ka, B1, B0, A2, A0, A1); if (!m5) break; }
+      }
+    }
+  } else
   if (umask != 0u) {
     int kc = __ffs((int)umask) - 1, kn;
     umask &= umask - 1;
@@ -800,6 +870,9 @@ __global__ void __launch_bounds__(64) gather_gemm_v4_kernel(const float* __restr
     }
   }
 #undef V4_OFFSET
+#undef V4_OFFSET3
+#undef V4_OFFSETD
+#undef V4_NEXT
 #undef V4_MFMA
 #undef V4_GATHER
 #undef V4_IDX
@@ -1723,18 +1796,26 @@ static float* autopack_scratch(bool bwd) {
   if (b == nullptr && hipMalloc((void**)&b, kAutopackBytes) != hipSuccess) b = nullptr;
   return b;
 }
-// Wave-autonomous kernel (v4): vc_debug_set conv_v4 = 0 never | 1 every eligible shape (both channel counts multiples of 16,
-// fp32 operands) | 2 = per shape (the table below, from tools/kbench.py --v4 A/B runs)
-int g_conv_v4 = 2;
-static inline bool conv_use_v4(int ck, int cn, bool bwd) {
+// Wave-autonomous kernel (v4): vc_debug_set conv_v4 = 0 never (default) | 1 every eligible shape (both channel counts multiples
+// of 16, fp32 operands) | 2 = per launch (the rule below, from tools/kbench.py --v4 A/B runs)
+int g_conv_v4 = 0;   // off: inside the train step (weight-gradient stream contending for the same CUs) the table ties or loses, 5.64 vs 5.60 ms
+int g_conv_v4_pf = 1;          // developer: gather prefetch distance of the v4 kernel (1 | 2 | 4), plain launches with an image only
+int g_conv_v4_ablate = 0;      // developer ablations of the v4 kernel (see its ABL parameter); results are wrong when set
+// Measured (tools/kbench.py --v4 0|1 --autopack, VirConv-L bs 4, profiles/r02_kbench_v4.txt): a wave per 64 rows needs about
+// 2.3 of them per SIMD to hide its own latencies -- the 195 k / 310 k-row layers of stages 2 and 3 gain 5-20 % (SubM 16->16
+// 65 -> 53 us, 32->32 116 -> 101 us, 64->32 196 -> 188 us), the 76 k-row layers of stage 4 lose 20-30 % -- and the strided
+// backward tables (row-ordered) are better off with the LDS-staged kernel's 8-wave blocks.
+static constexpr int64_t kV4MinRows = 150000;
+static inline bool conv_use_v4(int ck, int cn, bool bwd, int64_t rows, bool ordered) {
   if (ck % 16 != 0 || cn % 16 != 0 || g_conv_v4 == 0) return false;
   if (g_conv_v4 == 1) return true;
   (void)bwd;
-  return false;  // no shape enabled until measured
+  return rows >= kV4MinRows && !ordered;
 }
-static inline int conv_block_waves(int ck, int cn, bool bwd) {
+// rows = output rows of the launch; ordered = the launch takes a row order (vc_row_order)
+static inline int conv_block_waves(int ck, int cn, bool bwd, int64_t rows, bool ordered) {
   if (ck < 16 || cn < 16) return 4;
-  if (conv_use_v4(ck, cn, bwd)) return 4;  // 64 rows per workgroup: the same partial-row count as a 4-wave v2 block
+  if (conv_use_v4(ck, cn, bwd, rows, ordered)) return 4;  // 64 rows per workgroup: the partial-row count of a 4-wave v2 block
   if (g_conv_nw == 8) return 8;
   if (g_conv_nw == 4) return 4;
   return (bwd && ck == 32 && cn == 64) ? 8 : 4;
@@ -1777,7 +1858,7 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
     }
   }
   if constexpr (CK % 16 == 0 && CN % 16 == 0) {
-    if (conv_use_v4(CK, CN, BWD) && ot == VC_OPERAND_F32 && kv <= 32 && n_src * CK * 4 < (1LL << 31) &&
+    if (conv_use_v4(CK, CN, BWD, n_out, order != nullptr) && ot == VC_OPERAND_F32 && kv <= 32 && n_src * CK * 4 < (1LL << 31) &&
         (int64_t)kv * CK * CN * 4 < (1LL << 31)) {
       const size_t lds4 = (size_t)(kv + 1) * 64 * sizeof(int);
       const dim3 grid4((unsigned)cdiv(n_out, 64));
@@ -1789,7 +1870,30 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
                             tbl, w, out, rep, order, n_out, kv, centre, mirror, epi);                                          \
   } while (0)
       bool done = true;
-      if (epi_kind == VC_EPI_NONE) VC_L4(VC_EPI_NONE);
+      if constexpr (!BWD && CN == 32 && (CK == 64 || CK == 32)) {
+        if (g_conv_v4_ablate && wpk && epi_kind == VC_EPI_NONE) {
+#define VC_L4A(A_) hipLaunchKernelGGL((gather_gemm_v4_kernel<CK, CN, false, VC_EPI_NONE, true, A_, 1>), grid4, dim3(64), lds4, st, src, \
+                                      src_centre, n_src, tbl, wpk, out, rep, order, n_out, kv, centre, mirror, epi)
+          switch (g_conv_v4_ablate) {
+            case 1: VC_L4A(1); break;
+            case 2: VC_L4A(2); break;
+            case 3: VC_L4A(3); break;
+            default: VC_L4A(4); break;
+          }
+#undef VC_L4A
+          VC_CHECK_LAUNCH("gather_gemm_v4_kernel<ablation>");
+          return VC_OK;
+        }
+      }
+      if (epi_kind == VC_EPI_NONE && wpk && (g_conv_v4_pf == 2 || g_conv_v4_pf == 4)) {
+        if (g_conv_v4_pf == 2)
+          hipLaunchKernelGGL((gather_gemm_v4_kernel<CK, CN, BWD, VC_EPI_NONE, true, 0, 2>), grid4, dim3(64), lds4, st, src, src_centre,
+                             n_src, tbl, wpk, out, rep, order, n_out, kv, centre, mirror, epi);
+        else
+          hipLaunchKernelGGL((gather_gemm_v4_kernel<CK, CN, BWD, VC_EPI_NONE, true, 0, 4>), grid4, dim3(64), lds4, st, src, src_centre,
+                             n_src, tbl, wpk, out, rep, order, n_out, kv, centre, mirror, epi);
+      }
+      else if (epi_kind == VC_EPI_NONE) VC_L4(VC_EPI_NONE);
       else if (BWD && epi_kind == VC_EPI_BWD) { if constexpr (BWD) VC_L4(VC_EPI_BWD); }
       else if (!BWD && epi_kind == VC_EPI_STATS) { if constexpr (!BWD) VC_L4(VC_EPI_STATS); }
       else if (!BWD && epi_kind == VC_EPI_AFFINE) { if constexpr (!BWD) VC_L4(VC_EPI_AFFINE); }
@@ -1802,7 +1906,7 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
     }
   }
   if constexpr (CK >= 16) {
-    if (conv_block_waves(CK, CN, BWD) == 4 && epi_kind != VC_EPI_BWD && use_window_kernel<CK>(flags, ot, rep, order, n_src, kv, src_centre)) {
+    if (conv_block_waves(CK, CN, BWD, n_out, order != nullptr) == 4 && epi_kind != VC_EPI_BWD && use_window_kernel<CK>(flags, ot, rep, order, n_src, kv, src_centre)) {
       constexpr int NCH = CK / 16, NT = (CN + 15) / 16;
       // experiment switches (vc_debug_set): conv_wdma = W images through the LDS-DMA engine, conv_winrows = 24-row windows
       const bool wdma = g_conv_wdma && CN % 16 == 0 && epi_kind == VC_EPI_NONE;
@@ -1844,7 +1948,7 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
     const bool half_ops = (ot != VC_OPERAND_F32) && CK >= 16 && CN >= 16;
     const int rt = (g_conv_rt == 2 && !half_ops && epi_kind == VC_EPI_NONE) ? 2 : 1;
     if constexpr (CK >= 16 && CN >= 16) {
-      if (conv_block_waves(CK, CN, BWD) == 8 && !half_ops && rt == 1 && epi_kind != VC_EPI_AFFINE) {
+      if (conv_block_waves(CK, CN, BWD, n_out, order != nullptr) == 8 && !half_ops && rt == 1 && epi_kind != VC_EPI_AFFINE) {
         // 8-wave blocks (128 rows): see the kernel's NW parameter
         const size_t lds8 = (size_t)2 * NCH * NT * 64 * V * sizeof(float) + (size_t)(kv + 1) * 128 * sizeof(int) + 16;
         const dim3 grid8((unsigned)cdiv(n_out, 128));
@@ -2051,6 +2155,8 @@ int vc_debug_set(const char* key, int value) {
   if (key && !strcmp(key, "conv_rt")) { g_conv_rt = value; return VC_OK; }
   if (key && !strcmp(key, "conv_v4")) { g_conv_v4 = value; return VC_OK; }
   if (key && !strcmp(key, "conv_autopack")) { g_conv_autopack = value; return VC_OK; }
+  if (key && !strcmp(key, "conv_v4_ablate")) { g_conv_v4_ablate = value; return VC_OK; }
+  if (key && !strcmp(key, "conv_v4_pf")) { g_conv_v4_pf = value; return VC_OK; }
   if (key && !strcmp(key, "conv_packed")) { g_conv_use_packed = value; return VC_OK; }
   if (key && !strcmp(key, "conv_window")) { g_conv_window = value; return VC_OK; }
   if (key && !strcmp(key, "conv_nw")) { g_conv_nw = (value == 8 || value == 4) ? value : 0; return VC_OK; }
@@ -2161,7 +2267,7 @@ size_t vc_conv_stats_partial_floats(int64_t n_in, int64_t n_out, int cin, int co
   if (n_out < 0 || cout < 1) return 0;
   // one partial row (sum, sum of squares per channel) per 16-row wave tile: 4 per 64-row block (8 per 128-row block), direct and
   // window kernel alike
-  if (conv_block_waves(cin, cout, false) == 8) return (size_t)cdiv(n_out, 128) * 8 * 2 * cout;
+  if (conv_block_waves(cin, cout, false, n_out, false) == 8) return (size_t)cdiv(n_out, 128) * 8 * 2 * cout;
   return (size_t)cdiv(n_out, 64) * 4 * 2 * cout;
 }
 
@@ -2201,10 +2307,10 @@ int vc_conv_backward_input(const float* dy, const float* dy_centre, int64_t n_sr
   return rc;
 }
 
-size_t vc_conv_bwd_stats_partial_floats(int64_t n_in, int cin, int cout) {
+size_t vc_conv_bwd_stats_partial_floats(int64_t n_in, int cin, int cout, int row_ordered) {
   if (n_in < 0 || cin < 1 || cout < 1) return 0;
-  // one partial row per 16-row wave tile of the backward-input kernel <CK = cout, CN = cin>
-  const int nw = conv_block_waves(cout, cin, true);
+  // one partial row per 16-row wave tile of the backward-input kernel <CK = cout, CN = cin> that this launch will get
+  const int nw = conv_block_waves(cout, cin, true, n_in, row_ordered != 0);
   return (size_t)cdiv(n_in, 16 * nw) * nw * 2 * cin;
 }
 

@@ -333,7 +333,7 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
         }
         cprod = prod_unit[o.src];
         if (cprod >= 0) {
-          const size_t pf = vc_conv_bwd_stats_partial_floats(t.n_in, u.cin, u.cout);
+          const size_t pf = vc_conv_bwd_stats_partial_floats(t.n_in, u.cin, u.cout, t.order_bwd != nullptr);
           fpart = at(bump.take(pf * sizeof(float)));
           fused[cprod].partial = dry ? marker : fpart;
           fused[cprod].nblocks = (int64_t)(pf / (2 * (size_t)u.cin));
