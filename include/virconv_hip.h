@@ -441,6 +441,22 @@ int vc_group_points_grad(int batch_size, int64_t m, int c, int64_t n, int nsampl
                          const int32_t* idx, const int32_t* idx_batch_cnt, const int32_t* features_batch_cnt,
                          float* grad_features, void* stream);
 
+/* ---- rotated-box BEV overlap / IoU and NMS (replaces pcdet/ops/iou3d_nms) --------------------------------
+ * boxes: (n, 7) float32 [x, y, z, dx, dy, dz, heading], contiguous.
+ *   vc_boxes_overlap_bev  -> (n_a, n_b) overlap areas   = iou3d_nms_cuda.boxes_overlap_bev_gpu (iou3d_nms.cpp:47-69, kernel .cu:235-246)
+ *   vc_boxes_iou_bev      -> (n_a, n_b) BEV IoU         = iou3d_nms_cuda.boxes_iou_bev_gpu     (iou3d_nms.cpp:71-96, kernel .cu:248-261)
+ *   vc_boxes_iou3d        -> (n_a, n_b) 3-D IoU         = iou3d_nms_utils.boxes_iou3d_gpu (iou3d_nms_utils.py:67-99) as ONE launch
+ *   vc_nms                : boxes ALREADY sorted by descending score; keep (capacity n) receives the selected positions in
+ *                           ascending order, *num_out (device) their count -- iou3d_nms_cuda.nms_gpu (rotated = 1,
+ *                           iou3d_nms.cpp:98-150) / nms_normal_gpu (rotated = 0, :153-187) with the selection loop on the
+ *                           device instead of on the host.  n <= 65536.  ws: vc_nms_workspace_bytes(n) bytes.              */
+int vc_boxes_overlap_bev(const float* boxes_a, int64_t n_a, const float* boxes_b, int64_t n_b, float* overlap, void* stream);
+int vc_boxes_iou_bev(const float* boxes_a, int64_t n_a, const float* boxes_b, int64_t n_b, float* iou, void* stream);
+int vc_boxes_iou3d(const float* boxes_a, int64_t n_a, const float* boxes_b, int64_t n_b, float* iou, void* stream);
+size_t vc_nms_workspace_bytes(int64_t n);
+int vc_nms(const float* boxes, int64_t n, float thresh, int rotated, int64_t* keep, int64_t* num_out, void* ws, size_t ws_bytes,
+           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,11 @@ SIGNATURES = {
     "vc_voxel_query": (_I, [_P, _SZ, _I64, _I, _P, _P, _P, _P, _I64, _I, _I, _I, _F, _I, _P, _P, _P]),
     "vc_group_points": (_I, [_I, _I64, _I, _I, _P, _P, _P, _P, _P, _P]),
     "vc_group_points_grad": (_I, [_I, _I64, _I, _I64, _I, _P, _P, _P, _P, _P, _P]),
+    "vc_boxes_overlap_bev": (_I, [_P, _I64, _P, _I64, _P, _P]),
+    "vc_boxes_iou_bev": (_I, [_P, _I64, _P, _I64, _P, _P]),
+    "vc_boxes_iou3d": (_I, [_P, _I64, _P, _I64, _P, _P]),
+    "vc_nms_workspace_bytes": (_SZ, [_I64]),
+    "vc_nms": (_I, [_P, _I64, _F, _I, _P, _P, _P, _SZ, _P]),
     "vc_conv_packed_weight_floats": (_SZ, [_I, _I, _I, _I]),
     "vc_conv_pack_weights": (_I, [_I, _P, _P, _P, _P, _I, _P, _P]),
     "vc_conv_clear_packed_weights": (_I, []),

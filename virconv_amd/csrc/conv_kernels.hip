@@ -989,7 +989,7 @@ __global__ void __launch_bounds__(64) gather_gemm_v4_kernel(const float* __restr
 //
 // W_k staging (per offset, double-buffered, one block barrier per offset) and the XCD-aware block mapping are v2's.
 // EPI == VC_EPI_STATS here writes one partial row per WAVE (16 output rows): no extra barrier in the epilogue.
-static constexpr int kWinRowsDefault = 32;
+[[maybe_unused]] static constexpr int kWinRowsDefault = 32;
 
 // full-wave integer min / max on the DPP crossbar (row_shr 1/2/4/8 scans a 16-lane row, row_bcast:15 / :31 chain the rows; the
 // result is lane 63's): seven VALU instructions and no LDS round trip -- __shfl_xor lowers to ds_bpermute + a wait per step,
