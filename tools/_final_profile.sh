@@ -1,6 +1,6 @@
 # Round-end measurement run on the GPU box: bench line(s), rocprofv3 --stats, PMC passes (each in its own run), kernel table.
 # Raw output under gpurun_out/f2/; tools/make_profiles.py turns it into the summaries committed under profiles/.
-D=gpurun_out/f2
+D=gpurun_out/f3
 mkdir -p $D
 R=$PWD
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $D/smoke.log 2>&1

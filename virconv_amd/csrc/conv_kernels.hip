@@ -2077,6 +2077,7 @@ static int dispatch_ck(int ck, int cn, const float* src, const float* src_centre
   return VC_EINVAL;
 }
 
+int g_bw_rows_per_split = 1024;  // weight gradient: target rows per block (vc_debug_set bw_rows_per_split); more rows = fewer, longer blocks and fewer partial sums
 int g_bw_legacy_order = 0;      // debug: 1 = offset-major block order of the weight-gradient kernel
 extern int g_pass_dw_main_tail; // pass.hip
 extern int g_pass_bwd_epilogue; // pass.hip
@@ -2092,7 +2093,7 @@ static inline int bw_max_split(int kv, int cin, int cout) {
 }
 
 static inline void bw_split(int64_t n_out, int kv, int cin, int cout, int& nsplit, int64_t& rows_per_block) {
-  int64_t want = cdiv(n_out, 1024);
+  int64_t want = cdiv(n_out, g_bw_rows_per_split);
   const int cap = bw_max_split(kv, cin, cout);
   if (want < 1) want = 1;
   if (want > cap) want = cap;
@@ -2163,6 +2164,7 @@ int vc_debug_set(const char* key, int value) {
   if (key && !strcmp(key, "conv_wdma")) { g_conv_wdma = value; return VC_OK; }
   if (key && !strcmp(key, "conv_winrows")) { g_conv_winrows = value; return VC_OK; }
   if (key && !strcmp(key, "bw_legacy_order")) { g_bw_legacy_order = value; return VC_OK; }
+  if (key && !strcmp(key, "bw_rows_per_split")) { if (value >= 256) g_bw_rows_per_split = value; return VC_OK; }
   if (key && !strcmp(key, "pass_dw_main_tail")) { g_pass_dw_main_tail = value; return VC_OK; }
   if (key && !strcmp(key, "pass_bwd_epilogue")) { g_pass_bwd_epilogue = value; return VC_OK; }
   if (key && !strcmp(key, "xcd_swizzle_off")) {
