@@ -308,6 +308,17 @@ def main():
     prime = [torch.empty((1 << 30,), dtype=torch.uint8, device=device) for _ in range(8)]
     del prime
 
+    # Setup (untimed): take Python's cyclic garbage collector out of the loop.  `import torch` leaves ~10^6 long-lived container
+    # objects behind; a full (generation-2) collection walks all of them (tens of ms), and WHEN the per-frame garbage triggers
+    # one depends on the ratio of young to old objects -- three more ctypes function objects at import time moved the bs-1
+    # inference loop from 1.35 to 2.8-5.2 ms per frame (bisected, VIRCONV_GC_FREEZE=0 reproduces it).  gc.freeze() moves
+    # everything alive now into the permanent generation: later collections only look at what the loop itself allocates.
+    # Any serving / training loop around this backbone should do the same.
+    if os.environ.get("VIRCONV_GC_FREEZE", "1") != "0":
+        import gc
+        gc.collect()
+        gc.freeze()
+
     if args.mode == "infer":
         return run_infer(args, model, batch, device, rank, world)
 

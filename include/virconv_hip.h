@@ -90,6 +90,24 @@ int vc_spconv_emit_pairs(const int32_t* indices, int64_t n, int ndim, int batch_
                          size_t ws_bytes, int64_t n_out, int32_t* out_indices, int32_t* pair_fwd,
                          int32_t* pair_bwd, void* stream);
 
+/* A CHAIN of strided convs (stage 2 -> 3 -> 4 -> conv_out of the backbone when no layer discard sits between them) needs only
+ * ONE host read for all of its output counts: every level's stage 1 can consume the previous level's output coordinates while
+ * their count is still on the device, and the coordinate emission takes a row capacity instead of the exact count
+ * ("capacity + device-side count"):
+ *   vc_spconv_mark_count_dev : vc_spconv_mark_count whose input holds *n_dev (device int32) valid rows of n_capacity allocated
+ *   vc_spconv_emit_indices   : the coordinate half of step 3 -- out_indices rows [0, count) for count <= capacity
+ *   vc_spconv_pairs          : the table half of step 3, after vc_spconv_emit_indices on the same workspace, exact n / n_out  */
+int vc_spconv_mark_count_dev(const int32_t* indices, int64_t n_capacity, const int32_t* n_dev, int ndim, int batch_size,
+                             const int32_t* host_out_shape, const int32_t* host_ksize, const int32_t* host_stride,
+                             const int32_t* host_padding, const int32_t* host_dilation, void* ws, size_t ws_bytes,
+                             int32_t* n_out_dev, void* stream);
+int vc_spconv_emit_indices(int ndim, int batch_size, const int32_t* host_out_shape, void* ws, size_t ws_bytes, int64_t capacity,
+                           int32_t* out_indices, void* stream);
+int vc_spconv_pairs(const int32_t* indices, int64_t n, int ndim, int batch_size, const int32_t* host_out_shape,
+                    const int32_t* host_ksize, const int32_t* host_stride, const int32_t* host_padding,
+                    const int32_t* host_dilation, const void* ws, size_t ws_bytes, int64_t n_out, int32_t* pair_fwd,
+                    int32_t* pair_bwd, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ K6/K7 gather-GEMM
  * Output-stationary implicit GEMM on fp32 MFMA (v_mfma_f32_16x16x4_f32), no atomics, run-to-run bitwise stable:
  *     out[o, :] = sum_k  src_k[ tbl[k, o], : ] @ Wsel(k)

@@ -31,6 +31,9 @@ SIGNATURES = {
     "vc_spconv_workspace_bytes": (_SZ, [_I, _I, _P]),
     "vc_spconv_mark_count": (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P, _P]),
     "vc_spconv_emit_pairs": (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _I64, _P, _P, _P, _P]),
+    "vc_spconv_mark_count_dev": (_I, [_P, _I64, _P, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P, _P]),
+    "vc_spconv_emit_indices": (_I, [_I, _I, _P, _P, _SZ, _I64, _P, _P]),
+    "vc_spconv_pairs": (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _I64, _P, _P, _P]),
     "vc_conv_forward": (_I, [_P, _I64, _P, _I64, _I, _P, _I, _I, _P, _I, _I, _P, _P]),
     "vc_conv_backward_input": (_I, [_P, _P, _I64, _P, _I64, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
     "vc_voxel_index_workspace_bytes": (_SZ, [_I64, _I, _P]),

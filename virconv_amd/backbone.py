@@ -254,6 +254,26 @@ def _plan_stream(device):
     return _PLAN_STREAMS[key]
 
 
+_FRAME_MARKS = {}
+
+
+def _bound_run_ahead(device, main):
+    """Flow control for forward-only loops.  The plan stream only waits for the inputs, so a host that is faster than the GPU can
+    plan frame after frame while the main stream still owes the feature passes of earlier frames -- and the high-priority plan
+    kernels of those future frames then starve the main stream: measured, the same inference loop runs at 1.35 ms/frame or at
+    2.8-5.2 ms/frame depending on which side of that edge the host happens to sit.  Every forward marks the main stream on
+    entry (= "everything up to the previous frame is enqueued before this point") and waits for the PREVIOUS forward's mark:
+    at most two frames are ever in flight (plan of frame f over the feature pass of frame f - 1).  In training the mark is
+    a step old and long complete."""
+    key = torch.device(device).index
+    prev = _FRAME_MARKS.get(key)
+    mark = torch.cuda.Event()
+    mark.record(main)
+    _FRAME_MARKS[key] = mark
+    if prev is not None:
+        prev.synchronize()
+
+
 class _PlanScope:
     """Run the geometry plan on the high-priority side stream (see VirConvL8x.build_plan) and hand the result to the main
     stream.  CPU tensors: a no-op scope."""
@@ -262,6 +282,7 @@ class _PlanScope:
         self.on_gpu = ref_tensor.is_cuda
         if self.on_gpu:
             self.main = torch.cuda.current_stream()
+            _bound_run_ahead(ref_tensor.device, self.main)
             self.side = _plan_stream(ref_tensor.device)
             ready = batch_dict.get("inputs_ready_event")
             if ready is not None:
@@ -305,7 +326,19 @@ def _plan_nrconv_chain(blocks, in_idx, shape, batch_size, calib, trans_param, di
     as soon as the current block's output coordinates (and its discard) exist and only then issues the current block's SubM /
     projection / 2-D rulebook kernels, so the count is on the host by the time it is needed."""
     stages = []
-    pending = blocks[0][0].begin_down(in_idx, shape, batch_size) if blocks else None
+    # No layer discard anywhere (inference, or the reference's run-time behaviour under spconv 2.x): the active set only changes at
+    # the strided convs, so ALL of their rulebooks are built up front with ONE host read (ops.build_sparse_rulebook_chain)
+    # instead of one read per conv; the loop below then finds every strided rulebook ready.
+    ready = None
+    if all(t is None for t in discard_tags):
+        convs = [blk.down_layer[0] for blk, _ in blocks if blk.stride > 1] + ([tail] if tail is not None else [])
+        ready = ops.build_sparse_rulebook_chain(in_idx, shape, batch_size, convs) if convs else None
+    if ready is not None:
+        ready = list(ready)
+        take_ready = lambda b: ready.pop(0) if (b is not None and b.stride > 1) else None   # noqa: E731
+        pending = take_ready(blocks[0][0]) if blocks else None
+    else:
+        pending = blocks[0][0].begin_down(in_idx, shape, batch_size) if blocks else None
     for i, ((blk, stride), tag) in enumerate(zip(blocks, discard_tags)):
         nxt = blocks[i + 1][0] if i + 1 < len(blocks) else None
 
@@ -314,7 +347,9 @@ def _plan_nrconv_chain(blocks, in_idx, shape, batch_size, calib, trans_param, di
             if tag is not None:
                 keep = _draw_keep(rate, idx.shape[0], batch_dict, tag, idx.device)
                 _, kept = ops.get_backend().gather_rows(None, idx, keep)
-            if nxt is not None:
+            if ready is not None:
+                begun = take_ready(nxt) if nxt is not None else (ready.pop(0) if (last and tail is not None) else None)
+            elif nxt is not None:
                 begun = nxt.begin_down(kept, shp, batch_size)
             elif last and tail is not None:
                 begun = ops.begin_sparse_rulebook(kept, shp, batch_size, tail.kernel_size, tail.stride, tail.padding, tail.dilation)

@@ -184,6 +184,62 @@ class HipBackend:
               "vc_spconv_emit_pairs")
         return out_indices, h["out_shape"], pair_fwd, pair_bwd
 
+    def sparse_rulebook_chain(self, indices: torch.Tensor, spatial_shape, batch_size: int, geoms):
+        """Strided convs applied one after the other with nothing in between that changes the active set (the backbone's
+        stage 2 -> 3 -> 4 -> conv_out when no layer discard is active; SubM convs keep the set).  geoms: [(ksize, stride, padding,
+        dilation), ...].  Stage 1 and the coordinate emission of EVERY level run before the host reads anything: level l + 1
+        marks from level l's coordinates with their count still on the device; buffers are sized by capacity (an input row
+        reaches at most prod(ceil(k / s)) output cells).  ONE host read returns all counts, then the pair tables are built.
+        -> [(out_indices, out_shape, pair_fwd, pair_bwd), ...] exactly as `sparse_rulebook` would return level by level."""
+        indices = _need(indices, torch.int32, "indices")
+        dev, ndim = indices.device, indices.shape[1] - 1
+        st = _stream()
+        levels = []
+        cur, cur_cap, cur_n_dev, shape = indices, indices.shape[0], None, tuple(int(v) for v in spatial_shape)
+        counts = torch.zeros((len(geoms),), dtype=torch.int32, device=dev)
+        for li, (ksize, stride, padding, dilation) in enumerate(geoms):
+            out_shape = conv_out_shape(shape, ksize, stride, padding, dilation)
+            oshp = i32arr(out_shape)
+            ws_bytes = self.lib.vc_spconv_workspace_bytes(batch_size, ndim, oshp)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+            ks, sd, pd, dl = i32arr(ksize), i32arr(stride), i32arr(padding), i32arr(dilation)
+            n_out_dev = counts[li:li + 1]
+            if cur_n_dev is None:
+                check(self.lib.vc_spconv_mark_count(_ptr(cur), cur_cap, ndim, batch_size, oshp, ks, sd, pd, dl, _ptr(ws), ws_bytes,
+                                                    _ptr(n_out_dev), st), "vc_spconv_mark_count")
+            else:
+                check(self.lib.vc_spconv_mark_count_dev(_ptr(cur), cur_cap, _ptr(cur_n_dev), ndim, batch_size, oshp, ks, sd, pd, dl,
+                                                        _ptr(ws), ws_bytes, _ptr(n_out_dev), st), "vc_spconv_mark_count_dev")
+            reach = int(np.prod([-(-int(k) // int(s)) for k, s in zip(ksize, stride)]))
+            cap = int(min(cur_cap * reach, batch_size * int(np.prod(out_shape))))
+            out_idx = torch.empty((cap, ndim + 1), dtype=torch.int32, device=dev)
+            check(self.lib.vc_spconv_emit_indices(ndim, batch_size, oshp, _ptr(ws), ws_bytes, cap, _ptr(out_idx), st),
+                  "vc_spconv_emit_indices")
+            levels.append({"in": cur, "ws": ws, "ws_bytes": ws_bytes, "oshp": oshp, "geom": (ks, sd, pd, dl), "out_shape": out_shape,
+                           "out_cap": out_idx, "kv": int(np.prod(ksize))})
+            cur, cur_cap, cur_n_dev, shape = out_idx, cap, n_out_dev, out_shape
+        if self._pinned is None:
+            self._pinned = torch.empty((16,), dtype=torch.int32).pin_memory()
+            self._pin_ev = torch.cuda.Event()
+        assert len(geoms) <= 7
+        self._pinned[9:9 + len(geoms)].copy_(counts, non_blocking=True)   # slots 0-8 belong to the per-conv reads
+        self._pin_ev.record()
+        while not self._pin_ev.query():
+            pass
+        n_outs = [int(v) for v in self._pinned[9:9 + len(geoms)]]
+        res, n_in = [], indices.shape[0]
+        for lv, n_out in zip(levels, n_outs):
+            ks, sd, pd, dl = lv["geom"]
+            src = lv["in"][:n_in]                      # a contiguous prefix of the capacity buffer
+            out_idx = lv["out_cap"][:n_out]
+            pf = torch.empty((lv["kv"], n_out), dtype=torch.int32, device=dev)
+            pb = torch.empty((lv["kv"], n_in), dtype=torch.int32, device=dev)
+            check(self.lib.vc_spconv_pairs(_ptr(src), n_in, ndim, batch_size, lv["oshp"], ks, sd, pd, dl, _ptr(lv["ws"]),
+                                           lv["ws_bytes"], n_out, _ptr(pf), _ptr(pb), st), "vc_spconv_pairs")
+            res.append((out_idx, lv["out_shape"], pf, pb, src))
+            n_in = n_out
+        return res
+
     def sparse_rulebook(self, indices: torch.Tensor, spatial_shape, batch_size: int, ksize, stride, padding, dilation):
         """-> out_indices (M, ndim+1) int32 ascending, out_shape, pair_fwd (KV, M), pair_bwd (KV, N)."""
         return self.sparse_rulebook_finish(self.sparse_rulebook_begin(indices, spatial_shape, batch_size, ksize, stride, padding,

@@ -188,8 +188,16 @@ __device__ __forceinline__ int64_t sp_candidate(const SpGeom& g, int b, int z, i
 // Same block shape as subm_rulebook_kernel (64 rows x 4 offset groups).  For one offset the 64 lanes of a wave are 64
 // x-consecutive rows whose candidate cells mostly fall into the SAME 64-cell bitmap word: a segmented OR-scan over the wave
 // merges them and only the last lane of each run issues the atomic (same-address L2 atomics serialise).
+// n_dev (optional): the number of rows lives on the device (a strided conv chained behind another one whose output count the host
+// has not read yet): the grid covers the CAPACITY n, blocks past the real count leave at once.
 __global__ void __launch_bounds__(256) sp_mark_kernel(const int32_t* __restrict__ indices, int64_t n, int ndim,
-                                                      SpGeom g, unsigned long long* __restrict__ bitmap) {
+                                                      SpGeom g, unsigned long long* __restrict__ bitmap,
+                                                      const int32_t* __restrict__ n_dev) {
+  if (n_dev != nullptr) {
+    const int64_t real = *n_dev;
+    if (real < n) n = real;
+    if ((int64_t)blockIdx.x * 64 >= n) return;
+  }
   __shared__ int s_off[128];
   fill_offset_table(s_off, g.k[0], g.k[1], g.k[2]);
   const int lane = threadIdx.x & 63, kg = threadIdx.x >> 6;
@@ -1006,9 +1014,28 @@ static inline SpGeom make_spgeom(const Dims& o, const Kern3& k) {
   return g;
 }
 
+static int spconv_mark_count(const int32_t* indices, int64_t n, const int32_t* n_dev, int ndim, int batch_size,
+                             const int32_t* out_shape, const int32_t* ksize, const int32_t* stride_, const int32_t* padding,
+                             const int32_t* dilation, void* ws, size_t ws_bytes, int32_t* n_out_dev, void* stream);
+
 int vc_spconv_mark_count(const int32_t* indices, int64_t n, int ndim, int batch_size, const int32_t* out_shape,
                          const int32_t* ksize, const int32_t* stride_, const int32_t* padding, const int32_t* dilation,
                          void* ws, size_t ws_bytes, int32_t* n_out_dev, void* stream) {
+  return spconv_mark_count(indices, n, nullptr, ndim, batch_size, out_shape, ksize, stride_, padding, dilation, ws, ws_bytes,
+                           n_out_dev, stream);
+}
+
+int vc_spconv_mark_count_dev(const int32_t* indices, int64_t n_capacity, const int32_t* n_dev, int ndim, int batch_size,
+                             const int32_t* out_shape, const int32_t* ksize, const int32_t* stride_, const int32_t* padding,
+                             const int32_t* dilation, void* ws, size_t ws_bytes, int32_t* n_out_dev, void* stream) {
+  VC_REQUIRE(n_dev != nullptr, "vc_spconv_mark_count_dev: null device row count");
+  return spconv_mark_count(indices, n_capacity, n_dev, ndim, batch_size, out_shape, ksize, stride_, padding, dilation, ws,
+                           ws_bytes, n_out_dev, stream);
+}
+
+static int spconv_mark_count(const int32_t* indices, int64_t n, const int32_t* n_dev, int ndim, int batch_size,
+                             const int32_t* out_shape, const int32_t* ksize, const int32_t* stride_, const int32_t* padding,
+                             const int32_t* dilation, void* ws, size_t ws_bytes, int32_t* n_out_dev, void* stream) {
   VC_REQUIRE(ndim == 2 || ndim == 3, "vc_spconv_mark_count: ndim must be 2 or 3");
   VC_REQUIRE(n >= 0 && batch_size >= 1 && out_shape && ksize && stride_ && padding && ws && n_out_dev &&
                  (indices || n == 0), "vc_spconv_mark_count: null/invalid argument");
@@ -1026,7 +1053,7 @@ int vc_spconv_mark_count(const int32_t* indices, int64_t n, int ndim, int batch_
   VC_REQUIRE(k.kv <= 128, "strided rulebook: kernel volume %d > 128", k.kv);
   SpGeom g = make_spgeom(o, k);
   if (n > 0) {
-    hipLaunchKernelGGL(sp_mark_kernel, dim3((unsigned)cdiv(n, 64)), dim3(256), 0, st, indices, n, ndim, g, bitmap);
+    hipLaunchKernelGGL(sp_mark_kernel, dim3((unsigned)cdiv(n, 64)), dim3(256), 0, st, indices, n, ndim, g, bitmap, n_dev);
     VC_CHECK_LAUNCH("sp_mark_kernel");
   }
   hipLaunchKernelGGL(sp_blocksum_kernel, dim3((unsigned)nb), dim3(256), 0, st, bitmap, nwords, blocksum);
@@ -1034,6 +1061,43 @@ int vc_spconv_mark_count(const int32_t* indices, int64_t n, int ndim, int batch_
   hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(256), 0, st, blocksum, nb, n_out_dev, blocksum + nb);
   VC_CHECK_LAUNCH("scan_blocksums_kernel");
   return VC_OK;
+}
+
+// Second stage in two halves, so that a chain of strided convs can run stage 1 + the coordinate emission of every level before
+// the host has read a single count (the emission takes a row CAPACITY), and build the pair tables once the counts are known.
+int vc_spconv_emit_indices(int ndim, int batch_size, const int32_t* out_shape, void* ws, size_t ws_bytes, int64_t capacity,
+                           int32_t* out_indices, void* stream) {
+  VC_REQUIRE(ndim == 2 || ndim == 3, "vc_spconv_emit_indices: ndim must be 2 or 3");
+  VC_REQUIRE(capacity >= 0 && out_shape && ws && (out_indices || capacity == 0), "vc_spconv_emit_indices: null argument");
+  Dims o = make_dims(ndim, out_shape);
+  int64_t nwords, nb;
+  sp_layout(batch_size, ndim, out_shape, nwords, nb);
+  if (ws_bytes < vc_spconv_workspace_bytes(batch_size, ndim, out_shape)) { set_error("vc_spconv_emit_indices: workspace too small"); return VC_ECAPACITY; }
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned long long* bitmap = (const unsigned long long*)ws;
+  uint32_t* prefix = (uint32_t*)(bitmap + nwords);
+  const int32_t* blocksum = (const int32_t*)(prefix + nwords);
+  hipLaunchKernelGGL(sp_prefix_kernel, dim3((unsigned)nb), dim3(256), 0, st, bitmap, nwords, blocksum, prefix);
+  VC_CHECK_LAUNCH("sp_prefix_kernel");
+  hipLaunchKernelGGL(sp_emit_kernel, dim3((unsigned)cdiv(nwords, 256)), dim3(256), 0, st, bitmap, nwords, prefix, ndim,
+                     o.D, o.H, o.W, capacity, out_indices);
+  VC_CHECK_LAUNCH("sp_emit_kernel");
+  return VC_OK;
+}
+
+static int spconv_pairs(const int32_t* indices, int64_t n, int ndim, int batch_size, const int32_t* out_shape,
+                        const int32_t* ksize, const int32_t* stride_, const int32_t* padding, const int32_t* dilation,
+                        const void* ws, size_t ws_bytes, int64_t n_out, int32_t* pair_fwd, int32_t* pair_bwd, void* stream);
+
+int vc_spconv_pairs(const int32_t* indices, int64_t n, int ndim, int batch_size, const int32_t* out_shape,
+                    const int32_t* ksize, const int32_t* stride_, const int32_t* padding, const int32_t* dilation,
+                    const void* ws, size_t ws_bytes, int64_t n_out, int32_t* pair_fwd, int32_t* pair_bwd, void* stream) {
+  VC_REQUIRE(ndim == 2 || ndim == 3, "vc_spconv_pairs: ndim must be 2 or 3");
+  VC_REQUIRE(n >= 0 && n_out >= 0 && out_shape && ksize && stride_ && padding && ws, "vc_spconv_pairs: null argument");
+  VC_REQUIRE((n_out == 0 || pair_fwd) && (n == 0 || (indices && pair_bwd)), "vc_spconv_pairs: null tables");
+  if (ws_bytes < vc_spconv_workspace_bytes(batch_size, ndim, out_shape)) { set_error("vc_spconv_pairs: workspace too small"); return VC_ECAPACITY; }
+  return spconv_pairs(indices, n, ndim, batch_size, out_shape, ksize, stride_, padding, dilation, ws, ws_bytes, n_out, pair_fwd,
+                      pair_bwd, stream);
 }
 
 int vc_spconv_emit_pairs(const int32_t* indices, int64_t n, int ndim, int batch_size, const int32_t* out_shape,
@@ -1044,22 +1108,25 @@ int vc_spconv_emit_pairs(const int32_t* indices, int64_t n, int ndim, int batch_
   VC_REQUIRE(n >= 0 && n_out >= 0 && out_shape && ksize && stride_ && padding && ws, "vc_spconv_emit_pairs: null argument");
   VC_REQUIRE(n_out == 0 || (out_indices && pair_fwd), "vc_spconv_emit_pairs: null outputs");
   VC_REQUIRE(n == 0 || (indices && pair_bwd), "vc_spconv_emit_pairs: null inputs");
+  const int rc = vc_spconv_emit_indices(ndim, batch_size, out_shape, const_cast<void*>(ws), ws_bytes, n_out, out_indices, stream);
+  if (rc != VC_OK) return rc;
+  return spconv_pairs(indices, n, ndim, batch_size, out_shape, ksize, stride_, padding, dilation, ws, ws_bytes, n_out, pair_fwd,
+                      pair_bwd, stream);
+}
+
+static int spconv_pairs(const int32_t* indices, int64_t n, int ndim, int batch_size, const int32_t* out_shape,
+                        const int32_t* ksize, const int32_t* stride_, const int32_t* padding, const int32_t* dilation,
+                        const void* ws, size_t ws_bytes, int64_t n_out, int32_t* pair_fwd, int32_t* pair_bwd, void* stream) {
+  (void)ws_bytes;
   Dims o = make_dims(ndim, out_shape);
   int64_t nwords, nb;
   sp_layout(batch_size, ndim, out_shape, nwords, nb);
-  if (ws_bytes < vc_spconv_workspace_bytes(batch_size, ndim, out_shape)) { set_error("vc_spconv_emit_pairs: workspace too small"); return VC_ECAPACITY; }
   hipStream_t st = (hipStream_t)stream;
   const unsigned long long* bitmap = (const unsigned long long*)ws;
-  uint32_t* prefix = (uint32_t*)(bitmap + nwords);
-  const int32_t* blocksum = (const int32_t*)(prefix + nwords);
+  const uint32_t* prefix = (const uint32_t*)(bitmap + nwords);
   Kern3 k = make_kern(ndim, ksize, stride_, padding, dilation);
   VC_REQUIRE(k.kv <= 128, "strided rulebook: kernel volume %d > 128", k.kv);
   SpGeom g = make_spgeom(o, k);
-  hipLaunchKernelGGL(sp_prefix_kernel, dim3((unsigned)nb), dim3(256), 0, st, bitmap, nwords, blocksum, prefix);
-  VC_CHECK_LAUNCH("sp_prefix_kernel");
-  hipLaunchKernelGGL(sp_emit_kernel, dim3((unsigned)cdiv(nwords, 256)), dim3(256), 0, st, bitmap, nwords, prefix, ndim,
-                     o.D, o.H, o.W, n_out, out_indices);
-  VC_CHECK_LAUNCH("sp_emit_kernel");
   if (n_out > 0) VC_CHECK_HIP(hipMemsetAsync(pair_fwd, 0xFF, (size_t)k.kv * n_out * 4, st));
   if (n > 0) {
     hipLaunchKernelGGL(sp_pairs_kernel, dim3((unsigned)cdiv(n, 64)), dim3(256), 0, st, indices, n, ndim, g,

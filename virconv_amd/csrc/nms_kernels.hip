@@ -74,6 +74,13 @@ __device__ __forceinline__ void oriented_corners(const float* box, P2* c) {  // 
 
 // iou3d_nms_kernel.cu:127-225
 __device__ float rbox_overlap(const float* a, const float* b) {
+  {  // far-apart boxes: no edge can cross and no corner can fall inside the other box even with the reference's 1e-2 margin, so
+     // the reference's polygon is empty and its area exactly 0 -- skip the clipping (most pairs of a proposal set)
+    const float dx = a[0] - b[0], dy = a[1] - b[1];
+    const float ra = 0.5f * sqrtf(a[3] * a[3] + a[4] * a[4]), rb = 0.5f * sqrtf(b[3] * b[3] + b[4] * b[4]);
+    const float reach = ra + rb + 0.05f;
+    if (dx * dx + dy * dy > reach * reach) return 0.f;
+  }
   P2 ca[5], cb[5];
   oriented_corners(a, ca);
   oriented_corners(b, cb);
@@ -92,7 +99,7 @@ __device__ float rbox_overlap(const float* a, const float* b) {
     if (inside_with_margin(a, cb[k])) { sx += cb[k].x; sy += cb[k].y; pts[cnt++] = cb[k]; }
     if (inside_with_margin(b, ca[k])) { sx += ca[k].x; sy += ca[k].y; pts[cnt++] = ca[k]; }
   }
-  if (cnt < 3) return 0.f;  // the reference divides by cnt and sums an empty / degenerate fan: 0 (or NaN/2 -> fabs -> NaN for cnt = 0; see DESIGN)
+  if (cnt < 3) return 0.f;  // the reference's fan over fewer than three points sums nothing (cnt <= 1) or one zero cross product (cnt = 2)
   const float mx = sx / cnt, my = sy / cnt;
   // angular order around the mean: the reference bubble-sorts with atan2 evaluated inside the comparator (a stable ascending
   // sort); a stable insertion sort on the angles computed once gives the same permutation

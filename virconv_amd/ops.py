@@ -118,21 +118,50 @@ def begin_sparse_rulebook(indices: torch.Tensor, spatial_shape, batch_size: int,
     return {"args": args, "handle": handle}
 
 
+def _sparse_rulebook_from(indices, shape, out_idx, out_shape, pf, pb, ks, st, pd, dl) -> Rulebook:
+    be = get_backend()
+    out_idx._vc_sorted = True  # ascending linear order by construction (bitmap rank); see build_subm_rulebook
+    rb = Rulebook("sparse", pf, pb, None, indices.shape[0], out_idx.shape[0], indices, out_idx, shape,
+                  tuple(int(s) for s in out_shape), ks, st, pd, dl)
+    # the row order only serves the backward-input conv: not built when no gradient will flow (inference)
+    if ROW_ORDER in ("bwd", "all") and 8 < rb.kv <= 32 and torch.is_grad_enabled():
+        rb.order_bwd = be.row_order(pb, window=ROW_ORDER_WINDOW)
+        if ROW_ORDER == "all":
+            rb.order_fwd = be.row_order(pf, window=ROW_ORDER_WINDOW)
+    return rb
+
+
+# One host read for a whole chain of strided convs (HipBackend.sparse_rulebook_chain) instead of one per conv; "0" = off
+CHAIN_RULEBOOKS = os.environ.get("VIRCONV_CHAIN_RULEBOOKS", "1") != "0"
+
+
+def build_sparse_rulebook_chain(indices: torch.Tensor, spatial_shape, batch_size: int, convs):
+    """Rulebooks of strided convs applied one after the other on an unchanged active set (`convs`: objects with kernel_size /
+    stride / padding / dilation), or None when the backend has no chained path.  -> [{"ready": Rulebook}, ...]: handles that
+    `finish_sparse_rulebook` accepts in place of a begun rulebook."""
+    be = get_backend()
+    if not (CHAIN_RULEBOOKS and hasattr(be, "sparse_rulebook_chain") and indices.is_cuda and len(convs) >= 2):
+        return None
+    ndim = indices.shape[1] - 1
+    geoms = [(ntuple(c.kernel_size, ndim), ntuple(c.stride, ndim), ntuple(c.padding, ndim), ntuple(c.dilation, ndim)) for c in convs]
+    shape = tuple(int(s) for s in spatial_shape)
+    out = []
+    for (ks, st, pd, dl), (out_idx, out_shape, pf, pb, src) in zip(geoms, be.sparse_rulebook_chain(indices, shape, int(batch_size), geoms)):
+        out.append({"ready": _sparse_rulebook_from(src, shape, out_idx, out_shape, pf, pb, ks, st, pd, dl)})
+        shape = tuple(int(s) for s in out_shape)
+    return out
+
+
 def finish_sparse_rulebook(pending) -> Rulebook:
+    if "ready" in pending:
+        return pending["ready"]
     indices, shape, batch_size, ks, st, pd, dl = pending["args"]
     be = get_backend()
     if pending["handle"] is not None:
         out_idx, out_shape, pf, pb = be.sparse_rulebook_finish(pending["handle"])
     else:
         out_idx, out_shape, pf, pb = be.sparse_rulebook(indices, shape, batch_size, ks, st, pd, dl)
-    out_idx._vc_sorted = True  # ascending linear order by construction (bitmap rank); see build_subm_rulebook
-    rb = Rulebook("sparse", pf, pb, None, indices.shape[0], out_idx.shape[0], indices, out_idx, shape,
-                  tuple(int(s) for s in out_shape), ks, st, pd, dl)
-    if ROW_ORDER in ("bwd", "all") and 8 < rb.kv <= 32:
-        rb.order_bwd = be.row_order(pb, window=ROW_ORDER_WINDOW)
-        if ROW_ORDER == "all":
-            rb.order_fwd = be.row_order(pf, window=ROW_ORDER_WINDOW)
-    return rb
+    return _sparse_rulebook_from(indices, shape, out_idx, out_shape, pf, pb, ks, st, pd, dl)
 
 
 def build_sparse_rulebook(indices: torch.Tensor, spatial_shape, batch_size: int, ksize, stride, padding, dilation=1) -> Rulebook:
