@@ -1054,3 +1054,29 @@ def test_facade_handles_channel_counts_the_kernels_are_not_instantiated_for(hip_
     for a, b_, name in zip(got, ref, ("out", "dx", "dw", "dgamma", "dbeta", "running_mean", "running_var")):
         tol = 2e-4 * max(1.0, float(b_.abs().max()))
         assert float((a - b_).abs().max()) <= tol, (name, float((a - b_).abs().max()), tol)
+
+
+# ------------------------------------------------------------------------------------------------ chained strided rulebooks
+@pytest.mark.parametrize("n", [0, 1, 700, 9000])
+def test_chained_strided_rulebooks_equal_the_level_by_level_ones(hip_backend, n):
+    """sparse_rulebook_chain (stage 1 + coordinate emission of every level before ONE host read; capacity buffers, device-side
+    counts) returns exactly what sparse_rulebook returns level by level: the backbone's stage 2 -> 3 -> 4 -> conv_out geometry."""
+    shape = (41, 160, 128)
+    idx = synth.small_scene_indices(61, n, shape, 2) if n else np.zeros((0, 4), np.int32)
+    it = torch.from_numpy(np.ascontiguousarray(idx)).cuda()
+    geoms = [((3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1)),
+             ((3, 3, 3), (2, 2, 2), (0, 1, 1), (1, 1, 1)), ((3, 1, 1), (2, 1, 1), (0, 0, 0), (1, 1, 1))]
+    chain = hip_backend.sparse_rulebook_chain(it, shape, 2, geoms)
+    assert len(chain) == 4
+    cur, cur_shape = it, shape
+    for (ks, st, pd, dl), (oi, osh, pf, pb, src) in zip(geoms, chain):
+        r_oi, r_osh, r_pf, r_pb = hip_backend.sparse_rulebook(cur, cur_shape, 2, ks, st, pd, dl)
+        assert tuple(osh) == tuple(r_osh) and oi.is_contiguous()
+        assert torch.equal(src, cur) and torch.equal(oi, r_oi) and torch.equal(pf, r_pf) and torch.equal(pb, r_pb)
+        cur, cur_shape = r_oi, r_osh
+    # and against the oracle for the first two levels
+    if n:
+        o1, s1, p1, _ = sparse_ref.sparse_rulebook(idx, list(shape), 2, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+        assert np.array_equal(chain[0][0].cpu().numpy(), o1) and np.array_equal(chain[0][2].cpu().numpy(), p1)
+        o2, _, p2, _ = sparse_ref.sparse_rulebook(o1, list(s1), 2, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+        assert np.array_equal(chain[1][0].cpu().numpy(), o2) and np.array_equal(chain[1][2].cpu().numpy(), p2)

@@ -25,7 +25,7 @@ import torch
 from . import _lib, ops
 
 NATIVE_PASS = os.environ.get("VIRCONV_NATIVE_PASS", "1") != "0"
-NATIVE_PASS_EVAL = os.environ.get("VIRCONV_NATIVE_PASS_EVAL", "0") != "0"
+NATIVE_PASS_EVAL = os.environ.get("VIRCONV_NATIVE_PASS_EVAL", "1") != "0"
 _CHANNELS = (4, 8, 16, 32, 64)
 
 
@@ -204,10 +204,11 @@ def usable(model, feats: torch.Tensor, plan) -> bool:
     if seqs is None or not _units_ok(seqs + [model.conv_out], model.training):
         return False
     if not model.training:
-        # eval: the node-by-node path is already ONE launch per unit (BatchNorm folded into the conv store) and at bs 1 the step is
-        # bound by the geometry plan's count reads, not by the feature pass: measured 1.25 ms/frame (nodes) vs 1.31 ms (native
-        # pass, whose burst of launches competes with the next frame's plan kernels).  The native eval pass stays available
-        # (VIRCONV_NATIVE_PASS_EVAL=1, bit-equal, tested) but is not the default.
+        # eval: the node-by-node path is already ONE launch per unit (BatchNorm folded into the conv store); while the geometry plan
+        # still read four counts per frame the native pass lost to it (1.31 vs 1.25 ms/frame at bs 1: its burst of launches
+        # competed with the next frame's plan kernels).  With ONE count read per frame (ops.build_sparse_rulebook_chain) it wins:
+        # 1.22 vs 1.30 ms/frame at bs 1, 1.77 vs 1.92 ms per 4 frames.  Bit-equal to the node path (tested);
+        # VIRCONV_NATIVE_PASS_EVAL=0 selects the node path.
         if not NATIVE_PASS_EVAL:
             return False
         if torch.is_grad_enabled() and (feats.requires_grad or any(p.requires_grad for p in model.parameters())):
