@@ -198,3 +198,39 @@ def test_feature_pass_layout_and_validation_without_gpu():
     assert lib.vc_trace_end(None, 0, C.byref(n)) == _lib.VC_OK and n.value == 0
     assert lib.vc_trace_begin(2, 64, 32, 16, 0x1000) == _lib.VC_EINVAL
     assert lib.vc_trace_begin(0, 64, 32, 16, None) == _lib.VC_EINVAL
+
+
+def test_second_session_entry_points_validate_their_arguments_without_gpu():
+    """Weight images, the chained strided rulebook, rotated IoU / NMS: every check below fails (or returns) before any HIP call."""
+    import ctypes
+    lib = _lib.load()
+    dummy = ctypes.c_void_p(64)
+    # fragment-ordered weight images: only shapes whose two channel counts are multiples of 16, kv <= 32
+    assert lib.vc_conv_packed_weight_floats(64, 32, 27, 0) == 27 * 64 * 32 and lib.vc_conv_packed_weight_floats(64, 32, 27, 1) == 27 * 64 * 32
+    assert lib.vc_conv_packed_weight_floats(8, 32, 27, 0) == 0 and lib.vc_conv_packed_weight_floats(32, 16, 33, 0) == 0
+    assert lib.vc_conv_pack_weights(49, dummy, dummy, dummy, dummy, 0, dummy, None) == _lib.VC_EINVAL
+    assert lib.vc_conv_pack_weights(0, None, None, None, None, 0, None, None) == _lib.VC_OK
+    w = (ctypes.c_void_p * 1)(64)
+    out = (ctypes.c_void_p * 1)(128)
+    assert lib.vc_conv_pack_weights(1, w, _lib.i32arr([8]), _lib.i32arr([8]), _lib.i32arr([27]), 0, out, None) == _lib.VC_EINVAL
+    assert b"takes no packed image" in lib.vc_last_error()
+    assert lib.vc_conv_clear_packed_weights() == _lib.VC_OK
+    # partial rows of the backward-input epilogue: per 16-row tile; a row-ordered <32, 64> launch keeps the 8-wave blocks
+    assert lib.vc_conv_bwd_stats_partial_floats(130, 32, 32, 0) == 3 * 4 * 2 * 32
+    assert lib.vc_conv_bwd_stats_partial_floats(130, 64, 32, 1) == 2 * 8 * 2 * 64
+    # chained strided rulebook
+    shp, k3 = _lib.i32arr([21, 400, 352]), _lib.i32arr([3, 3, 3])
+    assert lib.vc_spconv_mark_count_dev(dummy, 10, None, 3, 1, shp, k3, k3, k3, k3, dummy, 1 << 30, dummy, None) == _lib.VC_EINVAL
+    assert b"device row count" in lib.vc_last_error()
+    assert lib.vc_spconv_emit_indices(4, 1, shp, dummy, 1 << 30, 10, dummy, None) == _lib.VC_EINVAL
+    assert lib.vc_spconv_emit_indices(3, 1, shp, dummy, 16, 10, dummy, None) == _lib.VC_ECAPACITY
+    assert lib.vc_spconv_pairs(dummy, 10, 3, 1, shp, k3, k3, k3, k3, dummy, 16, 5, dummy, dummy, None) == _lib.VC_ECAPACITY
+    assert lib.vc_spconv_pairs(dummy, 10, 3, 1, shp, k3, k3, k3, k3, dummy, 1 << 30, 5, None, dummy, None) == _lib.VC_EINVAL
+    # rotated IoU / NMS
+    assert lib.vc_boxes_iou_bev(None, 0, None, 5, None, None) == _lib.VC_OK            # an empty side: nothing to do
+    assert lib.vc_boxes_iou3d(None, 3, dummy, 5, dummy, None) == _lib.VC_EINVAL
+    assert lib.vc_boxes_overlap_bev(dummy, -1, dummy, 5, dummy, None) == _lib.VC_EINVAL
+    assert lib.vc_nms_workspace_bytes(4096) == 4096 * 64 * 8 + 256 and lib.vc_nms_workspace_bytes(65) == 65 * 2 * 8 + 256
+    assert lib.vc_nms(dummy, 70000, 0.5, 1, dummy, dummy, dummy, 1 << 40, None) == _lib.VC_EINVAL and b"up to" in lib.vc_last_error()
+    assert lib.vc_nms(dummy, 100, 0.5, 1, dummy, dummy, dummy, 8, None) == _lib.VC_EINVAL and b"workspace" in lib.vc_last_error()
+    assert lib.vc_nms(dummy, 100, 0.5, 1, dummy, None, dummy, 1 << 20, None) == _lib.VC_EINVAL
