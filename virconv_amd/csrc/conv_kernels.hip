@@ -657,6 +657,7 @@ __global__ void __launch_bounds__(64) gather_gemm_v4_kernel(const float* __restr
   static_assert(EPI == VC_EPI_NONE || (EPI == VC_EPI_BWD) == BWD, "STATS / AFFINE: forward kernel; BWD: backward-input kernel");
   constexpr int RT = 4, R = 64;
   constexpr int NCH = CK / 16, NT = CN / 16;
+  static_assert(PF != 11 || PK, "the interleaved schedule reads the weight image");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int* s_idx = reinterpret_cast<int*>(smem);  // [kv][64]
   int* s_row = s_idx + kv * R;                // [64] output row of each slot (-1: none)
@@ -786,6 +787,38 @@ __global__ void __launch_bounds__(64) gather_gemm_v4_kernel(const float* __restr
     idn = V4_IDX(KN, 1); V4_GATHER(KN, idg, A0); V4_MFMA(3, KC, A1, BC); idg = idn;                \
   } while (0)
 
+  // PF == 11 (needs a weight image): the schedule of PF == 1 with the loads INTERLEAVED into the MFMA stream -- one gather
+  // instruction (and, every G / NB groups, one weight-fragment instruction of the next offset) in front of each K chunk's MFMAs,
+  // pinned there by sched_barrier.  A wave whose VMEM issue is back-pressured by the CU's memory pipeline then waits while its
+  // previous MFMAs still execute, instead of in front of a whole burst.
+#define V4_SLOT_IL(T, KC, KG, ANEXT, ACUR, BC, KN, BN)                                             \
+  do {                                                                                             \
+    const __amdgpu_buffer_rsrc_t rs_ = ((KG) == centre) ? rs_ctr : rs_src;                         \
+    const unsigned base_ = (unsigned)idg * (unsigned)(CK * 4) + (unsigned)(q * 16);                \
+    const bool act_ = ((tm[T] >> (KC)) & 1u) != 0u;                                                \
+    const unsigned sob_ = (unsigned)(((ABL == 3 || ABL == 4) ? 0 : (mirror ? (kv - 1 - (KN)) : (KN))) * (NCH * NT * 1024)); \
+    _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch) {                                           \
+      BufLoad<4>::ld(rs_, base_ + (unsigned)(ch * 64), ANEXT[ch]);                                 \
+      if ((((T) * NCH + ch) * (NCH * NT)) % (RT * NCH) == 0) {                                     \
+        const int u_ = ((T) * NCH + ch) * (NCH * NT) / (RT * NCH);                                 \
+        BufLoadS<4>::ld(rs_w, wv[0], sob_ + (unsigned)(u_ * 1024), BN[u_ / NT][u_ % NT]);          \
+      }                                                                                            \
+      if (act_) {                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                              \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                      \
+                acc[T][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ACUR[ch][j], BC[ch][nt][j], acc[T][nt], 0, 0, 0); \
+      }                                                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                           \
+    }                                                                                              \
+  } while (0)
+#define V4_OFFSET_IL(KC, KN, BC, BN)                                                               \
+  do {                                                                                             \
+    idn = V4_IDX(KC, 2); V4_SLOT_IL(0, KC, KC, A1, A0, BC, KN, BN); idg = idn;                     \
+    idn = V4_IDX(KC, 3); V4_SLOT_IL(1, KC, KC, A0, A1, BC, KN, BN); idg = idn;                     \
+    idn = V4_IDX(KN, 0); V4_SLOT_IL(2, KC, KC, A1, A0, BC, KN, BN); idg = idn;                     \
+    idn = V4_IDX(KN, 1); V4_SLOT_IL(3, KC, KN, A0, A1, BC, KN, BN); idg = idn;                     \
+  } while (0)
+
   // PF == 2: tile 0's rows in AX, tile 1's in AY (possibly still in flight), idg = table entries of tile 2; the next offset
   // starts with (AY, AZ, AX)
 #define V4_OFFSET3(KC, KN, BC, BN, AX, AY, AZ)                                                     \
@@ -860,16 +893,18 @@ __global__ void __launch_bounds__(64) gather_gemm_v4_kernel(const float* __restr
       const bool more0 = umask != 0u;
       kn = more0 ? (__ffs((int)umask) - 1) : kc;
       umask &= umask - 1;
-      V4_OFFSET(kc, kn, B0, B1);
+      if constexpr (PF == 11) V4_OFFSET_IL(kc, kn, B0, B1); else V4_OFFSET(kc, kn, B0, B1);
       if (!more0) break;
       const bool more1 = umask != 0u;
       kc = more1 ? (__ffs((int)umask) - 1) : kn;
       umask &= umask - 1;
-      V4_OFFSET(kn, kc, B1, B0);
+      if constexpr (PF == 11) V4_OFFSET_IL(kn, kc, B1, B0); else V4_OFFSET(kn, kc, B1, B0);
       if (!more1) break;
     }
   }
 #undef V4_OFFSET
+#undef V4_OFFSET_IL
+#undef V4_SLOT_IL
 #undef V4_OFFSET3
 #undef V4_OFFSETD
 #undef V4_NEXT
@@ -1885,8 +1920,11 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
           return VC_OK;
         }
       }
-      if (epi_kind == VC_EPI_NONE && wpk && (g_conv_v4_pf == 2 || g_conv_v4_pf == 4)) {
-        if (g_conv_v4_pf == 2)
+      if (epi_kind == VC_EPI_NONE && wpk && (g_conv_v4_pf == 2 || g_conv_v4_pf == 4 || g_conv_v4_pf == 11)) {
+        if (g_conv_v4_pf == 11)
+          hipLaunchKernelGGL((gather_gemm_v4_kernel<CK, CN, BWD, VC_EPI_NONE, true, 0, 11>), grid4, dim3(64), lds4, st, src, src_centre,
+                             n_src, tbl, wpk, out, rep, order, n_out, kv, centre, mirror, epi);
+        else if (g_conv_v4_pf == 2)
           hipLaunchKernelGGL((gather_gemm_v4_kernel<CK, CN, BWD, VC_EPI_NONE, true, 0, 2>), grid4, dim3(64), lds4, st, src, src_centre,
                              n_src, tbl, wpk, out, rep, order, n_out, kv, centre, mirror, epi);
         else
