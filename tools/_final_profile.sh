@@ -1,6 +1,6 @@
 # Round-end measurement run on the GPU box: bench line(s), rocprofv3 --stats, PMC passes (each in its own run), kernel table.
 # Raw output under gpurun_out/f2/; tools/make_profiles.py turns it into the summaries committed under profiles/.
-D=gpurun_out/f3
+D=gpurun_out/f4
 mkdir -p $D
 R=$PWD
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $D/smoke.log 2>&1
@@ -21,5 +21,7 @@ python tools/trace_gaps.py $(find $D/stats -name "*kernel_trace.csv" | head -1) 
 find $D -name "*kernel_trace.csv" -delete
 timeout 150 python tools/kbench.py > $D/kbench.txt 2>&1
 timeout 100 python tools/step_phases.py > $D/phases.txt 2>&1
+timeout 60 python tools/nmsbench.py > $D/nmsbench.txt 2>&1
+(tools/ubench/gather_ubench; tools/ubench/gather_ubench 75991) > $D/gather_ubench.txt 2>&1
 grep -h ms_per_step $D/*.log | cut -c1-200
 echo finished
