@@ -214,3 +214,34 @@ def test_v4_whole_train_step_equals_v2(hip_backend, discard, monkeypatch):
         tol = 1e-5 * max(float(ref[2][k].abs().max()), 1e-30)
         assert float((ref[2][k] - got[2][k]).abs().max()) <= tol, k
         assert torch.equal(got[2][k], again[2][k]), k
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 32), (32, 64), (32, 32), (16, 64), (64, 16)])
+def test_v5_loader_consumer_kernel_bit_identical_to_v2(hip_backend, cin, cout):
+    """gather_gemm_v5_kernel (loader waves + MFMA-only waves, quad-mapped gathers through swizzled LDS stages; a developer
+    experiment behind vc_debug_set conv_v5, plain launches with a weight image): same MFMA sequence per row as v2."""
+    rng = np.random.default_rng(7 * cin + cout)
+    lib = hip_backend.lib
+    idx = synth.small_scene_indices(57, 9000, SHAPE3, 2)
+    n = idx.shape[0]
+    it = torch.from_numpy(idx).cuda()
+    x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.standard_normal((cout, 3, 3, 3, cin)) / 5).astype(np.float32)).cuda()
+    g = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32)).cuda()
+    pair, _ = hip_backend.subm_rulebook(it, SHAPE3, (3, 3, 3), (1, 1, 1), want_rep=False)
+    oi, _, pf, pb = hip_backend.sparse_rulebook(it, SHAPE3, 2, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1))
+    go = torch.from_numpy(rng.standard_normal((oi.shape[0], cout)).astype(np.float32)).cuda()
+
+    def run():
+        return (hip_backend.conv_forward(x, w, pair), hip_backend.conv_backward_input(g, w, pair, n, mirror=True),
+                hip_backend.conv_forward(x, w, pf), hip_backend.conv_backward_input(go, w, pb, n, mirror=False),
+                hip_backend.conv_forward(x[:70], w, pair[:, :70].contiguous().clamp(max=69)))
+
+    ref = run()
+    assert lib.vc_debug_set(b"conv_autopack", 1) == 0 and lib.vc_debug_set(b"conv_v5", 1) == 0
+    try:
+        got = run()
+    finally:
+        assert lib.vc_debug_set(b"conv_autopack", 0) == 0 and lib.vc_debug_set(b"conv_v5", 0) == 0
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)

@@ -1003,6 +1003,173 @@ __global__ void __launch_bounds__(64) gather_gemm_v4_kernel(const float* __restr
   }
 }
 
+// --------------------------------------------------------------------------------------------- K6/K7 v5 (loader / MFMA wave roles)
+// What §4.2b of DESIGN.md points at, as an experiment (vc_debug_set conv_v5, plain launches with a weight image only): the waves
+// that issue MFMAs never touch the vector-memory pipeline.  A 512-thread workgroup owns 64 output rows:
+//   * waves 0-3 ("MFMA waves", one per SIMD) own one 16-row tile each.  Per active offset they read their A fragments and the W_k
+//     fragments from LDS (ds_read_b128, conflict-free) and issue the MFMAs -- no VMEM instruction in their loop, so back-pressure
+//     of the CU's memory pipeline cannot stall an MFMA stream;
+//   * waves 4-7 ("loader waves") gather.  They are free to use the QUAD lane mapping (lane 4r + c reads 16 bytes of row r: one
+//     cache line per quad instead of four, tools/ubench/gather_ubench.hip), park the rows of offset j + 2 in registers while
+//     offset j computes, and write the rows of offset j + 1 into the other LDS stage in the MFMA-ready order (chunk swizzle
+//     slot = c ^ ((r >> 3) << 1): the consumers' ds_read_b128 hit 16 distinct bank groups); the same waves copy W_{k} (the
+//     fragment-ordered image, 1 KB contiguous per instruction) into the stage.
+// One block barrier per offset separates the two LDS stages.  Same MFMA sequence per output row as v2 / v4: bit-identical results.
+template <int CK, int CN, int EPI>
+__global__ void __launch_bounds__(512) gather_gemm_v5_kernel(const float* __restrict__ src,
+                                                             const float* __restrict__ src_centre, int64_t n_src,
+                                                             const int32_t* __restrict__ tbl,
+                                                             const float* __restrict__ wpk, float* __restrict__ out,
+                                                             const int32_t* __restrict__ rep,
+                                                             const int32_t* __restrict__ order, int64_t n_out, int kv,
+                                                             int centre, int mirror, ConvEpilogue epi) {
+  static_assert(CK % 16 == 0 && CN % 16 == 0 && ((CK / 16) * (CN / 16)) % 4 == 0, "v5: 16-channel chunks, W image split over 4 loader waves");
+  static_assert(EPI == VC_EPI_NONE, "v5 is an experiment: plain launches only");
+  constexpr int NCH = CK / 16, NT = CN / 16;
+  constexpr int TILE_A = NCH * 1024;                 // bytes of one 16-row tile in a stage: [ch][16 rows][64 B]
+  constexpr int STAGE_A = 4 * TILE_A, STAGE_B = NCH * NT * 1024;
+  constexpr int NWL = NCH * NT / 4;                  // 1 KB pieces of the W image per loader wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* s_a = smem;                          // [2][STAGE_A]
+  unsigned char* s_b = smem + 2 * STAGE_A;            // [2][STAGE_B]
+  int* s_idx = reinterpret_cast<int*>(smem + 2 * STAGE_A + 2 * STAGE_B);  // [kv][64]
+  int* s_row = s_idx + kv * 64;                        // [64]
+  unsigned* s_tm = reinterpret_cast<unsigned*>(s_row + 64);  // [4] active offsets per tile
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler too (scalar offsets, no waterfall loops)
+  const bool consumer = wave < 4;
+  const int i = lane & 15, q = lane >> 4;            // MFMA lane coordinates (consumers)
+  const int r = lane >> 2, c = lane & 3;             // quad mapping (loaders): row r of the tile, 16-byte piece c
+  int64_t lbid;
+  {
+    const unsigned nb = gridDim.x, bid = blockIdx.x, xcd = bid & 7u, qd = nb >> 3, rm = nb & 7u;
+    lbid = (int64_t)(xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    if (g_xcd_swizzle_off) lbid = bid;
+  }
+  const int64_t brow0 = lbid * 64;
+  const __amdgpu_buffer_rsrc_t rs_src =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)(n_src * CK * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_ctr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(src_centre ? src_centre : src), 0, (int)(n_src * CK * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wpk), 0, (int)(kv * CK * CN * 4), 0x00020000);
+
+  if (tid < 4) s_tm[tid] = 0u;
+  __syncthreads();
+  {  // the block's slice of the pair table: wave w stages offsets w, w + 8, ...; lane = row slot
+    const bool inb = brow0 + lane < n_out;
+    const int64_t row = inb ? (order ? (int64_t)order[brow0 + lane] : brow0 + lane) : -1;
+    if (wave == 0) s_row[lane] = (int)row;
+    const bool centre_only = (rep != nullptr) && inb && (rep[row] != (int32_t)row);
+    for (int k = wave; k < kv; k += 8) {
+      int v = inb ? tbl[(int64_t)k * n_out + row] : -1;
+      if (centre_only && k != centre) v = -1;
+      s_idx[k * 64 + lane] = v;
+      const unsigned long long b = __ballot(v >= 0);
+      if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if ((b >> (16 * t)) & 0xFFFFull) atomicOr(&s_tm[t], 1u << k);
+      }
+    }
+  }
+  __syncthreads();
+  unsigned rest = (unsigned)__builtin_amdgcn_readfirstlane((int)(s_tm[0] | s_tm[1] | s_tm[2] | s_tm[3]));
+  const unsigned mytm = (unsigned)__builtin_amdgcn_readfirstlane((int)s_tm[wave & 3]);
+  const int p = wave & 3;                             // loader wave p gathers tile p and copies quarter p of the W image
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float ga[NCH][4];                                   // loaders: the gathered rows parked in registers
+  float gw[NWL][4];
+
+  // consumer LDS read offsets (bytes inside a stage) / loader LDS write offsets
+  const int a_rd = p * TILE_A + i * 64 + ((q ^ ((i >> 3) << 1)) * 16);
+  const int a_wr = p * TILE_A + r * 64 + ((c ^ ((r >> 3) << 1)) * 16);
+
+#define V5_LOAD(K)                                                                                 \
+  do {                                                                                             \
+    const int id_ = s_idx[(K) * 64 + p * 16 + r];                                                  \
+    const __amdgpu_buffer_rsrc_t rs_ = ((K) == centre) ? rs_ctr : rs_src;                          \
+    const unsigned base_ = (unsigned)id_ * (unsigned)(CK * 4) + (unsigned)(c * 16);                \
+    _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch) BufLoad<4>::ld(rs_, base_ + (unsigned)(ch * 64), ga[ch]); \
+    const int kw_ = mirror ? (kv - 1 - (K)) : (K);                                                 \
+    _Pragma("unroll") for (int u = 0; u < NWL; ++u)                                                \
+        BufLoadS<4>::ld(rs_w, (unsigned)(lane * 16), (unsigned)(kw_ * STAGE_B + (p * NWL + u) * 1024), gw[u]); \
+  } while (0)
+#define V5_STORE(STG)                                                                              \
+  do {                                                                                             \
+    _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                             \
+        *reinterpret_cast<float4*>(s_a + (STG) * STAGE_A + a_wr + ch * 1024) = float4{ga[ch][0], ga[ch][1], ga[ch][2], ga[ch][3]}; \
+    _Pragma("unroll") for (int u = 0; u < NWL; ++u)                                                \
+        *reinterpret_cast<float4*>(s_b + (STG) * STAGE_B + (p * NWL + u) * 1024 + lane * 16) = float4{gw[u][0], gw[u][1], gw[u][2], gw[u][3]}; \
+  } while (0)
+#define V5_CONSUME(STG, K)                                                                         \
+  do {                                                                                             \
+    if ((mytm >> (K)) & 1u) {                                                                      \
+      float a_[NCH][4], b_[NCH][NT][4];                                                            \
+      _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch) {                                         \
+        const float4 v_ = *reinterpret_cast<const float4*>(s_a + (STG) * STAGE_A + a_rd + ch * 1024); \
+        a_[ch][0] = v_.x; a_[ch][1] = v_.y; a_[ch][2] = v_.z; a_[ch][3] = v_.w;                    \
+      }                                                                                            \
+      _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
+          _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                      \
+            const float4 v_ = *reinterpret_cast<const float4*>(s_b + (STG) * STAGE_B + (ch * NT + nt) * 1024 + lane * 16); \
+            b_[ch][nt][0] = v_.x; b_[ch][nt][1] = v_.y; b_[ch][nt][2] = v_.z; b_[ch][nt][3] = v_.w; \
+          }                                                                                        \
+      _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j)                                            \
+              _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                    \
+                  acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[ch][j], b_[ch][nt][j], acc[nt], 0, 0, 0); \
+    }                                                                                              \
+  } while (0)
+
+  if (rest != 0u) {
+    int kc = __ffs((int)rest) - 1;
+    rest &= rest - 1;
+    int kn = rest ? (__ffs((int)rest) - 1) : -1;
+    rest &= rest - 1;
+    if (!consumer) {
+      V5_LOAD(kc);
+      V5_STORE(0);
+      if (kn >= 0) V5_LOAD(kn);
+    }
+    __syncthreads();
+    int stage = 0;
+    for (;;) {
+      const int kn2 = rest ? (__ffs((int)rest) - 1) : -1;
+      rest &= rest - 1;
+      if (consumer) {
+        V5_CONSUME(stage, kc);
+      } else {
+        if (kn >= 0) V5_STORE(stage ^ 1);
+        if (kn2 >= 0) V5_LOAD(kn2);
+      }
+      __syncthreads();
+      if (kn < 0) break;
+      kc = kn; kn = kn2; stage ^= 1;
+    }
+  }
+#undef V5_CONSUME
+#undef V5_STORE
+#undef V5_LOAD
+
+  if (consumer) {
+    int64_t orow[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) orow[reg] = s_row[p * 16 + q * 4 + reg];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 16 + i;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        if (orow[reg] >= 0) out[orow[reg] * CN + n] = acc[nt][reg];
+    }
+  }
+}
+
 // --------------------------------------------------------------------------------------------- K6/K7 v3 (LDS row windows)
 // The gather-GEMM for tables whose rows are in ascending coordinate order (the SubM convs of stages 2-4, forward and
 // backward-input): the feature gathers are staged through LDS instead of going L2 -> VGPR per kernel offset.
@@ -1834,6 +2001,7 @@ static float* autopack_scratch(bool bwd) {
 // Wave-autonomous kernel (v4): vc_debug_set conv_v4 = 0 never (default) | 1 every eligible shape (both channel counts multiples
 // of 16, fp32 operands) | 2 = per launch (the rule below, from tools/kbench.py --v4 A/B runs)
 int g_conv_v4 = 0;   // off: inside the train step (weight-gradient stream contending for the same CUs) the table ties or loses, 5.64 vs 5.60 ms
+int g_conv_v5 = 0;             // developer: loader / MFMA wave-role kernel (plain launches with a weight image)
 int g_conv_v4_pf = 1;          // developer: gather prefetch distance of the v4 kernel (1 | 2 | 4), plain launches with an image only
 int g_conv_v4_ablate = 0;      // developer ablations of the v4 kernel (see its ABL parameter); results are wrong when set
 // Measured (tools/kbench.py --v4 0|1 --autopack, VirConv-L bs 4, profiles/r02_kbench_v4.txt): a wave per 64 rows needs about
@@ -1889,6 +2057,18 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
           VC_CHECK_LAUNCH("pack_weights_kernel");
           wpk = scratch;
         }
+      }
+    }
+  }
+  if constexpr (CK % 16 == 0 && CN % 16 == 0 && ((CK / 16) * (CN / 16)) % 4 == 0) {
+    if (g_conv_v5 && wpk && epi_kind == VC_EPI_NONE && kv <= 32 && n_src * CK * 4 < (1LL << 31)) {
+      constexpr size_t lds_ab = (size_t)2 * 4 * (CK / 16) * 1024 + (size_t)2 * (CK / 16) * (CN / 16) * 1024;
+      const size_t lds5 = lds_ab + (size_t)(kv + 1) * 64 * sizeof(int) + 64;
+      if (lds5 <= 64 * 1024) {
+        hipLaunchKernelGGL((gather_gemm_v5_kernel<CK, CN, VC_EPI_NONE>), dim3((unsigned)cdiv(n_out, 64)), dim3(512), lds5, st, src,
+                           src_centre, n_src, tbl, wpk, out, rep, order, n_out, kv, centre, mirror, epi);
+        VC_CHECK_LAUNCH("gather_gemm_v5_kernel");
+        return VC_OK;
       }
     }
   }
@@ -2196,6 +2376,7 @@ int vc_debug_set(const char* key, int value) {
   if (key && !strcmp(key, "conv_autopack")) { g_conv_autopack = value; return VC_OK; }
   if (key && !strcmp(key, "conv_v4_ablate")) { g_conv_v4_ablate = value; return VC_OK; }
   if (key && !strcmp(key, "conv_v4_pf")) { g_conv_v4_pf = value; return VC_OK; }
+  if (key && !strcmp(key, "conv_v5")) { g_conv_v5 = value; return VC_OK; }
   if (key && !strcmp(key, "conv_packed")) { g_conv_use_packed = value; return VC_OK; }
   if (key && !strcmp(key, "conv_window")) { g_conv_window = value; return VC_OK; }
   if (key && !strcmp(key, "conv_nw")) { g_conv_nw = (value == 8 || value == 4) ? value : 0; return VC_OK; }
