@@ -33,7 +33,12 @@ def ref_lib():
             if build_ref.build(verbose=False) is None:
                 return None
         import torch  # noqa: F401  (libtorch must be in the process before the reference library resolves its symbols)
-        lib = ctypes.CDLL(path)
+        try:
+            lib = ctypes.CDLL(path)
+        except OSError as e:   # built against another libtorch: treat as "not built" (the numpy restatement still checks the kernels)
+            import warnings
+            warnings.warn(f"oracle/_ref/libiou3d_ref.so does not load here ({e}); rebuild with python -m oracle.build_ref")
+            return None
         lib.ref_boxes_iou_bev_cpu.restype = ctypes.c_int
         lib.ref_boxes_iou_bev_cpu.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         _REF = lib
