@@ -245,3 +245,35 @@ def test_v5_loader_consumer_kernel_bit_identical_to_v2(hip_backend, cin, cout):
         assert lib.vc_debug_set(b"conv_autopack", 0) == 0 and lib.vc_debug_set(b"conv_v5", 0) == 0
     for a, b in zip(ref, got):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (64, 32), (32, 64), (64, 64)])
+def test_dx_shift_variant_is_bit_identical(hip_backend, cin, cout):
+    """conv_dxs (the dx = +-1 fragments of a 27-offset SubM table taken from the group's centre fragment by a DPP lane shift where
+    the table says so, gathered otherwise): same operands, same MFMA order -- bit-identical on a coordinate-sorted tensor (where
+    most lanes shift) and on a row-permuted one (where almost none does).  A developer experiment, off by default."""
+    rng = np.random.default_rng(31 * cin + cout)
+    lib = hip_backend.lib
+    idx = synth.small_scene_indices(58, 9000, SHAPE3, 2)
+    srt = idx[np.lexsort((idx[:, 3], idx[:, 2], idx[:, 1], idx[:, 0]))]
+    for tab in (srt, idx):
+        n = tab.shape[0]
+        it = torch.from_numpy(np.ascontiguousarray(tab)).cuda()
+        pair, _ = hip_backend.subm_rulebook(it, SHAPE3, (3, 3, 3), (1, 1, 1), want_rep=False)
+        x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).cuda()
+        g = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32)).cuda()
+        w = torch.from_numpy((rng.standard_normal((cout, 3, 3, 3, cin)) / 5).astype(np.float32)).cuda()
+
+        def run():
+            y, partial = hip_backend.conv_forward_stats(x, w, pair)
+            return hip_backend.conv_forward(x, w, pair), hip_backend.conv_backward_input(g, w, pair, n, mirror=True), y, partial
+
+        assert lib.vc_debug_set(b"conv_autopack", 1) == 0
+        try:
+            ref = run()
+            assert lib.vc_debug_set(b"conv_dxs", 1) == 0
+            got = run()
+        finally:
+            assert lib.vc_debug_set(b"conv_dxs", 0) == 0 and lib.vc_debug_set(b"conv_autopack", 0) == 0
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)

@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--ablate", type=int, default=0, help="v4 ablations (vc_debug_set conv_v4_ablate; wrong results): 1 no MFMA | 2 coalesced gathers | 3 W from one image | 4 = 2 + 3")
     ap.add_argument("--pf", type=int, default=1, help="v4 gather prefetch distance (vc_debug_set conv_v4_pf): 1 | 2 | 4")
     ap.add_argument("--v5", type=int, default=0, help="loader / MFMA wave-role gather-GEMM (vc_debug_set conv_v5; needs --autopack)")
+    ap.add_argument("--dxs", type=int, default=-1, help="dx shift in the LDS-staged kernel (vc_debug_set conv_dxs): 0 | 1; -1 = library default; needs --autopack")
     ap.add_argument("--layers", default="", help="comma-separated substrings: only time layers whose name contains one of them")
     args = ap.parse_args()
     ops.WINDOW_GATHER = bool(args.window)
@@ -76,6 +77,8 @@ def main():
     assert be.lib.vc_debug_set(b"conv_v4_ablate", args.ablate) == 0
     assert be.lib.vc_debug_set(b"conv_v4_pf", args.pf) == 0
     assert be.lib.vc_debug_set(b"conv_v5", args.v5) == 0
+    if args.dxs >= 0:
+        assert be.lib.vc_debug_set(b"conv_dxs", args.dxs) == 0
     torch.zeros(1, device=dev)
     assert be.lib.vc_debug_set(b"xcd_swizzle_off", 1 if args.no_xcd else 0) == 0
     batch = bench.make_batch(list(range(args.bs)), dev, training=True)

@@ -63,6 +63,8 @@ class HipBackend:
             check(self.lib.vc_debug_set(b"conv_packed", int(os.environ["VIRCONV_CONV_PACKED"])), "vc_debug_set")
         if os.environ.get("VIRCONV_BW_ROWS"):   # weight gradient: target rows per block
             check(self.lib.vc_debug_set(b"bw_rows_per_split", int(os.environ["VIRCONV_BW_ROWS"])), "vc_debug_set")
+        if os.environ.get("VIRCONV_CONV_DXS"):   # 0 = no dx shift in the gather-GEMM (A/B)
+            check(self.lib.vc_debug_set(b"conv_dxs", int(os.environ["VIRCONV_CONV_DXS"])), "vc_debug_set")
         if os.environ.get("VIRCONV_CONV_V4"):   # wave-autonomous gather-GEMM: 0 never | 1 every eligible shape | 2 library table
             check(self.lib.vc_debug_set(b"conv_v4", int(os.environ["VIRCONV_CONV_V4"])), "vc_debug_set")
 

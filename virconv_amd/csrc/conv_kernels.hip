@@ -303,7 +303,16 @@ struct ConvEpilogue {
 };
 static constexpr int VC_EPI_BWD = 3;  // internal (not part of vc_epilogue: selected by vc_conv_backward_input_epilogue)
 
-template <int CK, int CN, bool BWD, int RT, int OT, int EPI, int NW = 4, bool PK = false>
+// DXS ("dx shift", 27-offset tables, one tile per wave): the offsets of one (dz, dy) group are the dx = -1 / 0 / +1 taps.  Where
+// the output rows of a tile are x-adjacent voxels -- the normal case on a tensor whose rows are in ascending (b, z, y, x) order:
+// 81-90 % of the dx = +-1 rows at stages 2-4, tests/analysis_dx_shift.py -- the row a lane needs for dx = -1 is the row its left
+// neighbour lane needs for dx = 0 (tbl[3g][i] == tbl[3g+1][i-1]), and for dx = +1 its right neighbour's.  So the centre
+// fragment of a group is gathered ONCE and kept; a side offset takes it shifted by one lane inside the 16-lane MFMA row (DPP
+// row_shr / row_shl) wherever the table entries agree, and gathers only the lanes that disagree (index -1 for the others: no
+// memory access; no instruction at all when every lane agrees).  The check is per lane on the table itself, so any table is
+// handled correctly; the arithmetic -- operands, MFMA order -- is unchanged, results are bit-identical.  What it buys is the
+// CU's vector-memory pipeline: 1.3-1.5 gathered rows per (tile, side offset) instead of 7-13.
+template <int CK, int CN, bool BWD, int RT, int OT, int EPI, int NW = 4, bool PK = false, bool DXS = false>
 __global__ void __launch_bounds__(64 * NW) gather_gemm_v2_kernel(const float* __restrict__ src,
                                                              const float* __restrict__ src_centre, int64_t n_src,
                                                              const int32_t* __restrict__ tbl,
@@ -313,6 +322,7 @@ __global__ void __launch_bounds__(64 * NW) gather_gemm_v2_kernel(const float* __
                                                              int centre, int mirror, ConvEpilogue epi) {
   static_assert(EPI == VC_EPI_NONE || RT == 1, "epilogues exist for the one-tile-per-wave kernel only");
   static_assert(!PK || (CK % 16 == 0 && OT == VC_OPERAND_F32), "packed weight images: fp32 operands, 16-channel K chunks");
+  static_assert(!DXS || (RT == 1 && CK % 16 == 0 && OT == VC_OPERAND_F32), "dx shift: one tile per wave, 16-byte row chunks, fp32");
   static_assert(EPI == VC_EPI_NONE || (EPI == VC_EPI_BWD) == BWD, "STATS / AFFINE: forward kernel; BWD: backward-input kernel");
   constexpr int V = (CK >= 16) ? 4 : CK / 4;
   constexpr int NCH = CK / (4 * V);
@@ -480,6 +490,99 @@ __global__ void __launch_bounds__(64 * NW) gather_gemm_v2_kernel(const float* __
     }                                                                                              \
   } while (0)
 
+  if constexpr (DXS) {
+    // C = centre fragment of the loaded group; idc = its table entries; F0 / F1 = operand sets (a_cur / a_nxt): first the target of
+    // the fix-up gather, then (VC_DXS_FORM, right before the MFMAs) the finished operand
+    float c_reg[NCH][V];
+    int idc = -1, gl = -1;
+    int mt_cur = 0, mt_nxt = 0, side_cur = 1, side_nxt = 1;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+      for (int j = 0; j < V; ++j) { c_reg[ch][j] = 0.f; a_cur[0][ch][j] = 0.f; a_nxt[0][ch][j] = 0.f; }
+
+#define VC_DXS_ISSUE(K, F, MT, SIDE, ACT)                                                          \
+  do {                                                                                             \
+    const int g_ = (K) / 3;                                                                        \
+    SIDE = (K) - 3 * g_;                                                                           \
+    if (g_ != gl) {   /* new group: its centre rows, all of them */                                \
+      gl = g_;                                                                                     \
+      idc = s_idx[(3 * g_ + 1) * TM + wave * 16 + i];                                              \
+      const unsigned cb_ = (unsigned)idc * (unsigned)(CK * 4) + (unsigned)(q * V * 4);             \
+      _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
+          BufLoad<V>::ld(rs_src, cb_ + (unsigned)(ch * 4 * V * 4), c_reg[ch]);                     \
+    }                                                                                              \
+    const int idk_ = s_idx[(K) * TM + wave * 16 + i];                                              \
+    ACT[0] = __builtin_amdgcn_readfirstlane((int)(__ballot(idk_ >= 0) != 0ULL));                   \
+    MT = 1;                                                                                        \
+    if (SIDE != 1) {                                                                               \
+      const int sh_ = (SIDE == 0) ? __builtin_amdgcn_update_dpp(-2, idc, 0x111, 0xf, 0xf, false)   \
+                                  : __builtin_amdgcn_update_dpp(-2, idc, 0x101, 0xf, 0xf, false);  \
+      MT = (idk_ == sh_) ? 1 : 0;                                                                  \
+      if (__ballot(MT == 0) != 0ULL) {   /* some lane's row is not its neighbour's centre row: gather those lanes only */ \
+        const int idf_ = MT ? -1 : idk_;                                                           \
+        const unsigned fb_ = (unsigned)idf_ * (unsigned)(CK * 4) + (unsigned)(q * V * 4);          \
+        _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                         \
+            BufLoad<V>::ld(rs_src, fb_ + (unsigned)(ch * 4 * V * 4), F[0][ch]);                    \
+      }                                                                                            \
+    }                                                                                              \
+  } while (0)
+
+#define VC_DXS_FORM(F, MT, SIDE)                                                                   \
+  do {                                                                                             \
+    if (SIDE == 1) {                                                                               \
+      _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
+          _Pragma("unroll") for (int j = 0; j < V; ++j) F[0][ch][j] = c_reg[ch][j];                \
+    } else if (SIDE == 0) {                                                                        \
+      _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
+          _Pragma("unroll") for (int j = 0; j < V; ++j) {                                          \
+            const int s_ = __builtin_amdgcn_update_dpp(0, __float_as_int(c_reg[ch][j]), 0x111, 0xf, 0xf, false); \
+            F[0][ch][j] = MT ? __int_as_float(s_) : F[0][ch][j];                                   \
+          }                                                                                        \
+    } else {                                                                                       \
+      _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
+          _Pragma("unroll") for (int j = 0; j < V; ++j) {                                          \
+            const int s_ = __builtin_amdgcn_update_dpp(0, __float_as_int(c_reg[ch][j]), 0x101, 0xf, 0xf, false); \
+            F[0][ch][j] = MT ? __int_as_float(s_) : F[0][ch][j];                                   \
+          }                                                                                        \
+    }                                                                                              \
+  } while (0)
+
+    if (bmask != 0u) {
+      int kcur = __ffs((int)bmask) - 1;
+      bmask &= bmask - 1;
+      VC_LOAD_B(kcur);
+      VC_DXS_ISSUE(kcur, a_cur, mt_cur, side_cur, act_cur);
+      for (;;) {
+        VC_STORE_B(0);
+        __syncthreads();
+        VC_DXS_FORM(a_cur, mt_cur, side_cur);
+        const bool more0 = bmask != 0u;
+        const int k1 = more0 ? (__ffs((int)bmask) - 1) : kcur;
+        bmask &= bmask - 1;
+        if (more0) {
+          VC_LOAD_B(k1);
+          VC_DXS_ISSUE(k1, a_nxt, mt_nxt, side_nxt, act_nxt);
+        }
+        VC_MFMA(a_cur, act_cur, 0);
+        if (!more0) break;
+        VC_STORE_B(1);
+        __syncthreads();
+        VC_DXS_FORM(a_nxt, mt_nxt, side_nxt);
+        const bool more1 = bmask != 0u;
+        kcur = more1 ? (__ffs((int)bmask) - 1) : k1;
+        bmask &= bmask - 1;
+        if (more1) {
+          VC_LOAD_B(kcur);
+          VC_DXS_ISSUE(kcur, a_cur, mt_cur, side_cur, act_cur);
+        }
+        VC_MFMA(a_nxt, act_nxt, 1);
+        if (!more1) break;
+      }
+    }
+#undef VC_DXS_FORM
+#undef VC_DXS_ISSUE
+  } else
   if (bmask != 0u) {
     int kcur = __ffs((int)bmask) - 1;
     bmask &= bmask - 1;
@@ -2001,6 +2104,12 @@ static float* autopack_scratch(bool bwd) {
 // Wave-autonomous kernel (v4): vc_debug_set conv_v4 = 0 never (default) | 1 every eligible shape (both channel counts multiples
 // of 16, fp32 operands) | 2 = per launch (the rule below, from tools/kbench.py --v4 A/B runs)
 int g_conv_v4 = 0;   // off: inside the train step (weight-gradient stream contending for the same CUs) the table ties or loses, 5.64 vs 5.60 ms
+// dx shift in the LDS-staged kernel (vc_debug_set conv_dxs; needs a weight image).  OFF: measured slower although it halves the
+// gathered rows -- SubM 64->32 194 -> 231 us, 32->32 113 -> 129 us, 16->16 65 -> 88 us, train step 5.60 -> 5.74 ms
+// (tools/kbench.py --autopack --dxs 0|1).  The third fragment set costs the 64-channel shapes three waves per SIMD (62 -> 94
+// VGPRs; forcing 6 waves spills), but the 32-channel shapes keep all eight and lose as well: the 32 DPP / select operations per
+// side offset sit between the loads' arrival and the MFMAs.  Fewer gathered rows alone do not buy time.
+int g_conv_dxs = 0;
 int g_conv_v5 = 0;             // developer: loader / MFMA wave-role kernel (plain launches with a weight image)
 int g_conv_v4_pf = 1;          // developer: gather prefetch distance of the v4 kernel (1 | 2 | 4), plain launches with an image only
 int g_conv_v4_ablate = 0;      // developer ablations of the v4 kernel (see its ABL parameter); results are wrong when set
@@ -2154,6 +2263,9 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
       return VC_OK;
     }
   }
+  // dx shift (see the kernel's DXS parameter): SubM-shaped 27-offset tables in natural row order, where it has something to find
+  const bool dxs = g_conv_dxs && wpk != nullptr && kv == 27 && n_src == n_out && order == nullptr && rep == nullptr &&
+                   src_centre == nullptr;
   if (g_conv_variant == 2 && kv <= 32 && n_src * CK * 4 < (1LL << 31)) {
     constexpr int V = (CK >= 16) ? 4 : CK / 4;
     constexpr int NCH = CK / (4 * V);
@@ -2173,6 +2285,11 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
 #define VC_L8(B_, E_)                                                                                                          \
   do {                                                                                                                         \
     if constexpr (CN % 16 == 0) {                                                                                              \
+      if (wpk && dxs) {                                                                                                        \
+        hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, B_, 1, VC_OPERAND_F32, E_, 8, true, true>), grid8, dim3(512), lds8, st, src, \
+                           src_centre, n_src, tbl, wpk, out, rep, order, n_out, kv, centre, mirror, epi);                     \
+        break;                                                                                                                 \
+      }                                                                                                                        \
       if (wpk) {                                                                                                               \
         hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, B_, 1, VC_OPERAND_F32, E_, 8, true>), grid8, dim3(512), lds8, st, src, \
                            src_centre, n_src, tbl, wpk, out, rep, order, n_out, kv, centre, mirror, epi);                     \
@@ -2211,6 +2328,10 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
 #define VC_L2(B_, E_)                                                                                                          \
   do {                                                                                                                         \
     if constexpr (CK % 16 == 0 && CN % 16 == 0) {                                                                              \
+      if (wpk && dxs) {                                                                                                        \
+        hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, B_, 1, VC_OPERAND_F32, E_, 4, true, true>), grid, dim3(256), lds, st, VC_ARGS_PK); \
+        break;                                                                                                                 \
+      }                                                                                                                        \
       if (wpk) {                                                                                                               \
         hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, B_, 1, VC_OPERAND_F32, E_, 4, true>), grid, dim3(256), lds, st, VC_ARGS_PK); \
         break;                                                                                                                 \
@@ -2377,6 +2498,7 @@ int vc_debug_set(const char* key, int value) {
   if (key && !strcmp(key, "conv_v4_ablate")) { g_conv_v4_ablate = value; return VC_OK; }
   if (key && !strcmp(key, "conv_v4_pf")) { g_conv_v4_pf = value; return VC_OK; }
   if (key && !strcmp(key, "conv_v5")) { g_conv_v5 = value; return VC_OK; }
+  if (key && !strcmp(key, "conv_dxs")) { g_conv_dxs = value; return VC_OK; }
   if (key && !strcmp(key, "conv_packed")) { g_conv_use_packed = value; return VC_OK; }
   if (key && !strcmp(key, "conv_window")) { g_conv_window = value; return VC_OK; }
   if (key && !strcmp(key, "conv_nw")) { g_conv_nw = (value == 8 || value == 4) ? value : 0; return VC_OK; }
