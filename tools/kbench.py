@@ -55,8 +55,8 @@ def main():
     ap.add_argument("--nw", type=int, default=0, help="direct kernel: waves per block 4 | 8 (vc_debug_set conv_nw); 0 = library default")
     ap.add_argument("--v4", type=int, default=-1, help="wave-autonomous gather-GEMM (vc_debug_set conv_v4): 0 never | 1 every eligible shape | 2 library table; -1 = leave the default")
     ap.add_argument("--autopack", action="store_true", help="repack the weights into fragment order before every conv launch (vc_debug_set conv_autopack; the pack launch is inside the timing)")
-    ap.add_argument("--ablate", type=int, default=0, help="v4 ablations (vc_debug_set conv_v4_ablate; wrong results): 1 no MFMA | 2 coalesced gathers | 3 W from one image | 4 = 2 + 3")
-    ap.add_argument("--pf", type=int, default=1, help="v4 gather prefetch distance (vc_debug_set conv_v4_pf): 1 | 2 | 4")
+    ap.add_argument("--ablate", type=int, default=0, help="v4 ablations (vc_debug_set conv_v4_ablate; wrong results; library built with VIRCONV_HIPCC_EXTRA=-DVC_EXPERIMENTS): 1 no MFMA | 2 coalesced gathers | 3 W from one image | 4 = 2 + 3")
+    ap.add_argument("--pf", type=int, default=1, help="v4 gather prefetch distance (vc_debug_set conv_v4_pf; values other than 1 need a -DVC_EXPERIMENTS build): 1 | 2 | 4 | 11 = interleaved")
     ap.add_argument("--v5", type=int, default=0, help="loader / MFMA wave-role gather-GEMM (vc_debug_set conv_v5; needs --autopack)")
     ap.add_argument("--dxs", type=int, default=-1, help="dx shift in the LDS-staged kernel (vc_debug_set conv_dxs): 0 | 1; -1 = library default; needs --autopack")
     ap.add_argument("--layers", default="", help="comma-separated substrings: only time layers whose name contains one of them")

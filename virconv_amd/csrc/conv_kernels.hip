@@ -2194,6 +2194,7 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
                             tbl, w, out, rep, order, n_out, kv, centre, mirror, epi);                                          \
   } while (0)
       bool done = true;
+#ifdef VC_EXPERIMENTS   // ablations and prefetch-depth variants of v4: measured, kept out of the default build
       if constexpr (!BWD && CN == 32 && (CK == 64 || CK == 32)) {
         if (g_conv_v4_ablate && wpk && epi_kind == VC_EPI_NONE) {
 #define VC_L4A(A_) hipLaunchKernelGGL((gather_gemm_v4_kernel<CK, CN, false, VC_EPI_NONE, true, A_, 1>), grid4, dim3(64), lds4, st, src, \
@@ -2220,7 +2221,9 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
           hipLaunchKernelGGL((gather_gemm_v4_kernel<CK, CN, BWD, VC_EPI_NONE, true, 0, 4>), grid4, dim3(64), lds4, st, src, src_centre,
                              n_src, tbl, wpk, out, rep, order, n_out, kv, centre, mirror, epi);
       }
-      else if (epi_kind == VC_EPI_NONE) VC_L4(VC_EPI_NONE);
+      else
+#endif
+      if (epi_kind == VC_EPI_NONE) VC_L4(VC_EPI_NONE);
       else if (BWD && epi_kind == VC_EPI_BWD) { if constexpr (BWD) VC_L4(VC_EPI_BWD); }
       else if (!BWD && epi_kind == VC_EPI_STATS) { if constexpr (!BWD) VC_L4(VC_EPI_STATS); }
       else if (!BWD && epi_kind == VC_EPI_AFFINE) { if constexpr (!BWD) VC_L4(VC_EPI_AFFINE); }
@@ -2495,8 +2498,16 @@ int vc_debug_set(const char* key, int value) {
   if (key && !strcmp(key, "conv_rt")) { g_conv_rt = value; return VC_OK; }
   if (key && !strcmp(key, "conv_v4")) { g_conv_v4 = value; return VC_OK; }
   if (key && !strcmp(key, "conv_autopack")) { g_conv_autopack = value; return VC_OK; }
+#ifdef VC_EXPERIMENTS
   if (key && !strcmp(key, "conv_v4_ablate")) { g_conv_v4_ablate = value; return VC_OK; }
   if (key && !strcmp(key, "conv_v4_pf")) { g_conv_v4_pf = value; return VC_OK; }
+#else
+  if (key && (!strcmp(key, "conv_v4_ablate") || !strcmp(key, "conv_v4_pf"))) {
+    if (value == (!strcmp(key, "conv_v4_pf") ? 1 : 0)) return VC_OK;   // the default build has only the shipped schedule
+    set_error("vc_debug_set %s = %d: build the library with -DVC_EXPERIMENTS (VIRCONV_HIPCC_EXTRA) for the v4 experiment variants", key, value);
+    return VC_EINVAL;
+  }
+#endif
   if (key && !strcmp(key, "conv_v5")) { g_conv_v5 = value; return VC_OK; }
   if (key && !strcmp(key, "conv_dxs")) { g_conv_dxs = value; return VC_OK; }
   if (key && !strcmp(key, "conv_packed")) { g_conv_use_packed = value; return VC_OK; }
