@@ -36,6 +36,16 @@ class OracleBackend:
                                                         dilation)
         return torch.from_numpy(oi), oshape, torch.from_numpy(pf), torch.from_numpy(pb)
 
+    def sparse_rulebook_chain(self, indices, spatial_shape, batch_size, geoms):
+        """The contract of HipBackend.sparse_rulebook_chain, level by level (so that the geometry plan's "every strided rulebook is
+        ready" path runs in the CPU tests too): [(out_indices, out_shape, pair_fwd, pair_bwd, in_indices), ...]."""
+        res, cur, shape = [], indices, tuple(int(v) for v in spatial_shape)
+        for ksize, stride, padding, dilation in geoms:
+            oi, oshape, pf, pb = self.sparse_rulebook(cur, shape, batch_size, ksize, stride, padding, dilation)
+            res.append((oi, oshape, pf, pb, cur))
+            cur, shape = oi, tuple(int(v) for v in oshape)
+        return res
+
     # ------------------------------------------------------------------ convolution
     def row_order(self, tbl, rep=None, centre=-1, window=1024):
         return None  # scheduling hint of the HIP path only; results never depend on it

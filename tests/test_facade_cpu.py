@@ -197,3 +197,40 @@ def test_front_end_refuses_host_tensors_on_the_product_backend():
     with pytest.raises(_lib.VirConvError):
         be.frontend_voxelize_mean(torch.zeros((10, 8)), torch.zeros((10, 8)), 2, 0.8, synth.POINT_CLOUD_RANGE, synth.VOXEL_SIZE,
                                   5, 100, True)
+
+
+def test_geometry_plan_uses_the_one_read_rulebook_chain_when_no_discard_is_active(oracle_backend, monkeypatch):
+    """VirConvL8x.build_plan: without layer discard (inference / spconv2_noop) the four strided rulebooks come from ONE
+    sparse_rulebook_chain call and the plan equals the level-by-level one; with discard the chain is not used."""
+    import numpy as np
+    import torch
+    from helpers import GRID, MODEL_CFG, golden_batch, load_golden
+    from virconv_amd import ops
+    from virconv_amd.backbone import VirConvL8x
+
+    g = load_golden()
+    calls = []
+    orig = type(oracle_backend).sparse_rulebook_chain
+    monkeypatch.setattr(type(oracle_backend), "sparse_rulebook_chain",
+                        lambda self, *a, **k: (calls.append(len(a[3])), orig(self, *a, **k))[1])
+
+    def plan(mode, chain):
+        monkeypatch.setattr(ops, "CHAIN_RULEBOOKS", chain)
+        model = VirConvL8x(dict(MODEL_CFG, LAYER_DISCARD_MODE=mode), input_channels=8, grid_size=GRID).train(True)
+        bd = golden_batch(g, "cpu")
+        calib = ops.calib_tensor(bd["calib"], bd["voxel_features"].device) if not torch.is_tensor(bd["calib"]) else bd["calib"]
+        torch.manual_seed(3)
+        return model.build_plan(bd["voxel_coords"], bd["batch_size"], calib, bd.get("aug_param"), bd)
+
+    ref = plan("spconv2_noop", False)
+    assert calls == []
+    got = plan("spconv2_noop", True)
+    assert calls == [4]                                   # stage 2, 3, 4 down convs + conv_out in one call
+    for a, b in zip(ref["stages"], got["stages"]):
+        assert np.array_equal(a["out_indices"].numpy(), b["out_indices"].numpy())
+        for k in a["rb3d"]:
+            assert np.array_equal(a["rb3d"][k].pair_fwd.numpy(), b["rb3d"][k].pair_fwd.numpy())
+    (ka, ra), (kb, rb) = next(iter(ref["conv_out"].items())), next(iter(got["conv_out"].items()))
+    assert ka == kb and np.array_equal(ra.pair_fwd.numpy(), rb.pair_fwd.numpy()) and np.array_equal(ra.out_indices.numpy(), rb.out_indices.numpy())
+    plan("spconv1_inplace", True)
+    assert calls == [4]                                   # layer discard between the stages: per-conv rulebooks

@@ -140,7 +140,7 @@ def build_sparse_rulebook_chain(indices: torch.Tensor, spatial_shape, batch_size
     stride / padding / dilation), or None when the backend has no chained path.  -> [{"ready": Rulebook}, ...]: handles that
     `finish_sparse_rulebook` accepts in place of a begun rulebook."""
     be = get_backend()
-    if not (CHAIN_RULEBOOKS and hasattr(be, "sparse_rulebook_chain") and indices.is_cuda and len(convs) >= 2):
+    if not (CHAIN_RULEBOOKS and hasattr(be, "sparse_rulebook_chain") and len(convs) >= 2):
         return None
     ndim = indices.shape[1] - 1
     geoms = [(ntuple(c.kernel_size, ndim), ntuple(c.stride, ndim), ntuple(c.padding, ndim), ntuple(c.dilation, ndim)) for c in convs]
