@@ -136,6 +136,21 @@ def make_loss_weights(device):
     return w
 
 
+def synthetic_loss(out, lw):
+    """loss = (out.dense() * G).sum() + sum_i (x_conv_i.features * g_i).sum()   (the heads are out of scope).
+    Written as dot products -- sum(dense * G) = <dense, G>, sum(X * g) = <X.sum(0), g> -- so that this stand-in for the heads
+    costs one reduction per term instead of an elementwise product plus a reduction over tensors of up to 36 MB."""
+    dense = out["encoded_spconv_tensor"].dense()
+    key = ("dense_flat", dense.shape[0])
+    if key not in lw:   # G broadcast over the batch, materialised once (setup, not per step)
+        lw[key] = lw["dense"].expand(dense.shape[0], -1, -1, -1, -1).contiguous().view(-1)
+    loss = torch.dot(dense.reshape(-1), lw[key])
+    for group in ("multi_scale_3d_features", "multi_scale_3d_features_mm"):
+        for name, t in out.get(group, {}).items():
+            loss = loss + torch.dot(t.features.sum(0), lw[name])
+    return loss
+
+
 def train_step(model, optimizer, batch, lw, grad_sync=None, raw=None):
     """fwd + bwd + Adam.  loss = (out.dense()*G).sum() + sum_i (x_conv_i.features * g_i).sum()  (heads out of scope).
     `raw`: run the data front-end on the raw points first (the --frontend workload); `batch` then only carries calib / aug."""
@@ -146,12 +161,7 @@ def train_step(model, optimizer, batch, lw, grad_sync=None, raw=None):
         bd = dict(batch)
         bd["voxel_features"] = batch["voxel_features"].clone()  # the backbone zeroes RGB in place
     out = model(bd)
-    loss = (out["encoded_spconv_tensor"].dense() * lw["dense"]).sum()
-    for name, t in out["multi_scale_3d_features"].items():
-        loss = loss + (t.features * lw[name]).sum()
-    if "multi_scale_3d_features_mm" in out:
-        for name, t in out["multi_scale_3d_features_mm"].items():
-            loss = loss + (t.features * lw[name]).sum()
+    loss = synthetic_loss(out, lw)
     loss.backward()
     if grad_sync is not None:
         grad_sync()  # data-parallel exchange: one flat RCCL all-reduce of the gradients
@@ -233,13 +243,16 @@ def run_infer(args, model, batch, device, rank, world):
 def _pmc_traffic(tdir, tck, tcn):
     """HBM bytes per launch of the traced kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected in separate
     runs of this same command and corrected as MI355X_MICROARCH.md prescribes; summary committed under profiles/).
-    PMC counters cannot be read from inside the process, so the number comes from that file; None if absent."""
-    path = os.path.join(ROOT, "profiles", f"r02_traffic_gather_gemm_{tck}_{tcn}_{tdir}.json")
-    try:
-        with open(path) as f:
-            return float(json.load(f)["hbm_bytes_per_launch_corrected"])
-    except Exception:
-        return None
+    PMC counters cannot be read from inside the process: the number is the one of the newest committed profile of this command,
+    and the JSON line says so (`traffic_source`); (None, None) if absent."""
+    for tag in ("r03", "r02"):
+        rel = os.path.join("profiles", f"{tag}_traffic_gather_gemm_{tck}_{tcn}_{tdir}.json")
+        try:
+            with open(os.path.join(ROOT, rel)) as f:
+                return float(json.load(f)["hbm_bytes_per_launch_corrected"]), rel + " (rocprofv3 --pmc passes of this command, not this run)"
+        except Exception:
+            continue
+    return None, None
 
 
 def main():
@@ -259,6 +272,8 @@ def main():
     ap.add_argument("--model", default="L", choices=["L", "8x"],
                     help="L = VirConvL8x, BASELINE configs[2] (default, the headline); 8x = VirConv8x (LiDAR + virtual-point "
                          "streams), the backbone of BASELINE configs[3], bs 2 per GPU unless --batch-size is given")
+    ap.add_argument("--family-steps", type=int, default=3,
+                    help="extra untimed steps after the timed region with every conv launch event-bracketed (family / step roofline)")
     ap.add_argument("--frontend", action="store_true",
                     help="include the GPU data front-end (input point discard + LiDAR-first voxeliser + MeanVFE from raw "
                          "device-resident points) in every timed step (model L)")
@@ -362,6 +377,19 @@ def main():
     trace = be.trace_end()
     dt = parallel.max_over_ranks(dt, device)
 
+    # Family- and step-level roofline (outside the timed region, rank 0): a few more steps with EVERY gather-GEMM and
+    # weight-gradient launch bracketed by HIP events on its launch stream (vc_trace_begin direction -1)
+    fam = None
+    if args.family_steps > 0:          # every rank steps (the gradient all-reduce is collective); rank 0 records
+        if rank == 0:
+            be.trace_begin("all", 0, 0, max_records=256 * args.family_steps)
+        for _ in range(args.family_steps):
+            train_step(ddp, optimizer, batch, lw, grad_sync, raw)
+        torch.cuda.synchronize()
+        if rank == 0:
+            fam = be.trace_end()
+    parallel.barrier()
+
     if rank != 0:
         return
     frames = bs * world * args.steps
@@ -373,8 +401,9 @@ def main():
         byts = sum(e["bytes"] for e in trace)
         ach = flops / (t_ms * 1e-3) / 1e12
         peak = MFMA_F32_PEAK_TFLOPS if args.operand == "f32" else MFMA_16BIT_PEAK_TFLOPS
+        traffic, traffic_src = _pmc_traffic(tdir, tck, tcn) if args.operand == "f32" else (None, None)
         roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": _pmc_traffic(tdir, tck, tcn) if args.operand == "f32" else None,
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": (f"gather_gemm_v3_kernel<CK={tck},CN={tcn},BWD={'true' if tdir == 'bwd' else 'false'}> (LDS row windows)"
                            if all(e["windowed"] for e in trace) else
                            f"gather_gemm_v2_kernel<CK={tck},CN={tcn},BWD={'true' if tdir == 'bwd' else 'false'},RT=1>"),
@@ -382,6 +411,25 @@ def main():
                 "algorithmic_gflop_per_launch": round(flops / n_launch / 1e9, 4),
                 "algorithmic_mb_per_launch": round(byts / n_launch / 1e6, 3),
                 "hbm_frac_of_algorithmic_bytes": round(byts / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if fam:
+            # family: all conv kernels of the step (forward, backward-input, weight gradient) -- algorithmic flops / kernel time;
+            # step: the same flops over the WALL time of a step (everything else -- BatchNorm, rulebooks, optimizer -- counts as loss)
+            k = args.family_steps
+            f_flops = sum(e["flops"] for e in fam)
+            f_ms = sum(e["ms"] for e in fam)
+            per_dir = {}
+            for e in fam:
+                d = per_dir.setdefault(e["dir"], [0.0, 0.0])
+                d[0] += e["flops"]; d[1] += e["ms"]
+            roof.update({
+                "family_frac": round(f_flops / (f_ms * 1e-3) / 1e12 / peak, 4),
+                "family_tflops": round(f_flops / (f_ms * 1e-3) / 1e12, 2),
+                "family_kernel_ms_per_step": {d: round(v[1] / k, 3) for d, v in per_dir.items()},
+                "family_gflop_per_step": round(f_flops / k / 1e9, 2),
+                "step_frac": round(f_flops / k / (dt / args.steps) / 1e12 / peak, 4),
+                "family_note": f"{k} extra steps after the timed region, HIP events around every conv launch on its own stream "
+                               "(the weight gradients run on a side stream beside the backward-input convs: their bracketed "
+                               "times overlap, the sum is kernel time, not wall time)"})
     if args.model == "8x":
         metric = "KITTI frames/sec (fwd+bwd) VirConv8x backbone (VirConv-T/S)"
         workload = ("BASELINE configs[3] backbone: VirConv8x (LiDAR stream + virtual-point MM stream) train step (fwd+bwd+Adam), "
@@ -403,7 +451,12 @@ def main():
         "config": {"workload": workload,
                    "frames_per_gpu": bs, "global_batch": bs * world,
                    "voxels_rank0": n_vox if args.frontend else int(batch["voxel_features"].shape[0]),
-                   "parallelism": f"dp{world}", "cpu_affinity": numa},
+                   "parallelism": f"dp{world}", "cpu_affinity": numa,
+                   "untimed_setup": {"settle_seconds_of_steps_before_warmup": settle, "allocator_priming_gib": 8,
+                                     "gc_freeze": os.environ.get("VIRCONV_GC_FREEZE", "1") != "0",
+                                     "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+                                     "streams": "main + geometry plan (high priority) + weight-gradient side stream",
+                                     "row_order": ops.ROW_ORDER}},
         "roofline": roof,
     }
     if world == 1 and not args.no_cpu_baseline:

@@ -218,6 +218,16 @@ int vc_group_sum(const float* dy, const int32_t* rep, int64_t n, int c, float* d
  * ONCE; the first word holds max|dy| as above, and the call hands the accumulators back all-zero (the convert kernel clears
  * what it reads) -- no 8*n*c-byte memset per layer.                                                                     */
 int vc_group_sum_prepare(void* ws, size_t ws_bytes, int64_t n, int c, void* stream);
+/* The same sum with the order of the additions fixed by the DATA instead of by integer arithmetic (round 3; what the unit /
+ * feature-pass calls use): the caller sorts the rows once per table by representative -- keys from vc_group_keys
+ * (keys[i] = rep[i] < 0 ? i : rep[i]), any STABLE ascending sort of (keys, row ids) -- and passes
+ * grp_plan = [order (n) | sorted keys (n)] int32.  Runs of equal keys are summed in ascending sorted position (plain fp32 adds),
+ * runs cut by a 32-row chunk border through one partial per chunk, combined in chunk order: no atomics, no max|dy| pass, no
+ * 8-byte accumulators, bit-stable.  c must be a power of two.  Same output contract as vc_group_sum (representatives only). */
+int vc_group_keys(const int32_t* rep, int64_t n, int32_t* keys, void* stream);
+size_t vc_group_sum_sorted_workspace_bytes(int64_t n, int c);
+int vc_group_sum_sorted(const float* dy, const int32_t* grp_plan, int64_t n, int c, float* dy_grp, void* ws, size_t ws_bytes,
+                        void* stream);
 
 /* ------------------------------------------------------------------------------------------------ K9 projection
  * Voxel index -> image pixel index.  Replaces index2points + index2uv +
@@ -349,7 +359,7 @@ int vc_bn_relu_backward_from_partial(const float* x, const float* dy, int dy_str
  *             the channel concat of NRConvBlock is written in place)
  *   backward: dy (row stride dy_stride, column dy_col0) -> d_raw (BatchNorm + ReLU backward), dgamma, dbeta; dx = conv^T(d_raw)
  *             through tbl_dx (SubM: pair_fwd, mirror = 1; strided: pair_bwd, mirror = 0; duplicate-pixel 2-D convs: rep /
- *             centre + the persistent group-sum accumulator `group_acc`, see vc_group_sum prepared = 2); dw = weight gradient. */
+ *             centre + the table's group plan `grp_plan`, see vc_group_sum_sorted); dw = weight gradient. */
 size_t vc_post_act_block_forward_workspace_bytes(int64_t n_in, int64_t n_out, int kv, int cin, int cout, int flags);
 int vc_post_act_block_forward(const float* x, int64_t n_in, const int32_t* pair_fwd, int64_t n_out, int kv,
                               const float* weight, int cin, int cout, const int32_t* row_order, int operand_type, int flags,
@@ -360,10 +370,10 @@ size_t vc_post_act_block_backward_workspace_bytes(int64_t n_out, int kv, int cin
 int vc_post_act_block_backward(const float* x, int64_t n_in, const float* y_raw, int64_t n_out, const float* dy,
                                int dy_stride, int dy_col0, const float* mean, const float* var, const float* gamma,
                                const float* beta, float eps, int relu, const int32_t* pair_fwd, const int32_t* tbl_dx,
-                               int64_t n_dx, int mirror, int centre, const int32_t* rep, const int32_t* row_order_dx, int kv,
+                               int64_t n_dx, int mirror, int centre, const int32_t* rep, const int32_t* grp_plan,
+                               const int32_t* row_order_dx, int kv,
                                const float* weight, int cin, int cout, int operand_type, int flags, int need_dx, int need_dw,
-                               float* d_raw, float* dx, float* dw, float* dgamma, float* dbeta, void* group_acc,
-                               size_t group_acc_bytes, void* ws, size_t ws_bytes,
+                               float* d_raw, float* dx, float* dw, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                                void* side_stream /* nullable hipStream_t: the weight gradient runs on it underneath the
                                backward-input conv; forked and joined inside the call */, void* stream);
 
@@ -398,6 +408,7 @@ typedef struct vc_pass_table {   /* one rulebook (vc_subm_rulebook / vc_spconv_e
   const int32_t* pair_fwd; const int32_t* pair_bwd /* strided only */; const int32_t* rep /* duplicate-pixel rule or NULL */;
   const int32_t* order_fwd; const int32_t* order_bwd;     /* vc_row_order hints or NULL */
   int64_t n_in, n_out; int32_t kv, subm, centre, sorted_rows;
+  const int32_t* grp_plan;                                /* with rep: [order | sorted keys] of vc_group_sum_sorted */
 } vc_pass_table;
 typedef struct vc_pass_buf { int64_t rows; int32_t cols; int32_t external; void* ptr /* external only */; } vc_pass_buf;
 typedef struct vc_pass_op { int32_t kind, src, dst, dst_col0, unit, table, keep, relu; } vc_pass_op;
@@ -416,15 +427,16 @@ int vc_pass_forward(const vc_pass_program* prog, void* arena, size_t arena_bytes
 size_t vc_pass_backward_arena_bytes(const vc_pass_program* prog, const float* const* ext_grads, int need_input_grad);
 int vc_pass_backward(const vc_pass_program* prog, const void* fwd_arena, size_t fwd_arena_bytes,
                      const float* const* ext_grads /* n_bufs */, float* input_grad /* gradient of buffer 0 or NULL */,
-                     void* group_acc, size_t group_acc_bytes /* persistent accumulator of vc_group_sum(prepared = 2) */,
                      void* arena, size_t arena_bytes, void* side_stream /* nullable */, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ kernel timing
  * Brackets every launch of ONE gather-GEMM instantiation (direction: 0 forward, 1 backward-input; ck, cn = its gathered /
  * produced channel counts) with HIP events on the launch stream, inside whatever call issues it (vc_conv_*,
  * vc_post_act_block_*, vc_pass_*), and counts the table's active pairs on the device right after it (outside the
- * bracket).  bench.py's roofline figure comes from here.  `dev_pairs`: device int64[max_records], caller-owned.        */
-typedef struct vc_trace_record { float ms; int32_t kv, ck, cn, windowed; int64_t n_src, n_out, pairs; } vc_trace_record;
+ * bracket).  bench.py's roofline figure comes from here.  `dev_pairs`: device int64[max_records], caller-owned.
+ * direction = -1 records EVERY gather-GEMM launch (record.direction 0 / 1) and every weight-gradient launch (2: kernel + its
+ * reduce; ck = cin, cn = cout): the family- and step-level roofline figures of bench.py.                                 */
+typedef struct vc_trace_record { float ms; int32_t kv, ck, cn, windowed; int64_t n_src, n_out, pairs; int32_t direction; } vc_trace_record;
 int vc_trace_begin(int direction, int ck, int cn, int max_records, int64_t* dev_pairs);
 int vc_trace_end(vc_trace_record* out, int capacity, int* n_records /* synchronises the traced events */);
 

@@ -68,7 +68,7 @@ class OracleBackend:
         return False  # fused epilogues are a product optimisation; the oracle always takes the plain path
 
     def conv_backward_input(self, dy, weight, tbl, n_in, mirror, centre=-1, rep=None, order=None, operand="f32",
-                            group_ws=None, sorted_rows=False):
+                            group_ws=None, sorted_rows=False, grp_plan=None):
         """dX of the three conv flavours, in the product's calling convention (include/virconv_hip.h).
 
         SubM (mirror=True, tbl = pair_fwd): the EXACT transpose of the forward gather,

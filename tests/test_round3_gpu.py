@@ -1,0 +1,150 @@
+"""GPU tests of the round-3 kernels: the sorted (segmented) duplicate-pixel group sum, the one-launch BatchNorm statistics from
+conv-epilogue partial rows, the row order of tables with many distinct masks.  Everything goes through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sparse_ref
+from virconv_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _group_ref(dy: np.ndarray, rep: np.ndarray) -> np.ndarray:
+    out = np.zeros(dy.shape, np.float64)
+    np.add.at(out, rep, dy.astype(np.float64))
+    return out
+
+
+@pytest.mark.parametrize("c", [8, 16, 32, 64])
+@pytest.mark.parametrize("case", ["random", "giant", "aligned", "singletons", "one_group", "tiny"])
+def test_group_sum_sorted_equals_the_exact_sum_at_representatives(hip_backend, c, case):
+    """vc_group_sum_sorted: dy_grp[rep] = sum of the group's rows, written at representatives only.  Cases: random groups, a
+    giant group spanning hundreds of 32-row chunks (border pixels), groups that start exactly on chunk borders, all singletons,
+    a single group, fewer rows than one chunk.  Reference: float64 np.add.at; bound: fp32 summation error of the group size."""
+    rng = np.random.default_rng(c + len(case))
+    if case == "tiny":
+        n = 19
+        lab = rng.integers(0, n, n)
+    elif case == "singletons":
+        n = 4099
+        lab = rng.permutation(n)
+    elif case == "one_group":
+        n = 5000
+        lab = np.zeros(n, np.int64)
+    elif case == "aligned":       # contiguous groups of exactly 32 / 64 rows: every run of the sorted plan begins on a chunk border
+        sizes = [32, 64] * 26 + [5]
+        n = sum(sizes)
+        lab = np.concatenate([np.full(s, i) for i, s in enumerate(sizes)])
+    elif case == "giant":
+        n = 30011
+        lab = rng.integers(0, n, n)
+        lab[rng.permutation(n)[:12000]] = 7          # one pixel collects 12 000 rows (what out-of-frustum voxels do)
+        lab[rng.permutation(n)[:3000]] = 11
+    else:
+        n = 20000
+        lab = rng.integers(0, n // 3, n)
+    # the product's rule: the representative of a group is its HIGHEST row
+    top = np.full(int(lab.max()) + 1, -1, np.int64)
+    np.maximum.at(top, lab, np.arange(n))
+    rep = top[lab].astype(np.int32)
+    dy = (rng.standard_normal((n, c)) * rng.choice([1e-3, 1.0, 30.0])).astype(np.float32)
+    rep_t, dy_t = torch.from_numpy(rep).cuda(), torch.from_numpy(dy).cuda()
+    plan = hip_backend.group_plan(rep_t)
+    p = plan.cpu().numpy()
+    np.testing.assert_array_equal(p[0], np.argsort(rep, kind="stable").astype(np.int32))
+    np.testing.assert_array_equal(p[1], np.sort(rep))
+    grp = hip_backend.group_sum_sorted(dy_t, plan)
+    for _ in range(3):                                   # fixed order of additions: re-runs are bit-equal
+        assert torch.equal(grp, hip_backend.group_sum_sorted(dy_t, plan))
+    ref = _group_ref(dy, rep)
+    reps = np.unique(rep)
+    got = grp.cpu().numpy()[reps].astype(np.float64)
+    size = np.bincount(rep, minlength=n)[reps][:, None]
+    absum = np.zeros(dy.shape, np.float64)
+    np.add.at(absum, rep, np.abs(dy).astype(np.float64))
+    bound = 2.0 ** -23 * (np.log2(np.maximum(size, 2)) + 40) * absum[reps] + 1e-30   # pairwise-ish + sequential tail, generous
+    assert np.all(np.abs(got - ref[reps]) <= bound), float((np.abs(got - ref[reps]) / bound).max())
+
+
+def test_duplicate_pixel_backward_with_the_group_plan_matches_the_exact_transpose(hip_backend):
+    """The 2-D SubM backward-input with the sorted group sum against the oracle's scatter-add transpose (float64), with a huge
+    border-pixel group; bit-equal re-runs; equals the fixed-point variant within fp32 rounding."""
+    rng = np.random.default_rng(21)
+    shape = (160, 60)
+    b = rng.integers(0, 2, 20000); u = rng.integers(0, 40, 20000); v = rng.integers(0, 15, 20000)
+    idx = np.stack([b, u, v], 1).astype(np.int32)
+    idx[:6000, 1:] = 0
+    n = idx.shape[0]
+    it = torch.from_numpy(idx).cuda()
+    pair, rep = hip_backend.subm_rulebook(it, shape, (3, 3), (1, 1), want_rep=True)
+    plan = hip_backend.group_plan(rep)
+    w = torch.from_numpy((rng.standard_normal((32, 3, 3, 32)) / 17).astype(np.float32)).cuda()
+    g = torch.from_numpy((rng.standard_normal((n, 32)) * 1e-3).astype(np.float32)).cuda()
+    a = hip_backend.conv_backward_input(g, w, pair, n, mirror=True, centre=4, rep=rep, grp_plan=plan)
+    for _ in range(3):
+        assert torch.equal(a, hip_backend.conv_backward_input(g, w, pair, n, mirror=True, centre=4, rep=rep, grp_plan=plan))
+    pref = sparse_ref.subm_rulebook(idx, shape, (3, 3))
+    dx_ref, _ = sparse_ref.conv_backward(torch.zeros((n, 32), dtype=torch.float64), w.cpu().double(), pref, g.cpu().double())
+    dx_ref = dx_ref.numpy()
+    err = np.abs(a.cpu().numpy() - dx_ref)
+    assert np.all(err <= 1e-5 * np.abs(dx_ref) + 1e-4 * np.abs(dx_ref).max() * 1e-2), float(err.max())
+    old = hip_backend.conv_backward_input(g, w, pair, n, mirror=True, centre=4, rep=rep)
+    assert float((a - old).abs().max()) <= 1e-5 * float(old.abs().max())
+
+
+@pytest.mark.parametrize("c", [8, 16, 32, 64])
+@pytest.mark.parametrize("nb", [1, 7, 1000, 1024, 1025, 19397])
+def test_one_launch_batchnorm_statistics_from_partial_rows(hip_backend, c, nb):
+    """bn_partial_fused_kernel (one launch) against float64 sums of the same partial rows, and against the two-launch route it
+    replaces; running statistics and num_batches_tracked included; bit-stable."""
+    rng = np.random.default_rng(nb + c)
+    lib = hip_backend.lib
+    part = (rng.standard_normal((nb, 2, c)) * 3).astype(np.float32)
+    part[:, 1] = np.abs(part[:, 1]) * 16 + 9.0
+    n_rows = nb * 16
+    pt = torch.from_numpy(part).cuda()
+
+    def run(fused):
+        assert lib.vc_debug_set(b"bn_fused_partial", fused) == 0
+        mean, var = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+        rm, rv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+        nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+        ws_bytes = lib.vc_bn_workspace_bytes(n_rows, c)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device="cuda")
+        _lib.check(lib.vc_bn_stats_from_partial(pt.data_ptr(), nb, n_rows, c, mean.data_ptr(), var.data_ptr(), rm.data_ptr(),
+                                                rv.data_ptr(), nbt.data_ptr(), 0.01, ws.data_ptr(), ws_bytes,
+                                                torch.cuda.current_stream().cuda_stream), "vc_bn_stats_from_partial")
+        return mean, var, rm, rv, nbt
+
+    try:
+        new, new2, old = run(1), run(1), run(0)
+    finally:
+        lib.vc_debug_set(b"bn_fused_partial", 1)
+    for a, b in zip(new, new2):
+        assert torch.equal(a, b)
+    s = part.astype(np.float64).sum(0)
+    m = s[0] / n_rows
+    v = np.maximum(s[1] / n_rows - m * m, 0.0)
+    np.testing.assert_allclose(new[0].cpu().numpy(), m, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(new[1].cpu().numpy(), v, rtol=1e-6, atol=1e-6)
+    assert int(new[4]) == 1
+    for a, b in zip(new[:4], old[:4]):
+        assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("kv", [27, 9])
+def test_row_order_of_a_table_with_thousands_of_distinct_masks(hip_backend, kv):
+    """Strided FORWARD tables and SubM tables overflow the 128-slot mask set of vc_row_order: the kernel must drop to the bitonic
+    path at once (round 3: it used to probe the full set for every further mask, 1.4-2.8 ms per table) and still return the
+    windowed stable mask sort."""
+    rng = np.random.default_rng(kv)
+    n, win = 3 * 2048 + 333, 2048
+    pair = np.where(rng.random((kv, n)) < 0.4, 5, -1).astype(np.int32)
+    masks = np.zeros(n, np.int64)
+    for k in range(kv):
+        masks |= (pair[k] >= 0).astype(np.int64) << k
+    assert len(np.unique(masks[:win])) > 128
+    order = hip_backend.row_order(torch.from_numpy(pair).cuda(), window=win).cpu().numpy()
+    want = np.concatenate([s + np.argsort(masks[s:s + win], kind="stable") for s in range(0, n, win)])
+    np.testing.assert_array_equal(order, want.astype(np.int32))

@@ -144,7 +144,7 @@ def main():
             res["fwd"] = timeit(lambda: be.conv_forward(x, w, rb.pair_fwd, order=rb.order_fwd, operand=args.operand, sorted_rows=srt), args.iters)
         if args.only in ("all", "bwd"):
             if rb.kind == "subm":
-                res["bwd"] = timeit(lambda: be.conv_backward_input(dy, w, rb.pair_fwd, rb.n_in, True, rb.centre, rb.rep, order=rb.order_bwd, operand=args.operand, sorted_rows=srt), args.iters)
+                res["bwd"] = timeit(lambda: be.conv_backward_input(dy, w, rb.pair_fwd, rb.n_in, True, rb.centre, rb.rep, order=rb.order_bwd, operand=args.operand, sorted_rows=srt, grp_plan=rb.grp_plan), args.iters)
             else:
                 res["bwd"] = timeit(lambda: be.conv_backward_input(dy, w, rb.pair_bwd, rb.n_in, False, order=rb.order_bwd, operand=args.operand), args.iters)
         if args.only in ("all", "dw"):

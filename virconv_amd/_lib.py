@@ -62,6 +62,9 @@ SIGNATURES = {
     "vc_group_sum_workspace_bytes": (_SZ, [_I64, _I]),
     "vc_group_sum": (_I, [_P, _P, _I64, _I, _P, _P, _SZ, _I, _P]),
     "vc_group_sum_prepare": (_I, [_P, _SZ, _I64, _I, _P]),
+    "vc_group_keys": (_I, [_P, _I64, _P, _P]),
+    "vc_group_sum_sorted_workspace_bytes": (_SZ, [_I64, _I]),
+    "vc_group_sum_sorted": (_I, [_P, _P, _I64, _I, _P, _P, _SZ, _P]),
     "vc_project_prepare": (_I, [_P, _P, _I, _P, _P]),
     "vc_project_uv": (_I, [_P, _I64, _P, _I, _I, _P, _P, _P]),
     "vc_gather_rows": (_I, [_P, _P, _I, _I, _P, _I64, _P, _P, _P]),
@@ -82,12 +85,12 @@ SIGNATURES = {
     "vc_post_act_block_forward": (_I, [_P, _I64, _P, _I64, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P,
                                        _I, _I, _P, _P, _P, _SZ, _P]),
     "vc_post_act_block_backward_workspace_bytes": (_SZ, [_I64, _I, _I, _I]),
-    "vc_post_act_block_backward": (_I, [_P, _I64, _P, _I64, _P, _I, _I, _P, _P, _P, _P, _F, _I, _P, _P, _I64, _I, _I, _P, _P,
-                                        _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _P, _P]),
+    "vc_post_act_block_backward": (_I, [_P, _I64, _P, _I64, _P, _I, _I, _P, _P, _P, _P, _F, _I, _P, _P, _I64, _I, _I, _P, _P, _P,
+                                        _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _SZ, _P, _P]),
     "vc_pass_forward_arena_bytes": (_SZ, [_P]),
     "vc_pass_forward": (_I, [_P, _P, _SZ, _P, _P]),
     "vc_pass_backward_arena_bytes": (_SZ, [_P, _P, _I]),
-    "vc_pass_backward": (_I, [_P, _P, _SZ, _P, _P, _P, _SZ, _P, _SZ, _P, _P]),
+    "vc_pass_backward": (_I, [_P, _P, _SZ, _P, _P, _P, _SZ, _P, _P]),
     "vc_trace_begin": (_I, [_I, _I, _I, _I, _P]),
     "vc_trace_end": (_I, [_P, _I, _P]),
     "vc_conv_bwd_stats_partial_floats": (_SZ, [_I64, _I, _I, _I]),
@@ -116,7 +119,7 @@ class PassUnit(C.Structure):
 class PassTable(C.Structure):
     _fields_ = [("pair_fwd", _P), ("pair_bwd", _P), ("rep", _P), ("order_fwd", _P), ("order_bwd", _P),
                 ("n_in", _I64), ("n_out", _I64), ("kv", C.c_int32), ("subm", C.c_int32), ("centre", C.c_int32),
-                ("sorted_rows", C.c_int32)]
+                ("sorted_rows", C.c_int32), ("grp_plan", _P)]
 
 
 class PassBuf(C.Structure):
@@ -137,7 +140,7 @@ class PassProgram(C.Structure):
 
 class TraceRecord(C.Structure):
     _fields_ = [("ms", _F), ("kv", C.c_int32), ("ck", C.c_int32), ("cn", C.c_int32), ("windowed", C.c_int32),
-                ("n_src", _I64), ("n_out", _I64), ("pairs", _I64)]
+                ("n_src", _I64), ("n_out", _I64), ("pairs", _I64), ("direction", C.c_int32)]
 
 
 _lib = None

@@ -232,7 +232,8 @@ def _record_stream(obj, stream):
         if obj.is_cuda:
             obj.record_stream(stream)
     elif isinstance(obj, ops.Rulebook):
-        for t in (obj.pair_fwd, obj.pair_bwd, obj.rep, obj.in_indices, obj.out_indices, obj.order_fwd, obj.order_bwd):
+        for t in (obj.pair_fwd, obj.pair_bwd, obj.rep, obj.in_indices, obj.out_indices, obj.order_fwd, obj.order_bwd,
+                  obj.grp_plan):
             _record_stream(t, stream)
     elif isinstance(obj, dict):
         for v in obj.values():

@@ -86,9 +86,9 @@ class HipBackend:
         stream, INSIDE the library (vc_trace_begin): whichever call issues the launch -- an operator, a post_act_block unit or
         the whole feature pass -- is timed as it runs in the product path.  The active pairs of each traced table are counted
         on the device right after the launch (outside the bracket)."""
-        assert direction in ("fwd", "bwd")
+        assert direction in ("fwd", "bwd", "all")   # "all": every gather-GEMM and weight-gradient launch (ck, cn ignored)
         self._trace_pairs = torch.zeros((max_records,), dtype=torch.int64, device="cuda")
-        check(self.lib.vc_trace_begin(0 if direction == "fwd" else 1, int(ck), int(cn), int(max_records),
+        check(self.lib.vc_trace_begin({"fwd": 0, "bwd": 1, "all": -1}[direction], int(ck), int(cn), int(max_records),
                                       _ptr(self._trace_pairs)), "vc_trace_begin")
         self._trace_cap = int(max_records)
 
@@ -105,7 +105,8 @@ class HipBackend:
         for r in recs[:n.value]:
             out.append({"ms": r.ms, "flops": 2.0 * r.pairs * r.ck * r.cn,
                         "bytes": 4.0 * (r.n_src * r.ck + r.n_out * r.cn + r.kv * r.ck * r.cn) + 4.0 * r.kv * r.n_out,
-                        "pairs": int(r.pairs), "n_out": int(r.n_out), "windowed": bool(r.windowed)})
+                        "pairs": int(r.pairs), "n_out": int(r.n_out), "windowed": bool(r.windowed),
+                        "dir": ("fwd", "bwd", "dw")[r.direction], "ck": int(r.ck), "cn": int(r.cn), "kv": int(r.kv)})
         return out
 
     def _read_count(self, dev_scalar: torch.Tensor) -> int:
@@ -322,8 +323,11 @@ class HipBackend:
     def conv_backward_input(self, dy: torch.Tensor, weight: torch.Tensor, tbl: torch.Tensor, n_in: int, mirror: bool,
                             centre: int = -1, rep: Optional[torch.Tensor] = None,
                             order: Optional[torch.Tensor] = None, operand: str = "f32",
-                            group_ws: Optional[torch.Tensor] = None, sorted_rows: bool = False) -> torch.Tensor:
-        """`group_ws`: workspace from group_sum_prepare whose header already holds max|dy| (left there by bn_backward)."""
+                            group_ws: Optional[torch.Tensor] = None, sorted_rows: bool = False,
+                            grp_plan: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`grp_plan`: the duplicate-pixel table's rows sorted by representative (group_plan): the group sum runs in that
+        fixed order (vc_group_sum_sorted).  Without it the order-free fixed-point sum is used; `group_ws`: its workspace from
+        group_sum_prepare whose header already holds max|dy| (left there by bn_backward)."""
         dy = _need(dy, torch.float32, "grad_out")
         weight = _need(weight, torch.float32, "weight")
         tbl = _need(tbl, torch.int32, "pair table")
@@ -334,6 +338,9 @@ class HipBackend:
         src, src_centre = dy, None
         if rep is not None:
             rep = _need(rep, torch.int32, "rep")
+        if rep is not None and grp_plan is not None and (cout & (cout - 1)) == 0:
+            src, src_centre = self.group_sum_sorted(dy, grp_plan), dy
+        elif rep is not None:
             grp = torch.empty_like(dy)
             gws_bytes = self.lib.vc_group_sum_workspace_bytes(dy.shape[0], cout)
             gws = group_ws if group_ws is not None else torch.empty((gws_bytes,), dtype=torch.uint8, device=dy.device)
@@ -696,8 +703,32 @@ class HipBackend:
               "vc_post_act_block_forward")
         return y, y_raw, stats[0], stats[1]
 
+    def group_plan(self, rep: torch.Tensor) -> torch.Tensor:
+        """(2, n) int32 [rows sorted stably by representative | sorted representatives] of a duplicate-pixel table: what
+        vc_group_sum_sorted walks.  Built once per table by the geometry plan (torch's stable radix sort of the keys)."""
+        rep = _need(rep, torch.int32, "rep")
+        n = rep.shape[0]
+        keys = torch.empty((n,), dtype=torch.int32, device=rep.device)
+        check(self.lib.vc_group_keys(_ptr(rep), n, _ptr(keys), _stream()), "vc_group_keys")
+        skeys, order = torch.sort(keys, stable=True)
+        plan = torch.empty((2, n), dtype=torch.int32, device=rep.device)
+        plan[0].copy_(order)            # int64 -> int32
+        plan[1].copy_(skeys)
+        return plan
+
+    def group_sum_sorted(self, dy: torch.Tensor, plan: torch.Tensor) -> torch.Tensor:
+        """dy_grp[rep] = sum of dy over the rows of rep's pixel group, written at representatives only (vc_group_sum_sorted)."""
+        dy = _need(dy, torch.float32, "grad_out")
+        n, c = dy.shape
+        grp = torch.empty_like(dy)
+        ws_bytes = self.lib.vc_group_sum_sorted_workspace_bytes(n, c)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dy.device)
+        check(self.lib.vc_group_sum_sorted(_ptr(dy), _ptr(plan), n, c, _ptr(grp), _ptr(ws), ws_bytes, _stream()),
+              "vc_group_sum_sorted")
+        return grp
+
     def post_act_block_backward(self, x, weight, y_raw, dy_wide, dy_col0: int, mean, var, gamma, beta, eps: float, relu: bool,
-                                pair_fwd, tbl_dx, n_dx: int, mirror: bool, centre: int, rep, order_dx, operand: str,
+                                pair_fwd, tbl_dx, n_dx: int, mirror: bool, centre: int, rep, grp_plan, order_dx, operand: str,
                                 sorted_rows: bool, need_dx: bool, need_dw: bool):
         """BatchNorm+ReLU backward -> (group sum) -> backward-input conv -> weight gradient in ONE C-ABI call.
         -> (dx | None, dw | None, dgamma, dbeta)"""
@@ -711,17 +742,17 @@ class HipBackend:
         dgb = torch.empty((2, cout), dtype=torch.float32, device=dev)
         ws_bytes = self.lib.vc_post_act_block_backward_workspace_bytes(n_out, kv, cin, cout)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-        gacc, gacc_bytes = None, 0
-        if rep is not None and need_dx:
-            gacc_bytes = self.lib.vc_group_sum_workspace_bytes(n_out, cout)
-            gacc = self._group_acc(gacc_bytes, dev)
+        x = _need(x, torch.float32, "features")          # saved tensors may be user views: the C call reads raw pointers
+        weight = _need(weight, torch.float32, "weight")
+        y_raw = _need(y_raw, torch.float32, "y_raw")
+        if rep is not None and need_dx and grp_plan is None:
+            grp_plan = self.group_plan(rep)
         check(self.lib.vc_post_act_block_backward(_ptr(x), x.shape[0], _ptr(y_raw), n_out, _ptr(dy_wide), dy_wide.shape[1],
                                                   dy_col0, _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), float(eps),
                                                   1 if relu else 0, _ptr(pair_fwd), _ptr(tbl_dx), n_dx, 1 if mirror else 0,
-                                                  centre, _ptr(rep), _ptr(order_dx), kv, _ptr(weight), cin, cout,
+                                                  centre, _ptr(rep), _ptr(grp_plan), _ptr(order_dx), kv, _ptr(weight), cin, cout,
                                                   OPERAND_TYPES[operand], flags, 1 if need_dx else 0, 1 if need_dw else 0,
-                                                  _ptr(d_raw), _ptr(dx), _ptr(dw), _ptr(dgb[0]), _ptr(dgb[1]), _ptr(gacc),
-                                                  gacc.numel() if gacc is not None else 0, _ptr(ws), ws_bytes,
+                                                  _ptr(d_raw), _ptr(dx), _ptr(dw), _ptr(dgb[0]), _ptr(dgb[1]), _ptr(ws), ws_bytes,
                                                   self._side_stream(dev) if UNIT_OVERLAP_DW else None, _stream()),
               "vc_post_act_block_backward")
         return dx, dw, dgb[0], dgb[1]

@@ -28,6 +28,7 @@ SOURCES = {
     "frontend_kernels.hip": ["-ffp-contract=off"],
     # rotated IoU / NMS: no mul+add contraction, so that the polygon arithmetic rounds like the reference's CPU build
     "nms_kernels.hip": ["-ffp-contract=off"],
+    "group_kernels.hip": [],
     "unit.hip": [],
     "pass.hip": [],
 }
@@ -57,10 +58,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return _build_to(out, os.path.join(HERE, "build_ab"), extra_env, verbose)
     if not force and not _stale():
         return LIB
-    return _build_to(LIB, os.path.join(HERE, "build"), extra_env, verbose)
+    return _build_to(LIB, os.path.join(HERE, "build"), extra_env, verbose, force_all=force)
 
 
-def _build_to(LIB: str, objdir: str, extra_env, verbose: bool) -> str:
+def _build_to(LIB: str, objdir: str, extra_env, verbose: bool, force_all: bool = False) -> str:
     hipcc = _hipcc()
     os.makedirs(objdir, exist_ok=True)
 
@@ -68,6 +69,13 @@ def _build_to(LIB: str, objdir: str, extra_env, verbose: bool) -> str:
         src, extra = item
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         cmd = [hipcc, *COMMON, *extra, *extra_env, "-c", os.path.join(CSRC, src), "-o", obj]
+        # per-object staleness: the object is reused when it is newer than its source and the shared headers and was built
+        # with the same command line (stamp file next to it)
+        stamp, line = obj + ".cmd", " ".join(cmd)
+        deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "virconv_hip.h")]
+        if (not force_all and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == line
+                and all(os.path.getmtime(d) < os.path.getmtime(obj) for d in deps)):
+            return obj
         if verbose:
             print("[virconv_amd.build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -75,6 +83,8 @@ def _build_to(LIB: str, objdir: str, extra_env, verbose: bool) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
+        with open(stamp, "w") as f:
+            f.write(line)
         return obj
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:

@@ -211,6 +211,84 @@ __global__ void __launch_bounds__(256) bn_partial_reduce_kernel(const float* __r
   }
 }
 
+// ONE launch from the conv epilogue's per-wave fp32 partial rows [nb][2][c] to the finished per-channel numbers (round 3; it
+// replaces bn_partial_reduce_kernel + bn_stats_finalize_kernel / bn_bwd_finalize_kernel, i.e. 40 launches and 40 kernel
+// boundaries per train step).  Block = 4 channels (one 16-byte column of the sums and the matching one of the second
+// moments) x 1024 threads; thread t adds up rows t, t + 1024, ... in that order in fp64 with up to 8 rows (16 loads of 16
+// bytes) in flight, then a fixed-order butterfly per wave and a fixed-order sum over the 16 waves: run-to-run bit-stable.
+//   BWD = false: (sum x, sum x^2)      -> mean, biased var, running statistics, num_batches_tracked
+//   BWD = true : (sum d, sum d * xhat) -> dbeta, dgamma, sums[2][c] for the dx kernel; clears the max|dx| word
+static constexpr int kBnFusedThreads = 1024;
+
+template <bool BWD>
+__global__ void __launch_bounds__(kBnFusedThreads) bn_partial_fused_kernel(const float* __restrict__ partial, int64_t nb, int64_t n,
+                                                                         int c, float* __restrict__ o0, float* __restrict__ o1,
+                                                                         float* __restrict__ r0, float* __restrict__ r1,
+                                                                         long long* __restrict__ num_batches_tracked,
+                                                                         float momentum, unsigned* __restrict__ zero_word) {
+  __shared__ double red[kBnFusedThreads / 64][8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cq = blockIdx.x;
+  if (BWD && zero_word != nullptr && cq == 0 && tid == 0) *zero_word = 0u;
+  if (!BWD && num_batches_tracked != nullptr && cq == 0 && tid == 0) *num_batches_tracked += 1;
+  double acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.0;
+  const float* col = partial + cq * 4;
+  const int64_t rs = (int64_t)2 * c;   // floats per partial row
+  int64_t r = tid;
+  for (; r + 7 * (int64_t)kBnFusedThreads < nb; r += 8 * (int64_t)kBnFusedThreads) {
+    float4 a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float* p = col + (r + (int64_t)u * kBnFusedThreads) * rs;
+      a[u] = *reinterpret_cast<const float4*>(p);
+      b[u] = *reinterpret_cast<const float4*>(p + c);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc[0] += (double)a[u].x; acc[1] += (double)a[u].y; acc[2] += (double)a[u].z; acc[3] += (double)a[u].w;
+      acc[4] += (double)b[u].x; acc[5] += (double)b[u].y; acc[6] += (double)b[u].z; acc[7] += (double)b[u].w;
+    }
+  }
+  for (; r < nb; r += kBnFusedThreads) {
+    const float* p = col + r * rs;
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + c);
+    acc[0] += (double)a.x; acc[1] += (double)a.y; acc[2] += (double)a.z; acc[3] += (double)a.w;
+    acc[4] += (double)b.x; acc[5] += (double)b.y; acc[6] += (double)b.z; acc[7] += (double)b.w;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
+  if (lane == 0)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[wave][j] = acc[j];
+  __syncthreads();
+  if (tid >= 4) return;
+  const int ch = cq * 4 + tid;
+  double s = 0.0, ss = 0.0;
+  for (int w = 0; w < kBnFusedThreads / 64; ++w) { s += red[w][tid]; ss += red[w][4 + tid]; }
+  if (!BWD) {
+    const double m = s / (double)n;
+    double v = ss / (double)n - m * m;
+    if (v < 0.0) v = 0.0;
+    o0[ch] = (float)m;
+    o1[ch] = (float)v;
+    if (r0) r0[ch] = (1.f - momentum) * r0[ch] + momentum * (float)m;
+    if (r1) {
+      const double unb = (n > 1) ? v * (double)n / (double)(n - 1) : v;
+      r1[ch] = (1.f - momentum) * r1[ch] + momentum * (float)unb;
+    }
+  } else {
+    if (o0) o0[ch] = (float)s;    // dbeta
+    if (o1) o1[ch] = (float)ss;   // dgamma
+    r0[ch] = (float)s;            // sums[0][ch]
+    r0[c + ch] = (float)ss;       // sums[1][ch]
+  }
+}
+
 __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const double* __restrict__ partial, int nb, int c,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ sums /* [2][c]: dbeta, dgamma */,
@@ -427,6 +505,9 @@ static inline void bn_split(int64_t n, int c, int& nb, int64_t& rpb) {
   nb = (int)cdiv(n, rpb);
 }
 
+// vc_debug_set "bn_fused_partial" (default 1): conv-epilogue partial rows -> statistics in one launch; 0 = the two-launch route
+int g_bn_fused_partial = 1;
+
 static inline bool bn_c_ok(int c) { return c == 4 || c == 8 || c == 16 || c == 32 || c == 64 || c == 128; }
 
 }  // namespace vc
@@ -466,6 +547,12 @@ int vc_bn_stats_from_partial(const float* partial, int64_t nblocks, int64_t n, i
                              void* ws, size_t ws_bytes, void* stream) {
   VC_REQUIRE(c >= 1 && n >= 1 && nblocks >= 1 && partial && mean && var, "vc_bn_stats_from_partial: null/invalid argument");
   hipStream_t st = (hipStream_t)stream;
+  if (g_bn_fused_partial && c % 4 == 0) {  // one launch (round 3)
+    hipLaunchKernelGGL((bn_partial_fused_kernel<false>), dim3(c / 4), dim3(kBnFusedThreads), 0, st, partial, nblocks, n, c, mean, var,
+                       running_mean, running_var, (long long*)num_batches_tracked, momentum, (unsigned*)nullptr);
+    VC_CHECK_LAUNCH("bn_partial_fused_kernel<stats>");
+    return VC_OK;
+  }
   if (nblocks > 512 && ws != nullptr && 2 * c <= 256 && (c & (c - 1)) == 0) {
     // many partial rows: coalesced slab reduce to <= 256 fp64 rows, then the ordinary finalize
     if (ws_bytes < vc_bn_workspace_bytes(n, c)) { set_error("vc_bn_stats_from_partial: workspace too small"); return VC_ECAPACITY; }
@@ -551,12 +638,18 @@ int vc_bn_relu_backward_from_partial(const float* x, const float* dy, int dy_str
   hipStream_t st = (hipStream_t)stream;
   double* partial = (double*)ws;
   float* sums = (float*)(partial + (size_t)kMaxBnBlocks * 2 * c);
-  const int64_t rpb = cdiv(nblocks, 256);
-  const int g = (int)cdiv(nblocks, rpb);
-  hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(g), dim3(256), 0, st, fpartial, nblocks, rpb, c, partial);
-  VC_CHECK_LAUNCH("bn_partial_reduce_kernel");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, partial, g, c, dgamma, dbeta, sums, absmax_out);
-  VC_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+  if (g_bn_fused_partial) {  // one launch (round 3)
+    hipLaunchKernelGGL((bn_partial_fused_kernel<true>), dim3(c / 4), dim3(kBnFusedThreads), 0, st, fpartial, nblocks, n, c, dbeta, dgamma,
+                       sums, (float*)nullptr, (long long*)nullptr, 0.f, absmax_out);
+    VC_CHECK_LAUNCH("bn_partial_fused_kernel<bwd>");
+  } else {
+    const int64_t rpb = cdiv(nblocks, 256);
+    const int g = (int)cdiv(nblocks, rpb);
+    hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(g), dim3(256), 0, st, fpartial, nblocks, rpb, c, partial);
+    VC_CHECK_LAUNCH("bn_partial_reduce_kernel");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, partial, g, c, dgamma, dbeta, sums, absmax_out);
+    VC_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+  }
   const int lg = bn_lg_c4(c);
   VC_REQUIRE(lg >= 0, "vc_bn_relu_backward_from_partial: channel count must be a power of two");
   const int rows_per_block = (256 >> lg) * kBnRowsPerThread;

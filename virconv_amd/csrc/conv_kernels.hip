@@ -2063,15 +2063,17 @@ static bool g_last_windowed = false;  // set by launch_gg: the launch just issue
 // -> record slot (its start event is on the stream) or -1
 static inline int trace_open(int dir, int ck, int cn, hipStream_t st) {
   TraceState& T = g_trace;
-  if (!T.on || T.dir != dir || T.ck != ck || T.cn != cn || T.n >= T.cap) return -1;
+  // T.dir == -1: every gather-GEMM (0 forward, 1 backward-input) and weight-gradient (2) launch is recorded
+  if (!T.on || T.n >= T.cap || (T.dir != -1 && (T.dir != dir || T.ck != ck || T.cn != cn))) return -1;
   const int i = T.n;
   if (hipEventRecord(T.ev[2 * i], st) != hipSuccess) return -1;
   return i;
 }
-static inline void trace_close(int i, const int32_t* tbl, int kv, int64_t n_src, int64_t n_out, hipStream_t st) {
+static inline void trace_close(int i, int dir, int ck, int cn, const int32_t* tbl, int kv, int64_t n_src, int64_t n_out,
+                               hipStream_t st) {
   TraceState& T = g_trace;
   if (hipEventRecord(T.ev[2 * i + 1], st) != hipSuccess) return;
-  T.rec[i] = vc_trace_record{0.f, kv, T.ck, T.cn, g_last_windowed ? 1 : 0, n_src, n_out, 0};
+  T.rec[i] = vc_trace_record{0.f, kv, ck, cn, (dir != 2 && g_last_windowed) ? 1 : 0, n_src, n_out, 0, dir};
   int64_t nb = cdiv((int64_t)kv * n_out, 256 * 16);
   if (nb > 2048) nb = 2048;
   if (nb < 1) nb = 1;
@@ -2423,6 +2425,7 @@ int g_bw_rows_per_split = 1024;  // weight gradient: target rows per block (vc_d
 int g_bw_legacy_order = 0;      // debug: 1 = offset-major block order of the weight-gradient kernel
 extern int g_pass_dw_main_tail; // pass.hip
 extern int g_pass_bwd_epilogue; // pass.hip
+extern int g_bn_fused_partial;  // bn_kernels.hip
 static constexpr int kMaxSplit = 256;
 static constexpr size_t kMaxPartialBytes = 24u << 20;
 
@@ -2519,6 +2522,7 @@ int vc_debug_set(const char* key, int value) {
   if (key && !strcmp(key, "bw_rows_per_split")) { if (value >= 256) g_bw_rows_per_split = value; return VC_OK; }
   if (key && !strcmp(key, "pass_dw_main_tail")) { g_pass_dw_main_tail = value; return VC_OK; }
   if (key && !strcmp(key, "pass_bwd_epilogue")) { g_pass_bwd_epilogue = value; return VC_OK; }
+  if (key && !strcmp(key, "bn_fused_partial")) { g_bn_fused_partial = value; return VC_OK; }
   if (key && !strcmp(key, "xcd_swizzle_off")) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_swizzle_off), &value, sizeof(int)) == hipSuccess ? VC_OK : VC_EHIP;
   }
@@ -2527,7 +2531,7 @@ int vc_debug_set(const char* key, int value) {
 }
 
 int vc_trace_begin(int direction, int ck, int cn, int max_records, int64_t* dev_pairs) {
-  VC_REQUIRE((direction == 0 || direction == 1) && ck >= 1 && cn >= 1 && max_records >= 1 && dev_pairs,
+  VC_REQUIRE(((direction == -1) || ((direction == 0 || direction == 1) && ck >= 1 && cn >= 1)) && max_records >= 1 && dev_pairs,
              "vc_trace_begin: invalid argument");
   TraceState& T = g_trace;
   T.on = false;
@@ -2607,7 +2611,7 @@ int vc_conv_forward(const float* x, int64_t n_in, const int32_t* pair_fwd, int64
   const int tr = trace_open(0, cin, cout, (hipStream_t)stream);
   const int rc = dispatch_ck<false>(cin, cout, x, nullptr, n_in, pair_fwd, weight, y, nullptr, row_order, n_out, kv, -1, 0,
                                     operand_type, VC_EPI_NONE, ConvEpilogue{}, flags, (hipStream_t)stream);
-  if (tr >= 0) trace_close(tr, pair_fwd, kv, n_in, n_out, (hipStream_t)stream);
+  if (tr >= 0) trace_close(tr, 0, cin, cout, pair_fwd, kv, n_in, n_out, (hipStream_t)stream);
   return rc;
 }
 
@@ -2641,7 +2645,7 @@ int vc_conv_forward_epilogue(const float* x, int64_t n_in, const int32_t* pair_f
   const int tr = trace_open(0, cin, cout, (hipStream_t)stream);
   const int rc = dispatch_ck<false>(cin, cout, x, nullptr, n_in, pair_fwd, weight, y, nullptr, row_order, n_out, kv, -1, 0,
                                     VC_OPERAND_F32, epilogue, e, flags, (hipStream_t)stream);
-  if (tr >= 0) trace_close(tr, pair_fwd, kv, n_in, n_out, (hipStream_t)stream);
+  if (tr >= 0) trace_close(tr, 0, cin, cout, pair_fwd, kv, n_in, n_out, (hipStream_t)stream);
   return rc;
 }
 
@@ -2657,7 +2661,7 @@ int vc_conv_backward_input(const float* dy, const float* dy_centre, int64_t n_sr
   const int tr = trace_open(1, cout, cin, (hipStream_t)stream);
   const int rc = dispatch_ck<true>(cout, cin, dy, dy_centre, n_src, tbl, weight, dx, rep, row_order, n_in, kv, centre,
                                    mirror ? 1 : 0, operand_type, VC_EPI_NONE, ConvEpilogue{}, flags, (hipStream_t)stream);
-  if (tr >= 0) trace_close(tr, tbl, kv, n_src, n_in, (hipStream_t)stream);
+  if (tr >= 0) trace_close(tr, 1, cout, cin, tbl, kv, n_src, n_in, (hipStream_t)stream);
   return rc;
 }
 
@@ -2689,7 +2693,7 @@ int vc_conv_backward_input_epilogue(const float* dy, const float* dy_centre, int
   const int tr = trace_open(1, cout, cin, (hipStream_t)stream);
   const int rc = dispatch_ck<true>(cout, cin, dy, dy_centre, n_src, tbl, weight, dx, rep, row_order, n_in, kv, centre,
                                    mirror ? 1 : 0, VC_OPERAND_F32, VC_EPI_BWD, e, flags, (hipStream_t)stream);
-  if (tr >= 0) trace_close(tr, tbl, kv, n_src, n_in, (hipStream_t)stream);
+  if (tr >= 0) trace_close(tr, 1, cout, cin, tbl, kv, n_src, n_in, (hipStream_t)stream);
   return rc;
 }
 
@@ -2715,15 +2719,20 @@ int vc_conv_backward_weight(const float* x, const float* dy, const int32_t* pair
   }
   VC_REQUIRE(x && dy && pair_fwd, "vc_conv_backward_weight: null argument");
   float* partial = (float*)ws;
+  const int tr = trace_open(2, cin, cout, st);   // recorded only by the trace-everything mode (direction -1)
+  int rc;
   switch (cin) {
-    case 4: return dispatch_bw_co<4>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st);
-    case 8: return dispatch_bw_co<8>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st);
-    case 16: return dispatch_bw_co<16>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st);
-    case 32: return dispatch_bw_co<32>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st);
-    case 64: return dispatch_bw_co<64>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st);
+    case 4: rc = dispatch_bw_co<4>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st); break;
+    case 8: rc = dispatch_bw_co<8>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st); break;
+    case 16: rc = dispatch_bw_co<16>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st); break;
+    case 32: rc = dispatch_bw_co<32>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st); break;
+    case 64: rc = dispatch_bw_co<64>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st); break;
+    default:
+      set_error("bwd-weight: unsupported input channel count %d", cin);
+      rc = VC_EINVAL;
   }
-  set_error("bwd-weight: unsupported input channel count %d", cin);
-  return VC_EINVAL;
+  if (tr >= 0) trace_close(tr, 2, cin, cout, pair_fwd, kv, n_out, n_out, st);
+  return rc;
 }
 
 size_t vc_group_sum_workspace_bytes(int64_t n, int c) {

@@ -195,14 +195,14 @@ struct GradView {
 
 // the reverse sweep; dry = only size the arena (no launches, no dereference)
 static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const float* const* ext_grads, float* input_grad,
-                          bool want_input_grad, void* group_acc, size_t group_acc_bytes, char* arena, size_t arena_bytes,
+                          bool want_input_grad, char* arena, size_t arena_bytes,
                           hipStream_t side, hipStream_t st, bool dry, size_t* need_bytes) {
   FwdLayout L;
   fwd_layout(p, L);
   Bump bump;
   // shared scratch: BatchNorm partial sums (main stream), group-summed d_raw (main stream), weight-gradient partials (all weight
   // gradients run in order on ONE stream, the side stream when there is one)
-  size_t bn_bytes = 256, grp_bytes = 256, dw_bytes = 256;
+  size_t bn_bytes = 256, grp_bytes = 256, gpart_bytes = 256, dw_bytes = 256;
   for (int i = 0; i < p->n_ops; ++i) {
     const vc_pass_op& o = p->ops[i];
     if (o.kind != VC_PASS_UNIT) continue;
@@ -210,10 +210,13 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
     const vc_pass_table& t = p->tables[o.table];
     bn_bytes = std::max(bn_bytes, vc_bn_workspace_bytes(t.n_out, u.cout));
     dw_bytes = std::max(dw_bytes, vc_conv_backward_weight_workspace_bytes(t.n_out, t.kv, u.cin, u.cout));
-    if (t.rep) grp_bytes = std::max(grp_bytes, (size_t)t.n_out * u.cout * sizeof(float));
+    if (t.rep) {
+      grp_bytes = std::max(grp_bytes, (size_t)t.n_out * u.cout * sizeof(float));
+      gpart_bytes = std::max(gpart_bytes, vc_group_sum_sorted_workspace_bytes(t.n_out, u.cout));
+    }
   }
-  const size_t bn_off = bump.take(bn_bytes), grp_off = bump.take(grp_bytes), dw_off = bump.take(dw_bytes),
-               dw2_off = bump.take(dw_bytes);
+  const size_t bn_off = bump.take(bn_bytes), grp_off = bump.take(grp_bytes), gpart_off = bump.take(gpart_bytes),
+               dw_off = bump.take(dw_bytes), dw2_off = bump.take(dw_bytes);
   auto at = [&](size_t off) -> float* { return dry ? nullptr : (float*)(arena + off); };
 
   // transposed fragment-ordered weight images for the backward-input convs (one pack launch for the whole sweep)
@@ -351,18 +354,18 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
       const float* mean = (const float*)((const char*)fwd_arena + L.stats_off[i]);
       const float* var = mean + u.cout;
       if (dup) {
-        VC_REQUIRE(group_acc && group_acc_bytes >= vc_group_sum_workspace_bytes(t.n_out, u.cout) && (u.cout & (u.cout - 1)) == 0,
-                   "vc_pass_backward: duplicate-pixel table needs the persistent group-sum accumulator");
+        VC_REQUIRE(t.grp_plan && (u.cout & (u.cout - 1)) == 0,
+                   "vc_pass_backward: duplicate-pixel table needs its group plan (vc_pass_table.grp_plan, vc_group_sum_sorted)");
       }
       if (fused[i].partial != nullptr)
         rc = vc_bn_relu_backward_from_partial(y_raw, g.p, g.stride, g.col0 + o.dst_col0, t.n_out, u.cout, mean, var, u.gamma,
                                               u.beta, u.eps, o.relu, fused[i].partial, fused[i].nblocks, d_raw,
                                               u.dgamma ? u.dgamma : dgb, u.dbeta ? u.dbeta : dgb + u.cout,
-                                              dup ? (unsigned*)group_acc : nullptr, arena + bn_off, bn_bytes, st);
+                                              nullptr, arena + bn_off, bn_bytes, st);
       else
         rc = vc_bn_relu_backward(y_raw, g.p, g.stride, g.col0 + o.dst_col0, t.n_out, u.cout, mean, var, u.gamma, u.beta, u.eps,
                                  o.relu, d_raw, u.dgamma ? u.dgamma : dgb, u.dbeta ? u.dbeta : dgb + u.cout,
-                                 dup ? (unsigned*)group_acc : nullptr, arena + bn_off, bn_bytes, st);
+                                 nullptr, arena + bn_off, bn_bytes, st);
       if (rc != VC_OK) return rc;
       if (need_dw && on_side) {  // fork: the weight gradient only reads x (forward arena) and d_raw (never rewritten in this call)
         VC_CHECK_HIP(hipEventRecord(ev[0], st));
@@ -376,7 +379,7 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
         const float* src = d_raw;
         const float* src_centre = nullptr;
         if (dup) {
-          rc = vc_group_sum(d_raw, t.rep, t.n_out, u.cout, (float*)(arena + grp_off), group_acc, group_acc_bytes, 2, st);
+          rc = vc_group_sum_sorted(d_raw, t.grp_plan, t.n_out, u.cout, (float*)(arena + grp_off), arena + gpart_off, gpart_bytes, st);
           if (rc != VC_OK) return rc;
           src = (const float*)(arena + grp_off);
           src_centre = d_raw;
@@ -534,14 +537,14 @@ int vc_pass_forward(const vc_pass_program* p, void* arena, size_t arena_bytes, i
 size_t vc_pass_backward_arena_bytes(const vc_pass_program* prog, const float* const* ext_grads, int need_input_grad) {
   if (check_program(prog) != VC_OK || !prog->training) return 0;
   size_t need = 0;
-  if (backward_sweep(prog, nullptr, ext_grads, nullptr, need_input_grad != 0, nullptr, 0, nullptr, 0, nullptr, nullptr, true,
+  if (backward_sweep(prog, nullptr, ext_grads, nullptr, need_input_grad != 0, nullptr, 0, nullptr, nullptr, true,
                      &need) != VC_OK)
     return 0;
   return need;
 }
 
 int vc_pass_backward(const vc_pass_program* p, const void* fwd_arena, size_t fwd_arena_bytes, const float* const* ext_grads,
-                     float* input_grad, void* group_acc, size_t group_acc_bytes, void* arena, size_t arena_bytes,
+                     float* input_grad, void* arena, size_t arena_bytes,
                      void* side_stream, void* stream) {
   int rc = check_program(p);
   if (rc != VC_OK) return rc;
@@ -551,10 +554,10 @@ int vc_pass_backward(const vc_pass_program* p, const void* fwd_arena, size_t fwd
   fwd_layout(p, L);
   if (fwd_arena_bytes < L.total) { set_error("vc_pass_backward: forward arena smaller than the program's layout"); return VC_ECAPACITY; }
   size_t need = 0;
-  rc = backward_sweep(p, nullptr, ext_grads, nullptr, input_grad != nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, true, &need);
+  rc = backward_sweep(p, nullptr, ext_grads, nullptr, input_grad != nullptr, nullptr, 0, nullptr, nullptr, true, &need);
   if (rc != VC_OK) return rc;
   if (arena_bytes < need) { set_error("vc_pass_backward: arena too small"); return VC_ECAPACITY; }
-  return backward_sweep(p, fwd_arena, ext_grads, input_grad, input_grad != nullptr, group_acc, group_acc_bytes, (char*)arena,
+  return backward_sweep(p, fwd_arena, ext_grads, input_grad, input_grad != nullptr, (char*)arena,
                         arena_bytes, (hipStream_t)side_stream, (hipStream_t)stream, false, nullptr);
 }
 

@@ -57,13 +57,14 @@ int vc_post_act_block_forward(const float* x, int64_t n_in, const int32_t* pair_
 size_t vc_post_act_block_backward_workspace_bytes(int64_t n_out, int kv, int cin, int cout) {
   if (n_out < 0 || cin < 1 || cout < 1 || kv < 1) return 0;
   return al256(vc_bn_workspace_bytes(n_out, cout)) + al256(vc_conv_backward_weight_workspace_bytes(n_out, kv, cin, cout)) +
-         al256((size_t)n_out * cout * sizeof(float)) /* group-summed d_raw (duplicate-pixel convs) */ + 256;
+         al256((size_t)n_out * cout * sizeof(float)) /* group-summed d_raw (duplicate-pixel convs) */ +
+         al256(vc_group_sum_sorted_workspace_bytes(n_out, cout)) /* its chunk partials */ + 256;
 }
 
 /* tbl_dx: the table the backward-input gather-GEMM walks (SubM: pair_fwd with mirror = 1; strided: pair_bwd, mirror = 0), over
  * n_dx output rows (= the conv's INPUT rows); pair_fwd is always the forward table (n_out columns) for the weight gradient.
- * rep / centre: duplicate-pixel rule of the 2-D SubM convs (NULL / -1 otherwise); group_acc: the persistent all-zero int64
- * accumulator of vc_group_sum(prepared = 2) (required when rep != NULL).                                                  */
+ * rep / centre: duplicate-pixel rule of the 2-D SubM convs (NULL / -1 otherwise); grp_plan: the table's rows sorted by
+ * representative, [order | sorted keys] (vc_group_sum_sorted; required when rep != NULL and need_dx).                      */
 // fork/join events for the optional side-stream weight gradient (created once per host thread; no device memory)
 static hipEvent_t* unit_events() {
   static thread_local hipEvent_t ev[2] = {nullptr, nullptr};
@@ -80,10 +81,11 @@ static hipEvent_t* unit_events() {
 int vc_post_act_block_backward(const float* x, int64_t n_in, const float* y_raw, int64_t n_out, const float* dy,
                                int dy_stride, int dy_col0, const float* mean, const float* var, const float* gamma,
                                const float* beta, float eps, int relu, const int32_t* pair_fwd, const int32_t* tbl_dx,
-                               int64_t n_dx, int mirror, int centre, const int32_t* rep, const int32_t* row_order_dx, int kv,
+                               int64_t n_dx, int mirror, int centre, const int32_t* rep, const int32_t* grp_plan,
+                               const int32_t* row_order_dx, int kv,
                                const float* weight, int cin, int cout, int operand_type, int flags, int need_dx, int need_dw,
-                               float* d_raw, float* dx, float* dw, float* dgamma, float* dbeta, void* group_acc,
-                               size_t group_acc_bytes, void* ws, size_t ws_bytes, void* side_stream, void* stream) {
+                               float* d_raw, float* dx, float* dw, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                               void* side_stream, void* stream) {
   VC_REQUIRE(n_out >= 1 && x && y_raw && dy && mean && var && d_raw && dgamma && dbeta && ws && pair_fwd && weight,
              "vc_post_act_block_backward: null/invalid argument");
   VC_REQUIRE(!need_dx || (tbl_dx && dx), "vc_post_act_block_backward: need_dx without table / output");
@@ -97,13 +99,15 @@ int vc_post_act_block_backward(const float* x, int64_t n_in, const float* y_raw,
   char* dw_ws = bn_ws + al256(bn_bytes);
   const size_t dw_bytes = vc_conv_backward_weight_workspace_bytes(n_out, kv, cin, cout);
   float* grp = (float*)(dw_ws + al256(dw_bytes));
+  char* gpart = (char*)grp + al256((size_t)n_out * cout * sizeof(float));
+  const size_t gpart_bytes = vc_group_sum_sorted_workspace_bytes(n_out, cout);
   const bool dup = rep != nullptr && need_dx;
   if (dup) {
-    VC_REQUIRE(group_acc && group_acc_bytes >= vc_group_sum_workspace_bytes(n_out, cout) && (cout & (cout - 1)) == 0,
-               "vc_post_act_block_backward: duplicate-pixel conv needs the persistent group-sum accumulator");
+    VC_REQUIRE(grp_plan && (cout & (cout - 1)) == 0,
+               "vc_post_act_block_backward: duplicate-pixel conv needs the table's group plan (vc_group_sum_sorted)");
   }
   int rc = vc_bn_relu_backward(y_raw, dy, dy_stride, dy_col0, n_out, cout, mean, var, gamma, beta, eps, relu, d_raw, dgamma,
-                               dbeta, dup ? (unsigned*)group_acc : nullptr, bn_ws, bn_bytes, stream);
+                               dbeta, nullptr, bn_ws, bn_bytes, stream);
   if (rc != VC_OK) return rc;
   // dW and dX both only read d_raw and are independent: with a side stream the weight gradient runs underneath the
   // backward-input conv (fork after the BatchNorm backward, join before returning -- the caller's stream-ordered allocator may
@@ -122,7 +126,7 @@ int vc_post_act_block_backward(const float* x, int64_t n_in, const float* y_raw,
     const float* src = d_raw;
     const float* src_centre = nullptr;
     if (dup) {
-      rc = vc_group_sum(d_raw, rep, n_out, cout, grp, group_acc, group_acc_bytes, /*prepared=*/2, stream);
+      rc = vc_group_sum_sorted(d_raw, grp_plan, n_out, cout, grp, gpart, gpart_bytes, stream);
       if (rc != VC_OK) return rc;
       src = grp;
       src_centre = d_raw;

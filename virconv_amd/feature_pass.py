@@ -232,7 +232,7 @@ _PROGRAMS = weakref.WeakKeyDictionary()   # model -> {(discard_active, training)
 
 class _Call:
     """Everything one forward call filled in (kept alive for the backward of the same call)."""
-    __slots__ = ("prog", "c_prog", "c_bufs", "c_units", "c_tables", "c_keeps", "arena", "offsets", "keep_alive", "group_bytes")
+    __slots__ = ("prog", "c_prog", "c_bufs", "c_units", "c_tables", "c_keeps", "arena", "offsets", "keep_alive")
 
 
 def _fill(P: _Program, feats, ctx, training: bool) -> Optional[_Call]:
@@ -243,7 +243,6 @@ def _fill(P: _Program, feats, ctx, training: bool) -> Optional[_Call]:
     if any(rb.n_out <= 0 or rb.n_in <= 0 for rb in tables) or any(k is None or k.shape[0] == 0 for k in keeps):
         return None
     c_tables = (_lib.PassTable * len(tables))()
-    group_bytes = 0
     for i, rb in enumerate(tables):
         t = c_tables[i]
         subm = rb.kind == "subm"
@@ -253,6 +252,7 @@ def _fill(P: _Program, feats, ctx, training: bool) -> Optional[_Call]:
         t.n_in, t.n_out, t.kv, t.subm = rb.n_in, rb.n_out, kv, 1 if subm else 0
         t.centre = kv // 2 if subm else -1     # odd kernel sizes: the centre tap is the middle offset
         t.sorted_rows = 1 if rb.sorted_rows else 0
+        t.grp_plan = _ptr(rb.grp_plan)
     c_keeps = (C.c_void_p * max(len(keeps), 1))()
     for i, k in enumerate(keeps):
         assert k.dtype == torch.int64 and k.is_contiguous()
@@ -275,9 +275,6 @@ def _fill(P: _Program, feats, ctx, training: bool) -> Optional[_Call]:
         u.running_mean, u.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
         u.num_batches_tracked = _ptr(bn.num_batches_tracked)
         u.cin, u.cout, u.momentum, u.eps = w.shape[-1], w.shape[0], bn.momentum, bn.eps
-        rb = tables[P.unit_table[i]]
-        if rb.rep is not None:   # duplicate-pixel table: its backward needs the persistent group-sum accumulator
-            group_bytes = max(group_bytes, rb.n_out * w.shape[0] * 8 + 64)
     c_prog = _lib.PassProgram()
     c_prog.ops, c_prog.n_ops = P.c_ops, len(P.ops)
     c_prog.bufs, c_prog.n_bufs = c_bufs, len(P.cols)
@@ -287,7 +284,6 @@ def _fill(P: _Program, feats, ctx, training: bool) -> Optional[_Call]:
     c_prog.training, c_prog.operand_type = 1 if training else 0, _lib.OPERAND_TYPES[ops.MFMA_OPERAND]
     call.c_prog, call.c_bufs, call.c_units, call.c_tables, call.c_keeps = c_prog, c_bufs, c_units, c_tables, c_keeps
     call.keep_alive = (tables, keeps, feats)
-    call.group_bytes = group_bytes
     return call
 
 
@@ -308,6 +304,9 @@ class PassFunction(torch.autograd.Function):
         _lib.check(lib.vc_pass_forward(prog, arena.data_ptr(), nbytes, offsets, be.stream()), "vc_pass_forward")
         call.arena, call.offsets = arena, offsets
         ctx.call = call
+        # the backward re-reads the input features and every parameter through the raw pointers bound in `call`: saving them makes
+        # autograd's version counters catch an in-place edit between forward and backward
+        ctx.save_for_backward(feats, *params)
         outs = []
         for b in P.outputs:
             rows, cols = call.c_bufs[b].rows, P.cols[b]
@@ -319,6 +318,11 @@ class PassFunction(torch.autograd.Function):
         be = ops.get_backend()
         lib = be.lib
         call = ctx.call
+        if call is None:
+            raise RuntimeError("virconv_amd feature pass: backward called twice on the same forward (its activation arena is "
+                               "released after the first backward; retain_graph is not supported by the native pass -- set "
+                               "VIRCONV_NATIVE_PASS=0 for the node-by-node path)")
+        _ = ctx.saved_tensors   # raises if the input features or a parameter were modified in place since the forward
         P = call.prog
         dev = call.arena.device
         ext = (C.c_void_p * len(P.cols))()
@@ -346,11 +350,9 @@ class PassFunction(torch.autograd.Function):
         if nbytes == 0:
             _lib.check(_lib.VC_EINVAL, "vc_pass_backward_arena_bytes")
         arena = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-        gacc = be._group_acc(call.group_bytes, dev) if call.group_bytes else None
         side = be._side_stream(dev) if be.pass_overlap_dw() else None
-        _lib.check(lib.vc_pass_backward(prog, call.arena.data_ptr(), call.arena.numel(), ext, _ptr(gin), _ptr(gacc),
-                                        gacc.numel() if gacc is not None else 0, arena.data_ptr(), nbytes, side, be.stream()),
-                   "vc_pass_backward")
+        _lib.check(lib.vc_pass_backward(prog, call.arena.data_ptr(), call.arena.numel(), ext, _ptr(gin), arena.data_ptr(),
+                                        nbytes, side, be.stream()), "vc_pass_backward")
         grads = []
         for i in range(len(P.grad_sizes)):
             if need[2 + i]:
@@ -363,12 +365,18 @@ class PassFunction(torch.autograd.Function):
 
 
 def _run_program(P: _Program, feats: torch.Tensor, ctx, training: bool):
-    call = _fill(P, feats, ctx, training)
-    if call is None:
-        return None
+    # the native calls bind raw pointers with dense row strides: a strided view (a column slice from a custom VFE, say) must be
+    # packed first, and a non-contiguous parameter sends the call to the node-by-node path (which copies through _need())
+    if not feats.is_contiguous():
+        feats = feats.contiguous()
     params = []
     for conv, bn in P.units:
         params += [conv.weight, bn.weight, bn.bias]
+    if not all(p.is_contiguous() for p in params):
+        return None
+    call = _fill(P, feats, ctx, training)
+    if call is None:
+        return None
     return PassFunction.apply(feats, call, *params)
 
 

@@ -73,6 +73,9 @@ class Rulebook:
     # SubM rulebook over rows that are in ascending coordinate order (the output of a strided conv): the gather-GEMM may
     # stage its gathers through LDS row windows (VC_CONV_SORTED_ROWS)
     sorted_rows: bool = False
+    # duplicate-pixel tables: (2, n) int32 [rows sorted stably by representative | the sorted representatives] -- fixes the
+    # order of the additions of the backward's group sum (vc_group_sum_sorted)
+    grp_plan: Optional[torch.Tensor] = None
 
     @property
     def kv(self) -> int:
@@ -93,6 +96,8 @@ def build_subm_rulebook(indices: torch.Tensor, spatial_shape, ksize, dilation=1,
                   (1,) * ndim, tuple(k // 2 for k in ks), dl)
     # strided-conv outputs are emitted in ascending (b, z, y, x) order and tagged below; a SubM conv on them reads a sorted table
     rb.sorted_rows = bool(WINDOW_GATHER and getattr(indices, "_vc_sorted", False) and not allow_duplicates)
+    if rb.rep is not None and hasattr(get_backend(), "group_plan") and indices.is_cuda and torch.is_grad_enabled():
+        rb.grp_plan = get_backend().group_plan(rb.rep)
     if rb.rep is not None and REP_FIRST_ORDER and ROW_ORDER != "all" and hasattr(get_backend(), "rep_order") and indices.is_cuda:
         # duplicate-pixel table: the backward-input walks representatives first (homogeneous tiles, see vc_rep_order)
         rb.order_bwd = get_backend().rep_order(rb.rep)
@@ -124,10 +129,12 @@ def _sparse_rulebook_from(indices, shape, out_idx, out_shape, pf, pb, ks, st, pd
     rb = Rulebook("sparse", pf, pb, None, indices.shape[0], out_idx.shape[0], indices, out_idx, shape,
                   tuple(int(s) for s in out_shape), ks, st, pd, dl)
     # the row order only serves the backward-input conv: not built when no gradient will flow (inference)
-    if ROW_ORDER in ("bwd", "all") and 8 < rb.kv <= 32 and torch.is_grad_enabled():
+    if ROW_ORDER in ("bwd", "strided", "all") and 8 < rb.kv <= 32 and torch.is_grad_enabled():
         rb.order_bwd = be.row_order(pb, window=ROW_ORDER_WINDOW)
-        if ROW_ORDER == "all":
-            rb.order_fwd = be.row_order(pf, window=ROW_ORDER_WINDOW)
+    if ROW_ORDER in ("strided", "all") and 8 < rb.kv <= 32:
+        # forward table of a strided conv: 4.9 active offsets per row but 17.7 per 16-row tile in natural order (72 % of the
+        # issued MFMAs are padding); mask-sorted rows bring the tile union down (-25 % measured)
+        rb.order_fwd = be.row_order(pf, window=ROW_ORDER_WINDOW)
     return rb
 
 
@@ -213,7 +220,7 @@ def _conv_backward(rb: "Rulebook", inverse: bool, features, weight, grad_out, ne
         elif rb.kind == "subm":
             dx = be.conv_backward_input(grad_out, weight, rb.pair_fwd, rb.n_in, mirror=True, centre=rb.centre, rep=rb.rep,
                                         order=rb.order_bwd, operand=MFMA_OPERAND, group_ws=group_ws,
-                                        sorted_rows=rb.sorted_rows)
+                                        sorted_rows=rb.sorted_rows, grp_plan=rb.grp_plan)
         else:
             dx = be.conv_backward_input(grad_out, weight, rb.pair_bwd, rb.n_in, mirror=False, order=rb.order_bwd,
                                         operand=MFMA_OPERAND)
@@ -288,9 +295,9 @@ class ConvBNReLUFunction(torch.autograd.Function):
                 tbl_w, tbl_dx, n_dx, mirror, order_dx, rep, centre = rb.pair_fwd, rb.pair_bwd, rb.n_in, False, rb.order_bwd, None, -1
             dx, dw, dgamma, dbeta = be.post_act_block_backward(
                 x, weight, y_raw, wide, col0, mean, var, gamma, beta, eps, relu, tbl_w, tbl_dx, n_dx, mirror, centre, rep,
-                order_dx, MFMA_OPERAND, rb.sorted_rows and rb.kind == "subm" and not inverse, need_dx, need_dw)
+                rb.grp_plan if rep is not None else None, order_dx, MFMA_OPERAND, rb.sorted_rows and rb.kind == "subm" and not inverse, need_dx, need_dw)
             return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None
-        if (rb.rep is not None and not ctx.inverse and rb.kind == "subm" and need_dx
+        if (rb.rep is not None and rb.grp_plan is None and not ctx.inverse and rb.kind == "subm" and need_dx
                 and hasattr(be, "group_sum_prepare") and y_raw.is_cuda
                 and (y_raw.shape[1] & (y_raw.shape[1] - 1)) == 0):
             # duplicate-pixel conv: its backward group-sums d_raw in fixed point and needs max|d_raw|; the BN backward
@@ -337,6 +344,8 @@ FUSED_UNIT_CALLS = os.environ.get("VIRCONV_FUSED_UNIT_CALLS", "1") != "0"
 # vc_row_order permutations computed with the rulebooks (tile-homogeneity hint for the gather-GEMM; results identical).
 #   "bwd"  (default) strided convs' backward-input tables only: their active sets are parity classes, sorting cuts the
 #          issued work 2.3x (measured: s3.down bwd 197 -> 85 us) and a 1024-row window is enough
+#   "strided" (default since round 3) the strided convs' forward AND backward-input tables: the sorts run on the geometry-plan
+#          stream underneath the previous step's backward
 #   "all"  every table (measured: strided forward -25 %, SubM +-0 -- the sort costs more than it saves there)
 #   "none" natural order everywhere
 # MFMA operand type of the conv kernels: "f32" (exact, default, the parity path) | "f16" | "bf16" (BASELINE configs[4]:
@@ -347,7 +356,7 @@ MFMA_OPERAND = os.environ.get("VIRCONV_MFMA_OPERAND", "f32")
 # LDS, LDS costs resident waves, and these kernels' throughput follows their occupancy -- profiles/r02_kbench_variants.txt,
 # r02_pmc_conv_variants.md).  Off by default; "1" turns it on (tools/kbench.py measures both).
 WINDOW_GATHER = os.environ.get("VIRCONV_WINDOW_GATHER", "0") != "0"
-ROW_ORDER = os.environ.get("VIRCONV_ROW_ORDER", "bwd")
+ROW_ORDER = os.environ.get("VIRCONV_ROW_ORDER", "strided")
 # duplicate-pixel (2-D) SubM tables: backward-input in representative-first row order (vc_rep_order).  Measured: no gain (2-D
 # backward-input 316 vs 303 us per pass, train step 6.21 vs 6.17 ms) -- those launches are dominated by the group-sum machinery
 # and the gathers, not by padded MFMAs.  Off by default.
