@@ -204,6 +204,13 @@ size_t vc_conv_backward_weight_workspace_bytes(int64_t n_out, int kv, int cin, i
 int vc_conv_backward_weight(const float* x, const float* dy, const int32_t* pair_fwd, int64_t n_out, int kv,
                             int cin, int cout, int operand_type, float* dweight, void* ws, size_t ws_bytes,
                             void* stream);
+/* Duplicate-coordinate SubM tables (2-D image-space branch): all rows of a pixel group read the same neighbour row through a
+ * non-centre offset, so those offsets are summed over the REPRESENTATIVES only against the group-summed gradient dy_grp
+ * (vc_group_sum_sorted; the backward-input conv needs it anyway), the centre offset over every row against dy.  Same dW up to
+ * the order of the fp32 additions, 2-5x fewer pairs.                                                                   */
+int vc_conv_backward_weight_dup(const float* x, const float* dy, const float* dy_grp, const int32_t* rep, int centre,
+                                const int32_t* pair_fwd, int64_t n_out, int kv, int cin, int cout, int operand_type,
+                                float* dweight, void* ws, size_t ws_bytes, void* stream);
 
 /* dy_grp[rep[i], :] = sum over the rows i sharing representative rep[i] of dy[i, :]  (rows that are nobody's
  * representative are NOT written: vc_conv_backward_input reads dy_grp at representatives only, and 47-81 % of the rows of
@@ -225,6 +232,9 @@ int vc_group_sum_prepare(void* ws, size_t ws_bytes, int64_t n, int c, void* stre
  * runs cut by a 32-row chunk border through one partial per chunk, combined in chunk order: no atomics, no max|dy| pass, no
  * 8-byte accumulators, bit-stable.  c must be a power of two.  Same output contract as vc_group_sum (representatives only). */
 int vc_group_keys(const int32_t* rep, int64_t n, int32_t* keys, void* stream);
+/* ... or let the library build the plan: keys + one stable radix sort of the (key, row) pairs.  grp_plan: 2 * n int32.           */
+size_t vc_group_plan_workspace_bytes(int64_t n);
+int vc_group_plan(const int32_t* rep, int64_t n, int32_t* grp_plan, void* ws, size_t ws_bytes, void* stream);
 size_t vc_group_sum_sorted_workspace_bytes(int64_t n, int c);
 int vc_group_sum_sorted(const float* dy, const int32_t* grp_plan, int64_t n, int c, float* dy_grp, void* ws, size_t ws_bytes,
                         void* stream);

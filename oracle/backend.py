@@ -68,7 +68,7 @@ class OracleBackend:
         return False  # fused epilogues are a product optimisation; the oracle always takes the plain path
 
     def conv_backward_input(self, dy, weight, tbl, n_in, mirror, centre=-1, rep=None, order=None, operand="f32",
-                            group_ws=None, sorted_rows=False, grp_plan=None):
+                            group_ws=None, sorted_rows=False, grp_plan=None, grp=None):
         """dX of the three conv flavours, in the product's calling convention (include/virconv_hip.h).
 
         SubM (mirror=True, tbl = pair_fwd): the EXACT transpose of the forward gather,
@@ -93,7 +93,8 @@ class OracleBackend:
             dx.index_add_(0, torch.from_numpy(rows.astype(np.int64)), g @ wk[k].t())
         return dx
 
-    def conv_backward_weight(self, x, dy, pair_fwd, weight_shape, stream=None, keep_alive=None, operand="f32"):
+    def conv_backward_weight(self, x, dy, pair_fwd, weight_shape, stream=None, keep_alive=None, operand="f32", rep=None, centre=-1,
+                             dy_grp=None):
         w0 = x.new_zeros(tuple(weight_shape))
         x, dy = self._operands(operand, int(weight_shape[-1]), int(weight_shape[0]), x, dy)
         _, dw = sparse_ref.conv_backward(x, w0, _np(pair_fwd), dy)

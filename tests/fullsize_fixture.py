@@ -1,0 +1,142 @@
+"""Shared pieces of the FULL-SIZE reference-composition fixture (tests/golden/virconv_l_fullsize_ref.npz).
+
+The fixture is produced by tests/golden/make_golden_fullsize.py from the reference's UNMODIFIED VirConvL8x
+(pcdet/models/backbones_3d/spconv_backbone.py:538-699, NRConvBlock :150-229) run on the CPU oracle operators over two FULL
+synthetic KITTI frames (~33 000 voxels each: populated neighbourhoods, 60-90 k rows at stride 2), eval mode and train mode
+(BatchNorm batch statistics, layer discard as the reference's code behaves under the spconv 2.x it requires: a no-op,
+SURVEY App-C.1) with a backward pass.  A full tensor dump would be ~100 MB, so per tensor the fixture keeps
+    N, sha256(indices), per-channel sum and abs-sum (float64), and K sampled rows (positions + values),
+and per parameter gradient / BatchNorm running statistic: sum, abs-sum and up to K sampled entries.
+Inputs are NOT stored: they are regenerated here from the seeds (numpy PCG64 + the oracle's numpy geometry, deterministic) and
+checked against the stored sha256 of the voxel coordinates.
+"""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+import torch
+
+from oracle import geometry
+from virconv_amd import synth
+
+K_ROWS = 1024          # sampled rows per output tensor
+K_GRAD = 512           # sampled entries per gradient tensor
+TENSORS = ("x_conv1", "x_conv2", "x_conv3", "x_conv4", "out")
+CHANNELS = {"x_conv1": 16, "x_conv2": 32, "x_conv3": 64, "x_conv4": 64, "out": 64}
+PARAM_SEED = 7
+
+
+def make_inputs(seeds):
+    """Frames -> reference data path on the oracle (input discard 0.8 / 2 bins, LiDAR-first concat, voxelise 0.05^3 <= 5 pts,
+    cap 40 000, MeanVFE 'max'); same recipe as tests/golden/make_golden.py at full size."""
+    feats, coords, calibs, augs = [], [], [], []
+    for b, seed in enumerate(seeds):
+        fr = synth.make_frame(int(seed))
+        perm_rng = np.random.default_rng(1000 + int(seed))
+        virt = geometry.input_point_discard(fr["points_virtual"], bin_num=2, rate=0.8, permutation=perm_rng.permutation)
+        pts = np.concatenate([fr["points_lidar"], virt])
+        vox, c, num = geometry.voxelize(pts, synth.VOXEL_SIZE, synth.POINT_CLOUD_RANGE, 5, 40000)
+        feats.append(geometry.mean_vfe(vox, num, "max"))
+        coords.append(np.concatenate([np.full((c.shape[0], 1), b, np.int32), c], axis=1))
+        calibs.append(fr["calib"])
+        augs.append(fr["aug_param"])
+    return np.concatenate(feats), np.concatenate(coords), calibs, np.stack(augs)
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def sample_positions(n: int, k: int, salt: int) -> np.ndarray:
+    rng = np.random.default_rng(977 + salt)
+    return np.sort(rng.choice(n, size=min(n, k), replace=False)).astype(np.int64)
+
+
+def loss_weights(name: str, n: int, c: int) -> torch.Tensor:
+    """G[row, ch] = g[ch] * (1 + 0.5 cos(0.37 row)): a fixed, row-dependent stand-in for the heads' gradient (float64 math,
+    rounded once to fp32)."""
+    rng = np.random.default_rng(4242 + TENSORS.index(name))
+    g = rng.standard_normal(c) * 0.05
+    rows = 1.0 + 0.5 * np.cos(0.37 * np.arange(n, dtype=np.float64))
+    return torch.from_numpy((rows[:, None] * g[None, :]).astype(np.float32))
+
+
+def outputs_of(batch_dict):
+    """{name: (features (N, C) tensor, indices (N, 4) tensor)} for the five pinned tensors."""
+    res = {n: batch_dict["multi_scale_3d_features"][n] for n in TENSORS[:4]}
+    res["out"] = batch_dict["encoded_spconv_tensor"]
+    return {k: (t.features, t.indices) for k, t in res.items()}
+
+
+def loss_of(outs) -> torch.Tensor:
+    loss = None
+    for name in TENSORS:
+        f = outs[name][0]
+        term = (f * loss_weights(name, f.shape[0], f.shape[1]).to(f.device)).sum()
+        loss = term if loss is None else loss + term
+    return loss
+
+
+def summarize_outputs(outs, prefix: str) -> dict:
+    d = {}
+    for ti, name in enumerate(TENSORS):
+        f = outs[name][0].detach().cpu().numpy().astype(np.float64)
+        idx = outs[name][1].detach().cpu().numpy().astype(np.int32)
+        pos = sample_positions(f.shape[0], K_ROWS, ti)
+        d[f"{prefix}_{name}_n"] = np.array(f.shape[0])
+        d[f"{prefix}_{name}_idx_sha"] = np.array(sha(idx))
+        d[f"{prefix}_{name}_colsum"] = f.sum(0)
+        d[f"{prefix}_{name}_colabs"] = np.abs(f).sum(0)
+        d[f"{prefix}_{name}_rows"] = f[pos].astype(np.float32)
+    return d
+
+
+def summarize_named(tensors: dict, prefix: str) -> dict:
+    """{name: tensor} (parameter gradients, running statistics) -> sums + sampled entries."""
+    d = {}
+    for ti, name in enumerate(sorted(tensors)):
+        v = tensors[name].detach().cpu().numpy().astype(np.float64).reshape(-1)
+        pos = sample_positions(v.shape[0], K_GRAD, 100 + ti)
+        d[f"{prefix}|{name}|sum"] = np.array([v.sum(), np.abs(v).sum(), np.abs(v).max()])
+        d[f"{prefix}|{name}|val"] = v[pos].astype(np.float32)
+    return d
+
+
+def check_outputs(outs, g, prefix: str, tol: float = 1e-4, report=None):
+    """Compare a run against the fixture: N and indices bit-exact (hash), sampled rows within tol * max|tensor| element-wise
+    (plus a relative term), per-channel sums within the fp32 summation bound of the tensor."""
+    for ti, name in enumerate(TENSORS):
+        f = outs[name][0].detach().cpu().numpy().astype(np.float64)
+        idx = outs[name][1].detach().cpu().numpy().astype(np.int32)
+        assert f.shape[0] == int(g[f"{prefix}_{name}_n"]), f"{prefix} {name}: N {f.shape[0]} != {int(g[f'{prefix}_{name}_n'])}"
+        assert sha(idx) == str(g[f"{prefix}_{name}_idx_sha"]), f"{prefix} {name}: indices differ from the reference composition"
+        pos = sample_positions(f.shape[0], K_ROWS, ti)
+        ref = g[f"{prefix}_{name}_rows"].astype(np.float64)
+        scale = max(1.0, float((g[f"{prefix}_{name}_colabs"] / f.shape[0]).max()) * 8.0, float(np.abs(ref).max()))
+        err = np.abs(f[pos] - ref)
+        bound = tol * scale * 1e-1 + tol * np.abs(ref)          # element-wise: atol = 1e-5 * scale, rtol = 1e-4
+        assert np.all(err <= bound), f"{prefix} {name}: sampled rows differ, worst {float((err / bound).max()):.2f} x bound"
+        cs, ca = g[f"{prefix}_{name}_colsum"], g[f"{prefix}_{name}_colabs"]
+        serr = np.abs(f.sum(0) - cs)
+        assert np.all(serr <= tol * ca + 1e-6), f"{prefix} {name}: channel sums differ ({float((serr / (tol * ca + 1e-6)).max()):.2f} x bound)"
+        serr = np.abs(np.abs(f).sum(0) - ca)
+        assert np.all(serr <= tol * ca + 1e-6), f"{prefix} {name}: channel abs-sums differ"
+        if report is not None:
+            report.append(f"{prefix} {name}: N {f.shape[0]}, indices sha ok, rows max err {float(err.max()):.3e} (scale {scale:.3g})")
+
+
+def check_named(tensors: dict, g, prefix: str, rtol: float, report=None):
+    """Gradients / running statistics against the fixture: sampled entries within rtol * max|tensor|, sums within rtol * abs-sum."""
+    names = sorted(tensors)
+    for ti, name in enumerate(names):
+        v = tensors[name].detach().cpu().numpy().astype(np.float64).reshape(-1)
+        s = g[f"{prefix}|{name}|sum"]
+        ref = g[f"{prefix}|{name}|val"].astype(np.float64)
+        pos = sample_positions(v.shape[0], K_GRAD, 100 + ti)
+        mx = max(float(s[2]), 1e-12)
+        err = np.abs(v[pos] - ref)
+        assert np.all(err <= rtol * mx), f"{prefix} {name}: worst {float(err.max() / mx):.3e} of max|.| (bound {rtol})"
+        assert abs(v.sum() - s[0]) <= rtol * max(s[1], 1e-12) * 4, f"{prefix} {name}: sum differs"
+        if report is not None:
+            report.append(f"{prefix} {name}: {float(err.max() / mx):.3e}")

@@ -1,0 +1,150 @@
+"""virconv_amd.backbone.VirConvL8x at KITTI scale against the fixture produced by the reference's UNMODIFIED composition code
+(tests/golden/make_golden_fullsize.py -> virconv_l_fullsize_ref.npz; two full synthetic frames, 66 k / 146 k / 96 k / 40 k rows).
+
+  * CPU (`-m "not gpu"`): the inputs regenerate bit-identically from the seeds; virconv_amd.backbone on the ORACLE backend equals
+    the reference composition (eval and train: N, indices, sampled rows, channel sums, running statistics, loss, gradients);
+    when /root/reference is present the reference composition itself is re-run and must reproduce the committed fixture.
+  * GPU: the HIP path against the same fixture.  Gradients are judged against the fixture's float64 run with the fp32
+    reference-composition run as the yardstick (the fp32 oracle is itself up to 1.7e-3 * max|g| from the exact gradient on this
+    batch); the rigorous treatment of isolated ReLU-mask flips is tests/test_fullsize_gpu.py::_compare_train (masks compared and
+    forced) -- here <= 3 % of the SAMPLED entries of a tensor may exceed the calibrated bound, and must stay below 2e-2 * max.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fullsize_fixture as fx
+import refharness
+from helpers import GRID, MODEL_CFG, fill_parameters, load_golden
+from virconv_amd.backbone import VirConvL8x
+
+CFG = dict(MODEL_CFG, LAYER_DISCARD_MODE="spconv2_noop")   # what the reference's code does under spconv 2.x
+
+
+@pytest.fixture(scope="module")
+def fixture_inputs():
+    g = load_golden("virconv_l_fullsize_ref.npz")
+    inputs = fx.make_inputs([int(s) for s in g["seeds"]])
+    return g, inputs
+
+
+def _batch(inputs, device):
+    feats, coords, calibs, aug = inputs
+    return {"batch_size": len(calibs), "voxel_features": torch.from_numpy(feats.copy()).to(device),
+            "voxel_coords": torch.from_numpy(coords.astype(np.float32)).to(device), "calib": calibs,
+            "aug_param": torch.from_numpy(aug.copy()).to(device)}
+
+
+def _model(device, training):
+    m = VirConvL8x(CFG, input_channels=8, grid_size=GRID).to(device)
+    fill_parameters(m, fx.PARAM_SEED)
+    m.train(training)
+    return m
+
+
+def _eval_check(g, inputs, device, report=None):
+    with torch.no_grad():
+        out = _model(device, False)(_batch(inputs, device))
+    fx.check_outputs(fx.outputs_of(out), g, "eval", report=report)
+
+
+def _train_run(inputs, device):
+    m = _model(device, True)
+    out = m(_batch(inputs, device))
+    outs = fx.outputs_of(out)
+    loss = fx.loss_of(outs)
+    loss.backward()
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    stats = {k: v for k, v in m.state_dict().items() if "running_" in k}
+    return outs, float(loss.detach()), grads, stats
+
+
+def test_fixture_inputs_regenerate_bit_identically(fixture_inputs):
+    g, inputs = fixture_inputs
+    assert inputs[0].shape[0] == int(g["n_voxels"]) > 60000
+    assert fx.sha(inputs[1]) == str(g["coords_sha"]) and fx.sha(inputs[0]) == str(g["feats_sha"])
+
+
+def test_fullsize_oracle_backend_equals_the_reference_composition_eval(oracle_backend, fixture_inputs):
+    g, inputs = fixture_inputs
+    _eval_check(g, inputs, "cpu")
+
+
+def test_fullsize_oracle_backend_equals_the_reference_composition_train(oracle_backend, fixture_inputs):
+    """Same operators under both compositions: everything agrees to fp32 re-association noise (1e-5 class)."""
+    g, inputs = fixture_inputs
+    outs, loss, grads, stats = _train_run(inputs, "cpu")
+    fx.check_outputs(outs, g, "train")
+    assert abs(loss - float(g["train_loss"])) <= 1e-2
+    fx.check_named(stats, g, "train_stat", rtol=1e-5)
+    fx.check_named(grads, g, "train_grad", rtol=2e-4)
+
+
+@pytest.mark.skipif(not refharness.available(), reason="reference tree not present (GPU box)")
+def test_fixture_regenerates_from_the_reference_composition(fixture_inputs):
+    """Re-run the reference's unmodified VirConvL8x (eval) on the oracle operators: it must reproduce the committed fixture."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_fullsize as mk
+    from oracle.backend import OracleBackend
+    from virconv_amd import ops
+    g, inputs = fixture_inputs
+    ref = refharness.import_reference_backbone()
+    with ops.use_backend(OracleBackend()):
+        with torch.no_grad():
+            out = mk.reference_model(ref, False)(mk.reference_batch(*inputs))
+        outs = fx.outputs_of(out)
+        assert mk.projection_matches(ref, outs, inputs[2], inputs[3])
+    new = fx.summarize_outputs(outs, "eval")
+    for k, v in new.items():
+        if v.dtype.kind in "US":
+            assert str(v) == str(g[k]), k
+        else:
+            np.testing.assert_allclose(v, g[k], rtol=1e-6, atol=1e-6, err_msg=k)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_fullsize_hip_equals_the_reference_composition_eval(hip_backend, fixture_inputs):
+    g, inputs = fixture_inputs
+    report = []
+    _eval_check(g, inputs, "cuda", report)
+    _write_report("fixture_eval", report)
+
+
+@pytest.mark.gpu
+def test_fullsize_hip_equals_the_reference_composition_train(hip_backend, fixture_inputs):
+    g, inputs = fixture_inputs
+    report = []
+    outs, loss, grads, stats = _train_run(inputs, "cuda")
+    fx.check_outputs(outs, g, "train", report=report)
+    l64, l32 = float(g["train64_loss"]), float(g["train_loss"])
+    assert abs(loss - l64) <= max(1e-2, 3 * abs(l32 - l64)), (loss, l64, l32)
+    fx.check_named(stats, g, "train_stat", rtol=1e-5, report=report)
+    names = sorted(grads)
+    worst = 0.0
+    for ti, name in enumerate(names):
+        v = grads[name].detach().cpu().numpy().astype(np.float64).reshape(-1)
+        pos = fx.sample_positions(v.shape[0], fx.K_GRAD, 100 + ti)
+        r64 = g[f"train64_grad|{name}|val"].astype(np.float64)
+        r32 = g[f"train_grad|{name}|val"].astype(np.float64)
+        mx = max(float(g[f"train64_grad|{name}|sum"][2]), 1e-12)
+        e32 = float(np.abs(r32 - r64).max()) / mx
+        err = np.abs(v[pos] - r64) / mx
+        bound = max(1e-4, 3 * e32)
+        n_over = int((err > bound).sum())
+        allowed = max(2, int(0.03 * err.size)) if grads[name].dim() > 1 else 2
+        report.append(f"train_grad {name:34s} hip-f64 {err.max():.2e} f32ref-f64 {e32:.2e} bound {bound:.2e} over {n_over}/{allowed}")
+        assert err.max() <= bound or (n_over <= allowed and err.max() <= 2e-2), report[-1]
+        worst = max(worst, float(err.max()))
+    report.append(f"loss {loss:.6f} (reference composition float64 {l64:.6f}, float32 {l32:.6f}); worst gradient entry {worst:.2e} of max|g|")
+    _write_report("fixture_train", report)
+
+
+def _write_report(tag, rows):
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, f"parity_{tag}.txt"), "w") as f:
+        f.write("\n".join(rows) + "\n")

@@ -228,6 +228,25 @@ def _bench_loss(out, lw, mm=False):
     return loss
 
 
+class _DoubleTensor:
+    def __init__(self, t):
+        self._t = t
+        self.features = t.features.detach().double()
+
+    def dense(self):
+        return self._t.dense().detach().double()
+
+
+class _Double(dict):
+    """View of a backbone output dict whose sparse tensors hand out float64 copies of their features (loss re-accumulation)."""
+    def __init__(self, out):
+        super().__init__()
+        self["encoded_spconv_tensor"] = _DoubleTensor(out["encoded_spconv_tensor"])
+        for g in ("multi_scale_3d_features", "multi_scale_3d_features_mm"):
+            if g in out:
+                self[g] = {k: _DoubleTensor(t) for k, t in out[g].items()}
+
+
 def _train_pass(model, batch, lw, mm=False):
     model.zero_grad(set_to_none=True)
     bd = dict(batch)
@@ -237,6 +256,9 @@ def _train_pass(model, batch, lw, mm=False):
     out = model(bd)
     loss = _bench_loss(out, lw, mm)
     loss.backward()
+    with torch.no_grad():   # the same loss accumulated in float64 from the fp32 outputs: feature errors only, no fp32 summation noise
+        lw64 = {k: v.double() for k, v in lw.items()}
+        loss64 = float(_bench_loss(_Double(out), lw64, mm))
     res = {}
     for name, t in out["multi_scale_3d_features"].items():
         res[name] = (t.features.detach().cpu().numpy(), t.indices.cpu().numpy())
@@ -246,7 +268,7 @@ def _train_pass(model, batch, lw, mm=False):
     t = out["encoded_spconv_tensor"]
     res["out"] = (t.features.detach().cpu().numpy(), t.indices.cpu().numpy())
     grads = {k: p.grad.detach().cpu().numpy() for k, p in model.named_parameters()}
-    return float(loss.detach()), res, grads
+    return loss64, res, grads
 
 
 def _record_discards(monkeypatch):
@@ -266,7 +288,81 @@ def _record_discards(monkeypatch):
     return rec
 
 
-def _oracle_pass(model_cls, cfg, state, batch, lw, keeps, dtype, mm=False):
+class ReluMasks:
+    """On the CPU oracle path every conv+BN+ReLU unit ends in a stock nn.ReLU module (SparseSequential applies plain modules to
+    .features).  Inside `with ReluMasks(...)` nn.ReLU.forward is replaced: it RECORDS the mask z > 0 (and optionally z, the
+    BatchNorm output) of every unit in forward order, or applies FORCED masks instead -- y = where(mask, z, 0), whose autograd
+    backward passes dy exactly where the mask is set.  Lets the gradient comparison separate "a pre-activation within rounding
+    of 0 took the other side of the ReLU" from every other kind of error."""
+
+    def __init__(self, forced=None, keep_z=False):
+        self.forced, self.keep_z = forced, keep_z
+        self.masks, self.z = [], []
+
+    def __enter__(self):
+        self._orig = torch.nn.ReLU.forward
+        me = self
+
+        def forward(module, z):
+            i = len(me.masks)
+            m = me.forced[i] if me.forced is not None else (z.detach() > 0)
+            assert m.shape == z.shape, (i, tuple(m.shape), tuple(z.shape))
+            me.masks.append(m)
+            if me.keep_z:
+                me.z.append(z.detach().clone())
+            return torch.where(m, z, torch.zeros_like(z))
+
+        torch.nn.ReLU.forward = forward
+        return self
+
+    def __exit__(self, *exc):
+        torch.nn.ReLU.forward = self._orig
+        return False
+
+
+def _hip_masks(hip_backend, model_cls, cfg, state, batch_h, lw, monkeypatch, mm=False):
+    """ReLU masks (y > 0) of every unit of the HIP path, in forward order: a second run on the node-by-node path (bit-identical
+    to the native feature pass, test_native_feature_pass_equals_the_node_by_node_path) with the unit call wrapped."""
+    from virconv_amd import feature_pass
+    masks = []
+    orig = hip_backend.post_act_block_forward
+
+    def recording(*a, **k):
+        res = orig(*a, **k)
+        masks.append((res[0] > 0).cpu())
+        return res
+
+    monkeypatch.setattr(hip_backend, "post_act_block_forward", recording)
+    monkeypatch.setattr(feature_pass, "NATIVE_PASS", False)
+    m = model_cls(cfg, 8, synth.GRID_SIZE).to("cuda").train()
+    m.load_state_dict(state)
+    _, res, _ = _train_pass(m, batch_h, lw, mm)
+    monkeypatch.setattr(hip_backend, "post_act_block_forward", orig)
+    monkeypatch.setattr(feature_pass, "NATIVE_PASS", True)
+    return masks, res
+
+
+def _flip_census(masks_h, be64, tag):
+    """Compare the HIP masks with the float64 oracle's: every differing (row, channel) must be a pre-activation within fp32
+    rounding of zero -- |z| <= 1e-5 * max(1, max|z|) of its unit (z = BatchNorm output, O(1))."""
+    assert len(masks_h) == len(be64.masks), (len(masks_h), len(be64.masks))
+    n_flip, worst, rows = 0, 0.0, []
+    for i, (mh, mo, z) in enumerate(zip(masks_h, be64.masks, be64.z)):
+        assert mh.shape == mo.shape, (i, mh.shape, mo.shape)
+        diff = mh != mo
+        k = int(diff.sum())
+        if k:
+            scale = max(1.0, float(z.abs().max()))
+            zz = float(z[diff].abs().max()) / scale
+            worst = max(worst, zz)
+            rows.append(f"unit {i:2d} {tuple(mo.shape)}: {k} of {mo.numel()} mask entries differ, max |z| there = {zz:.2e} of the unit's scale")
+            assert zz <= 1e-5, rows[-1]
+        n_flip += k
+    rows.append(f"{tag}: {n_flip} differing ReLU mask entries in {len(masks_h)} units, all with |z| <= {worst:.2e} * scale (bound 1e-5)")
+    return n_flip, rows
+
+
+def _oracle_pass(model_cls, cfg, state, batch, lw, keeps, dtype, mm=False, relu=None):
     """One oracle train pass in `dtype` (float32 = the reference's arithmetic, float64 = the exact answer) with the given
     injected keeps; the model is rebuilt from `state` so that BN running statistics start identically."""
     m = model_cls(cfg, 8, synth.GRID_SIZE).train().to(dtype)
@@ -282,12 +378,13 @@ def _oracle_pass(model_cls, cfg, state, batch, lw, keeps, dtype, mm=False):
     if keeps is not None:
         b["layer_discard_keep"] = keeps
     lwd = {k: v.cpu().to(dtype) for k, v in lw.items()}
-    with ops.use_backend(OracleBackend()):
+    import contextlib
+    with ops.use_backend(OracleBackend()), (relu if relu is not None else contextlib.nullcontext()):
         res = _train_pass(m, b, lwd, mm)
     return res, m
 
 
-def _compare_train(ref64, ref32, got, tag, feat_tol=1e-4, grad_floor=1e-4, noise_factor=3.0):
+def _compare_train(ref64, ref32, got, tag, feat_tol=1e-4, grad_floor=1e-4, noise_factor=3.0, allow_flips=False, extra_rows=()):
     """HIP (`got`) against the oracle.
 
     Indices: bit-exact.  Features: <= feat_tol * max (north_star: "features within 1e-4 fp32"), plus element-wise
@@ -296,14 +393,16 @@ def _compare_train(ref64, ref32, got, tag, feat_tol=1e-4, grad_floor=1e-4, noise
     DESIGN.md §3).  A flat 1e-4 bound is therefore not a property any fp32 implementation has; what is required instead is
     that the HIP path is as close to the EXACT (float64) gradients as the fp32 restatement of the reference algorithm is:
         err(hip, f64) <= max(grad_floor, noise_factor * err(oracle_f32, f64))    per tensor, max-normalised AND element-wise.
-    One more fp32 effect has to be allowed for: a pre-activation that lands within rounding distance of 0 takes the other
-    side of the ReLU in one of the two implementations; that single row then enters (or leaves) a weight gradient that is a
-    random-walk sum over N rows, i.e. it moves the entries of ONE output channel by ~1/sqrt(N) of their size (4e-3 at
-    N = 64 k).  Such isolated flips are accepted when they touch <= 3 % of a tensor's entries (<= 2 entries of a BatchNorm
-    vector) and stay below 2e-2 * max; the norm of the whole gradient vector has to agree to
-    max(2e-3, noise_factor * the fp32 oracle's own error).  Every tensor is written to gpurun_out/parity_<tag>.txt."""
+    One more fp32 effect exists: a pre-activation that lands within rounding distance of 0 takes the other side of the ReLU
+    in one of the two implementations; that single row then enters (or leaves) a weight gradient that is a random-walk sum over
+    N rows, i.e. it moves the entries of ONE output channel by ~1/sqrt(N) of their size (4e-3 at N = 64 k).  Round 3 no longer
+    ASSUMES that story: the callers compare the ReLU masks of the two backends (_flip_census: every differing entry must be a
+    pre-activation within 1e-5 of zero) and hand in oracle runs with the HIP masks FORCED, so that this function applies the
+    bound with NO allowance (allow_flips = False).  The loss (accumulated in float64 from each backend's fp32 outputs) has to
+    agree to 1e-2 absolute; the norm of the whole gradient vector to max(2e-3, noise_factor * the fp32 oracle's own error).
+    Every tensor is written to gpurun_out/parity_<tag>.txt."""
     (l64, out64, g64), (l32, out32, g32), (lh, outh, gh) = ref64, ref32, got
-    assert abs(lh - l64) <= 1e-4 * max(1.0, abs(l64)), (lh, l64)
+    assert abs(lh - l64) <= 1e-2, (lh, l64)
     for name in out64:
         np.testing.assert_array_equal(outh[name][1], out64[name][1], err_msg=f"{name}: indices differ")
         fo, fh = out64[name][0], outh[name][0]
@@ -320,7 +419,7 @@ def _compare_train(ref64, ref32, got, tag, feat_tol=1e-4, grad_floor=1e-4, noise
         bound = max(grad_floor, noise_factor * e_o)
         over = np.abs(gh[k] - ref) > bound * scale + 2e-3 * np.abs(ref)
         n_over, allowed = int(over.sum()), (max(2, int(0.03 * ref.size)) if ref.ndim > 1 else 2)
-        ok = (e_h <= bound) or (n_over <= allowed and e_h <= 2e-2)
+        ok = (e_h <= bound) or (allow_flips and n_over <= allowed and e_h <= 2e-2)
         rows.append(f"{k:34s} n={ref.size:7d} max|g|={scale:9.3e} hip-f64={e_h:8.2e} f32oracle-f64={e_o:8.2e} bound={bound:8.2e} "
                     f"over={n_over:5d}/{allowed:<5d} {'ok' if e_h <= bound else ('flip' if ok else 'FAIL')}")
         if not ok:
@@ -329,6 +428,7 @@ def _compare_train(ref64, ref32, got, tag, feat_tol=1e-4, grad_floor=1e-4, noise
     a, b, c = cat(gh), cat(g64), cat(g32)
     rel_h, rel_o = np.linalg.norm(a - b) / np.linalg.norm(b), np.linalg.norm(c - b) / np.linalg.norm(b)
     rows.append(f"whole gradient vector: |hip - f64| / |f64| = {rel_h:.3e}; fp32 oracle: {rel_o:.3e}; loss {lh:.6f} vs {l64:.6f}")
+    rows.extend(extra_rows)
     import os
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
@@ -354,20 +454,28 @@ def test_fullsize_benchmarked_train_config_vs_oracle(hip_backend, monkeypatch):
 
     rec = _record_discards(monkeypatch)
     torch.manual_seed(5)
-    ref32, cpu_model = _oracle_pass(VirConvL8x, bench.MODEL_CFG, state, batch, lw, None, torch.float32)
+    got = _train_pass(model, dict(batch), lw)                      # the HIP run draws the discard permutations ...
     assert set(rec) == {"x_conv1", "x_conv2", "x_conv3"}
-    keeps = dict(rec)
-    ref64, _ = _oracle_pass(VirConvL8x, bench.MODEL_CFG, state, batch, lw, keeps, torch.float64)
-
-    bh = dict(batch)
-    bh["layer_discard_keep"] = {k: v.to(dev) for k, v in keeps.items()}
-    got = _train_pass(model, bh, lw)
+    keeps = dict(rec)                                              # ... which every other run gets injected
     # the discard really happened (x_conv1 is returned AFTER its discard: 90 % of the input rows, permuted order)
     n0 = batch["voxel_features"].shape[0]
     assert got[1]["x_conv1"][0].shape[0] == int(n0 * 0.9)
-    n_flip, rel_h, rel_o = _compare_train(ref64, ref32, got, "virconv_l_configs2")
+    bh = dict(batch)
+    bh["layer_discard_keep"] = {k: v.to(dev) for k, v in keeps.items()}
+    masks_h, res_node = _hip_masks(hip_backend, VirConvL8x, bench.MODEL_CFG, state, bh, lw, monkeypatch)
+    for name in res_node:                                          # the mask run IS the compared run, bit for bit
+        assert np.array_equal(res_node[name][0], got[1][name][0]) and np.array_equal(res_node[name][1], got[1][name][1]), name
+    be64 = ReluMasks(keep_z=True)
+    _oracle_pass(VirConvL8x, bench.MODEL_CFG, state, batch, lw, keeps, torch.float64, relu=be64)   # float64 masks + z
+    n_flip, flip_rows = _flip_census(masks_h, be64, "virconv_l_configs2")
+    del be64
+    ref64, _ = _oracle_pass(VirConvL8x, bench.MODEL_CFG, state, batch, lw, keeps, torch.float64, relu=ReluMasks(forced=masks_h))
+    ref32, cpu_model = _oracle_pass(VirConvL8x, bench.MODEL_CFG, state, batch, lw, keeps, torch.float32,
+                                    relu=ReluMasks(forced=masks_h))
+    _, rel_h, rel_o = _compare_train(ref64, ref32, got, "virconv_l_configs2", extra_rows=flip_rows)
     print(f"[parity configs[2]] loss {got[0]:.6f} vs {ref64[0]:.6f}; gradient vector: |hip - f64| / |f64| = {rel_h:.2e} "
-          f"(fp32 oracle: {rel_o:.2e}); tensors with an isolated ReLU flip: {n_flip}")
+          f"(fp32 oracle: {rel_o:.2e}); ReLU mask entries that differ from the float64 oracle: {n_flip} (all within rounding of 0, "
+          f"masks forced for the gradient comparison: no allowance)")
     # BN running statistics after the step (momentum update fused into the stats kernel)
     sd_h, sd_o = model.state_dict(), cpu_model.state_dict()
     for k in sd_o:
@@ -376,6 +484,38 @@ def test_fullsize_benchmarked_train_config_vs_oracle(hip_backend, monkeypatch):
             assert np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(b).max()), k
         if k.endswith("num_batches_tracked"):
             assert int(sd_h[k]) == int(sd_o[k]) == 1
+
+
+def test_exact_bench_batch_bs4_train_step_vs_oracle(hip_backend, monkeypatch):
+    """The batch bench.py times, exactly: frames 0-3 (133 578 input voxels, 310 k rows at stride 2), model seeded as bench.py
+    seeds it, train mode, layer discard 0.1, native feature pass.  One fp32 oracle pass with the drawn keeps injected: indices
+    bit-exact, features element-wise (rtol 1e-3 / atol 1e-4 * scale as the bs-2 test + 1e-4 * max), loss 1e-2 absolute, and the
+    whole gradient vector within 2e-3 of the fp32 oracle's (the per-tensor float64-calibrated statement is the bs-2 test's)."""
+    dev = torch.device("cuda", 0)
+    batch = bench.make_batch([0, 1, 2, 3], dev, training=True)
+    assert batch["voxel_features"].shape[0] > 120000
+    lw = bench.make_loss_weights(dev)
+    torch.manual_seed(0)
+    model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).to(dev).train()
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    rec = _record_discards(monkeypatch)
+    torch.manual_seed(100)
+    lh, outh, gh = _train_pass(model, dict(batch), lw)
+    keeps = dict(rec)
+    (lo, outo, go), _ = _oracle_pass(VirConvL8x, bench.MODEL_CFG, state, batch, lw, keeps, torch.float32)
+    assert abs(lh - lo) <= 1e-2, (lh, lo)
+    assert max(v[0].shape[0] for v in outh.values()) > 250000          # the 310 k-row stage-2 tensors (after discard: ~280 k)
+    for name in outo:
+        np.testing.assert_array_equal(outh[name][1], outo[name][1], err_msg=f"{name}: indices differ")
+        fo, fh = outo[name][0], outh[name][0]
+        assert np.abs(fh - fo).max() <= 1e-4 * max(1.0, np.abs(fo).max()), name
+        frac, _ = _elementwise_close(fh, fo, rtol=1e-3, atol=1e-4)
+        assert frac == 0.0, (name, frac)
+    cat = lambda g: np.concatenate([g[k].reshape(-1).astype(np.float64) for k in go])
+    a, b = cat(gh), cat(go)
+    rel = np.linalg.norm(a - b) / np.linalg.norm(b)
+    assert rel <= 2e-3, rel
+    print(f"[parity bench batch bs 4] loss {lh:.6f} vs {lo:.6f}; gradient vector |hip - oracle_f32| / |oracle_f32| = {rel:.2e}")
 
 
 def test_fullsize_virconv8x_train_vs_oracle(hip_backend, monkeypatch):
@@ -402,16 +542,23 @@ def test_fullsize_virconv8x_train_vs_oracle(hip_backend, monkeypatch):
 
     rec = _record_discards(monkeypatch)
     torch.manual_seed(6)
-    ref32, _ = _oracle_pass(VirConv8x, cfg, state, batch, lw, None, torch.float32, mm=True)
+    got = _train_pass(model, dict(batch), lw, mm=True)
     assert set(rec) == {"mm_input", "mm_x_conv1", "mm_x_conv2", "mm_x_conv3"}
     keeps = dict(rec)
-    ref64, _ = _oracle_pass(VirConv8x, cfg, state, batch, lw, keeps, torch.float64, mm=True)
     bh = dict(batch)
     bh["layer_discard_keep"] = {k: v.to(dev) for k, v in keeps.items()}
-    got = _train_pass(model, bh, lw, mm=True)
-    n_flip, rel_h, rel_o = _compare_train(ref64, ref32, got, "virconv_8x_configs3")
+    masks_h, res_node = _hip_masks(hip_backend, VirConv8x, cfg, state, bh, lw, monkeypatch, mm=True)
+    for name in res_node:
+        assert np.array_equal(res_node[name][0], got[1][name][0]) and np.array_equal(res_node[name][1], got[1][name][1]), name
+    be64 = ReluMasks(keep_z=True)
+    _oracle_pass(VirConv8x, cfg, state, batch, lw, keeps, torch.float64, mm=True, relu=be64)
+    n_flip, flip_rows = _flip_census(masks_h, be64, "virconv_8x_configs3")
+    del be64
+    ref64, _ = _oracle_pass(VirConv8x, cfg, state, batch, lw, keeps, torch.float64, mm=True, relu=ReluMasks(forced=masks_h))
+    ref32, _ = _oracle_pass(VirConv8x, cfg, state, batch, lw, keeps, torch.float32, mm=True, relu=ReluMasks(forced=masks_h))
+    _, rel_h, rel_o = _compare_train(ref64, ref32, got, "virconv_8x_configs3", extra_rows=flip_rows)
     print(f"[parity configs[3] backbone] loss {got[0]:.6f} vs {ref64[0]:.6f}; gradient vector: |hip - f64| / |f64| = {rel_h:.2e} "
-          f"(fp32 oracle: {rel_o:.2e}); tensors with an isolated ReLU flip: {n_flip}")
+          f"(fp32 oracle: {rel_o:.2e}); ReLU mask entries that differ from the float64 oracle: {n_flip}")
 
 
 @pytest.mark.parametrize("discard", ["spconv1_inplace", "spconv2_noop"])

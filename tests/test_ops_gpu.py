@@ -17,7 +17,13 @@ SHAPE3 = (21, 64, 48)
 
 
 def _rel_err(a: np.ndarray, b: np.ndarray) -> float:
-    return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+    """Element-wise normalised error: `_rel_err(a, b) < TOL` means |a_i - b_i| <= TOL * (|b_i| + 0.1 * max(1, max|b|)) for EVERY
+    element, i.e. rtol = TOL and atol = TOL / 10 of the tensor's scale (the former max|a - b| / max(1, max|b|) was
+    blind to small-magnitude channels)."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    if b.size == 0:
+        return 0.0
+    return float((np.abs(a - b) / (np.abs(b) + 0.1 * max(1.0, np.abs(b).max()))).max())
 
 
 def _indices3(seed, n, bs=2, shape=SHAPE3):

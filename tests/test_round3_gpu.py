@@ -55,10 +55,11 @@ def test_group_sum_sorted_equals_the_exact_sum_at_representatives(hip_backend, c
     np.testing.assert_array_equal(p[0], np.argsort(rep, kind="stable").astype(np.int32))
     np.testing.assert_array_equal(p[1], np.sort(rep))
     grp = hip_backend.group_sum_sorted(dy_t, plan)
-    for _ in range(3):                                   # fixed order of additions: re-runs are bit-equal
-        assert torch.equal(grp, hip_backend.group_sum_sorted(dy_t, plan))
-    ref = _group_ref(dy, rep)
     reps = np.unique(rep)
+    reps_t = torch.from_numpy(reps).cuda().long()
+    for _ in range(3):                                   # fixed order of additions: re-runs are bit-equal (at the rows that are written)
+        assert torch.equal(grp[reps_t], hip_backend.group_sum_sorted(dy_t, plan)[reps_t])
+    ref = _group_ref(dy, rep)
     got = grp.cpu().numpy()[reps].astype(np.float64)
     size = np.bincount(rep, minlength=n)[reps][:, None]
     absum = np.zeros(dy.shape, np.float64)
@@ -148,3 +149,32 @@ def test_row_order_of_a_table_with_thousands_of_distinct_masks(hip_backend, kv):
     order = hip_backend.row_order(torch.from_numpy(pair).cuda(), window=win).cpu().numpy()
     want = np.concatenate([s + np.argsort(masks[s:s + win], kind="stable") for s in range(0, n, win)])
     np.testing.assert_array_equal(order, want.astype(np.int32))
+
+
+@pytest.mark.parametrize("cin,cout", [(8, 8), (16, 16), (32, 32), (32, 16)])
+def test_duplicate_pixel_weight_gradient_over_representatives_equals_the_plain_one(hip_backend, cin, cout):
+    """vc_conv_backward_weight_dup: non-centre offsets over the representatives against the group-summed gradient, centre offset
+    over every row.  Same dW as the plain kernel (and as the float64 oracle) up to fp32 re-association; bit-stable."""
+    rng = np.random.default_rng(cin * 7 + cout)
+    shape = (160, 60)
+    n = 20000
+    idx = np.stack([rng.integers(0, 2, n), rng.integers(0, 40, n), rng.integers(0, 15, n)], 1).astype(np.int32)
+    idx[:5000, 1:] = 0
+    it = torch.from_numpy(idx).cuda()
+    pair, rep = hip_backend.subm_rulebook(it, shape, (3, 3), (1, 1), want_rep=True)
+    plan = hip_backend.group_plan(rep)
+    x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).cuda()
+    g = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32)).cuda()
+    grp = hip_backend.group_sum_sorted(g, plan)
+    wshape = (cout, 3, 3, cin)
+    a = hip_backend.conv_backward_weight(x, g, pair, wshape, rep=rep, centre=4, dy_grp=grp)
+    for _ in range(2):
+        assert torch.equal(a, hip_backend.conv_backward_weight(x, g, pair, wshape, rep=rep, centre=4, dy_grp=grp))
+    plain = hip_backend.conv_backward_weight(x, g, pair, wshape)
+    pref = sparse_ref.subm_rulebook(idx, shape, (3, 3))
+    _, dw_ref = sparse_ref.conv_backward(x.cpu().double(), torch.zeros(wshape, dtype=torch.float64), pref, g.cpu().double())
+    dw_ref = dw_ref.numpy()
+    scale = np.abs(dw_ref).max()
+    for got in (a, plain):
+        err = np.abs(got.cpu().numpy() - dw_ref)
+        assert np.all(err <= 1e-4 * np.abs(dw_ref) + 1e-5 * scale), float(err.max() / scale)

@@ -148,7 +148,12 @@ def main():
             else:
                 res["bwd"] = timeit(lambda: be.conv_backward_input(dy, w, rb.pair_bwd, rb.n_in, False, order=rb.order_bwd, operand=args.operand), args.iters)
         if args.only in ("all", "dw"):
-            res["dw"] = timeit(lambda: be.conv_backward_weight(x, dy, rb.pair_fwd, w.shape, operand=args.operand), args.iters)
+            if rb.kind == "subm" and rb.rep is not None and rb.grp_plan is not None:   # duplicate-pixel table: dW over representatives
+                grp = be.group_sum_sorted(dy, rb.grp_plan)
+                res["dw"] = timeit(lambda: be.conv_backward_weight(x, dy, rb.pair_fwd, w.shape, operand=args.operand, rep=rb.rep,
+                                                                   centre=rb.centre, dy_grp=grp), args.iters)
+            else:
+                res["dw"] = timeit(lambda: be.conv_backward_weight(x, dy, rb.pair_fwd, w.shape, operand=args.operand), args.iters)
 
         def tf(us):
             return flops / (us * 1e-6) / 1e12

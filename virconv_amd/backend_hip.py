@@ -324,7 +324,7 @@ class HipBackend:
                             centre: int = -1, rep: Optional[torch.Tensor] = None,
                             order: Optional[torch.Tensor] = None, operand: str = "f32",
                             group_ws: Optional[torch.Tensor] = None, sorted_rows: bool = False,
-                            grp_plan: Optional[torch.Tensor] = None) -> torch.Tensor:
+                            grp_plan: Optional[torch.Tensor] = None, grp: Optional[torch.Tensor] = None) -> torch.Tensor:
         """`grp_plan`: the duplicate-pixel table's rows sorted by representative (group_plan): the group sum runs in that
         fixed order (vc_group_sum_sorted).  Without it the order-free fixed-point sum is used; `group_ws`: its workspace from
         group_sum_prepare whose header already holds max|dy| (left there by bn_backward)."""
@@ -338,7 +338,9 @@ class HipBackend:
         src, src_centre = dy, None
         if rep is not None:
             rep = _need(rep, torch.int32, "rep")
-        if rep is not None and grp_plan is not None and (cout & (cout - 1)) == 0:
+        if rep is not None and grp is not None:          # group sum computed by the caller (it also feeds the weight gradient)
+            src, src_centre = grp, dy
+        elif rep is not None and grp_plan is not None and (cout & (cout - 1)) == 0:
             src, src_centre = self.group_sum_sorted(dy, grp_plan), dy
         elif rep is not None:
             grp = torch.empty_like(dy)
@@ -357,10 +359,13 @@ class HipBackend:
 
     def conv_backward_weight(self, x: torch.Tensor, dy: torch.Tensor, pair_fwd: torch.Tensor, weight_shape,
                              stream: Optional[int] = None, keep_alive: Optional[list] = None,
-                             operand: str = "f32") -> torch.Tensor:
+                             operand: str = "f32", rep: Optional[torch.Tensor] = None, centre: int = -1,
+                             dy_grp: Optional[torch.Tensor] = None) -> torch.Tensor:
         """`stream` (raw hipStream_t) overrides torch's current stream for the launches; the caller joins the streams and
         MUST pass `keep_alive`: the scratch buffer is appended to it so that torch's allocator (which only knows about the
-        current stream) cannot hand its memory to another tensor before the join."""
+        current stream) cannot hand its memory to another tensor before the join.
+        `rep` / `centre` / `dy_grp` (duplicate-pixel tables): the non-centre offsets walk the representatives only, against the
+        group-summed gradient (vc_conv_backward_weight_dup)."""
         assert stream is None or keep_alive is not None
         x = _need(x, torch.float32, "features")
         dy = _need(dy, torch.float32, "grad_out")
@@ -370,12 +375,20 @@ class HipBackend:
         dw = torch.empty(tuple(weight_shape), dtype=torch.float32, device=x.device)
         ws_bytes = self.lib.vc_conv_backward_weight_workspace_bytes(n_out, kv, cin, cout)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
-        check(self.lib.vc_conv_backward_weight(_ptr(x), _ptr(dy), _ptr(pair_fwd), n_out, kv, cin, cout,
-                                               OPERAND_TYPES[operand], _ptr(dw), _ptr(ws), ws_bytes,
-                                               _stream() if stream is None else stream),
-              "vc_conv_backward_weight")
+        if rep is not None and dy_grp is not None:
+            rep = _need(rep, torch.int32, "rep")
+            dy_grp = _need(dy_grp, torch.float32, "dy_grp")
+            check(self.lib.vc_conv_backward_weight_dup(_ptr(x), _ptr(dy), _ptr(dy_grp), _ptr(rep), int(centre), _ptr(pair_fwd), n_out,
+                                                       kv, cin, cout, OPERAND_TYPES[operand], _ptr(dw), _ptr(ws), ws_bytes,
+                                                       _stream() if stream is None else stream),
+                  "vc_conv_backward_weight_dup")
+        else:
+            check(self.lib.vc_conv_backward_weight(_ptr(x), _ptr(dy), _ptr(pair_fwd), n_out, kv, cin, cout,
+                                                   OPERAND_TYPES[operand], _ptr(dw), _ptr(ws), ws_bytes,
+                                                   _stream() if stream is None else stream),
+                  "vc_conv_backward_weight")
         if keep_alive is not None:
-            keep_alive.extend((ws, x, dy, pair_fwd))
+            keep_alive.extend((ws, x, dy, pair_fwd, rep, dy_grp))
         return dw
 
     # ------------------------------------------------------------------ RoI grid pooling
@@ -705,15 +718,13 @@ class HipBackend:
 
     def group_plan(self, rep: torch.Tensor) -> torch.Tensor:
         """(2, n) int32 [rows sorted stably by representative | sorted representatives] of a duplicate-pixel table: what
-        vc_group_sum_sorted walks.  Built once per table by the geometry plan (torch's stable radix sort of the keys)."""
+        vc_group_sum_sorted walks.  Built once per table by the geometry plan (vc_group_plan: keys + one stable radix sort)."""
         rep = _need(rep, torch.int32, "rep")
         n = rep.shape[0]
-        keys = torch.empty((n,), dtype=torch.int32, device=rep.device)
-        check(self.lib.vc_group_keys(_ptr(rep), n, _ptr(keys), _stream()), "vc_group_keys")
-        skeys, order = torch.sort(keys, stable=True)
         plan = torch.empty((2, n), dtype=torch.int32, device=rep.device)
-        plan[0].copy_(order)            # int64 -> int32
-        plan[1].copy_(skeys)
+        ws_bytes = self.lib.vc_group_plan_workspace_bytes(n)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=rep.device)
+        check(self.lib.vc_group_plan(_ptr(rep), n, _ptr(plan), _ptr(ws), ws_bytes, _stream()), "vc_group_plan")
         return plan
 
     def group_sum_sorted(self, dy: torch.Tensor, plan: torch.Tensor) -> torch.Tensor:

@@ -505,8 +505,11 @@ static inline void bn_split(int64_t n, int c, int& nb, int64_t& rpb) {
   nb = (int)cdiv(n, rpb);
 }
 
-// vc_debug_set "bn_fused_partial" (default 1): conv-epilogue partial rows -> statistics in one launch; 0 = the two-launch route
-int g_bn_fused_partial = 1;
+// vc_debug_set "bn_fused_partial": conv-epilogue partial rows -> statistics in ONE launch (bn_partial_fused_kernel) instead of
+// slab reduce + finalize.  MEASURED SLOWER and therefore off (round 3, profiles/r03_bn_fused_partial_rejected.txt): a block per 4
+// channels means 2-16 blocks pulling 0.5-5 MB through one CU each -- 24 us (statistics) / 31 us (backward sums) per launch against
+// 6.5 + 5 us for the two-launch route, +0.5 ms per train step.  Kept for A/B runs only.
+int g_bn_fused_partial = 0;
 
 static inline bool bn_c_ok(int c) { return c == 4 || c == 8 || c == 16 || c == 32 || c == 64 || c == 128; }
 

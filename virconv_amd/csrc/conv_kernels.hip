@@ -1704,7 +1704,12 @@ template <int CI, int CO, int OT>
 __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                          const int32_t* __restrict__ tbl, int64_t n_out, int kv,
                                                          int64_t rows_per_block, int nsplit, int legacy_order,
-                                                         float* __restrict__ partial) {
+                                                         float* __restrict__ partial, const int32_t* __restrict__ rep,
+                                                         int centre, const float* __restrict__ dy_grp) {
+  // Duplicate-pixel tables (rep != NULL; the 2-D image-space SubM convs): every row of a pixel group reads the SAME neighbour
+  // row through a non-centre offset k, so sum_{o in group} x[tbl[k][o]]^T dy[o] = x[tbl[k][r]]^T dy_grp[r] with r the group's
+  // representative and dy_grp the group-summed gradient the backward-input conv needs anyway (vc_group_sum_sorted): the
+  // non-centre offsets walk the representatives only (19-53 % of the rows) against dy_grp, the centre offset every row against dy.
   constexpr int VA = (CI >= 16) ? CI / 16 : 1, VB = (CO >= 16) ? CO / 16 : 1;
   constexpr int MA = (CI >= 16) ? 16 : CI, NB = (CO >= 16) ? 16 : CO;  // lanes of the tile that carry data
   constexpr int U = (VA * VB >= 8) ? 2 : 4;                            // groups of 4 pairs gathered per iteration
@@ -1728,6 +1733,8 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
     split = rl * 8 + xcd;
   }
   if (split >= nsplit) return;
+  const bool reps_only = rep != nullptr && k != centre;
+  if (reps_only) dy = dy_grp;
   const int64_t brow0 = (int64_t)split * rows_per_block;
   const int64_t bend = min(brow0 + rows_per_block, n_out);
   const int64_t rpw = rows_per_block / 4;  // rows_per_block is a multiple of 256
@@ -1744,12 +1751,17 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
   int* qi = q_in[wave];
   int* qo = q_out[wave];
   int qlen = 0;
-  int v_next = (wstart + lane < wend) ? tbl[(int64_t)k * n_out + wstart + lane] : -1;
+  auto entry = [&](int64_t r) -> int {
+    if (r >= wend) return -1;
+    const int v = tbl[(int64_t)k * n_out + r];
+    return (reps_only && rep[r] != (int32_t)r) ? -1 : v;
+  };
+  int v_next = entry(wstart + lane);
   for (int64_t base = wstart; base < wend; base += 64) {
     const int64_t r = base + lane;
     const int v = v_next;
     // prefetch the next 64 table entries: their latency hides under the gathers / MFMAs of this batch
-    v_next = (r + 64 < wend) ? tbl[(int64_t)k * n_out + r + 64] : -1;
+    v_next = entry(r + 64);
     const bool valid = v >= 0;
     const unsigned long long m = __ballot(valid);
     if (m == 0ULL) continue;
@@ -2450,12 +2462,13 @@ static inline void bw_split(int64_t n_out, int kv, int cin, int cout, int& nspli
 
 template <int CI, int CO>
 static int launch_bw(const float* x, const float* dy, const int32_t* tbl, int64_t n_out, int kv, float* dweight,
-                     float* partial, int ot, hipStream_t st) {
+                     float* partial, int ot, hipStream_t st, const int32_t* rep = nullptr, int centre = -1,
+                     const float* dy_grp = nullptr) {
   int nsplit;
   int64_t rpb;
   bw_split(n_out, kv, CI, CO, nsplit, rpb);
   const unsigned nblocks = g_bw_legacy_order ? (unsigned)(nsplit * kv) : (unsigned)(cdiv(nsplit, 8) * 8 * kv);
-#define VC_ARGS x, dy, tbl, n_out, kv, rpb, nsplit, g_bw_legacy_order, partial
+#define VC_ARGS x, dy, tbl, n_out, kv, rpb, nsplit, g_bw_legacy_order, partial, rep, centre, dy_grp
   bool launched = false;
   if constexpr (CI >= 16 && CO >= 16) {  // 16-bit operands only where both channel counts are >= 16 (as in the gather-GEMM)
     if (ot == VC_OPERAND_F16) {
@@ -2478,13 +2491,14 @@ static int launch_bw(const float* x, const float* dy, const int32_t* tbl, int64_
 
 template <int CI>
 static int dispatch_bw_co(int co, const float* x, const float* dy, const int32_t* tbl, int64_t n_out, int kv,
-                          float* dweight, float* partial, int ot, hipStream_t st) {
+                          float* dweight, float* partial, int ot, hipStream_t st, const int32_t* rep = nullptr, int centre = -1,
+                          const float* dy_grp = nullptr) {
   switch (co) {
-    case 4: return launch_bw<CI, 4>(x, dy, tbl, n_out, kv, dweight, partial, ot, st);
-    case 8: return launch_bw<CI, 8>(x, dy, tbl, n_out, kv, dweight, partial, ot, st);
-    case 16: return launch_bw<CI, 16>(x, dy, tbl, n_out, kv, dweight, partial, ot, st);
-    case 32: return launch_bw<CI, 32>(x, dy, tbl, n_out, kv, dweight, partial, ot, st);
-    case 64: return launch_bw<CI, 64>(x, dy, tbl, n_out, kv, dweight, partial, ot, st);
+    case 4: return launch_bw<CI, 4>(x, dy, tbl, n_out, kv, dweight, partial, ot, st, rep, centre, dy_grp);
+    case 8: return launch_bw<CI, 8>(x, dy, tbl, n_out, kv, dweight, partial, ot, st, rep, centre, dy_grp);
+    case 16: return launch_bw<CI, 16>(x, dy, tbl, n_out, kv, dweight, partial, ot, st, rep, centre, dy_grp);
+    case 32: return launch_bw<CI, 32>(x, dy, tbl, n_out, kv, dweight, partial, ot, st, rep, centre, dy_grp);
+    case 64: return launch_bw<CI, 64>(x, dy, tbl, n_out, kv, dweight, partial, ot, st, rep, centre, dy_grp);
   }
   set_error("bwd-weight: unsupported output channel count %d", co);
   return VC_EINVAL;
@@ -2703,8 +2717,27 @@ size_t vc_conv_backward_weight_workspace_bytes(int64_t n_out, int kv, int cin, i
   return (size_t)bw_max_split(kv, cin, cout) * kv * cin * cout * sizeof(float);
 }
 
+static int conv_backward_weight_impl(const float* x, const float* dy, const int32_t* pair_fwd, int64_t n_out, int kv, int cin,
+                                     int cout, int operand_type, float* dweight, void* ws, size_t ws_bytes, void* stream,
+                                     const int32_t* rep, int centre, const float* dy_grp);
+
 int vc_conv_backward_weight(const float* x, const float* dy, const int32_t* pair_fwd, int64_t n_out, int kv, int cin,
                             int cout, int operand_type, float* dweight, void* ws, size_t ws_bytes, void* stream) {
+  return conv_backward_weight_impl(x, dy, pair_fwd, n_out, kv, cin, cout, operand_type, dweight, ws, ws_bytes, stream, nullptr, -1,
+                                   nullptr);
+}
+
+int vc_conv_backward_weight_dup(const float* x, const float* dy, const float* dy_grp, const int32_t* rep, int centre,
+                                const int32_t* pair_fwd, int64_t n_out, int kv, int cin, int cout, int operand_type,
+                                float* dweight, void* ws, size_t ws_bytes, void* stream) {
+  VC_REQUIRE(dy_grp && rep && centre >= 0 && centre < kv, "vc_conv_backward_weight_dup: null/invalid duplicate-pixel arguments");
+  return conv_backward_weight_impl(x, dy, pair_fwd, n_out, kv, cin, cout, operand_type, dweight, ws, ws_bytes, stream, rep, centre,
+                                   dy_grp);
+}
+
+static int conv_backward_weight_impl(const float* x, const float* dy, const int32_t* pair_fwd, int64_t n_out, int kv, int cin,
+                                     int cout, int operand_type, float* dweight, void* ws, size_t ws_bytes, void* stream,
+                                     const int32_t* rep, int centre, const float* dy_grp) {
   VC_REQUIRE(n_out >= 0 && kv >= 1 && dweight && ws, "vc_conv_backward_weight: null/invalid argument");
   VC_REQUIRE(operand_type >= VC_OPERAND_F32 && operand_type <= VC_OPERAND_BF16,
              "vc_conv_backward_weight: unknown operand_type");
@@ -2722,11 +2755,11 @@ int vc_conv_backward_weight(const float* x, const float* dy, const int32_t* pair
   const int tr = trace_open(2, cin, cout, st);   // recorded only by the trace-everything mode (direction -1)
   int rc;
   switch (cin) {
-    case 4: rc = dispatch_bw_co<4>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st); break;
-    case 8: rc = dispatch_bw_co<8>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st); break;
-    case 16: rc = dispatch_bw_co<16>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st); break;
-    case 32: rc = dispatch_bw_co<32>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st); break;
-    case 64: rc = dispatch_bw_co<64>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st); break;
+    case 4: rc = dispatch_bw_co<4>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st, rep, centre, dy_grp); break;
+    case 8: rc = dispatch_bw_co<8>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st, rep, centre, dy_grp); break;
+    case 16: rc = dispatch_bw_co<16>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st, rep, centre, dy_grp); break;
+    case 32: rc = dispatch_bw_co<32>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st, rep, centre, dy_grp); break;
+    case 64: rc = dispatch_bw_co<64>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st, rep, centre, dy_grp); break;
     default:
       set_error("bwd-weight: unsupported input channel count %d", cin);
       rc = VC_EINVAL;

@@ -326,6 +326,10 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
       float* d_raw = at(bump.take((size_t)t.n_out * u.cout * sizeof(float)));
       float* dx = need_dx ? at(bump.take((size_t)t.n_in * u.cin * sizeof(float))) : nullptr;
       float* dgb = (u.dgamma && u.dbeta) ? nullptr : at(bump.take((size_t)2 * u.cout * sizeof(float)));
+      // Duplicate-pixel unit: the group sum feeds the backward-input conv AND the weight gradient (vc_conv_backward_weight_dup).  The
+      // side stream runs its weight gradients in order but LATER than the main chain, so such a unit gets its own group buffer (the
+      // shared one would be overwritten by the next duplicate-pixel unit of the main chain before the side stream has read it).
+      float* grp = !dup ? nullptr : (need_dw ? at(bump.take((size_t)t.n_out * u.cout * sizeof(float))) : at(grp_off));
       // epilogue fusion: this conv delivers the last contribution to the gradient of its source buffer
       bool fold = false;
       GradView addv{nullptr, 0, 0};
@@ -367,21 +371,28 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
                                  o.relu, d_raw, u.dgamma ? u.dgamma : dgb, u.dbeta ? u.dbeta : dgb + u.cout,
                                  nullptr, arena + bn_off, bn_bytes, st);
       if (rc != VC_OK) return rc;
-      if (need_dw && on_side) {  // fork: the weight gradient only reads x (forward arena) and d_raw (never rewritten in this call)
+      if (dup) {
+        rc = vc_group_sum_sorted(d_raw, t.grp_plan, t.n_out, u.cout, grp, arena + gpart_off, gpart_bytes, st);
+        if (rc != VC_OK) return rc;
+      }
+      auto weight_grad = [&](char* ws_, hipStream_t s_) -> int {
+        return dup ? vc_conv_backward_weight_dup(x, d_raw, grp, t.rep, t.centre, t.pair_fwd, t.n_out, t.kv, u.cin, u.cout,
+                                                 p->operand_type, u.dweight, ws_, dw_bytes, s_)
+                   : vc_conv_backward_weight(x, d_raw, t.pair_fwd, t.n_out, t.kv, u.cin, u.cout, p->operand_type, u.dweight, ws_,
+                                             dw_bytes, s_);
+      };
+      if (need_dw && on_side) {  // fork: the weight gradient only reads x (forward arena), d_raw and grp (never rewritten in this call)
         VC_CHECK_HIP(hipEventRecord(ev[0], st));
         VC_CHECK_HIP(hipStreamWaitEvent(side, ev[0], 0));
         forked = true;
-        rc = vc_conv_backward_weight(x, d_raw, t.pair_fwd, t.n_out, t.kv, u.cin, u.cout, p->operand_type, u.dweight,
-                                     arena + dw_off, dw_bytes, side);
+        rc = weight_grad(arena + dw_off, side);
         if (rc != VC_OK) return rc;
       }
       if (need_dx) {
         const float* src = d_raw;
         const float* src_centre = nullptr;
         if (dup) {
-          rc = vc_group_sum_sorted(d_raw, t.grp_plan, t.n_out, u.cout, (float*)(arena + grp_off), arena + gpart_off, gpart_bytes, st);
-          if (rc != VC_OK) return rc;
-          src = (const float*)(arena + grp_off);
+          src = grp;
           src_centre = d_raw;
         }
         const int flags = (t.sorted_rows && t.subm) ? VC_CONV_SORTED_ROWS : 0;
@@ -408,8 +419,7 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
         if (rc != VC_OK) return rc;
       }
       if (need_dw && !on_side) {  // main stream: its own partial-sum scratch (the side stream may still be using the shared one)
-        rc = vc_conv_backward_weight(x, d_raw, t.pair_fwd, t.n_out, t.kv, u.cin, u.cout, p->operand_type, u.dweight,
-                                     arena + dw2_off, dw_bytes, st);
+        rc = weight_grad(arena + dw2_off, st);
         if (rc != VC_OK) return rc;
       }
     } else if (o.kind == VC_PASS_COPY) {

@@ -114,10 +114,19 @@ int vc_post_act_block_backward(const float* x, int64_t n_in, const float* y_raw,
   // then recycle every buffer of this call).  Both kernels are latency-bound at ~50 % of the matrix pipes on their own.
   hipEvent_t* ev = (side_stream && need_dx && need_dw) ? unit_events() : nullptr;
   bool forked = false;
+  if (dup) {  // the group sum feeds the backward-input conv AND the weight gradient (non-centre taps over representatives only)
+    rc = vc_group_sum_sorted(d_raw, grp_plan, n_out, cout, grp, gpart, gpart_bytes, stream);
+    if (rc != VC_OK) return rc;
+  }
+  auto weight_grad = [&](void* s_) -> int {
+    return dup ? vc_conv_backward_weight_dup(x, d_raw, grp, rep, centre, pair_fwd, n_out, kv, cin, cout, operand_type, dw, dw_ws,
+                                             dw_bytes, s_)
+               : vc_conv_backward_weight(x, d_raw, pair_fwd, n_out, kv, cin, cout, operand_type, dw, dw_ws, dw_bytes, s_);
+  };
   if (ev != nullptr) {
     VC_CHECK_HIP(hipEventRecord(ev[0], (hipStream_t)stream));
     VC_CHECK_HIP(hipStreamWaitEvent((hipStream_t)side_stream, ev[0], 0));
-    rc = vc_conv_backward_weight(x, d_raw, pair_fwd, n_out, kv, cin, cout, operand_type, dw, dw_ws, dw_bytes, side_stream);
+    rc = weight_grad(side_stream);
     if (rc != VC_OK) return rc;
     VC_CHECK_HIP(hipEventRecord(ev[1], (hipStream_t)side_stream));
     forked = true;
@@ -126,8 +135,6 @@ int vc_post_act_block_backward(const float* x, int64_t n_in, const float* y_raw,
     const float* src = d_raw;
     const float* src_centre = nullptr;
     if (dup) {
-      rc = vc_group_sum_sorted(d_raw, grp_plan, n_out, cout, grp, gpart, gpart_bytes, stream);
-      if (rc != VC_OK) return rc;
       src = grp;
       src_centre = d_raw;
     }
@@ -138,7 +145,7 @@ int vc_post_act_block_backward(const float* x, int64_t n_in, const float* y_raw,
   if (forked) {
     VC_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, ev[1], 0));
   } else if (need_dw) {
-    rc = vc_conv_backward_weight(x, d_raw, pair_fwd, n_out, kv, cin, cout, operand_type, dw, dw_ws, dw_bytes, stream);
+    rc = weight_grad(stream);
     if (rc != VC_OK) return rc;
   }
   (void)n_in;

@@ -205,6 +205,14 @@ def _conv_backward(rb: "Rulebook", inverse: bool, features, weight, grad_out, ne
     dx = dw = None
     tbl_w = rb.pair_bwd if inverse else rb.pair_fwd
     side = _side_stream(grad_out.device) if (OVERLAP_WEIGHT_GRAD and need_dx and need_dw and grad_out.is_cuda) else None
+    # duplicate-pixel table with a group plan: ONE group sum feeds the backward-input conv and the weight gradient (whose
+    # non-centre offsets then walk the representatives only) -- the same launches as vc_post_act_block_backward
+    dup_kw, grp = {}, None
+    cout = weight.shape[0]
+    if (need_dx and not inverse and rb.kind == "subm" and rb.rep is not None and rb.grp_plan is not None and grad_out.is_cuda
+            and (cout & (cout - 1)) == 0 and hasattr(be, "group_sum_sorted")):
+        grp = be.group_sum_sorted(grad_out, rb.grp_plan)
+        dup_kw = dict(rep=rb.rep, centre=rb.centre, dy_grp=grp)
     if side is not None:
         # buffers are allocated on the main stream and kept referenced until the join below, which orders every later
         # reuse after the side stream's work (no record_stream bookkeeping needed)
@@ -212,7 +220,7 @@ def _conv_backward(rb: "Rulebook", inverse: bool, features, weight, grad_out, ne
         side.wait_stream(main)
         alive = []  # scratch + operands of the side-stream launch stay referenced until the join
         dw = be.conv_backward_weight(features, grad_out, tbl_w, tuple(weight.shape), stream=side.cuda_stream,
-                                     keep_alive=alive, operand=MFMA_OPERAND)
+                                     keep_alive=alive, operand=MFMA_OPERAND, **dup_kw)
     if need_dx:
         if inverse:
             dx = be.conv_backward_input(grad_out, weight, rb.pair_fwd, rb.n_out, mirror=False, order=rb.order_fwd,
@@ -220,7 +228,7 @@ def _conv_backward(rb: "Rulebook", inverse: bool, features, weight, grad_out, ne
         elif rb.kind == "subm":
             dx = be.conv_backward_input(grad_out, weight, rb.pair_fwd, rb.n_in, mirror=True, centre=rb.centre, rep=rb.rep,
                                         order=rb.order_bwd, operand=MFMA_OPERAND, group_ws=group_ws,
-                                        sorted_rows=rb.sorted_rows, grp_plan=rb.grp_plan)
+                                        sorted_rows=rb.sorted_rows, grp_plan=rb.grp_plan, grp=grp)
         else:
             dx = be.conv_backward_input(grad_out, weight, rb.pair_bwd, rb.n_in, mirror=False, order=rb.order_bwd,
                                         operand=MFMA_OPERAND)
@@ -228,7 +236,7 @@ def _conv_backward(rb: "Rulebook", inverse: bool, features, weight, grad_out, ne
         main.wait_stream(side)
         del alive
     elif need_dw:
-        dw = be.conv_backward_weight(features, grad_out, tbl_w, tuple(weight.shape), operand=MFMA_OPERAND)
+        dw = be.conv_backward_weight(features, grad_out, tbl_w, tuple(weight.shape), operand=MFMA_OPERAND, **dup_kw)
     return dx, dw
 
 
