@@ -277,6 +277,16 @@ int vc_from_dense(const float* dense, const int32_t* indices, int64_t n, int c, 
 size_t vc_to_dense_fill_workspace_bytes(int batch_size, int ndim, const int32_t* host_spatial_shape);
 int vc_to_dense_fill(const float* features, const int32_t* indices, int64_t n, int c, int ndim, int batch_size,
                      const int32_t* host_spatial_shape, float* dense, void* ws, size_t ws_bytes, void* stream);
+/* SURVEY §8f rank 3 -- HeightCompression emitting the BEV map in the form the FIRST BEV conv consumes: the first block of
+ * BaseBEVBackbone is ZeroPad2d(1) + Conv2d(k3, padding 0) (base_bev_backbone.py:31-36), i.e. a full copy of the 36 MB-per-frame
+ * map just to add a border.  Here `dense` is (B, C, D, H + 2 pad_h, W + 2 pad_w) and the border is written, once, as zeros by the
+ * same pass that writes the interior; the conv then runs on it with padding 0 and no pad kernel.  vc_from_dense_padded is the
+ * backward gather from such a volume.  Workspace as vc_to_dense_fill (the row-id volume covers the UNPADDED grid).          */
+int vc_to_dense_fill_padded(const float* features, const int32_t* indices, int64_t n, int c, int ndim, int batch_size,
+                            const int32_t* host_spatial_shape, int pad_h, int pad_w, float* dense, void* ws, size_t ws_bytes,
+                            void* stream);
+int vc_from_dense_padded(const float* dense, const int32_t* indices, int64_t n, int c, int ndim, int batch_size,
+                         const int32_t* host_spatial_shape, int pad_h, int pad_w, float* features, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ K1 voxelize + a3 MeanVFE
  * First-touch voxelisation of one frame's points with the mean (+ 'max' on the last channel) fused
@@ -443,10 +453,13 @@ int vc_pass_backward(const vc_pass_program* prog, const void* fwd_arena, size_t 
  * Brackets every launch of ONE gather-GEMM instantiation (direction: 0 forward, 1 backward-input; ck, cn = its gathered /
  * produced channel counts) with HIP events on the launch stream, inside whatever call issues it (vc_conv_*,
  * vc_post_act_block_*, vc_pass_*), and counts the table's active pairs on the device right after it (outside the
- * bracket).  bench.py's roofline figure comes from here.  `dev_pairs`: device int64[max_records], caller-owned.
+ * bracket; the first 16 records of a one-kernel trace (128 with direction -1) count exactly, later ones take the pairs-per-row ratio of the last counted launch of the
+ * same shape -- the count is measurement work inside the timed step).  bench.py's roofline figure comes from here.
+ * `dev_pairs`: device int64[max_records], caller-owned.
  * direction = -1 records EVERY gather-GEMM launch (record.direction 0 / 1) and every weight-gradient launch (2: kernel + its
  * reduce; ck = cin, cn = cout): the family- and step-level roofline figures of bench.py.                                 */
-typedef struct vc_trace_record { float ms; int32_t kv, ck, cn, windowed; int64_t n_src, n_out, pairs; int32_t direction; } vc_trace_record;
+typedef struct vc_trace_record { float ms; int32_t kv, ck, cn, windowed; int64_t n_src, n_out, pairs; int32_t direction;
+                                 float t0_ms /* start of the launch, since the first traced launch */; } vc_trace_record;
 int vc_trace_begin(int direction, int ck, int cn, int max_records, int64_t* dev_pairs);
 int vc_trace_end(vc_trace_record* out, int capacity, int* n_records /* synchronises the traced events */);
 

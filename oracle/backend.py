@@ -118,12 +118,17 @@ class OracleBackend:
         g[keep.long()] = grad_out
         return g
 
-    def to_dense(self, features, indices, spatial_shape, batch_size):
-        return sparse_ref.to_dense(features.detach(), _np(indices), spatial_shape, batch_size)
+    def to_dense(self, features, indices, spatial_shape, batch_size, pad=(0, 0)):
+        d = sparse_ref.to_dense(features.detach(), _np(indices), spatial_shape, batch_size)
+        if pad[0] or pad[1]:    # zero border around the last two axes (what nn.ZeroPad2d adds in front of the first BEV conv)
+            d = torch.nn.functional.pad(d, (pad[1], pad[1], pad[0], pad[0]))
+        return d
 
-    def from_dense(self, dense, indices, spatial_shape, batch_size):
+    def from_dense(self, dense, indices, spatial_shape, batch_size, pad=(0, 0)):
         idx = indices.long()
-        sl = (idx[:, 0], slice(None)) + tuple(idx[:, a + 1] for a in range(idx.shape[1] - 1))
+        nd = idx.shape[1] - 1
+        off = [0] * (nd - 2) + [int(pad[0]), int(pad[1])]
+        sl = (idx[:, 0], slice(None)) + tuple(idx[:, a + 1] + off[a] for a in range(nd))
         return dense[sl].contiguous()
 
     # ------------------------------------------------------------------ RoI grid pooling

@@ -1,0 +1,123 @@
+"""HeightCompression emitting the BEV map with the border of the FIRST BEV conv already written
+(vc_to_dense_fill_padded + adapt_bev_backbone), against the reference recipe
+    HeightCompression.forward (height_compression.py:27-31) -> BaseBEVBackbone block 0 = ZeroPad2d(1) + Conv2d(k3, p0) + BN + ReLU
+    (base_bev_backbone.py:31-38).
+CPU: on the oracle backend, with the reference's UNMODIFIED HeightCompression / BaseBEVBackbone when /root/reference is present.
+GPU: the padded write-once kernel bit-exact against zero-pad of .dense(), its backward gather, and the stem against the CPU oracle."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+import refharness
+from helpers import GRID, MODEL_CFG, fill_parameters, golden_batch, load_golden
+from oracle import sparse_ref
+from virconv_amd import ops
+from virconv_amd.backbone import HeightCompression, VirConvL8x, adapt_bev_backbone
+
+BEV_CFG = dict(LAYER_NUMS=[1, 1], LAYER_STRIDES=[1, 2], NUM_FILTERS=[64, 128], UPSAMPLE_STRIDES=[1, 2], NUM_UPSAMPLE_FILTERS=[128, 128])
+
+
+def _first_block(cin=256, cout=64, seed=3):
+    """Restatement of BaseBEVBackbone's first layers (base_bev_backbone.py:31-38) for boxes without /root/reference."""
+    blk = nn.Sequential(nn.ZeroPad2d(1), nn.Conv2d(cin, cout, 3, stride=1, padding=0, bias=False),
+                        nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01), nn.ReLU())
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        blk[1].weight.copy_(torch.randn(blk[1].weight.shape, generator=g) / np.sqrt(9 * cin))
+        blk[2].weight.copy_(torch.rand(cout, generator=g) + 0.5)
+        blk[2].bias.copy_(torch.randn(cout, generator=g) * 0.1)
+    return blk.eval()
+
+
+def _backbone_out(device):
+    g = load_golden()
+    cfg = dict(MODEL_CFG, LAYER_DISCARD_MODE="spconv2_noop")
+    m = VirConvL8x(cfg, input_channels=8, grid_size=GRID).to(device)
+    fill_parameters(m, 7)
+    m.eval()
+    with torch.no_grad():
+        return m(golden_batch(g, device))
+
+
+def test_padded_dense_on_the_oracle_backend_is_zero_pad_of_dense(oracle_backend):
+    bd = _backbone_out("cpu")
+    t = bd["encoded_spconv_tensor"]
+    a = t.dense(pad=(1, 1))
+    b = torch.nn.functional.pad(t.dense(), (1, 1, 1, 1))
+    assert a.shape[-2:] == (202, 178) and torch.equal(a, b)
+
+
+def test_height_compression_with_bev_pad_feeds_the_adapted_first_block(oracle_backend):
+    bd = _backbone_out("cpu")
+    blk = _first_block()
+    ref = blk(HeightCompression({"NUM_BEV_FEATURES": 256})(dict(bd))["spatial_features"])
+    fused_blk = nn.Sequential(nn.Identity(), *list(blk)[1:])
+    hc = HeightCompression({"NUM_BEV_FEATURES": 256, "BEV_PAD": 1})
+    out = hc(dict(bd))
+    assert out["spatial_features"].shape == (2, 256, 202, 178) and out["spatial_features_pad"] == 1
+    assert torch.equal(fused_blk(out["spatial_features"]), ref)
+
+
+@pytest.mark.skipif(not refharness.available(), reason="reference tree not present (GPU box)")
+def test_adapt_bev_backbone_on_the_reference_modules(oracle_backend):
+    """The reference's UNMODIFIED HeightCompression + BaseBEVBackbone vs HeightCompression(BEV_PAD=1) + adapt_bev_backbone of the
+    same BaseBEVBackbone (same parameters): identical st_features_2d."""
+    refharness.import_reference_backbone()
+    from easydict import EasyDict
+    ref_hc = importlib.import_module("pcdet.models.backbones_2d.map_to_bev.height_compression")
+    ref_bev = importlib.import_module("pcdet.models.backbones_2d.base_bev_backbone")
+    bd = _backbone_out("cpu")
+    torch.manual_seed(4)
+    bev = ref_bev.BaseBEVBackbone(EasyDict(BEV_CFG), input_channels=256).eval()
+    with torch.no_grad():
+        want = bev(ref_hc.HeightCompression(EasyDict(NUM_BEV_FEATURES=256))(dict(bd)))["st_features_2d"].clone()
+        adapt_bev_backbone(bev, pad=1)
+        assert isinstance(bev.blocks[0][0], nn.Identity) and "blocks.0.1.weight" in bev.state_dict()
+        got = bev(HeightCompression({"NUM_BEV_FEATURES": 256, "BEV_PAD": 1})(dict(bd)))["st_features_2d"]
+    assert torch.equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("c,shape,bs,pad", [(64, (4, 200, 176), 2, (1, 1)), (16, (5, 33, 70), 3, (2, 1)), (8, (21, 64, 48), 2, (0, 3))])
+def test_padded_write_once_dense_bit_exact_and_its_backward(hip_backend, c, shape, bs, pad):
+    rng = np.random.default_rng(c)
+    n = 5000
+    idx = np.stack([rng.integers(0, bs, n)] + [rng.integers(0, s, n) for s in shape], 1).astype(np.int32)
+    idx = np.unique(idx, axis=0)
+    idx = idx[rng.permutation(idx.shape[0])]
+    f = rng.standard_normal((idx.shape[0], c)).astype(np.float32)
+    ft = torch.from_numpy(f).cuda().requires_grad_(True)
+    it = torch.from_numpy(idx).cuda()
+    d = ops.to_dense(ft, it, shape, bs, pad=pad)
+    want = torch.nn.functional.pad(sparse_ref.to_dense(torch.from_numpy(f), idx, shape, bs), (pad[1], pad[1], pad[0], pad[0]))
+    assert d.shape == want.shape and torch.equal(d.cpu(), want)
+    g = torch.from_numpy(rng.standard_normal(tuple(want.shape)).astype(np.float32)).cuda()
+    (d * g).sum().backward()
+    gi = g.cpu()[(torch.from_numpy(idx[:, 0]).long(), slice(None)) + tuple(
+        torch.from_numpy(idx[:, a + 1]).long() + ([0] * (len(shape) - 2) + list(pad))[a] for a in range(len(shape)))]
+    assert torch.equal(ft.grad.cpu(), gi)
+
+
+@pytest.mark.gpu
+def test_bev_stem_on_hip_equals_the_oracle_recipe(hip_backend):
+    """backbone (HIP) -> HeightCompression(BEV_PAD=1) -> first BEV block without its pad module, against
+    backbone (oracle, CPU) -> reference recipe (dense, ZeroPad2d, conv, BN, ReLU) on the CPU: 1e-4."""
+    from oracle.backend import OracleBackend
+    with ops.use_backend(OracleBackend()):
+        bd_o = _backbone_out("cpu")
+        blk = _first_block()
+        want = blk(HeightCompression({"NUM_BEV_FEATURES": 256})(dict(bd_o))["spatial_features"]).numpy()
+    bd_h = _backbone_out("cuda")
+    blk_h = _first_block().cuda()
+    with torch.no_grad():
+        plain = blk_h(HeightCompression({"NUM_BEV_FEATURES": 256})(dict(bd_h))["spatial_features"])
+        fused = nn.Sequential(nn.Identity(), *list(blk_h)[1:])(
+            HeightCompression({"NUM_BEV_FEATURES": 256, "BEV_PAD": 1})(dict(bd_h))["spatial_features"])
+    assert torch.equal(fused, plain)          # same conv on the same padded map: the border costs nothing in accuracy
+    got = fused.cpu().numpy()
+    err = np.abs(got - want)
+    assert np.all(err <= 1e-4 * np.abs(want) + 1e-5 * max(1.0, np.abs(want).max())), float(err.max())

@@ -81,6 +81,9 @@ def main():
         assert be.lib.vc_debug_set(b"conv_dxs", args.dxs) == 0
     torch.zeros(1, device=dev)
     assert be.lib.vc_debug_set(b"xcd_swizzle_off", 1 if args.no_xcd else 0) == 0
+    for kv_ in filter(None, os.environ.get("VIRCONV_DEBUG_SET", "").split(",")):   # "key=value,..." -> vc_debug_set
+        key, val = kv_.split("=")
+        assert be.lib.vc_debug_set(key.encode(), int(val)) == 0, kv_
     batch = bench.make_batch(list(range(args.bs)), dev, training=True)
     idx = batch["voxel_coords"].int()
     shape = [int(v) for v in (np.asarray(synth.GRID_SIZE)[::-1] + [1, 0, 0])]

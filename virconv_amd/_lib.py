@@ -76,6 +76,8 @@ SIGNATURES = {
     "vc_from_dense": (_I, [_P, _P, _I64, _I, _I, _I, _P, _P, _P]),
     "vc_to_dense_fill_workspace_bytes": (_SZ, [_I, _I, _P]),
     "vc_to_dense_fill": (_I, [_P, _P, _I64, _I, _I, _I, _P, _P, _P, _SZ, _P]),
+    "vc_to_dense_fill_padded": (_I, [_P, _P, _I64, _I, _I, _I, _P, _I, _I, _P, _P, _SZ, _P]),
+    "vc_from_dense_padded": (_I, [_P, _P, _I64, _I, _I, _I, _P, _I, _I, _P, _P]),
     "vc_voxelize_workspace_bytes": (_SZ, [_I64, _I]),
     "vc_voxelize_mean": (_I, [_P, _I64, _I, _P, _P, _I, _I, _I, _P, _SZ, _P, _P, _P, _P, _P]),
     "vc_voxelize": (_I, [_P, _I64, _I, _P, _P, _I, _I, _P, _SZ, _P, _P, _P, _P, _P]),
@@ -143,7 +145,7 @@ class PassProgram(C.Structure):
 
 class TraceRecord(C.Structure):
     _fields_ = [("ms", _F), ("kv", C.c_int32), ("ck", C.c_int32), ("cn", C.c_int32), ("windowed", C.c_int32),
-                ("n_src", _I64), ("n_out", _I64), ("pairs", _I64), ("direction", C.c_int32)]
+                ("n_src", _I64), ("n_out", _I64), ("pairs", _I64), ("direction", C.c_int32), ("t0_ms", _F)]
 
 
 _lib = None

@@ -778,19 +778,38 @@ class VirConv8x(nn.Module):
 
 
 class HeightCompression(nn.Module):
-    """First consumer of the path's output (pcdet/models/backbones_2d/map_to_bev/height_compression.py:27-31)."""
+    """First consumer of the path's output (pcdet/models/backbones_2d/map_to_bev/height_compression.py:27-31).
+
+    SURVEY 8f rank 3: with ``BEV_PAD: 1`` in the config the BEV map is emitted WITH the zero border the first BEV conv needs --
+    (B, C*D, H + 2, W + 2), border and interior written once by the same kernel (vc_to_dense_fill_padded) -- so that the
+    ``nn.ZeroPad2d(1)`` in front of ``Conv2d(k3, padding=0)`` (base_bev_backbone.py:31-36), a full copy of the 36 MB-per-frame
+    map, disappears: ``adapt_bev_backbone`` drops that pad module from a BaseBEVBackbone.  Default (0): the reference's layout."""
 
     def __init__(self, model_cfg=None, **kwargs):
         super().__init__()
         self.model_cfg = model_cfg
         self.num_bev_features = _cfg_get(model_cfg, "NUM_BEV_FEATURES", 256) if model_cfg is not None else 256
+        self.bev_pad = int(_cfg_get(model_cfg, "BEV_PAD", 0)) if model_cfg is not None else 0
 
     def forward(self, batch_dict):
         batch_dict["spatial_features_stride"] = batch_dict["encoded_spconv_tensor_stride"]
-        sp = batch_dict["encoded_spconv_tensor"].dense()
+        t = batch_dict["encoded_spconv_tensor"]
+        sp = t.dense(pad=(self.bev_pad, self.bev_pad)) if self.bev_pad else t.dense()
         n, c, d, h, w = sp.shape
         batch_dict["spatial_features"] = sp.view(n, c * d, h, w)
+        batch_dict["spatial_features_pad"] = self.bev_pad
         return batch_dict
+
+
+def adapt_bev_backbone(bev_backbone: nn.Module, pad: int = 1) -> nn.Module:
+    """Make a BaseBEVBackbone (pcdet/models/backbones_2d/base_bev_backbone.py:27-43) consume the pre-padded BEV map of
+    ``HeightCompression(BEV_PAD=pad)``: its first block begins with ``nn.ZeroPad2d(1)`` followed by ``Conv2d(k3, padding=0)``;
+    the pad module is replaced by an identity (state_dict keys are unchanged: ZeroPad2d has no parameters, indices stay)."""
+    first = bev_backbone.blocks[0]
+    assert isinstance(first[0], nn.ZeroPad2d) and tuple(first[0].padding) == (pad,) * 4, "first BEV block does not start with ZeroPad2d"
+    assert isinstance(first[1], nn.Conv2d) and first[1].padding == (0, 0) and first[1].kernel_size == (2 * pad + 1,) * 2
+    first[0] = nn.Identity()
+    return bev_backbone
 
 
 __all__ = {"VirConvL8x": VirConvL8x, "VirConv8x": VirConv8x}

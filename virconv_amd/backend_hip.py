@@ -106,7 +106,8 @@ class HipBackend:
             out.append({"ms": r.ms, "flops": 2.0 * r.pairs * r.ck * r.cn,
                         "bytes": 4.0 * (r.n_src * r.ck + r.n_out * r.cn + r.kv * r.ck * r.cn) + 4.0 * r.kv * r.n_out,
                         "pairs": int(r.pairs), "n_out": int(r.n_out), "windowed": bool(r.windowed),
-                        "dir": ("fwd", "bwd", "dw")[r.direction], "ck": int(r.ck), "cn": int(r.cn), "kv": int(r.kv)})
+                        "dir": ("fwd", "bwd", "dw")[r.direction], "ck": int(r.ck), "cn": int(r.cn), "kv": int(r.kv),
+                        "t0_ms": float(r.t0_ms)})
         return out
 
     def _read_count(self, dev_scalar: torch.Tensor) -> int:
@@ -498,13 +499,23 @@ class HipBackend:
               "vc_scatter_rows")
         return gi
 
-    def to_dense(self, features: torch.Tensor, indices: torch.Tensor, spatial_shape, batch_size: int) -> torch.Tensor:
+    def to_dense(self, features: torch.Tensor, indices: torch.Tensor, spatial_shape, batch_size: int, pad=(0, 0)) -> torch.Tensor:
+        """`pad` = (pad_h, pad_w): zero border around the last two axes, written by the same pass (vc_to_dense_fill_padded)."""
         features = _need(features, torch.float32, "features")
         indices = _need(indices, torch.int32, "indices")
         n, c = features.shape
         ndim = indices.shape[1] - 1
         shp = i32arr(spatial_shape)
         ws_bytes = self.lib.vc_to_dense_fill_workspace_bytes(batch_size, ndim, shp)
+        if pad[0] or pad[1]:
+            assert c <= 128, "padded dense: channel count too large for the write-once kernel"
+            out_shape = tuple(int(v) for v in spatial_shape[:-2]) + (int(spatial_shape[-2]) + 2 * pad[0], int(spatial_shape[-1]) + 2 * pad[1])
+            dense = torch.empty((batch_size, c) + out_shape, dtype=torch.float32, device=features.device)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=features.device)
+            check(self.lib.vc_to_dense_fill_padded(_ptr(features), _ptr(indices), n, c, ndim, batch_size, shp, int(pad[0]),
+                                                   int(pad[1]), _ptr(dense), _ptr(ws), ws_bytes, _stream()),
+                  "vc_to_dense_fill_padded")
+            return dense
         if DENSE_WRITE_ONCE and ws_bytes <= (1 << 30) and c <= 128:
             # write-once fill (vc_to_dense_fill): no zero-fill of the (B, C, *spatial) output, one coalesced pass
             dense = torch.empty((batch_size, c) + tuple(int(s) for s in spatial_shape), dtype=torch.float32,
@@ -519,14 +530,14 @@ class HipBackend:
               "vc_to_dense")
         return dense
 
-    def from_dense(self, dense: torch.Tensor, indices: torch.Tensor, spatial_shape, batch_size: int) -> torch.Tensor:
+    def from_dense(self, dense: torch.Tensor, indices: torch.Tensor, spatial_shape, batch_size: int, pad=(0, 0)) -> torch.Tensor:
         dense = _need(dense, torch.float32, "dense")
         indices = _need(indices, torch.int32, "indices")
         n, c = indices.shape[0], dense.shape[1]
         ndim = indices.shape[1] - 1
         f = torch.empty((n, c), dtype=torch.float32, device=dense.device)
-        check(self.lib.vc_from_dense(_ptr(dense), _ptr(indices), n, c, ndim, batch_size, i32arr(spatial_shape), _ptr(f),
-                                     _stream()), "vc_from_dense")
+        check(self.lib.vc_from_dense_padded(_ptr(dense), _ptr(indices), n, c, ndim, batch_size, i32arr(spatial_shape),
+                                            int(pad[0]), int(pad[1]), _ptr(f), _stream()), "vc_from_dense_padded")
         return f
 
     # ------------------------------------------------------------------ voxelise + MeanVFE

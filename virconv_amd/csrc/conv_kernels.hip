@@ -2070,6 +2070,7 @@ struct TraceState {
   vc_trace_record* rec = nullptr;
 };
 static TraceState g_trace;
+static int g_trace_counted = 16;   // records of a trace whose pairs are counted exactly (set per trace in vc_trace_begin)
 static bool g_last_windowed = false;  // set by launch_gg: the launch just issued was the LDS row-window kernel
 
 // -> record slot (its start event is on the stream) or -1
@@ -2085,12 +2086,19 @@ static inline void trace_close(int i, int dir, int ck, int cn, const int32_t* tb
                                hipStream_t st) {
   TraceState& T = g_trace;
   if (hipEventRecord(T.ev[2 * i + 1], st) != hipSuccess) return;
-  T.rec[i] = vc_trace_record{0.f, kv, ck, cn, (dir != 2 && g_last_windowed) ? 1 : 0, n_src, n_out, 0, dir};
-  int64_t nb = cdiv((int64_t)kv * n_out, 256 * 16);
-  if (nb > 2048) nb = 2048;
-  if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(count_pairs_kernel, dim3((unsigned)nb), dim3(256), 0, st, tbl, (int64_t)kv * n_out, T.dev_pairs + i);
-  (void)hipGetLastError();
+  T.rec[i] = vc_trace_record{0.f, kv, ck, cn, (dir != 2 && g_last_windowed) ? 1 : 0, n_src, n_out, 0, dir, 0.f};
+  // The pair count walks the whole table (40 us for 21 MB): it is measurement work INSIDE the timed step, so only the first
+  // g_trace_counted (16 for a one-kernel trace, 128 for direction -1) records of a trace count exactly; later ones take the pairs-per-row ratio of the last counted record of the same
+  // kernel shape (layer discard draws a new permutation per step: the ratio moves by < 1 %).  pairs = -1 marks "to be estimated".
+  if (i < g_trace_counted) {
+    int64_t nb = cdiv((int64_t)kv * n_out, 256 * 16);
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(count_pairs_kernel, dim3((unsigned)nb), dim3(256), 0, st, tbl, (int64_t)kv * n_out, T.dev_pairs + i);
+    (void)hipGetLastError();
+  } else {
+    T.rec[i].pairs = -1;
+  }
   T.n = i + 1;
 }
 
@@ -2560,6 +2568,7 @@ int vc_trace_begin(int direction, int ck, int cn, int max_records, int64_t* dev_
   VC_CHECK_HIP(hipDeviceSynchronize());
   VC_CHECK_HIP(hipMemset(dev_pairs, 0, sizeof(int64_t) * (size_t)max_records));
   T.dir = direction; T.ck = ck; T.cn = cn; T.cap = max_records; T.n = 0; T.dev_pairs = dev_pairs;
+  g_trace_counted = (direction == -1) ? 128 : 16;
   T.on = true;
   return VC_OK;
 }
@@ -2577,7 +2586,21 @@ int vc_trace_end(vc_trace_record* out, int capacity, int* n_records) {
     VC_CHECK_HIP(hipEventElapsedTime(&ms, T.ev[2 * i], T.ev[2 * i + 1]));
     out[i] = T.rec[i];
     out[i].ms = ms;
-    VC_CHECK_HIP(hipMemcpy(&out[i].pairs, T.dev_pairs + i, sizeof(int64_t), hipMemcpyDeviceToHost));
+    float t0 = 0.f;
+    if (i > 0) VC_CHECK_HIP(hipEventElapsedTime(&t0, T.ev[0], T.ev[2 * i]));   // start of this launch since the first traced one
+    out[i].t0_ms = t0;
+    if (T.rec[i].pairs >= 0) {
+      VC_CHECK_HIP(hipMemcpy(&out[i].pairs, T.dev_pairs + i, sizeof(int64_t), hipMemcpyDeviceToHost));
+    } else {   // estimated: ratio of the last counted record with the same shape
+      double ratio = 0.0;
+      for (int j = i - 1; j >= 0; --j)
+        if (T.rec[j].pairs >= 0 && out[j].kv == out[i].kv && out[j].ck == out[i].ck && out[j].cn == out[i].cn &&
+            out[j].direction == out[i].direction && out[j].n_out > 0) {
+          ratio = (double)out[j].pairs / (double)out[j].n_out;
+          break;
+        }
+      out[i].pairs = (int64_t)(ratio * (double)out[i].n_out + 0.5);
+    }
   }
   *n_records = n;
   return VC_OK;

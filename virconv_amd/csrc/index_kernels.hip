@@ -498,7 +498,10 @@ __global__ void __launch_bounds__(256) random_keep_kernel(int64_t n, int64_t n_k
 template <bool TO_DENSE>
 __global__ void __launch_bounds__(256) dense_kernel(float* __restrict__ feat, const int32_t* __restrict__ indices,
                                                     int64_t n, int c, int ndim, int D, int H, int W,
-                                                    float* __restrict__ dense) {
+                                                    float* __restrict__ dense, int ph = 0, int pw = 0) {
+  // ph / pw: the dense volume carries a border of ph rows / pw columns around every (H, W) plane (vc_to_dense_fill_padded)
+  H += 2 * ph;
+  W += 2 * pw;
   extern __shared__ float d_tile[];                       // [64][c + 1] floats, then 64 int64 base offsets
   const int ld = c + 1;
   int64_t* s_base = reinterpret_cast<int64_t*>(d_tile + 64 * ld + ((64 * ld) & 1));
@@ -508,7 +511,7 @@ __global__ void __launch_bounds__(256) dense_kernel(float* __restrict__ feat, co
   if (threadIdx.x < rows) {
     int b, z, y, x;
     load_coord(indices, row0 + threadIdx.x, ndim, b, z, y, x);
-    s_base[threadIdx.x] = (((int64_t)b * c * D + z) * H + y) * W + x;   // offset of channel 0
+    s_base[threadIdx.x] = (((int64_t)b * c * D + z) * H + y + ph) * W + x + pw;   // offset of channel 0
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (TO_DENSE) {
@@ -548,27 +551,35 @@ __global__ void __launch_bounds__(256) dense_rowid_kernel(const int32_t* __restr
 
 __global__ void __launch_bounds__(256) dense_fill_kernel(const float* __restrict__ feat, const int32_t* __restrict__ rowid,
                                                          int c, int D, int H, int W, int tiles_per_line,
-                                                         float* __restrict__ dense) {
+                                                         float* __restrict__ dense, int ph, int pw) {
+  // Output planes are (H + 2 ph) x (W + 2 pw): the border of the FIRST BEV conv (ZeroPad2d(1) in front of Conv2d(k3, p0),
+  // base_bev_backbone.py:31-36) is written here, once, as zeros -- the 36 MB-per-frame pad copy in front of that conv disappears.
+  // A block = one padded line (b, z, yp) x one 64-wide tile of padded columns.
   extern __shared__ float f_tile[];                 // [64][c + 1]
   __shared__ int s_rid[64];
   __shared__ int s_any;
   const int ld = c + 1;
+  const int Hp = H + 2 * ph, Wp = W + 2 * pw;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t line = blockIdx.x / tiles_per_line;  // (b*D + z)*H + y
-  const int x0 = (int)(blockIdx.x - line * tiles_per_line) * 64;
-  const int cells = min(64, W - x0);
+  const int64_t line = blockIdx.x / tiles_per_line;  // (b*D + z)*Hp + yp
+  const int x0 = (int)(blockIdx.x - line * tiles_per_line) * 64;   // padded column of the tile's first cell
+  const int cells = min(64, Wp - x0);
+  const int yp = (int)(line % Hp);
+  const int64_t bz = line / Hp;                      // b*D + z
+  const int y = yp - ph;
   if (threadIdx.x == 0) s_any = 0;
   __syncthreads();
   if (threadIdx.x < 64) {
-    const int rid = (threadIdx.x < cells) ? rowid[line * W + x0 + threadIdx.x] : 0;
+    const int x = x0 + (int)threadIdx.x - pw;
+    const bool inside = threadIdx.x < cells && y >= 0 && y < H && x >= 0 && x < W;
+    const int rid = inside ? rowid[(bz * H + y) * W + x] : 0;
     s_rid[threadIdx.x] = rid;
     if (rid != 0) s_any = 1;
   }
   __syncthreads();
-  const int64_t zy = line % ((int64_t)D * H);        // z*H + y
-  const int64_t b = line / ((int64_t)D * H);
-  const int64_t plane = (int64_t)D * H * W;
-  float* out = dense + (b * c * D) * (int64_t)H * W + zy * W + x0;   // channel 0 of this tile; channel ch at + ch * plane
+  const int64_t b = bz / D, z = bz - b * D;
+  const int64_t plane = (int64_t)D * Hp * Wp;
+  float* out = dense + (b * c * D + z) * (int64_t)Hp * Wp + (int64_t)yp * Wp + x0;   // channel 0 of this tile; channel ch at + ch * plane
   if (s_any == 0) {  // most tiles: nothing active
     if (lane < cells)
       for (int ch = wave; ch < c; ch += 4) out[ch * plane + lane] = 0.f;
@@ -1217,13 +1228,19 @@ size_t vc_to_dense_fill_workspace_bytes(int batch_size, int ndim, const int32_t*
 
 int vc_to_dense_fill(const float* features, const int32_t* indices, int64_t n, int c, int ndim, int batch_size,
                      const int32_t* shape, float* dense, void* ws, size_t ws_bytes, void* stream) {
+  return vc_to_dense_fill_padded(features, indices, n, c, ndim, batch_size, shape, 0, 0, dense, ws, ws_bytes, stream);
+}
+
+int vc_to_dense_fill_padded(const float* features, const int32_t* indices, int64_t n, int c, int ndim, int batch_size,
+                            const int32_t* shape, int pad_h, int pad_w, float* dense, void* ws, size_t ws_bytes, void* stream) {
   VC_REQUIRE((ndim == 2 || ndim == 3) && shape && c > 0 && batch_size >= 1 && dense && ws, "vc_to_dense_fill: invalid argument");
+  VC_REQUIRE(pad_h >= 0 && pad_w >= 0 && pad_h <= 64 && pad_w <= 64, "vc_to_dense_fill_padded: invalid padding");
   VC_REQUIRE(n == 0 || (features && indices), "vc_to_dense_fill: null argument");
   if (ws_bytes < vc_to_dense_fill_workspace_bytes(batch_size, ndim, shape)) { set_error("vc_to_dense_fill: workspace too small"); return VC_ECAPACITY; }
   Dims d = make_dims(ndim, shape);
   hipStream_t st = (hipStream_t)stream;
-  const int64_t lines = (int64_t)batch_size * d.D * d.H;
-  const int tiles = (int)cdiv(d.W, 64);
+  const int64_t lines = (int64_t)batch_size * d.D * (d.H + 2 * pad_h);
+  const int tiles = (int)cdiv(d.W + 2 * pad_w, 64);
   VC_REQUIRE(lines * tiles < (1LL << 31) && n < (1LL << 31) - 1, "vc_to_dense_fill: tensor too large");
   const size_t lds = (size_t)64 * (c + 1) * sizeof(float);
   VC_REQUIRE(lds <= 60 * 1024, "vc_to_dense_fill: channel count %d too large", c);
@@ -1234,21 +1251,27 @@ int vc_to_dense_fill(const float* features, const int32_t* indices, int64_t n, i
     VC_CHECK_LAUNCH("dense_rowid_kernel");
   }
   hipLaunchKernelGGL(dense_fill_kernel, dim3((unsigned)(lines * tiles)), dim3(256), lds, st, features, rowid, c, d.D, d.H, d.W,
-                     tiles, dense);
+                     tiles, dense, pad_h, pad_w);
   VC_CHECK_LAUNCH("dense_fill_kernel");
   return VC_OK;
 }
 
 int vc_from_dense(const float* dense, const int32_t* indices, int64_t n, int c, int ndim, int batch_size,
                   const int32_t* shape, float* features, void* stream) {
+  return vc_from_dense_padded(dense, indices, n, c, ndim, batch_size, shape, 0, 0, features, stream);
+}
+
+int vc_from_dense_padded(const float* dense, const int32_t* indices, int64_t n, int c, int ndim, int batch_size,
+                         const int32_t* shape, int pad_h, int pad_w, float* features, void* stream) {
   VC_REQUIRE((ndim == 2 || ndim == 3) && shape && c > 0 && batch_size >= 1, "vc_from_dense: invalid argument");
+  VC_REQUIRE(pad_h >= 0 && pad_w >= 0, "vc_from_dense_padded: invalid padding");
   if (n == 0) return VC_OK;
   VC_REQUIRE(features && indices && dense, "vc_from_dense: null argument");
   Dims d = make_dims(ndim, shape);
   const size_t lds = (size_t)64 * (c + 1) * sizeof(float) + 64 * sizeof(int64_t) + 8;
   VC_REQUIRE(lds <= 64 * 1024, "vc_from_dense: channel count %d too large", c);
   hipLaunchKernelGGL(dense_kernel<false>, dim3((unsigned)cdiv(n, 64)), dim3(256), lds, (hipStream_t)stream, features,
-                     indices, n, c, ndim, d.D, d.H, d.W, const_cast<float*>(dense));
+                     indices, n, c, ndim, d.D, d.H, d.W, const_cast<float*>(dense), pad_h, pad_w);
   VC_CHECK_LAUNCH("dense_kernel<from>");
   return VC_OK;
 }

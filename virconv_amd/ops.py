@@ -352,8 +352,10 @@ FUSED_UNIT_CALLS = os.environ.get("VIRCONV_FUSED_UNIT_CALLS", "1") != "0"
 # vc_row_order permutations computed with the rulebooks (tile-homogeneity hint for the gather-GEMM; results identical).
 #   "bwd"  (default) strided convs' backward-input tables only: their active sets are parity classes, sorting cuts the
 #          issued work 2.3x (measured: s3.down bwd 197 -> 85 us) and a 1024-row window is enough
-#   "strided" (default since round 3) the strided convs' forward AND backward-input tables: the sorts run on the geometry-plan
-#          stream underneath the previous step's backward
+#   "strided" the strided convs' forward AND backward-input tables.  Round 3 made the sort of a many-mask table 20x cheaper
+#          (1.4-2.8 ms -> 65-100 us: the mask-set overflow exits at once) and measured it: stand-alone the strided forwards gain
+#          (s2/s3/s4.down 70/171/163 -> 51/140/147 us), inside the step the three extra sorts on the plan stream cost more GPU
+#          time than the 65 us they save on the main stream: 5.66 vs 5.49 ms per step, same box (profiles/r03_bench_lines.txt)
 #   "all"  every table (measured: strided forward -25 %, SubM +-0 -- the sort costs more than it saves there)
 #   "none" natural order everywhere
 # MFMA operand type of the conv kernels: "f32" (exact, default, the parity path) | "f16" | "bf16" (BASELINE configs[4]:
@@ -364,7 +366,7 @@ MFMA_OPERAND = os.environ.get("VIRCONV_MFMA_OPERAND", "f32")
 # LDS, LDS costs resident waves, and these kernels' throughput follows their occupancy -- profiles/r02_kbench_variants.txt,
 # r02_pmc_conv_variants.md).  Off by default; "1" turns it on (tools/kbench.py measures both).
 WINDOW_GATHER = os.environ.get("VIRCONV_WINDOW_GATHER", "0") != "0"
-ROW_ORDER = os.environ.get("VIRCONV_ROW_ORDER", "strided")
+ROW_ORDER = os.environ.get("VIRCONV_ROW_ORDER", "bwd")
 # duplicate-pixel (2-D) SubM tables: backward-input in representative-first row order (vc_rep_order).  Measured: no gain (2-D
 # backward-input 316 vs 303 us per pass, train step 6.21 vs 6.17 ms) -- those launches are dominated by the group-sum machinery
 # and the gathers, not by padded MFMAs.  Off by default.
@@ -440,26 +442,30 @@ def discard_rows(features: torch.Tensor, indices: torch.Tensor, keep: torch.Tens
 
 class ToDenseFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, features, indices, spatial_shape, batch_size):
-        ctx.meta = (tuple(spatial_shape), int(batch_size))
+    def forward(ctx, features, indices, spatial_shape, batch_size, pad=(0, 0)):
+        ctx.meta = (tuple(spatial_shape), int(batch_size), (int(pad[0]), int(pad[1])))
         ctx.save_for_backward(indices)
+        if pad[0] or pad[1]:
+            return get_backend().to_dense(features, indices, spatial_shape, batch_size, pad=ctx.meta[2])
         return get_backend().to_dense(features, indices, spatial_shape, batch_size)
 
     @staticmethod
     def backward(ctx, grad_dense):
         (indices,) = ctx.saved_tensors
-        shape, bs = ctx.meta
+        shape, bs, pad = ctx.meta
+        kw = {"pad": pad} if (pad[0] or pad[1]) else {}
         if grad_dense.dim() >= 3 and grad_dense.shape[0] > 1 and grad_dense.stride(0) == 0:
             # a gradient that is the same for every sample (broadcast along the batch axis): gather from ONE sample's planes
             # instead of materialising batch_size copies of them
             idx0 = indices.clone()
             idx0[:, 0] = 0
-            return get_backend().from_dense(grad_dense[:1].contiguous(), idx0, shape, 1), None, None, None
-        return get_backend().from_dense(grad_dense.contiguous(), indices, shape, bs), None, None, None
+            return get_backend().from_dense(grad_dense[:1].contiguous(), idx0, shape, 1, **kw), None, None, None, None
+        return get_backend().from_dense(grad_dense.contiguous(), indices, shape, bs, **kw), None, None, None, None
 
 
-def to_dense(features, indices, spatial_shape, batch_size):
-    return ToDenseFunction.apply(features, indices, tuple(int(s) for s in spatial_shape), batch_size)
+def to_dense(features, indices, spatial_shape, batch_size, pad=(0, 0)):
+    """(B, C, *spatial) scatter; `pad` = (pad_h, pad_w) adds a zero border around the last two axes in the same pass."""
+    return ToDenseFunction.apply(features, indices, tuple(int(s) for s in spatial_shape), batch_size, (int(pad[0]), int(pad[1])))
 
 
 class BNReLUFunction(torch.autograd.Function):

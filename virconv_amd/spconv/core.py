@@ -59,9 +59,10 @@ class SparseConvTensor:
             return None
         return self.indice_dict.get(key)
 
-    def dense(self, channels_first: bool = True) -> torch.Tensor:
-        """(B, C, *spatial) scatter of the active rows."""
-        d = ops.to_dense(self.features, self.indices, self.spatial_shape, self.batch_size)
+    def dense(self, channels_first: bool = True, pad=(0, 0)) -> torch.Tensor:
+        """(B, C, *spatial) scatter of the active rows.  `pad` (an extension, default off): zero border of
+        (pad_h, pad_w) cells around the last two axes, written by the same pass (the ZeroPad2d of the first BEV conv)."""
+        d = ops.to_dense(self.features, self.indices, self.spatial_shape, self.batch_size, pad)
         if channels_first:
             return d
         nd = len(self.spatial_shape)
