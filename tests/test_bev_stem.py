@@ -107,7 +107,7 @@ def test_bev_stem_on_hip_equals_the_oracle_recipe(hip_backend):
     """backbone (HIP) -> HeightCompression(BEV_PAD=1) -> first BEV block without its pad module, against
     backbone (oracle, CPU) -> reference recipe (dense, ZeroPad2d, conv, BN, ReLU) on the CPU: 1e-4."""
     from oracle.backend import OracleBackend
-    with ops.use_backend(OracleBackend()):
+    with ops.use_backend(OracleBackend()), torch.no_grad():
         bd_o = _backbone_out("cpu")
         blk = _first_block()
         want = blk(HeightCompression({"NUM_BEV_FEATURES": 256})(dict(bd_o))["spatial_features"]).numpy()

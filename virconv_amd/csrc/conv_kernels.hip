@@ -2591,13 +2591,18 @@ int vc_trace_end(vc_trace_record* out, int capacity, int* n_records) {
     out[i].t0_ms = t0;
     if (T.rec[i].pairs >= 0) {
       VC_CHECK_HIP(hipMemcpy(&out[i].pairs, T.dev_pairs + i, sizeof(int64_t), hipMemcpyDeviceToHost));
-    } else {   // estimated: ratio of the last counted record with the same shape
+    } else {   // estimated: pairs-per-row ratio of the counted record of the same kernel shape whose table is closest in size
+      // (the same layer of an earlier step: two layers can share a shape, e.g. s3.d3_conv1 and s4.d3_conv1 are both 64 -> 32)
       double ratio = 0.0;
-      for (int j = i - 1; j >= 0; --j)
+      int64_t best = -1;
+      for (int j = 0; j < i; ++j)
         if (T.rec[j].pairs >= 0 && out[j].kv == out[i].kv && out[j].ck == out[i].ck && out[j].cn == out[i].cn &&
             out[j].direction == out[i].direction && out[j].n_out > 0) {
-          ratio = (double)out[j].pairs / (double)out[j].n_out;
-          break;
+          const int64_t d = out[j].n_out > out[i].n_out ? out[j].n_out - out[i].n_out : out[i].n_out - out[j].n_out;
+          if (best < 0 || d < best) {
+            best = d;
+            ratio = (double)out[j].pairs / (double)out[j].n_out;
+          }
         }
       out[i].pairs = (int64_t)(ratio * (double)out[i].n_out + 0.5);
     }

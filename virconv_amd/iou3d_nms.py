@@ -64,9 +64,14 @@ def boxes_bev_iou_cpu(boxes_a, boxes_b):
     return out.numpy() if is_numpy else out
 
 
+_NMS_MAX = 65536
+
+
 def nms_sorted(boxes: torch.Tensor, thresh: float, rotated: bool = True):
     """NMS over boxes already sorted by descending score -> (keep positions (n) int64 on the device, count () int64 on the
-    device).  No host synchronisation."""
+    device).  No host synchronisation.  Limit: n <= 65536 boxes (vc_nms; the suppression-word workspace is n^2 / 8 bytes, 512 MB
+    at the cap) -- the reference's nms_gpu has no such limit but is used with NMS_PRE_MAXSIZE 4096-9000 (VirConv-L.yaml); more
+    boxes are handled by `nms_gpu` below by keeping the 65536 best-scored ones first (what pre_maxsize does)."""
     boxes = _need(boxes, torch.float32, "boxes")
     n = boxes.shape[0]
     keep = torch.empty((n,), dtype=torch.int64, device=boxes.device)
@@ -84,12 +89,13 @@ def nms_gpu(boxes: torch.Tensor, scores: torch.Tensor, thresh: float, pre_maxsiz
     order = scores.sort(0, descending=True)[1]
     if pre_maxsize is not None:
         order = order[:pre_maxsize]
+    order = order[:_NMS_MAX]          # vc_nms cap (see nms_sorted)
     keep, num = nms_sorted(boxes[order].contiguous(), thresh, rotated=True)
     return order[keep[:int(num)]].contiguous(), None
 
 
 def nms_normal_gpu(boxes: torch.Tensor, scores: torch.Tensor, thresh: float, **kwargs):
     assert boxes.shape[1] == 7
-    order = scores.sort(0, descending=True)[1]
+    order = scores.sort(0, descending=True)[1][:_NMS_MAX]
     keep, num = nms_sorted(boxes[order].contiguous(), thresh, rotated=False)
     return order[keep[:int(num)]].contiguous(), None

@@ -126,14 +126,26 @@ class FlatGradAllReduce:
             return
         # every rank packs EVERY parameter (zeros where this rank produced no gradient -- an empty stream, a skipped
         # block): the flat buffer has the same layout on all ranks, like DDP's buckets
+        if not self.params:
+            return
+        had = [p.grad is not None for p in self.params]
         for p in self.params:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
         grads = [p.grad for p in self.params]
-        if not grads:
-            return
-        flat = torch.cat([g.reshape(-1) for g in grads])
+        # one "this rank produced a gradient" flag per parameter rides at the end of the flat buffer: a parameter that is None on
+        # EVERY rank goes back to None afterwards, so the optimizer skips it exactly as under DistributedDataParallel / on one GPU
+        # (weight decay and Adam state would otherwise advance on zeros -- ADVICE r2)
+        if all(had):     # the usual case: a cached all-ones flag vector (no host-to-device copy per step)
+            if getattr(self, "_ones", None) is None or self._ones.device != grads[0].device:
+                self._ones = torch.ones((len(self.params),), dtype=grads[0].dtype, device=grads[0].device)
+            flags = self._ones
+        else:
+            flags = torch.tensor([1.0 if h else 0.0 for h in had], dtype=grads[0].dtype, device=grads[0].device)
+        flat = torch.cat([g.reshape(-1) for g in grads] + [flags])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        n_flag = len(self.params)
+        any_host = flat[-n_flag:].cpu().tolist() if not all(had) else None   # host read only when this rank had a None
         flat.div_(dist.get_world_size())
         views, off = [], 0
         for g in grads:
@@ -141,6 +153,10 @@ class FlatGradAllReduce:
             views.append(flat[off:off + n].view_as(g))
             off += n
         torch._foreach_copy_(grads, views)
+        if any_host is not None:
+            for p, h, a in zip(self.params, had, any_host):
+                if not h and a == 0.0:
+                    p.grad = None
 
 
 def max_over_ranks(value: float, device) -> float:
