@@ -42,7 +42,7 @@ def test_binding_table_covers_header_exactly():
 
 def test_host_side_queries_and_argument_validation_without_gpu():
     lib = _lib.load()
-    assert lib.vc_hash_workspace_bytes(1000) == 8 * 2048 * 12  # 8 slots per x-octet, octet load factor <= 1/2
+    assert lib.vc_hash_workspace_bytes(1000) == 8 * 1024 * 12  # 8 slots per x-octet, octets = next_pow2(> n): a free slot in every chain
     assert lib.vc_spconv_workspace_bytes(1, 3, _lib.i32arr([41, 800, 704])) > 41 * 800 * 704 // 8
     assert lib.vc_conv_backward_weight_workspace_bytes(1000, 27, 64, 64) >= 16 * 27 * 64 * 64 * 4
     assert lib.vc_voxelize_workspace_bytes(1000, 5) > 0 and lib.vc_bn_workspace_bytes(1000, 64) > 0
