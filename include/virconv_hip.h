@@ -130,7 +130,10 @@ int vc_spconv_pairs(const int32_t* indices, int64_t n, int ndim, int batch_size,
  *   then gather one nearly contiguous run of source rows per 16-row tile, and the kernel stages that run through LDS ("LDS
  *   staging of the per-kernel-offset feature gathers") instead of gathering L2 -> registers per offset; runs that do not fit
  *   the 32-row window gather directly.  Like row_order a pure performance hint: results are bit-identical either way.    */
-typedef enum vc_conv_flags { VC_CONV_SORTED_ROWS = 1 } vc_conv_flags;
+typedef enum vc_conv_flags { VC_CONV_SORTED_ROWS = 1, VC_CONV_SRC_INTERLEAVED = 2 } vc_conv_flags;
+/*   VC_CONV_SRC_INTERLEAVED (round-3 experiment, vc_conv_forward only, channel counts multiples of 16, a packed weight image
+ *   registered): `x` is given in 16-row groups, chunk-major inside a group -- [row / 16][cin / 4][row % 16][4] floats, rows padded to
+ *   a multiple of 16 -- instead of row-major; results are bit-identical, the gathers of consecutive rows coalesce.              */
 int vc_conv_forward(const float* x, int64_t n_in, const int32_t* pair_fwd, int64_t n_out, int kv,
                     const float* weight, int cin, int cout, const int32_t* row_order, int operand_type, int flags,
                     float* y, void* stream);

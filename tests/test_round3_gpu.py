@@ -178,3 +178,29 @@ def test_duplicate_pixel_weight_gradient_over_representatives_equals_the_plain_o
     for got in (a, plain):
         err = np.abs(got.cpu().numpy() - dw_ref)
         assert np.all(err <= 1e-4 * np.abs(dw_ref) + 1e-5 * scale), float(err.max() / scale)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (64, 32), (32, 64), (64, 64)])
+def test_interleaved_source_layout_gives_the_same_conv_bits(hip_backend, cin, cout):
+    """VC_CONV_SRC_INTERLEAVED (round-3 experiment): the source features in 16-row groups, chunk-major inside a group.  Same
+    arithmetic per output row: bit-identical to the row-major gather, on a sorted scene, a permuted one and a row count that is
+    not a multiple of 16."""
+    from virconv_amd import synth
+    rng = np.random.default_rng(cin + cout)
+    lib = hip_backend.lib
+    shape = (21, 64, 48)
+    for perm in (False, True):
+        idx = synth.small_scene_indices(5, 5003, shape, 2)
+        if perm:
+            idx = idx[rng.permutation(idx.shape[0])]
+        n = idx.shape[0]
+        pair, _ = hip_backend.subm_rulebook(torch.from_numpy(np.ascontiguousarray(idx)).cuda(), shape, (3, 3, 3), (1, 1, 1), want_rep=False)
+        x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).cuda()
+        w = torch.from_numpy((rng.standard_normal((cout, 3, 3, 3, cin)) / 9).astype(np.float32)).cuda()
+        assert lib.vc_debug_set(b"conv_autopack", 1) == 0
+        try:
+            y_ref = hip_backend.conv_forward(x, w, pair)
+            y_il = hip_backend.conv_forward(hip_backend.interleave_rows(x), w, pair, interleaved_rows=n)
+        finally:
+            lib.vc_debug_set(b"conv_autopack", 0)
+        assert torch.equal(y_ref, y_il)

@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--v5", type=int, default=0, help="loader / MFMA wave-role gather-GEMM (vc_debug_set conv_v5; needs --autopack)")
     ap.add_argument("--dxs", type=int, default=-1, help="dx shift in the LDS-staged kernel (vc_debug_set conv_dxs): 0 | 1; -1 = library default; needs --autopack")
     ap.add_argument("--layers", default="", help="comma-separated substrings: only time layers whose name contains one of them")
+    ap.add_argument("--il", action="store_true", help="forward convs (channel counts multiples of 16) also with the source features in the 16-row interleaved layout (VC_CONV_SRC_INTERLEAVED; implies --autopack)")
     args = ap.parse_args()
     ops.WINDOW_GATHER = bool(args.window)
     dev = torch.device("cuda", 0)
@@ -73,7 +74,7 @@ def main():
         assert be.lib.vc_debug_set(b"conv_nw", args.nw) == 0
     if args.v4 >= 0:
         assert be.lib.vc_debug_set(b"conv_v4", args.v4) == 0
-    assert be.lib.vc_debug_set(b"conv_autopack", 1 if args.autopack else 0) == 0
+    assert be.lib.vc_debug_set(b"conv_autopack", 1 if (args.autopack or args.il) else 0) == 0
     assert be.lib.vc_debug_set(b"conv_v4_ablate", args.ablate) == 0
     assert be.lib.vc_debug_set(b"conv_v4_pf", args.pf) == 0
     assert be.lib.vc_debug_set(b"conv_v5", args.v5) == 0
@@ -145,6 +146,13 @@ def main():
         srt = rb.sorted_rows and not args.no_window
         if args.only in ("all", "fwd"):
             res["fwd"] = timeit(lambda: be.conv_forward(x, w, rb.pair_fwd, order=rb.order_fwd, operand=args.operand, sorted_rows=srt), args.iters)
+        if args.il and args.only in ("all", "fwd") and cin % 16 == 0 and cout % 16 == 0:
+            xil = be.interleave_rows(x)
+            y_ref = be.conv_forward(x, w, rb.pair_fwd, order=rb.order_fwd, operand=args.operand)
+            y_il = be.conv_forward(xil, w, rb.pair_fwd, order=rb.order_fwd, operand=args.operand, interleaved_rows=rb.n_in)
+            assert torch.equal(y_ref, y_il), f"{name}: interleaved source changed the result"
+            res["il"] = timeit(lambda: be.conv_forward(xil, w, rb.pair_fwd, order=rb.order_fwd, operand=args.operand,
+                                                       interleaved_rows=rb.n_in), args.iters)
         if args.only in ("all", "bwd"):
             if rb.kind == "subm":
                 res["bwd"] = timeit(lambda: be.conv_backward_input(dy, w, rb.pair_fwd, rb.n_in, True, rb.centre, rb.rep, order=rb.order_bwd, operand=args.operand, sorted_rows=srt, grp_plan=rb.grp_plan), args.iters)
@@ -166,6 +174,8 @@ def main():
         line += (f"{f:8.1f} {tf(f):6.2f} {100 * tf(f) / PEAK:5.1f} {byts / (f * 1e-6) / 1e9:6.0f} | " if f else " " * 34 + "| ")
         line += (f"{b:8.1f} {tf(b):6.2f} {100 * tf(b) / PEAK:5.1f} | " if b else " " * 23 + "| ")
         line += (f"{d:8.1f} {tf(d):6.2f} {100 * tf(d) / PEAK:5.1f}" if d else "")
+        if res.get("il"):
+            line += f" | fwd interleaved src {res['il']:8.1f} us ({100 * tf(res['il']) / PEAK:4.1f} %pk, {res['fwd'] / res['il']:.2f}x)"
         if ops.ROW_ORDER != "none" and not args.layers:
             line += f" | ord {timeit(lambda: be.row_order(rb.pair_fwd, window=ops.ROW_ORDER_WINDOW), args.iters):6.1f}"
         print(line)

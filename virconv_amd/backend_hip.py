@@ -270,20 +270,33 @@ class HipBackend:
         return order
 
     def conv_forward(self, x: torch.Tensor, weight: torch.Tensor, pair_fwd: torch.Tensor,
-                     order: Optional[torch.Tensor] = None, operand: str = "f32", sorted_rows: bool = False) -> torch.Tensor:
+                     order: Optional[torch.Tensor] = None, operand: str = "f32", sorted_rows: bool = False,
+                     interleaved_rows: Optional[int] = None) -> torch.Tensor:
         """`sorted_rows`: VC_CONV_SORTED_ROWS hint (table rows and the rows they gather are in ascending coordinate order):
-        the kernel stages the gathers through LDS row windows.  Results are bit-identical with and without it."""
+        the kernel stages the gathers through LDS row windows.  Results are bit-identical with and without it.
+        `interleaved_rows` = n_in (round-3 experiment, VC_CONV_SRC_INTERLEAVED): `x` is the output of `interleave_rows`."""
         x = _need(x, torch.float32, "features")
         weight = _need(weight, torch.float32, "weight")
         pair_fwd = _need(pair_fwd, torch.int32, "pair_fwd")
         kv, n_out = pair_fwd.shape
         cout, cin = weight.shape[0], weight.shape[-1]
-        assert weight.numel() == cout * kv * cin and x.shape[1] == cin
+        n_in = x.shape[0] if interleaved_rows is None else int(interleaved_rows)
+        assert weight.numel() == cout * kv * cin and x.numel() >= n_in * cin
         y = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
-        check(self.lib.vc_conv_forward(_ptr(x), x.shape[0], _ptr(pair_fwd), n_out, kv, _ptr(weight), cin, cout,
-                                       _ptr(order), OPERAND_TYPES[operand], CONV_SORTED_ROWS if sorted_rows else 0, _ptr(y),
-                                       _stream()), "vc_conv_forward")
+        flags = (CONV_SORTED_ROWS if sorted_rows else 0) | (2 if interleaved_rows is not None else 0)
+        check(self.lib.vc_conv_forward(_ptr(x), n_in, _ptr(pair_fwd), n_out, kv, _ptr(weight), cin, cout,
+                                       _ptr(order), OPERAND_TYPES[operand], flags, _ptr(y), _stream()), "vc_conv_forward")
         return y
+
+    @staticmethod
+    def interleave_rows(x: torch.Tensor) -> torch.Tensor:
+        """(n, c) row-major -> the 16-row interleaved layout of VC_CONV_SRC_INTERLEAVED: [ceil(n / 16)][c / 4][16][4], zero rows
+        appended up to a multiple of 16 (plain torch ops: the experiment measures the gather, not this copy)."""
+        n, c = x.shape
+        g = (n + 15) // 16
+        xp = torch.zeros((g * 16, c), dtype=x.dtype, device=x.device)
+        xp[:n] = x
+        return xp.view(g, 16, c // 4, 4).permute(0, 2, 1, 3).contiguous()
 
     def conv_epilogue_supported(self, n_in: int, cin: int, cout: int, kv: int, operand: str = "f32") -> bool:
         return bool(self.lib.vc_conv_epilogue_supported(n_in, cin, cout, kv, OPERAND_TYPES[operand]))

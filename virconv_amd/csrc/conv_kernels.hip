@@ -312,7 +312,12 @@ static constexpr int VC_EPI_BWD = 3;  // internal (not part of vc_epilogue: sele
 // memory access; no instruction at all when every lane agrees).  The check is per lane on the table itself, so any table is
 // handled correctly; the arithmetic -- operands, MFMA order -- is unchanged, results are bit-identical.  What it buys is the
 // CU's vector-memory pipeline: 1.3-1.5 gathered rows per (tile, side offset) instead of 7-13.
-template <int CK, int CN, bool BWD, int RT, int OT, int EPI, int NW = 4, bool PK = false, bool DXS = false>
+// IL ("interleaved source", round-3 experiment, VC_CONV_SRC_INTERLEAVED): `src` is stored in 16-row groups, chunk-major inside a
+// group -- [row / 16][channel / 4][row % 16][4 floats] -- so that the 16 lanes of one MFMA row-slot quarter (same K chunk q, rows
+// i = 0..15) read 256 CONTIGUOUS bytes when their rows are consecutive (x-adjacent voxels of a sorted tensor), i.e. 4 cache lines
+// per quarter instead of 16: the L1 tag look-ups per gather instruction are what paces this kernel's vector-memory pipeline
+// (8.0-8.7 TB/s for the row-major MFMA mapping against 14.5 TB/s when a quad of lanes shares a line).
+template <int CK, int CN, bool BWD, int RT, int OT, int EPI, int NW = 4, bool PK = false, bool DXS = false, bool IL = false>
 __global__ void __launch_bounds__(64 * NW) gather_gemm_v2_kernel(const float* __restrict__ src,
                                                              const float* __restrict__ src_centre, int64_t n_src,
                                                              const int32_t* __restrict__ tbl,
@@ -323,6 +328,7 @@ __global__ void __launch_bounds__(64 * NW) gather_gemm_v2_kernel(const float* __
   static_assert(EPI == VC_EPI_NONE || RT == 1, "epilogues exist for the one-tile-per-wave kernel only");
   static_assert(!PK || (CK % 16 == 0 && OT == VC_OPERAND_F32), "packed weight images: fp32 operands, 16-channel K chunks");
   static_assert(!DXS || (RT == 1 && CK % 16 == 0 && OT == VC_OPERAND_F32), "dx shift: one tile per wave, 16-byte row chunks, fp32");
+  static_assert(!IL || (CK % 16 == 0 && !DXS), "interleaved source: 16-byte row chunks");
   static_assert(EPI == VC_EPI_NONE || (EPI == VC_EPI_BWD) == BWD, "STATS / AFFINE: forward kernel; BWD: backward-input kernel");
   constexpr int V = (CK >= 16) ? 4 : CK / 4;
   constexpr int NCH = CK / (4 * V);
@@ -355,10 +361,11 @@ __global__ void __launch_bounds__(64 * NW) gather_gemm_v2_kernel(const float* __
   }
   const int64_t brow0 = lbid * TM;
 
+  const int64_t n_src_buf = IL ? ((n_src + 15) & ~(int64_t)15) : n_src;   // interleaved sources are padded to whole 16-row groups
   const __amdgpu_buffer_rsrc_t rs_src =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)(n_src * CK * 4), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)(n_src_buf * CK * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_ctr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(src_centre ? src_centre : src), 0, (int)(n_src * CK * 4), 0x00020000);
+      const_cast<float*>(src_centre ? src_centre : src), 0, (int)(n_src_buf * CK * 4), 0x00020000);
 
   if (tid == 0) s_mask[0] = 0u;
   __syncthreads();
@@ -437,9 +444,11 @@ __global__ void __launch_bounds__(64 * NW) gather_gemm_v2_kernel(const float* __
     _Pragma("unroll") for (int t = 0; t < RT; ++t) {                                               \
       const int id = s_idx[(K) * TM + wave * (RT * 16) + t * 16 + i];                              \
       ACT[t] = __builtin_amdgcn_readfirstlane((int)(__ballot(id >= 0) != 0ULL));                   \
-      const unsigned base = (unsigned)id * (unsigned)(CK * 4) + (unsigned)(q * V * 4);             \
+      /* index -1: (unsigned)(-1 >> 4) * CK * 64 + ... stays just below 2^32 -> out of range -> zeros, as in the row-major form */ \
+      const unsigned base = IL ? ((unsigned)(id >> 4) * (unsigned)(CK * 64) + (unsigned)((id & 15) * 16) + (unsigned)(q * 256)) \
+                               : ((unsigned)id * (unsigned)(CK * 4) + (unsigned)(q * V * 4));      \
       _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
-          BufLoad<V>::ld(rs_, base + (unsigned)(ch * 4 * V * 4), A[t][ch]);                        \
+          BufLoad<V>::ld(rs_, base + (unsigned)(IL ? ch * 1024 : ch * 4 * V * 4), A[t][ch]);       \
     }                                                                                              \
   } while (0)
 
@@ -2287,6 +2296,26 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
       g_last_windowed = true;
       return VC_OK;
     }
+  }
+  if constexpr (CK % 16 == 0 && CN % 16 == 0 && !BWD) {
+    if (flags & VC_CONV_SRC_INTERLEAVED) {   // round-3 experiment: see the kernel's IL parameter
+      if (!(wpk && epi_kind == VC_EPI_NONE && ot == VC_OPERAND_F32 && src_centre == nullptr && kv <= 32 &&
+            ((n_src + 15) & ~(int64_t)15) * CK * 4 < (1LL << 31))) {
+        set_error("gather-GEMM: VC_CONV_SRC_INTERLEAVED needs a packed weight image, fp32 operands, no epilogue");
+        return VC_EINVAL;
+      }
+      constexpr int NCH_ = CK / 16, NT_ = CN / 16;
+      const size_t lds_il = (size_t)2 * NCH_ * NT_ * 64 * 4 * sizeof(float) + (size_t)(kv + 1) * 64 * sizeof(int) + 16;
+      hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, false, 1, VC_OPERAND_F32, VC_EPI_NONE, 4, true, false, true>),
+                         dim3((unsigned)cdiv(n_out, 64)), dim3(256), lds_il, st, src, src_centre, n_src, tbl, wpk, out, rep, order,
+                         n_out, kv, centre, mirror, epi);
+      VC_CHECK_LAUNCH("gather_gemm_v2_kernel<interleaved source>");
+      return VC_OK;
+    }
+  }
+  if (flags & VC_CONV_SRC_INTERLEAVED) {
+    set_error("gather-GEMM: VC_CONV_SRC_INTERLEAVED is implemented for forward convs with channel counts that are multiples of 16");
+    return VC_EINVAL;
   }
   // dx shift (see the kernel's DXS parameter): SubM-shaped 27-offset tables in natural row order, where it has something to find
   const bool dxs = g_conv_dxs && wpk != nullptr && kv == 27 && n_src == n_out && order == nullptr && rep == nullptr &&
