@@ -1919,6 +1919,56 @@ __global__ void __launch_bounds__(256) bwd_weight_reduce_kernel(const float* __r
   }
 }
 
+// All split-N reductions of a reverse sweep in ONE launch (round 3).  The per-layer reduce above is a 14 us latency-bound launch for
+// <= 14 MB of partial sums, 20 of them per train step (0.28 ms of side-stream kernel time, 3.4 % of the step's kernel time); the
+// feature pass gives every weight gradient its own partial buffer and reduces them all here, after its last weight-gradient
+// kernel: the same 64-element blocks, the same fixed addition order (bit-identical results), one launch whose blocks overlap
+// each other's latency.
+static constexpr int kMaxBwDefer = 48;
+struct BwReduceDesc {
+  const float* partial;
+  float* dweight;
+  int nsplit, kv, ci, co, block0;   // block0: first block of this tensor in the launch
+};
+struct BwReduceArgs {
+  BwReduceDesc d[kMaxBwDefer];
+  int n;
+};
+
+__global__ void __launch_bounds__(256) bwd_weight_reduce_multi_kernel(BwReduceArgs a) {
+  __shared__ float red[4][64];
+  int u = 0;
+  for (int j = 1; j < a.n; ++j)
+    if ((int)blockIdx.x >= a.d[j].block0) u = j;
+  const BwReduceDesc D = a.d[u];
+  const float* __restrict__ partial = D.partial;
+  const int total = D.kv * D.ci * D.co;
+  const int e = ((int)blockIdx.x - D.block0) * 64 + (threadIdx.x & 63);
+  const int sg = threadIdx.x >> 6;
+  float s = 0.f;
+  if (e < total) {
+    int sp = sg;
+    for (; sp + 12 < D.nsplit; sp += 16) {
+      const float v0 = partial[(int64_t)sp * total + e], v1 = partial[(int64_t)(sp + 4) * total + e];
+      const float v2 = partial[(int64_t)(sp + 8) * total + e], v3 = partial[(int64_t)(sp + 12) * total + e];
+      s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; sp < D.nsplit; sp += 4) s += partial[(int64_t)sp * total + e];
+  }
+  red[sg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sg == 0 && e < total) {
+    const float v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    const int co = e % D.co;
+    const int ci = (e / D.co) % D.ci;
+    const int k = e / (D.co * D.ci);
+    D.dweight[((int64_t)co * D.kv + k) * D.ci + ci] = v;
+  }
+}
+
+// deferral list of the calling thread (set by the feature pass around its side-stream weight gradients; NULL = reduce at once)
+static thread_local BwReduceArgs* g_bw_defer = nullptr;
+
 // --------------------------------------------------------------------------------------------- group sum (dup path)
 // Bit-stable group sum.  fp32 atomics would make the result depend on the arrival order of a pixel's rows, so the sum is
 // carried in 64-bit FIXED POINT: integer addition is associative, hence any arrival order gives the same bits.
@@ -2475,6 +2525,7 @@ int g_bw_legacy_order = 0;      // debug: 1 = offset-major block order of the we
 extern int g_pass_dw_main_tail; // pass.hip
 extern int g_pass_bwd_epilogue; // pass.hip
 extern int g_bn_fused_partial;  // bn_kernels.hip
+extern int g_pass_defer_dw_reduce;  // pass.hip
 static constexpr int kMaxSplit = 256;
 static constexpr size_t kMaxPartialBytes = 24u << 20;
 
@@ -2520,9 +2571,31 @@ static int launch_bw(const float* x, const float* dy, const int32_t* tbl, int64_
 #undef VC_ARGS
   VC_CHECK_LAUNCH("bwd_weight_kernel");
   const int total = kv * CI * CO;
+  if (g_bw_defer != nullptr && g_bw_defer->n < kMaxBwDefer) {   // reduced later, together with the sweep's other weight gradients
+    BwReduceArgs& A = *g_bw_defer;
+    const int b0 = A.n ? A.d[A.n - 1].block0 + (int)cdiv((int64_t)A.d[A.n - 1].kv * A.d[A.n - 1].ci * A.d[A.n - 1].co, 64) : 0;
+    A.d[A.n++] = BwReduceDesc{partial, dweight, nsplit, kv, CI, CO, b0};
+    return VC_OK;
+  }
   hipLaunchKernelGGL(bwd_weight_reduce_kernel, dim3((unsigned)cdiv(total, 64)), dim3(256), 0, st, partial, nsplit, kv,
                      CI, CO, dweight);
   VC_CHECK_LAUNCH("bwd_weight_reduce_kernel");
+  return VC_OK;
+}
+
+// feature pass <-> weight gradient: defer the split-N reductions of the calls made between begin and flush (same host thread)
+static thread_local BwReduceArgs g_bw_defer_store;
+void bw_defer_begin() { g_bw_defer_store.n = 0; }
+void bw_defer_enable(bool on) { g_bw_defer = on ? &g_bw_defer_store : nullptr; }
+int bw_defer_flush(hipStream_t st) {
+  g_bw_defer = nullptr;
+  BwReduceArgs& A = g_bw_defer_store;
+  if (A.n == 0) return VC_OK;
+  const BwReduceDesc& L = A.d[A.n - 1];
+  const unsigned blocks = (unsigned)(L.block0 + cdiv((int64_t)L.kv * L.ci * L.co, 64));
+  hipLaunchKernelGGL(bwd_weight_reduce_multi_kernel, dim3(blocks), dim3(256), 0, st, A);
+  A.n = 0;
+  VC_CHECK_LAUNCH("bwd_weight_reduce_multi_kernel");
   return VC_OK;
 }
 
@@ -2574,6 +2647,7 @@ int vc_debug_set(const char* key, int value) {
   if (key && !strcmp(key, "pass_dw_main_tail")) { g_pass_dw_main_tail = value; return VC_OK; }
   if (key && !strcmp(key, "pass_bwd_epilogue")) { g_pass_bwd_epilogue = value; return VC_OK; }
   if (key && !strcmp(key, "bn_fused_partial")) { g_bn_fused_partial = value; return VC_OK; }
+  if (key && !strcmp(key, "pass_defer_dw_reduce")) { g_pass_defer_dw_reduce = value; return VC_OK; }
   if (key && !strcmp(key, "xcd_swizzle_off")) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_swizzle_off), &value, sizeof(int)) == hipSuccess ? VC_OK : VC_EHIP;
   }

@@ -182,6 +182,11 @@ static int launch_add_views(float* out, int64_t n, int c, const float* a, int as
 // main chain (they can only start after each unit's BatchNorm backward), so at the end of the sweep the main stream idles in
 // the join; moving the tail's weight gradients over fills that hole.
 int g_pass_dw_main_tail = 0;
+// conv_kernels.hip: the split-N reductions of the side-stream weight gradients of one sweep, deferred into ONE launch
+void bw_defer_begin();
+void bw_defer_enable(bool on);
+int bw_defer_flush(hipStream_t st);
+int g_pass_defer_dw_reduce = 1;   // vc_debug_set "pass_defer_dw_reduce": 0 = every weight gradient reduces at once (A/B)
 // vc_debug_set "pass_bwd_epilogue" (default 1): let the backward-input conv that delivers the LAST contribution to a buffer's
 // gradient add the earlier contribution in its epilogue and, when that buffer is the whole output of a unit, also form that
 // unit's BatchNorm-backward sums there (vc_conv_backward_input_epilogue): no gradient-add kernel, no reduction pass over
@@ -246,6 +251,11 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
     }
   }
 
+  auto dw_bytes_of = [](const vc_pass_table& t_, const vc_pass_unit& u_) {
+    return vc_conv_backward_weight_workspace_bytes(t_.n_out, t_.kv, u_.cin, u_.cout);
+  };
+  if (!dry) bw_defer_begin();
+  struct DeferOff { ~DeferOff() { bw_defer_enable(false); } } defer_off_on_exit;
   std::vector<std::vector<GradView>> contrib(p->n_bufs);
   std::vector<int> state(p->n_bufs, 0);  // 0 unresolved, 1 resolved to `res`, 2 no gradient reaches the buffer
   std::vector<GradView> res(p->n_bufs);
@@ -330,6 +340,10 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
       // side stream runs its weight gradients in order but LATER than the main chain, so such a unit gets its own group buffer (the
       // shared one would be overwritten by the next duplicate-pixel unit of the main chain before the side stream has read it).
       float* grp = !dup ? nullptr : (need_dw ? at(bump.take((size_t)t.n_out * u.cout * sizeof(float))) : at(grp_off));
+      // a side-stream weight gradient keeps its split-N partial sums until the sweep's single reduce launch: its own buffer
+      const bool defer = need_dw && on_side && g_pass_defer_dw_reduce;
+      char* dwp = defer ? (dry ? nullptr : arena + bump.take(dw_bytes_of(t, u))) : nullptr;
+      if (defer && dry) bump.take(dw_bytes_of(t, u));
       // epilogue fusion: this conv delivers the last contribution to the gradient of its source buffer
       bool fold = false;
       GradView addv{nullptr, 0, 0};
@@ -385,7 +399,9 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
         VC_CHECK_HIP(hipEventRecord(ev[0], st));
         VC_CHECK_HIP(hipStreamWaitEvent(side, ev[0], 0));
         forked = true;
-        rc = weight_grad(arena + dw_off, side);
+        bw_defer_enable(defer);
+        rc = weight_grad(defer ? dwp : arena + dw_off, side);
+        bw_defer_enable(false);
         if (rc != VC_OK) return rc;
       }
       if (need_dx) {
@@ -456,6 +472,8 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
     }
   }
   if (forked) {  // join: every weight gradient is complete before the caller's stream moves on (and may recycle the arenas)
+    const int rcf = bw_defer_flush(side);   // ONE reduce launch for all deferred split-N partial sums
+    if (rcf != VC_OK) return rcf;
     VC_CHECK_HIP(hipEventRecord(ev[1], side));
     VC_CHECK_HIP(hipStreamWaitEvent(st, ev[1], 0));
   }
