@@ -271,6 +271,7 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
     const vc_pass_buf& B = p->bufs[b];
     float* out = at(bump.take((size_t)B.rows * B.cols * sizeof(float)));
     if (!dry) {
+      if (bump.off > arena_bytes) { set_error("vc_pass_backward: arena too small"); return VC_ECAPACITY; }
       int rc = launch_add_views(out, B.rows, B.cols, c[0].p, c[0].stride, c[0].col0, c[1].p, c[1].stride, c[1].col0, st);
       if (rc != VC_OK) return rc;
       for (size_t k = 2; k < c.size(); ++k) {
@@ -341,9 +342,12 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
       // shared one would be overwritten by the next duplicate-pixel unit of the main chain before the side stream has read it).
       float* grp = !dup ? nullptr : (need_dw ? at(bump.take((size_t)t.n_out * u.cout * sizeof(float))) : at(grp_off));
       // a side-stream weight gradient keeps its split-N partial sums until the sweep's single reduce launch: its own buffer
-      const bool defer = need_dw && on_side && g_pass_defer_dw_reduce;
-      char* dwp = defer ? (dry ? nullptr : arena + bump.take(dw_bytes_of(t, u))) : nullptr;
-      if (defer && dry) bump.take(dw_bytes_of(t, u));
+      // (the buffer is taken whenever the unit COULD run on the side stream, so that the sizing run -- which has no streams --
+      // and the real run lay the arena out identically)
+      const bool may_defer = need_dw && units_left > g_pass_dw_main_tail && g_pass_defer_dw_reduce;
+      const size_t dwp_off = may_defer ? bump.take(dw_bytes_of(t, u)) : 0;
+      const bool defer = may_defer && on_side;
+      char* dwp = (defer && !dry) ? arena + dwp_off : nullptr;
       // epilogue fusion: this conv delivers the last contribution to the gradient of its source buffer
       bool fold = false;
       GradView addv{nullptr, 0, 0};
@@ -366,6 +370,10 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
       }
       if (need_dx) contrib[o.src].push_back({dry ? marker : dx, u.cin, 0});
       if (dry) continue;
+      if (bump.off > arena_bytes) {   // never launch into memory the caller did not provide
+        set_error("vc_pass_backward: arena too small");
+        return VC_ECAPACITY;
+      }
       const GradView g = res[o.dst];
       const float* x = buf_ptr(p, L, fwd_arena, o.src);
       const float* y_raw = (const float*)((const char*)fwd_arena + L.yraw_off[i]);
@@ -447,6 +455,7 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
       if (g.stride != D.cols || g.col0 != 0) {
         float* dense = at(bump.take((size_t)D.rows * D.cols * sizeof(float)));
         if (!dry) {
+          if (bump.off > arena_bytes) { set_error("vc_pass_backward: arena too small"); return VC_ECAPACITY; }
           rc = launch_add_views(dense, D.rows, D.cols, g.p, g.stride, g.col0, nullptr, 0, 0, st);
           if (rc != VC_OK) return rc;
         }
@@ -455,6 +464,10 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
       float* gs = at(bump.take((size_t)S.rows * S.cols * sizeof(float)));
       contrib[o.src].push_back({dry ? marker : gs, S.cols, 0});
       if (dry) continue;
+      if (bump.off > arena_bytes) {
+        set_error("vc_pass_backward: arena too small");
+        return VC_ECAPACITY;
+      }
       rc = vc_scatter_rows(g.p, D.cols, p->keeps[o.keep], D.rows, S.rows, gs, st);
       if (rc != VC_OK) return rc;
     }
