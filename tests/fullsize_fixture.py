@@ -25,6 +25,12 @@ K_GRAD = 512           # sampled entries per gradient tensor
 TENSORS = ("x_conv1", "x_conv2", "x_conv3", "x_conv4", "out")
 CHANNELS = {"x_conv1": 16, "x_conv2": 32, "x_conv3": 64, "x_conv4": 64, "out": 64}
 PARAM_SEED = 7
+PARAM_SEED_8X = 11
+RIDS = ("", "1", "2")          # rot_num = 3 (VirConv-T/S): key suffixes of the transformed frames
+# VirConv8x: per rotation the encoded LiDAR tensor, its x_conv3 / x_conv4 and the four MM-stream scales
+TENSORS_8X_EVAL = tuple(n + r for r in RIDS for n in ("out", "x_conv3", "x_conv4", "mm_x_conv1", "mm_x_conv2", "mm_x_conv3", "mm_x_conv4"))
+TENSORS_8X_TRAIN = TENSORS_8X_EVAL
+TRANSFORMS_8X = np.array([[0.0, 0.0, 1.0], [0.39269908, 1.0, 0.98], [-0.39269908, 0.0, 1.02]], dtype=np.float32)  # rot, flip, scale
 
 
 def make_inputs(seeds):
@@ -53,10 +59,14 @@ def sample_positions(n: int, k: int, salt: int) -> np.ndarray:
     return np.sort(rng.choice(n, size=min(n, k), replace=False)).astype(np.int64)
 
 
+def _salt(name: str) -> int:
+    return TENSORS.index(name) if name in TENSORS else 50 + TENSORS_8X_EVAL.index(name)
+
+
 def loss_weights(name: str, n: int, c: int) -> torch.Tensor:
     """G[row, ch] = g[ch] * (1 + 0.5 cos(0.37 row)): a fixed, row-dependent stand-in for the heads' gradient (float64 math,
     rounded once to fp32)."""
-    rng = np.random.default_rng(4242 + TENSORS.index(name))
+    rng = np.random.default_rng(4242 + _salt(name))
     g = rng.standard_normal(c) * 0.05
     rows = 1.0 + 0.5 * np.cos(0.37 * np.arange(n, dtype=np.float64))
     return torch.from_numpy((rows[:, None] * g[None, :]).astype(np.float32))
@@ -69,18 +79,20 @@ def outputs_of(batch_dict):
     return {k: (t.features, t.indices) for k, t in res.items()}
 
 
-def loss_of(outs) -> torch.Tensor:
+def loss_of(outs, names=TENSORS) -> torch.Tensor:
     loss = None
-    for name in TENSORS:
+    for name in names:
         f = outs[name][0]
+        if not f.requires_grad:        # (index-only outputs of a stream that carries no gradient)
+            continue
         term = (f * loss_weights(name, f.shape[0], f.shape[1]).to(f.device)).sum()
         loss = term if loss is None else loss + term
     return loss
 
 
-def summarize_outputs(outs, prefix: str) -> dict:
+def summarize_outputs(outs, prefix: str, names=TENSORS) -> dict:
     d = {}
-    for ti, name in enumerate(TENSORS):
+    for ti, name in enumerate(names):
         f = outs[name][0].detach().cpu().numpy().astype(np.float64)
         idx = outs[name][1].detach().cpu().numpy().astype(np.int32)
         pos = sample_positions(f.shape[0], K_ROWS, ti)
@@ -103,10 +115,10 @@ def summarize_named(tensors: dict, prefix: str) -> dict:
     return d
 
 
-def check_outputs(outs, g, prefix: str, tol: float = 1e-4, report=None):
+def check_outputs(outs, g, prefix: str, tol: float = 1e-4, report=None, names=TENSORS):
     """Compare a run against the fixture: N and indices bit-exact (hash), sampled rows within tol * max|tensor| element-wise
     (plus a relative term), per-channel sums within the fp32 summation bound of the tensor."""
-    for ti, name in enumerate(TENSORS):
+    for ti, name in enumerate(names):
         f = outs[name][0].detach().cpu().numpy().astype(np.float64)
         idx = outs[name][1].detach().cpu().numpy().astype(np.int32)
         assert f.shape[0] == int(g[f"{prefix}_{name}_n"]), f"{prefix} {name}: N {f.shape[0]} != {int(g[f'{prefix}_{name}_n'])}"
@@ -140,3 +152,47 @@ def check_named(tensors: dict, g, prefix: str, rtol: float, report=None):
         assert abs(v.sum() - s[0]) <= rtol * max(s[1], 1e-12) * 4, f"{prefix} {name}: sum differs"
         if report is not None:
             report.append(f"{prefix} {name}: {float(err.max() / mx):.3e}")
+
+
+# ------------------------------------------------------------------------------------------------ VirConv8x (VirConv-T/S backbone)
+def _transform_points(pts, t):
+    """forward world transform: rotation about z, flip y, scaling (X_transform.py:125-137 order; as tests/golden/make_golden_8x.py)"""
+    p = pts.copy()
+    c, s = np.float32(np.cos(t[0])), np.float32(np.sin(t[0]))
+    x, y = p[:, 0] * c - p[:, 1] * s, p[:, 0] * s + p[:, 1] * c
+    p[:, 0], p[:, 1] = x, y
+    if t[1] != 0:
+        p[:, 1] = -p[:, 1]
+    p[:, 0:3] *= t[2]
+    return p
+
+
+def make_inputs_8x(seed: int, max_voxels: int = 16000):
+    """One full frame as VirConv8x reads it: per transformed copy (rot_num = 3) a LiDAR-only voxel set and a fused (MM) voxel set,
+    <= 16 000 voxels each (VirConv-T.yaml:9,119-122), MeanVFE without the 'max' flag channel rule."""
+    fr = synth.make_frame(int(seed))
+    virt = geometry.input_point_discard(fr["points_virtual"], 2, 0.8, np.random.default_rng(int(seed)).permutation)
+    mm = np.concatenate([fr["points_lidar"], virt])
+    d = {"batch_size": 1, "calib": [fr["calib"]], "transform_param": TRANSFORMS_8X[None].copy()}
+    for i, t in enumerate(TRANSFORMS_8X):
+        rid = RIDS[i]
+        for name, pts in (("", fr["points_lidar"]), ("_mm", mm)):
+            vox, c, num = geometry.voxelize(_transform_points(pts, t), synth.VOXEL_SIZE, synth.POINT_CLOUD_RANGE, 5, max_voxels)
+            d["voxel_features" + name + rid] = geometry.mean_vfe(vox, num, None)
+            d["voxel_coords" + name + rid] = np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1)
+    return d
+
+
+def outputs_of_8x(out):
+    res = {}
+    for rid in RIDS:
+        t = out["encoded_spconv_tensor" + rid]
+        res["out" + rid] = (t.features, t.indices)
+        ms = out["multi_scale_3d_features" + rid]
+        for n in ("x_conv3", "x_conv4"):
+            res[n + rid] = (ms[n].features, ms[n].indices)
+        mm = out["multi_scale_3d_features_mm" + rid]
+        for n in ("x_conv1", "x_conv2", "x_conv3", "x_conv4"):
+            res["mm_" + n + rid] = (mm[n].features, mm[n].indices)
+    return res
+
