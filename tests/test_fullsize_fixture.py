@@ -151,6 +151,9 @@ def _write_report(tag, rows):
 
 
 # ================================================================================================ VirConv8x (VirConv-T/S backbone)
+# tests/golden/virconv_8x_fullsize_ref.npz (make_golden_fullsize_8x.py): the reference's VirConv8x.forward, NRConvBlock,
+# decompose_tensor and x-concatenation on one full frame -- with the reference's torch index2uv replaced by the oracle's
+# restatement during generation (3 of 245 k projected rows differ between the two on this frame; see the generator's docstring).
 CFG_8X = dict(NAME="VirConv8x", NUM_FILTERS=[16, 32, 64, 64], RETURN_NUM_FEATURES_AS_DICT=True, OUT_FEATURES=64,
               LAYER_DISCARD_RATE=0.15, MM=True, LAYER_DISCARD_MODE="spconv2_noop")
 
@@ -223,10 +226,10 @@ def test_8x_fullsize_oracle_backend_equals_the_reference_composition(oracle_back
     if mode == "eval":
         with torch.no_grad():
             out = _model_8x("cpu", False)(_batch_8x(d, "cpu"))
-        fx.check_outputs(fx.outputs_of_8x(out), g, "eval", names=fx.TENSORS_8X_EVAL)
+        fx.check_outputs(fx.outputs_of_8x(out), g, "eval", names=fx.TENSORS_8X_EVAL, k_rows=fx.K_ROWS_8X)
         return
     outs, loss, grads, stats = _train_run_8x(d, "cpu")
-    fx.check_outputs(outs, g, "train", names=fx.TENSORS_8X_TRAIN)
+    fx.check_outputs(outs, g, "train", names=fx.TENSORS_8X_TRAIN, k_rows=fx.K_ROWS_8X)
     assert abs(loss - float(g["train_loss"])) <= 1e-2
     fx.check_named(stats, g, "train_stat", rtol=1e-5)
     fx.check_named(grads, g, "train_grad", rtol=2e-4)
@@ -238,7 +241,7 @@ def test_8x_fullsize_hip_equals_the_reference_composition_eval(hip_backend, fixt
     report = []
     with torch.no_grad():
         out = _model_8x("cuda", False)(_batch_8x(d, "cuda"))
-    fx.check_outputs(fx.outputs_of_8x(out), g, "eval", report=report, names=fx.TENSORS_8X_EVAL)
+    fx.check_outputs(fx.outputs_of_8x(out), g, "eval", report=report, names=fx.TENSORS_8X_EVAL, k_rows=fx.K_ROWS_8X)
     _write_report("fixture_8x_eval", report)
 
 
@@ -247,7 +250,7 @@ def test_8x_fullsize_hip_equals_the_reference_composition_train(hip_backend, fix
     g, d = fixture_8x
     report = []
     outs, loss, grads, stats = _train_run_8x(d, "cuda")
-    fx.check_outputs(outs, g, "train", report=report, names=fx.TENSORS_8X_TRAIN)
+    fx.check_outputs(outs, g, "train", report=report, names=fx.TENSORS_8X_TRAIN, k_rows=fx.K_ROWS_8X)
     l64, l32 = float(g["train64_loss"]), float(g["train_loss"])
     assert abs(loss - l64) <= max(1e-2, 3 * abs(l32 - l64)), (loss, l64, l32)
     fx.check_named(stats, g, "train_stat", rtol=1e-5, report=report)
