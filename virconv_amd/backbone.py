@@ -16,14 +16,13 @@ What is different from running the reference file on the facade (which also work
 """
 from __future__ import annotations
 
+import os
 from functools import partial
 from typing import Optional
 
 import numpy as np
 import torch
 from torch import nn
-
-import os
 
 from . import feature_pass, ops
 from . import spconv
@@ -251,7 +250,7 @@ def _plan_stream(device):
     if key not in _PLAN_STREAMS:
         # high priority: the plan's short index kernels (and the host waiting on their counts) must not queue behind
         # the main stream's long conv kernels
-        _PLAN_STREAMS[key] = torch.cuda.Stream(device=device, priority=-1)
+        _PLAN_STREAMS[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get("VIRCONV_PLAN_PRIORITY", "-1")))
     return _PLAN_STREAMS[key]
 
 
