@@ -204,3 +204,44 @@ def test_interleaved_source_layout_gives_the_same_conv_bits(hip_backend, cin, co
         finally:
             lib.vc_debug_set(b"conv_autopack", 0)
         assert torch.equal(y_ref, y_il)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 16), (16, 32), (64, 32), (32, 64), (64, 64)])
+@pytest.mark.parametrize("kind", ["subm", "strided", "kv3"])
+def test_weight_gradient_v2_dy_window_in_lds(hip_backend, cin, cout, kind):
+    """bwd_weight_v2_kernel (vc_debug_set bw_variant 2): the row range's dy rows staged through LDS once for a group of offsets,
+    every wave owning whole offsets.  Same dW as v1 and as the float64 oracle up to fp32 re-association; bit-stable; SubM tables,
+    strided tables (n_in != n_out) and a 3-offset kernel; row counts that are not multiples of the window."""
+    from virconv_amd import synth
+    rng = np.random.default_rng(cin * 3 + cout)
+    lib = hip_backend.lib
+    shape = (21, 64, 48)
+    idx = synth.small_scene_indices(9, 7003, shape, 2)
+    it = torch.from_numpy(np.ascontiguousarray(idx)).cuda()
+    if kind == "subm":
+        pair, _ = hip_backend.subm_rulebook(it, shape, (3, 3, 3), (1, 1, 1), want_rep=False)
+        ks = (3, 3, 3)
+    elif kind == "strided":
+        _, _, pair, _ = hip_backend.sparse_rulebook(it, shape, 2, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1))
+        ks = (3, 3, 3)
+    else:
+        _, _, pair, _ = hip_backend.sparse_rulebook(it, shape, 2, (3, 1, 1), (2, 1, 1), (0, 0, 0), (1, 1, 1))
+        ks = (3, 1, 1)
+    n_in, n_out = idx.shape[0], pair.shape[1]
+    x = torch.from_numpy(rng.standard_normal((n_in, cin)).astype(np.float32)).cuda()
+    g = torch.from_numpy(rng.standard_normal((n_out, cout)).astype(np.float32)).cuda()
+    wshape = (cout,) + ks + (cin,)
+    v1 = hip_backend.conv_backward_weight(x, g, pair, wshape)
+    assert lib.vc_debug_set(b"bw_variant", 2) == 0
+    try:
+        v2 = hip_backend.conv_backward_weight(x, g, pair, wshape)
+        for _ in range(2):
+            assert torch.equal(v2, hip_backend.conv_backward_weight(x, g, pair, wshape))
+    finally:
+        lib.vc_debug_set(b"bw_variant", 1)
+    _, dw_ref = sparse_ref.conv_backward(x.cpu().double(), torch.zeros(wshape, dtype=torch.float64), pair.cpu().numpy(), g.cpu().double())
+    dw_ref = dw_ref.numpy()
+    scale = np.abs(dw_ref).max()
+    for got in (v1, v2):
+        err = np.abs(got.cpu().numpy() - dw_ref)
+        assert np.all(err <= 1e-4 * np.abs(dw_ref) + 1e-5 * scale), float(err.max() / scale)

@@ -1888,6 +1888,159 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
   for (int e = threadIdx.x; e < CI * CO; e += 256) dst[e] = red[e];
 }
 
+// --------------------------------------------------------------------------------------------- K8 v2 (dy window in LDS)
+// Round 3.  The weight gradient gathers BOTH operands of every pair -- x[in] and dy[out] -- which is why it sits at 36-43 % of the
+// fp32-MFMA peak although it has no tile padding: per 4 pairs it issues two vector-memory instructions for VA*VB MFMAs, and the
+// CU's one vector-memory pipeline is the pacer.  But dy is not a gather at all: the out rows of a block's
+// row range are CONSECUTIVE, and every offset needs the same ones.  v2 therefore gives a block a row range AND a group of
+// G = 4 * NOFF offsets: the range's dy rows are staged through LDS in windows of WIN rows (coalesced 16-byte loads, once for
+// all G offsets), each of the 4 waves owns NOFF of the group's offsets outright (its accumulators never meet another wave's:
+// no cross-wave reduction, no atomics, fixed order -> bit-stable) and walks ALL rows of the window for them, compacting the
+// active pairs by ballot as v1 does; x rows still come from global memory (one vector load per 4 pairs), dy rows from LDS.
+// Partial sums land in the same [split][k][ci][co] buffer, so the split-N reduce is shared with v1.
+template <int CI, int CO, int NOFF>
+__global__ void __launch_bounds__(256) bwd_weight_v2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const int32_t* __restrict__ tbl, int64_t n_out, int kv,
+                                                            int64_t rows_per_block, int nsplit, float* __restrict__ partial) {
+  static_assert(CI % 16 == 0 && CO % 16 == 0, "v2: channel counts multiples of 16");
+  constexpr int VA = CI / 16, VB = CO / 16;
+  constexpr int G = 4 * NOFF;
+  constexpr int WIN = (CO <= 32) ? 256 : 128;          // dy rows per LDS window
+  constexpr int PITCH = CO + 4;                        // floats per staged row (keeps 16-byte alignment, spreads the banks)
+  constexpr int U = (VA * VB >= 8) ? 2 : 4;            // groups of 4 pairs per trip
+  __shared__ __attribute__((aligned(16))) float s_dy[WIN * PITCH];
+  __shared__ int q_in[4][136];
+  __shared__ int q_out[4][136];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int ngroups = (kv + G - 1) / G;
+  // block order as v1: the offset-group blocks of one row range are adjacent in launch order and on the same XCD
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int rl = j / ngroups, grp = j - rl * ngroups;
+  const int split = rl * 8 + xcd;
+  if (split >= nsplit) return;
+  const int64_t brow0 = (int64_t)split * rows_per_block;
+  const int64_t bend = min(brow0 + rows_per_block, n_out);
+
+  f32x4 acc[NOFF][VA][VB];
+#pragma unroll
+  for (int t = 0; t < NOFF; ++t)
+#pragma unroll
+    for (int ja = 0; ja < VA; ++ja)
+#pragma unroll
+      for (int jb = 0; jb < VB; ++jb) acc[t][ja][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int* qi = q_in[wave];
+  int* qo = q_out[wave];
+  for (int64_t win0 = brow0; win0 < bend; win0 += WIN) {
+    const int wrows = (int)min((int64_t)WIN, bend - win0);
+    __syncthreads();   // every wave is done with the previous window
+    for (int e = threadIdx.x; e < wrows * (CO / 4); e += 256) {
+      const int r = e / (CO / 4), c4 = e - r * (CO / 4);
+      *reinterpret_cast<float4*>(&s_dy[r * PITCH + 4 * c4]) = *reinterpret_cast<const float4*>(dy + (win0 + r) * CO + 4 * c4);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NOFF; ++t) {
+      const int k = grp * G + wave + 4 * t;
+      if (k >= kv) continue;   // wave-uniform
+      int qlen = 0;
+      int v_next = (lane < wrows) ? tbl[(int64_t)k * n_out + win0 + lane] : -1;
+      for (int base = 0; base < wrows; base += 64) {
+        const int lr = base + lane;
+        const int v = v_next;
+        v_next = (lr + 64 < wrows) ? tbl[(int64_t)k * n_out + win0 + lr + 64] : -1;
+        const unsigned long long m = __ballot(v >= 0);
+        if (m != 0ULL) {
+          const int pos = __popcll(m & ((1ULL << lane) - 1ULL));
+          if (v >= 0) { qi[qlen + pos] = v; qo[qlen + pos] = lr; }
+          qlen += __popcll(m);
+          __builtin_amdgcn_wave_barrier();
+        }
+        const bool last = base + 64 >= wrows;
+        int ng = qlen >> 2;
+        if (last && (qlen & 3)) {   // the window's tail group: pad the queue with (row 0, zero weight) by masking below
+          ++ng;
+        }
+        int g = 0;
+        for (; g + U <= ng; g += U) {
+          float a[U][VA], b[U][VB];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int slot = (g + u) * 4 + q;
+            const bool ok = slot < qlen;
+            const int pin = ok ? qi[slot] : 0, lrow = ok ? qo[slot] : 0;
+            VecLoad<VA>::ld(x + (int64_t)pin * CI + VA * i, a[u]);
+            VecLoad<VB>::ld(&s_dy[lrow * PITCH + VB * i], b[u]);
+            if (!ok) {   // padding slot of a tail group: exact zeros on both sides (0 * inf would be NaN)
+#pragma unroll
+              for (int ja = 0; ja < VA; ++ja) a[u][ja] = 0.f;
+#pragma unroll
+              for (int jb = 0; jb < VB; ++jb) b[u][jb] = 0.f;
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int ja = 0; ja < VA; ++ja)
+#pragma unroll
+              for (int jb = 0; jb < VB; ++jb)
+                acc[t][ja][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][ja], b[u][jb], acc[t][ja][jb], 0, 0, 0);
+        }
+        for (; g < ng; ++g) {
+          const int slot = g * 4 + q;
+          const bool ok = slot < qlen;
+          const int pin = ok ? qi[slot] : 0, lrow = ok ? qo[slot] : 0;
+          float a[VA], b[VB];
+          VecLoad<VA>::ld(x + (int64_t)pin * CI + VA * i, a);
+          VecLoad<VB>::ld(&s_dy[lrow * PITCH + VB * i], b);
+          if (!ok) {
+#pragma unroll
+            for (int ja = 0; ja < VA; ++ja) a[ja] = 0.f;
+#pragma unroll
+            for (int jb = 0; jb < VB; ++jb) b[jb] = 0.f;
+          }
+#pragma unroll
+          for (int ja = 0; ja < VA; ++ja)
+#pragma unroll
+            for (int jb = 0; jb < VB; ++jb)
+              acc[t][ja][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ja], b[jb], acc[t][ja][jb], 0, 0, 0);
+        }
+        // keep the pairs that did not fill a group of 4 (none after the window's last batch: the tail group took them)
+        const int done = last ? qlen : (qlen & ~3);
+        const int rem = qlen - done;
+        int t1 = 0, t2 = 0;
+        if (lane < rem) { t1 = qi[done + lane]; t2 = qo[done + lane]; }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < rem) { qi[lane] = t1; qo[lane] = t2; }
+        qlen = rem;
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  // each wave owns its offsets: straight to the partial buffer [split][k][ci][co], ci = VA*m + ja (m = 4q + reg), co = VB*i + jb
+#pragma unroll
+  for (int t = 0; t < NOFF; ++t) {
+    const int k = grp * G + wave + 4 * t;
+    if (k >= kv) continue;
+    float* dst = partial + ((int64_t)split * kv + k) * (CI * CO);
+#pragma unroll
+    for (int ja = 0; ja < VA; ++ja)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int ci = VA * (q * 4 + reg) + ja;
+        if constexpr (VB == 4) {
+          *reinterpret_cast<float4*>(dst + ci * CO + 4 * i) =
+              make_float4(acc[t][ja][0][reg], acc[t][ja][1][reg], acc[t][ja][2][reg], acc[t][ja][3][reg]);
+        } else if constexpr (VB == 2) {
+          *reinterpret_cast<float2*>(dst + ci * CO + 2 * i) = make_float2(acc[t][ja][0][reg], acc[t][ja][1][reg]);
+        } else {
+          dst[ci * CO + i] = acc[t][ja][0][reg];
+        }
+      }
+  }
+}
+
 // dweight[(co*kv + k)*CI + ci] = sum_s partial[s][k][ci][co]   (fixed order: 4 interleaved partial sums, then 0+1+2+3)
 // 64 consecutive (k, ci, co) elements per block in the partial's native order (coalesced reads), 4 split-groups.
 __global__ void __launch_bounds__(256) bwd_weight_reduce_kernel(const float* __restrict__ partial, int nsplit, int kv,
@@ -2522,6 +2675,7 @@ static int dispatch_ck(int ck, int cn, const float* src, const float* src_centre
 
 int g_bw_rows_per_split = 1024;  // weight gradient: target rows per block (vc_debug_set bw_rows_per_split); more rows = fewer, longer blocks and fewer partial sums
 int g_bw_legacy_order = 0;      // debug: 1 = offset-major block order of the weight-gradient kernel
+int g_bw_variant = 1;           // vc_debug_set bw_variant: 1 = bwd_weight_kernel, 2 = bwd_weight_v2_kernel (dy window in LDS) where it applies
 extern int g_pass_dw_main_tail; // pass.hip
 extern int g_pass_bwd_epilogue; // pass.hip
 extern int g_bn_fused_partial;  // bn_kernels.hip
@@ -2555,6 +2709,26 @@ static int launch_bw(const float* x, const float* dy, const int32_t* tbl, int64_
   int nsplit;
   int64_t rpb;
   bw_split(n_out, kv, CI, CO, nsplit, rpb);
+  if constexpr (CI % 16 == 0 && CO % 16 == 0) {
+    if (g_bw_variant == 2 && ot == VC_OPERAND_F32 && rep == nullptr) {   // v2: dy window in LDS, offsets split over the waves
+      constexpr int NOFF = ((CI / 16) * (CO / 16) >= 16) ? 1 : 2;
+      const int ngroups = (kv + 4 * NOFF - 1) / (4 * NOFF);
+      hipLaunchKernelGGL((bwd_weight_v2_kernel<CI, CO, NOFF>), dim3((unsigned)(cdiv(nsplit, 8) * 8 * ngroups)), dim3(256), 0, st, x, dy,
+                         tbl, n_out, kv, rpb, nsplit, partial);
+      VC_CHECK_LAUNCH("bwd_weight_v2_kernel");
+      const int total2 = kv * CI * CO;
+      if (g_bw_defer != nullptr && g_bw_defer->n < kMaxBwDefer) {
+        BwReduceArgs& A = *g_bw_defer;
+        const int b0 = A.n ? A.d[A.n - 1].block0 + (int)cdiv((int64_t)A.d[A.n - 1].kv * A.d[A.n - 1].ci * A.d[A.n - 1].co, 64) : 0;
+        A.d[A.n++] = BwReduceDesc{partial, dweight, nsplit, kv, CI, CO, b0};
+        return VC_OK;
+      }
+      hipLaunchKernelGGL(bwd_weight_reduce_kernel, dim3((unsigned)cdiv(total2, 64)), dim3(256), 0, st, partial, nsplit, kv, CI, CO,
+                         dweight);
+      VC_CHECK_LAUNCH("bwd_weight_reduce_kernel");
+      return VC_OK;
+    }
+  }
   const unsigned nblocks = g_bw_legacy_order ? (unsigned)(nsplit * kv) : (unsigned)(cdiv(nsplit, 8) * 8 * kv);
 #define VC_ARGS x, dy, tbl, n_out, kv, rpb, nsplit, g_bw_legacy_order, partial, rep, centre, dy_grp
   bool launched = false;
@@ -2643,6 +2817,7 @@ int vc_debug_set(const char* key, int value) {
   if (key && !strcmp(key, "conv_wdma")) { g_conv_wdma = value; return VC_OK; }
   if (key && !strcmp(key, "conv_winrows")) { g_conv_winrows = value; return VC_OK; }
   if (key && !strcmp(key, "bw_legacy_order")) { g_bw_legacy_order = value; return VC_OK; }
+  if (key && !strcmp(key, "bw_variant")) { g_bw_variant = value; return VC_OK; }
   if (key && !strcmp(key, "bw_rows_per_split")) { if (value >= 256) g_bw_rows_per_split = value; return VC_OK; }
   if (key && !strcmp(key, "pass_dw_main_tail")) { g_pass_dw_main_tail = value; return VC_OK; }
   if (key && !strcmp(key, "pass_bwd_epilogue")) { g_pass_bwd_epilogue = value; return VC_OK; }
