@@ -206,6 +206,9 @@ def run_infer(args, model, batch, device, rank, world):
 
     for _ in range(args.warmup):
         step()
+    be = ops.get_backend()
+    tdir, tck, tcn = args.trace.split(",")
+    be.trace_begin(tdir, int(tck), int(tcn))     # the same instantiation as the train line (here with the eval-BatchNorm epilogue)
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -214,6 +217,7 @@ def run_infer(args, model, batch, device, rank, world):
     torch.cuda.synchronize()
     parallel.barrier()
     dt = parallel.max_over_ranks(time.perf_counter() - t0, device)
+    trace = be.trace_end()
     # the loop above keeps two frames in flight (the geometry plan of frame f + 1 over the feature pass of frame f): throughput.
     # Latency of ONE frame with an idle GPU in front of it, for the record (median of 10, outside the timed region):
     lat = []
@@ -233,7 +237,8 @@ def run_infer(args, model, batch, device, rank, world):
                           "config": {"workload": "BASELINE configs[1]: VirConv-L forward only, eval mode, + dense(); two frames in "
                                                  "flight (plan of the next frame over the feature pass of this one)",
                                      "frames_per_gpu": bs, "voxels_rank0": int(batch["voxel_features"].shape[0]),
-                                     "single_step_latency_ms": round(lat_ms, 3)}}), flush=True)
+                                     "single_step_latency_ms": round(lat_ms, 3)},
+                          "roofline": _traced_roofline(trace, args, tdir, tck, tcn, pmc=False), "cpu_baseline": None}), flush=True)
 
 
 def _pmc_traffic(tdir, tck, tcn):
@@ -249,6 +254,28 @@ def _pmc_traffic(tdir, tck, tcn):
         except Exception:
             continue
     return None, None
+
+
+def _traced_roofline(trace, args, tdir, tck, tcn, pmc):
+    """`roofline` object of the traced gather-GEMM instantiation: algorithmic flops of its launches / their HIP-event durations."""
+    n_launch = len(trace)
+    if not n_launch:
+        return None
+    t_ms = sum(e["ms"] for e in trace)
+    flops = sum(e["flops"] for e in trace)
+    byts = sum(e["bytes"] for e in trace)
+    ach = flops / (t_ms * 1e-3) / 1e12
+    peak = MFMA_F32_PEAK_TFLOPS if args.operand == "f32" else MFMA_16BIT_PEAK_TFLOPS
+    traffic, traffic_src = _pmc_traffic(tdir, tck, tcn) if (pmc and args.operand == "f32") else (None, None)
+    return {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": (f"gather_gemm_v3_kernel<CK={tck},CN={tcn},BWD={'true' if tdir == 'bwd' else 'false'}> (LDS row windows)"
+                       if all(e["windowed"] for e in trace) else
+                       f"gather_gemm_v2_kernel<CK={tck},CN={tcn},BWD={'true' if tdir == 'bwd' else 'false'},RT=1>"),
+            "launches": n_launch, "avg_us": round(t_ms / n_launch * 1e3, 2),
+            "algorithmic_gflop_per_launch": round(flops / n_launch / 1e9, 4),
+            "algorithmic_mb_per_launch": round(byts / n_launch / 1e6, 3),
+            "hbm_frac_of_algorithmic_bytes": round(byts / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
 def main():
@@ -392,24 +419,9 @@ def main():
     if rank != 0:
         return
     frames = bs * world * args.steps
-    n_launch = len(trace)
-    roof = None
-    if n_launch:
-        t_ms = sum(e["ms"] for e in trace)
-        flops = sum(e["flops"] for e in trace)
-        byts = sum(e["bytes"] for e in trace)
-        ach = flops / (t_ms * 1e-3) / 1e12
-        peak = MFMA_F32_PEAK_TFLOPS if args.operand == "f32" else MFMA_16BIT_PEAK_TFLOPS
-        traffic, traffic_src = _pmc_traffic(tdir, tck, tcn) if args.operand == "f32" else (None, None)
-        roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": (f"gather_gemm_v3_kernel<CK={tck},CN={tcn},BWD={'true' if tdir == 'bwd' else 'false'}> (LDS row windows)"
-                           if all(e["windowed"] for e in trace) else
-                           f"gather_gemm_v2_kernel<CK={tck},CN={tcn},BWD={'true' if tdir == 'bwd' else 'false'},RT=1>"),
-                "launches": n_launch, "avg_us": round(t_ms / n_launch * 1e3, 2),
-                "algorithmic_gflop_per_launch": round(flops / n_launch / 1e9, 4),
-                "algorithmic_mb_per_launch": round(byts / n_launch / 1e6, 3),
-                "hbm_frac_of_algorithmic_bytes": round(byts / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    roof = _traced_roofline(trace, args, tdir, tck, tcn, pmc=True)
+    if roof is not None:
+        peak = roof["peak"]
         if fam:
             # family: all conv kernels of the step (forward, backward-input, weight gradient) -- algorithmic flops / kernel time;
             # step: the same flops over the WALL time of a step (everything else -- BatchNorm, rulebooks, optimizer -- counts as loss)
