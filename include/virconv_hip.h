@@ -53,6 +53,8 @@ const char* vc_version(void);
 const char* vc_last_error(void);
 /* developer switch for A/B measurements (tools/kbench.py): "conv_variant" = 1 | 2 */
 int vc_debug_set(const char* key, int value);
+/* developer counters: "conv_bn_finish_launches" = conv launches of this process that finished their BatchNorm sums in-kernel */
+int vc_debug_get(const char* key, int64_t* value);
 
 /* ------------------------------------------------------------------------------------------------ K3 hash
  * Coordinate -> row hash (open addressing, 64-bit linearised key, duplicate rule rep(c) = max row; SURVEY

@@ -67,6 +67,10 @@ class HipBackend:
             check(self.lib.vc_debug_set(b"conv_dxs", int(os.environ["VIRCONV_CONV_DXS"])), "vc_debug_set")
         if os.environ.get("VIRCONV_CONV_V4"):   # wave-autonomous gather-GEMM: 0 never | 1 every eligible shape | 2 library table
             check(self.lib.vc_debug_set(b"conv_v4", int(os.environ["VIRCONV_CONV_V4"])), "vc_debug_set")
+        # generic A/B switches for every tool that builds a backend: VIRCONV_DEBUG_SET="key=value,key=value" -> vc_debug_set
+        for kv in filter(None, os.environ.get("VIRCONV_DEBUG_SET", "").split(",")):
+            key, val = kv.split("=")
+            check(self.lib.vc_debug_set(key.strip().encode(), int(val)), f"vc_debug_set {kv}")
 
     # ------------------------------------------------------------------ kernel timing for bench.py's roofline
     native_pass = True   # vc_pass_forward / vc_pass_backward are available (virconv_amd/feature_pass.py)

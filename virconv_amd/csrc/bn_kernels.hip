@@ -513,6 +513,20 @@ int g_bn_fused_partial = 0;
 
 static inline bool bn_c_ok(int c) { return c == 4 || c == 8 || c == 16 || c == 32 || c == 64 || c == 128; }
 
+int bn_bwd_dx_launch(const float* x, const float* dy, int dy_stride, int dy_col0, int64_t n, int c, const float* mean,
+                     const float* var, const float* gamma, const float* beta, float eps, int relu, const float* sums, float* dx,
+                     hipStream_t st) {
+  VC_REQUIRE(bn_c_ok(c) && n >= 1 && x && dy && mean && var && sums && dx, "bn_bwd_dx_launch: null/invalid argument");
+  VC_REQUIRE(dy_stride >= c && dy_stride % 4 == 0 && dy_col0 % 4 == 0 && dy_col0 + c <= dy_stride, "bn_bwd_dx_launch: bad stride arguments");
+  const int lg = bn_lg_c4(c);
+  VC_REQUIRE(lg >= 0, "bn_bwd_dx_launch: channel count must be a power of two");
+  const int rows_per_block = (256 >> lg) * kBnRowsPerThread;
+  hipLaunchKernelGGL(bn_bwd_dx_pow2_kernel, dim3((unsigned)cdiv(n, rows_per_block)), dim3(256), 0, st, x, dy, dy_stride, dy_col0,
+                     n, c, lg, mean, var, gamma, beta, eps, relu, sums, dx, (unsigned*)nullptr);
+  VC_CHECK_LAUNCH("bn_bwd_dx_kernel");
+  return VC_OK;
+}
+
 }  // namespace vc
 
 using namespace vc;
@@ -559,7 +573,7 @@ int vc_bn_stats_from_partial(const float* partial, int64_t nblocks, int64_t n, i
   if (nblocks > 512 && ws != nullptr && 2 * c <= 256 && (c & (c - 1)) == 0) {
     // many partial rows: coalesced slab reduce to <= 256 fp64 rows, then the ordinary finalize
     if (ws_bytes < vc_bn_workspace_bytes(n, c)) { set_error("vc_bn_stats_from_partial: workspace too small"); return VC_ECAPACITY; }
-    const int64_t rpb = cdiv(nblocks, 256);
+    const int64_t rpb = bn_partial_rows_per_group(nblocks);
     const int g = (int)cdiv(nblocks, rpb);
     double* dpartial = (double*)ws;
     hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(g), dim3(256), 0, st, partial, nblocks, rpb, c, dpartial);
@@ -646,7 +660,7 @@ int vc_bn_relu_backward_from_partial(const float* x, const float* dy, int dy_str
                        sums, (float*)nullptr, (long long*)nullptr, 0.f, absmax_out);
     VC_CHECK_LAUNCH("bn_partial_fused_kernel<bwd>");
   } else {
-    const int64_t rpb = cdiv(nblocks, 256);
+    const int64_t rpb = bn_partial_rows_per_group(nblocks);
     const int g = (int)cdiv(nblocks, rpb);
     hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(g), dim3(256), 0, st, fpartial, nblocks, rpb, c, partial);
     VC_CHECK_LAUNCH("bn_partial_reduce_kernel");

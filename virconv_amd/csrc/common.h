@@ -157,6 +157,30 @@ static inline uint64_t hash_capacity(int64_t n) {  // point hash of the voxelize
   return cap;
 }
 
+// BatchNorm sums out of conv-epilogue partial rows: the rows are reduced in groups of `bn_partial_rows_per_group` consecutive
+// rows (<= 256 groups; a multiple of 8 rows, so that a group is a whole number of 4- or 8-wave conv blocks), then over the
+// groups.  The same grouping is used by the two-launch route (bn_partial_reduce_kernel + finalize) and by the in-kernel finish
+// of the gather-GEMM (conv_finish_tail), which therefore agree bit for bit.
+static inline int64_t bn_partial_rows_per_group(int64_t nrows) { return (cdiv(nrows, 256) + 7) & ~(int64_t)7; }
+
+// In-kernel finish of the BatchNorm sums (conv_kernels.hip): a caller arms a request, the next epilogue launch of this host
+// thread takes it if its kernel supports the finish (the v2 gather-GEMM with > 512 partial rows), conv_finish_take() tells.
+struct BnFinishRequest {
+  int bwd;             // 0: statistics (mean, var, running statistics); 1: backward sums (dbeta, dgamma, sums[2][c])
+  int64_t n;           // rows of the tensor the statistics are over
+  float *o0, *o1;      // stats: mean, var;  bwd: dbeta, dgamma (may be null)
+  float *r0, *r1;      // stats: running mean / var (may be null);  bwd: r0 = sums[2][c]
+  long long* nbt;      // stats: num_batches_tracked (may be null)
+  float momentum;
+  double* dpartial;    // >= 256 x 2c doubles of scratch, private to the launch while it runs
+};
+void conv_finish_arm(const BnFinishRequest& r);
+bool conv_finish_take();   // true: the launch since the last arm finished the sums itself; always disarms
+// the dx kernel of the BatchNorm(+ReLU) backward alone, the per-channel sums given (bn_kernels.hip)
+int bn_bwd_dx_launch(const float* x, const float* dy, int dy_stride, int dy_col0, int64_t n, int c, const float* mean,
+                     const float* var, const float* gamma, const float* beta, float eps, int relu, const float* sums, float* dx,
+                     hipStream_t st);
+
 static inline uint64_t coord_hash_capacity(int64_t n) {
   uint64_t oct = 128;
   while (oct <= (uint64_t)n) oct <<= 1;

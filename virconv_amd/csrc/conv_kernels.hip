@@ -12,6 +12,8 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 
 #include "common.h"
 
@@ -289,6 +291,27 @@ struct BufLoad<1> {
 //                  PRODUCED this conv's input -- sum(dy_masked), sum(dy_masked * xhat) per channel, per-wave partial rows as in
 //                  STATS -- are formed from the stored tile and that unit's pre-BatchNorm output: the unit's separate reduction
 //                  pass over (y_raw, dy) and the gradient-add kernel disappear
+// In-kernel finish of the BatchNorm sums (round 3): the v2 kernel's STATS / BWD epilogue can carry the per-wave partial rows all
+// the way to the finished per-channel numbers, instead of leaving them to bn_partial_reduce_kernel + a finalize kernel -- two
+// 5-6 us launches (and two kernel boundaries) per BatchNorm on the main stream's critical path, 55 of them per train step.
+// Arrival tickets, no spinning (MI355X guide, "in-launch split-K reduction", write-through form): every block stores its
+// partial rows write-through (sc1), waits for them (vmcnt(0)), and draws a ticket of its GROUP (bn_partial_rows_per_group
+// consecutive rows = a whole number of blocks); the block that draws the group's last ticket adds the group's rows up exactly
+// as bn_partial_reduce_kernel does (fp64, same order), stores the fp64 row write-through and draws a ticket of the launch; the
+// block that draws the last of those adds the <= 256 group rows up exactly as the finalize kernels do and writes the results.
+// Which block does a reduction varies from run to run, WHAT it computes does not: the results are bit-identical to the
+// two-launch route and run-to-run stable.  The last block also clears the tickets (they are zero between launches).
+struct ConvFinish {
+  unsigned* cnt = nullptr;   // [0]: launch tickets, [1 + g]: tickets of group g; nullptr: no in-kernel finish
+  double* dpartial = nullptr;  // [ngroups][2 CN]
+  float *o0 = nullptr, *o1 = nullptr, *r0 = nullptr, *r1 = nullptr;   // see BnFinishRequest
+  long long* nbt = nullptr;
+  long long n = 0;
+  float momentum = 0.f;
+  int bwd = 0;
+  int rpb = 0, ngroups = 0, nrows = 0;   // partial rows per group, groups, partial rows (= blocks x waves per block)
+};
+
 struct ConvEpilogue {
   float* partial;        // STATS / BWD
   const float* mean;     // AFFINE (running statistics) / BWD (batch statistics of the producing unit)
@@ -300,7 +323,115 @@ struct ConvEpilogue {
   const float* y_raw = nullptr;    // BWD: pre-BatchNorm output of the producing unit, (rows of this launch) x CN
   const float* addend = nullptr;   // BWD: out += addend[:, add_col0 : add_col0 + CN] (row stride add_stride)
   int add_stride = 0, add_col0 = 0;
+  ConvFinish fin{};                // STATS / BWD statistics: finish the sums inside this launch
 };
+
+__device__ __forceinline__ float ld_agent(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // global_load sc1: past this CU's L1
+}
+__device__ __forceinline__ double ld_agent(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // global_store sc1: write-through
+}
+__device__ __forceinline__ void st_agent(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Tail of a v2 block whose launch finishes the BatchNorm sums (see ConvFinish).  Called by ALL threads of the block after the
+// partial rows of its waves were stored with st_agent; `smem` is the block's dynamic LDS (>= 2 KB + 16 B, free by now).
+template <int CN, int NTHR>
+__device__ __forceinline__ void conv_finish_tail(const ConvFinish& f, const float* __restrict__ partial, int lbid, int wave,
+                                                 unsigned char* smem) {
+  constexpr int C2 = 2 * CN;
+  constexpr int RS = 256 / C2;             // row sub-threads of the group reduce (bn_partial_reduce_kernel's mapping)
+  constexpr int NWV = NTHR / 64;
+  static_assert(C2 <= 256 && (C2 & (C2 - 1)) == 0, "in-kernel BatchNorm finish: power-of-two channel count <= 128");
+  // lane from mbcnt, thread index from (wave, lane): nothing of the main loop's registers has to stay alive for this tail
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int tid = wave * 64 + lane;
+  int* s_flag = reinterpret_cast<int*>(smem + 2048);
+  double* s_red = reinterpret_cast<double*>(smem);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through partial-row stores have left
+  __syncthreads();
+  const int grp = (lbid * NWV) / f.rpb;
+  const int g_r0 = grp * f.rpb, g_r1 = min(g_r0 + f.rpb, f.nrows);
+  if (tid == 0) {
+    const unsigned want = (unsigned)((g_r1 - g_r0) / NWV);   // blocks of this group
+    const unsigned t = __hip_atomic_fetch_add(&f.cnt[1 + grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t + 1u == want) ? 1 : 0;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    s_flag[0] = last;
+  }
+  __syncthreads();
+  if (s_flag[0] == 0) return;   // block-uniform
+  // ---- level 1: this group's rows -> one fp64 row (arithmetic of bn_partial_reduce_kernel: thread = (row sub-index, column))
+  if (tid < 256) {
+    const int col = tid % C2, rs = tid / C2;
+    double acc = 0.0;
+    int r = g_r0 + rs;
+    for (; r + 7 * RS < g_r1; r += 8 * RS) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ld_agent(partial + (int64_t)(r + u * RS) * C2 + col);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (double)v[u];
+    }
+    for (; r < g_r1; r += RS) acc += (double)ld_agent(partial + (int64_t)r * C2 + col);
+    s_red[tid] = acc;
+  }
+  __syncthreads();
+  if (tid < C2) {
+    double t = s_red[tid];
+    for (int u = 1; u < RS; ++u) t += s_red[u * C2 + tid];
+    st_agent(f.dpartial + (int64_t)grp * C2 + tid, t);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned t = __hip_atomic_fetch_add(&f.cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t + 1u == (unsigned)f.ngroups) ? 1 : 0;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    s_flag[0] = last;
+  }
+  __syncthreads();
+  if (s_flag[0] == 0) return;
+  // ---- level 2: the group rows -> per-channel numbers (arithmetic of bn_stats_finalize_kernel / bn_bwd_finalize_kernel: lane l
+  // adds rows l, l + 64, ... in that order, then the xor butterfly 32 .. 1); one wave per channel, channels strided over the waves
+  for (int ch = wave; ch < CN; ch += NWV) {
+    double s = 0.0, ss = 0.0;
+    for (int b = lane; b < f.ngroups; b += 64) {
+      s += ld_agent(f.dpartial + (int64_t)b * C2 + ch);
+      ss += ld_agent(f.dpartial + (int64_t)b * C2 + CN + ch);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      s += __shfl_xor(s, off, 64);
+      ss += __shfl_xor(ss, off, 64);
+    }
+    if (lane != 0) continue;
+    if (f.bwd) {
+      if (f.o0) f.o0[ch] = (float)s;     // dbeta
+      if (f.o1) f.o1[ch] = (float)ss;    // dgamma
+      f.r0[ch] = (float)s;               // sums[0][ch]
+      f.r0[CN + ch] = (float)ss;         // sums[1][ch]
+    } else {
+      const double m = s / (double)f.n;
+      double v = ss / (double)f.n - m * m;
+      if (v < 0.0) v = 0.0;
+      f.o0[ch] = (float)m;
+      f.o1[ch] = (float)v;
+      if (f.r0) f.r0[ch] = (1.f - f.momentum) * f.r0[ch] + f.momentum * (float)m;
+      if (f.r1) {
+        const double unb = (f.n > 1) ? v * (double)f.n / (double)(f.n - 1) : v;
+        f.r1[ch] = (1.f - f.momentum) * f.r1[ch] + f.momentum * (float)unb;
+      }
+      if (ch == 0 && f.nbt) *f.nbt += 1;
+    }
+  }
+  for (int j = tid; j <= f.ngroups; j += NTHR) f.cnt[j] = 0u;   // every ticket of this launch has been drawn
+}
 static constexpr int VC_EPI_BWD = 3;  // internal (not part of vc_epilogue: selected by vc_conv_backward_input_epilogue)
 
 // DXS ("dx shift", 27-offset tables, one tile per wave): the offsets of one (dz, dy) group are the dx = -1 / 0 / +1 taps.  Where
@@ -317,8 +448,17 @@ static constexpr int VC_EPI_BWD = 3;  // internal (not part of vc_epilogue: sele
 // i = 0..15) read 256 CONTIGUOUS bytes when their rows are consecutive (x-adjacent voxels of a sorted tensor), i.e. 4 cache lines
 // per quarter instead of 16: the L1 tag look-ups per gather instruction are what paces this kernel's vector-memory pipeline
 // (8.0-8.7 TB/s for the row-major MFMA mapping against 14.5 TB/s when a quad of lanes shares a line).
+// Occupancy target of an instantiation (waves per SIMD the register allocation must allow; 1 = no requirement).  The
+// backward-epilogue kernels with 64 output channels sat exactly on the 64-VGPR line (8 waves) before the in-kernel BatchNorm
+// finish was added and came out 1-2 registers above it with the tail inlined; pinned back (no scratch, tools/vgpr_table.py).
+template <int CK, int CN, int EPI, int NW, bool PK, bool DXS>
+constexpr int v2_min_waves() {
+  return (EPI == 3 /* VC_EPI_BWD */ && CN == 64 && CK <= 32 && !DXS && !(CK == 32 && NW == 4 && !PK)) ? 8 : 1;
+}
+
 template <int CK, int CN, bool BWD, int RT, int OT, int EPI, int NW = 4, bool PK = false, bool DXS = false, bool IL = false>
-__global__ void __launch_bounds__(64 * NW) gather_gemm_v2_kernel(const float* __restrict__ src,
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(v2_min_waves<CK, CN, EPI, NW, PK, DXS>())))
+gather_gemm_v2_kernel(const float* __restrict__ src,
                                                              const float* __restrict__ src_centre, int64_t n_src,
                                                              const int32_t* __restrict__ tbl,
                                                              const float* __restrict__ w, float* __restrict__ out,
@@ -638,7 +778,10 @@ __global__ void __launch_bounds__(64 * NW) gather_gemm_v2_kernel(const float* __
       sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
       sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
       const int n = nt * 16 + i;
-      if (q == 0 && n < CN) { prow[n] = sm; prow[CN + n] = sq; }
+      if (q == 0 && n < CN) {
+        if (epi.fin.cnt != nullptr) { st_agent(prow + n, sm); st_agent(prow + CN + n, sq); }   // read by another block of this launch
+        else { prow[n] = sm; prow[CN + n] = sq; }
+      }
     }
   }
   float sc[NT], sh[NT];
@@ -712,9 +855,15 @@ __global__ void __launch_bounds__(64 * NW) gather_gemm_v2_kernel(const float* __
         sa += __shfl_xor(sa, 16, 64); sb += __shfl_xor(sb, 16, 64);
         sa += __shfl_xor(sa, 32, 64); sb += __shfl_xor(sb, 32, 64);
         const int n = nt * 16 + i;
-        if (q == 0 && n < CN) { prow[n] = sa; prow[CN + n] = sb; }
+        if (q == 0 && n < CN) {
+          if (epi.fin.cnt != nullptr) { st_agent(prow + n, sa); st_agent(prow + CN + n, sb); }
+          else { prow[n] = sa; prow[CN + n] = sb; }
+        }
       }
     }
+  }
+  if constexpr ((EPI == VC_EPI_STATS || EPI == VC_EPI_BWD) && RT == 1 && (CN & (CN - 1)) == 0) {
+    if (epi.fin.cnt != nullptr) conv_finish_tail<CN, NTHR>(epi.fin, epi.partial, (int)lbid, wave, smem);   // kernel-uniform
   }
 }
 
@@ -2379,11 +2528,73 @@ static inline bool use_window_kernel(int flags, int ot, const int32_t* rep, cons
          rep == nullptr && order == nullptr && src_centre == nullptr && kv <= 32 && n_src * CK * 4 < (1LL << 31);
 }
 
+// ---- in-kernel BatchNorm finish: request hand-over (see BnFinishRequest in common.h) and the ticket pool
+// vc_debug_set "conv_bn_finish": 1 = the epilogue launches finish the BatchNorm sums themselves.  OFF by default -- measured
+// (profiles/r03_bn_finish_in_kernel.md): bit-identical and stable, 75 launches fewer per train step, but the launch's LAST block
+// walks the <= 256 group rows one channel per wave at a time (1.7 us per trip of dependent loads): the conv launches grow by
+// 8 (C = 8) to 29 us (C = 64) against the 13 us (two 5-6 us kernels + two boundaries) they save; train step 5.64 vs 5.45-5.59 ms.
+int g_conv_bn_finish = 0;
+static std::atomic<long long> g_fin_launches{0};   // vc_debug_get "conv_bn_finish_launches"
+struct FinState { bool armed = false, taken = false; BnFinishRequest req{}; };
+static thread_local FinState t_fin;
+void conv_finish_arm(const BnFinishRequest& r) { t_fin.armed = true; t_fin.taken = false; t_fin.req = r; }
+bool conv_finish_take() {
+  const bool t = t_fin.taken;
+  t_fin.armed = t_fin.taken = false;
+  return t;
+}
+// Tickets: kFinSlots x kFinSlotWords zero words per device, allocated once; launches take the slots round-robin.  A slot is
+// all-zero again when its launch ends (the last block clears it); launches of one stream are ordered, so a slot could only be
+// handed to a second launch in flight if kFinSlots finishing launches were outstanding on concurrent streams at once.
+static constexpr int kFinSlots = 256, kFinSlotWords = 288;   // 1 + <= 256 group tickets
+static unsigned* fin_ticket_slot() {
+  static std::mutex mu;
+  static unsigned* base[32] = {};
+  static unsigned next = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (base[dev] == nullptr) {
+    void* p = nullptr;
+    const size_t bytes = (size_t)kFinSlots * kFinSlotWords * sizeof(unsigned);
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return nullptr; }
+    base[dev] = (unsigned*)p;
+  }
+  return base[dev] + (size_t)(next++ % kFinSlots) * kFinSlotWords;
+}
+// attach the armed request to this launch's epilogue if the launch qualifies; `lds` = the launch's dynamic LDS bytes
+static void fin_attach(ConvEpilogue& epi, int epi_kind, unsigned nblocks, int nw, int cn, size_t& lds) {
+  if (!t_fin.armed || t_fin.taken || !g_conv_bn_finish) return;
+  const bool bwd = epi_kind == VC_EPI_BWD;
+  if (!(epi_kind == VC_EPI_STATS || (bwd && epi.y_raw != nullptr)) || (t_fin.req.bwd != 0) != bwd) return;
+  const int64_t nrows = (int64_t)nblocks * nw;
+  if (nrows <= 512 || (cn & (cn - 1)) != 0 || 2 * cn > 256 || t_fin.req.dpartial == nullptr) return;
+  if (bwd ? (t_fin.req.r0 == nullptr) : (t_fin.req.o0 == nullptr || t_fin.req.o1 == nullptr)) return;
+  unsigned* cnt = fin_ticket_slot();
+  if (cnt == nullptr) return;
+  ConvFinish& f = epi.fin;
+  f.cnt = cnt;
+  f.dpartial = t_fin.req.dpartial;
+  f.o0 = t_fin.req.o0; f.o1 = t_fin.req.o1; f.r0 = t_fin.req.r0; f.r1 = t_fin.req.r1;
+  f.nbt = t_fin.req.nbt;
+  f.n = (long long)t_fin.req.n;
+  f.momentum = t_fin.req.momentum;
+  f.bwd = bwd ? 1 : 0;
+  f.rpb = (int)bn_partial_rows_per_group(nrows);
+  f.ngroups = (int)cdiv(nrows, (int64_t)f.rpb);
+  f.nrows = (int)nrows;
+  if (lds < 2048 + 16) lds = 2048 + 16;
+  t_fin.taken = true;
+  g_fin_launches.fetch_add(1, std::memory_order_relaxed);
+}
+
 template <int CK, int CN, bool BWD>
 static int launch_gg(const float* src, const float* src_centre, int64_t n_src, const int32_t* tbl, const float* w,
                      float* out, const int32_t* rep, const int32_t* order, int64_t n_out, int kv, int centre, int mirror, int ot,
-                       int epi_kind, const ConvEpilogue& epi, int flags, hipStream_t st) {
+                       int epi_kind, const ConvEpilogue& epi_in, int flags, hipStream_t st) {
   const int64_t rows_per_block = 4 * kRT * 16;
+  ConvEpilogue epi = epi_in;
   g_last_windowed = false;
   // fragment-ordered weight image registered for this weight tensor and direction (vc_conv_pack_weights), or -- developer
   // switch conv_autopack, for stand-alone kernel timing -- packed right here into a scratch the library owns
@@ -2537,8 +2748,9 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
     if constexpr (CK >= 16 && CN >= 16) {
       if (conv_block_waves(CK, CN, BWD, n_out, order != nullptr) == 8 && !half_ops && rt == 1 && epi_kind != VC_EPI_AFFINE) {
         // 8-wave blocks (128 rows): see the kernel's NW parameter
-        const size_t lds8 = (size_t)2 * NCH * NT * 64 * V * sizeof(float) + (size_t)(kv + 1) * 128 * sizeof(int) + 16;
+        size_t lds8 = (size_t)2 * NCH * NT * 64 * V * sizeof(float) + (size_t)(kv + 1) * 128 * sizeof(int) + 16;
         const dim3 grid8((unsigned)cdiv(n_out, 128));
+        fin_attach(epi, epi_kind, grid8.x, 8, CN, lds8);
 #define VC_L8(B_, E_)                                                                                                          \
   do {                                                                                                                         \
     if constexpr (CN % 16 == 0) {                                                                                              \
@@ -2576,9 +2788,10 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
         return VC_OK;
       }
     }
-    const size_t lds = (size_t)2 * NCH * NT * 64 * V * (half_ops ? 2 : sizeof(float)) +
-                       (size_t)(kv + 1) * 64 * rt * sizeof(int) + 16;
+    size_t lds = (size_t)2 * NCH * NT * 64 * V * (half_ops ? 2 : sizeof(float)) +
+                 (size_t)(kv + 1) * 64 * rt * sizeof(int) + 16;
     const dim3 grid((unsigned)cdiv(n_out, (int64_t)64 * rt));
+    if (!half_ops && rt == 1) fin_attach(epi, epi_kind, grid.x, 4, CN, lds);
 #define VC_ARGS src, src_centre, n_src, tbl, w, out, rep, order, n_out, kv, centre, mirror, epi
 #define VC_ARGS_PK src, src_centre, n_src, tbl, wpk, out, rep, order, n_out, kv, centre, mirror, epi
     // fp32, one tile per wave, 4-wave blocks: the fragment-ordered weight image when there is one
@@ -2794,6 +3007,13 @@ using namespace vc;
 
 extern "C" {
 
+int vc_debug_get(const char* key, int64_t* value) {
+  VC_REQUIRE(key && value, "vc_debug_get: null argument");
+  if (!strcmp(key, "conv_bn_finish_launches")) { *value = (int64_t)g_fin_launches.load(std::memory_order_relaxed); return VC_OK; }
+  set_error("vc_debug_get: unknown key %s", key);
+  return VC_EINVAL;
+}
+
 int vc_debug_set(const char* key, int value) {
   if (key && !strcmp(key, "conv_variant")) { g_conv_variant = value; return VC_OK; }
   if (key && !strcmp(key, "conv_rt")) { g_conv_rt = value; return VC_OK; }
@@ -2822,6 +3042,7 @@ int vc_debug_set(const char* key, int value) {
   if (key && !strcmp(key, "pass_dw_main_tail")) { g_pass_dw_main_tail = value; return VC_OK; }
   if (key && !strcmp(key, "pass_bwd_epilogue")) { g_pass_bwd_epilogue = value; return VC_OK; }
   if (key && !strcmp(key, "bn_fused_partial")) { g_bn_fused_partial = value; return VC_OK; }
+  if (key && !strcmp(key, "conv_bn_finish")) { g_conv_bn_finish = value; return VC_OK; }
   if (key && !strcmp(key, "pass_defer_dw_reduce")) { g_pass_defer_dw_reduce = value; return VC_OK; }
   if (key && !strcmp(key, "xcd_swizzle_off")) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_swizzle_off), &value, sizeof(int)) == hipSuccess ? VC_OK : VC_EHIP;

@@ -305,7 +305,8 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
   }
   for (int b = 0; b < p->n_bufs; ++b)
     if (n_writers[b] != 1) prod_unit[b] = -1;
-  struct FusedSums { const float* partial = nullptr; int64_t nblocks = 0; };
+  // sums != nullptr: the epilogue launch finished them itself (conv_finish_tail), only the dx kernel is left
+  struct FusedSums { const float* partial = nullptr; int64_t nblocks = 0; const float* sums = nullptr; };
   std::vector<FusedSums> fused(p->n_ops);  // per unit op: BatchNorm-backward sums delivered by a conv epilogue
 
   hipEvent_t* ev = (side != nullptr && !dry) ? pass_events() : nullptr;
@@ -362,8 +363,9 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
         }
         cprod = prod_unit[o.src];
         if (cprod >= 0) {
+          // partial rows, then 2 x cin floats for the finished sums and 256 fp64 group rows (in-kernel finish)
           const size_t pf = vc_conv_bwd_stats_partial_floats(t.n_in, u.cin, u.cout, t.order_bwd != nullptr);
-          fpart = at(bump.take(pf * sizeof(float)));
+          fpart = at(bump.take((pf + 2 * (size_t)u.cin) * sizeof(float) + 64 + (size_t)256 * 2 * u.cin * sizeof(double)));
           fused[cprod].partial = dry ? marker : fpart;
           fused[cprod].nblocks = (int64_t)(pf / (2 * (size_t)u.cin));
         }
@@ -383,7 +385,10 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
         VC_REQUIRE(t.grp_plan && (u.cout & (u.cout - 1)) == 0,
                    "vc_pass_backward: duplicate-pixel table needs its group plan (vc_pass_table.grp_plan, vc_group_sum_sorted)");
       }
-      if (fused[i].partial != nullptr)
+      if (fused[i].sums != nullptr)
+        rc = bn_bwd_dx_launch(y_raw, g.p, g.stride, g.col0 + o.dst_col0, t.n_out, u.cout, mean, var, u.gamma, u.beta, u.eps, o.relu,
+                              fused[i].sums, d_raw, st);
+      else if (fused[i].partial != nullptr)
         rc = vc_bn_relu_backward_from_partial(y_raw, g.p, g.stride, g.col0 + o.dst_col0, t.n_out, u.cout, mean, var, u.gamma,
                                               u.beta, u.eps, o.relu, fused[i].partial, fused[i].nblocks, d_raw,
                                               u.dgamma ? u.dgamma : dgb, u.dbeta ? u.dbeta : dgb + u.cout,
@@ -430,11 +435,19 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
             cmean = (const float*)((const char*)fwd_arena + L.stats_off[cprod]);
             cvar = cmean + cu.cout;
             cg = cu.gamma; cb = cu.beta; ceps = cu.eps; crelu = p->ops[cprod].relu;
+            if (cu.dgamma && cu.dbeta) {  // this launch may finish the producing unit's sums itself
+              const size_t pf = (size_t)fused[cprod].nblocks * 2 * u.cin;
+              float* sums = fpart + pf;
+              double* dpart = (double*)(((uintptr_t)(sums + 2 * u.cin) + 63) & ~(uintptr_t)63);
+              conv_finish_arm(BnFinishRequest{1, (int64_t)p->tables[p->ops[cprod].table].n_out, cu.dbeta, cu.dgamma, sums, nullptr,
+                                              nullptr, 0.f, dpart});
+            }
           }
           rc = vc_conv_backward_input_epilogue(src, src_centre, t.n_out, t.subm ? t.pair_fwd : t.pair_bwd, t.n_in, t.kv, u.weight,
                                                u.cin, u.cout, t.subm ? 1 : 0, dup ? t.centre : -1, dup ? t.rep : nullptr,
                                                t.order_bwd, flags, addv.p, addv.stride, addv.col0, cy, cmean, cvar, cg, cb, ceps,
                                                crelu, fpart, dx, st);
+          if (conv_finish_take() && cprod >= 0) fused[cprod].sums = fpart + (size_t)fused[cprod].nblocks * 2 * u.cin;
         } else {
           rc = vc_conv_backward_input(src, src_centre, t.n_out, t.subm ? t.pair_fwd : t.pair_bwd, t.n_in, t.kv, u.weight, u.cin,
                                       u.cout, t.subm ? 1 : 0, dup ? t.centre : -1, dup ? t.rep : nullptr, t.order_bwd,

@@ -39,11 +39,16 @@ int vc_post_act_block_forward(const float* x, int64_t n_in, const int32_t* pair_
   // the shape; else from a pass over y_raw
   const size_t pf = vc_conv_stats_partial_floats(n_in, n_out, cin, cout, kv, flags);
   if (operand_type == VC_OPERAND_F32 && vc_conv_epilogue_supported(n_in, cin, cout, kv, VC_OPERAND_F32)) {
+    // the conv launch finishes the statistics itself where its kernel can (conv_finish_tail: no reduce / finalize launches)
+    conv_finish_arm(BnFinishRequest{0, n_out, mean, var, running_mean, running_var, (long long*)num_batches_tracked, momentum,
+                                    (double*)bn_ws});
     rc = vc_conv_forward_epilogue(x, n_in, pair_fwd, n_out, kv, weight, cin, cout, row_order, VC_EPI_STATS, flags, partial,
                                   nullptr, nullptr, nullptr, nullptr, 0.f, 0, y_raw, stream);
+    const bool finished = conv_finish_take();
     if (rc != VC_OK) return rc;
-    rc = vc_bn_stats_from_partial(partial, (int64_t)(pf / (2 * (size_t)cout)), n_out, cout, mean, var, running_mean,
-                                  running_var, num_batches_tracked, momentum, bn_ws, bn_bytes, stream);
+    if (!finished)
+      rc = vc_bn_stats_from_partial(partial, (int64_t)(pf / (2 * (size_t)cout)), n_out, cout, mean, var, running_mean,
+                                    running_var, num_batches_tracked, momentum, bn_ws, bn_bytes, stream);
   } else {
     rc = vc_conv_forward(x, n_in, pair_fwd, n_out, kv, weight, cin, cout, row_order, operand_type, flags, y_raw, stream);
     if (rc != VC_OK) return rc;
