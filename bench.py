@@ -138,12 +138,12 @@ def make_loss_weights(device):
 
 def synthetic_loss(out, lw):
     """loss = (out.dense() * G).sum() + sum_i (x_conv_i.features * g_i).sum()   (the heads are out of scope).
-    The per-scale terms are written sum(X * g) = <X.sum(0), g>: one column reduction instead of an elementwise product plus a
-    reduction over an (N, C) tensor, and the gradient is a broadcast."""
-    loss = (out["encoded_spconv_tensor"].dense() * lw["dense"]).sum()   # (a 9 M-element torch.dot is a 69 us rocBLAS kernel: slower)
+    Every term is one fused, deterministic multiply-and-reduce pass (ops.weighted_sum -> vc_weighted_sum; torch's product + sum
+    cost 0.24 ms of the 5.4 ms step); on the CPU oracle it is plain tensor ops."""
+    loss = ops.weighted_sum(out["encoded_spconv_tensor"].dense(), lw["dense"])   # one fused pass (vc_weighted_sum) on the GPU
     for group in ("multi_scale_3d_features", "multi_scale_3d_features_mm"):
         for name, t in out.get(group, {}).items():
-            loss = loss + torch.dot(t.features.sum(0), lw[name])
+            loss = loss + ops.weighted_sum(t.features, lw[name])
     return loss
 
 

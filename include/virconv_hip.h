@@ -244,6 +244,15 @@ size_t vc_group_sum_sorted_workspace_bytes(int64_t n, int c);
 int vc_group_sum_sorted(const float* dy, const int32_t* grp_plan, int64_t n, int c, float* dy_grp, void* ws, size_t ws_bytes,
                         void* stream);
 
+/* Weighted sum (fused elementwise product + full reduction): out[0] = sum_{b < nb} sum_{i < e} x[b * e + i] * g[i]; e % 4 == 0.
+ * One pass over x, no temporary; deterministic (fixed partition, fp64 partials, fixed-order second stage).  The contraction the
+ * benchmark's stand-in detection loss is made of (the heads are out of scope) -- replaces torch's
+ * `(x * g).sum()` there.  vc_weighted_sum_backward: dx[b * e + i] = gout[0] * g[i] for b < nb_out (nb_out = 1: the row every
+ * sample shares, for a broadcast view). */
+size_t vc_weighted_sum_workspace_bytes(int64_t nb, int64_t e);
+int vc_weighted_sum(const float* x, int64_t nb, int64_t e, const float* g, float* out, void* ws, size_t ws_bytes, void* stream);
+int vc_weighted_sum_backward(const float* gout, const float* g, int64_t nb_out, int64_t e, float* dx, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ K9 projection
  * Voxel index -> image pixel index.  Replaces index2points + index2uv +
  * X_TRANS.backward_with_param + Calibration.lidar_to_rect_cuda/rect_to_img_cuda

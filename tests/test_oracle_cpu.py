@@ -257,3 +257,15 @@ def test_mean_vfe_equals_reference_module():
     m = MeanVFE({"MODEL": "max"}, 8)
     out = m({"voxels": torch.from_numpy(vox), "voxel_num_points": torch.from_numpy(num)})["voxel_features"].numpy()
     np.testing.assert_allclose(geometry.mean_vfe(vox, num, "max"), out, rtol=0, atol=1e-6)
+
+
+def test_weighted_sum_on_the_cpu_oracle_is_plain_tensor_ops():
+    from oracle.backend import OracleBackend
+    from virconv_amd import ops
+    with ops.use_backend(OracleBackend()):
+        x = torch.randn(5, 4, 6, dtype=torch.float64, requires_grad=True)
+        g = torch.randn(4, 6, dtype=torch.float64)
+        y = ops.weighted_sum(x, g)
+        assert torch.allclose(y, (x * g).sum())
+        y.backward()
+        assert torch.allclose(x.grad, g.expand(5, 4, 6))

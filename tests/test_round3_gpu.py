@@ -245,3 +245,25 @@ def test_weight_gradient_v2_dy_window_in_lds(hip_backend, cin, cout, kind):
     for got in (v1, v2):
         err = np.abs(got.cpu().numpy() - dw_ref)
         assert np.all(err <= 1e-4 * np.abs(dw_ref) + 1e-5 * scale), float(err.max() / scale)
+
+
+@pytest.mark.parametrize("shape,gshape", [((4, 64, 2, 200, 176), (1, 64, 2, 200, 176)), ((3, 8, 5, 12), (8, 5, 12)),
+                                          ((310351, 32), (32,)), ((75991, 64), (64,)), ((1, 16), (16,)), ((1000, 256), (256,))])
+def test_weighted_sum_is_one_deterministic_pass_and_matches_float64(hip_backend, shape, gshape):
+    """vc_weighted_sum / ops.weighted_sum: sum(x * g) with g broadcast over the leading axis -- value against float64, bit-stable
+    run to run, gradient = gout * g (a stride-0 view over the batch axis for dense maps, materialised rows for (N, C))."""
+    from virconv_amd import ops
+    gen = torch.Generator(device="cpu").manual_seed(sum(shape))
+    x = torch.randn(shape, generator=gen).cuda().requires_grad_(True)
+    g = (torch.randn(gshape, generator=gen) * 0.01).cuda()
+    y = ops.weighted_sum(x, g)
+    assert y.grad_fn is not None and type(y.grad_fn).__name__ == "WeightedSumFunctionBackward"
+    ref = float((x.detach().double() * g.double()).sum())
+    mag = float((x.detach().double() * g.double()).abs().sum())
+    assert abs(float(y) - ref) <= 1e-6 * mag + 1e-7 * abs(ref)
+    for _ in range(3):
+        assert torch.equal(y.detach(), ops.weighted_sum(x.detach(), g))
+    (y * 3.0).backward()
+    want = (3.0 * g).reshape((1,) + tuple(x.shape[1:])).expand(x.shape) if x.dim() > 2 else (3.0 * g).expand(x.shape)
+    assert x.grad.shape == x.shape
+    assert torch.equal(x.grad, want.contiguous()) or float((x.grad - want).abs().max()) <= 1e-7 * float(want.abs().max())

@@ -744,6 +744,30 @@ class HipBackend:
               "vc_post_act_block_forward")
         return y, y_raw, stats[0], stats[1]
 
+    def weighted_sum(self, x: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+        """sum_b sum_i x[b, i] * g[i] as ONE deterministic pass over x (vc_weighted_sum); x: (nb, ...) contiguous, g: the shape of
+        one sample (or with a leading 1).  -> 0-dim float32 tensor."""
+        x = _need(x, torch.float32, "x")
+        g = _need(g, torch.float32, "g")
+        nb = x.shape[0]
+        e = x.numel() // max(nb, 1)
+        if g.numel() != e:
+            raise ValueError(f"weighted_sum: g has {g.numel()} elements, one sample of x has {e}")
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        ws_bytes = self.lib.vc_weighted_sum_workspace_bytes(nb, e)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+        check(self.lib.vc_weighted_sum(_ptr(x), nb, e, _ptr(g), _ptr(out), _ptr(ws), ws_bytes, _stream()), "vc_weighted_sum")
+        return out
+
+    def weighted_sum_backward(self, gout: torch.Tensor, g: torch.Tensor, nb_out: int) -> torch.Tensor:
+        """(nb_out, e) rows gout * g (vc_weighted_sum_backward); nb_out = 1 gives the row every sample shares."""
+        gout = _need(gout, torch.float32, "grad_out")
+        g = _need(g, torch.float32, "g")
+        e = g.numel()
+        dx = torch.empty((nb_out, e), dtype=torch.float32, device=g.device)
+        check(self.lib.vc_weighted_sum_backward(_ptr(gout), _ptr(g), nb_out, e, _ptr(dx), _stream()), "vc_weighted_sum_backward")
+        return dx
+
     def group_plan(self, rep: torch.Tensor) -> torch.Tensor:
         """(2, n) int32 [rows sorted stably by representative | sorted representatives] of a duplicate-pixel table: what
         vc_group_sum_sorted walks.  Built once per table by the geometry plan (vc_group_plan: keys + one stable radix sort)."""

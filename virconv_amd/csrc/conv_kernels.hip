@@ -26,6 +26,7 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ int g_xcd_swizzle_off = 0;  // developer switch (tools/kbench.py --no-xcd)
+__device__ int g_pc_ablate = 0;        // developer ablations of the pair-compacted kernel (vc_debug_set conv_pc_ablate; wrong results): 1 no LDS adds | 2 no gathers | 4 no MFMAs | 8 no per-offset barrier
 // v2 MFMA phase order.  0 (default) = the round-1 order: hipcc reads each B fragment right before its four MFMAs, 68 VGPRs,
 // 6 waves per SIMD.  1 = every B fragment of an offset read before its first MFMA + accumulator-alternating MFMAs: better
 // per-wave code but 97 VGPRs / 4 waves per SIMD, and MEASURED SLOWER (s3.d3_conv1 64->32 forward 242 vs 208 us,
@@ -864,6 +865,239 @@ gather_gemm_v2_kernel(const float* __restrict__ src,
   }
   if constexpr ((EPI == VC_EPI_STATS || EPI == VC_EPI_BWD) && RT == 1 && (CN & (CN - 1)) == 0) {
     if (epi.fin.cnt != nullptr) conv_finish_tail<CN, NTHR>(epi.fin, epi.partial, (int)lbid, wave, smem);   // kernel-uniform
+  }
+}
+
+// --------------------------------------------------------------------------------------------- K6 pc (pair-compacted forward)
+// Round 3.  The strided convs have 1.7 - 8.7 active kernel offsets per OUTPUT row out of 27 (kbench P/N), i.e. per offset 6 - 30 %
+// of the rows of a tile gather anything; v2 issues a full 16-row MFMA tile for every (tile, offset) with at least one active row --
+// 45 - 71 tile-units per 64 rows against 6.6 - 33 useful ones (profiles/r03_pair_compaction_analysis.txt), 5 - 21 % of the MFMA peak.
+// This kernel takes the padding out instead of sorting rows around it:
+//   * a block owns 128 consecutive output rows; their (KV x 128) table slice is staged into LDS and COMPACTED per offset, in place:
+//     queue k = the (input row, local output row) pairs of offset k in ascending output-row order (ballot + popcount, one wave per
+//     offset), padded to whole 16-pair tiles with (-1, -);
+//   * the block walks the active offsets in ascending order, in lock step (one barrier per offset: the W_k image is staged once per
+//     block into LDS, double buffered, exactly as in v2); wave w takes pair tile w of the offset's queue -- at most 8 tiles = 128 pairs --
+//     gathers its 16 input rows (buffer loads, -1 -> zeros), runs the MFMAs into a ZEROED accumulator and adds the 16 x CN result
+//     into the block's output accumulator rows in LDS (ds_add_f32; inside one offset every output row appears at most once, and the
+//     per-offset barrier orders the offsets: every output element is the fixed-order sum  ((0 + P_k1) + P_k2) + ...  over its
+//     active offsets in ascending order -- deterministic, independent of which wave computed which tile);
+//   * the gathers and the W slice of offset n + 1 are in flight under the MFMAs of offset n (v2's ping-pong pipeline);
+//   * after the last offset the 128 x CN tile goes from LDS to memory in whole rows (coalesced 16-byte stores), with the STATS
+//     (one partial row per 16 output rows, the v2 8-wave contract) or AFFINE epilogue applied on the way.
+// Arithmetic differs from v2 only in WHERE the per-offset products are added (v2 chains them through the MFMA accumulator, here
+// each P_k is rounded to fp32 before the add): same bound against the fp64 oracle, not bit-identical to v2.
+template <int CK, int CN, int EPI, bool PK>
+__global__ void __launch_bounds__(512) gather_gemm_pc_kernel(const float* __restrict__ src, int64_t n_src,
+                                                             const int32_t* __restrict__ tbl, const float* __restrict__ w,
+                                                             float* __restrict__ out, int64_t n_out, int kv, ConvEpilogue epi) {
+  static_assert(CK % 16 == 0 && CN % 16 == 0, "pair-compacted kernel: channel counts in multiples of 16");
+  static_assert(EPI == VC_EPI_NONE || EPI == VC_EPI_STATS || EPI == VC_EPI_AFFINE, "forward epilogues only");
+  constexpr int V = 4, NW = 8, NTHR = 512, TMB = 128;
+  constexpr int NCH = CK / 16, NT = CN / 16;
+  constexpr int NFRAG = NCH * NT * 64, BF = NFRAG * V, BBYTES = BF * 4;
+  constexpr int BLD = (NFRAG + NTHR - 1) / NTHR;
+  constexpr int ACS = CN + 4;                                  // accumulator row stride (floats): rows start in different banks
+  // Pipeline depth: the gathers and the W slice of offset n + D - 1 are issued while offset n computes.  A block has its offsets
+  // in lock step, so -- unlike v2, which hides a 2-3 us gather round trip behind six resident blocks per CU -- the latency has to
+  // be covered by loads in flight: depth 2 (v2's ping-pong) measured 546 us on the 32 -> 64 stage-3 conv against v2's 170.
+  constexpr int D = (CK >= 64) ? 3 : 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* s_b = smem;                                                      // [2][BBYTES]
+  float* s_acc = reinterpret_cast<float*>(smem + 2 * BBYTES);                     // [TMB][ACS]
+  int* s_qin = reinterpret_cast<int*>(s_acc + TMB * ACS);                         // [kv][TMB] table slice, then the queues' input rows
+  int* s_cnt = s_qin + kv * TMB;                                                  // [32] pairs per offset
+  int* s_klist = s_cnt + 32;                                                      // [32] active offsets ascending, [32] = how many
+  unsigned char* s_qout = reinterpret_cast<unsigned char*>(s_klist + 36);         // [kv][TMB] the queues' local output rows
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  int64_t lbid;
+  {
+    const unsigned nb = gridDim.x, bid = blockIdx.x, xcd = bid & 7u, qd = nb >> 3, rm = nb & 7u;
+    lbid = (int64_t)(xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    if (g_xcd_swizzle_off) lbid = bid;
+  }
+  const int64_t brow0 = lbid * TMB;
+  const __amdgpu_buffer_rsrc_t rs_src =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)(n_src * CK * 4), 0x00020000);
+
+  {  // ---- phase 0: table slice -> LDS (coalesced over rows; all of a thread's loads in flight together), accumulators = 0
+    const int r = tid % TMB, k0 = tid / TMB;
+    const bool inb = brow0 + r < n_out;
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + u * (NTHR / TMB);
+      v[u] = (inb && k < kv) ? tbl[(int64_t)k * n_out + brow0 + r] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + u * (NTHR / TMB);
+      if (k < kv) s_qin[k * TMB + r] = v[u];
+    }
+    for (int e = tid; e < TMB * ACS / 4; e += NTHR) reinterpret_cast<float4*>(s_acc)[e] = float4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  // ---- phase 1: compaction, one wave per offset (the wave reads its offset's 128 entries before it writes any of them)
+  for (int k = wave; k < kv; k += NW) {
+    int* qi = s_qin + k * TMB;
+    unsigned char* qo = s_qout + k * TMB;
+    const int v0 = qi[lane], v1 = qi[64 + lane];
+    const unsigned long long b0 = __ballot(v0 >= 0), b1 = __ballot(v1 >= 0);
+    const unsigned long long lt = (1ULL << lane) - 1ULL;
+    const int c0 = __popcll(b0), cnt = c0 + __popcll(b1);
+    if (v0 >= 0) { const int p_ = __popcll(b0 & lt); qi[p_] = v0; qo[p_] = (unsigned char)lane; }
+    if (v1 >= 0) { const int p_ = c0 + __popcll(b1 & lt); qi[p_] = v1; qo[p_] = (unsigned char)(64 + lane); }
+    const int padded = (cnt + 15) & ~15;
+    if (cnt + lane < padded) { qi[cnt + lane] = -1; qo[cnt + lane] = 0; }   // < 16 padding entries
+    if (lane == 0) s_cnt[k] = cnt;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int n = 0;
+    for (int k = 0; k < kv; ++k)
+      if (s_cnt[k] > 0) s_klist[n++] = k;
+    s_klist[32] = n;
+  }
+  __syncthreads();
+  const int n_items = __builtin_amdgcn_readfirstlane(s_klist[32]);
+  const int abl = g_pc_ablate;
+
+  float breg[D][BLD][V];
+  float a[D][NCH][V];
+  int act[D];
+
+#define PC_K_OF(IT) __builtin_amdgcn_readfirstlane(s_klist[(IT) < n_items ? (IT) : n_items - 1])
+#define PC_LOAD_B(K, S)                                                                            \
+  do {                                                                                             \
+    _Pragma("unroll") for (int u = 0; u < BLD; ++u) {                                              \
+      const int f = tid + u * NTHR;                                                                \
+      if (NFRAG % NTHR == 0 || f < NFRAG) {                                                         \
+        if constexpr (PK) {                                                                        \
+          VecLoad<V>::ld(w + ((int64_t)(K) * NFRAG + f) * V, breg[S][u]);                          \
+        } else {                                                                                   \
+          const int fl = f & 63, nt_ = (f >> 6) % NT, ch_ = (f >> 6) / NT;                         \
+          const int n_ = nt_ * 16 + (fl & 15), kk0 = ch_ * 16 + (fl >> 4) * V;                     \
+          VecLoad<V>::ld(w + ((int64_t)n_ * kv + (K)) * CK + kk0, breg[S][u]);                     \
+        }                                                                                          \
+      }                                                                                            \
+    }                                                                                              \
+  } while (0)
+#define PC_STORE_B(BUF, S)                                                                         \
+  do {                                                                                             \
+    _Pragma("unroll") for (int u = 0; u < BLD; ++u) {                                              \
+      const int f = tid + u * NTHR;                                                                \
+      if (NFRAG % NTHR == 0 || f < NFRAG) {                                                         \
+        float* d_ = reinterpret_cast<float*>(s_b + (BUF) * BBYTES) + f * V;                        \
+        _Pragma("unroll") for (int j = 0; j < V; ++j) d_[j] = breg[S][u][j];                       \
+      }                                                                                            \
+    }                                                                                              \
+  } while (0)
+  // pair tile `wave` of offset K: 16 input rows (-1 beyond the queue or past the last offset: no memory access, zeros)
+#define PC_GATHER_A(K, S, LIVE)                                                                    \
+  do {                                                                                             \
+    act[S] = ((LIVE) && wave * 16 < s_cnt[(K)]) ? 1 : 0;                                           \
+    const int id = (act[S] && !(abl & 2)) ? s_qin[(K) * TMB + wave * 16 + i] : -1;                 \
+    const unsigned base_ = (unsigned)id * (unsigned)(CK * 4) + (unsigned)(q * V * 4);              \
+    _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch) BufLoad<V>::ld(rs_src, base_ + (unsigned)(ch * 64), a[S][ch]); \
+  } while (0)
+  // MFMAs of the tile into a zeroed accumulator, then the 16 x CN result into the output rows of the tile's pairs
+#define PC_MFMA_ADD(K, S, BUF)                                                                     \
+  do {                                                                                             \
+    if (act[S]) {                                                                                  \
+      const float* __restrict__ B_ = reinterpret_cast<const float*>(s_b + (BUF) * BBYTES);         \
+      f32x4 acc[NT];                                                                               \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};       \
+      _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch) {                                         \
+        float b[NT][V];                                                                            \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) VecLoad<V>::ld(B_ + ((ch * NT + nt) * 64 + lane) * V, b[nt]); \
+        if (!(abl & 4)) {                                                                          \
+        _Pragma("unroll") for (int j = 0; j < V; ++j)                                              \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                      \
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[S][ch][j], b[nt][j], acc[nt], 0, 0, 0); \
+        } else { _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[nt][0] += a[S][ch][0] * b[nt][0]; } \
+      }                                                                                            \
+      const int cnt_ = (abl & 1) ? 0 : s_cnt[(K)];                                                 \
+      _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                                        \
+        const int e_ = wave * 16 + q * 4 + reg;                                                    \
+        if (e_ < cnt_) {                                                                           \
+          /* plain read-add-write: inside one offset every output row belongs to exactly one pair, i.e. one lane group of one   \
+             wave (ds_add_f32 measured 166 cycles per wave instruction: 586 us instead of 144 for the stage-3 conv) */           \
+          float* dst_ = s_acc + (int)s_qout[(K) * TMB + e_] * ACS + i;                             \
+          float cur_[NT];                                                                          \
+          _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) cur_[nt] = dst_[nt * 16];              \
+          _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) dst_[nt * 16] = cur_[nt] + acc[nt][reg]; \
+        }                                                                                          \
+      }                                                                                            \
+    }                                                                                              \
+  } while (0)
+
+  if (n_items > 0) {
+#pragma unroll
+    for (int s_ = 0; s_ < D - 1; ++s_) {   // prologue: offsets 0 .. D - 2 in flight
+      const int k_ = PC_K_OF(s_);
+      PC_LOAD_B(k_, s_);
+      PC_GATHER_A(k_, s_, s_ < n_items);
+    }
+    for (int base = 0; base < n_items; base += D) {
+#pragma unroll
+      for (int s_ = 0; s_ < D; ++s_) {
+        const int it = base + s_;
+        if (it >= n_items) break;              // block-uniform
+        const int kcur = PC_K_OF(it);
+        const int buf = it & 1;
+        PC_STORE_B(buf, s_);
+        if (!(abl & 8)) __syncthreads();   // W_kcur staged; every LDS add of the previous offset has completed (its waves waited lgkmcnt(0) to get here)
+        const int kn = PC_K_OF(it + D - 1);
+        PC_LOAD_B(kn, (s_ + D - 1) % D);
+        PC_GATHER_A(kn, (s_ + D - 1) % D, it + D - 1 < n_items);
+        PC_MFMA_ADD(kcur, s_, buf);
+      }
+    }
+  }
+#undef PC_MFMA_ADD
+#undef PC_GATHER_A
+#undef PC_STORE_B
+#undef PC_LOAD_B
+#undef PC_K_OF
+  __syncthreads();
+
+  // ---- epilogue: LDS accumulators -> memory, whole rows
+  if constexpr (EPI == VC_EPI_STATS) {
+    // one partial row per 16 output rows: wave w sums rows 16 w .. 16 w + 15 of its column(s) in ascending row order
+    float* prow = epi.partial + ((lbid * NW + wave) * 2) * CN;
+    for (int c = lane; c < CN; c += 64) {
+      float sm = 0.f, sq = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = s_acc[(wave * 16 + r) * ACS + c];
+        sm += v;
+        sq += v * v;
+      }
+      prow[c] = sm;
+      prow[CN + c] = sq;
+    }
+  }
+  constexpr int C4 = CN / 4;
+  for (int e = tid; e < TMB * C4; e += NTHR) {
+    const int r = e / C4, c4 = e - r * C4;
+    if (brow0 + r >= n_out) continue;
+    float4 v = *reinterpret_cast<const float4*>(s_acc + r * ACS + c4 * 4);
+    if constexpr (EPI == VC_EPI_AFFINE) {
+      float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = c4 * 4 + j;
+        const float istd = 1.0f / sqrtf(epi.var[n] + epi.eps);
+        const float sc = (epi.gamma ? epi.gamma[n] : 1.f) * istd;
+        const float sh = (epi.beta ? epi.beta[n] : 0.f) - epi.mean[n] * sc;
+        o[j] = o[j] * sc + sh;
+        if (epi.relu) o[j] = fmaxf(o[j], 0.f);
+      }
+      v = float4{o[0], o[1], o[2], o[3]};
+    }
+    *reinterpret_cast<float4*>(out + (brow0 + r) * CN + c4 * 4) = v;
   }
 }
 
@@ -2515,6 +2749,18 @@ static inline int conv_block_waves(int ck, int cn, bool bwd, int64_t rows, bool 
   if (g_conv_nw == 4) return 4;
   return (bwd && ck == 32 && cn == 64) ? 8 : 4;
 }
+// Pair-compacted forward kernel (gather_gemm_pc_kernel) for tables with few active offsets per row.  The library recognises them
+// by n_in != n_out: a strided conv or its inverse (a SubM table has n_in == n_out; a strided table that happens to keep the row
+// count just stays on v2).  vc_debug_set "conv_pc": 1 = take it.  OFF by default -- measured (profiles/r03_pair_compacted_kernel.md):
+// it issues 2-5x fewer MFMA tiles and gathers than v2 and still only ties it on the stage-3 conv (171 vs 170 us) and loses on the
+// others (stage 2: 113 vs 73, stage 4: 232 vs 167, conv_out: 29 vs 24 us): the offsets of a block run in lock step, so a block's
+// critical path is 27 x (one tile on one or two of its eight waves) whatever the fill, and only 1-2 such blocks fit a CU next to
+// their 35 KB of LDS accumulators, where v2 keeps six blocks with every wave busy.
+int g_conv_pc = 0;
+static inline bool conv_use_pc(int ck, int cn, int kv, int64_t n_in, int64_t n_out, int ot) {
+  return g_conv_pc && g_conv_variant == 2 && ck % 16 == 0 && cn % 16 == 0 && ck <= 64 && cn <= 64 && kv > 1 && kv <= 32 &&
+         n_in != n_out && ot == VC_OPERAND_F32 && n_in * (int64_t)ck * 4 < (1LL << 31);
+}
 int g_conv_window = 1;         // 0 = never take the LDS-window kernel (A/B measurements)
 int g_conv_wdma = 0;           // 1 = W images through the LDS-DMA engine in the window kernel
 int g_conv_winrows = 32;       // 24 = smaller per-wave windows (one more block per CU at 64 channels)
@@ -2612,6 +2858,36 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
           wpk = scratch;
         }
       }
+    }
+  }
+  if constexpr (!BWD && CK % 16 == 0 && CN % 16 == 0) {
+    if (conv_use_pc(CK, CN, kv, n_src, n_out, ot) && rep == nullptr && src_centre == nullptr && !(flags & VC_CONV_SRC_INTERLEAVED) &&
+        (epi_kind == VC_EPI_NONE || epi_kind == VC_EPI_STATS || epi_kind == VC_EPI_AFFINE)) {
+      constexpr int NFRAG_ = (CK / 16) * (CN / 16) * 64;
+      const size_t ldsp = (size_t)2 * NFRAG_ * 16 + (size_t)128 * (CN + 4) * 4 + (size_t)kv * 128 * 4 + 128 + 144 + (size_t)kv * 128 + 16;
+      const dim3 gridp((unsigned)cdiv(n_out, 128));
+#define VC_LP(E_)                                                                                                              \
+  do {                                                                                                                         \
+    if (wpk) {                                                                                                                 \
+      static const hipError_t attr_ = hipFuncSetAttribute((const void*)gather_gemm_pc_kernel<CK, CN, E_, true>,                \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);            \
+      (void)attr_;                                                                                                             \
+      hipLaunchKernelGGL((gather_gemm_pc_kernel<CK, CN, E_, true>), gridp, dim3(512), ldsp, st, src, n_src, tbl, wpk, out,     \
+                         n_out, kv, epi);                                                                                      \
+    } else {                                                                                                                   \
+      static const hipError_t attr_ = hipFuncSetAttribute((const void*)gather_gemm_pc_kernel<CK, CN, E_, false>,               \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);            \
+      (void)attr_;                                                                                                             \
+      hipLaunchKernelGGL((gather_gemm_pc_kernel<CK, CN, E_, false>), gridp, dim3(512), ldsp, st, src, n_src, tbl, w, out,      \
+                         n_out, kv, epi);                                                                                      \
+    }                                                                                                                          \
+  } while (0)
+      if (epi_kind == VC_EPI_STATS) VC_LP(VC_EPI_STATS);
+      else if (epi_kind == VC_EPI_AFFINE) VC_LP(VC_EPI_AFFINE);
+      else VC_LP(VC_EPI_NONE);
+#undef VC_LP
+      VC_CHECK_LAUNCH("gather_gemm_pc_kernel");
+      return VC_OK;
     }
   }
   if constexpr (CK % 16 == 0 && CN % 16 == 0 && ((CK / 16) * (CN / 16)) % 4 == 0) {
@@ -3043,6 +3319,9 @@ int vc_debug_set(const char* key, int value) {
   if (key && !strcmp(key, "pass_bwd_epilogue")) { g_pass_bwd_epilogue = value; return VC_OK; }
   if (key && !strcmp(key, "bn_fused_partial")) { g_bn_fused_partial = value; return VC_OK; }
   if (key && !strcmp(key, "conv_bn_finish")) { g_conv_bn_finish = value; return VC_OK; }
+  if (key && !strcmp(key, "conv_pc")) { g_conv_pc = value; return VC_OK; }
+  if (key && !strcmp(key, "conv_pc_ablate"))
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_pc_ablate), &value, sizeof(int)) == hipSuccess ? VC_OK : VC_EHIP;
   if (key && !strcmp(key, "pass_defer_dw_reduce")) { g_pass_defer_dw_reduce = value; return VC_OK; }
   if (key && !strcmp(key, "xcd_swizzle_off")) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_swizzle_off), &value, sizeof(int)) == hipSuccess ? VC_OK : VC_EHIP;
@@ -3162,10 +3441,11 @@ int vc_conv_epilogue_supported(int64_t n_in, int cin, int cout, int kv, int oper
 }
 
 size_t vc_conv_stats_partial_floats(int64_t n_in, int64_t n_out, int cin, int cout, int kv, int flags) {
-  (void)n_in; (void)kv; (void)flags;
+  (void)flags;
   if (n_out < 0 || cout < 1) return 0;
   // one partial row (sum, sum of squares per channel) per 16-row wave tile: 4 per 64-row block (8 per 128-row block), direct and
-  // window kernel alike
+  // window kernel alike; the pair-compacted kernel: 8 per 128-row block
+  if (conv_use_pc(cin, cout, kv, n_in, n_out, VC_OPERAND_F32)) return (size_t)cdiv(n_out, 128) * 8 * 2 * cout;
   if (conv_block_waves(cin, cout, false, n_out, false) == 8) return (size_t)cdiv(n_out, 128) * 8 * 2 * cout;
   return (size_t)cdiv(n_out, 64) * 4 * 2 * cout;
 }

@@ -468,6 +468,39 @@ def to_dense(features, indices, spatial_shape, batch_size, pad=(0, 0)):
     return ToDenseFunction.apply(features, indices, tuple(int(s) for s in spatial_shape), batch_size, (int(pad[0]), int(pad[1])))
 
 
+class WeightedSumFunction(torch.autograd.Function):
+    """sum(x * g) with g broadcast over the leading axis of x, as one pass over x (vc_weighted_sum) instead of an elementwise product
+    plus a reduction.  The gradient for x is gout * g: a stride-0 view over the leading axis for a dense (B, ...) map (to_dense's
+    backward gathers it from one sample's planes), materialised rows for an (N, C) feature matrix (what the feature pass takes)."""
+
+    @staticmethod
+    def forward(ctx, x, g):
+        ctx.save_for_backward(g)
+        ctx.xshape = tuple(x.shape)
+        return get_backend().weighted_sum(x, g)
+
+    @staticmethod
+    def backward(ctx, gout):
+        (g,) = ctx.saved_tensors
+        shp = ctx.xshape
+        be = get_backend()
+        if len(shp) == 2:
+            return be.weighted_sum_backward(gout.reshape(1), g, shp[0]), None
+        row = be.weighted_sum_backward(gout.reshape(1), g, 1)
+        return row.view((1,) + shp[1:]).expand(shp), None
+
+
+def weighted_sum(x: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """sum(x * g), g broadcast over x's leading axis.  One fused, deterministic pass on the HIP backend; plain tensor ops otherwise
+    (the CPU oracle)."""
+    be = get_backend()
+    e = x.numel() // max(x.shape[0], 1)
+    if hasattr(be, "weighted_sum") and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and e % 4 == 0 and x.shape[0] >= 1 \
+            and not g.requires_grad and (e <= 1024 and (e & (e - 1)) == 0 or x.shape[0] <= 65535):
+        return WeightedSumFunction.apply(x, g)
+    return (x * g).sum()
+
+
 class BNReLUFunction(torch.autograd.Function):
     """Training-mode BatchNorm1d(+ReLU) over the active rows."""
 
