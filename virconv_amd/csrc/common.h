@@ -175,7 +175,7 @@ struct BnFinishRequest {
   double* dpartial;    // >= 256 x 2c doubles of scratch, private to the launch while it runs
 };
 void conv_finish_arm(const BnFinishRequest& r);
-bool conv_finish_take();   // true: the launch since the last arm finished the sums itself; always disarms
+bool conv_finish_take(hipStream_t st);   // true: the sums are finished (by the launch since the last arm); always disarms
 // the dx kernel of the BatchNorm(+ReLU) backward alone, the per-channel sums given (bn_kernels.hip)
 int bn_bwd_dx_launch(const float* x, const float* dy, int dy_stride, int dy_col0, int64_t n, int c, const float* mean,
                      const float* var, const float* gamma, const float* beta, float eps, int relu, const float* sums, float* dx,

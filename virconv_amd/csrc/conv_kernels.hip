@@ -292,25 +292,29 @@ struct BufLoad<1> {
 //                  PRODUCED this conv's input -- sum(dy_masked), sum(dy_masked * xhat) per channel, per-wave partial rows as in
 //                  STATS -- are formed from the stored tile and that unit's pre-BatchNorm output: the unit's separate reduction
 //                  pass over (y_raw, dy) and the gradient-add kernel disappear
-// In-kernel finish of the BatchNorm sums (round 3): the v2 kernel's STATS / BWD epilogue can carry the per-wave partial rows all
-// the way to the finished per-channel numbers, instead of leaving them to bn_partial_reduce_kernel + a finalize kernel -- two
+// In-kernel finish of the BatchNorm sums (round 3): the v2 kernel's STATS / BWD epilogue can carry its partial sums all the way to
+// the finished per-channel numbers, instead of leaving per-wave partial rows to bn_partial_reduce_kernel + a finalize kernel -- two
 // 5-6 us launches (and two kernel boundaries) per BatchNorm on the main stream's critical path, 55 of them per train step.
-// Arrival tickets, no spinning (MI355X guide, "in-launch split-K reduction", write-through form): every block stores its
-// partial rows write-through (sc1), waits for them (vmcnt(0)), and draws a ticket of its GROUP (bn_partial_rows_per_group
-// consecutive rows = a whole number of blocks); the block that draws the group's last ticket adds the group's rows up exactly
-// as bn_partial_reduce_kernel does (fp64, same order), stores the fp64 row write-through and draws a ticket of the launch; the
-// block that draws the last of those adds the <= 256 group rows up exactly as the finalize kernels do and writes the results.
-// Which block does a reduction varies from run to run, WHAT it computes does not: the results are bit-identical to the
-// two-launch route and run-to-run stable.  The last block also clears the tickets (they are zero between launches).
+// Three levels, arrival tickets, no spinning (MI355X guide, "in-launch split-K reduction", write-through form):
+//   level 0  every block adds the rows of its 4 / 8 waves through LDS (fp32, wave order) and stores ONE row write-through (sc1);
+//   level 1  blocks are grouped rpb = ceil(blocks / 64) at a time; the block that draws a group's last ticket adds the group's
+//            block rows (fp64; thread = (row sub-index, column), rows ascending, then the sub-indices ascending) and stores the
+//            fp64 group row write-through;
+//   level 2  the block that draws the launch's last ticket adds the <= 64 group rows per column in a fixed halving tree
+//            (v[u] += v[u + h], h = 32, 16, ... 1 over the group index) -- one row per lane, all channels at once -- writes the
+//            finished numbers and clears the tickets.
+// Which block does a reduction varies from run to run, WHAT it computes does not: results are run-to-run stable and bit-identical
+// to bn_finish_reference_kernel, a single block that performs the same three levels one after the other (tests).
 struct ConvFinish {
-  unsigned* cnt = nullptr;   // [0]: launch tickets, [1 + g]: tickets of group g; nullptr: no in-kernel finish
+  unsigned* cnt = nullptr;     // [0]: launch tickets, [1 + g]: tickets of group g; nullptr: no in-kernel finish
+  float* brows = nullptr;      // [nblocks][2 CN] block rows (the launch's partial buffer)
   double* dpartial = nullptr;  // [ngroups][2 CN]
   float *o0 = nullptr, *o1 = nullptr, *r0 = nullptr, *r1 = nullptr;   // see BnFinishRequest
   long long* nbt = nullptr;
   long long n = 0;
   float momentum = 0.f;
   int bwd = 0;
-  int rpb = 0, ngroups = 0, nrows = 0;   // partial rows per group, groups, partial rows (= blocks x waves per block)
+  int rpb = 0, ngroups = 0, nblocks = 0;   // blocks per group, groups (<= 64), blocks of the launch
 };
 
 struct ConvEpilogue {
@@ -340,54 +344,162 @@ __device__ __forceinline__ void st_agent(double* p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Tail of a v2 block whose launch finishes the BatchNorm sums (see ConvFinish).  Called by ALL threads of the block after the
-// partial rows of its waves were stored with st_agent; `smem` is the block's dynamic LDS (>= 2 KB + 16 B, free by now).
-template <int CN, int NTHR>
-__device__ __forceinline__ void conv_finish_tail(const ConvFinish& f, const float* __restrict__ partial, int lbid, int wave,
+// ---- the three levels as device functions, shared by the ticketed tail and by the single-block reference kernel
+// level 0: column `col` of a block row = the block's per-wave rows added in wave order
+template <int C2, int NWV>
+__device__ __forceinline__ float fin_level0(const float* rows /* [NWV][C2] */, int col) {
+  float t = rows[col];
+#pragma unroll
+  for (int w_ = 1; w_ < NWV; ++w_) t += rows[w_ * C2 + col];
+  return t;
+}
+// level 1, thread part: block rows r0 + rs, r0 + rs + RS, ... < r1 of column col, ascending, fp64
+template <int C2>
+__device__ __forceinline__ double fin_level1_part(const float* __restrict__ brows, int r0, int r1, int rs, int col) {
+  constexpr int RS = 256 / C2;
+  double acc = 0.0;
+  int r = r0 + rs;
+  for (; r + 7 * RS < r1; r += 8 * RS) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ld_agent(brows + (int64_t)(r + u * RS) * C2 + col);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += (double)v[u];
+  }
+  for (; r + 3 * RS < r1; r += 4 * RS) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = ld_agent(brows + (int64_t)(r + u * RS) * C2 + col);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc += (double)v[u];
+  }
+  for (; r < r1; r += RS) acc += (double)ld_agent(brows + (int64_t)r * C2 + col);
+  return acc;
+}
+template <int C2>
+__device__ __forceinline__ double fin_level1_combine(const double* s_red /* [RS][C2] */, int col) {
+  constexpr int RS = 256 / C2;
+  double t = s_red[col];
+#pragma unroll
+  for (int u = 1; u < RS; ++u) t += s_red[u * C2 + col];
+  return t;
+}
+// level 2, thread part: the halving tree over the group rows l = p, p + RS, ... (a subtree of the tree over 64 rows), column col
+template <int C2>
+__device__ __forceinline__ double fin_level2_part(const double* __restrict__ dpartial, int ngroups, int p, int col) {
+  constexpr int RS = 256 / C2;
+  constexpr int NL = 64 / RS;          // rows of this part: 2 (C2 = 8) ... 32 (C2 = 128)
+  double v[NL >= 32 ? NL / 4 : NL];
+  if constexpr (NL >= 32) {            // the two upper tree levels folded into the loading, two results per batch: 8 loads in flight
+#pragma unroll
+    for (int ub = 0; ub < NL / 8; ++ub) {
+      double t[2][4];
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int l = p + RS * (ub * 2 + k + j * (NL / 4));
+          t[k][j] = l < ngroups ? ld_agent(dpartial + (int64_t)l * C2 + col) : 0.0;
+        }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) v[ub * 2 + k] = (t[k][0] + t[k][2]) + (t[k][1] + t[k][3]);   // (u, u + 16) then (+ 8)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int h = NL / 8; h >= 1; h >>= 1)
+#pragma unroll
+      for (int u = 0; u < h; ++u) v[u] += v[u + h];
+  } else {
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int l = p + RS * u;
+      v[u] = l < ngroups ? ld_agent(dpartial + (int64_t)l * C2 + col) : 0.0;
+    }
+#pragma unroll
+    for (int h = NL / 2; h >= 1; h >>= 1)
+#pragma unroll
+      for (int u = 0; u < h; ++u) v[u] += v[u + h];
+  }
+  return v[0];
+}
+template <int C2>
+__device__ __forceinline__ double fin_level2_combine(const double* s_part /* [RS][C2] */, int col) {
+  constexpr int RS = 256 / C2;
+  double w_[RS];
+#pragma unroll
+  for (int p = 0; p < RS; ++p) w_[p] = s_part[p * C2 + col];
+#pragma unroll
+  for (int h = RS / 2; h >= 1; h >>= 1)
+#pragma unroll
+    for (int p = 0; p < h; ++p) w_[p] += w_[p + h];
+  return w_[0];
+}
+template <int CN>
+__device__ __forceinline__ void fin_write(const ConvFinish& f, int ch, double s, double ss) {
+  if (f.bwd) {
+    if (f.o0) f.o0[ch] = (float)s;     // dbeta
+    if (f.o1) f.o1[ch] = (float)ss;    // dgamma
+    f.r0[ch] = (float)s;               // sums[0][ch]
+    f.r0[CN + ch] = (float)ss;         // sums[1][ch]
+  } else {
+    const double m = s / (double)f.n;
+    double v = ss / (double)f.n - m * m;
+    if (v < 0.0) v = 0.0;
+    f.o0[ch] = (float)m;
+    f.o1[ch] = (float)v;
+    if (f.r0) f.r0[ch] = (1.f - f.momentum) * f.r0[ch] + f.momentum * (float)m;
+    if (f.r1) {
+      const double unb = (f.n > 1) ? v * (double)f.n / (double)(f.n - 1) : v;
+      f.r1[ch] = (1.f - f.momentum) * f.r1[ch] + f.momentum * (float)unb;
+    }
+    if (ch == 0 && f.nbt) *f.nbt += 1;
+  }
+}
+
+// Tail of a v2 block whose launch finishes the BatchNorm sums (see ConvFinish).  Called by ALL threads of the block once its
+// epilogue stores are issued; (pa, pb)[nt] = this wave's partial sums of columns nt * 16 + i (valid in the lanes q == 0).
+// `smem` is the block's dynamic LDS (>= 4 KB + 16 B).
+template <int CN, int NTHR, int NT>
+__device__ __forceinline__ void conv_finish_tail(const ConvFinish& f, int lbid, int wave, const float (&pa)[NT], const float (&pb)[NT],
                                                  unsigned char* smem) {
   constexpr int C2 = 2 * CN;
-  constexpr int RS = 256 / C2;             // row sub-threads of the group reduce (bn_partial_reduce_kernel's mapping)
   constexpr int NWV = NTHR / 64;
-  static_assert(C2 <= 256 && (C2 & (C2 - 1)) == 0, "in-kernel BatchNorm finish: power-of-two channel count <= 128");
+  static_assert(C2 <= 128 && C2 >= 16 && (C2 & (C2 - 1)) == 0, "in-kernel BatchNorm finish: power-of-two channel count 8 .. 64");
   // lane from mbcnt, thread index from (wave, lane): nothing of the main loop's registers has to stay alive for this tail
   const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const int tid = wave * 64 + lane;
-  int* s_flag = reinterpret_cast<int*>(smem + 2048);
-  double* s_red = reinterpret_cast<double*>(smem);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through partial-row stores have left
+  const int i = lane & 15, q = lane >> 4;
+  float* s_rows = reinterpret_cast<float*>(smem);           // [NWV][C2]  (level 0)
+  double* s_red = reinterpret_cast<double*>(smem);          // [RS][C2]   (levels 1 and 2, after s_rows is dead)
+  double* s_tot = reinterpret_cast<double*>(smem + 2048);   // [C2]       (level 2)
+  int* s_flag = reinterpret_cast<int*>(smem + 4096);
+  __syncthreads();                                          // every wave is done with the main loop's LDS
+  if (q == 0) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 16 + i;
+      if (n < CN) { s_rows[wave * C2 + n] = pa[nt]; s_rows[wave * C2 + CN + n] = pb[nt]; }
+    }
+  }
   __syncthreads();
-  const int grp = (lbid * NWV) / f.rpb;
-  const int g_r0 = grp * f.rpb, g_r1 = min(g_r0 + f.rpb, f.nrows);
-  if (tid == 0) {
-    const unsigned want = (unsigned)((g_r1 - g_r0) / NWV);   // blocks of this group
-    const unsigned t = __hip_atomic_fetch_add(&f.cnt[1 + grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = (t + 1u == want) ? 1 : 0;
-    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    s_flag[0] = last;
+  const int grp = lbid / f.rpb;
+  const int g_r0 = grp * f.rpb, g_r1 = min(g_r0 + f.rpb, f.nblocks);
+  if (wave == 0) {
+    for (int col = lane; col < C2; col += 64) st_agent(f.brows + (int64_t)lbid * C2 + col, fin_level0<C2, NWV>(s_rows, col));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the block row has left (write-through)
+    if (lane == 0) {
+      const unsigned t = __hip_atomic_fetch_add(&f.cnt[1 + grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = (t + 1u == (unsigned)(g_r1 - g_r0)) ? 1 : 0;
+      if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      s_flag[0] = last;
+    }
   }
   __syncthreads();
   if (s_flag[0] == 0) return;   // block-uniform
-  // ---- level 1: this group's rows -> one fp64 row (arithmetic of bn_partial_reduce_kernel: thread = (row sub-index, column))
-  if (tid < 256) {
-    const int col = tid % C2, rs = tid / C2;
-    double acc = 0.0;
-    int r = g_r0 + rs;
-    for (; r + 7 * RS < g_r1; r += 8 * RS) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = ld_agent(partial + (int64_t)(r + u * RS) * C2 + col);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc += (double)v[u];
-    }
-    for (; r < g_r1; r += RS) acc += (double)ld_agent(partial + (int64_t)r * C2 + col);
-    s_red[tid] = acc;
-  }
+  // ---- level 1
+  if (tid < 256) s_red[tid] = fin_level1_part<C2>(f.brows, g_r0, g_r1, tid / C2, tid % C2);
   __syncthreads();
-  if (tid < C2) {
-    double t = s_red[tid];
-    for (int u = 1; u < RS; ++u) t += s_red[u * C2 + tid];
-    st_agent(f.dpartial + (int64_t)grp * C2 + tid, t);
-  }
+  if (tid < C2) st_agent(f.dpartial + (int64_t)grp * C2 + tid, fin_level1_combine<C2>(s_red, tid));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
@@ -398,40 +510,44 @@ __device__ __forceinline__ void conv_finish_tail(const ConvFinish& f, const floa
   }
   __syncthreads();
   if (s_flag[0] == 0) return;
-  // ---- level 2: the group rows -> per-channel numbers (arithmetic of bn_stats_finalize_kernel / bn_bwd_finalize_kernel: lane l
-  // adds rows l, l + 64, ... in that order, then the xor butterfly 32 .. 1); one wave per channel, channels strided over the waves
-  for (int ch = wave; ch < CN; ch += NWV) {
-    double s = 0.0, ss = 0.0;
-    for (int b = lane; b < f.ngroups; b += 64) {
-      s += ld_agent(f.dpartial + (int64_t)b * C2 + ch);
-      ss += ld_agent(f.dpartial + (int64_t)b * C2 + CN + ch);
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      s += __shfl_xor(s, off, 64);
-      ss += __shfl_xor(ss, off, 64);
-    }
-    if (lane != 0) continue;
-    if (f.bwd) {
-      if (f.o0) f.o0[ch] = (float)s;     // dbeta
-      if (f.o1) f.o1[ch] = (float)ss;    // dgamma
-      f.r0[ch] = (float)s;               // sums[0][ch]
-      f.r0[CN + ch] = (float)ss;         // sums[1][ch]
-    } else {
-      const double m = s / (double)f.n;
-      double v = ss / (double)f.n - m * m;
-      if (v < 0.0) v = 0.0;
-      f.o0[ch] = (float)m;
-      f.o1[ch] = (float)v;
-      if (f.r0) f.r0[ch] = (1.f - f.momentum) * f.r0[ch] + f.momentum * (float)m;
-      if (f.r1) {
-        const double unb = (f.n > 1) ? v * (double)f.n / (double)(f.n - 1) : v;
-        f.r1[ch] = (1.f - f.momentum) * f.r1[ch] + f.momentum * (float)unb;
-      }
-      if (ch == 0 && f.nbt) *f.nbt += 1;
-    }
-  }
+  // ---- level 2
+  if (tid < 256) s_red[tid] = fin_level2_part<C2>(f.dpartial, f.ngroups, tid / C2, tid % C2);
+  __syncthreads();
+  if (tid < C2) s_tot[tid] = fin_level2_combine<C2>(s_red, tid);
+  __syncthreads();
+  if (tid < CN) fin_write<CN>(f, tid, s_tot[tid], s_tot[CN + tid]);
   for (int j = tid; j <= f.ngroups; j += NTHR) f.cnt[j] = 0u;   // every ticket of this launch has been drawn
+}
+
+// The same three levels by ONE block, one after the other, from the per-wave partial rows a launch WITHOUT the finish leaves
+// behind (tests: vc_debug_set conv_bn_finish = 2).  brows / dpartial: scratch as in ConvFinish.
+template <int CN>
+__global__ void __launch_bounds__(256) bn_finish_reference_kernel(ConvFinish f, const float* __restrict__ wave_rows, int nwv) {
+  constexpr int C2 = 2 * CN;
+  __shared__ double s_red[256];
+  __shared__ double s_tot[C2];
+  const int tid = threadIdx.x;
+  for (int b = 0; b < f.nblocks; ++b)
+    if (tid < C2) {
+      const float* rows = wave_rows + (int64_t)b * nwv * C2;
+      f.brows[(int64_t)b * C2 + tid] = (nwv == 8) ? fin_level0<C2, 8>(rows, tid) : fin_level0<C2, 4>(rows, tid);
+    }
+  __threadfence();
+  __syncthreads();
+  for (int g = 0; g < f.ngroups; ++g) {
+    const int r0 = g * f.rpb, r1 = min(r0 + f.rpb, f.nblocks);
+    s_red[tid] = fin_level1_part<C2>(f.brows, r0, r1, tid / C2, tid % C2);
+    __syncthreads();
+    if (tid < C2) f.dpartial[(int64_t)g * C2 + tid] = fin_level1_combine<C2>(s_red, tid);
+    __syncthreads();
+  }
+  __threadfence();
+  __syncthreads();
+  s_red[tid] = fin_level2_part<C2>(f.dpartial, f.ngroups, tid / C2, tid % C2);
+  __syncthreads();
+  if (tid < C2) s_tot[tid] = fin_level2_combine<C2>(s_red, tid);
+  __syncthreads();
+  if (tid < CN) fin_write<CN>(f, tid, s_tot[tid], s_tot[CN + tid]);
 }
 static constexpr int VC_EPI_BWD = 3;  // internal (not part of vc_epilogue: selected by vc_conv_backward_input_epilogue)
 
@@ -449,12 +565,15 @@ static constexpr int VC_EPI_BWD = 3;  // internal (not part of vc_epilogue: sele
 // i = 0..15) read 256 CONTIGUOUS bytes when their rows are consecutive (x-adjacent voxels of a sorted tensor), i.e. 4 cache lines
 // per quarter instead of 16: the L1 tag look-ups per gather instruction are what paces this kernel's vector-memory pipeline
 // (8.0-8.7 TB/s for the row-major MFMA mapping against 14.5 TB/s when a quad of lanes shares a line).
-// Occupancy target of an instantiation (waves per SIMD the register allocation must allow; 1 = no requirement).  The
-// backward-epilogue kernels with 64 output channels sat exactly on the 64-VGPR line (8 waves) before the in-kernel BatchNorm
-// finish was added and came out 1-2 registers above it with the tail inlined; pinned back (no scratch, tools/vgpr_table.py).
+// Occupancy target of an instantiation (waves per SIMD the register allocation must allow; 1 = no requirement).  The epilogue
+// kernels with 64 output channels sat on or just below the 64-VGPR line (8 waves) before the in-kernel BatchNorm finish was
+// added; with the tail inlined the allocator takes 74.  Pinned back: the main loop is unaffected, the tail (run by every
+// block once, its reduction levels by a few blocks per launch) spills 44-52 bytes (tools/vgpr_table.py).
 template <int CK, int CN, int EPI, int NW, bool PK, bool DXS>
 constexpr int v2_min_waves() {
-  return (EPI == 3 /* VC_EPI_BWD */ && CN == 64 && CK <= 32 && !DXS && !(CK == 32 && NW == 4 && !PK)) ? 8 : 1;
+  if (DXS || CN != 64 || !(EPI == 1 /* STATS */ || EPI == 3 /* VC_EPI_BWD */)) return 1;
+  if (CK <= 32) return (EPI == 3 && CK == 32 && NW == 4 && !PK) ? 1 : 8;   // were 42-64 VGPRs without the tail
+  return (NW == 8 && PK) ? 7 : 1;                                           // 64 -> 64, 8 waves: was 72
 }
 
 template <int CK, int CN, bool BWD, int RT, int OT, int EPI, int NW = 4, bool PK = false, bool DXS = false, bool IL = false>
@@ -766,6 +885,9 @@ gather_gemm_v2_kernel(const float* __restrict__ src,
 #undef VC_STORE_B
 #undef VC_GATHER_A
 
+  float fin_a[NT], fin_b[NT];   // this wave's partial sums (STATS / BWD) for the in-kernel finish
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { fin_a[nt] = 0.f; fin_b[nt] = 0.f; }
   if constexpr (EPI == VC_EPI_STATS) {
     // per-WAVE partial sums (the wave's 16 rows): rows beyond n_out gathered nothing, their accumulators are exact zeros; fixed
     // order (4 accumulator rows, then the q lanes), no LDS and no barrier -- the block-level reduce this replaces cost two
@@ -779,10 +901,8 @@ gather_gemm_v2_kernel(const float* __restrict__ src,
       sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
       sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
       const int n = nt * 16 + i;
-      if (q == 0 && n < CN) {
-        if (epi.fin.cnt != nullptr) { st_agent(prow + n, sm); st_agent(prow + CN + n, sq); }   // read by another block of this launch
-        else { prow[n] = sm; prow[CN + n] = sq; }
-      }
+      fin_a[nt] = sm; fin_b[nt] = sq;   // in-kernel finish: kept until the block's tail
+      if (q == 0 && n < CN && epi.fin.cnt == nullptr) { prow[n] = sm; prow[CN + n] = sq; }
     }
   }
   float sc[NT], sh[NT];
@@ -856,15 +976,13 @@ gather_gemm_v2_kernel(const float* __restrict__ src,
         sa += __shfl_xor(sa, 16, 64); sb += __shfl_xor(sb, 16, 64);
         sa += __shfl_xor(sa, 32, 64); sb += __shfl_xor(sb, 32, 64);
         const int n = nt * 16 + i;
-        if (q == 0 && n < CN) {
-          if (epi.fin.cnt != nullptr) { st_agent(prow + n, sa); st_agent(prow + CN + n, sb); }
-          else { prow[n] = sa; prow[CN + n] = sb; }
-        }
+        fin_a[nt] = sa; fin_b[nt] = sb;
+        if (q == 0 && n < CN && epi.fin.cnt == nullptr) { prow[n] = sa; prow[CN + n] = sb; }
       }
     }
   }
-  if constexpr ((EPI == VC_EPI_STATS || EPI == VC_EPI_BWD) && RT == 1 && (CN & (CN - 1)) == 0) {
-    if (epi.fin.cnt != nullptr) conv_finish_tail<CN, NTHR>(epi.fin, epi.partial, (int)lbid, wave, smem);   // kernel-uniform
+  if constexpr ((EPI == VC_EPI_STATS || EPI == VC_EPI_BWD) && RT == 1 && (CN & (CN - 1)) == 0 && CN >= 8) {
+    if (epi.fin.cnt != nullptr) conv_finish_tail<CN, NTHR, NT>(epi.fin, (int)lbid, wave, fin_a, fin_b, smem);   // kernel-uniform
   }
 }
 
@@ -2775,24 +2893,26 @@ static inline bool use_window_kernel(int flags, int ot, const int32_t* rep, cons
 }
 
 // ---- in-kernel BatchNorm finish: request hand-over (see BnFinishRequest in common.h) and the ticket pool
-// vc_debug_set "conv_bn_finish": 1 = the epilogue launches finish the BatchNorm sums themselves.  OFF by default -- measured
-// (profiles/r03_bn_finish_in_kernel.md): bit-identical and stable, 75 launches fewer per train step, but the launch's LAST block
-// walks the <= 256 group rows one channel per wave at a time (1.7 us per trip of dependent loads): the conv launches grow by
-// 8 (C = 8) to 29 us (C = 64) against the 13 us (two 5-6 us kernels + two boundaries) they save; train step 5.64 vs 5.45-5.59 ms.
-int g_conv_bn_finish = 0;
+// vc_debug_set "conv_bn_finish": 1 = the epilogue launches finish the BatchNorm sums themselves (conv_finish_tail); 0 = partial rows
+// are left to the BatchNorm kernels; 2 = tests: partial rows, then bn_finish_reference_kernel (the same three levels, one block).
+int g_conv_bn_finish = 1;
 static std::atomic<long long> g_fin_launches{0};   // vc_debug_get "conv_bn_finish_launches"
-struct FinState { bool armed = false, taken = false; BnFinishRequest req{}; };
+struct FinState {
+  bool armed = false, taken = false;
+  BnFinishRequest req{};
+  int nw = 0, nblocks = 0, cn = 0;   // the qualifying launch since the last arm (0: none)
+  float* partial = nullptr;
+};
 static thread_local FinState t_fin;
-void conv_finish_arm(const BnFinishRequest& r) { t_fin.armed = true; t_fin.taken = false; t_fin.req = r; }
-bool conv_finish_take() {
-  const bool t = t_fin.taken;
-  t_fin.armed = t_fin.taken = false;
-  return t;
+void conv_finish_arm(const BnFinishRequest& r) {
+  t_fin = FinState{};
+  t_fin.armed = true;
+  t_fin.req = r;
 }
 // Tickets: kFinSlots x kFinSlotWords zero words per device, allocated once; launches take the slots round-robin.  A slot is
 // all-zero again when its launch ends (the last block clears it); launches of one stream are ordered, so a slot could only be
 // handed to a second launch in flight if kFinSlots finishing launches were outstanding on concurrent streams at once.
-static constexpr int kFinSlots = 256, kFinSlotWords = 288;   // 1 + <= 256 group tickets
+static constexpr int kFinSlots = 256, kFinSlotWords = 80;   // 1 + <= 64 group tickets
 static unsigned* fin_ticket_slot() {
   static std::mutex mu;
   static unsigned* base[32] = {};
@@ -2809,30 +2929,52 @@ static unsigned* fin_ticket_slot() {
   }
   return base[dev] + (size_t)(next++ % kFinSlots) * kFinSlotWords;
 }
+static void fin_fill(ConvFinish& f, const BnFinishRequest& r, float* partial, int nblocks) {
+  f.brows = partial;
+  f.dpartial = r.dpartial;
+  f.o0 = r.o0; f.o1 = r.o1; f.r0 = r.r0; f.r1 = r.r1;
+  f.nbt = r.nbt;
+  f.n = (long long)r.n;
+  f.momentum = r.momentum;
+  f.bwd = r.bwd ? 1 : 0;
+  f.nblocks = nblocks;
+  f.rpb = (int)cdiv((int64_t)nblocks, 64);
+  f.ngroups = (int)cdiv((int64_t)nblocks, (int64_t)f.rpb);
+}
 // attach the armed request to this launch's epilogue if the launch qualifies; `lds` = the launch's dynamic LDS bytes
 static void fin_attach(ConvEpilogue& epi, int epi_kind, unsigned nblocks, int nw, int cn, size_t& lds) {
-  if (!t_fin.armed || t_fin.taken || !g_conv_bn_finish) return;
+  if (!t_fin.armed || t_fin.taken || t_fin.nw != 0 || !g_conv_bn_finish) return;
   const bool bwd = epi_kind == VC_EPI_BWD;
   if (!(epi_kind == VC_EPI_STATS || (bwd && epi.y_raw != nullptr)) || (t_fin.req.bwd != 0) != bwd) return;
-  const int64_t nrows = (int64_t)nblocks * nw;
-  if (nrows <= 512 || (cn & (cn - 1)) != 0 || 2 * cn > 256 || t_fin.req.dpartial == nullptr) return;
+  if ((int64_t)nblocks * nw <= 512 || (cn & (cn - 1)) != 0 || cn < 8 || cn > 64 || t_fin.req.dpartial == nullptr) return;
   if (bwd ? (t_fin.req.r0 == nullptr) : (t_fin.req.o0 == nullptr || t_fin.req.o1 == nullptr)) return;
+  t_fin.nw = nw;
+  t_fin.nblocks = (int)nblocks;
+  t_fin.cn = cn;
+  t_fin.partial = epi.partial;
+  if (g_conv_bn_finish != 1) return;   // 2: the caller's conv_finish_take launches the reference kernel behind this launch
   unsigned* cnt = fin_ticket_slot();
   if (cnt == nullptr) return;
-  ConvFinish& f = epi.fin;
-  f.cnt = cnt;
-  f.dpartial = t_fin.req.dpartial;
-  f.o0 = t_fin.req.o0; f.o1 = t_fin.req.o1; f.r0 = t_fin.req.r0; f.r1 = t_fin.req.r1;
-  f.nbt = t_fin.req.nbt;
-  f.n = (long long)t_fin.req.n;
-  f.momentum = t_fin.req.momentum;
-  f.bwd = bwd ? 1 : 0;
-  f.rpb = (int)bn_partial_rows_per_group(nrows);
-  f.ngroups = (int)cdiv(nrows, (int64_t)f.rpb);
-  f.nrows = (int)nrows;
-  if (lds < 2048 + 16) lds = 2048 + 16;
+  epi.fin.cnt = cnt;
+  fin_fill(epi.fin, t_fin.req, epi.partial, (int)nblocks);
+  if (lds < 4096 + 16) lds = 4096 + 16;
   t_fin.taken = true;
   g_fin_launches.fetch_add(1, std::memory_order_relaxed);
+}
+bool conv_finish_take(hipStream_t st) {
+  bool done = t_fin.taken;
+  if (!done && t_fin.armed && g_conv_bn_finish == 2 && t_fin.nw != 0) {   // tests: the same arithmetic by one block
+    ConvFinish f;
+    fin_fill(f, t_fin.req, t_fin.partial, t_fin.nblocks);
+    switch (t_fin.cn) {
+#define VC_FR(C_) case C_: hipLaunchKernelGGL((bn_finish_reference_kernel<C_>), dim3(1), dim3(256), 0, st, f, (const float*)t_fin.partial, t_fin.nw); break
+      VC_FR(8); VC_FR(16); VC_FR(32); VC_FR(64);
+#undef VC_FR
+    }
+    done = hipGetLastError() == hipSuccess;
+  }
+  t_fin = FinState{};
+  return done;
 }
 
 template <int CK, int CN, bool BWD>

@@ -447,7 +447,7 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
                                                u.cin, u.cout, t.subm ? 1 : 0, dup ? t.centre : -1, dup ? t.rep : nullptr,
                                                t.order_bwd, flags, addv.p, addv.stride, addv.col0, cy, cmean, cvar, cg, cb, ceps,
                                                crelu, fpart, dx, st);
-          if (conv_finish_take() && cprod >= 0) fused[cprod].sums = fpart + (size_t)fused[cprod].nblocks * 2 * u.cin;
+          if (conv_finish_take(st) && cprod >= 0) fused[cprod].sums = fpart + (size_t)fused[cprod].nblocks * 2 * u.cin;
         } else {
           rc = vc_conv_backward_input(src, src_centre, t.n_out, t.subm ? t.pair_fwd : t.pair_bwd, t.n_in, t.kv, u.weight, u.cin,
                                       u.cout, t.subm ? 1 : 0, dup ? t.centre : -1, dup ? t.rep : nullptr, t.order_bwd,

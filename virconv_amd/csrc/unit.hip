@@ -44,7 +44,7 @@ int vc_post_act_block_forward(const float* x, int64_t n_in, const int32_t* pair_
                                     (double*)bn_ws});
     rc = vc_conv_forward_epilogue(x, n_in, pair_fwd, n_out, kv, weight, cin, cout, row_order, VC_EPI_STATS, flags, partial,
                                   nullptr, nullptr, nullptr, nullptr, 0.f, 0, y_raw, stream);
-    const bool finished = conv_finish_take();
+    const bool finished = conv_finish_take((hipStream_t)stream);
     if (rc != VC_OK) return rc;
     if (!finished)
       rc = vc_bn_stats_from_partial(partial, (int64_t)(pf / (2 * (size_t)cout)), n_out, cout, mean, var, running_mean,
