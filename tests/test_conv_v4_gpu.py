@@ -196,6 +196,16 @@ def test_v4_whole_train_step_equals_v2(hip_backend, discard, monkeypatch):
         return float(loss.detach()), res, {k: p.grad.detach().clone() for k, p in model.named_parameters()}
 
     lib = hip_backend.lib
+    # v4 leaves its partial rows to the BatchNorm kernels; v2 would finish the sums in its own launch (another, equally fixed,
+    # summation order): compare the two conv kernels on the same route
+    assert lib.vc_debug_set(b"conv_bn_finish", 0) == 0
+    try:
+        _run_v4_vs_v2(lib, one)
+    finally:
+        assert lib.vc_debug_set(b"conv_bn_finish", 1) == 0
+
+
+def _run_v4_vs_v2(lib, one):
     with _V4(lib, 0):
         ref = one()                                   # v2, fragment-ordered weight images (the pass packs them)
         assert lib.vc_debug_set(b"conv_packed", 0) == 0

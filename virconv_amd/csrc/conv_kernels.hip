@@ -296,7 +296,7 @@ struct BufLoad<1> {
 // the finished per-channel numbers, instead of leaving per-wave partial rows to bn_partial_reduce_kernel + a finalize kernel -- two
 // 5-6 us launches (and two kernel boundaries) per BatchNorm on the main stream's critical path, 55 of them per train step.
 // Three levels, arrival tickets, no spinning (MI355X guide, "in-launch split-K reduction", write-through form):
-//   level 0  every block adds the rows of its 4 / 8 waves through LDS (fp32, wave order) and stores ONE row write-through (sc1);
+//   level 0  every block adds the rows of its 4 / 8 waves through LDS (fp64, wave order) and stores ONE fp64 row write-through (sc1);
 //   level 1  blocks are grouped rpb = ceil(blocks / 64) at a time; the block that draws a group's last ticket adds the group's
 //            block rows (fp64; thread = (row sub-index, column), rows ascending, then the sub-indices ascending) and stores the
 //            fp64 group row write-through;
@@ -307,7 +307,7 @@ struct BufLoad<1> {
 // to bn_finish_reference_kernel, a single block that performs the same three levels one after the other (tests).
 struct ConvFinish {
   unsigned* cnt = nullptr;     // [0]: launch tickets, [1 + g]: tickets of group g; nullptr: no in-kernel finish
-  float* brows = nullptr;      // [nblocks][2 CN] block rows (the launch's partial buffer)
+  double* brows = nullptr;     // [nblocks][2 CN] fp64 block rows (in the launch's partial buffer: 2 x 4 bytes <= waves x 4 bytes)
   double* dpartial = nullptr;  // [ngroups][2 CN]
   float *o0 = nullptr, *o1 = nullptr, *r0 = nullptr, *r1 = nullptr;   // see BnFinishRequest
   long long* nbt = nullptr;
@@ -347,33 +347,33 @@ __device__ __forceinline__ void st_agent(double* p, double v) {
 // ---- the three levels as device functions, shared by the ticketed tail and by the single-block reference kernel
 // level 0: column `col` of a block row = the block's per-wave rows added in wave order
 template <int C2, int NWV>
-__device__ __forceinline__ float fin_level0(const float* rows /* [NWV][C2] */, int col) {
-  float t = rows[col];
+__device__ __forceinline__ double fin_level0(const float* rows /* [NWV][C2] */, int col) {
+  double t = (double)rows[col];   // fp64 from the 16-row wave sums up, as on the two-launch route
 #pragma unroll
-  for (int w_ = 1; w_ < NWV; ++w_) t += rows[w_ * C2 + col];
+  for (int w_ = 1; w_ < NWV; ++w_) t += (double)rows[w_ * C2 + col];
   return t;
 }
 // level 1, thread part: block rows r0 + rs, r0 + rs + RS, ... < r1 of column col, ascending, fp64
 template <int C2>
-__device__ __forceinline__ double fin_level1_part(const float* __restrict__ brows, int r0, int r1, int rs, int col) {
+__device__ __forceinline__ double fin_level1_part(const double* __restrict__ brows, int r0, int r1, int rs, int col) {
   constexpr int RS = 256 / C2;
   double acc = 0.0;
   int r = r0 + rs;
   for (; r + 7 * RS < r1; r += 8 * RS) {
-    float v[8];
+    double v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = ld_agent(brows + (int64_t)(r + u * RS) * C2 + col);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc += (double)v[u];
+    for (int u = 0; u < 8; ++u) acc += v[u];
   }
   for (; r + 3 * RS < r1; r += 4 * RS) {
-    float v[4];
+    double v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) v[u] = ld_agent(brows + (int64_t)(r + u * RS) * C2 + col);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc += (double)v[u];
+    for (int u = 0; u < 4; ++u) acc += v[u];
   }
-  for (; r < r1; r += RS) acc += (double)ld_agent(brows + (int64_t)r * C2 + col);
+  for (; r < r1; r += RS) acc += ld_agent(brows + (int64_t)r * C2 + col);
   return acc;
 }
 template <int C2>
@@ -456,22 +456,21 @@ __device__ __forceinline__ void fin_write(const ConvFinish& f, int ch, double s,
   }
 }
 
-// Tail of a v2 block whose launch finishes the BatchNorm sums (see ConvFinish).  Called by ALL threads of the block once its
-// epilogue stores are issued; (pa, pb)[nt] = this wave's partial sums of columns nt * 16 + i (valid in the lanes q == 0).
-// `smem` is the block's dynamic LDS (>= 4 KB + 16 B).
+// Tail of a v2 block whose launch finishes the BatchNorm sums (see ConvFinish), in two parts so that the block's output stores can
+// sit between them: the ticket part must not wait for them (a write-through store is followed by vmcnt(0), which would also drain
+// every output store issued before it: 1-2 us per block with all of its waves parked at a barrier).
+// conv_finish_ticket: called by ALL threads once the wave's partial sums are final; (pa, pb)[nt] = this wave's partial sums of
+// columns nt * 16 + i (valid in the lanes q == 0); `smem` = the block's dynamic LDS (>= 4 KB + 16 B; the caller must have read
+// whatever it still needs from it).  Returns (block-uniform) whether this block drew the last ticket of its group.
 template <int CN, int NTHR, int NT>
-__device__ __forceinline__ void conv_finish_tail(const ConvFinish& f, int lbid, int wave, const float (&pa)[NT], const float (&pb)[NT],
-                                                 unsigned char* smem) {
+__device__ __forceinline__ int conv_finish_ticket(const ConvFinish& f, int lbid, int wave, const float (&pa)[NT], const float (&pb)[NT],
+                                                  unsigned char* smem) {
   constexpr int C2 = 2 * CN;
   constexpr int NWV = NTHR / 64;
   static_assert(C2 <= 128 && C2 >= 16 && (C2 & (C2 - 1)) == 0, "in-kernel BatchNorm finish: power-of-two channel count 8 .. 64");
-  // lane from mbcnt, thread index from (wave, lane): nothing of the main loop's registers has to stay alive for this tail
   const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-  const int tid = wave * 64 + lane;
   const int i = lane & 15, q = lane >> 4;
   float* s_rows = reinterpret_cast<float*>(smem);           // [NWV][C2]  (level 0)
-  double* s_red = reinterpret_cast<double*>(smem);          // [RS][C2]   (levels 1 and 2, after s_rows is dead)
-  double* s_tot = reinterpret_cast<double*>(smem + 2048);   // [C2]       (level 2)
   int* s_flag = reinterpret_cast<int*>(smem + 4096);
   __syncthreads();                                          // every wave is done with the main loop's LDS
   if (q == 0) {
@@ -482,9 +481,9 @@ __device__ __forceinline__ void conv_finish_tail(const ConvFinish& f, int lbid, 
     }
   }
   __syncthreads();
-  const int grp = lbid / f.rpb;
-  const int g_r0 = grp * f.rpb, g_r1 = min(g_r0 + f.rpb, f.nblocks);
   if (wave == 0) {
+    const int grp = lbid / f.rpb;
+    const int g_r0 = grp * f.rpb, g_r1 = min(g_r0 + f.rpb, f.nblocks);
     for (int col = lane; col < C2; col += 64) st_agent(f.brows + (int64_t)lbid * C2 + col, fin_level0<C2, NWV>(s_rows, col));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the block row has left (write-through)
     if (lane == 0) {
@@ -495,7 +494,21 @@ __device__ __forceinline__ void conv_finish_tail(const ConvFinish& f, int lbid, 
     }
   }
   __syncthreads();
-  if (s_flag[0] == 0) return;   // block-uniform
+  return s_flag[0];
+}
+// conv_finish_reduce: called by ALL threads of a block whose conv_finish_ticket returned 1: level 1 of its group and, if the group
+// is the launch's last one to finish, level 2.
+template <int CN, int NTHR>
+__device__ __forceinline__ void conv_finish_reduce(const ConvFinish& f, int lbid, int wave, unsigned char* smem) {
+  constexpr int C2 = 2 * CN;
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int tid = wave * 64 + lane;
+  double* s_red = reinterpret_cast<double*>(smem);          // [RS][C2]
+  double* s_tot = reinterpret_cast<double*>(smem + 2048);   // [C2]
+  int* s_flag = reinterpret_cast<int*>(smem + 4096);
+  const int grp = lbid / f.rpb;
+  const int g_r0 = grp * f.rpb, g_r1 = min(g_r0 + f.rpb, f.nblocks);
+  __syncthreads();   // every thread has read the ticket flag
   // ---- level 1
   if (tid < 256) s_red[tid] = fin_level1_part<C2>(f.brows, g_r0, g_r1, tid / C2, tid % C2);
   __syncthreads();
@@ -527,11 +540,18 @@ __global__ void __launch_bounds__(256) bn_finish_reference_kernel(ConvFinish f, 
   __shared__ double s_red[256];
   __shared__ double s_tot[C2];
   const int tid = threadIdx.x;
-  for (int b = 0; b < f.nblocks; ++b)
+  for (int b = 0; b < f.nblocks; ++b) {
+    // in place: block b's fp64 row covers floats [2 b C2, 2 (b + 1) C2) of the buffer, i.e. wave rows of blocks <= b / 2 (b = 0:
+    // its own first two wave rows, read just before)
+    double t = 0.0;
     if (tid < C2) {
       const float* rows = wave_rows + (int64_t)b * nwv * C2;
-      f.brows[(int64_t)b * C2 + tid] = (nwv == 8) ? fin_level0<C2, 8>(rows, tid) : fin_level0<C2, 4>(rows, tid);
+      t = (nwv == 8) ? fin_level0<C2, 8>(rows, tid) : fin_level0<C2, 4>(rows, tid);
     }
+    __syncthreads();
+    if (tid < C2) f.brows[(int64_t)b * C2 + tid] = t;
+    __syncthreads();
+  }
   __threadfence();
   __syncthreads();
   for (int g = 0; g < f.ngroups; ++g) {
@@ -935,37 +955,41 @@ gather_gemm_v2_kernel(const float* __restrict__ src,
       }
     }
   }
+  // ---- phase A: the final values, in place in the accumulators (AFFINE: scale / shift / ReLU; BWD: + addend, and the sums)
+  int orow[RT][4];   // output rows of this wave's tile slots, read before the finish part reuses the LDS
 #pragma unroll
-  for (int t = 0; t < RT; ++t) {
-    int64_t orow[4];
+  for (int t = 0; t < RT; ++t)
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) orow[reg] = s_row[wave * (RT * 16) + t * 16 + q * 4 + reg];
+    for (int reg = 0; reg < 4; ++reg) orow[t][reg] = s_row[wave * (RT * 16) + t * 16 + q * 4 + reg];
+  if constexpr (EPI == VC_EPI_AFFINE || EPI == VC_EPI_BWD) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = nt * 16 + i;
-      if (n >= CN) continue;
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        float v = acc[t][nt][reg];
-        if constexpr (EPI == VC_EPI_AFFINE) {
-          v = v * sc[nt] + sh[nt];
-          if (epi.relu) v = fmaxf(v, 0.f);
-        }
-        if constexpr (EPI == VC_EPI_BWD) {
-          if (orow[reg] >= 0) {
-            if (epi.addend != nullptr) v += epi.addend[orow[reg] * epi.add_stride + epi.add_col0 + n];
-            if (bwd_stats) {
-              const float xh = (epi.y_raw[orow[reg] * CN + n] - b_mu[nt]) * b_istd[nt];
-              float d = v;
-              if (epi.relu && !(xh * b_g[nt] + b_bt[nt] > 0.f)) d = 0.f;
-              b_sa[nt] += d;
-              b_sb[nt] += d * xh;
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 16 + i;
+        if (n >= CN) continue;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          float v = acc[t][nt][reg];
+          if constexpr (EPI == VC_EPI_AFFINE) {
+            v = v * sc[nt] + sh[nt];
+            if (epi.relu) v = fmaxf(v, 0.f);
+          }
+          if constexpr (EPI == VC_EPI_BWD) {
+            if (orow[t][reg] >= 0) {
+              if (epi.addend != nullptr) v += epi.addend[(int64_t)orow[t][reg] * epi.add_stride + epi.add_col0 + n];
+              if (bwd_stats) {
+                const float xh = (epi.y_raw[(int64_t)orow[t][reg] * CN + n] - b_mu[nt]) * b_istd[nt];
+                float d = v;
+                if (epi.relu && !(xh * b_g[nt] + b_bt[nt] > 0.f)) d = 0.f;
+                b_sa[nt] += d;
+                b_sb[nt] += d * xh;
+              }
             }
           }
+          acc[t][nt][reg] = v;
         }
-        if (orow[reg] >= 0) out[orow[reg] * CN + n] = v;
       }
-    }
   }
   if constexpr (EPI == VC_EPI_BWD) {
     if (bwd_stats) {  // per-WAVE partial row [2][CN]: (sum dy_masked, sum dy_masked * xhat), fixed order, no LDS, no barrier
@@ -981,8 +1005,24 @@ gather_gemm_v2_kernel(const float* __restrict__ src,
       }
     }
   }
+  // ---- in-kernel BatchNorm finish, ticket part: BEFORE the output stores (it waits for its own write-through store only)
+  int fin_last = 0;
   if constexpr ((EPI == VC_EPI_STATS || EPI == VC_EPI_BWD) && RT == 1 && (CN & (CN - 1)) == 0 && CN >= 8) {
-    if (epi.fin.cnt != nullptr) conv_finish_tail<CN, NTHR, NT>(epi.fin, (int)lbid, wave, fin_a, fin_b, smem);   // kernel-uniform
+    if (epi.fin.cnt != nullptr) fin_last = conv_finish_ticket<CN, NTHR, NT>(epi.fin, (int)lbid, wave, fin_a, fin_b, smem);   // kernel-uniform
+  }
+  // ---- phase B: the stores
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 16 + i;
+      if (n >= CN) continue;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        if (orow[t][reg] >= 0) out[(int64_t)orow[t][reg] * CN + n] = acc[t][nt][reg];
+    }
+  if constexpr ((EPI == VC_EPI_STATS || EPI == VC_EPI_BWD) && RT == 1 && (CN & (CN - 1)) == 0 && CN >= 8) {
+    if (fin_last) conv_finish_reduce<CN, NTHR>(epi.fin, (int)lbid, wave, smem);   // block-uniform
   }
 }
 
@@ -2930,7 +2970,7 @@ static unsigned* fin_ticket_slot() {
   return base[dev] + (size_t)(next++ % kFinSlots) * kFinSlotWords;
 }
 static void fin_fill(ConvFinish& f, const BnFinishRequest& r, float* partial, int nblocks) {
-  f.brows = partial;
+  f.brows = reinterpret_cast<double*>(partial);
   f.dpartial = r.dpartial;
   f.o0 = r.o0; f.o1 = r.o1; f.r0 = r.r0; f.r1 = r.r1;
   f.nbt = r.nbt;
