@@ -30,6 +30,7 @@ FAMILIES = [
     ("rulebook (hash/subm/sp_*/row_order)", r"vc::(hash_|subm_|sp_|scan_|row_order|flag_)"),
     ("group_sum (seg_sum / seg_fixup / plan keys; r1-r2: fixed-point + absmax + convert)", r"vc::(group_|seg_|absmax)"),
     ("sort (rocPRIM radix sort of the duplicate-pixel group plans)", r"rocprim"),
+    ("loss (vc_weighted_sum: the benchmark's stand-in loss, fused product + reduction)", r"weighted_sum"),
     ("other vc:: (project, gather/scatter rows, dense, voxelizer)", r"vc::"),
     ("memset/copy", r"__amd_rocclr"),
     ("torch (loss, optimizer, randperm, cat, ...)", r"."),
