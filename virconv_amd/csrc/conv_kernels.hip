@@ -658,11 +658,27 @@ gather_gemm_v2_kernel(const float* __restrict__ src,
     const int64_t row = inb ? (order ? (int64_t)order[brow0 + r] : brow0 + r) : -1;
     if (tid < TM) s_row[r] = (int)row;
     const bool centre_only = (rep != nullptr) && inb && (rep[row] != (int32_t)row);
-    for (int k = tid / TM; k < kv; k += NTHR / TM) {
-      int v = inb ? tbl[(int64_t)k * n_out + row] : -1;
-      if (centre_only && k != centre) v = -1;
-      s_idx[k * TM + r] = v;
-      if (__ballot(v >= 0) != 0ULL && lane == 0) atomicOr(&s_mask[0], 1u << k);
+    // all of a thread's table entries in flight together (up to 8 per trip): the plain loop waited for every load before its
+    // LDS store and ballot -- 7 dependent global round trips at the head of EVERY block (KV = 27), most of the run time of the
+    // single-round launches of stage 1
+    constexpr int KSTEP = NTHR / TM;
+    for (int kb = tid / TM; kb < kv; kb += 8 * KSTEP) {
+      int vv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = kb + u * KSTEP;
+        vv[u] = (inb && k < kv) ? tbl[(int64_t)k * n_out + row] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = kb + u * KSTEP;   // wave-uniform (TM is a multiple of 64)
+        if (k < kv) {
+          int v = vv[u];
+          if (centre_only && k != centre) v = -1;
+          s_idx[k * TM + r] = v;
+          if (__ballot(v >= 0) != 0ULL && lane == 0) atomicOr(&s_mask[0], 1u << k);
+        }
+      }
     }
   }
   __syncthreads();
