@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 3, GPU call 25: final bench lines
+R="$GRAFT_REPO_ROOT"; cd "$R" || exit 1
+O=gpurun_out/r3z
+mkdir -p $O
+python bench.py > $O/bench_full.log 2>&1
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_form.log 2>&1
+python bench.py --model 8x --steps 40 --warmup 12 --no-cpu-baseline > $O/bench_8x.log 2>&1
+python bench.py --operand f16 --steps 40 --warmup 12 --no-cpu-baseline --family-steps 0 > $O/bench_f16.log 2>&1
+python bench.py --frontend --steps 40 --warmup 12 --no-cpu-baseline --family-steps 0 > $O/bench_frontend.log 2>&1
+python bench.py --mode infer --batch-size 1 > $O/infer_bs1.log 2>&1
+python bench.py --mode infer --batch-size 4 > $O/infer_bs4.log 2>&1
+timeout 100 python tools/step_phases.py > $O/phases.txt 2>&1
+for f in $O/*.log; do echo $f $(grep -o '"ms_per_step": [0-9.]*' $f) $(grep -o '"value": [0-9.]*' $f | head -1); done; tail -1 $O/phases.txt
