@@ -55,6 +55,10 @@ const char* vc_last_error(void);
 int vc_debug_set(const char* key, int value);
 /* developer counters: "conv_bn_finish_launches" = conv launches of this process that finished their BatchNorm sums in-kernel */
 int vc_debug_get(const char* key, int64_t* value);
+/* developer check (tests): a consumer on a second stream behind a slow producer on `stream_a`; mode 1 = the dependency is the
+ * producer launch's own completion event (hipExtLaunchKernelGGL, what the feature pass uses for its weight-gradient forks),
+ * 0 = hipEventRecord, 2 = none (negative control).  buf, out: n int32 each; out[i] = what the consumer read (1 = produced). */
+int vc_debug_stop_event_dependency(int32_t* buf, int32_t* out, int64_t n, int spin, int mode, void* stream_a);
 
 /* ------------------------------------------------------------------------------------------------ K3 hash
  * Coordinate -> row hash (open addressing, 64-bit linearised key, duplicate rule rep(c) = max row; SURVEY

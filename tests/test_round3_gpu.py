@@ -267,3 +267,22 @@ def test_weighted_sum_is_one_deterministic_pass_and_matches_float64(hip_backend,
     want = (3.0 * g).reshape((1,) + tuple(x.shape[1:])).expand(x.shape) if x.dim() > 2 else (3.0 * g).expand(x.shape)
     assert x.grad.shape == x.shape
     assert torch.equal(x.grad, want.contiguous()) or float((x.grad - want).abs().max()) <= 1e-7 * float(want.abs().max())
+
+
+def test_kernel_completion_event_orders_a_second_stream(hip_backend):
+    """The feature pass forks its weight gradients onto the side stream behind the COMPLETION EVENT of the unit's last main-stream
+    launch (hipExtLaunchKernelGGL stop event: no marker packet in the main queue).  vc_debug_stop_event_dependency: a ~1 ms producer
+    on one stream, a consumer on another; with the bound event (mode 1) and with hipEventRecord (mode 0) the consumer must see
+    every element produced; without any dependency (mode 2, control) it must not -- which shows the check can fail."""
+    from virconv_amd.backend_hip import _ptr, _stream
+    lib = hip_backend.lib
+    n = 1 << 22
+    buf = torch.empty(n, dtype=torch.int32, device="cuda")
+    out = torch.empty(n, dtype=torch.int32, device="cuda")
+    for mode in (1, 0, 1, 1):
+        assert lib.vc_debug_stop_event_dependency(_ptr(buf), _ptr(out), n, 20000, mode, _stream()) == 0
+        torch.cuda.synchronize()
+        assert int((out != 1).sum()) == 0, mode
+    assert lib.vc_debug_stop_event_dependency(_ptr(buf), _ptr(out), n, 20000, 2, _stream()) == 0
+    torch.cuda.synchronize()
+    assert int((out != 1).sum()) > 0, "the control (no dependency) saw everything: the producer is too fast for this check"

@@ -26,6 +26,7 @@ SIGNATURES = {
     "vc_last_error": (C.c_char_p, []),
     "vc_debug_set": (_I, [C.c_char_p, _I]),
     "vc_debug_get": (_I, [C.c_char_p, _P]),
+    "vc_debug_stop_event_dependency": (_I, [_P, _P, _I64, _I, _I, _P]),
     "vc_weighted_sum_workspace_bytes": (_SZ, [_I64, _I64]),
     "vc_weighted_sum": (_I, [_P, _I64, _I64, _P, _P, _P, _SZ, _P]),
     "vc_weighted_sum_backward": (_I, [_P, _P, _I64, _I64, _P, _P]),

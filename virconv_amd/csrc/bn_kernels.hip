@@ -521,7 +521,7 @@ int bn_bwd_dx_launch(const float* x, const float* dy, int dy_stride, int dy_col0
   const int lg = bn_lg_c4(c);
   VC_REQUIRE(lg >= 0, "bn_bwd_dx_launch: channel count must be a power of two");
   const int rows_per_block = (256 >> lg) * kBnRowsPerThread;
-  hipLaunchKernelGGL(bn_bwd_dx_pow2_kernel, dim3((unsigned)cdiv(n, rows_per_block)), dim3(256), 0, st, x, dy, dy_stride, dy_col0,
+  VC_LAUNCH_WITH_STOP_EVENT(bn_bwd_dx_pow2_kernel, dim3((unsigned)cdiv(n, rows_per_block)), dim3(256), 0, st, x, dy, dy_stride, dy_col0,
                      n, c, lg, mean, var, gamma, beta, eps, relu, sums, dx, (unsigned*)nullptr);
   VC_CHECK_LAUNCH("bn_bwd_dx_kernel");
   return VC_OK;
@@ -631,11 +631,11 @@ int vc_bn_relu_backward(const float* x, const float* dy, int dy_stride, int dy_c
   const int lg = bn_lg_c4(c);
   if (lg >= 0) {
     const int rows_per_block = (256 >> lg) * kBnRowsPerThread;
-    hipLaunchKernelGGL(bn_bwd_dx_pow2_kernel, dim3((unsigned)cdiv(n, rows_per_block)), dim3(256), 0, st, x, dy, dy_stride,
+    VC_LAUNCH_WITH_STOP_EVENT(bn_bwd_dx_pow2_kernel, dim3((unsigned)cdiv(n, rows_per_block)), dim3(256), 0, st, x, dy, dy_stride,
                        dy_col0, n, c, lg, mean, var, gamma, beta, eps, relu, sums, dx, absmax_out);
   } else {
     VC_REQUIRE(absmax_out == nullptr, "vc_bn_relu_backward: absmax_out needs a power-of-two channel count");
-    hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3((unsigned)cdiv(n * (c / 4), 256)), dim3(256), 0, st, x, dy, dy_stride,
+    VC_LAUNCH_WITH_STOP_EVENT(bn_bwd_dx_kernel, dim3((unsigned)cdiv(n * (c / 4), 256)), dim3(256), 0, st, x, dy, dy_stride,
                        dy_col0, n, c, mean, var, gamma, beta, eps, relu, sums, dx);
   }
   VC_CHECK_LAUNCH("bn_bwd_dx_kernel");
@@ -670,7 +670,7 @@ int vc_bn_relu_backward_from_partial(const float* x, const float* dy, int dy_str
   const int lg = bn_lg_c4(c);
   VC_REQUIRE(lg >= 0, "vc_bn_relu_backward_from_partial: channel count must be a power of two");
   const int rows_per_block = (256 >> lg) * kBnRowsPerThread;
-  hipLaunchKernelGGL(bn_bwd_dx_pow2_kernel, dim3((unsigned)cdiv(n, rows_per_block)), dim3(256), 0, st, x, dy, dy_stride, dy_col0,
+  VC_LAUNCH_WITH_STOP_EVENT(bn_bwd_dx_pow2_kernel, dim3((unsigned)cdiv(n, rows_per_block)), dim3(256), 0, st, x, dy, dy_stride, dy_col0,
                      n, c, lg, mean, var, gamma, beta, eps, relu, sums, dx, absmax_out);
   VC_CHECK_LAUNCH("bn_bwd_dx_kernel");
   return VC_OK;

@@ -1,6 +1,7 @@
 // Shared host/device helpers for libvirconv_hip.so (gfx950 only; wave = 64).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -180,6 +181,27 @@ bool conv_finish_take(hipStream_t st);   // true: the sums are finished (by the 
 int bn_bwd_dx_launch(const float* x, const float* dy, int dy_stride, int dy_col0, int64_t n, int c, const float* mean,
                      const float* var, const float* gamma, const float* beta, float eps, int relu, const float* sums, float* dx,
                      hipStream_t st);
+
+// Cross-stream dependency without a marker packet.  hipEventRecord puts a barrier packet into the producer's queue; between two
+// short kernels of the main stream that packet costs 5-8 us of queue time (profiles/r03_trace_gaps.txt: the gap in front of every
+// backward-input conv whose unit forks its weight gradient onto the side stream).  hipExtLaunchKernelGGL can instead bind an event
+// to the completion signal of the kernel it launches.  A caller arms the slot with an event right before calling an operator; the
+// operator's LAST launch (VC_LAUNCH_WITH_STOP_EVENT) takes it; the caller then waits on the event from the other stream, or falls
+// back to hipEventRecord when nothing took it.
+struct StopEventSlot {
+  hipEvent_t ev = nullptr;
+  bool bound = false;
+};
+inline thread_local StopEventSlot t_stop_event;
+#define VC_LAUNCH_WITH_STOP_EVENT(kernel, grid, block, lds, st, ...)                                              \
+  do {                                                                                                            \
+    if (::vc::t_stop_event.ev != nullptr && !::vc::t_stop_event.bound) {                                          \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, st, nullptr, ::vc::t_stop_event.ev, 0, __VA_ARGS__);         \
+      ::vc::t_stop_event.bound = true;                                                                            \
+    } else {                                                                                                      \
+      hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                              \
+    }                                                                                                             \
+  } while (0)
 
 static inline uint64_t coord_hash_capacity(int64_t n) {
   uint64_t oct = 128;

@@ -3364,7 +3364,8 @@ int g_bw_rows_per_split = 1024;  // weight gradient: target rows per block (vc_d
 int g_bw_legacy_order = 0;      // debug: 1 = offset-major block order of the weight-gradient kernel
 int g_bw_variant = 1;           // vc_debug_set bw_variant: 1 = bwd_weight_kernel, 2 = bwd_weight_v2_kernel (dy window in LDS) where it applies
 extern int g_pass_dw_main_tail; // pass.hip
-extern int g_pass_bwd_epilogue; // pass.hip
+extern int g_pass_bwd_epilogue;
+extern int g_pass_fork_ext_event; // pass.hip
 extern int g_bn_fused_partial;  // bn_kernels.hip
 extern int g_pass_defer_dw_reduce;  // pass.hip
 static constexpr int kMaxSplit = 256;
@@ -3515,6 +3516,7 @@ int vc_debug_set(const char* key, int value) {
   if (key && !strcmp(key, "bw_rows_per_split")) { if (value >= 256) g_bw_rows_per_split = value; return VC_OK; }
   if (key && !strcmp(key, "pass_dw_main_tail")) { g_pass_dw_main_tail = value; return VC_OK; }
   if (key && !strcmp(key, "pass_bwd_epilogue")) { g_pass_bwd_epilogue = value; return VC_OK; }
+  if (key && !strcmp(key, "pass_fork_ext_event")) { g_pass_fork_ext_event = value; return VC_OK; }
   if (key && !strcmp(key, "bn_fused_partial")) { g_bn_fused_partial = value; return VC_OK; }
   if (key && !strcmp(key, "conv_bn_finish")) { g_conv_bn_finish = value; return VC_OK; }
   if (key && !strcmp(key, "conv_pc")) { g_conv_pc = value; return VC_OK; }

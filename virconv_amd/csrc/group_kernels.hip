@@ -208,6 +208,18 @@ __global__ void __launch_bounds__(256) weighted_sum_backward_kernel(const float*
   }
 }
 
+__global__ void __launch_bounds__(256) dbg_slow_fill_kernel(int32_t* __restrict__ buf, int64_t n, int spin) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  unsigned x = (unsigned)i;
+  for (int s_ = 0; s_ < spin; ++s_) x = x * 1664525u + 1013904223u;   // a dependent chain the compiler cannot fold
+  buf[i] = 1 + (int)(x == 0xdeadbeefu && spin < 0);
+}
+__global__ void __launch_bounds__(256) dbg_copy_kernel(const int32_t* __restrict__ a, int32_t* __restrict__ b, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) b[i] = __hip_atomic_load(a + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 static inline void weighted_sum_grid(int64_t nb, int64_t e, int& mode, dim3& grid) {
   if (e <= 1024 && (e & (e - 1)) == 0) {
     mode = 1;
@@ -289,14 +301,52 @@ int vc_group_sum_sorted(const float* dy, const int32_t* grp_plan, int64_t n, int
   const int32_t* order = grp_plan;
   const int32_t* keys = grp_plan + n;
   const int64_t threads = cdiv(n, kSegRows) * c;
-  hipLaunchKernelGGL(seg_sum_kernel, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, st, dy, order, keys, n, c, lg, dy_grp,
-                     (float*)ws);
-  VC_CHECK_LAUNCH("seg_sum_kernel");
   if (n > kSegRows) {
-    hipLaunchKernelGGL(seg_fixup_kernel, dim3((unsigned)(cdiv(n, kSegRows) - 1)), dim3(256), 0, st, keys, n, c, lg, (const float*)ws,
-                       dy_grp);
+    hipLaunchKernelGGL(seg_sum_kernel, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, st, dy, order, keys, n, c, lg, dy_grp,
+                       (float*)ws);
+    VC_CHECK_LAUNCH("seg_sum_kernel");
+    VC_LAUNCH_WITH_STOP_EVENT(seg_fixup_kernel, dim3((unsigned)(cdiv(n, kSegRows) - 1)), dim3(256), 0, st, keys, n, c, lg,
+                              (const float*)ws, dy_grp);
+    VC_CHECK_LAUNCH("seg_fixup_kernel");
+  } else {
+    VC_LAUNCH_WITH_STOP_EVENT(seg_sum_kernel, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, st, dy, order, keys, n, c, lg, dy_grp,
+                              (float*)ws);
+    VC_CHECK_LAUNCH("seg_sum_kernel");
   }
-  VC_CHECK_LAUNCH("seg_fixup_kernel");
+  return VC_OK;
+}
+
+// ---- developer check of the stop-event dependency (tests/test_round3_gpu.py): a slow producer on `stream_a`, a consumer on a
+// second stream.  mode 1: the producer's completion event bound by its launch (VC_LAUNCH_WITH_STOP_EVENT); mode 0: hipEventRecord
+// behind it; mode 2: no dependency at all (negative control).  out[i] = what the consumer saw of buf[i].
+int vc_debug_stop_event_dependency(int32_t* buf, int32_t* out, int64_t n, int spin, int mode, void* stream_a) {
+  VC_REQUIRE(buf && out && n >= 1 && spin >= 0 && mode >= 0 && mode <= 2, "vc_debug_stop_event_dependency: invalid argument");
+  hipStream_t a = (hipStream_t)stream_a, b = nullptr;
+  hipEvent_t ev = nullptr;
+  VC_CHECK_HIP(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
+  VC_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  VC_CHECK_HIP(hipMemsetAsync(buf, 0, (size_t)n * 4, a));
+  VC_CHECK_HIP(hipMemsetAsync(out, 0xFF, (size_t)n * 4, a));
+  VC_CHECK_HIP(hipStreamSynchronize(a));
+  const dim3 grid((unsigned)cdiv(n, 256));
+  if (mode == 1) {
+    t_stop_event = StopEventSlot{ev, false};
+    VC_LAUNCH_WITH_STOP_EVENT(dbg_slow_fill_kernel, grid, dim3(256), 0, a, buf, n, spin);
+    const bool bound = t_stop_event.bound;
+    t_stop_event = StopEventSlot{};
+    if (!bound) { set_error("vc_debug_stop_event_dependency: the launch did not take the event"); return VC_EHIP; }
+  } else {
+    hipLaunchKernelGGL(dbg_slow_fill_kernel, grid, dim3(256), 0, a, buf, n, spin);
+    if (mode == 0) VC_CHECK_HIP(hipEventRecord(ev, a));
+  }
+  VC_CHECK_LAUNCH("dbg_slow_fill_kernel");
+  if (mode != 2) VC_CHECK_HIP(hipStreamWaitEvent(b, ev, 0));
+  hipLaunchKernelGGL(dbg_copy_kernel, grid, dim3(256), 0, b, (const int32_t*)buf, out, n);
+  VC_CHECK_LAUNCH("dbg_copy_kernel");
+  VC_CHECK_HIP(hipStreamSynchronize(b));
+  VC_CHECK_HIP(hipStreamSynchronize(a));
+  VC_CHECK_HIP(hipEventDestroy(ev));
+  VC_CHECK_HIP(hipStreamDestroy(b));
   return VC_OK;
 }
 

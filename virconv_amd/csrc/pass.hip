@@ -192,6 +192,9 @@ int g_pass_defer_dw_reduce = 1;   // vc_debug_set "pass_defer_dw_reduce": 0 = ev
 // unit's BatchNorm-backward sums there (vc_conv_backward_input_epilogue): no gradient-add kernel, no reduction pass over
 // (y_raw, dy) for 15 of the 20 units of VirConvL8x.  0 = every unit reduces for itself (the node-by-node arithmetic).
 int g_pass_bwd_epilogue = 1;
+// vc_debug_set "pass_fork_ext_event" (default 1): the weight-gradient fork takes the completion event of the unit's last main-stream
+// launch (hipExtLaunchKernelGGL stop event, common.h) instead of a hipEventRecord marker packet in the main queue.
+int g_pass_fork_ext_event = 1;
 
 struct GradView {
   const float* p;
@@ -205,6 +208,7 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
   FwdLayout L;
   fwd_layout(p, L);
   Bump bump;
+  t_stop_event = StopEventSlot{};
   // shared scratch: BatchNorm partial sums (main stream), group-summed d_raw (main stream), weight-gradient partials (all weight
   // gradients run in order on ONE stream, the side stream when there is one)
   size_t bn_bytes = 256, grp_bytes = 256, gpart_bytes = 256, dw_bytes = 256;
@@ -385,6 +389,10 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
         VC_REQUIRE(t.grp_plan && (u.cout & (u.cout - 1)) == 0,
                    "vc_pass_backward: duplicate-pixel table needs its group plan (vc_pass_table.grp_plan, vc_group_sum_sorted)");
       }
+      // the fork of the weight gradient waits for this unit's last main-stream launch in front of it: the BatchNorm backward's dx
+      // kernel, or the group sum of a duplicate-pixel unit -- that launch carries the event
+      const bool ext_fork = need_dw && on_side && g_pass_fork_ext_event != 0;
+      t_stop_event = (ext_fork && !dup) ? StopEventSlot{ev[0], false} : StopEventSlot{};
       if (fused[i].sums != nullptr)
         rc = bn_bwd_dx_launch(y_raw, g.p, g.stride, g.col0 + o.dst_col0, t.n_out, u.cout, mean, var, u.gamma, u.beta, u.eps, o.relu,
                               fused[i].sums, d_raw, st);
@@ -399,9 +407,12 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
                                  nullptr, arena + bn_off, bn_bytes, st);
       if (rc != VC_OK) return rc;
       if (dup) {
+        if (ext_fork) t_stop_event = StopEventSlot{ev[0], false};
         rc = vc_group_sum_sorted(d_raw, t.grp_plan, t.n_out, u.cout, grp, arena + gpart_off, gpart_bytes, st);
         if (rc != VC_OK) return rc;
       }
+      const bool fork_bound = t_stop_event.bound;
+      t_stop_event = StopEventSlot{};
       auto weight_grad = [&](char* ws_, hipStream_t s_) -> int {
         return dup ? vc_conv_backward_weight_dup(x, d_raw, grp, t.rep, t.centre, t.pair_fwd, t.n_out, t.kv, u.cin, u.cout,
                                                  p->operand_type, u.dweight, ws_, dw_bytes, s_)
@@ -409,7 +420,7 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
                                              dw_bytes, s_);
       };
       if (need_dw && on_side) {  // fork: the weight gradient only reads x (forward arena), d_raw and grp (never rewritten in this call)
-        VC_CHECK_HIP(hipEventRecord(ev[0], st));
+        if (!fork_bound) VC_CHECK_HIP(hipEventRecord(ev[0], st));
         VC_CHECK_HIP(hipStreamWaitEvent(side, ev[0], 0));
         forked = true;
         bw_defer_enable(defer);
