@@ -7,7 +7,7 @@ Per layer, in 16-row MFMA tile-offset units per 64 output rows (one unit = CK/4 
   useful        pairs / 16                                    (no padding at all)
   v2            sum over the four 16-row tiles of |union of active offsets|   (what gather_gemm_v2 issues; natural row order)
   v2 sorted     the same after the 2048-row windowed mask sort (vc_row_order)
-  pc64 / pc256  per offset ceil(pairs of the 64- / 256-row group / 16): compaction over one wave's rows (accumulators can stay
+  pc32 / pc64 / pc256  per offset ceil(pairs of the 32- / 64- / 256-row group / 16): compaction over one wave's rows (accumulators can stay
                 wave-private: no barrier, deterministic) / over a 4-wave block (needs a per-offset barrier or LDS-resident
                 accumulators shared by the waves); pc256 is reported per 64 rows
 and the number of 64-row wave units the layer has at bs 4 (x4 the single frame) against the chip's 1024 SIMDs."""
@@ -44,10 +44,11 @@ def stats(name, pair):
         key |= act[k].astype(np.int64) << k
     o = np.concatenate([s + np.argsort(key[s:s + 2048], kind="stable") for s in range(0, n, 2048)])
     v2s = units(act[:, o], 16).any(2).sum() / (n // 16 * 16 / 64)
+    pc32 = np.ceil(units(act, 32).sum(2) / 16).sum() / (n // 32) * 2
     pc64 = np.ceil(units(act, 64).sum(2) / 16).sum() / (n // 64)
     pc256 = np.ceil(units(act, 256).sum(2) / 16).sum() / (n // 256) / 4
     print(f"{name:10s} N {n:6d} pairs/row {act.sum() / n:5.2f} | per 64 rows: useful {useful:5.1f}  v2 {v2:5.1f}  v2 sorted {v2s:5.1f}  "
-          f"pc64 {pc64:5.1f}  pc256 {pc256:5.1f} | 64-row waves at bs 4: {4 * n // 64:5d} ({4 * n / 64 / 1024:.1f} per SIMD)")
+          f"pc32 {pc32:5.1f}  pc64 {pc64:5.1f}  pc256 {pc256:5.1f} | 64-row waves at bs 4: {4 * n // 64:5d} ({4 * n / 64 / 1024:.1f} per SIMD)")
 
 
 cur, cs = idx, shape
