@@ -158,10 +158,9 @@ static inline uint64_t hash_capacity(int64_t n) {  // point hash of the voxelize
   return cap;
 }
 
-// BatchNorm sums out of conv-epilogue partial rows: the rows are reduced in groups of `bn_partial_rows_per_group` consecutive
-// rows (<= 256 groups; a multiple of 8 rows, so that a group is a whole number of 4- or 8-wave conv blocks), then over the
-// groups.  The same grouping is used by the two-launch route (bn_partial_reduce_kernel + finalize) and by the in-kernel finish
-// of the gather-GEMM (conv_finish_tail), which therefore agree bit for bit.
+// BatchNorm sums out of conv-epilogue partial rows on the two-launch route (bn_partial_reduce_kernel + finalize): the rows are
+// reduced in <= 256 groups of `bn_partial_rows_per_group` consecutive rows (a multiple of 8), then over the groups.  (The in-kernel
+// finish of the gather-GEMM, conv_finish_ticket / _reduce, has its own three levels: conv_kernels.hip.)
 static inline int64_t bn_partial_rows_per_group(int64_t nrows) { return (cdiv(nrows, 256) + 7) & ~(int64_t)7; }
 
 // In-kernel finish of the BatchNorm sums (conv_kernels.hip): a caller arms a request, the next epilogue launch of this host

@@ -1053,7 +1053,7 @@ gather_gemm_v2_kernel(const float* __restrict__ src,
 //   * the block walks the active offsets in ascending order, in lock step (one barrier per offset: the W_k image is staged once per
 //     block into LDS, double buffered, exactly as in v2); wave w takes pair tile w of the offset's queue -- at most 8 tiles = 128 pairs --
 //     gathers its 16 input rows (buffer loads, -1 -> zeros), runs the MFMAs into a ZEROED accumulator and adds the 16 x CN result
-//     into the block's output accumulator rows in LDS (ds_add_f32; inside one offset every output row appears at most once, and the
+//     into the block's output accumulator rows in LDS (a plain read-add-write: inside one offset every output row appears at most once, and the
 //     per-offset barrier orders the offsets: every output element is the fixed-order sum  ((0 + P_k1) + P_k2) + ...  over its
 //     active offsets in ascending order -- deterministic, independent of which wave computed which tile);
 //   * the gathers and the W slice of offset n + 1 are in flight under the MFMAs of offset n (v2's ping-pong pipeline);
