@@ -1,0 +1,63 @@
+"""The driver's bench contract, checked without a GPU: the committed round line (profiles/r03_bench.json) carries every field the
+contract names, the roofline arithmetic of bench.py is what DESIGN.md 4 says it is, and `value` is frames per second of the whole job."""
+import argparse
+import json
+import os
+
+import pytest
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line():
+    with open(os.path.join(ROOT, "profiles", "r03_bench.json")) as f:
+        return json.loads(f.read())
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    j = _line()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["unit"] == "frames/s" and j["higher_is_better"] is True and j["scaling"] == "weak" and j["vs_baseline"] is None
+    assert j["data"] == "synthetic" and j["dtype"] == "f32" and j["n_gpus"] == 1
+    assert "workload" in j["config"] and "BASELINE configs[2]" in j["config"]["workload"] and "model" not in j["config"]
+    # value = frames of the whole job / wall time: global batch / ms_per_step
+    assert j["value"] == pytest.approx(j["config"]["global_batch"] / (j["ms_per_step"] * 1e-3), rel=2e-3)
+    r = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "family_frac", "step_frac"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == bench.MFMA_F32_PEAK_TFLOPS
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], abs=2e-4)
+    assert 0 < r["step_frac"] < r["family_frac"] < r["frac"] < 1
+    assert r["traffic"] is None or r["traffic"] > r["algorithmic_mb_per_launch"] * 1e6 * 0.9   # PMC bytes >= algorithmic bytes
+    c = j["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["unit"] == "frames/s" and c["cores"] >= 1
+
+
+def test_traced_roofline_arithmetic():
+    """achieved = algorithmic flops of the traced launches / their HIP-event durations; frac = achieved / dense fp32-MFMA peak."""
+    args = argparse.Namespace(operand="f32")
+    trace = [{"ms": 0.125, "flops": 8.0e9, "bytes": 6.0e7, "windowed": False}, {"ms": 0.135, "flops": 8.2e9, "bytes": 6.1e7, "windowed": False}]
+    r = bench._traced_roofline(trace, args, "fwd", "64", "32", pmc=False)
+    tf = (8.0e9 + 8.2e9) / (0.260e-3) / 1e12
+    assert r["achieved"] == pytest.approx(tf, rel=1e-3) and r["frac"] == pytest.approx(tf / bench.MFMA_F32_PEAK_TFLOPS, abs=1e-4)
+    assert r["launches"] == 2 and r["avg_us"] == pytest.approx(130.0, rel=1e-3) and r["traffic"] is None
+    assert bench._traced_roofline([], args, "fwd", "64", "32", pmc=False) is None
+
+
+def test_every_line_of_the_round_file_parses_and_names_its_workload():
+    n = 0
+    with open(os.path.join(ROOT, "profiles", "r03_bench_lines.txt")) as f:
+        for line in f:
+            if not line.startswith("{"):
+                continue
+            j = json.loads(line)
+            n += 1
+            assert j["unit"] == "frames/s" and "workload" in j["config"] and "roofline" in j and "cpu_baseline" in j
+            assert j["value"] > 0 and j["ms_per_step"] > 0
+    assert n >= 10
