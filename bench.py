@@ -236,7 +236,7 @@ def run_infer(args, model, batch, device, rank, world):
     lat_ms = sorted(lat)[len(lat) // 2]
     if rank == 0:
         bs = args.batch_size
-        _emit({"metric": "KITTI frames/sec (forward only) VirConv-L backbone", "value": round(bs * world * args.steps / dt, 3),
+        return {"metric": "KITTI frames/sec (forward only) VirConv-L backbone", "value": round(bs * world * args.steps / dt, 3),
                           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -244,7 +244,8 @@ def run_infer(args, model, batch, device, rank, world):
                                                  "flight (plan of the next frame over the feature pass of this one)",
                                      "frames_per_gpu": bs, "voxels_rank0": int(batch["voxel_features"].shape[0]),
                                      "single_step_latency_ms": round(lat_ms, 3)},
-                          "roofline": _traced_roofline(trace, args, tdir, tck, tcn, pmc=False), "cpu_baseline": None})
+                          "roofline": _traced_roofline(trace, args, tdir, tck, tcn, pmc=False), "cpu_baseline": None}
+    return None
 
 
 def _emit(res):
@@ -255,7 +256,7 @@ def _emit(res):
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
-    _emit(res)
+    print(json.dumps(res), flush=True)
 
 
 def _pmc_traffic(tdir, tck, tcn):
@@ -448,7 +449,7 @@ def main():
     parallel.barrier()
 
     if rank != 0:
-        return
+        return None
     frames = bs * world * args.steps
     roof = _traced_roofline(trace, args, tdir, tck, tcn, pmc=True)
     if roof is not None:
@@ -527,8 +528,11 @@ def main():
         res["cpu_baseline"] = cpu_baseline()
     else:
         res["cpu_baseline"] = None
-    print(json.dumps(res), flush=True)
+    return res
 
 
 if __name__ == "__main__":
-    main()
+    _res = main()            # rank 0: the result line; other ranks: None
+    parallel.shutdown()      # tear the process group down BEFORE interpreter exit (its watchdog thread otherwise races HIP's teardown)
+    if _res is not None:
+        _emit(_res)

@@ -167,6 +167,16 @@ def max_over_ranks(value: float, device) -> float:
     return float(t.item())
 
 
+def shutdown() -> None:
+    """Destroy the process group (all ranks call it once their work is done).  Leaving it to interpreter exit lets the NCCL/RCCL
+    watchdog thread poll HIP events while the HIP runtime is being torn down: 'watchdog thread terminated with exception: HIP error'
+    and a core dump AFTER the result was printed -- a non-zero exit status for a finished run."""
+    if dist.is_available() and dist.is_initialized():
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        dist.destroy_process_group()
+
+
 def barrier() -> None:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
