@@ -69,7 +69,9 @@ def _worker(rank, world, port, out_dir, mode="ddp"):
     t = parallel.max_over_ranks(float(rank + 1), "cpu")
     assert t == float(world)
     parallel.barrier()
-    dist.destroy_process_group()
+    parallel.shutdown()        # what bench.py calls before it prints its line: the group is gone, a second call is a no-op
+    assert not dist.is_initialized()
+    parallel.shutdown()
 
 
 def _single(frame):
