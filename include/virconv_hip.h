@@ -122,7 +122,7 @@ int vc_spconv_pairs(const int32_t* indices, int64_t n, int ndim, int batch_size,
  *                with k' = mirror ? KV-1-k : k                                                   -> out (n_in, cin)
  *   SubM backward passes tbl = pair_fwd and mirror = 1 (pair_bwd[k] == pair_fwd[KV-1-k]).
  *   Duplicate-coordinate SubM backward (2-D image-space branch): src_centre = dy is used for the
- *   centre tap, src = group-summed dy (vc_group_sum) for the others, and rows with rep[o] != o take the centre
+ *   centre tap, src = group-summed dy (vc_group_sum_sorted) for the others, and rows with rep[o] != o take the centre
  *   tap only.  Pass centre = -1, rep = NULL, src_centre = NULL when not needed.
  *   operand_type: VC_OPERAND_F32 (exact fp32 MFMA; the parity path) | VC_OPERAND_F16 | VC_OPERAND_BF16 -- tensors stay fp32
  *   in memory, the MFMA operands are rounded (RNE) to 16 bit in registers and accumulate in fp32 (BASELINE configs[4],
@@ -223,23 +223,13 @@ int vc_conv_backward_weight_dup(const float* x, const float* dy, const float* dy
 
 /* dy_grp[rep[i], :] = sum over the rows i sharing representative rep[i] of dy[i, :]  (rows that are nobody's
  * representative are NOT written: vc_conv_backward_input reads dy_grp at representatives only, and 47-81 % of the rows of
- * the image-space tensors are not representatives).  Only used by the duplicate-coordinate SubM backward.  Bit-stable: the sum is carried in
- * 64-bit fixed point scaled by the tensor's max |dy| (integer adds are associative), then rounded once to fp32.       */
-size_t vc_group_sum_workspace_bytes(int64_t n, int c);
-int vc_group_sum(const float* dy, const int32_t* rep, int64_t n, int c, float* dy_grp, void* ws, size_t ws_bytes,
-                 int prepared, void* stream);
-/* Optional two-step form that saves the max|dy| pass: vc_group_sum_prepare zeroes `ws`; the kernel that PRODUCES dy then
- * leaves max|dy| in the first word of ws (vc_bn_relu_backward's absmax_out = ws); vc_group_sum(..., prepared = 1).
- * prepared = 2: `ws` is a PERSISTENT buffer (>= vc_group_sum_workspace_bytes of the largest layer) that the caller zeroed
- * ONCE; the first word holds max|dy| as above, and the call hands the accumulators back all-zero (the convert kernel clears
- * what it reads) -- no 8*n*c-byte memset per layer.                                                                     */
-int vc_group_sum_prepare(void* ws, size_t ws_bytes, int64_t n, int c, void* stream);
-/* The same sum with the order of the additions fixed by the DATA instead of by integer arithmetic (round 3; what the unit /
- * feature-pass calls use): the caller sorts the rows once per table by representative -- keys from vc_group_keys
+ * the image-space tensors are not representatives).  Only used by the duplicate-coordinate SubM backward.
+ * The order of the additions is fixed by the DATA: the caller sorts the rows once per table by representative -- keys from vc_group_keys
  * (keys[i] = rep[i] < 0 ? i : rep[i]), any STABLE ascending sort of (keys, row ids) -- and passes
  * grp_plan = [order (n) | sorted keys (n)] int32.  Runs of equal keys are summed in ascending sorted position (plain fp32 adds),
  * runs cut by a 32-row chunk border through one partial per chunk, combined in chunk order: no atomics, no max|dy| pass, no
- * 8-byte accumulators, bit-stable.  c must be a power of two.  Same output contract as vc_group_sum (representatives only). */
+ * 8-byte accumulators, bit-stable.  c must be a power of two.  (Rounds 1-2 carried the sum in 64-bit fixed point with atomics:
+ * csrc/experiments/group_sum_fixed.inc, -DVC_EXPERIMENTS builds only.)                                                       */
 int vc_group_keys(const int32_t* rep, int64_t n, int32_t* keys, void* stream);
 /* ... or let the library build the plan: keys + one stable radix sort of the (key, row) pairs.  grp_plan: 2 * n int32.           */
 size_t vc_group_plan_workspace_bytes(int64_t n);

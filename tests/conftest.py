@@ -31,3 +31,12 @@ def hip_backend():
     from virconv_amd.backend_hip import HipBackend
     with ops.use_backend(HipBackend()) as be:
         yield be
+
+
+def require_experiments(backend):
+    """Skip unless libvirconv_hip.so was built with -DVC_EXPERIMENTS (the measured-and-rejected kernel variants of
+    virconv_amd/csrc/experiments/: VIRCONV_HIPCC_EXTRA=-DVC_EXPERIMENTS python -m virconv_amd.build --force)."""
+    import ctypes
+    v = ctypes.c_int64(0)
+    if backend.lib.vc_debug_get(b"experiments", ctypes.byref(v)) != 0 or v.value == 0:
+        pytest.skip("experiment kernels are not in the product build (-DVC_EXPERIMENTS)")

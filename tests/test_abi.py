@@ -88,9 +88,9 @@ def test_new_entry_points_validate_their_arguments_without_gpu():
     # layer discard
     assert lib.vc_random_keep(10, 11, 1, dummy, None) == _lib.VC_EINVAL
     assert lib.vc_random_keep(10, 0, 1, None, None) == _lib.VC_OK
-    # group sum
-    assert lib.vc_group_sum_workspace_bytes(100, 16) == 100 * 16 * 8 + 64
-    assert lib.vc_group_sum_prepare(dummy, 8, 100, 16, None) == _lib.VC_ECAPACITY
+    # group sum (segmented, fixed order): channel count must be a power of two
+    assert lib.vc_group_sum_sorted_workspace_bytes(100, 16) > 0
+    assert lib.vc_group_sum_sorted(dummy, dummy, 100, 24, dummy, dummy, 1 << 20, None) == _lib.VC_EINVAL
 
 
 def test_product_has_no_cpu_path():

@@ -18,6 +18,8 @@ SHAPE3 = (21, 64, 48)
 @pytest.fixture(autouse=True)
 def _pc_on(hip_backend):
     """The kernel is OFF by default (measured: it ties v2 at best, profiles/r03_pair_compacted_kernel.md); these tests turn it on."""
+    from conftest import require_experiments
+    require_experiments(hip_backend)
     assert hip_backend.lib.vc_debug_set(b"conv_pc", 1) == 0
     yield
     assert hip_backend.lib.vc_debug_set(b"conv_pc", 0) == 0

@@ -182,6 +182,8 @@ def test_duplicate_pixel_weight_gradient_over_representatives_equals_the_plain_o
 
 @pytest.mark.parametrize("cin,cout", [(16, 16), (64, 32), (32, 64), (64, 64)])
 def test_interleaved_source_layout_gives_the_same_conv_bits(hip_backend, cin, cout):
+    from conftest import require_experiments
+    require_experiments(hip_backend)
     """VC_CONV_SRC_INTERLEAVED (round-3 experiment): the source features in 16-row groups, chunk-major inside a group.  Same
     arithmetic per output row: bit-identical to the row-major gather, on a sorted scene, a permuted one and a row count that is
     not a multiple of 16."""
@@ -212,6 +214,8 @@ def test_weight_gradient_v2_dy_window_in_lds(hip_backend, cin, cout, kind):
     """bwd_weight_v2_kernel (vc_debug_set bw_variant 2): the row range's dy rows staged through LDS once for a group of offsets,
     every wave owning whole offsets.  Same dW as v1 and as the float64 oracle up to fp32 re-association; bit-stable; SubM tables,
     strided tables (n_in != n_out) and a 3-offset kernel; row counts that are not multiples of the window."""
+    from conftest import require_experiments
+    require_experiments(hip_backend)
     from virconv_amd import synth
     rng = np.random.default_rng(cin * 3 + cout)
     lib = hip_backend.lib
@@ -248,7 +252,10 @@ def test_weight_gradient_v2_dy_window_in_lds(hip_backend, cin, cout, kind):
 
 
 @pytest.mark.parametrize("shape,gshape", [((4, 64, 2, 200, 176), (1, 64, 2, 200, 176)), ((3, 8, 5, 12), (8, 5, 12)),
-                                          ((310351, 32), (32,)), ((75991, 64), (64,)), ((1, 16), (16,)), ((1000, 256), (256,))])
+                                          ((310351, 32), (32,)), ((75991, 64), (64,)), ((1, 16), (16,)), ((1000, 256), (256,)),
+                                          # a non-power-of-two row length with more than 2048 samples launches one block per
+                                          # sample -- the workspace must hold that many partials
+                                          ((5000, 48), (48,)), ((20000, 48), (48,))])
 def test_weighted_sum_is_one_deterministic_pass_and_matches_float64(hip_backend, shape, gshape):
     """vc_weighted_sum / ops.weighted_sum: sum(x * g) with g broadcast over the leading axis -- value against float64, bit-stable
     run to run, gradient = gout * g (a stride-0 view over the batch axis for dense maps, materialised rows for (N, C))."""

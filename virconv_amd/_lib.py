@@ -65,9 +65,6 @@ SIGNATURES = {
     "vc_conv_backward_weight_workspace_bytes": (_SZ, [_I64, _I, _I, _I]),
     "vc_conv_backward_weight": (_I, [_P, _P, _P, _I64, _I, _I, _I, _I, _P, _P, _SZ, _P]),
     "vc_conv_backward_weight_dup": (_I, [_P, _P, _P, _P, _I, _P, _I64, _I, _I, _I, _I, _P, _P, _SZ, _P]),
-    "vc_group_sum_workspace_bytes": (_SZ, [_I64, _I]),
-    "vc_group_sum": (_I, [_P, _P, _I64, _I, _P, _P, _SZ, _I, _P]),
-    "vc_group_sum_prepare": (_I, [_P, _SZ, _I64, _I, _P]),
     "vc_group_keys": (_I, [_P, _I64, _P, _P]),
     "vc_group_plan_workspace_bytes": (_SZ, [_I64]),
     "vc_group_plan": (_I, [_P, _I64, _P, _P, _SZ, _P]),

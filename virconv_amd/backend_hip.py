@@ -344,8 +344,7 @@ class HipBackend:
                             group_ws: Optional[torch.Tensor] = None, sorted_rows: bool = False,
                             grp_plan: Optional[torch.Tensor] = None, grp: Optional[torch.Tensor] = None) -> torch.Tensor:
         """`grp_plan`: the duplicate-pixel table's rows sorted by representative (group_plan): the group sum runs in that
-        fixed order (vc_group_sum_sorted).  Without it the order-free fixed-point sum is used; `group_ws`: its workspace from
-        group_sum_prepare whose header already holds max|dy| (left there by bn_backward)."""
+        fixed order (vc_group_sum_sorted); built on the fly when absent.  `group_ws` is ignored (kept for call compatibility)."""
         dy = _need(dy, torch.float32, "grad_out")
         weight = _need(weight, torch.float32, "weight")
         tbl = _need(tbl, torch.int32, "pair table")
@@ -358,16 +357,13 @@ class HipBackend:
             rep = _need(rep, torch.int32, "rep")
         if rep is not None and grp is not None:          # group sum computed by the caller (it also feeds the weight gradient)
             src, src_centre = grp, dy
-        elif rep is not None and grp_plan is not None and (cout & (cout - 1)) == 0:
-            src, src_centre = self.group_sum_sorted(dy, grp_plan), dy
         elif rep is not None:
-            grp = torch.empty_like(dy)
-            gws_bytes = self.lib.vc_group_sum_workspace_bytes(dy.shape[0], cout)
-            gws = group_ws if group_ws is not None else torch.empty((gws_bytes,), dtype=torch.uint8, device=dy.device)
-            assert gws.numel() >= gws_bytes
-            check(self.lib.vc_group_sum(_ptr(dy), _ptr(rep), dy.shape[0], cout, _ptr(grp), _ptr(gws), gws_bytes,
-                                        1 if group_ws is not None else 0, _stream()), "vc_group_sum")
-            src, src_centre = grp, dy
+            # no plan yet (a rulebook built under no_grad, a direct operator call): build it here -- the group sum always runs in
+            # the fixed order of a plan (the order-free fixed-point sum of rounds 1-2 is an experiment build only)
+            if (cout & (cout - 1)) != 0:
+                raise _lib.VirConvError("duplicate-pixel backward: the output channel count must be a power of two")
+            plan = grp_plan if grp_plan is not None else self.group_plan(rep)
+            src, src_centre = self.group_sum_sorted(dy, plan), dy
         check(self.lib.vc_conv_backward_input(_ptr(src), _ptr(src_centre), dy.shape[0], _ptr(tbl), n_in, kv, _ptr(weight),
                                               cin, cout, 1 if mirror else 0, centre if rep is not None else -1,
                                               _ptr(rep), _ptr(order), OPERAND_TYPES[operand],
@@ -524,8 +520,10 @@ class HipBackend:
         ndim = indices.shape[1] - 1
         shp = i32arr(spatial_shape)
         ws_bytes = self.lib.vc_to_dense_fill_workspace_bytes(batch_size, ndim, shp)
+        if (pad[0] or pad[1]) and not (c <= 128 and ws_bytes <= (1 << 30)):
+            # wide or huge maps: the write-once kernel does not serve them -- unpadded map, then a zero border
+            return torch.nn.functional.pad(self.to_dense(features, indices, spatial_shape, batch_size), (pad[1], pad[1], pad[0], pad[0]))
         if pad[0] or pad[1]:
-            assert c <= 128, "padded dense: channel count too large for the write-once kernel"
             out_shape = tuple(int(v) for v in spatial_shape[:-2]) + (int(spatial_shape[-2]) + 2 * pad[0], int(spatial_shape[-1]) + 2 * pad[1])
             dense = torch.empty((batch_size, c) + out_shape, dtype=torch.float32, device=features.device)
             ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=features.device)
@@ -705,15 +703,6 @@ class HipBackend:
         return out, mean, var
 
     # ------------------------------------------------------------------ post_act_block (conv + BN + ReLU) as one call each way
-    def _group_acc(self, nbytes: int, device) -> torch.Tensor:
-        """Persistent all-zero int64 accumulator of the duplicate-pixel group sum (vc_group_sum prepared = 2): zeroed when it
-        is (re)allocated, handed back all-zero by every call."""
-        buf = getattr(self, "_gacc", None)
-        if buf is None or buf.numel() < nbytes or buf.device != torch.device(device):
-            buf = torch.zeros((int(nbytes * 1.25) + 4096,), dtype=torch.uint8, device=device)
-            self._gacc = buf
-        return buf
-
     def _side_stream(self, device) -> int:
         st = getattr(self, "_side", None)
         if st is None or st.device != torch.device(device):
@@ -819,13 +808,6 @@ class HipBackend:
                                                   self._side_stream(dev) if UNIT_OVERLAP_DW else None, _stream()),
               "vc_post_act_block_backward")
         return dx, dw, dgb[0], dgb[1]
-
-    def group_sum_prepare(self, n: int, c: int, device) -> torch.Tensor:
-        """Zeroed group-sum workspace; hand it to bn_backward(absmax_ws=...) and then to conv_backward_input(group_ws=...)."""
-        nbytes = self.lib.vc_group_sum_workspace_bytes(n, c)
-        ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
-        check(self.lib.vc_group_sum_prepare(_ptr(ws), nbytes, n, c, _stream()), "vc_group_sum_prepare")
-        return ws
 
     def bn_backward(self, x, dy, dy_col0, mean, var, gamma, beta, eps: float, relu: bool,
                     absmax_ws: Optional[torch.Tensor] = None):

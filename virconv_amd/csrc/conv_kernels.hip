@@ -26,7 +26,9 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ int g_xcd_swizzle_off = 0;  // developer switch (tools/kbench.py --no-xcd)
+#ifdef VC_EXPERIMENTS
 __device__ int g_pc_ablate = 0;        // developer ablations of the pair-compacted kernel (vc_debug_set conv_pc_ablate; wrong results): 1 no LDS adds | 2 no gathers | 4 no MFMAs | 8 no per-offset barrier
+#endif
 // v2 MFMA phase order.  0 (default) = the round-1 order: hipcc reads each B fragment right before its four MFMAs, 68 VGPRs,
 // 6 waves per SIMD.  1 = every B fragment of an offset read before its first MFMA + accumulator-alternating MFMAs: better
 // per-wave code but 97 VGPRs / 4 waves per SIMD, and MEASURED SLOWER (s3.d3_conv1 64->32 forward 242 vs 208 us,
@@ -1042,1180 +1044,14 @@ gather_gemm_v2_kernel(const float* __restrict__ src,
   }
 }
 
-// --------------------------------------------------------------------------------------------- K6 pc (pair-compacted forward)
-// Round 3.  The strided convs have 1.7 - 8.7 active kernel offsets per OUTPUT row out of 27 (kbench P/N), i.e. per offset 6 - 30 %
-// of the rows of a tile gather anything; v2 issues a full 16-row MFMA tile for every (tile, offset) with at least one active row --
-// 45 - 71 tile-units per 64 rows against 6.6 - 33 useful ones (profiles/r03_pair_compaction_analysis.txt), 5 - 21 % of the MFMA peak.
-// This kernel takes the padding out instead of sorting rows around it:
-//   * a block owns 128 consecutive output rows; their (KV x 128) table slice is staged into LDS and COMPACTED per offset, in place:
-//     queue k = the (input row, local output row) pairs of offset k in ascending output-row order (ballot + popcount, one wave per
-//     offset), padded to whole 16-pair tiles with (-1, -);
-//   * the block walks the active offsets in ascending order, in lock step (one barrier per offset: the W_k image is staged once per
-//     block into LDS, double buffered, exactly as in v2); wave w takes pair tile w of the offset's queue -- at most 8 tiles = 128 pairs --
-//     gathers its 16 input rows (buffer loads, -1 -> zeros), runs the MFMAs into a ZEROED accumulator and adds the 16 x CN result
-//     into the block's output accumulator rows in LDS (a plain read-add-write: inside one offset every output row appears at most once, and the
-//     per-offset barrier orders the offsets: every output element is the fixed-order sum  ((0 + P_k1) + P_k2) + ...  over its
-//     active offsets in ascending order -- deterministic, independent of which wave computed which tile);
-//   * the gathers and the W slice of offset n + 1 are in flight under the MFMAs of offset n (v2's ping-pong pipeline);
-//   * after the last offset the 128 x CN tile goes from LDS to memory in whole rows (coalesced 16-byte stores), with the STATS
-//     (one partial row per 16 output rows, the v2 8-wave contract) or AFFINE epilogue applied on the way.
-// Arithmetic differs from v2 only in WHERE the per-offset products are added (v2 chains them through the MFMA accumulator, here
-// each P_k is rounded to fp32 before the add): same bound against the fp64 oracle, not bit-identical to v2.
-template <int CK, int CN, int EPI, bool PK>
-__global__ void __launch_bounds__(512) gather_gemm_pc_kernel(const float* __restrict__ src, int64_t n_src,
-                                                             const int32_t* __restrict__ tbl, const float* __restrict__ w,
-                                                             float* __restrict__ out, int64_t n_out, int kv, ConvEpilogue epi) {
-  static_assert(CK % 16 == 0 && CN % 16 == 0, "pair-compacted kernel: channel counts in multiples of 16");
-  static_assert(EPI == VC_EPI_NONE || EPI == VC_EPI_STATS || EPI == VC_EPI_AFFINE, "forward epilogues only");
-  constexpr int V = 4, NW = 8, NTHR = 512, TMB = 128;
-  constexpr int NCH = CK / 16, NT = CN / 16;
-  constexpr int NFRAG = NCH * NT * 64, BF = NFRAG * V, BBYTES = BF * 4;
-  constexpr int BLD = (NFRAG + NTHR - 1) / NTHR;
-  constexpr int ACS = CN + 4;                                  // accumulator row stride (floats): rows start in different banks
-  // Pipeline depth: the gathers and the W slice of offset n + D - 1 are issued while offset n computes.  A block has its offsets
-  // in lock step, so -- unlike v2, which hides a 2-3 us gather round trip behind six resident blocks per CU -- the latency has to
-  // be covered by loads in flight: depth 2 (v2's ping-pong) measured 546 us on the 32 -> 64 stage-3 conv against v2's 170.
-  constexpr int D = (CK >= 64) ? 3 : 4;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* s_b = smem;                                                      // [2][BBYTES]
-  float* s_acc = reinterpret_cast<float*>(smem + 2 * BBYTES);                     // [TMB][ACS]
-  int* s_qin = reinterpret_cast<int*>(s_acc + TMB * ACS);                         // [kv][TMB] table slice, then the queues' input rows
-  int* s_cnt = s_qin + kv * TMB;                                                  // [32] pairs per offset
-  int* s_klist = s_cnt + 32;                                                      // [32] active offsets ascending, [32] = how many
-  unsigned char* s_qout = reinterpret_cast<unsigned char*>(s_klist + 36);         // [kv][TMB] the queues' local output rows
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i = lane & 15, q = lane >> 4;
-  int64_t lbid;
-  {
-    const unsigned nb = gridDim.x, bid = blockIdx.x, xcd = bid & 7u, qd = nb >> 3, rm = nb & 7u;
-    lbid = (int64_t)(xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-    if (g_xcd_swizzle_off) lbid = bid;
-  }
-  const int64_t brow0 = lbid * TMB;
-  const __amdgpu_buffer_rsrc_t rs_src =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)(n_src * CK * 4), 0x00020000);
-
-  {  // ---- phase 0: table slice -> LDS (coalesced over rows; all of a thread's loads in flight together), accumulators = 0
-    const int r = tid % TMB, k0 = tid / TMB;
-    const bool inb = brow0 + r < n_out;
-    int v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int k = k0 + u * (NTHR / TMB);
-      v[u] = (inb && k < kv) ? tbl[(int64_t)k * n_out + brow0 + r] : -1;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int k = k0 + u * (NTHR / TMB);
-      if (k < kv) s_qin[k * TMB + r] = v[u];
-    }
-    for (int e = tid; e < TMB * ACS / 4; e += NTHR) reinterpret_cast<float4*>(s_acc)[e] = float4{0.f, 0.f, 0.f, 0.f};
-  }
-  __syncthreads();
-  // ---- phase 1: compaction, one wave per offset (the wave reads its offset's 128 entries before it writes any of them)
-  for (int k = wave; k < kv; k += NW) {
-    int* qi = s_qin + k * TMB;
-    unsigned char* qo = s_qout + k * TMB;
-    const int v0 = qi[lane], v1 = qi[64 + lane];
-    const unsigned long long b0 = __ballot(v0 >= 0), b1 = __ballot(v1 >= 0);
-    const unsigned long long lt = (1ULL << lane) - 1ULL;
-    const int c0 = __popcll(b0), cnt = c0 + __popcll(b1);
-    if (v0 >= 0) { const int p_ = __popcll(b0 & lt); qi[p_] = v0; qo[p_] = (unsigned char)lane; }
-    if (v1 >= 0) { const int p_ = c0 + __popcll(b1 & lt); qi[p_] = v1; qo[p_] = (unsigned char)(64 + lane); }
-    const int padded = (cnt + 15) & ~15;
-    if (cnt + lane < padded) { qi[cnt + lane] = -1; qo[cnt + lane] = 0; }   // < 16 padding entries
-    if (lane == 0) s_cnt[k] = cnt;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int n = 0;
-    for (int k = 0; k < kv; ++k)
-      if (s_cnt[k] > 0) s_klist[n++] = k;
-    s_klist[32] = n;
-  }
-  __syncthreads();
-  const int n_items = __builtin_amdgcn_readfirstlane(s_klist[32]);
-  const int abl = g_pc_ablate;
-
-  float breg[D][BLD][V];
-  float a[D][NCH][V];
-  int act[D];
-
-#define PC_K_OF(IT) __builtin_amdgcn_readfirstlane(s_klist[(IT) < n_items ? (IT) : n_items - 1])
-#define PC_LOAD_B(K, S)                                                                            \
-  do {                                                                                             \
-    _Pragma("unroll") for (int u = 0; u < BLD; ++u) {                                              \
-      const int f = tid + u * NTHR;                                                                \
-      if (NFRAG % NTHR == 0 || f < NFRAG) {                                                         \
-        if constexpr (PK) {                                                                        \
-          VecLoad<V>::ld(w + ((int64_t)(K) * NFRAG + f) * V, breg[S][u]);                          \
-        } else {                                                                                   \
-          const int fl = f & 63, nt_ = (f >> 6) % NT, ch_ = (f >> 6) / NT;                         \
-          const int n_ = nt_ * 16 + (fl & 15), kk0 = ch_ * 16 + (fl >> 4) * V;                     \
-          VecLoad<V>::ld(w + ((int64_t)n_ * kv + (K)) * CK + kk0, breg[S][u]);                     \
-        }                                                                                          \
-      }                                                                                            \
-    }                                                                                              \
-  } while (0)
-#define PC_STORE_B(BUF, S)                                                                         \
-  do {                                                                                             \
-    _Pragma("unroll") for (int u = 0; u < BLD; ++u) {                                              \
-      const int f = tid + u * NTHR;                                                                \
-      if (NFRAG % NTHR == 0 || f < NFRAG) {                                                         \
-        float* d_ = reinterpret_cast<float*>(s_b + (BUF) * BBYTES) + f * V;                        \
-        _Pragma("unroll") for (int j = 0; j < V; ++j) d_[j] = breg[S][u][j];                       \
-      }                                                                                            \
-    }                                                                                              \
-  } while (0)
-  // pair tile `wave` of offset K: 16 input rows (-1 beyond the queue or past the last offset: no memory access, zeros)
-#define PC_GATHER_A(K, S, LIVE)                                                                    \
-  do {                                                                                             \
-    act[S] = ((LIVE) && wave * 16 < s_cnt[(K)]) ? 1 : 0;                                           \
-    const int id = (act[S] && !(abl & 2)) ? s_qin[(K) * TMB + wave * 16 + i] : -1;                 \
-    const unsigned base_ = (unsigned)id * (unsigned)(CK * 4) + (unsigned)(q * V * 4);              \
-    _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch) BufLoad<V>::ld(rs_src, base_ + (unsigned)(ch * 64), a[S][ch]); \
-  } while (0)
-  // MFMAs of the tile into a zeroed accumulator, then the 16 x CN result into the output rows of the tile's pairs
-#define PC_MFMA_ADD(K, S, BUF)                                                                     \
-  do {                                                                                             \
-    if (act[S]) {                                                                                  \
-      const float* __restrict__ B_ = reinterpret_cast<const float*>(s_b + (BUF) * BBYTES);         \
-      f32x4 acc[NT];                                                                               \
-      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};       \
-      _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch) {                                         \
-        float b[NT][V];                                                                            \
-        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) VecLoad<V>::ld(B_ + ((ch * NT + nt) * 64 + lane) * V, b[nt]); \
-        if (!(abl & 4)) {                                                                          \
-        _Pragma("unroll") for (int j = 0; j < V; ++j)                                              \
-            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                      \
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[S][ch][j], b[nt][j], acc[nt], 0, 0, 0); \
-        } else { _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[nt][0] += a[S][ch][0] * b[nt][0]; } \
-      }                                                                                            \
-      const int cnt_ = (abl & 1) ? 0 : s_cnt[(K)];                                                 \
-      _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                                        \
-        const int e_ = wave * 16 + q * 4 + reg;                                                    \
-        if (e_ < cnt_) {                                                                           \
-          /* plain read-add-write: inside one offset every output row belongs to exactly one pair, i.e. one lane group of one   \
-             wave (ds_add_f32 measured 166 cycles per wave instruction: 586 us instead of 144 for the stage-3 conv) */           \
-          float* dst_ = s_acc + (int)s_qout[(K) * TMB + e_] * ACS + i;                             \
-          float cur_[NT];                                                                          \
-          _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) cur_[nt] = dst_[nt * 16];              \
-          _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) dst_[nt * 16] = cur_[nt] + acc[nt][reg]; \
-        }                                                                                          \
-      }                                                                                            \
-    }                                                                                              \
-  } while (0)
-
-  if (n_items > 0) {
-#pragma unroll
-    for (int s_ = 0; s_ < D - 1; ++s_) {   // prologue: offsets 0 .. D - 2 in flight
-      const int k_ = PC_K_OF(s_);
-      PC_LOAD_B(k_, s_);
-      PC_GATHER_A(k_, s_, s_ < n_items);
-    }
-    for (int base = 0; base < n_items; base += D) {
-#pragma unroll
-      for (int s_ = 0; s_ < D; ++s_) {
-        const int it = base + s_;
-        if (it >= n_items) break;              // block-uniform
-        const int kcur = PC_K_OF(it);
-        const int buf = it & 1;
-        PC_STORE_B(buf, s_);
-        if (!(abl & 8)) __syncthreads();   // W_kcur staged; every LDS add of the previous offset has completed (its waves waited lgkmcnt(0) to get here)
-        const int kn = PC_K_OF(it + D - 1);
-        PC_LOAD_B(kn, (s_ + D - 1) % D);
-        PC_GATHER_A(kn, (s_ + D - 1) % D, it + D - 1 < n_items);
-        PC_MFMA_ADD(kcur, s_, buf);
-      }
-    }
-  }
-#undef PC_MFMA_ADD
-#undef PC_GATHER_A
-#undef PC_STORE_B
-#undef PC_LOAD_B
-#undef PC_K_OF
-  __syncthreads();
-
-  // ---- epilogue: LDS accumulators -> memory, whole rows
-  if constexpr (EPI == VC_EPI_STATS) {
-    // one partial row per 16 output rows: wave w sums rows 16 w .. 16 w + 15 of its column(s) in ascending row order
-    float* prow = epi.partial + ((lbid * NW + wave) * 2) * CN;
-    for (int c = lane; c < CN; c += 64) {
-      float sm = 0.f, sq = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = s_acc[(wave * 16 + r) * ACS + c];
-        sm += v;
-        sq += v * v;
-      }
-      prow[c] = sm;
-      prow[CN + c] = sq;
-    }
-  }
-  constexpr int C4 = CN / 4;
-  for (int e = tid; e < TMB * C4; e += NTHR) {
-    const int r = e / C4, c4 = e - r * C4;
-    if (brow0 + r >= n_out) continue;
-    float4 v = *reinterpret_cast<const float4*>(s_acc + r * ACS + c4 * 4);
-    if constexpr (EPI == VC_EPI_AFFINE) {
-      float o[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = c4 * 4 + j;
-        const float istd = 1.0f / sqrtf(epi.var[n] + epi.eps);
-        const float sc = (epi.gamma ? epi.gamma[n] : 1.f) * istd;
-        const float sh = (epi.beta ? epi.beta[n] : 0.f) - epi.mean[n] * sc;
-        o[j] = o[j] * sc + sh;
-        if (epi.relu) o[j] = fmaxf(o[j], 0.f);
-      }
-      v = float4{o[0], o[1], o[2], o[3]};
-    }
-    *reinterpret_cast<float4*>(out + (brow0 + r) * CN + c4 * 4) = v;
-  }
-}
-
-// --------------------------------------------------------------------------------------------- K6/K7 v4 (wave-autonomous)
-// Round 2, second design of the gather-GEMM for the MFMA-bound shapes (both channel counts multiples of 16).  v2's counters say
-// its matrix pipes are busy 56 % of the time although every resource it uses is far from saturated: each block walks its active
-// offsets in lock step (one barrier + one LDS-staged W_k image per offset, 32 MFMAs per wave between barriers), so a wave's
-// MFMA burst is short and every burst is gated by the slowest of four waves sitting on four different SIMDs.  v4 removes the
-// coupling instead of tuning it:
-//   * a workgroup is ONE wave that owns 64 consecutive output rows (4 MFMA row tiles): no block barrier anywhere;
-//   * W_k goes from L2 straight into the wave's registers in MFMA-fragment order (the canonical (Cout, KV, Cin) layout already
-//     gives a lane its fragment as contiguous 16 bytes; the transposed backward reads are dwords): the same L2 traffic per row
-//     as a 64-row block sharing one staged image, no LDS round trip; W_{k+1} is loaded while the four tiles of offset k
-//     compute (register ping-pong), i.e. one W_k load is amortised over up to 4 x 32 MFMAs of the same wave;
-//   * the gathers are pipelined at TILE granularity: while tile t of offset k runs its MFMAs, the rows of the next tile slot
-//     are in flight into the other A register set and the pair-table entries of the slot after that are being read from LDS;
-//     every load is unconditional (index -1 -> out-of-range buffer offset -> zeros), the body is straight-line code per
-//     offset pair, so hipcc keeps counted vmcnt waits;
-//   * consecutive MFMAs alternate between the output-column accumulators (no dependent back-to-back pair);
-//   * LDS holds only the wave's slice of the pair table (KV x 64 ints) -- 7 KB per wave.
-// Same arithmetic per output row as v2 (offsets ascending, K order (ch, j, q)): results are bit-identical to v2's.
-template <int NB>
-struct BufLoadS;
-template <>
-struct BufLoadS<4> {
-  static __device__ __forceinline__ void ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float* o) {
-    i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
-    o[0] = __int_as_float(v.x); o[1] = __int_as_float(v.y); o[2] = __int_as_float(v.z); o[3] = __int_as_float(v.w);
-  }
-};
-template <>
-struct BufLoadS<1> {
-  static __device__ __forceinline__ void ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float* o) {
-    o[0] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
-  }
-};
-
-// ABL (developer ablations, vc_debug_set conv_v4_ablate; results are WRONG for ABL != 0): 1 = the MFMAs replaced by a few FMAs
-// that keep every load alive, 2 = every gather reads the tile's own rows (coalesced, cache-resident), 3 = every W_k load reads
-// offset 0's image (cache-resident), 4 = 2 + 3
-// PF = gather prefetch distance: 1 = one tile slot ahead (two A register sets), 2 = two slots ahead (three sets), 4 = a whole
-// offset ahead (all four tiles of the next offset are in flight while the current offset computes: 2 x 4 sets)
-template <int CK, int CN, bool BWD, int EPI, bool PK = false, int ABL = 0, int PF = 1>
-__global__ void __launch_bounds__(64) gather_gemm_v4_kernel(const float* __restrict__ src,
-                                                            const float* __restrict__ src_centre, int64_t n_src,
-                                                            const int32_t* __restrict__ tbl,
-                                                            const float* __restrict__ w, float* __restrict__ out,
-                                                            const int32_t* __restrict__ rep,
-                                                            const int32_t* __restrict__ order, int64_t n_out, int kv,
-                                                            int centre, int mirror, ConvEpilogue epi) {
-  static_assert(CK % 16 == 0 && CN % 16 == 0, "v4 serves channel counts that are multiples of 16");
-  static_assert(EPI == VC_EPI_NONE || (EPI == VC_EPI_BWD) == BWD, "STATS / AFFINE: forward kernel; BWD: backward-input kernel");
-  constexpr int RT = 4, R = 64;
-  constexpr int NCH = CK / 16, NT = CN / 16;
-  static_assert(PF != 11 || PK, "the interleaved schedule reads the weight image");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  int* s_idx = reinterpret_cast<int*>(smem);  // [kv][64]
-  int* s_row = s_idx + kv * R;                // [64] output row of each slot (-1: none)
-
-  const int lane = threadIdx.x;
-  const int i = lane & 15, q = lane >> 4;
-  int64_t lbid;
-  {  // XCD-aware block -> row-range mapping (see v2)
-    const unsigned nb = gridDim.x, bid = blockIdx.x, xcd = bid & 7u, qd = nb >> 3, rm = nb & 7u;
-    lbid = (int64_t)(xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-    if (g_xcd_swizzle_off) lbid = bid;
-  }
-  const int64_t brow0 = lbid * R;
-
-  const __amdgpu_buffer_rsrc_t rs_src =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)(n_src * CK * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_ctr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(src_centre ? src_centre : src), 0, (int)(n_src * CK * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, (int)(kv * CK * CN * 4), 0x00020000);
-
-  // ---- the wave's slice of the pair table -> LDS, per-tile active-offset masks (bit k of tm[t]: tile t owns offset k)
-  unsigned tm[RT] = {0u, 0u, 0u, 0u};
-  {
-    const bool inb = brow0 + lane < n_out;
-    const int64_t row = inb ? (order ? (int64_t)order[brow0 + lane] : brow0 + lane) : -1;
-    s_row[lane] = (int)row;
-    const bool centre_only = (rep != nullptr) && inb && (rep[row] != (int32_t)row);
-    for (int k0 = 0; k0 < kv; k0 += 9) {
-      int v[9];
-#pragma unroll
-      for (int u = 0; u < 9; ++u) v[u] = (inb && k0 + u < kv) ? tbl[(int64_t)(k0 + u) * n_out + row] : -1;
-#pragma unroll
-      for (int u = 0; u < 9; ++u) {
-        if (k0 + u < kv) {
-          int x = v[u];
-          if (centre_only && k0 + u != centre) x = -1;
-          s_idx[(k0 + u) * R + lane] = x;
-          const unsigned long long b = __ballot(x >= 0);
-#pragma unroll
-          for (int t = 0; t < RT; ++t)
-            if ((b >> (16 * t)) & 0xFFFFull) tm[t] |= 1u << (k0 + u);
-        }
-      }
-    }
-  }
-  __syncthreads();  // one-wave workgroup: no s_barrier, only the LDS ordering
-  unsigned umask = tm[0] | tm[1] | tm[2] | tm[3];
-  umask = (unsigned)__builtin_amdgcn_readfirstlane((int)umask);
-
-  f32x4 acc[RT][NT];
-#pragma unroll
-  for (int t = 0; t < RT; ++t)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  float B0[NCH][NT][4], B1[NCH][NT][4];
-  float A0[NCH][4], A1[NCH][4];
-  float A2[PF == 2 ? NCH : 1][4];                 // PF == 2: third register set
-  float AC[PF == 4 ? RT : 1][NCH][4], AN[PF == 4 ? RT : 1][NCH][4];  // PF == 4: current / next offset, all tiles
-
-  // per-lane byte offsets of the W fragments
-  //   forward : w[(n * kv + kw) * CK + ch*16 + q*4 .. +3],  n = nt*16 + i   -> voff[nt] + soff(kw) + imm(ch)
-  //   backward: w[((ch*16 + q*4 + j) * kv + kw) * CN + nt*16 + i]          -> voff + soff(ch, j, kw) + imm(nt)
-  unsigned wv[NT];
-  if constexpr (PK) {
-    wv[0] = (unsigned)(lane * 16);
-  } else if constexpr (!BWD) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wv[nt] = (unsigned)(((nt * 16 + i) * kv * CK + q * 4) * 4);
-  } else {
-    wv[0] = (unsigned)((q * 4 * kv * CN + i) * 4);
-  }
-
-#define V4_LOAD_B(K, BX)                                                                           \
-  do {                                                                                             \
-    const int kw_ = (ABL == 3 || ABL == 4) ? 0 : (mirror ? (kv - 1 - (K)) : (K));                  \
-    if constexpr (PK) {  /* fragment-ordered image: every instruction reads 1 KB of contiguous memory */ \
-      const unsigned so_ = (unsigned)(kw_ * (NCH * NT * 1024));                                    \
-      _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
-          _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                        \
-              BufLoadS<4>::ld(rs_w, wv[0], so_ + (unsigned)((ch * NT + nt) * 1024), BX[ch][nt]);   \
-    } else if constexpr (!BWD) {                                                                   \
-      const unsigned so_ = (unsigned)(kw_ * CK * 4);                                               \
-      _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
-          _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                        \
-              BufLoadS<4>::ld(rs_w, wv[nt] + (unsigned)(ch * 64), so_, BX[ch][nt]);                \
-    } else {                                                                                       \
-      _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
-          _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                          \
-            const unsigned so_ = (unsigned)((((ch * 16 + j) * kv + kw_) * CN) * 4);                \
-            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                      \
-                BufLoadS<1>::ld(rs_w, wv[0] + (unsigned)(nt * 64), so_, &BX[ch][nt][j]);           \
-          }                                                                                        \
-    }                                                                                              \
-  } while (0)
-
-#define V4_IDX(K, T) ((ABL == 2 || ABL == 4) ? (s_idx[(K) * R + (T) * 16 + i] >= 0 ? (int)(brow0 % n_src) + (T) * 16 + i : -1) \
-                                             : s_idx[(K) * R + (T) * 16 + i])
-
-#define V4_GATHER(K, ID, AX)                                                                       \
-  do {                                                                                             \
-    const __amdgpu_buffer_rsrc_t rs_ = ((K) == centre) ? rs_ctr : rs_src;                          \
-    const unsigned base_ = (unsigned)(ID) * (unsigned)(CK * 4) + (unsigned)(q * 16);               \
-    _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch) BufLoad<4>::ld(rs_, base_ + (unsigned)(ch * 64), AX[ch]); \
-  } while (0)
-
-#define V4_MFMA(T, K, AX, BX)                                                                      \
-  do {                                                                                             \
-    if ((tm[T] >> (K)) & 1u) {                                                                     \
-      _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
-          _Pragma("unroll") for (int j = 0; j < 4; ++j)                                            \
-              _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                  \
-                if constexpr (ABL == 1) acc[T][nt][j] += AX[ch][j] * BX[ch][nt][j];                \
-                else acc[T][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(AX[ch][j], BX[ch][nt][j], acc[T][nt], 0, 0, 0); \
-              }                                                                                    \
-    }                                                                                              \
-  } while (0)
-
-  // one offset KC (its W image in BC, tile 0's rows in A0, idg = table entries of tile 1), next offset KN
-#define V4_OFFSET(KC, KN, BC, BN)                                                                  \
-  do {                                                                                             \
-    V4_LOAD_B(KN, BN);                                                                             \
-    idn = V4_IDX(KC, 2); V4_GATHER(KC, idg, A1); V4_MFMA(0, KC, A0, BC); idg = idn;                \
-    idn = V4_IDX(KC, 3); V4_GATHER(KC, idg, A0); V4_MFMA(1, KC, A1, BC); idg = idn;                \
-    idn = V4_IDX(KN, 0); V4_GATHER(KC, idg, A1); V4_MFMA(2, KC, A0, BC); idg = idn;                \
-    idn = V4_IDX(KN, 1); V4_GATHER(KN, idg, A0); V4_MFMA(3, KC, A1, BC); idg = idn;                \
-  } while (0)
-
-  // PF == 11 (needs a weight image): the schedule of PF == 1 with the loads INTERLEAVED into the MFMA stream -- one gather
-  // instruction (and, every G / NB groups, one weight-fragment instruction of the next offset) in front of each K chunk's MFMAs,
-  // pinned there by sched_barrier.  A wave whose VMEM issue is back-pressured by the CU's memory pipeline then waits while its
-  // previous MFMAs still execute, instead of in front of a whole burst.
-#define V4_SLOT_IL(T, KC, KG, ANEXT, ACUR, BC, KN, BN)                                             \
-  do {                                                                                             \
-    const __amdgpu_buffer_rsrc_t rs_ = ((KG) == centre) ? rs_ctr : rs_src;                         \
-    const unsigned base_ = (unsigned)idg * (unsigned)(CK * 4) + (unsigned)(q * 16);                \
-    const bool act_ = ((tm[T] >> (KC)) & 1u) != 0u;                                                \
-    const unsigned sob_ = (unsigned)(((ABL == 3 || ABL == 4) ? 0 : (mirror ? (kv - 1 - (KN)) : (KN))) * (NCH * NT * 1024)); \
-    _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch) {                                           \
-      BufLoad<4>::ld(rs_, base_ + (unsigned)(ch * 64), ANEXT[ch]);                                 \
-      if ((((T) * NCH + ch) * (NCH * NT)) % (RT * NCH) == 0) {                                     \
-        const int u_ = ((T) * NCH + ch) * (NCH * NT) / (RT * NCH);                                 \
-        BufLoadS<4>::ld(rs_w, wv[0], sob_ + (unsigned)(u_ * 1024), BN[u_ / NT][u_ % NT]);          \
-      }                                                                                            \
-      if (act_) {                                                                                  \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                              \
-            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                      \
-                acc[T][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ACUR[ch][j], BC[ch][nt][j], acc[T][nt], 0, 0, 0); \
-      }                                                                                            \
-      __builtin_amdgcn_sched_barrier(0);                                                           \
-    }                                                                                              \
-  } while (0)
-#define V4_OFFSET_IL(KC, KN, BC, BN)                                                               \
-  do {                                                                                             \
-    idn = V4_IDX(KC, 2); V4_SLOT_IL(0, KC, KC, A1, A0, BC, KN, BN); idg = idn;                     \
-    idn = V4_IDX(KC, 3); V4_SLOT_IL(1, KC, KC, A0, A1, BC, KN, BN); idg = idn;                     \
-    idn = V4_IDX(KN, 0); V4_SLOT_IL(2, KC, KC, A1, A0, BC, KN, BN); idg = idn;                     \
-    idn = V4_IDX(KN, 1); V4_SLOT_IL(3, KC, KN, A0, A1, BC, KN, BN); idg = idn;                     \
-  } while (0)
-
-  // PF == 2: tile 0's rows in AX, tile 1's in AY (possibly still in flight), idg = table entries of tile 2; the next offset
-  // starts with (AY, AZ, AX)
-#define V4_OFFSET3(KC, KN, BC, BN, AX, AY, AZ)                                                     \
-  do {                                                                                             \
-    V4_LOAD_B(KN, BN);                                                                             \
-    idn = V4_IDX(KC, 3); V4_GATHER(KC, idg, AZ); V4_MFMA(0, KC, AX, BC); idg = idn;                \
-    idn = V4_IDX(KN, 0); V4_GATHER(KC, idg, AX); V4_MFMA(1, KC, AY, BC); idg = idn;                \
-    idn = V4_IDX(KN, 1); V4_GATHER(KN, idg, AY); V4_MFMA(2, KC, AZ, BC); idg = idn;                \
-    idn = V4_IDX(KN, 2); V4_GATHER(KN, idg, AZ); V4_MFMA(3, KC, AX, BC); idg = idn;                \
-  } while (0)
-  // PF == 4: the four tiles of KC are in AXC, the four tiles of KN go to AXN
-#define V4_OFFSETD(KC, KN, BC, BN, AXC, AXN)                                                       \
-  do {                                                                                             \
-    V4_LOAD_B(KN, BN);                                                                             \
-    int id4_[RT];                                                                                  \
-    _Pragma("unroll") for (int t = 0; t < RT; ++t) id4_[t] = V4_IDX(KN, t);                        \
-    _Pragma("unroll") for (int t = 0; t < RT; ++t) V4_GATHER(KN, id4_[t], AXN[t]);                 \
-    V4_MFMA(0, KC, AXC[0], BC); V4_MFMA(1, KC, AXC[1], BC);                                        \
-    V4_MFMA(2, KC, AXC[2], BC); V4_MFMA(3, KC, AXC[3], BC);                                        \
-  } while (0)
-#define V4_NEXT(MORE, KNEW, KOLD)                                                                  \
-  const bool MORE = umask != 0u;                                                                   \
-  KNEW = MORE ? (__ffs((int)umask) - 1) : KOLD;                                                    \
-  umask &= umask - 1;
-
-#pragma unroll
-  for (int t = 0; t < RT; ++t) tm[t] = (unsigned)__builtin_amdgcn_readfirstlane((int)tm[t]);
-  if constexpr (PF == 4) {
-    if (umask != 0u) {
-      int kc = __ffs((int)umask) - 1, kn;
-      umask &= umask - 1;
-      V4_LOAD_B(kc, B0);
-#pragma unroll
-      for (int t = 0; t < RT; ++t) { const int id_ = V4_IDX(kc, t); V4_GATHER(kc, id_, AC[t]); }
-      for (;;) {
-        V4_NEXT(more0, kn, kc)
-        V4_OFFSETD(kc, kn, B0, B1, AC, AN);
-        if (!more0) break;
-        V4_NEXT(more1, kc, kn)
-        V4_OFFSETD(kn, kc, B1, B0, AN, AC);
-        if (!more1) break;
-      }
-    }
-  } else if constexpr (PF == 2) {
-    if (umask != 0u) {
-      int ka = __ffs((int)umask) - 1, kb;
-      umask &= umask - 1;
-      int idg, idn;
-      V4_LOAD_B(ka, B0);
-      idg = V4_IDX(ka, 0); V4_GATHER(ka, idg, A0);
-      idg = V4_IDX(ka, 1); V4_GATHER(ka, idg, A1);
-      idg = V4_IDX(ka, 2);
-      for (;;) {
-        { V4_NEXT(m0, kb, ka) V4_OFFSET3(ka, kb, B0, B1, A0, A1, A2); if (!m0) break; }
-        { V4_NEXT(m1, ka, kb) V4_OFFSET3(kb, ka, B1, B0, A1, A2, A0); if (!m1) break; }
-        { V4_NEXT(m2, kb, ka) V4_OFFSET3(ka, kb, B0, B1, A2, A0, A1); if (!m2) break; }
-        { V4_NEXT(m3, ka, kb) V4_OFFSET3(kb, ka, B1, B0, A0, A1, A2); if (!m3) break; }
-        { V4_NEXT(m4, kb, ka) V4_OFFSET3(ka, kb, B0, B1, A1, A2, A0); if (!m4) break; }
-        { V4_NEXT(m5, ka, kb) V4_OFFSET3(kb, ka, B1, B0, A2, A0, A1); if (!m5) break; }
-      }
-    }
-  } else
-  if (umask != 0u) {
-    int kc = __ffs((int)umask) - 1, kn;
-    umask &= umask - 1;
-    int idg, idn;
-    V4_LOAD_B(kc, B0);
-    idg = V4_IDX(kc, 0);
-    V4_GATHER(kc, idg, A0);
-    idg = V4_IDX(kc, 1);
-    for (;;) {
-      const bool more0 = umask != 0u;
-      kn = more0 ? (__ffs((int)umask) - 1) : kc;
-      umask &= umask - 1;
-      if constexpr (PF == 11) V4_OFFSET_IL(kc, kn, B0, B1); else V4_OFFSET(kc, kn, B0, B1);
-      if (!more0) break;
-      const bool more1 = umask != 0u;
-      kc = more1 ? (__ffs((int)umask) - 1) : kn;
-      umask &= umask - 1;
-      if constexpr (PF == 11) V4_OFFSET_IL(kn, kc, B1, B0); else V4_OFFSET(kn, kc, B1, B0);
-      if (!more1) break;
-    }
-  }
-#undef V4_OFFSET
-#undef V4_OFFSET_IL
-#undef V4_SLOT_IL
-#undef V4_OFFSET3
-#undef V4_OFFSETD
-#undef V4_NEXT
-#undef V4_MFMA
-#undef V4_GATHER
-#undef V4_IDX
-#undef V4_LOAD_B
-
-  // ---- epilogues: as v2, one partial row per 16-row tile (tile index = first row / 16)
-  if constexpr (EPI == VC_EPI_STATS) {
-#pragma unroll
-    for (int t = 0; t < RT; ++t) {
-      float* prow = epi.partial + ((lbid * RT + t) * 2) * CN;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        float sm = ((acc[t][nt][0] + acc[t][nt][1]) + acc[t][nt][2]) + acc[t][nt][3];
-        float sq = ((acc[t][nt][0] * acc[t][nt][0] + acc[t][nt][1] * acc[t][nt][1]) + acc[t][nt][2] * acc[t][nt][2]) +
-                   acc[t][nt][3] * acc[t][nt][3];
-        sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
-        sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
-        const int n = nt * 16 + i;
-        if (q == 0) { prow[n] = sm; prow[CN + n] = sq; }
-      }
-    }
-  }
-  float sc[NT], sh[NT];
-  if constexpr (EPI == VC_EPI_AFFINE) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = nt * 16 + i;
-      const float istd = 1.0f / sqrtf(epi.var[n] + epi.eps);
-      sc[nt] = (epi.gamma ? epi.gamma[n] : 1.f) * istd;
-      sh[nt] = (epi.beta ? epi.beta[n] : 0.f) - epi.mean[n] * sc[nt];
-    }
-  }
-  float b_mu[NT], b_istd[NT], b_g[NT], b_bt[NT];
-  const bool bwd_stats = (EPI == VC_EPI_BWD) && epi.y_raw != nullptr;
-  if constexpr (EPI == VC_EPI_BWD) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = nt * 16 + i;
-      b_mu[nt] = 0.f; b_istd[nt] = 0.f; b_g[nt] = 1.f; b_bt[nt] = 0.f;
-      if (bwd_stats) {
-        b_mu[nt] = epi.mean[n];
-        b_istd[nt] = 1.0f / sqrtf(epi.var[n] + epi.eps);
-        b_g[nt] = epi.gamma ? epi.gamma[n] : 1.f;
-        b_bt[nt] = epi.beta ? epi.beta[n] : 0.f;
-      }
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < RT; ++t) {
-    int64_t orow[4];
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) orow[reg] = s_row[t * 16 + q * 4 + reg];
-    float b_sa[NT], b_sb[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = nt * 16 + i;
-      b_sa[nt] = 0.f; b_sb[nt] = 0.f;
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        float v = acc[t][nt][reg];
-        if constexpr (EPI == VC_EPI_AFFINE) {
-          v = v * sc[nt] + sh[nt];
-          if (epi.relu) v = fmaxf(v, 0.f);
-        }
-        if constexpr (EPI == VC_EPI_BWD) {
-          if (orow[reg] >= 0) {
-            if (epi.addend != nullptr) v += epi.addend[orow[reg] * epi.add_stride + epi.add_col0 + n];
-            if (bwd_stats) {
-              const float xh = (epi.y_raw[orow[reg] * CN + n] - b_mu[nt]) * b_istd[nt];
-              float d = v;
-              if (epi.relu && !(xh * b_g[nt] + b_bt[nt] > 0.f)) d = 0.f;
-              b_sa[nt] += d;
-              b_sb[nt] += d * xh;
-            }
-          }
-        }
-        if (orow[reg] >= 0) out[orow[reg] * CN + n] = v;
-      }
-    }
-    if constexpr (EPI == VC_EPI_BWD) {
-      if (bwd_stats) {
-        float* prow = epi.partial + ((lbid * RT + t) * 2) * CN;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          float sa = b_sa[nt], sb = b_sb[nt];
-          sa += __shfl_xor(sa, 16, 64); sb += __shfl_xor(sb, 16, 64);
-          sa += __shfl_xor(sa, 32, 64); sb += __shfl_xor(sb, 32, 64);
-          const int n = nt * 16 + i;
-          if (q == 0) { prow[n] = sa; prow[CN + n] = sb; }
-        }
-      }
-    }
-  }
-}
-
-// --------------------------------------------------------------------------------------------- K6/K7 v5 (loader / MFMA wave roles)
-// What §4.2b of DESIGN.md points at, as an experiment (vc_debug_set conv_v5, plain launches with a weight image only): the waves
-// that issue MFMAs never touch the vector-memory pipeline.  A 512-thread workgroup owns 64 output rows:
-//   * waves 0-3 ("MFMA waves", one per SIMD) own one 16-row tile each.  Per active offset they read their A fragments and the W_k
-//     fragments from LDS (ds_read_b128, conflict-free) and issue the MFMAs -- no VMEM instruction in their loop, so back-pressure
-//     of the CU's memory pipeline cannot stall an MFMA stream;
-//   * waves 4-7 ("loader waves") gather.  They are free to use the QUAD lane mapping (lane 4r + c reads 16 bytes of row r: one
-//     cache line per quad instead of four, tools/ubench/gather_ubench.hip), park the rows of offset j + 2 in registers while
-//     offset j computes, and write the rows of offset j + 1 into the other LDS stage in the MFMA-ready order (chunk swizzle
-//     slot = c ^ ((r >> 3) << 1): the consumers' ds_read_b128 hit 16 distinct bank groups); the same waves copy W_{k} (the
-//     fragment-ordered image, 1 KB contiguous per instruction) into the stage.
-// One block barrier per offset separates the two LDS stages.  Same MFMA sequence per output row as v2 / v4: bit-identical results.
-template <int CK, int CN, int EPI>
-__global__ void __launch_bounds__(512) gather_gemm_v5_kernel(const float* __restrict__ src,
-                                                             const float* __restrict__ src_centre, int64_t n_src,
-                                                             const int32_t* __restrict__ tbl,
-                                                             const float* __restrict__ wpk, float* __restrict__ out,
-                                                             const int32_t* __restrict__ rep,
-                                                             const int32_t* __restrict__ order, int64_t n_out, int kv,
-                                                             int centre, int mirror, ConvEpilogue epi) {
-  static_assert(CK % 16 == 0 && CN % 16 == 0 && ((CK / 16) * (CN / 16)) % 4 == 0, "v5: 16-channel chunks, W image split over 4 loader waves");
-  static_assert(EPI == VC_EPI_NONE, "v5 is an experiment: plain launches only");
-  constexpr int NCH = CK / 16, NT = CN / 16;
-  constexpr int TILE_A = NCH * 1024;                 // bytes of one 16-row tile in a stage: [ch][16 rows][64 B]
-  constexpr int STAGE_A = 4 * TILE_A, STAGE_B = NCH * NT * 1024;
-  constexpr int NWL = NCH * NT / 4;                  // 1 KB pieces of the W image per loader wave
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* s_a = smem;                          // [2][STAGE_A]
-  unsigned char* s_b = smem + 2 * STAGE_A;            // [2][STAGE_B]
-  int* s_idx = reinterpret_cast<int*>(smem + 2 * STAGE_A + 2 * STAGE_B);  // [kv][64]
-  int* s_row = s_idx + kv * 64;                        // [64]
-  unsigned* s_tm = reinterpret_cast<unsigned*>(s_row + 64);  // [4] active offsets per tile
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler too (scalar offsets, no waterfall loops)
-  const bool consumer = wave < 4;
-  const int i = lane & 15, q = lane >> 4;            // MFMA lane coordinates (consumers)
-  const int r = lane >> 2, c = lane & 3;             // quad mapping (loaders): row r of the tile, 16-byte piece c
-  int64_t lbid;
-  {
-    const unsigned nb = gridDim.x, bid = blockIdx.x, xcd = bid & 7u, qd = nb >> 3, rm = nb & 7u;
-    lbid = (int64_t)(xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-    if (g_xcd_swizzle_off) lbid = bid;
-  }
-  const int64_t brow0 = lbid * 64;
-  const __amdgpu_buffer_rsrc_t rs_src =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)(n_src * CK * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_ctr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(src_centre ? src_centre : src), 0, (int)(n_src * CK * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wpk), 0, (int)(kv * CK * CN * 4), 0x00020000);
-
-  if (tid < 4) s_tm[tid] = 0u;
-  __syncthreads();
-  {  // the block's slice of the pair table: wave w stages offsets w, w + 8, ...; lane = row slot
-    const bool inb = brow0 + lane < n_out;
-    const int64_t row = inb ? (order ? (int64_t)order[brow0 + lane] : brow0 + lane) : -1;
-    if (wave == 0) s_row[lane] = (int)row;
-    const bool centre_only = (rep != nullptr) && inb && (rep[row] != (int32_t)row);
-    for (int k = wave; k < kv; k += 8) {
-      int v = inb ? tbl[(int64_t)k * n_out + row] : -1;
-      if (centre_only && k != centre) v = -1;
-      s_idx[k * 64 + lane] = v;
-      const unsigned long long b = __ballot(v >= 0);
-      if (lane == 0) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          if ((b >> (16 * t)) & 0xFFFFull) atomicOr(&s_tm[t], 1u << k);
-      }
-    }
-  }
-  __syncthreads();
-  unsigned rest = (unsigned)__builtin_amdgcn_readfirstlane((int)(s_tm[0] | s_tm[1] | s_tm[2] | s_tm[3]));
-  const unsigned mytm = (unsigned)__builtin_amdgcn_readfirstlane((int)s_tm[wave & 3]);
-  const int p = wave & 3;                             // loader wave p gathers tile p and copies quarter p of the W image
-
-  f32x4 acc[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float ga[NCH][4];                                   // loaders: the gathered rows parked in registers
-  float gw[NWL][4];
-
-  // consumer LDS read offsets (bytes inside a stage) / loader LDS write offsets
-  const int a_rd = p * TILE_A + i * 64 + ((q ^ ((i >> 3) << 1)) * 16);
-  const int a_wr = p * TILE_A + r * 64 + ((c ^ ((r >> 3) << 1)) * 16);
-
-#define V5_LOAD(K)                                                                                 \
-  do {                                                                                             \
-    const int id_ = s_idx[(K) * 64 + p * 16 + r];                                                  \
-    const __amdgpu_buffer_rsrc_t rs_ = ((K) == centre) ? rs_ctr : rs_src;                          \
-    const unsigned base_ = (unsigned)id_ * (unsigned)(CK * 4) + (unsigned)(c * 16);                \
-    _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch) BufLoad<4>::ld(rs_, base_ + (unsigned)(ch * 64), ga[ch]); \
-    const int kw_ = mirror ? (kv - 1 - (K)) : (K);                                                 \
-    _Pragma("unroll") for (int u = 0; u < NWL; ++u)                                                \
-        BufLoadS<4>::ld(rs_w, (unsigned)(lane * 16), (unsigned)(kw_ * STAGE_B + (p * NWL + u) * 1024), gw[u]); \
-  } while (0)
-#define V5_STORE(STG)                                                                              \
-  do {                                                                                             \
-    _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                             \
-        *reinterpret_cast<float4*>(s_a + (STG) * STAGE_A + a_wr + ch * 1024) = float4{ga[ch][0], ga[ch][1], ga[ch][2], ga[ch][3]}; \
-    _Pragma("unroll") for (int u = 0; u < NWL; ++u)                                                \
-        *reinterpret_cast<float4*>(s_b + (STG) * STAGE_B + (p * NWL + u) * 1024 + lane * 16) = float4{gw[u][0], gw[u][1], gw[u][2], gw[u][3]}; \
-  } while (0)
-#define V5_CONSUME(STG, K)                                                                         \
-  do {                                                                                             \
-    if ((mytm >> (K)) & 1u) {                                                                      \
-      float a_[NCH][4], b_[NCH][NT][4];                                                            \
-      _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch) {                                         \
-        const float4 v_ = *reinterpret_cast<const float4*>(s_a + (STG) * STAGE_A + a_rd + ch * 1024); \
-        a_[ch][0] = v_.x; a_[ch][1] = v_.y; a_[ch][2] = v_.z; a_[ch][3] = v_.w;                    \
-      }                                                                                            \
-      _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
-          _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                      \
-            const float4 v_ = *reinterpret_cast<const float4*>(s_b + (STG) * STAGE_B + (ch * NT + nt) * 1024 + lane * 16); \
-            b_[ch][nt][0] = v_.x; b_[ch][nt][1] = v_.y; b_[ch][nt][2] = v_.z; b_[ch][nt][3] = v_.w; \
-          }                                                                                        \
-      _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
-          _Pragma("unroll") for (int j = 0; j < 4; ++j)                                            \
-              _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                    \
-                  acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[ch][j], b_[ch][nt][j], acc[nt], 0, 0, 0); \
-    }                                                                                              \
-  } while (0)
-
-  if (rest != 0u) {
-    int kc = __ffs((int)rest) - 1;
-    rest &= rest - 1;
-    int kn = rest ? (__ffs((int)rest) - 1) : -1;
-    rest &= rest - 1;
-    if (!consumer) {
-      V5_LOAD(kc);
-      V5_STORE(0);
-      if (kn >= 0) V5_LOAD(kn);
-    }
-    __syncthreads();
-    int stage = 0;
-    for (;;) {
-      const int kn2 = rest ? (__ffs((int)rest) - 1) : -1;
-      rest &= rest - 1;
-      if (consumer) {
-        V5_CONSUME(stage, kc);
-      } else {
-        if (kn >= 0) V5_STORE(stage ^ 1);
-        if (kn2 >= 0) V5_LOAD(kn2);
-      }
-      __syncthreads();
-      if (kn < 0) break;
-      kc = kn; kn = kn2; stage ^= 1;
-    }
-  }
-#undef V5_CONSUME
-#undef V5_STORE
-#undef V5_LOAD
-
-  if (consumer) {
-    int64_t orow[4];
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) orow[reg] = s_row[p * 16 + q * 4 + reg];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = nt * 16 + i;
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg)
-        if (orow[reg] >= 0) out[orow[reg] * CN + n] = acc[nt][reg];
-    }
-  }
-}
-
-// --------------------------------------------------------------------------------------------- K6/K7 v3 (LDS row windows)
-// The gather-GEMM for tables whose rows are in ascending coordinate order (the SubM convs of stages 2-4, forward and
-// backward-input): the feature gathers are staged through LDS instead of going L2 -> VGPR per kernel offset.
-//
-// Why it works (tests/analysis_tile_window.py, oracle rulebooks of a synthetic KITTI frame): rows are sorted by (b, z, y, x), so
-// the source rows that the three dx-offsets of one (dz, dy) group gather for a 16-row MFMA tile form ONE nearly contiguous run
-// -- median span 16-18 rows, <= 32 rows for 97.4-98.1 % of the (tile, group) pairs -- and every row of the run is gathered
-// 1.6-2.5 times.  Per (wave, group) the run [lo, lo + span) is loaded ONCE with fully coalesced 16-byte loads (whole 64/128/256-
-// byte rows, 4/8/16 rows per wave instruction), parked in registers while the previous group computes (the registers are the
-// second buffer: no LDS double buffering, no block barrier -- the window is private to the wave), written to the wave's LDS
-// window (row stride CK*4 + 16 bytes: conflict-free ds_read_b128 for the MFMA fragment pattern) and the A fragments of the
-// three offsets are read from there; index -1 reads a zero row.  A (tile, group) whose span exceeds the window gathers
-// directly (buffer loads, as v2).
-//
-// MFMA phase (also what v2 got wrong, visible in its ISA: every B fragment was read into the same four registers and
-// waited for, eight exposed LDS latencies per offset, and the four MFMAs of a K-chunk were issued back to back on ONE
-// accumulator, 40-cycle dependent latency instead of the 32-cycle issue rate): all fragments of a stage are read first
-// (sched_barrier), then the MFMAs alternate between the NT accumulators.
-//
-// W_k staging (per offset, double-buffered, one block barrier per offset) and the XCD-aware block mapping are v2's.
-// EPI == VC_EPI_STATS here writes one partial row per WAVE (16 output rows): no extra barrier in the epilogue.
-[[maybe_unused]] static constexpr int kWinRowsDefault = 32;
-
-// full-wave integer min / max on the DPP crossbar (row_shr 1/2/4/8 scans a 16-lane row, row_bcast:15 / :31 chain the rows; the
-// result is lane 63's): seven VALU instructions and no LDS round trip -- __shfl_xor lowers to ds_bpermute + a wait per step,
-// six exposed LDS latencies per reduction.
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ int dpp_shift(int identity, int v) {
-  return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROWMASK, 0xf, false);
-}
-__device__ __forceinline__ int wave_min_i32(int v) {
-  constexpr int id = 0x7fffffff;
-  v = min(v, dpp_shift<0x111, 0xf>(id, v));
-  v = min(v, dpp_shift<0x112, 0xf>(id, v));
-  v = min(v, dpp_shift<0x114, 0xf>(id, v));
-  v = min(v, dpp_shift<0x118, 0xf>(id, v));
-  v = min(v, dpp_shift<0x142, 0xa>(id, v));
-  v = min(v, dpp_shift<0x143, 0xc>(id, v));
-  return __builtin_amdgcn_readlane(v, 63);
-}
-__device__ __forceinline__ int wave_max_i32(int v) {
-  constexpr int id = (int)0x80000000;
-  v = max(v, dpp_shift<0x111, 0xf>(id, v));
-  v = max(v, dpp_shift<0x112, 0xf>(id, v));
-  v = max(v, dpp_shift<0x114, 0xf>(id, v));
-  v = max(v, dpp_shift<0x118, 0xf>(id, v));
-  v = max(v, dpp_shift<0x142, 0xa>(id, v));
-  v = max(v, dpp_shift<0x143, 0xc>(id, v));
-  return __builtin_amdgcn_readlane(v, 63);
-}
-
-template <int CK, int CN, bool BWD, int EPI, bool WDMA, int WINROWS>
-__global__ void __launch_bounds__(256) gather_gemm_v3_kernel(const float* __restrict__ src, int64_t n_src,
-                                                             const int32_t* __restrict__ tbl,
-                                                             const float* __restrict__ w, float* __restrict__ out,
-                                                             int64_t n_out, int kv, int mirror, ConvEpilogue epi) {
-  static_assert(CK >= 16 && CK % 16 == 0, "the window kernel moves 16-byte chunks of whole rows");
-  static_assert(EPI == VC_EPI_NONE || !BWD, "epilogues exist for the forward kernel only");
-  static_assert(!WDMA || CN % 16 == 0, "the LDS-DMA weight pipeline cannot zero-fill padded output columns");
-  constexpr int kWinRows = WINROWS;             // rows of the per-wave LDS window (+ one zero row)
-  constexpr int NSLOT = WDMA ? 3 : 2;           // W images in LDS
-  constexpr int V = 4;
-  constexpr int NCH = CK / 16;
-  constexpr int NT = (CN + 15) / 16;
-  constexpr int NFRAG = NCH * NT * 64;
-  constexpr int BF = NFRAG * V;                 // floats of one W_k image
-  constexpr int BLD = (NFRAG + 255) / 256;
-  constexpr int WS = CK + 4;                    // window row stride in floats (16-byte pad)
-  constexpr int LPR = CK / 4;                   // lanes (16-byte chunks) per row
-  constexpr int RPI = 64 / LPR;                 // rows per wave load instruction
-  constexpr int NWI = (kWinRows + RPI - 1) / RPI;  // load instructions of a full window
-  constexpr int NDMA = BWD ? BF / 256 : BLD;    // LDS-DMA instructions per wave and W image (4-byte / 16-byte granules)
-  constexpr int NSTG = (NCH * NT > 8) ? 2 : 1;  // fragment stages per offset (register budget: <= 8 B fragments in flight)
-  constexpr int CPS = NCH / NSTG;               // K-chunks per stage
-  static_assert(NCH % NSTG == 0, "stage split");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* s_b = reinterpret_cast<float*>(smem);                                  // [NSLOT][BF]
-  int* s_idx = reinterpret_cast<int*>(s_b + NSLOT * BF);                        // [kv][64]
-  float* s_win = reinterpret_cast<float*>(s_idx + kv * 64);                     // [4][(kWinRows + 1) * WS]
-  unsigned* s_mask = reinterpret_cast<unsigned*>(s_win + 4 * (kWinRows + 1) * WS);
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i = lane & 15, q = lane >> 4;
-  int64_t lbid;
-  {
-    const unsigned nb = gridDim.x, bid = blockIdx.x, xcd = bid & 7u, qd = nb >> 3, rm = nb & 7u;
-    lbid = (int64_t)(xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-    if (g_xcd_swizzle_off) lbid = bid;
-  }
-  const int64_t brow0 = lbid * 64;
-  const __amdgpu_buffer_rsrc_t rs_src =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)(n_src * CK * 4), 0x00020000);
-  float* win = s_win + wave * ((kWinRows + 1) * WS);
-
-  if (tid == 0) s_mask[0] = 0u;
-  for (int c = lane; c < WS; c += 64) win[kWinRows * WS + c] = 0.f;  // the zero row (index -1 reads it)
-  __syncthreads();
-  {  // phase 0: the block's slice of the pair table -> LDS, active-offset mask
-    const int r = tid & 63;
-    const bool inb = brow0 + r < n_out;
-    for (int k = tid >> 6; k < kv; k += 4) {
-      const int v = inb ? tbl[(int64_t)k * n_out + brow0 + r] : -1;
-      s_idx[k * 64 + r] = v;
-      if (__ballot(v >= 0) != 0ULL && lane == 0) atomicOr(&s_mask[0], 1u << k);
-    }
-  }
-  __syncthreads();
-  unsigned bmask = (unsigned)__builtin_amdgcn_readfirstlane((int)s_mask[0]);
-
-  f32x4 acc[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (bmask != 0u) {
-    float bregA[BLD][V], bregB[BLD][V];  // W images in flight: loaded two offsets ahead, written to LDS one offset ahead
-    f32x4 wreg[NWI];
-#pragma unroll
-    for (int c = 0; c < NWI; ++c) wreg[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#define VC3_LOAD_B(K, BR)                                                                          \
-  do {                                                                                             \
-    const int kw_ = mirror ? (kv - 1 - (K)) : (K);                                                 \
-    _Pragma("unroll") for (int u = 0; u < BLD; ++u) {                                              \
-      const int f = tid + u * 256;                                                                 \
-      if (NFRAG % 256 == 0 || f < NFRAG) {                                                         \
-        const int fl = f & 63, nt_ = (f >> 6) % NT, ch_ = (f >> 6) / NT;                           \
-        const int n_ = nt_ * 16 + (fl & 15), kk0 = ch_ * 16 + (fl >> 4) * 4;                       \
-        if (CN % 16 == 0 || n_ < CN) {                                                             \
-          if (!BWD) {                                                                              \
-            VecLoad<V>::ld(w + ((int64_t)n_ * kv + kw_) * CK + kk0, BR[u]);                      \
-          } else {                                                                                 \
-            _Pragma("unroll") for (int j = 0; j < V; ++j)                                          \
-                BR[u][j] = w[((int64_t)(kk0 + j) * kv + kw_) * CN + n_];                         \
-          }                                                                                        \
-        } else {                                                                                   \
-          _Pragma("unroll") for (int j = 0; j < V; ++j) BR[u][j] = 0.f;                          \
-        }                                                                                          \
-      }                                                                                            \
-    }                                                                                              \
-  } while (0)
-
-    // group g = offsets 3g .. 3g+2 (the dx triple of one (dz, dy)); gmask bit g = the block visits the group
-    unsigned gmask = 0u;
-    for (int g = 0; g * 3 < kv; ++g)
-      if ((bmask >> (3 * g)) & 7u) gmask |= 1u << g;
-    // span of the rows group G gathers for this wave's tile -> (lo, span); span = 0 when nothing is gathered or it does not fit
-#define VC3_ANALYSE(G, LO, SPAN)                                                                   \
-  do {                                                                                             \
-    const int ko_ = 3 * (G) + q;                                                                   \
-    const int v_ = (q < 3 && ko_ < kv) ? s_idx[ko_ * 64 + wave * 16 + i] : -1;                     \
-    const int mn_ = wave_min_i32((v_ >= 0) ? v_ : 0x7fffffff);                                     \
-    const int mx_ = wave_max_i32(v_);                                                              \
-    const int sp_ = (mx_ >= 0) ? (mx_ - mn_ + 1) : 0;                                              \
-    LO = mn_;                                                                                      \
-    SPAN = (sp_ <= kWinRows) ? sp_ : 0;                                                            \
-  } while (0)
-
-    // coalesced load of rows [LO, LO + SPAN) into wreg: instruction c moves rows LO + c*RPI .. + RPI-1, lane = (row, 16-B
-    // chunk).  Straight-line code: an instruction whose rows lie beyond the span gets an out-of-range offset -- the buffer
-    // bounds check answers it with zeros without touching memory -- so there is no branch and no register merge per load.
-#define VC3_ISSUE(LO, SPAN)                                                                        \
-  do {                                                                                             \
-    const unsigned off0_ = ((unsigned)(LO) + (unsigned)(lane / LPR)) * (unsigned)(CK * 4) + (unsigned)(lane % LPR) * 16u; \
-    _Pragma("unroll") for (int c = 0; c < NWI; ++c) {                                              \
-      const unsigned o_ = (c * RPI < (SPAN)) ? off0_ + (unsigned)(c * RPI * CK * 4) : 0xfffffff0u; \
-      wreg[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, (int)o_, 0, 0)); \
-    }                                                                                              \
-  } while (0)
-
-    int pre_g = __ffs((int)gmask) - 1, pre_lo, pre_span;  // window parked in wreg (span 0: nothing fits / nothing gathered)
-    VC3_ANALYSE(pre_g, pre_lo, pre_span);
-    VC3_ISSUE(pre_lo, pre_span);
-    int cur_g = -1, cur_lo = 0, cur_ok = 0;                // window now in LDS
-
-#define VC3_STORE_B(P, BR)                                                                         \
-  do {                                                                                             \
-    _Pragma("unroll") for (int u = 0; u < BLD; ++u) {                                              \
-      const int f = tid + u * 256;                                                                 \
-      if (NFRAG % 256 == 0 || f < NFRAG)                                                           \
-        *reinterpret_cast<f32x4*>(s_b + (P) * BF + f * V) = f32x4{BR[u][0], BR[u][1], BR[u][2], BR[u][3]}; \
-    }                                                                                              \
-  } while (0)
-
-    // one offset for this wave, in two parts: the group switch (wave-local: parked rows -> LDS window, then the request for the
-    // next visited group's rows) and the MFMA phase on W image `p`
-    auto switch_group = [&](const int k) __attribute__((always_inline)) {
-      // ---- group switch (wave-local): parked rows -> LDS window, then start the load of the next visited group's rows
-      const int g = k / 3;
-      if (g != cur_g) {  // pre_g == g: the prefetch always targets the next visited group
-        __builtin_amdgcn_wave_barrier();  // the previous group's fragment reads are issued before the window is overwritten
-#pragma unroll
-        for (int c = 0; c < NWI; ++c)
-          if (kWinRows % RPI == 0 || c * RPI + lane / LPR < kWinRows)  // a partial last instruction must not touch the zero row
-            *reinterpret_cast<f32x4*>(win + (c * RPI + lane / LPR) * WS + (lane % LPR) * 4) = wreg[c];
-        __builtin_amdgcn_wave_barrier();  // LDS serves a wave's accesses in order: the reads below see these writes
-        cur_g = g; cur_lo = pre_lo; cur_ok = pre_span > 0;
-        const unsigned rest = gmask & ~((2u << g) - 1u);  // groups after g
-        pre_g = (rest != 0u) ? (__ffs((int)rest) - 1) : g;
-        VC3_ANALYSE(pre_g, pre_lo, pre_span);
-        if (rest == 0u) pre_span = 0;      // nothing left to prefetch: every load below is answered by the bounds check
-        VC3_ISSUE(pre_lo, pre_span);
-      }
-
-    };
-    auto mfma_phase = [&](const int k, const int p) __attribute__((always_inline)) {
-      // ---- this wave's 16 rows x offset k.  Two separate code paths: the window path must not contain a VMEM-sourced
-      // register (hipcc would put `s_waitcnt vmcnt(small)` in front of its MFMAs and drain the parked prefetches with it).
-      const int id = s_idx[k * 64 + wave * 16 + i];
-      if (__ballot(id >= 0) != 0ULL) {  // wave-uniform
-        const float* __restrict__ B_ = s_b + p * BF;
-#define VC3_STAGE(SG, ALOAD)                                                                       \
-  do {                                                                                             \
-    f32x4 a[CPS], b[CPS][NT];                                                                      \
-    _Pragma("unroll") for (int c = 0; c < CPS; ++c) a[c] = ALOAD((SG) * CPS + c);                  \
-    _Pragma("unroll") for (int c = 0; c < CPS; ++c)                                                \
-        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                          \
-            b[c][nt] = *reinterpret_cast<const f32x4*>(B_ + ((((SG) * CPS + c) * NT + nt) * 64 + lane) * 4); \
-    __builtin_amdgcn_sched_barrier(0); /* every fragment read of the stage is issued before its first MFMA */ \
-    _Pragma("unroll") for (int c = 0; c < CPS; ++c)                                                \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                              \
-            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) /* alternate accumulators: no dependent back-to-back MFMAs */ \
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[c][nt][j], acc[nt], 0, 0, 0); \
-  } while (0)
-        if (cur_ok) {
-          const float* arow = win + ((id >= 0) ? (id - cur_lo) : kWinRows) * WS + q * 4;
-#define VC3_A_LDS(CH) (*reinterpret_cast<const f32x4*>(arow + (CH) * 16))
-#pragma unroll
-          for (int sg = 0; sg < NSTG; ++sg) VC3_STAGE(sg, VC3_A_LDS);
-#undef VC3_A_LDS
-        } else {
-          const unsigned goff = (unsigned)id * (unsigned)(CK * 4) + (unsigned)(q * 16);  // id = -1 wraps out of range -> zeros
-#define VC3_A_GLB(CH) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, (int)(goff + (unsigned)((CH) * 64)), 0, 0))
-#pragma unroll
-          for (int sg = 0; sg < NSTG; ++sg) VC3_STAGE(sg, VC3_A_GLB);
-#undef VC3_A_GLB
-        }
-#undef VC3_STAGE
-      }
-    };
-
-    int k = __ffs((int)bmask) - 1;
-    bmask &= bmask - 1;
-    int k1 = (bmask != 0u) ? (__ffs((int)bmask) - 1) : -1;
-    bmask &= bmask - 1;
-    if constexpr (WDMA) {
-      // W pipeline on the LDS-DMA engine (global_load_lds: HBM/L2 -> LDS, no registers): the image of offset n+2 is requested
-      // at iteration n into slot (n+2) % 3 and nobody waits for it before the bottom of iteration n+1 -- two MFMA phases of
-      // flight.  Each wave waits for ITS part of image n+1 (a counted vmcnt: the DMAs of image n+2 stay in flight), the
-      // barrier at the top of iteration n+1 then publishes the whole image and retires every read of image n (slot reuse is
-      // three iterations away).  hipcc's own bookkeeping would drain the queue at every barrier, hence the raw barrier.
-#define VC3_DMA_B(K, SLOT)                                                                         \
-  do {                                                                                             \
-    const int kw_ = mirror ? (kv - 1 - (K)) : (K);                                                 \
-    if constexpr (!BWD) {                                                                          \
-      _Pragma("unroll") for (int u = 0; u < BLD; ++u) {                                            \
-        const int f0 = __builtin_amdgcn_readfirstlane(u * 256 + wave * 64);                        \
-        if (NFRAG % 256 == 0 || f0 < NFRAG) {                                                      \
-          const int f = f0 + lane;                                                                 \
-          const int fl = f & 63, nt_ = (f >> 6) % NT, ch_ = (f >> 6) / NT;                         \
-          const int n_ = nt_ * 16 + (fl & 15), kk0 = ch_ * 16 + (fl >> 4) * 4;                     \
-          __builtin_amdgcn_global_load_lds(                                                        \
-              (const __attribute__((address_space(1))) void*)(w + ((int64_t)n_ * kv + kw_) * CK + kk0), \
-              (__attribute__((address_space(3))) void*)(s_b + (SLOT) * BF + f0 * 4), 16, 0, 0);    \
-        }                                                                                          \
-      }                                                                                            \
-    } else {                                                                                       \
-      _Pragma("unroll") for (int e = 0; e < BF / 256; ++e) {                                       \
-        const int fi0 = __builtin_amdgcn_readfirstlane((e * 4 + wave) * 64);                       \
-        const int fi = fi0 + lane, f = fi >> 2, j = fi & 3;                                        \
-        const int fl = f & 63, nt_ = (f >> 6) % NT, ch_ = (f >> 6) / NT;                           \
-        const int n_ = nt_ * 16 + (fl & 15), kk = ch_ * 16 + (fl >> 4) * 4 + j;                    \
-        __builtin_amdgcn_global_load_lds(                                                          \
-            (const __attribute__((address_space(1))) void*)(w + ((int64_t)kk * kv + kw_) * CN + n_), \
-            (__attribute__((address_space(3))) void*)(s_b + (SLOT) * BF + fi0), 4, 0, 0);          \
-      }                                                                                            \
-    }                                                                                              \
-  } while (0)
-      static_assert(BWD ? (BF % 256 == 0) : true, "whole 256-byte granules per wave");
-      VC3_DMA_B(k, 0);
-      if (k1 >= 0) VC3_DMA_B(k1, 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      int slot = 0;
-      for (;;) {
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const int k2 = (bmask != 0u) ? (__ffs((int)bmask) - 1) : -1;
-        bmask &= bmask - 1;
-        switch_group(k);
-        const int slot2 = (slot >= 1) ? slot - 1 : 2;  // (slot + 2) % 3
-        if (k2 >= 0) VC3_DMA_B(k2, slot2);
-        mfma_phase(k, slot);
-        if (k1 < 0) break;
-        if (k2 >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        k = k1; k1 = k2; slot = (slot == 2) ? 0 : slot + 1;
-      }
-#undef VC3_DMA_B
-    } else {
-    // W pipeline through registers: the image of offset n+2 is REQUESTED at the top of iteration n (into the register set that
-    // iteration n-1 emptied), and the image of offset n+1 is WRITTEN to its LDS slot at the bottom of iteration n, after this
-    // offset's MFMAs.  (hipcc turns the counted wait in front of that write into vmcnt(0) across the loop back edge, so the
-    // effective flight time is one MFMA phase, as in v2.)  One barrier per offset: it publishes slot p and retires every read
-    // of slot p^1.
-    VC3_LOAD_B(k, bregA);
-    VC3_STORE_B(0, bregA);
-    if (k1 >= 0) VC3_LOAD_B(k1, bregB);
-    int p = 0;
-    for (;;) {
-      // ---- even iteration: request W_{n+2} into set A (emptied at the bottom of iteration n-1), publish W_{n+1} from set B
-      __syncthreads();
-      int k2 = (bmask != 0u) ? (__ffs((int)bmask) - 1) : -1;
-      bmask &= bmask - 1;
-      if (k2 >= 0) VC3_LOAD_B(k2, bregA);
-      switch_group(k);
-      mfma_phase(k, p);
-      if (k1 < 0) break;
-      VC3_STORE_B(p ^ 1, bregB);
-      k = k1; k1 = k2; p ^= 1;
-      // ---- odd iteration: the same with the register sets swapped
-      __syncthreads();
-      k2 = (bmask != 0u) ? (__ffs((int)bmask) - 1) : -1;
-      bmask &= bmask - 1;
-      if (k2 >= 0) VC3_LOAD_B(k2, bregB);
-      switch_group(k);
-      mfma_phase(k, p);
-      if (k1 < 0) break;
-      VC3_STORE_B(p ^ 1, bregA);
-      k = k1; k1 = k2; p ^= 1;
-    }
-    }
-#undef VC3_STORE_B
-#undef VC3_LOAD_B
-#undef VC3_ANALYSE
-#undef VC3_ISSUE
-  }
-
-  if constexpr (EPI == VC_EPI_STATS) {
-    // per-WAVE partial sums (16 rows): rows beyond n_out gathered nothing (exact zeros); fixed order: 4 accumulator rows,
-    // then the q lanes; no LDS, no barrier
-    float* prow = epi.partial + ((lbid * 4 + wave) * 2) * CN;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      float sm = ((acc[nt][0] + acc[nt][1]) + acc[nt][2]) + acc[nt][3];
-      float sq = ((acc[nt][0] * acc[nt][0] + acc[nt][1] * acc[nt][1]) + acc[nt][2] * acc[nt][2]) + acc[nt][3] * acc[nt][3];
-      sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
-      sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
-      const int n = nt * 16 + i;
-      if (q == 0 && n < CN) { prow[n] = sm; prow[CN + n] = sq; }
-    }
-  }
-  float sc[NT], sh[NT];
-  if constexpr (EPI == VC_EPI_AFFINE) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = nt * 16 + i;
-      sc[nt] = 1.f; sh[nt] = 0.f;
-      if (n < CN) {
-        const float istd = 1.0f / sqrtf(epi.var[n] + epi.eps);
-        sc[nt] = (epi.gamma ? epi.gamma[n] : 1.f) * istd;
-        sh[nt] = (epi.beta ? epi.beta[n] : 0.f) - epi.mean[n] * sc[nt];
-      }
-    }
-  }
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n = nt * 16 + i;
-    if (n >= CN) continue;
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int64_t r = brow0 + wave * 16 + q * 4 + reg;
-      float v = acc[nt][reg];
-      if constexpr (EPI == VC_EPI_AFFINE) {
-        v = v * sc[nt] + sh[nt];
-        if (epi.relu) v = fmaxf(v, 0.f);
-      }
-      if (r < n_out) out[r * CN + n] = v;
-    }
-  }
-}
+// The measured-and-rejected gather-GEMM variants (pair-compacted pc, wave-autonomous v4, loader/MFMA roles v5, LDS row windows v3)
+// live in csrc/experiments/ and are compiled only with -DVC_EXPERIMENTS.
+#ifdef VC_EXPERIMENTS
+#include "experiments/conv_pc.inc"
+#include "experiments/conv_v4.inc"
+#include "experiments/conv_v5.inc"
+#include "experiments/conv_v3.inc"
+#endif
 
 // --------------------------------------------------------------------------------------------- K8 weight gradient
 // grid (nsplit, kv); each block owns offset k = blockIdx.y and a contiguous range of output rows.  Each wave scans its
@@ -2445,158 +1281,9 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
   for (int e = threadIdx.x; e < CI * CO; e += 256) dst[e] = red[e];
 }
 
-// --------------------------------------------------------------------------------------------- K8 v2 (dy window in LDS)
-// Round 3.  The weight gradient gathers BOTH operands of every pair -- x[in] and dy[out] -- which is why it sits at 36-43 % of the
-// fp32-MFMA peak although it has no tile padding: per 4 pairs it issues two vector-memory instructions for VA*VB MFMAs, and the
-// CU's one vector-memory pipeline is the pacer.  But dy is not a gather at all: the out rows of a block's
-// row range are CONSECUTIVE, and every offset needs the same ones.  v2 therefore gives a block a row range AND a group of
-// G = 4 * NOFF offsets: the range's dy rows are staged through LDS in windows of WIN rows (coalesced 16-byte loads, once for
-// all G offsets), each of the 4 waves owns NOFF of the group's offsets outright (its accumulators never meet another wave's:
-// no cross-wave reduction, no atomics, fixed order -> bit-stable) and walks ALL rows of the window for them, compacting the
-// active pairs by ballot as v1 does; x rows still come from global memory (one vector load per 4 pairs), dy rows from LDS.
-// Partial sums land in the same [split][k][ci][co] buffer, so the split-N reduce is shared with v1.
-template <int CI, int CO, int NOFF>
-__global__ void __launch_bounds__(256) bwd_weight_v2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                            const int32_t* __restrict__ tbl, int64_t n_out, int kv,
-                                                            int64_t rows_per_block, int nsplit, float* __restrict__ partial) {
-  static_assert(CI % 16 == 0 && CO % 16 == 0, "v2: channel counts multiples of 16");
-  constexpr int VA = CI / 16, VB = CO / 16;
-  constexpr int G = 4 * NOFF;
-  constexpr int WIN = (CO <= 32) ? 256 : 128;          // dy rows per LDS window
-  constexpr int PITCH = CO + 4;                        // floats per staged row (keeps 16-byte alignment, spreads the banks)
-  constexpr int U = (VA * VB >= 8) ? 2 : 4;            // groups of 4 pairs per trip
-  __shared__ __attribute__((aligned(16))) float s_dy[WIN * PITCH];
-  __shared__ int q_in[4][136];
-  __shared__ int q_out[4][136];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = lane & 15, q = lane >> 4;
-  const int ngroups = (kv + G - 1) / G;
-  // block order as v1: the offset-group blocks of one row range are adjacent in launch order and on the same XCD
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int rl = j / ngroups, grp = j - rl * ngroups;
-  const int split = rl * 8 + xcd;
-  if (split >= nsplit) return;
-  const int64_t brow0 = (int64_t)split * rows_per_block;
-  const int64_t bend = min(brow0 + rows_per_block, n_out);
-
-  f32x4 acc[NOFF][VA][VB];
-#pragma unroll
-  for (int t = 0; t < NOFF; ++t)
-#pragma unroll
-    for (int ja = 0; ja < VA; ++ja)
-#pragma unroll
-      for (int jb = 0; jb < VB; ++jb) acc[t][ja][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  int* qi = q_in[wave];
-  int* qo = q_out[wave];
-  for (int64_t win0 = brow0; win0 < bend; win0 += WIN) {
-    const int wrows = (int)min((int64_t)WIN, bend - win0);
-    __syncthreads();   // every wave is done with the previous window
-    for (int e = threadIdx.x; e < wrows * (CO / 4); e += 256) {
-      const int r = e / (CO / 4), c4 = e - r * (CO / 4);
-      *reinterpret_cast<float4*>(&s_dy[r * PITCH + 4 * c4]) = *reinterpret_cast<const float4*>(dy + (win0 + r) * CO + 4 * c4);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < NOFF; ++t) {
-      const int k = grp * G + wave + 4 * t;
-      if (k >= kv) continue;   // wave-uniform
-      int qlen = 0;
-      int v_next = (lane < wrows) ? tbl[(int64_t)k * n_out + win0 + lane] : -1;
-      for (int base = 0; base < wrows; base += 64) {
-        const int lr = base + lane;
-        const int v = v_next;
-        v_next = (lr + 64 < wrows) ? tbl[(int64_t)k * n_out + win0 + lr + 64] : -1;
-        const unsigned long long m = __ballot(v >= 0);
-        if (m != 0ULL) {
-          const int pos = __popcll(m & ((1ULL << lane) - 1ULL));
-          if (v >= 0) { qi[qlen + pos] = v; qo[qlen + pos] = lr; }
-          qlen += __popcll(m);
-          __builtin_amdgcn_wave_barrier();
-        }
-        const bool last = base + 64 >= wrows;
-        int ng = qlen >> 2;
-        if (last && (qlen & 3)) {   // the window's tail group: pad the queue with (row 0, zero weight) by masking below
-          ++ng;
-        }
-        int g = 0;
-        for (; g + U <= ng; g += U) {
-          float a[U][VA], b[U][VB];
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int slot = (g + u) * 4 + q;
-            const bool ok = slot < qlen;
-            const int pin = ok ? qi[slot] : 0, lrow = ok ? qo[slot] : 0;
-            VecLoad<VA>::ld(x + (int64_t)pin * CI + VA * i, a[u]);
-            VecLoad<VB>::ld(&s_dy[lrow * PITCH + VB * i], b[u]);
-            if (!ok) {   // padding slot of a tail group: exact zeros on both sides (0 * inf would be NaN)
-#pragma unroll
-              for (int ja = 0; ja < VA; ++ja) a[u][ja] = 0.f;
-#pragma unroll
-              for (int jb = 0; jb < VB; ++jb) b[u][jb] = 0.f;
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int ja = 0; ja < VA; ++ja)
-#pragma unroll
-              for (int jb = 0; jb < VB; ++jb)
-                acc[t][ja][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][ja], b[u][jb], acc[t][ja][jb], 0, 0, 0);
-        }
-        for (; g < ng; ++g) {
-          const int slot = g * 4 + q;
-          const bool ok = slot < qlen;
-          const int pin = ok ? qi[slot] : 0, lrow = ok ? qo[slot] : 0;
-          float a[VA], b[VB];
-          VecLoad<VA>::ld(x + (int64_t)pin * CI + VA * i, a);
-          VecLoad<VB>::ld(&s_dy[lrow * PITCH + VB * i], b);
-          if (!ok) {
-#pragma unroll
-            for (int ja = 0; ja < VA; ++ja) a[ja] = 0.f;
-#pragma unroll
-            for (int jb = 0; jb < VB; ++jb) b[jb] = 0.f;
-          }
-#pragma unroll
-          for (int ja = 0; ja < VA; ++ja)
-#pragma unroll
-            for (int jb = 0; jb < VB; ++jb)
-              acc[t][ja][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ja], b[jb], acc[t][ja][jb], 0, 0, 0);
-        }
-        // keep the pairs that did not fill a group of 4 (none after the window's last batch: the tail group took them)
-        const int done = last ? qlen : (qlen & ~3);
-        const int rem = qlen - done;
-        int t1 = 0, t2 = 0;
-        if (lane < rem) { t1 = qi[done + lane]; t2 = qo[done + lane]; }
-        __builtin_amdgcn_wave_barrier();
-        if (lane < rem) { qi[lane] = t1; qo[lane] = t2; }
-        qlen = rem;
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-  }
-  // each wave owns its offsets: straight to the partial buffer [split][k][ci][co], ci = VA*m + ja (m = 4q + reg), co = VB*i + jb
-#pragma unroll
-  for (int t = 0; t < NOFF; ++t) {
-    const int k = grp * G + wave + 4 * t;
-    if (k >= kv) continue;
-    float* dst = partial + ((int64_t)split * kv + k) * (CI * CO);
-#pragma unroll
-    for (int ja = 0; ja < VA; ++ja)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int ci = VA * (q * 4 + reg) + ja;
-        if constexpr (VB == 4) {
-          *reinterpret_cast<float4*>(dst + ci * CO + 4 * i) =
-              make_float4(acc[t][ja][0][reg], acc[t][ja][1][reg], acc[t][ja][2][reg], acc[t][ja][3][reg]);
-        } else if constexpr (VB == 2) {
-          *reinterpret_cast<float2*>(dst + ci * CO + 2 * i) = make_float2(acc[t][ja][0][reg], acc[t][ja][1][reg]);
-        } else {
-          dst[ci * CO + i] = acc[t][ja][0][reg];
-        }
-      }
-  }
-}
+#ifdef VC_EXPERIMENTS
+#include "experiments/bwd_weight_v2.inc"
+#endif
 
 // dweight[(co*kv + k)*CI + ci] = sum_s partial[s][k][ci][co]   (fixed order: 4 interleaved partial sums, then 0+1+2+3)
 // 64 consecutive (k, ci, co) elements per block in the partial's native order (coalesced reads), 4 split-groups.
@@ -2679,130 +1366,9 @@ __global__ void __launch_bounds__(256) bwd_weight_reduce_multi_kernel(BwReduceAr
 // deferral list of the calling thread (set by the feature pass around its side-stream weight gradients; NULL = reduce at once)
 static thread_local BwReduceArgs* g_bw_defer = nullptr;
 
-// --------------------------------------------------------------------------------------------- group sum (dup path)
-// Bit-stable group sum.  fp32 atomics would make the result depend on the arrival order of a pixel's rows, so the sum is
-// carried in 64-bit FIXED POINT: integer addition is associative, hence any arrival order gives the same bits.
-//   scale = 2^(40 - exponent(max|dy|))  =>  |q| <= 2^40 per addend, up to 2^22 addends fit in int64, and the quantisation
-//   step is max|dy| * 2^-40 (2^-16 of an fp32 ulp of the largest element): more accurate than fp32 accumulation.
-// thread = (chunk of kGsRows consecutive rows, channel): consecutive rows that share a representative (very common: the
-// voxels outside the camera frustum all clamp onto border pixels) are summed in registers and flushed with ONE atomic
-// per run, which removes almost all same-address contention.
-static constexpr int kGsRows = 32;
-
-__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
-  // <= 512 blocks and ONE atomic per block: thousands of same-address atomics serialise in L2 (70 us measured)
-  __shared__ float red[4];
-  float m = 0.f;
-  const int64_t n4 = n >> 2;
-  const float4* x4 = reinterpret_cast<const float4*>(x);
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 3 * stride < n4; i += 4 * stride) {  // 4 independent 16-byte loads in flight per thread
-    const float4 v0 = x4[i], v1 = x4[i + stride], v2 = x4[i + 2 * stride], v3 = x4[i + 3 * stride];
-    m = fmaxf(m, fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w))));
-    m = fmaxf(m, fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w))));
-    m = fmaxf(m, fmaxf(fmaxf(fabsf(v2.x), fabsf(v2.y)), fmaxf(fabsf(v2.z), fabsf(v2.w))));
-    m = fmaxf(m, fmaxf(fmaxf(fabsf(v3.x), fabsf(v3.y)), fmaxf(fabsf(v3.z), fabsf(v3.w))));
-  }
-  for (; i < n4; i += stride) {
-    const float4 v = x4[i];
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-  }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    if (m > 0.f) atomicMax(out, __float_as_uint(m));  // non-negative floats order like their bit patterns
-  }
-}
-
-__device__ __forceinline__ double gs_scale(unsigned absmax_bits) {
-  const float am = __uint_as_float(absmax_bits);
-  if (!(am > 0.f) || !isfinite(am)) return 0.0;
-  int e;
-  frexpf(am, &e);                 // am = f * 2^e, f in [0.5, 1)
-  return ldexp(1.0, 40 - e);      // |x| * scale < 2^40
-}
-
-__global__ void __launch_bounds__(256) group_sum_fixed_kernel(const float* __restrict__ dy, const int32_t* __restrict__ rep,
-                                                              int64_t n, int c, const unsigned* __restrict__ absmax,
-                                                              long long* __restrict__ acc_out) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t chunk = t / c;
-  const int ch = (int)(t - chunk * c);
-  const int64_t r0 = chunk * kGsRows;
-  if (r0 >= n) return;
-  const double scale = gs_scale(*absmax);
-  const int64_t r1 = min(r0 + (int64_t)kGsRows, n);
-  int cur = rep[r0];
-  if (cur < 0) cur = (int)r0;
-  long long acc = __double2ll_rn((double)dy[r0 * c + ch] * scale);
-  // rows are consumed strictly in order (the run logic is sequential), but their loads are issued 8 at a time: with one
-  // dependent load per iteration the kernel was latency-bound (43 us for 18 MB)
-  int64_t r = r0 + 1;
-  for (; r + 8 <= r1; r += 8) {
-    int g[8];
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      g[u] = rep[r + u];
-      v[u] = dy[(r + u) * c + ch];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int gg = (g[u] < 0) ? (int)(r + u) : g[u];
-      const long long q = __double2ll_rn((double)v[u] * scale);
-      if (gg != cur) {
-        atomicAdd((unsigned long long*)&acc_out[(int64_t)cur * c + ch], (unsigned long long)acc);
-        cur = gg;
-        acc = q;
-      } else {
-        acc += q;
-      }
-    }
-  }
-  for (; r < r1; ++r) {
-    int g = rep[r];
-    if (g < 0) g = (int)r;
-    const long long v = __double2ll_rn((double)dy[r * c + ch] * scale);
-    if (g != cur) {
-      atomicAdd((unsigned long long*)&acc_out[(int64_t)cur * c + ch], (unsigned long long)acc);
-      cur = g;
-      acc = v;
-    } else {
-      acc += v;
-    }
-  }
-  atomicAdd((unsigned long long*)&acc_out[(int64_t)cur * c + ch], (unsigned long long)acc);
-}
-
-__global__ void __launch_bounds__(256) group_sum_convert_kernel(long long* __restrict__ acc, int64_t total, int c,
-                                                                const int32_t* __restrict__ rep,
-                                                                const unsigned* __restrict__ absmax,
-                                                                float* __restrict__ grp, int rezero) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= total) return;
-  // Only REPRESENTATIVE rows carry a group sum (the backward-input conv reads dy_grp at table entries, which are always
-  // representatives, and takes every row's own centre tap from dy): the other rows -- 47-81 % of a 2-D tensor's rows -- are
-  // skipped entirely; nothing was ever added to their accumulators, so they are still zero.
-  const int64_t row = (e < (1LL << 31)) ? (int64_t)((uint32_t)e / (uint32_t)c) : e / c;
-  const int g = rep[row];
-  if (g >= 0 && g != (int)row) return;
-  // the scale is a power of two: multiplying by its exact inverse 2^(e-40) equals the division bit for bit (an fp64 divide per
-  // element made this kernel ALU-bound)
-  const float am = __uint_as_float(*absmax);
-  const long long a = acc[e];
-  // persistent accumulator (prepared = 2): every touched element is read by exactly this thread, which hands it back cleared --
-  // the buffer is all-zero again for the next layer without a memset of 8*N*C bytes (8 of them per train step before)
-  if (rezero) acc[e] = 0;
-  if (!(am > 0.f) || !isfinite(am)) { grp[e] = 0.f; return; }
-  int ex;
-  frexpf(am, &ex);
-  grp[e] = (float)((double)a * ldexp(1.0, ex - 40));
-}
+#ifdef VC_EXPERIMENTS
+#include "experiments/group_sum_fixed.inc"
+#endif
 
 // --------------------------------------------------------------------------------------------- kernel timing (vc_trace_*)
 __global__ void __launch_bounds__(256) count_pairs_kernel(const int32_t* __restrict__ tbl, int64_t total, int64_t* __restrict__ out) {
@@ -3058,6 +1624,7 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
       }
     }
   }
+#ifdef VC_EXPERIMENTS
   if constexpr (!BWD && CK % 16 == 0 && CN % 16 == 0) {
     if (conv_use_pc(CK, CN, kv, n_src, n_out, ot) && rep == nullptr && src_centre == nullptr && !(flags & VC_CONV_SRC_INTERLEAVED) &&
         (epi_kind == VC_EPI_NONE || epi_kind == VC_EPI_STATS || epi_kind == VC_EPI_AFFINE)) {
@@ -3185,6 +1752,8 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
       return VC_OK;
     }
   }
+#endif
+#ifdef VC_EXPERIMENTS
   if constexpr (CK % 16 == 0 && CN % 16 == 0 && !BWD) {
     if (flags & VC_CONV_SRC_INTERLEAVED) {   // round-3 experiment: see the kernel's IL parameter
       if (!(wpk && epi_kind == VC_EPI_NONE && ot == VC_OPERAND_F32 && src_centre == nullptr && kv <= 32 &&
@@ -3201,13 +1770,16 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
       return VC_OK;
     }
   }
+#endif
   if (flags & VC_CONV_SRC_INTERLEAVED) {
-    set_error("gather-GEMM: VC_CONV_SRC_INTERLEAVED is implemented for forward convs with channel counts that are multiples of 16");
+    set_error("gather-GEMM: VC_CONV_SRC_INTERLEAVED is an experiment: forward convs with channel counts that are multiples of 16, library built with -DVC_EXPERIMENTS");
     return VC_EINVAL;
   }
   // dx shift (see the kernel's DXS parameter): SubM-shaped 27-offset tables in natural row order, where it has something to find
+#ifdef VC_EXPERIMENTS
   const bool dxs = g_conv_dxs && wpk != nullptr && kv == 27 && n_src == n_out && order == nullptr && rep == nullptr &&
                    src_centre == nullptr;
+#endif
   if (g_conv_variant == 2 && kv <= 32 && n_src * CK * 4 < (1LL << 31)) {
     constexpr int V = (CK >= 16) ? 4 : CK / 4;
     constexpr int NCH = CK / (4 * V);
@@ -3225,14 +1797,26 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
         size_t lds8 = (size_t)2 * NCH * NT * 64 * V * sizeof(float) + (size_t)(kv + 1) * 128 * sizeof(int) + 16;
         const dim3 grid8((unsigned)cdiv(n_out, 128));
         fin_attach(epi, epi_kind, grid8.x, 8, CN, lds8);
+#ifdef VC_EXPERIMENTS
+#define VC_DXS8(B_, E_)                                                                                                        \
+  if (wpk && dxs) {                                                                                                            \
+    hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, B_, 1, VC_OPERAND_F32, E_, 8, true, true>), grid8, dim3(512), lds8, st, src, \
+                       src_centre, n_src, tbl, wpk, out, rep, order, n_out, kv, centre, mirror, epi);                         \
+    break;                                                                                                                     \
+  }
+#define VC_DXS4(B_, E_)                                                                                                        \
+  if (wpk && dxs) {                                                                                                            \
+    hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, B_, 1, VC_OPERAND_F32, E_, 4, true, true>), grid, dim3(256), lds, st, VC_ARGS_PK); \
+    break;                                                                                                                     \
+  }
+#else
+#define VC_DXS8(B_, E_) do { } while (0)
+#define VC_DXS4(B_, E_) do { } while (0)
+#endif
 #define VC_L8(B_, E_)                                                                                                          \
   do {                                                                                                                         \
     if constexpr (CN % 16 == 0) {                                                                                              \
-      if (wpk && dxs) {                                                                                                        \
-        hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, B_, 1, VC_OPERAND_F32, E_, 8, true, true>), grid8, dim3(512), lds8, st, src, \
-                           src_centre, n_src, tbl, wpk, out, rep, order, n_out, kv, centre, mirror, epi);                     \
-        break;                                                                                                                 \
-      }                                                                                                                        \
+      VC_DXS8(B_, E_);                                                                                                         \
       if (wpk) {                                                                                                               \
         hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, B_, 1, VC_OPERAND_F32, E_, 8, true>), grid8, dim3(512), lds8, st, src, \
                            src_centre, n_src, tbl, wpk, out, rep, order, n_out, kv, centre, mirror, epi);                     \
@@ -3272,10 +1856,7 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
 #define VC_L2(B_, E_)                                                                                                          \
   do {                                                                                                                         \
     if constexpr (CK % 16 == 0 && CN % 16 == 0) {                                                                              \
-      if (wpk && dxs) {                                                                                                        \
-        hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, B_, 1, VC_OPERAND_F32, E_, 4, true, true>), grid, dim3(256), lds, st, VC_ARGS_PK); \
-        break;                                                                                                                 \
-      }                                                                                                                        \
+      VC_DXS4(B_, E_);                                                                                                         \
       if (wpk) {                                                                                                               \
         hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, B_, 1, VC_OPERAND_F32, E_, 4, true>), grid, dim3(256), lds, st, VC_ARGS_PK); \
         break;                                                                                                                 \
@@ -3397,6 +1978,7 @@ static int launch_bw(const float* x, const float* dy, const int32_t* tbl, int64_
   int nsplit;
   int64_t rpb;
   bw_split(n_out, kv, CI, CO, nsplit, rpb);
+#ifdef VC_EXPERIMENTS
   if constexpr (CI % 16 == 0 && CO % 16 == 0) {
     if (g_bw_variant == 2 && ot == VC_OPERAND_F32 && rep == nullptr) {   // v2: dy window in LDS, offsets split over the waves
       constexpr int NOFF = ((CI / 16) * (CO / 16) >= 16) ? 1 : 2;
@@ -3417,6 +1999,7 @@ static int launch_bw(const float* x, const float* dy, const int32_t* tbl, int64_
       return VC_OK;
     }
   }
+#endif
   const unsigned nblocks = g_bw_legacy_order ? (unsigned)(nsplit * kv) : (unsigned)(cdiv(nsplit, 8) * 8 * kv);
 #define VC_ARGS x, dy, tbl, n_out, kv, rpb, nsplit, g_bw_legacy_order, partial, rep, centre, dy_grp
   bool launched = false;
@@ -3485,48 +2068,66 @@ extern "C" {
 int vc_debug_get(const char* key, int64_t* value) {
   VC_REQUIRE(key && value, "vc_debug_get: null argument");
   if (!strcmp(key, "conv_bn_finish_launches")) { *value = (int64_t)g_fin_launches.load(std::memory_order_relaxed); return VC_OK; }
+  if (!strcmp(key, "experiments")) {   // 1: the library carries the measured-and-rejected variants of csrc/experiments/
+#ifdef VC_EXPERIMENTS
+    *value = 1;
+#else
+    *value = 0;
+#endif
+    return VC_OK;
+  }
   set_error("vc_debug_get: unknown key %s", key);
   return VC_EINVAL;
 }
 
-int vc_debug_set(const char* key, int value) {
-  if (key && !strcmp(key, "conv_variant")) { g_conv_variant = value; return VC_OK; }
-  if (key && !strcmp(key, "conv_rt")) { g_conv_rt = value; return VC_OK; }
-  if (key && !strcmp(key, "conv_v4")) { g_conv_v4 = value; return VC_OK; }
-  if (key && !strcmp(key, "conv_autopack")) { g_conv_autopack = value; return VC_OK; }
+// keys that select a measured-and-rejected variant (csrc/experiments/): only a library built with -DVC_EXPERIMENTS has them; the
+// product build accepts their "off" value and rejects anything else, so that tools and tests can tell the two builds apart
+static int experiment_key(const char* key, int value, int off_value, int* slot) {
 #ifdef VC_EXPERIMENTS
-  if (key && !strcmp(key, "conv_v4_ablate")) { g_conv_v4_ablate = value; return VC_OK; }
-  if (key && !strcmp(key, "conv_v4_pf")) { g_conv_v4_pf = value; return VC_OK; }
+  (void)off_value;
+  *slot = value;
+  return VC_OK;
 #else
-  if (key && (!strcmp(key, "conv_v4_ablate") || !strcmp(key, "conv_v4_pf"))) {
-    if (value == (!strcmp(key, "conv_v4_pf") ? 1 : 0)) return VC_OK;   // the default build has only the shipped schedule
-    set_error("vc_debug_set %s = %d: build the library with -DVC_EXPERIMENTS (VIRCONV_HIPCC_EXTRA) for the v4 experiment variants", key, value);
-    return VC_EINVAL;
-  }
+  (void)slot;
+  if (value == off_value) return VC_OK;
+  set_error("vc_debug_set %s = %d: an experiment variant; build the library with -DVC_EXPERIMENTS (VIRCONV_HIPCC_EXTRA)", key, value);
+  return VC_EINVAL;
 #endif
-  if (key && !strcmp(key, "conv_v5")) { g_conv_v5 = value; return VC_OK; }
-  if (key && !strcmp(key, "conv_dxs")) { g_conv_dxs = value; return VC_OK; }
-  if (key && !strcmp(key, "conv_packed")) { g_conv_use_packed = value; return VC_OK; }
-  if (key && !strcmp(key, "conv_window")) { g_conv_window = value; return VC_OK; }
-  if (key && !strcmp(key, "conv_nw")) { g_conv_nw = (value == 8 || value == 4) ? value : 0; return VC_OK; }
-  if (key && !strcmp(key, "conv_wdma")) { g_conv_wdma = value; return VC_OK; }
-  if (key && !strcmp(key, "conv_winrows")) { g_conv_winrows = value; return VC_OK; }
-  if (key && !strcmp(key, "bw_legacy_order")) { g_bw_legacy_order = value; return VC_OK; }
-  if (key && !strcmp(key, "bw_variant")) { g_bw_variant = value; return VC_OK; }
-  if (key && !strcmp(key, "bw_rows_per_split")) { if (value >= 256) g_bw_rows_per_split = value; return VC_OK; }
-  if (key && !strcmp(key, "pass_dw_main_tail")) { g_pass_dw_main_tail = value; return VC_OK; }
-  if (key && !strcmp(key, "pass_bwd_epilogue")) { g_pass_bwd_epilogue = value; return VC_OK; }
-  if (key && !strcmp(key, "pass_fork_ext_event")) { g_pass_fork_ext_event = value; return VC_OK; }
-  if (key && !strcmp(key, "bn_fused_partial")) { g_bn_fused_partial = value; return VC_OK; }
-  if (key && !strcmp(key, "conv_bn_finish")) { g_conv_bn_finish = value; return VC_OK; }
-  if (key && !strcmp(key, "conv_pc")) { g_conv_pc = value; return VC_OK; }
-  if (key && !strcmp(key, "conv_pc_ablate"))
+}
+
+int vc_debug_set(const char* key, int value) {
+  VC_REQUIRE(key, "vc_debug_set: null key");
+  if (!strcmp(key, "conv_variant")) { g_conv_variant = value; return VC_OK; }
+  if (!strcmp(key, "conv_rt")) { g_conv_rt = value; return VC_OK; }
+  if (!strcmp(key, "conv_autopack")) { g_conv_autopack = value; return VC_OK; }
+  if (!strcmp(key, "conv_v4")) return experiment_key(key, value, 0, &g_conv_v4);
+  if (!strcmp(key, "conv_v4_ablate")) return experiment_key(key, value, 0, &g_conv_v4_ablate);
+  if (!strcmp(key, "conv_v4_pf")) return experiment_key(key, value, 1, &g_conv_v4_pf);
+  if (!strcmp(key, "conv_v5")) return experiment_key(key, value, 0, &g_conv_v5);
+  if (!strcmp(key, "conv_dxs")) return experiment_key(key, value, 0, &g_conv_dxs);
+  if (!strcmp(key, "conv_pc")) return experiment_key(key, value, 0, &g_conv_pc);
+  if (!strcmp(key, "conv_wdma")) return experiment_key(key, value, 0, &g_conv_wdma);
+  if (!strcmp(key, "conv_winrows")) return experiment_key(key, value, 32, &g_conv_winrows);
+  if (!strcmp(key, "bw_variant")) return experiment_key(key, value, 1, &g_bw_variant);
+  if (!strcmp(key, "conv_packed")) { g_conv_use_packed = value; return VC_OK; }
+  if (!strcmp(key, "conv_window")) { g_conv_window = value; return VC_OK; }
+  if (!strcmp(key, "conv_nw")) { g_conv_nw = (value == 8 || value == 4) ? value : 0; return VC_OK; }
+  if (!strcmp(key, "bw_legacy_order")) { g_bw_legacy_order = value; return VC_OK; }
+  if (!strcmp(key, "bw_rows_per_split")) { if (value >= 256) g_bw_rows_per_split = value; return VC_OK; }
+  if (!strcmp(key, "pass_dw_main_tail")) { g_pass_dw_main_tail = value; return VC_OK; }
+  if (!strcmp(key, "pass_bwd_epilogue")) { g_pass_bwd_epilogue = value; return VC_OK; }
+  if (!strcmp(key, "pass_fork_ext_event")) { g_pass_fork_ext_event = value; return VC_OK; }
+  if (!strcmp(key, "bn_fused_partial")) { g_bn_fused_partial = value; return VC_OK; }
+  if (!strcmp(key, "conv_bn_finish")) { g_conv_bn_finish = value; return VC_OK; }
+  if (!strcmp(key, "pass_defer_dw_reduce")) { g_pass_defer_dw_reduce = value; return VC_OK; }
+#ifdef VC_EXPERIMENTS
+  if (!strcmp(key, "conv_pc_ablate"))
     return hipMemcpyToSymbol(HIP_SYMBOL(g_pc_ablate), &value, sizeof(int)) == hipSuccess ? VC_OK : VC_EHIP;
-  if (key && !strcmp(key, "pass_defer_dw_reduce")) { g_pass_defer_dw_reduce = value; return VC_OK; }
-  if (key && !strcmp(key, "xcd_swizzle_off")) {
+#endif
+  if (!strcmp(key, "xcd_swizzle_off")) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_swizzle_off), &value, sizeof(int)) == hipSuccess ? VC_OK : VC_EHIP;
   }
-  set_error("vc_debug_set: unknown key");
+  set_error("vc_debug_set: unknown key %s", key);
   return VC_EINVAL;
 }
 
@@ -3775,6 +2376,7 @@ static int conv_backward_weight_impl(const float* x, const float* dy, const int3
   return rc;
 }
 
+#ifdef VC_EXPERIMENTS   // order-free 64-bit fixed-point group sum of rounds 1-2 (csrc/experiments/group_sum_fixed.inc); not in the header
 size_t vc_group_sum_workspace_bytes(int64_t n, int c) {
   if (n < 0 || c < 1) return 0;
   return (size_t)n * c * sizeof(long long) + 64;
@@ -3812,5 +2414,7 @@ int vc_group_sum(const float* dy, const int32_t* rep, int64_t n, int c, float* d
   VC_CHECK_LAUNCH("group_sum_convert_kernel");
   return VC_OK;
 }
+
+#endif
 
 }  // extern "C"

@@ -352,7 +352,13 @@ int vc_debug_stop_event_dependency(int32_t* buf, int32_t* out, int64_t n, int sp
 
 size_t vc_weighted_sum_workspace_bytes(int64_t nb, int64_t e) {
   if (nb < 1 || e < 4) return 0;
-  return ((size_t)kWsMaxBlocks + (size_t)(nb > kWsMaxBlocks ? 0 : nb)) * sizeof(double) + 256;
+  // one fp64 partial per block of the launch: the grid of weighted_sum_grid (mode 0 with more than kWsMaxBlocks samples launches
+  // one block per sample, i.e. MORE than kWsMaxBlocks partials)
+  int mode;
+  dim3 grid;
+  weighted_sum_grid(nb, e, mode, grid);
+  const size_t blocks = (size_t)grid.x * grid.y;
+  return (blocks > (size_t)kWsMaxBlocks ? blocks : (size_t)kWsMaxBlocks) * sizeof(double) + 256;
 }
 
 int vc_weighted_sum(const float* x, int64_t nb, int64_t e, const float* g, float* out, void* ws, size_t ws_bytes, void* stream) {

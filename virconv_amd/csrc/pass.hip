@@ -259,7 +259,17 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
     return vc_conv_backward_weight_workspace_bytes(t_.n_out, t_.kv, u_.cin, u_.cout);
   };
   if (!dry) bw_defer_begin();
-  struct DeferOff { ~DeferOff() { bw_defer_enable(false); } } defer_off_on_exit;
+  // whatever path leaves this function (error returns included): no armed stop-event slot, no deferral, and no queued split-N
+  // reductions survive it -- a later direct call on this thread (vc_bn_relu_backward, vc_group_sum_sorted) must not bind its
+  // launch to this sweep's event, and a failed sweep must not leave its reductions for the next one
+  struct SweepGuard {
+    bool dry;
+    ~SweepGuard() {
+      t_stop_event = StopEventSlot{};
+      bw_defer_enable(false);
+      if (!dry) bw_defer_begin();
+    }
+  } sweep_guard_on_exit{dry};
   std::vector<std::vector<GradView>> contrib(p->n_bufs);
   std::vector<int> state(p->n_bufs, 0);  // 0 unresolved, 1 resolved to `res`, 2 no gradient reaches the buffer
   std::vector<GradView> res(p->n_bufs);

@@ -242,6 +242,13 @@ def _fill(P: _Program, feats, ctx, training: bool) -> Optional[_Call]:
     keeps = [g(ctx) for g in P.keep_getters]
     if any(rb.n_out <= 0 or rb.n_in <= 0 for rb in tables) or any(k is None or k.shape[0] == 0 for k in keeps):
         return None
+    if training:
+        # a duplicate-pixel table built under no_grad (a cached indice_dict entry, checkpoint-style recompute) has no group plan
+        # yet; vc_pass_backward needs it: build it now and keep it on the rulebook
+        be = ops.get_backend()
+        for rb in tables:
+            if rb.rep is not None and rb.grp_plan is None:
+                rb.grp_plan = be.group_plan(rb.rep)
     c_tables = (_lib.PassTable * len(tables))()
     for i, rb in enumerate(tables):
         t = c_tables[i]

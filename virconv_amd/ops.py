@@ -305,13 +305,7 @@ class ConvBNReLUFunction(torch.autograd.Function):
                 x, weight, y_raw, wide, col0, mean, var, gamma, beta, eps, relu, tbl_w, tbl_dx, n_dx, mirror, centre, rep,
                 rb.grp_plan if rep is not None else None, order_dx, MFMA_OPERAND, rb.sorted_rows and rb.kind == "subm" and not inverse, need_dx, need_dw)
             return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None
-        if (rb.rep is not None and rb.grp_plan is None and not ctx.inverse and rb.kind == "subm" and need_dx
-                and hasattr(be, "group_sum_prepare") and y_raw.is_cuda
-                and (y_raw.shape[1] & (y_raw.shape[1] - 1)) == 0):
-            # duplicate-pixel conv: its backward group-sums d_raw in fixed point and needs max|d_raw|; the BN backward
-            # kernel that writes d_raw leaves it in the (pre-zeroed) group-sum workspace: one pass over d_raw less
-            gws = be.group_sum_prepare(y_raw.shape[0], y_raw.shape[1], y_raw.device)
-        d_raw, dgamma, dbeta = be.bn_backward(y_raw, wide, col0, mean, var, gamma, beta, eps, relu, absmax_ws=gws)
+        d_raw, dgamma, dbeta = be.bn_backward(y_raw, wide, col0, mean, var, gamma, beta, eps, relu)
         dx, dw = _conv_backward(rb, ctx.inverse, x, weight, d_raw, need_dx, need_dw, group_ws=gws)
         return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, None
 
