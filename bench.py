@@ -484,6 +484,19 @@ def main():
                 else:
                     cur_b = max(cur_b, b)
             union += cur_b - cur_a
+            # the kernel shape with the largest share of the step's conv kernel time, so that the traced kernel's `frac` cannot be
+            # read as "the step runs at that fraction" 
+            by_shape = {}
+            for e in fam:
+                kname = (f"bwd_weight_kernel<{e['ck']},{e['cn']}>" if e["dir"] == "dw" else
+                         f"gather_gemm_v2_kernel<{e['ck']},{e['cn']},{'bwd' if e['dir'] == 'bwd' else 'fwd'}>")
+                d = by_shape.setdefault(kname, [0.0, 0.0, 0])
+                d[0] += e["flops"]; d[1] += e["ms"]; d[2] += 1
+            dom_name, dom = max(by_shape.items(), key=lambda kv_: kv_[1][1])
+            roof["dominant_by_time"] = {"kernel": dom_name, "ms_per_step": round(dom[1] / k, 3), "launches_per_step": round(dom[2] / k, 1),
+                                        "frac": round(dom[0] / (dom[1] * 1e-3) / 1e12 / peak, 4),
+                                        "note": "largest ms/step row of the conv family (in-step durations: the weight gradients and the "
+                                                "backward-input convs share the chip, so each is slower than stand-alone)"}
             roof.update({
                 "family_frac": round(f_flops / (union * 1e-3) / 1e12 / peak, 4),
                 "family_tflops": round(f_flops / (union * 1e-3) / 1e12, 2),

@@ -518,6 +518,77 @@ size_t vc_nms_workspace_bytes(int64_t n);
 int vc_nms(const float* boxes, int64_t n, float thresh, int rotated, int64_t* keep, int64_t* num_out, void* ws, size_t ws_bytes,
            void* stream);
 
+/* ------------------------------------------------------------------------------------------------ geometry plan
+ * Every index structure of a chain of NRConvBlocks (spconv_backbone.py:150-229) -- per block: the strided-conv rulebook of its
+ * down_layer (:164-171) with the block's output coordinates, the 3-D SubM rulebook shared by d3_conv1/2 (:186,199), the pixel
+ * coordinates of index2uv (:54-83, :214-216), the 2-D SubM rulebook shared by d2_conv1/2 over the duplicate pixel coordinates
+ * (:217-222) with its representatives and group plan, the rows layer_voxel_discard keeps (:134-147) -- plus the strided conv
+ * that follows the chain (conv_out, :561-567), built by TWO calls around ONE host read.  In the reference this is what spconv's
+ * indice generation does conv by conv inside VirConvL8x.forward (:609-699), with one device-to-host sync per strided conv.
+ *
+ *   vc_plan_begin   enqueues, with every row count still on the device: for each level the output-cell bitmap, its scan, the
+ *                   coordinate emission (row CAPACITY buffers) and the layer discard's keep / kept coordinates; every table of a
+ *                   first block that has no strided conv (its row count is the caller's); then the counts' copy to
+ *                   `host_counts` (pinned host memory, >= 64 int32) and an event.
+ *   vc_plan_wait    polls that event; checks injected keeps against the counts.  The ONE host synchronisation of the plan.
+ *   vc_plan_finish  enqueues every remaining table with exact row counts into `arena_b`.
+ * Host-side composition of the operators above plus index kernels that exploit what the chain knows (plan.hip): the coordinates
+ * of a strided conv's output are the set bits of its bitmap in ascending order, so the SubM rulebook of that tensor ranks
+ * neighbours in the SAME bitmap (no hash build); the pixel tensors index a dense per-sample image (no hash build, 6x fewer
+ * bytes to clear); the backward row order of a strided table is a counting sort on the stride-parity class of the input
+ * coordinate (no pass over the 27-row table); the group plan is a hand-written two-pass LDS radix sort.  Tables are bit-identical
+ * to vc_subm_rulebook / vc_spconv_emit_pairs / vc_group_plan on the same coordinates (tests); row orders are hints.
+ * The caller owns both arenas; `vc_plan_out` reports every structure as (arena, byte offset, rows, cols).                  */
+#define VC_PLAN_MAX_BLOCKS 8
+typedef struct vc_plan_conv { int32_t ksize[3], stride[3], padding[3], dilation[3]; } vc_plan_conv;
+typedef struct vc_plan_block {
+  int32_t has_down;                         /* a strided conv (down_layer) in front of the block */
+  vc_plan_conv down;
+  int32_t subm_ksize[3], subm_dilation[3];  /* the 3-D SubM rulebook shared by d3_conv1 / d3_conv2 */
+  int32_t has_2d;                           /* image-space branch: index2uv + the shared 2-D SubM rulebook */
+  int32_t uv_stride;                        /* index2uv stride of the block: 1 / 2 / 4 / 8 */
+  int32_t ksize2d[2], dilation2d[2];
+  int32_t discard;                          /* layer_voxel_discard after the block */
+  uint64_t keep_seed;                       /* discard, keep == NULL: rows = vc_random_keep(n, int(n * (1 - rate)), keep_seed) */
+  const int64_t* keep;                      /* injected kept rows (device int64) or NULL */
+  int64_t keep_rows;
+} vc_plan_block;
+typedef struct vc_plan_desc {
+  const int32_t* indices; int64_t n;        /* (n, 4) int32 [b, z, y, x] */
+  int32_t batch_size; int32_t spatial_shape[3];
+  const float* calib; const float* trans;   /* (B, 33) | (B, 3) or NULL, as vc_project_prepare */
+  int32_t image_shape[2];                   /* spatial shape of the 2-D tensors ([1600, 600], spconv_backbone.py:220) */
+  int32_t input_discard; uint64_t input_keep_seed; const int64_t* input_keep; int64_t input_keep_rows;  /* discard of the chain's input (VirConv8x MM stream, :488-489) */
+  int32_t n_blocks; vc_plan_block blocks[VC_PLAN_MAX_BLOCKS];
+  int32_t has_tail; vc_plan_conv tail;
+  double discard_rate;
+  int32_t need_grad;                        /* also build what only a backward pass needs: group plans, backward row orders */
+  int32_t row_order_fwd;                    /* 1: also a row order for the strided convs' FORWARD tables */
+} vc_plan_desc;
+typedef struct vc_plan_view { int32_t arena /* 0: arena_a, 1: arena_b, -1: absent */; int32_t cols; int64_t offset /* bytes */; int64_t rows; } vc_plan_view;
+typedef struct vc_plan_table_out {
+  vc_plan_view pair_fwd, pair_bwd, rep, order_fwd, order_bwd, grp_plan, in_indices, out_indices;
+  int64_t n_in, n_out; int32_t kv, present; int32_t out_shape[3], pad_;
+} vc_plan_table_out;
+typedef struct vc_plan_block_out {
+  vc_plan_table_out down, subm3d, subm2d;
+  vc_plan_view uv, keep, kept_indices;
+  int64_t n, n_keep;
+} vc_plan_block_out;
+typedef struct vc_plan_out {
+  vc_plan_view input_keep, input_kept_indices; int64_t n_input_kept;
+  vc_plan_block_out blocks[VC_PLAN_MAX_BLOCKS];
+  vc_plan_table_out tail;
+} vc_plan_out;
+typedef struct vc_plan_state { int64_t opaque[2048]; } vc_plan_state;   /* caller-held, written by vc_plan_begin */
+size_t vc_plan_begin_arena_bytes(const vc_plan_desc* desc);
+int vc_plan_begin(const vc_plan_desc* desc, void* arena_a, size_t arena_a_bytes, int32_t* host_counts, vc_plan_state* state,
+                  void* stream);
+int vc_plan_wait(const vc_plan_desc* desc, vc_plan_state* state);
+size_t vc_plan_finish_arena_bytes(const vc_plan_desc* desc, const vc_plan_state* state);
+int vc_plan_finish(const vc_plan_desc* desc, vc_plan_state* state, void* arena_a, void* arena_b, size_t arena_b_bytes,
+                   vc_plan_out* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -766,6 +766,8 @@ def _sorted_scene(seed=41, bs=2):
 def test_window_gather_gemm_is_bit_identical_to_the_direct_kernel_and_matches_the_oracle(hip_backend, cin, cout):
     """VC_CONV_SORTED_ROWS (LDS row windows, per-wave, with the direct-gather fall-back for runs that do not fit) is a pure
     scheduling choice: forward and backward-input are bit-identical to the direct kernel, and within 1e-4 of the oracle."""
+    from conftest import require_experiments
+    require_experiments(hip_backend)   # the LDS row-window kernel (v3) lives in csrc/experiments/ since round 4
     rng = np.random.default_rng(100 * cin + cout)
     idx, shape = _sorted_scene()
     n = idx.shape[0]
@@ -795,6 +797,8 @@ def test_window_gather_gemm_is_bit_identical_to_the_direct_kernel_and_matches_th
 def test_window_gather_gemm_hint_is_safe_on_any_table(hip_backend, case):
     """The hint is only a hint: row orders that give no contiguous runs (every (tile, group) falls back to direct gathers),
     1 / 15 / 65 rows, 2-D (KV = 9) and (3,1,1) (KV = 3) kernels, a strided conv's table -- always the direct kernel's bits."""
+    from conftest import require_experiments
+    require_experiments(hip_backend)   # the LDS row-window kernel (v3) lives in csrc/experiments/ since round 4
     rng = np.random.default_rng(7)
     cin, cout = 32, 32
     if case in ("permuted", "tiny", "ragged"):
@@ -838,6 +842,8 @@ def test_window_gather_gemm_hint_is_safe_on_any_table(hip_backend, case):
 def test_window_gather_gemm_epilogues(hip_backend, cin, cout):
     """BatchNorm epilogues of the window kernel: per-WAVE partial statistics (no barrier) feed the same mean / var as the
     pass over y; the folded eval-mode BN(+ReLU) equals conv-then-BN."""
+    from conftest import require_experiments
+    require_experiments(hip_backend)   # the LDS row-window kernel (v3) lives in csrc/experiments/ since round 4
     rng = np.random.default_rng(cin + 7 * cout)
     idx, shape = _sorted_scene(45, 1)
     n = idx.shape[0]
@@ -890,6 +896,8 @@ def test_backbone_marks_sorted_tables_and_uses_the_window_kernel(hip_backend, mo
 def test_window_gather_gemm_pipeline_variants_keep_the_bits(hip_backend, wdma, winrows, cin, cout):
     """The experiment switches of the window kernel (W images through the LDS-DMA engine; 24-row windows) are scheduling
     variants: forward and backward-input stay bit-identical to the direct kernel, on sorted and on permuted tables."""
+    from conftest import require_experiments
+    require_experiments(hip_backend)   # the LDS row-window kernel (v3) lives in csrc/experiments/ since round 4
     rng = np.random.default_rng(cin * 3 + cout + wdma)
     idx, shape = _sorted_scene(47, 1)
     lib = hip_backend.lib

@@ -1,0 +1,205 @@
+"""Native geometry plan (vc_plan_begin / vc_plan_wait / vc_plan_finish, csrc/plan.hip, virconv_amd/native_plan.py) against the
+operator-by-operator plan of round 3 (backbone._plan_nrconv_chain over vc_hash_build / vc_subm_rulebook / vc_spconv_* /
+vc_project_uv / vc_group_plan), which is itself pinned bit-exactly to the oracle (tests/test_ops_gpu.py).
+
+Reference semantics: the indice generation behind every conv of VirConvL8x.forward (pcdet/models/backbones_3d/
+spconv_backbone.py:609-699; NRConvBlock :150-229; layer_voxel_discard :134-147; conv_out :561-567).  Integer work: every table,
+coordinate list, pixel list, representative list, group plan and keep list must be BIT-IDENTICAL; row orders are scheduling hints
+(checked to be permutations that stay inside their 2048-row window and group the rows they are meant to group)."""
+import numpy as np
+import pytest
+import torch
+
+import bench
+from helpers import GRID, MODEL_CFG, golden_batch, load_golden
+from virconv_amd import native_plan, ops, synth
+from virconv_amd.backbone import VirConvL8x
+
+pytestmark = pytest.mark.gpu
+
+
+def _rb_tensors(rb):
+    return {"pair_fwd": rb.pair_fwd, "pair_bwd": rb.pair_bwd, "rep": rb.rep, "grp_plan": rb.grp_plan, "in": rb.in_indices,
+            "out": rb.out_indices}
+
+
+def _assert_same_plan(pn, pp, where=""):
+    assert torch.equal(pn["in_indices"], pp["in_indices"])
+    assert len(pn["stages"]) == len(pp["stages"])
+    for si, (sn, sp) in enumerate(zip(pn["stages"], pp["stages"])):
+        tag = f"{where} stage {si}"
+        assert list(sn["out_shape"]) == list(sp["out_shape"]), tag
+        assert torch.equal(sn["out_indices"], sp["out_indices"]), tag
+        assert torch.equal(sn["uv"], sp["uv"]), tag
+        assert (sn["keep"] is None) == (sp["keep"] is None), tag
+        if sn["keep"] is not None:
+            assert torch.equal(sn["keep"], sp["keep"]) and torch.equal(sn["kept_indices"], sp["kept_indices"]), tag
+        for group in ("rb3d", "rb2d"):
+            assert sn[group].keys() == sp[group].keys(), tag
+            for key in sn[group]:
+                _assert_same_rulebook(sn[group][key], sp[group][key], f"{tag} {key}")
+    assert pn["conv_out"].keys() == pp["conv_out"].keys()
+    for key in pn["conv_out"]:
+        _assert_same_rulebook(pn["conv_out"][key], pp["conv_out"][key], f"{where} conv_out")
+
+
+def _assert_same_rulebook(a, b, tag):
+    assert (a.kind, a.n_in, a.n_out, tuple(a.in_shape), tuple(a.out_shape), tuple(a.ksize), tuple(a.stride), tuple(a.padding),
+            tuple(a.dilation)) == (b.kind, b.n_in, b.n_out, tuple(b.in_shape), tuple(b.out_shape), tuple(b.ksize), tuple(b.stride),
+                                   tuple(b.padding), tuple(b.dilation)), tag
+    ta, tb = _rb_tensors(a), _rb_tensors(b)
+    for name in ta:
+        assert (ta[name] is None) == (tb[name] is None), f"{tag}: {name} presence"
+        if ta[name] is not None:
+            assert ta[name].shape == tb[name].shape and torch.equal(ta[name], tb[name]), f"{tag}: {name} differs"
+    for name in ("order_fwd", "order_bwd"):
+        oa, ob = getattr(a, name), getattr(b, name)
+        assert (oa is None) == (ob is None), f"{tag}: {name} presence"
+        if oa is not None:
+            n = oa.shape[0]
+            assert n == ob.shape[0]
+            o = oa.long().cpu().numpy()
+            assert np.array_equal(np.sort(o), np.arange(n)), f"{tag}: {name} is not a permutation"
+            assert np.array_equal(o // 2048, np.arange(n) // 2048), f"{tag}: {name} leaves its 2048-row window"
+
+
+def _plans(model, batch, monkeypatch, seed=5):
+    """(native plan, operator-by-operator plan) of the same model / batch / torch seed."""
+    bd = dict(batch)
+    calib = bd["calib"] if torch.is_tensor(bd["calib"]) else ops.calib_tensor(bd["calib"], bd["voxel_coords"].device)
+    out = []
+    for native in (True, False):
+        monkeypatch.setattr(native_plan, "NATIVE_PLAN", native)
+        torch.manual_seed(seed)
+        p = model.build_plan(bd["voxel_coords"], bd["batch_size"], calib, bd.get("aug_param"), bd)
+        torch.cuda.synchronize()
+        assert ("_arenas" in p) == native
+        out.append(p)
+    return out
+
+
+@pytest.mark.parametrize("mode", ["train_random_keep", "train_noop_discard", "eval"])
+def test_native_plan_equals_the_operator_by_operator_plan_small(hip_backend, monkeypatch, mode):
+    g = load_golden()
+    batch = golden_batch(g, "cuda")
+    cfg = dict(MODEL_CFG, LAYER_DISCARD_MODE="spconv1_inplace" if mode == "train_random_keep" else "spconv2_noop")
+    model = VirConvL8x(cfg, 8, GRID).cuda()
+    model.train(mode != "eval")
+    with torch.set_grad_enabled(mode != "eval"):
+        pn, pp = _plans(model, batch, monkeypatch)
+    _assert_same_plan(pn, pp, mode)
+
+
+@pytest.mark.parametrize("frames,inject", [([0, 1], False), ([0, 1, 2, 3], True), ([3], False)])
+def test_native_plan_equals_the_operator_by_operator_plan_full_size(hip_backend, monkeypatch, frames, inject):
+    """KITTI-sized synthetic frames (the bench batch for [0, 1, 2, 3]), layer discard on; `inject`: the keeps are injected
+    permutation prefixes instead of drawn ones (the row counts they need come from a first plan)."""
+    dev = torch.device("cuda", 0)
+    batch = bench.make_batch(frames, dev, training=True)
+    model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).cuda().train()
+    if inject:   # the keeps of a first (drawn) plan, injected into both routes as the tests / benchmarks do
+        monkeypatch.setattr(native_plan, "NATIVE_PLAN", False)
+        torch.manual_seed(3)
+        p0 = model.build_plan(batch["voxel_coords"], len(frames), batch["calib"], batch["aug_param"], batch)
+        batch["layer_discard_keep"] = {f"x_conv{bi + 1}": p0["stages"][bi]["keep"].flip(0).cpu() for bi in range(3)}
+    pn, pp = _plans(model, batch, monkeypatch)
+    _assert_same_plan(pn, pp, f"frames {frames}")
+    # the strided backward row orders of the native plan group the rows by stride-residue class inside every window: rows of one
+    # class have identical active-offset sets away from the grid border, which is what the order is for
+    for si in (1, 2, 3):
+        rb = [r for r in pn["stages"][si]["rb3d"].values() if r.kind == "sparse"][0]
+        o = rb.order_bwd.long()
+        c = rb.in_indices.long()[o]
+        cls = (((c[:, 1] + rb.padding[0]) % rb.stride[0]) * rb.stride[1] + ((c[:, 2] + rb.padding[1]) % rb.stride[1])) * rb.stride[2] + \
+              ((c[:, 3] + rb.padding[2]) % rb.stride[2])
+        win = torch.arange(o.shape[0], device=o.device) // 2048
+        key = win * 64 + cls
+        assert bool((key[1:] >= key[:-1]).all()), "rows of a window are not grouped by residue class"
+        same = key[1:] == key[:-1]
+        assert bool((o[1:][same] > o[:-1][same]).all()), "the order is not stable inside a class"
+
+
+@pytest.mark.parametrize("key", ["plan_subm_bitmap", "plan_image_2d", "plan_radix_sort", "plan_parity_order"])
+def test_plan_kernel_switches_do_not_change_any_table(hip_backend, monkeypatch, key):
+    """Every chain-aware index kernel has the generic operator as its A/B alternative (vc_debug_set): same tables either way."""
+    dev = torch.device("cuda", 0)
+    batch = bench.make_batch([0, 1], dev, training=True)
+    model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).cuda().train()
+    monkeypatch.setattr(native_plan, "NATIVE_PLAN", True)
+    lib = hip_backend.lib
+    plans = []
+    try:
+        for v in (1, 0):
+            assert lib.vc_debug_set(key.encode(), v) == 0
+            torch.manual_seed(11)
+            plans.append(model.build_plan(batch["voxel_coords"], 2, batch["calib"], batch["aug_param"], batch))
+            torch.cuda.synchronize()
+    finally:
+        assert lib.vc_debug_set(key.encode(), 1) == 0
+    _assert_same_plan(plans[0], plans[1], key)
+
+
+@pytest.mark.parametrize("n,groups", [(1, 1), (63, 5), (4096, 4096), (4097, 300), (70001, 9000), (310351, 60000), (200000, 3),
+                                      (2100000, 500000)])
+def test_group_plan_radix_sort_is_the_stable_sort_by_representative(hip_backend, n, groups):
+    """vc_group_plan's hand-written two-pass LDS radix sort (group_kernels.hip; three launches) against a stable argsort and against
+    the rocPRIM route (vc_debug_set plan_radix_sort = 0); the last case is beyond 512 tiles and takes rocPRIM either way."""
+    rng = np.random.default_rng(n + groups)
+    dev = torch.device("cuda", 0)
+    rep_groups = rng.integers(0, groups, n)
+    last = np.full(groups, -1, np.int64)
+    last[rep_groups] = np.arange(n)            # later rows overwrite: the highest row of each group = its representative
+    rep_np = last[rep_groups].astype(np.int32)
+    if n > 100:
+        rep_np[::17] = -1                      # "own representative" marker of some tables: key = the row itself
+    rep = torch.from_numpy(rep_np).to(dev)
+    keys = np.where(rep_np < 0, np.arange(n), rep_np)
+    order = np.argsort(keys, kind="stable")
+    lib = hip_backend.lib
+    got = hip_backend.group_plan(rep)
+    assert np.array_equal(got[0].cpu().numpy(), order) and np.array_equal(got[1].cpu().numpy(), keys[order])
+    for _ in range(2):
+        assert torch.equal(hip_backend.group_plan(rep), got)
+    try:
+        assert lib.vc_debug_set(b"plan_radix_sort", 0) == 0
+        assert torch.equal(hip_backend.group_plan(rep), got)
+    finally:
+        assert lib.vc_debug_set(b"plan_radix_sort", 1) == 0
+
+
+def test_train_step_with_the_native_plan_matches_the_operator_by_operator_plan(hip_backend, monkeypatch):
+    """Whole bench train step: with the residue-class row order switched off the two plans hold identical structures, so loss,
+    outputs and every gradient are BIT-identical; with it on (the default) only the tile composition of the strided
+    backward-input convs changes -- the BatchNorm-backward sums formed in their epilogue re-associate: <= 1e-5 of max."""
+    dev = torch.device("cuda", 0)
+    batch = bench.make_batch([0, 1], dev, training=True)
+    lw = bench.make_loss_weights(dev)
+    lib = hip_backend.lib
+
+    def run(native, parity):
+        monkeypatch.setattr(native_plan, "NATIVE_PLAN", native)
+        assert lib.vc_debug_set(b"plan_parity_order", parity) == 0
+        torch.manual_seed(0)
+        model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).cuda().train()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, fused=True)
+        torch.manual_seed(77)
+        opt.zero_grad(set_to_none=True)
+        bd = dict(batch)
+        bd["voxel_features"] = batch["voxel_features"].clone()
+        out = model(bd)
+        loss = bench.synthetic_loss(out, lw)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss), {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    try:
+        l_py, g_py = run(False, 1)
+        l_n0, g_n0 = run(True, 0)
+        l_n1, g_n1 = run(True, 1)
+    finally:
+        assert lib.vc_debug_set(b"plan_parity_order", 1) == 0
+    assert l_py == l_n0 == l_n1
+    for k in g_py:
+        assert torch.equal(g_py[k], g_n0[k]), k
+        scale = float(g_py[k].abs().max()) + 1e-30
+        assert float((g_py[k] - g_n1[k]).abs().max()) <= 1e-5 * scale, k

@@ -30,7 +30,7 @@ for step in "$@"; do
     bench40) timeout 300 python bench.py $BENCH40 > "$D/bench40.log" 2>&1; line "$D/bench40.log" ;;
     benchenv)
       f="$D/bench40_$(echo "$arg" | tr -c 'A-Za-z0-9_=\n' '_').log"
-      ( IFS=','; for kv in $arg; do export "$kv"; done; timeout 300 python bench.py $BENCH40 > "$f" 2>&1 ); line "$f" ;;
+      ( for kv in $(echo "$arg" | tr ',' ' '); do export "$kv"; done; timeout 300 python bench.py $BENCH40 > "$f" 2>&1 ); line "$f" ;;
     bench8x) timeout 300 python bench.py --model 8x $BENCH40 > "$D/bench_8x.log" 2>&1; line "$D/bench_8x.log" ;;
     benchf16) timeout 300 python bench.py --operand f16 $BENCH40 > "$D/bench_f16.log" 2>&1; line "$D/bench_f16.log" ;;
     benchfront) timeout 300 python bench.py --frontend $BENCH40 > "$D/bench_frontend.log" 2>&1; line "$D/bench_frontend.log" ;;

@@ -109,6 +109,11 @@ SIGNATURES = {
     "vc_bn_stats": (_I, [_P, _I64, _I, _P, _P, _P, _P, _P, _F, _P, _SZ, _P]),
     "vc_bn_apply_relu": (_I, [_P, _I64, _I, _P, _P, _P, _P, _F, _I, _P, _I, _I, _P]),
     "vc_bn_relu_backward": (_I, [_P, _P, _I, _I, _I64, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _SZ, _P]),
+    "vc_plan_begin_arena_bytes": (_SZ, [_P]),
+    "vc_plan_begin": (_I, [_P, _P, _SZ, _P, _P, _P]),
+    "vc_plan_wait": (_I, [_P, _P]),
+    "vc_plan_finish_arena_bytes": (_SZ, [_P, _P]),
+    "vc_plan_finish": (_I, [_P, _P, _P, _P, _SZ, _P, _P]),
 }
 
 
@@ -148,6 +153,52 @@ class PassProgram(C.Structure):
 class TraceRecord(C.Structure):
     _fields_ = [("ms", _F), ("kv", C.c_int32), ("ck", C.c_int32), ("cn", C.c_int32), ("windowed", C.c_int32),
                 ("n_src", _I64), ("n_out", _I64), ("pairs", _I64), ("direction", C.c_int32), ("t0_ms", _F)]
+
+
+# ---- structs of the geometry plan (include/virconv_hip.h: vc_plan_*)
+PLAN_MAX_BLOCKS = 8
+_I32 = C.c_int32
+
+
+class PlanConv(C.Structure):
+    _fields_ = [("ksize", _I32 * 3), ("stride", _I32 * 3), ("padding", _I32 * 3), ("dilation", _I32 * 3)]
+
+
+class PlanBlock(C.Structure):
+    _fields_ = [("has_down", _I32), ("down", PlanConv), ("subm_ksize", _I32 * 3), ("subm_dilation", _I32 * 3), ("has_2d", _I32),
+                ("uv_stride", _I32), ("ksize2d", _I32 * 2), ("dilation2d", _I32 * 2), ("discard", _I32), ("keep_seed", C.c_uint64),
+                ("keep", _P), ("keep_rows", _I64)]
+
+
+class PlanDesc(C.Structure):
+    _fields_ = [("indices", _P), ("n", _I64), ("batch_size", _I32), ("spatial_shape", _I32 * 3), ("calib", _P), ("trans", _P),
+                ("image_shape", _I32 * 2), ("input_discard", _I32), ("input_keep_seed", C.c_uint64), ("input_keep", _P),
+                ("input_keep_rows", _I64), ("n_blocks", _I32), ("blocks", PlanBlock * PLAN_MAX_BLOCKS), ("has_tail", _I32),
+                ("tail", PlanConv), ("discard_rate", _D), ("need_grad", _I32), ("row_order_fwd", _I32)]
+
+
+class PlanView(C.Structure):
+    _fields_ = [("arena", _I32), ("cols", _I32), ("offset", _I64), ("rows", _I64)]
+
+
+class PlanTableOut(C.Structure):
+    _fields_ = [("pair_fwd", PlanView), ("pair_bwd", PlanView), ("rep", PlanView), ("order_fwd", PlanView), ("order_bwd", PlanView),
+                ("grp_plan", PlanView), ("in_indices", PlanView), ("out_indices", PlanView), ("n_in", _I64), ("n_out", _I64),
+                ("kv", _I32), ("present", _I32), ("out_shape", _I32 * 3), ("pad_", _I32)]
+
+
+class PlanBlockOut(C.Structure):
+    _fields_ = [("down", PlanTableOut), ("subm3d", PlanTableOut), ("subm2d", PlanTableOut), ("uv", PlanView), ("keep", PlanView),
+                ("kept_indices", PlanView), ("n", _I64), ("n_keep", _I64)]
+
+
+class PlanOut(C.Structure):
+    _fields_ = [("input_keep", PlanView), ("input_kept_indices", PlanView), ("n_input_kept", _I64),
+                ("blocks", PlanBlockOut * PLAN_MAX_BLOCKS), ("tail", PlanTableOut)]
+
+
+class PlanState(C.Structure):
+    _fields_ = [("opaque", _I64 * 2048)]
 
 
 _lib = None

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import feature_pass, ops
+from . import feature_pass, native_plan, ops
 from . import spconv
 
 # layer discard: draw the kept rows with vc_random_keep (point-wise pseudo-random permutation) instead of torch.randperm
@@ -304,7 +304,8 @@ class _PlanScope:
     def publish(self, plan):
         if self.on_gpu:
             self.main.wait_stream(self.side)
-            _record_stream(plan, self.main)
+            # a native plan lives in two arenas (every structure is a view of one of them): marking those is marking everything
+            _record_stream(plan["_arenas"] if (isinstance(plan, dict) and "_arenas" in plan) else plan, self.main)
         return plan
 
 
@@ -437,10 +438,16 @@ class VirConvL8x(nn.Module):
         with _PlanScope(coords, batch_dict) as scope:
             idx = coords.int()
             co = self.conv_out[0]
-            stages, in_idx, shape, begun = _plan_nrconv_chain(blocks, idx, list(self.sparse_shape), batch_size, calib,
-                                                              trans_param, tags, self.layer_discard_rate, batch_dict, tail=co)
-            rb_out = ops.finish_sparse_rulebook(begun)
-            plan = {"in_indices": idx, "stages": stages, "conv_out": {co.indice_key: rb_out}}
+            if native_plan.usable(idx, blocks):
+                # the whole plan as three native calls around ONE count read (csrc/plan.hip)
+                stages, rb_out, _, _, arenas = native_plan.build(self, blocks, co, idx, batch_size, calib, trans_param, tags,
+                                                                 self.layer_discard_rate, batch_dict, NRConvBlock.IMAGE_SHAPE)
+                plan = {"in_indices": idx, "stages": stages, "conv_out": {co.indice_key: rb_out}, "_arenas": arenas + [idx]}
+            else:
+                stages, in_idx, shape, begun = _plan_nrconv_chain(blocks, idx, list(self.sparse_shape), batch_size, calib,
+                                                                  trans_param, tags, self.layer_discard_rate, batch_dict, tail=co)
+                rb_out = ops.finish_sparse_rulebook(begun)
+                plan = {"in_indices": idx, "stages": stages, "conv_out": {co.indice_key: rb_out}}
         return scope.publish(plan)
 
     def forward(self, batch_dict):

@@ -74,6 +74,7 @@ class HipBackend:
 
     # ------------------------------------------------------------------ kernel timing for bench.py's roofline
     native_pass = True   # vc_pass_forward / vc_pass_backward are available (virconv_amd/feature_pass.py)
+    native_plan = True   # vc_plan_begin / _wait / _finish are available (virconv_amd/native_plan.py)
 
     @staticmethod
     def stream() -> int:

@@ -31,6 +31,7 @@ SOURCES = {
     "group_kernels.hip": [],
     "unit.hip": [],
     "pass.hip": [],
+    "plan.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 

@@ -189,42 +189,45 @@ __device__ __forceinline__ int64_t sp_candidate(const SpGeom& g, int b, int z, i
 // x-consecutive rows whose candidate cells mostly fall into the SAME 64-cell bitmap word: a segmented OR-scan over the wave
 // merges them and only the last lane of each run issues the atomic (same-address L2 atomics serialise).
 // n_dev (optional): the number of rows lives on the device (a strided conv chained behind another one whose output count the host
-// has not read yet): the grid covers the CAPACITY n, blocks past the real count leave at once.
+// has not read yet): n is then the row CAPACITY; the launch takes a bounded grid and strides over the real rows.
 __global__ void __launch_bounds__(256) sp_mark_kernel(const int32_t* __restrict__ indices, int64_t n, int ndim,
                                                       SpGeom g, unsigned long long* __restrict__ bitmap,
                                                       const int32_t* __restrict__ n_dev) {
   if (n_dev != nullptr) {
     const int64_t real = *n_dev;
     if (real < n) n = real;
-    if ((int64_t)blockIdx.x * 64 >= n) return;
   }
   __shared__ int s_off[128];
   fill_offset_table(s_off, g.k[0], g.k[1], g.k[2]);
   const int lane = threadIdx.x & 63, kg = threadIdx.x >> 6;
-  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
-  const bool live = i < n;
-  int b = 0, z = 0, y = 0, x = 0;
-  if (live) load_coord(indices, i, ndim, b, z, y, x);
   const int kv = g.k[0] * g.k[1] * g.k[2];
-  for (int k = kg; k < kv; k += 4) {
-    const int64_t L = live ? sp_candidate(g, b, z, y, x, s_off[k]) : -1;
-    const bool valid = L >= 0;
-    // lanes without a candidate (for stride 2 every other x) adopt the word of the nearest valid lane below them, so that
-    // the lanes of one word form ONE contiguous run whose last lane flushes it
-    const unsigned long long vm = __ballot(valid);
-    const unsigned long long below = vm & ((lane == 63) ? ~0ULL : ((2ULL << lane) - 1ULL));
-    const int src = below ? 63 - __clzll((long long)below) : lane;
-    const long long w0 = valid ? (long long)(L >> 6) : (long long)(-1 - lane);
-    const long long w = __shfl(w0, src, 64);
-    unsigned long long bits = valid ? (1ULL << (L & 63)) : 0ULL;
+  // grid-stride over 64-row groups: a launch over a row CAPACITY (n_dev) takes a bounded grid instead of one block per 64 rows
+  // of capacity (the capacities of a chain of strided convs compound: 97 k blocks for 2.7 k real ones at stage 4)
+  for (int64_t rb = blockIdx.x; rb * 64 < n; rb += gridDim.x) {
+    const int64_t i = rb * 64 + lane;
+    const bool live = i < n;
+    int b = 0, z = 0, y = 0, x = 0;
+    if (live) load_coord(indices, i, ndim, b, z, y, x);
+    for (int k = kg; k < kv; k += 4) {
+      const int64_t L = live ? sp_candidate(g, b, z, y, x, s_off[k]) : -1;
+      const bool valid = L >= 0;
+      // lanes without a candidate (for stride 2 every other x) adopt the word of the nearest valid lane below them, so that
+      // the lanes of one word form ONE contiguous run whose last lane flushes it
+      const unsigned long long vm = __ballot(valid);
+      const unsigned long long below = vm & ((lane == 63) ? ~0ULL : ((2ULL << lane) - 1ULL));
+      const int src = below ? 63 - __clzll((long long)below) : lane;
+      const long long w0 = valid ? (long long)(L >> 6) : (long long)(-1 - lane);
+      const long long w = __shfl(w0, src, 64);
+      unsigned long long bits = valid ? (1ULL << (L & 63)) : 0ULL;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const long long ow = __shfl_up(w, off, 64);
-      const unsigned long long ob = __shfl_up(bits, off, 64);
-      if (lane >= off && ow == w) bits |= ob;
+      for (int off = 1; off < 64; off <<= 1) {
+        const long long ow = __shfl_up(w, off, 64);
+        const unsigned long long ob = __shfl_up(bits, off, 64);
+        if (lane >= off && ow == w) bits |= ob;
+      }
+      const long long nw = __shfl_down(w, 1, 64);
+      if (bits != 0ULL && (lane == 63 || nw != w)) atomicOr(&bitmap[w], bits);
     }
-    const long long nw = __shfl_down(w, 1, 64);
-    if (bits != 0ULL && (lane == 63 || nw != w)) atomicOr(&bitmap[w], bits);
   }
 }
 
@@ -1067,7 +1070,9 @@ static int spconv_mark_count(const int32_t* indices, int64_t n, const int32_t* n
   VC_REQUIRE(k.kv <= 128, "strided rulebook: kernel volume %d > 128", k.kv);
   SpGeom g = make_spgeom(o, k);
   if (n > 0) {
-    hipLaunchKernelGGL(sp_mark_kernel, dim3((unsigned)cdiv(n, 64)), dim3(256), 0, st, indices, n, ndim, g, bitmap, n_dev);
+    int64_t mark_blocks = cdiv(n, 64);
+    if (n_dev != nullptr && mark_blocks > 8192) mark_blocks = 8192;   // capacity launch: grid-stride inside the kernel
+    hipLaunchKernelGGL(sp_mark_kernel, dim3((unsigned)mark_blocks), dim3(256), 0, st, indices, n, ndim, g, bitmap, n_dev);
     VC_CHECK_LAUNCH("sp_mark_kernel");
   }
   hipLaunchKernelGGL(sp_blocksum_kernel, dim3((unsigned)nb), dim3(256), 0, st, bitmap, nwords, blocksum);

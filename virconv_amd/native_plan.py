@@ -1,0 +1,196 @@
+"""The geometry plan of an NRConvBlock chain as native calls (vc_plan_begin / vc_plan_wait / vc_plan_finish, csrc/plan.hip).
+
+Reference path: the indice generation spconv runs conv by conv inside ``VirConvL8x.forward``
+(pcdet/models/backbones_3d/spconv_backbone.py:609-699; NRConvBlock :150-229, layer_voxel_discard :134-147, conv_out :561-567),
+one device-to-host sync per strided conv.  Round 3 built the same structures from Python (``backbone._plan_nrconv_chain``: ~90
+ctypes calls, ~60 allocations and four pipelined count reads per train step -- 2.2 ms of host time per step and, through the
+plan stream's kernel work, 0.84 ms of step time, tools/whatif.py).  Here: three C calls, two arenas, ONE count read, and index
+kernels that use what the chain knows (bitmap-rank SubM rulebooks, dense pixel images, residue-class row orders, an LDS radix
+sort for the group plans).  The result is the same ``plan`` dictionary of ``ops.Rulebook`` objects the Python path builds: the
+feature pass and the node-by-node path consume it unchanged.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import weakref
+
+import torch
+
+from . import _lib, ops
+
+NATIVE_PLAN = os.environ.get("VIRCONV_NATIVE_PLAN", "1") != "0"
+_DESCS = weakref.WeakKeyDictionary()      # model -> static part of its vc_plan_desc
+_PINNED = {}                              # device index -> pinned int32[64] for the counts
+
+
+def _conv_geom(dst: _lib.PlanConv, conv) -> None:
+    for a in range(3):
+        dst.ksize[a], dst.stride[a] = int(conv.kernel_size[a]), int(conv.stride[a])
+        dst.padding[a], dst.dilation[a] = int(conv.padding[a]), int(conv.dilation[a])
+
+
+def _static_desc(blocks, tail, sparse_shape, image_shape) -> _lib.PlanDesc:
+    d = _lib.PlanDesc()
+    d.n_blocks = len(blocks)
+    for a in range(3):
+        d.spatial_shape[a] = int(sparse_shape[a])
+    d.image_shape[0], d.image_shape[1] = int(image_shape[0]), int(image_shape[1])
+    for b, (blk, uv_stride) in enumerate(blocks):
+        B = d.blocks[b]
+        B.has_down = 1 if blk.stride > 1 else 0
+        if blk.stride > 1:
+            _conv_geom(B.down, blk.down_layer[0])
+        c3, c2 = blk.d3_conv1[0], blk.d2_conv1[0]
+        for a in range(3):
+            B.subm_ksize[a], B.subm_dilation[a] = int(c3.kernel_size[a]), int(c3.dilation[a])
+        B.has_2d, B.uv_stride = 1, int(uv_stride)
+        for a in range(2):
+            B.ksize2d[a], B.dilation2d[a] = int(c2.kernel_size[a]), int(c2.dilation[a])
+    d.has_tail = 1 if tail is not None else 0
+    if tail is not None:
+        _conv_geom(d.tail, tail)
+    return d
+
+
+def usable(coords: torch.Tensor, blocks) -> bool:
+    be = ops.get_backend()
+    from .backbone import FAST_RANDOM_KEEP
+    return bool(NATIVE_PLAN and getattr(be, "native_plan", False) and coords.is_cuda and coords.shape[0] > 0 and FAST_RANDOM_KEEP
+                and ops.ROW_ORDER in ("bwd", "strided") and not ops.WINDOW_GATHER and len(blocks) <= _lib.PLAN_MAX_BLOCKS
+                and all(not blk.conv_depth and blk.d3_conv1[0].ndim == 3 and blk.d2_conv1[0].ndim == 2 for blk, _ in blocks))
+
+
+def _view(arenas, v: _lib.PlanView, external=None):
+    if v.arena < 0:
+        return external
+    a = arenas[v.arena]
+    return torch.as_strided(a, (v.rows, v.cols), (v.cols, 1), v.offset >> 2)
+
+
+def _view1(arenas, v: _lib.PlanView):
+    if v.arena < 0:
+        return None
+    return torch.as_strided(arenas[v.arena], (v.rows,), (1,), v.offset >> 2)
+
+
+def _keep_view(arenas, v: _lib.PlanView):
+    off = v.offset >> 2
+    return arenas[v.arena][off: off + 2 * v.rows].view(torch.int64)
+
+
+def _table(arenas, t: _lib.PlanTableOut, kind, in_shape, conv, in_idx) -> ops.Rulebook:
+    """ops.Rulebook over views of the arenas; `in_idx`: the tensor holding the table's input coordinates."""
+    ndim = conv.ndim
+    out_shape = tuple(int(t.out_shape[a]) for a in range(ndim))
+    out_idx = in_idx if kind == "subm" else _view(arenas, t.out_indices)
+    ks = tuple(int(k) for k in conv.kernel_size)
+    rb = ops.Rulebook(kind, _view(arenas, t.pair_fwd), _view(arenas, t.pair_bwd), _view1(arenas, t.rep), int(t.n_in), int(t.n_out),
+                      in_idx, out_idx, tuple(int(s) for s in in_shape), out_shape, ks,
+                      tuple(int(s) for s in conv.stride) if kind == "sparse" else (1,) * ndim,
+                      tuple(int(p) for p in conv.padding) if kind == "sparse" else tuple(k // 2 for k in ks),
+                      tuple(int(x) for x in conv.dilation))
+    rb.order_fwd, rb.order_bwd = _view1(arenas, t.order_fwd), _view1(arenas, t.order_bwd)
+    if t.grp_plan.arena >= 0:
+        rb.grp_plan = _view(arenas, t.grp_plan)
+    return rb
+
+
+def build(model, blocks, tail, idx: torch.Tensor, batch_size: int, calib, trans_param, discard_tags, rate: float, batch_dict,
+          image_shape, input_discard_tag=None):
+    """-> (stages, tail Rulebook | None, input keep | None, kept input indices | None, [arena_a, arena_b]) for the chain `blocks`
+    (+ `tail`: the strided conv behind it) over the coordinates `idx` (N, 4) int32; `discard_tags[b]`: the batch_dict tag of
+    the layer discard after block b or None; `input_discard_tag`: discard of the chain's input (VirConv8x MM stream)."""
+    be = ops.get_backend()
+    lib = be.lib
+    dev = idx.device
+    key = (len(blocks), tail is not None)
+    cache = _DESCS.setdefault(model, {})
+    if key not in cache:
+        cache[key] = _static_desc(blocks, tail, model.sparse_shape, image_shape)
+    d = cache[key]
+    hold = [idx, calib]
+    d.indices, d.n, d.batch_size = idx.data_ptr(), idx.shape[0], int(batch_size)
+    d.calib = calib.data_ptr()
+    if trans_param is not None:
+        trans_param = torch.as_tensor(trans_param, dtype=torch.float32, device=dev).reshape(batch_size, 3).contiguous()
+        hold.append(trans_param)
+        d.trans = trans_param.data_ptr()
+    else:
+        d.trans = None
+    d.discard_rate = float(rate) if (any(t is not None for t in discard_tags) or input_discard_tag is not None) else 0.0
+    d.need_grad = 1 if torch.is_grad_enabled() else 0
+    d.row_order_fwd = 1 if ops.ROW_ORDER == "strided" else 0
+    inj = batch_dict.get("layer_discard_keep")
+
+    def keep_source(tag):
+        """(seed, injected tensor | None): the injected permutation prefix, or a seed drawn from torch's CPU generator exactly as
+        backbone.draw_random_keep does (same sequence of draws => same kept rows as the Python plan)."""
+        if inj is not None:
+            k = inj[tag].to(device=dev, dtype=torch.int64).contiguous()
+            hold.append(k)
+            return 0, k
+        return int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF, None
+
+    d.input_discard = 0
+    if input_discard_tag is not None:
+        seed, k = keep_source(input_discard_tag)
+        d.input_discard, d.input_keep_seed = 1, seed
+        d.input_keep, d.input_keep_rows = (k.data_ptr(), k.shape[0]) if k is not None else (None, 0)
+    for b, tag in enumerate(discard_tags):
+        B = d.blocks[b]
+        B.discard = 1 if tag is not None else 0
+        B.keep, B.keep_rows, B.keep_seed = None, 0, 0
+        if tag is not None:
+            seed, k = keep_source(tag)
+            B.keep_seed = seed
+            if k is not None:
+                B.keep, B.keep_rows = k.data_ptr(), k.shape[0]
+    dref = C.byref(d)
+    st = be.stream()
+    na = lib.vc_plan_begin_arena_bytes(dref)
+    if na == 0:
+        _lib.check(_lib.VC_EINVAL, "vc_plan_begin_arena_bytes")
+    arena_a = torch.empty(((na + 3) >> 2,), dtype=torch.int32, device=dev)
+    pinned = _PINNED.get(dev.index)
+    if pinned is None:
+        pinned = _PINNED[dev.index] = torch.empty((64,), dtype=torch.int32).pin_memory()
+    state = _lib.PlanState()
+    sref = C.byref(state)
+    _lib.check(lib.vc_plan_begin(dref, arena_a.data_ptr(), arena_a.numel() * 4, pinned.data_ptr(), sref, st), "vc_plan_begin")
+    _lib.check(lib.vc_plan_wait(dref, sref), "vc_plan_wait")          # the ONE host synchronisation of the plan
+    nb = lib.vc_plan_finish_arena_bytes(dref, sref)
+    if nb == 0:
+        _lib.check(_lib.VC_EINVAL, "vc_plan_finish_arena_bytes")
+    arena_b = torch.empty(((nb + 3) >> 2,), dtype=torch.int32, device=dev)
+    out = _lib.PlanOut()
+    _lib.check(lib.vc_plan_finish(dref, sref, arena_a.data_ptr(), arena_b.data_ptr(), arena_b.numel() * 4, C.byref(out), st),
+               "vc_plan_finish")
+    del hold
+    arenas = (arena_a, arena_b)
+    stages = []
+    in_keep = in_kept = None
+    cur_idx, shape = idx, list(model.sparse_shape)
+    if input_discard_tag is not None:
+        in_keep, in_kept = _keep_view(arenas, out.input_keep), _view(arenas, out.input_kept_indices)
+        cur_idx = in_kept
+    for b, ((blk, _), tag) in enumerate(zip(blocks, discard_tags)):
+        O = out.blocks[b]
+        kd, k3, k2 = blk._keys()
+        rbs3 = {}
+        if blk.stride > 1:
+            rb = _table(arenas, O.down, "sparse", shape, blk.down_layer[0], cur_idx)
+            rbs3[kd] = rb
+            cur_idx, shape = rb.out_indices, list(rb.out_shape)
+        rb3 = _table(arenas, O.subm3d, "subm", shape, blk.d3_conv1[0], cur_idx)
+        rbs3[k3] = rb3
+        uv = _view(arenas, O.uv)
+        rb2 = _table(arenas, O.subm2d, "subm", image_shape, blk.d2_conv1[0], uv)
+        st_ = {"rb3d": rbs3, "uv": uv, "rb2d": {k2: rb2}, "out_indices": cur_idx, "out_shape": shape, "keep": None}
+        if tag is not None:
+            st_["keep"] = _keep_view(arenas, O.keep)
+            st_["kept_indices"] = _view(arenas, O.kept_indices)
+            cur_idx = st_["kept_indices"]
+        stages.append(st_)
+    rb_tail = _table(arenas, out.tail, "sparse", shape, tail, cur_idx) if tail is not None else None
+    return stages, rb_tail, in_keep, in_kept, [arena_a, arena_b]
