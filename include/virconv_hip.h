@@ -536,7 +536,7 @@ int vc_nms(const float* boxes, int64_t n, float thresh, int rotated, int64_t* ke
  * of a strided conv's output are the set bits of its bitmap in ascending order, so the SubM rulebook of that tensor ranks
  * neighbours in the SAME bitmap (no hash build); the pixel tensors index a dense per-sample image (no hash build, 6x fewer
  * bytes to clear); the backward row order of a strided table is a counting sort on the stride-parity class of the input
- * coordinate (no pass over the 27-row table); the group plan is a hand-written two-pass LDS radix sort.  Tables are bit-identical
+ * coordinate (no pass over the 27-row table).  Tables are bit-identical
  * to vc_subm_rulebook / vc_spconv_emit_pairs / vc_group_plan on the same coordinates (tests); row orders are hints.
  * The caller owns both arenas; `vc_plan_out` reports every structure as (arena, byte offset, rows, cols).                  */
 #define VC_PLAN_MAX_BLOCKS 8

@@ -285,6 +285,22 @@ def _record_discards(monkeypatch):
         return keep
 
     monkeypatch.setattr(bb, "_draw_keep", recording)
+    # the native geometry plan (virconv_amd/native_plan.py) draws the keeps on the device inside vc_plan_begin: read them off its result
+    from virconv_amd import native_plan as npn
+    orig_build = npn.build
+
+    def recording_build(model, blocks, tail, idx, batch_size, calib, trans_param, discard_tags, rate, batch_dict, image_shape,
+                        input_discard_tag=None):
+        res = orig_build(model, blocks, tail, idx, batch_size, calib, trans_param, discard_tags, rate, batch_dict, image_shape,
+                         input_discard_tag)
+        for st, tag in zip(res[0], discard_tags):
+            if tag is not None:
+                rec[tag] = st["keep"].detach().cpu().clone()
+        if input_discard_tag is not None:
+            rec[input_discard_tag] = res[2].detach().cpu().clone()
+        return res
+
+    monkeypatch.setattr(npn, "build", recording_build)
     return rec
 
 

@@ -119,7 +119,7 @@ def test_native_plan_equals_the_operator_by_operator_plan_full_size(hip_backend,
         assert bool((o[1:][same] > o[:-1][same]).all()), "the order is not stable inside a class"
 
 
-@pytest.mark.parametrize("key", ["plan_subm_bitmap", "plan_image_2d", "plan_radix_sort", "plan_parity_order"])
+@pytest.mark.parametrize("key", ["plan_subm_bitmap", "plan_image_2d", "plan_parity_order", "sp_mark_variant"])
 def test_plan_kernel_switches_do_not_change_any_table(hip_backend, monkeypatch, key):
     """Every chain-aware index kernel has the generic operator as its A/B alternative (vc_debug_set): same tables either way."""
     dev = torch.device("cuda", 0)
@@ -129,21 +129,21 @@ def test_plan_kernel_switches_do_not_change_any_table(hip_backend, monkeypatch, 
     lib = hip_backend.lib
     plans = []
     try:
-        for v in (1, 0):
+        for v in ((2, 1) if key == "sp_mark_variant" else (1, 0)):
             assert lib.vc_debug_set(key.encode(), v) == 0
             torch.manual_seed(11)
             plans.append(model.build_plan(batch["voxel_coords"], 2, batch["calib"], batch["aug_param"], batch))
             torch.cuda.synchronize()
     finally:
-        assert lib.vc_debug_set(key.encode(), 1) == 0
+        assert lib.vc_debug_set(key.encode(), 2 if key == "sp_mark_variant" else 1) == 0
     _assert_same_plan(plans[0], plans[1], key)
 
 
 @pytest.mark.parametrize("n,groups", [(1, 1), (63, 5), (4096, 4096), (4097, 300), (70001, 9000), (310351, 60000), (200000, 3),
                                       (2100000, 500000)])
-def test_group_plan_radix_sort_is_the_stable_sort_by_representative(hip_backend, n, groups):
-    """vc_group_plan's hand-written two-pass LDS radix sort (group_kernels.hip; three launches) against a stable argsort and against
-    the rocPRIM route (vc_debug_set plan_radix_sort = 0); the last case is beyond 512 tiles and takes rocPRIM either way."""
+def test_group_plan_is_the_stable_sort_by_representative(hip_backend, n, groups):
+    """vc_group_plan against a stable argsort; in a -DVC_EXPERIMENTS build also the hand-written LDS radix sort of
+    csrc/experiments/group_plan_radix.inc (vc_debug_set plan_radix_sort = 1; the last case is beyond its range)."""
     rng = np.random.default_rng(n + groups)
     dev = torch.device("cuda", 0)
     rep_groups = rng.integers(0, groups, n)
@@ -160,11 +160,11 @@ def test_group_plan_radix_sort_is_the_stable_sort_by_representative(hip_backend,
     assert np.array_equal(got[0].cpu().numpy(), order) and np.array_equal(got[1].cpu().numpy(), keys[order])
     for _ in range(2):
         assert torch.equal(hip_backend.group_plan(rep), got)
-    try:
-        assert lib.vc_debug_set(b"plan_radix_sort", 0) == 0
-        assert torch.equal(hip_backend.group_plan(rep), got)
-    finally:
-        assert lib.vc_debug_set(b"plan_radix_sort", 1) == 0
+    if lib.vc_debug_set(b"plan_radix_sort", 1) == 0:      # experiment builds only
+        try:
+            assert torch.equal(hip_backend.group_plan(rep), got)
+        finally:
+            assert lib.vc_debug_set(b"plan_radix_sort", 0) == 0
 
 
 def test_train_step_with_the_native_plan_matches_the_operator_by_operator_plan(hip_backend, monkeypatch):

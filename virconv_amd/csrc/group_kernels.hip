@@ -119,197 +119,11 @@ __global__ void __launch_bounds__(256) group_keys_kernel(const int32_t* __restri
 }
 
 static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
-int g_group_plan_radix = 1;   // vc_debug_set plan_radix_sort: 0 = rocPRIM's radix sort for every group plan (A/B)
+int g_group_plan_radix = 0;   // vc_debug_set plan_radix_sort (experiment builds): 1 = the hand-written LDS radix sort of csrc/experiments/
 
-// ------------------------------------------------------------------------------------------ group plan: LSD radix sort in LDS
-// grp_plan = [rows sorted stably by key | the sorted keys], key[i] = rep[i] < 0 ? i : rep[i] (< n): what vc_group_plan builds with
-// rocPRIM (a 6-launch merge sort at these sizes, 70 us per table).  Keys have ceil(log2 n) <= 22 significant bits: two stable
-// counting passes of DB = ceil(bits / 2) <= 11 bits, THREE launches in all:
-//   radix_hist     block = tile of 4096 keys: LDS histogram of digit 0 -> hist0[tile][bin]; also clears hist1[tile][*]
-//   radix_scatter  block = tile.  (1) its global bases: thread b walks column b of hist -- the keys of bin b in the tiles in front
-//                  of this one, and the bin's total -- then an in-block scan over the bin totals (no scan kernel: 76 tiles x 1024
-//                  bins = 311 KB from L2 per block); (2) wave w owns keys [1024 w, 1024 (w + 1)) of the tile and walks them 64
-//                  at a time in order; the lanes holding the same digit find each other with DB ballots, the lowest of them
-//                  advances the wave's private running counter of that digit, everybody writes (key, row) at base + rank;
-//                  (3) pass 0 also counts digit 1 of every key into hist1[tile of its NEW position][bin] (integer atomics:
-//                  order-free), so pass 1 needs no histogram launch.
-// Pass 0 reads the keys from rep (no key / row-id arrays are materialised), pass 1 writes the plan itself.  Stable: tiles, waves,
-// rounds and lanes are all taken in ascending position.  Tensors beyond 512 tiles (2 M rows) or 22 key bits take vc_group_plan.
-static constexpr int kRsTile = 4096, kRsThreads = 256, kRsPerThread = kRsTile / kRsThreads;   // 16 keys per thread
-static constexpr int kRsMaxBins = 2048, kRsMaxTiles = 512;
-
-__device__ __forceinline__ unsigned rs_key(const int32_t* __restrict__ rep, const uint32_t* __restrict__ keys_in, int64_t j) {
-  if (keys_in != nullptr) return keys_in[j];
-  const int g = rep[j];
-  return g < 0 ? (unsigned)j : (unsigned)g;
-}
-
-__global__ void __launch_bounds__(kRsThreads) radix_hist_kernel(const int32_t* __restrict__ rep, int64_t n, int nbins,
-                                                               int32_t* __restrict__ hist0, int32_t* __restrict__ hist1) {
-  __shared__ int h[kRsMaxBins];
-  for (int j = threadIdx.x; j < nbins; j += kRsThreads) h[j] = 0;
-  __syncthreads();
-  const int64_t t0 = (int64_t)blockIdx.x * kRsTile;
-#pragma unroll 4
-  for (int u = 0; u < kRsPerThread; ++u) {
-    const int64_t j = t0 + u * kRsThreads + threadIdx.x;
-    if (j < n) atomicAdd(&h[rs_key(rep, nullptr, j) & (unsigned)(nbins - 1)], 1);
-  }
-  __syncthreads();
-  for (int j = threadIdx.x; j < nbins; j += kRsThreads) {
-    hist0[(int64_t)blockIdx.x * nbins + j] = h[j];
-    if (hist1 != nullptr) hist1[(int64_t)blockIdx.x * nbins + j] = 0;
-  }
-}
-
-__global__ void __launch_bounds__(kRsThreads) radix_scatter_kernel(const int32_t* __restrict__ rep, const uint32_t* __restrict__ keys_in,
-                                                                  const int32_t* __restrict__ rows_in, int64_t n, int shift, int bits,
-                                                                  int nbins, int ntiles, const int32_t* __restrict__ hist,
-                                                                  uint32_t* __restrict__ keys_out, int32_t* __restrict__ rows_out,
-                                                                  int32_t* __restrict__ hist_next) {
-  extern __shared__ int s_dyn[];   // [4 waves][nbins] wave counters / write positions, then [nbins] bases, then 8 ints
-  int* s_cnt = s_dyn;
-  int* s_base = s_dyn + 4 * nbins;
-  int* s_wave = s_base + nbins;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned mask = (unsigned)(nbins - 1);
-  int* mine = s_cnt + wave * nbins;
-  for (int j = threadIdx.x; j < 4 * nbins; j += kRsThreads) s_cnt[j] = 0;
-  __syncthreads();
-  // (1a) column sums of the histogram: keys of bin b in the tiles in front of this one / in all tiles
-  const int tile = blockIdx.x;
-  for (int b = threadIdx.x; b < nbins; b += kRsThreads) {
-    int before = 0, total = 0;
-    int t = 0;
-    for (; t + 8 <= ntiles; t += 8) {
-      int v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = hist[(int64_t)(t + u) * nbins + b];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { total += v[u]; before += (t + u < tile) ? v[u] : 0; }
-    }
-    for (; t < ntiles; ++t) {
-      const int v = hist[(int64_t)t * nbins + b];
-      total += v;
-      before += (t < tile) ? v : 0;
-    }
-    s_base[b] = total;
-    s_cnt[b] = before;   // parked in wave 0's counter row until the scan below has run
-  }
-  __syncthreads();
-  {  // (1b) exclusive scan of the bin totals: nbins / 256 consecutive bins per thread
-    const int bpt = nbins / kRsThreads;   // 1 (256 bins) .. 8 (2048 bins); nbins >= 256 is guaranteed by the host
-    int v[8], sum = 0;
-    for (int j = 0; j < bpt; ++j) { v[j] = s_base[threadIdx.x * bpt + j]; sum += v[j]; }
-    int inc = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int o = __shfl_up(inc, off, 64);
-      if (lane >= off) inc += o;
-    }
-    if (lane == 63) s_wave[wave] = inc;
-    __syncthreads();
-    int run = inc - sum;
-    for (int w_ = 0; w_ < wave; ++w_) run += s_wave[w_];
-    for (int j = 0; j < bpt; ++j) {
-      const int b = threadIdx.x * bpt + j;
-      s_base[b] = run + s_cnt[b];   // first output position of (bin b, this tile)
-      run += v[j];
-    }
-  }
-  __syncthreads();
-  for (int b = threadIdx.x; b < nbins; b += kRsThreads) s_cnt[b] = 0;
-  __syncthreads();
-  // (2a) per-wave digit counts
-  const int64_t w0 = (int64_t)tile * kRsTile + (int64_t)wave * (kRsTile / 4);
-  constexpr int ROUNDS = kRsTile / 4 / 64;   // 16 rounds of 64 consecutive keys per wave
-  unsigned key[ROUNDS];
-#pragma unroll
-  for (int r = 0; r < ROUNDS; ++r) {
-    const int64_t j = w0 + r * 64 + lane;
-    key[r] = (j < n) ? rs_key(rep, keys_in, j) : 0xffffffffu;
-    if (j < n) atomicAdd(&mine[(key[r] >> shift) & mask], 1);   // wave-private counters: LDS atomics of one wave only
-  }
-  __syncthreads();
-  // (2b) mine[bin] = the wave's first write position for that bin
-  for (int b = threadIdx.x; b < nbins; b += kRsThreads) {
-    int run = s_base[b];
-#pragma unroll
-    for (int w_ = 0; w_ < 4; ++w_) {
-      const int c = s_cnt[w_ * nbins + b];
-      s_cnt[w_ * nbins + b] = run;
-      run += c;
-    }
-  }
-  __syncthreads();
-  // (2c) the ordered walk
-#pragma unroll
-  for (int r = 0; r < ROUNDS; ++r) {
-    const int64_t j = w0 + r * 64 + lane;
-    const bool valid = j < n;
-    const unsigned d = (key[r] >> shift) & mask;
-    unsigned long long peers = __ballot(valid);   // becomes: the valid lanes holding the same digit
-    for (int bt = 0; bt < bits; ++bt) {
-      const unsigned long long bal = __ballot((d >> bt) & 1u);
-      peers &= ((d >> bt) & 1u) ? bal : ~bal;
-    }
-    const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
-    int pos = 0;
-    if (valid && lane == leader) {
-      pos = mine[d];
-      mine[d] = pos + __popcll(peers);
-    }
-    pos = __shfl(pos, leader, 64);
-    if (valid) {
-      pos += __popcll(peers & ((1ULL << lane) - 1ULL));
-      keys_out[pos] = key[r];
-      rows_out[pos] = rows_in ? rows_in[j] : (int32_t)j;
-      if (hist_next != nullptr) atomicAdd(&hist_next[(int64_t)(pos / kRsTile) * nbins + ((key[r] >> (shift + bits)) & mask)], 1);
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-static inline int rs_key_bits(int64_t n) {
-  int b = 1;
-  while (b < 32 && (1LL << b) < n) ++b;
-  return b;
-}
-// -> digit bits of the two-pass sort (8 .. 11), or 0 when the tensor is outside what the hand-written sort serves
-static inline int rs_digit_bits(int64_t n) {
-  const int bits = rs_key_bits(n);
-  if (bits > 22 || cdiv(n > 0 ? n : 1, kRsTile) > kRsMaxTiles) return 0;
-  return std::max(8, (bits + 1) / 2);
-}
-static size_t radix_plan_workspace_bytes(int64_t n) {
-  const int db = rs_digit_bits(n);
-  if (db == 0) return 0;
-  const size_t hist = al256((size_t)(1 << db) * cdiv(n > 0 ? n : 1, kRsTile) * 4);
-  return 2 * hist + 2 * al256((size_t)n * 4) + 256;
-}
-static int radix_group_plan(const int32_t* rep, int64_t n, int32_t* grp_plan, void* ws, size_t ws_bytes, hipStream_t st) {
-  if (n == 0) return VC_OK;
-  if (ws_bytes < radix_plan_workspace_bytes(n)) { set_error("group plan (radix): workspace too small"); return VC_ECAPACITY; }
-  const int db = rs_digit_bits(n);
-  if (db == 0) { set_error("group plan (radix): tensor outside the hand-written sort"); return VC_EINVAL; }
-  const int nbins = 1 << db;
-  const int ntiles = (int)cdiv(n, kRsTile);
-  const size_t hbytes = al256((size_t)nbins * ntiles * 4), arr = al256((size_t)n * 4);
-  int32_t* hist0 = (int32_t*)ws;
-  int32_t* hist1 = (int32_t*)((char*)ws + hbytes);
-  uint32_t* kbuf = (uint32_t*)((char*)ws + 2 * hbytes);
-  int32_t* rbuf = (int32_t*)((char*)ws + 2 * hbytes + arr);
-  const size_t lds = (size_t)(5 * nbins + 8) * sizeof(int);
-  hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)ntiles), dim3(kRsThreads), 0, st, rep, n, nbins, hist0, hist1);
-  VC_CHECK_LAUNCH("radix_hist_kernel");
-  hipLaunchKernelGGL(radix_scatter_kernel, dim3((unsigned)ntiles), dim3(kRsThreads), lds, st, rep, (const uint32_t*)nullptr,
-                     (const int32_t*)nullptr, n, 0, db, nbins, ntiles, (const int32_t*)hist0, kbuf, rbuf, hist1);
-  VC_CHECK_LAUNCH("radix_scatter_kernel");
-  hipLaunchKernelGGL(radix_scatter_kernel, dim3((unsigned)ntiles), dim3(kRsThreads), lds, st, rep, (const uint32_t*)kbuf, (const int32_t*)rbuf,
-                     n, db, db, nbins, ntiles, (const int32_t*)hist1, (uint32_t*)(grp_plan + n), grp_plan, (int32_t*)nullptr);
-  VC_CHECK_LAUNCH("radix_scatter_kernel");
-  return VC_OK;
-}
+#ifdef VC_EXPERIMENTS
+#include "experiments/group_plan_radix.inc"
+#endif
 
 static inline int key_bits(int64_t n) {
   int b = 1;
@@ -459,12 +273,16 @@ static size_t rocprim_plan_workspace_bytes(int64_t n) {
   return ((temp + 255) & ~(size_t)255) + 2 * (((size_t)n * 4 + 255) & ~(size_t)255) + 256;
 }
 
-// The plan itself.  Default: the hand-written two-pass LDS radix sort above (3 launches; tensors up to 2 M rows / 22 key bits).
-// Otherwise (or vc_debug_set plan_radix_sort = 0): keys + row ids, then rocPRIM's device radix sort of the (key, row) pairs.
+// The plan itself: keys + row ids, then rocPRIM's device radix sort of the (key, row) pairs over the ceil(log2 n) significant bits.
+// (A hand-written two-pass LDS radix sort was built and measured slower on these key distributions: csrc/experiments/.)
 size_t vc_group_plan_workspace_bytes(int64_t n) {
   const size_t a = rocprim_plan_workspace_bytes(n);
   if (a == 0) return 0;
+#ifdef VC_EXPERIMENTS
   return std::max(a, radix_plan_workspace_bytes(n > 0 ? n : 1));   // either route fits (the switch is an A/B knob)
+#else
+  return a;
+#endif
 }
 
 int vc_group_plan(const int32_t* rep, int64_t n, int32_t* grp_plan, void* ws, size_t ws_bytes, void* stream) {
@@ -474,7 +292,9 @@ int vc_group_plan(const int32_t* rep, int64_t n, int32_t* grp_plan, void* ws, si
   const size_t need = vc_group_plan_workspace_bytes(n);
   if (need == 0 || ws_bytes < need) { set_error("vc_group_plan: workspace too small"); return VC_ECAPACITY; }
   hipStream_t st = (hipStream_t)stream;
+#ifdef VC_EXPERIMENTS
   if (g_group_plan_radix && rs_digit_bits(n) != 0) return radix_group_plan(rep, n, grp_plan, ws, ws_bytes, st);
+#endif
   const size_t arr = ((size_t)n * 4 + 255) & ~(size_t)255;
   uint32_t* keys_in = (uint32_t*)ws;
   int32_t* rows_in = (int32_t*)((char*)ws + arr);

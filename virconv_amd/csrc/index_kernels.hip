@@ -154,6 +154,7 @@ __global__ void __launch_bounds__(256) subm_rulebook_kernel(const int32_t* __res
 }
 
 // ------------------------------------------------------------------------------------------ K5 strided rulebook
+int g_sp_mark_variant = 2;   // vc_debug_set sp_mark_variant: 1 = sp_mark_kernel (27 offset tests + segmented scans), 2 = sp_mark2_kernel
 static constexpr int kWordsPerThread = 8;
 static constexpr int kWordsPerBlock = 256 * kWordsPerThread;
 
@@ -228,6 +229,82 @@ __global__ void __launch_bounds__(256) sp_mark_kernel(const int32_t* __restrict_
       const long long nw = __shfl_down(w, 1, 64);
       if (bits != 0ULL && (lane == 63 || nw != w)) atomicOr(&bitmap[w], bits);
     }
+  }
+}
+
+// sp_mark2_kernel (round 4): the same marking with the candidates enumerated from the OUTPUT side.  Along one axis an input
+// coordinate p reaches the output cells q = q0 - j, q0 = floor((p + pad) / stride), j = 0 .. J-1 with J = ceil(((k-1) d + 1) / s)
+// (<= 2 for the model's k = 3, s = 2 convs: 4 (z, y) combinations x 2 adjacent x cells instead of 27 offset tests, 3.4 of them
+// valid); the x cells of one combination are adjacent, so they are ONE word-and-mask (plus, rarely, a second one across a word
+// border).  Thread = row (256 rows per block).  Same-word atomics of a wave are merged where there is something to merge: the
+// lanes sharing the first pending lane's word OR their masks through a butterfly and one lane issues the atomic, twice (a wave of
+// x-consecutive rows spans one or two words); when the first lane shares its word with nobody -- rows in permuted order, the
+// training-time input of stages 2-4 after the layer discard -- every lane issues its own atomic at once.  The kernel above
+// folds runs with a 6-step segmented scan per offset, 27 times per row: 55 us per launch against the ~15 us of this one.
+static constexpr int kMarkJ = 4;   // candidates per axis this kernel serves (callers fall back to sp_mark_kernel beyond)
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v |= __shfl_xor(v, off, 64);
+  return v;
+}
+struct MarkAxis { int q0, valid; };   // valid: bit j set = cell q0 - j is a candidate
+__device__ __forceinline__ MarkAxis mark_axis(int p, int pad, int k, int s, int sh, int d, int out, int J) {
+  const int t = p + pad;                        // >= 0
+  MarkAxis a;
+  a.q0 = (sh >= 0) ? (t >> sh) : (t / s);
+  a.valid = 0;
+  for (int j = 0; j < J; ++j) {
+    const int q = a.q0 - j, o = t - q * s;      // o = kernel offset * dilation
+    if (q >= 0 && q < out && o % d == 0 && o / d < k) a.valid |= 1 << j;
+  }
+  return a;
+}
+__global__ void __launch_bounds__(256) sp_mark2_kernel(const int32_t* __restrict__ indices, int64_t n, int ndim, SpGeom g, int Jz, int Jy,
+                                                       int Jx, unsigned long long* __restrict__ bitmap, const int32_t* __restrict__ n_dev) {
+  if (n_dev != nullptr) {
+    const int64_t real = *n_dev;
+    if (real < n) n = real;
+  }
+  const int lane = threadIdx.x & 63;
+  for (int64_t base = (int64_t)blockIdx.x * 256; base < n; base += (int64_t)gridDim.x * 256) {
+    const int64_t i = base + threadIdx.x;
+    const bool live = i < n;
+    int b = 0, z = 0, y = 0, x = 0;
+    if (live) load_coord(indices, i, ndim, b, z, y, x);
+    const MarkAxis az = mark_axis(z, g.p[0], g.k[0], g.s[0], g.sh[0], g.d[0], g.Do, Jz);
+    const MarkAxis ay = mark_axis(y, g.p[1], g.k[1], g.s[1], g.sh[1], g.d[1], g.Ho, Jy);
+    const MarkAxis ax = mark_axis(x, g.p[2], g.k[2], g.s[2], g.sh[2], g.d[2], g.Wo, Jx);
+    for (int jz = 0; jz < Jz; ++jz)
+      for (int jy = 0; jy < Jy; ++jy) {
+        const bool on = live && ((az.valid >> jz) & 1) && ((ay.valid >> jy) & 1) && ax.valid != 0;
+        // cells (b, q0z - jz, q0y - jy, q0x - jx): the highest one decides the word, lower ones across a word border go to `lo`
+        const int64_t Lhi = (((int64_t)b * g.Do + (az.q0 - jz)) * g.Ho + (ay.q0 - jy)) * g.Wo + ax.q0;
+        const int64_t w = on ? (Lhi >> 6) : -1;
+        unsigned long long hi = 0ULL, lo = 0ULL;
+        if (on) {
+          const int bit = (int)(Lhi & 63);
+          for (int jx = 0; jx < Jx; ++jx)
+            if ((ax.valid >> jx) & 1) {
+              if (bit - jx >= 0) hi |= 1ULL << (bit - jx);
+              else lo |= 1ULL << (64 + bit - jx);
+            }
+        }
+        bool pending = hi != 0ULL;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const unsigned long long pm = __ballot(pending);
+          if (pm == 0ULL) break;
+          const int lead = __ffsll((long long)pm) - 1;
+          const long long wl = __shfl((long long)w, lead, 64);
+          const bool mine = pending && w == wl;
+          if (__popcll(__ballot(mine)) <= 1) break;      // nothing to merge: permuted rows
+          const unsigned long long all = wave_or64(mine ? hi : 0ULL);
+          if (lane == lead) atomicOr(&bitmap[wl], all);
+          if (mine) pending = false;
+        }
+        if (pending) atomicOr(&bitmap[w], hi);
+        if (lo != 0ULL) atomicOr(&bitmap[w - 1], lo);
+      }
   }
 }
 
@@ -1070,10 +1147,23 @@ static int spconv_mark_count(const int32_t* indices, int64_t n, const int32_t* n
   VC_REQUIRE(k.kv <= 128, "strided rulebook: kernel volume %d > 128", k.kv);
   SpGeom g = make_spgeom(o, k);
   if (n > 0) {
-    int64_t mark_blocks = cdiv(n, 64);
-    if (n_dev != nullptr && mark_blocks > 8192) mark_blocks = 8192;   // capacity launch: grid-stride inside the kernel
-    hipLaunchKernelGGL(sp_mark_kernel, dim3((unsigned)mark_blocks), dim3(256), 0, st, indices, n, ndim, g, bitmap, n_dev);
-    VC_CHECK_LAUNCH("sp_mark_kernel");
+    int J[3];
+    bool v2 = g_sp_mark_variant == 2;
+    for (int a = 0; a < 3; ++a) {
+      J[a] = ((k.k[a] - 1) * k.d[a] + 1 + k.s[a] - 1) / k.s[a];
+      if (J[a] > kMarkJ) v2 = false;
+    }
+    if (v2) {
+      int64_t mark_blocks = cdiv(n, 256);
+      if (n_dev != nullptr && mark_blocks > 4096) mark_blocks = 4096;   // capacity launch: grid-stride inside the kernel
+      hipLaunchKernelGGL(sp_mark2_kernel, dim3((unsigned)mark_blocks), dim3(256), 0, st, indices, n, ndim, g, J[0], J[1], J[2], bitmap, n_dev);
+      VC_CHECK_LAUNCH("sp_mark2_kernel");
+    } else {
+      int64_t mark_blocks = cdiv(n, 64);
+      if (n_dev != nullptr && mark_blocks > 8192) mark_blocks = 8192;   // capacity launch: grid-stride inside the kernel
+      hipLaunchKernelGGL(sp_mark_kernel, dim3((unsigned)mark_blocks), dim3(256), 0, st, indices, n, ndim, g, bitmap, n_dev);
+      VC_CHECK_LAUNCH("sp_mark_kernel");
+    }
   }
   hipLaunchKernelGGL(sp_blocksum_kernel, dim3((unsigned)nb), dim3(256), 0, st, bitmap, nwords, blocksum);
   VC_CHECK_LAUNCH("sp_blocksum_kernel");

@@ -17,7 +17,8 @@
 //   * parity_order_kernel: the active-offset set of an INPUT row of a strided conv is a function of its coordinate's residue
 //     modulo the stride (+ grid borders), so the backward row order is a stable counting sort on <= 16 residue classes per
 //     2048-row window, read from the coordinates alone (vc_row_order reads the 27-row table: 45 us -> 6 us per table);
-//   * the group plan's stable sort by representative is vc_group_plan's hand-written two-pass LDS radix sort (group_kernels.hip).
+//   * sp_mark2_kernel (index_kernels.hip): output cells enumerated from the output side, 8 candidates instead of 27 offset tests.
+// (A hand-written LDS radix sort for the group plans was built too and lost to rocPRIM on these keys: csrc/experiments/.)
 // Tables are bit-identical to the stand-alone operators on the same coordinates (tests/test_plan_gpu.py); row orders are hints.
 #include <algorithm>
 
@@ -517,7 +518,7 @@ static int block_tables(const vc_plan_desc* d, const PlanState& S, int b, const 
     }
     if (d->need_grad) {
       int32_t* gp = (int32_t*)(A.base + gpo);
-      rc = vc_group_plan(rep, n, gp, A.base + gwo, gw_bytes, st);   // hand-written LDS radix sort (group_kernels.hip)
+      rc = vc_group_plan(rep, n, gp, A.base + gwo, gw_bytes, st);
       if (rc != VC_OK) return rc;
     }
   }
