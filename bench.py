@@ -296,7 +296,10 @@ def _traced_roofline(trace, args, tdir, tck, tcn, pmc):
             "hbm_frac_of_algorithmic_bytes": round(byts / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
-def main():
+def main(argv=None, plumbing=False):
+    """`plumbing` (tests/test_bench_gloo.py only): run the same code path on the CPU with whatever operator backend the caller has
+    installed (the oracle) over `gloo` -- sharding, barrier, max-over-ranks timing, shutdown and the one JSON line are exercised
+    without a GPU; nothing about it is a measurement."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -318,7 +321,7 @@ def main():
     ap.add_argument("--frontend", action="store_true",
                     help="include the GPU data front-end (input point discard + LiDAR-first voxeliser + MeanVFE from raw "
                          "device-resident points) in every timed step (model L)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run
@@ -333,15 +336,21 @@ def main():
 
     rank, local_rank, world = parallel.init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N ranks, or run without a launcher)"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
-    device = torch.device("cuda", local_rank % torch.cuda.device_count())
-    torch.cuda.set_device(device)
-    numa = parallel.bind_to_gpu_numa(device.index)  # one process per GPU, on the cores next to that GPU
+    if plumbing:
+        device, numa = torch.device("cpu"), "plumbing test (cpu)"
+        sync = lambda: None   # noqa: E731
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+        device = torch.device("cuda", local_rank % torch.cuda.device_count())
+        torch.cuda.set_device(device)
+        numa = parallel.bind_to_gpu_numa(device.index)  # one process per GPU, on the cores next to that GPU
+        sync = torch.cuda.synchronize
     be = ops.get_backend()
     ops.MFMA_OPERAND = args.operand
     for kv_ in filter(None, os.environ.get("VIRCONV_DEBUG_SET", "").split(",")):   # A/B switches: "key=value,key=value" -> vc_debug_set
         key, val = kv_.split("=")
         assert be.lib.vc_debug_set(key.encode(), int(val)) == 0, kv_
+    can_trace = hasattr(be, "trace_begin")
 
     if args.model == "8x" and "--batch-size" not in " ".join(sys.argv):
         args.batch_size = 2                                        # VirConv-T.yaml: bs 2 per GPU
@@ -366,18 +375,19 @@ def main():
     ddp = parallel.wrap_ddp(model, device) if use_torch_ddp else model
     grad_sync = None if use_torch_ddp else parallel.FlatGradAllReduce(model)
     optimizer = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01,
-                                  fused=True)  # stock torch multi-tensor AdamW kernel (a16: optimizer stays stock torch)
+                                  fused=not plumbing)  # stock torch multi-tensor AdamW kernel (a16: optimizer stays stock torch)
     lw = make_loss_weights(device)
     torch.manual_seed(100 + rank)  # layer-discard permutations
     # the inputs are resident in HBM from here on: lets the backbone's geometry plan run ahead on its side stream
-    torch.cuda.synchronize()
-    batch["inputs_ready_event"] = torch.cuda.Event()
-    batch["inputs_ready_event"].record()
+    sync()
+    if not plumbing:
+        batch["inputs_ready_event"] = torch.cuda.Event()
+        batch["inputs_ready_event"].record()
 
-    # Setup (untimed, not a step): park a few GB of blocks in torch's caching allocator.  Layer discard is random, so
-    # tensor sizes differ from step to step and the first steps would otherwise pay hipMalloc for every new size.
-    prime = [torch.empty((1 << 30,), dtype=torch.uint8, device=device) for _ in range(8)]
-    del prime
+        # Setup (untimed, not a step): park a few GB of blocks in torch's caching allocator.  Layer discard is random, so
+        # tensor sizes differ from step to step and the first steps would otherwise pay hipMalloc for every new size.
+        prime = [torch.empty((1 << 30,), dtype=torch.uint8, device=device) for _ in range(8)]
+        del prime
 
     # Setup (untimed): take Python's cyclic garbage collector out of the loop.  `import torch` leaves ~10^6 long-lived container
     # objects behind; a full (generation-2) collection walks all of them (tens of ms), and WHEN the per-frame garbage triggers
@@ -396,11 +406,11 @@ def main():
     # Setup (untimed, not a step): a second of steady-state steps before the W warm-up steps (allocator, clocks).  Measured:
     # this does NOT remove the first-process-on-a-fresh-box penalty (7.5 ms vs 6.7-7.0 ms for later processes on the same
     # box, with or without 4 s of settling), whose cause is outside this process.
-    settle = float(os.environ.get("VIRCONV_SETTLE_SEC", "1.0"))
+    settle = 0.0 if plumbing else float(os.environ.get("VIRCONV_SETTLE_SEC", "1.0"))
     t_settle = time.perf_counter()
     while time.perf_counter() - t_settle < settle:
         train_step(ddp, optimizer, batch, lw, grad_sync, raw)
-        torch.cuda.synchronize()
+        sync()
 
     for _ in range(args.warmup):
         train_step(ddp, optimizer, batch, lw, grad_sync, raw)
@@ -409,40 +419,41 @@ def main():
         if os.environ.get(env):   # A/B switches of the feature pass, see virconv_amd/csrc/pass.hip
             assert be.lib.vc_debug_set(key, int(os.environ[env])) == 0
     tdir, tck, tcn = args.trace.split(",")
-    be.trace_begin(tdir, int(tck), int(tcn))
+    if can_trace:
+        be.trace_begin(tdir, int(tck), int(tcn))
     parallel.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         train_step(ddp, optimizer, batch, lw, grad_sync, raw)
-    torch.cuda.synchronize()
+    sync()
     parallel.barrier()
     dt = time.perf_counter() - t0
-    trace = be.trace_end()
+    trace = be.trace_end() if can_trace else []
     dt = parallel.max_over_ranks(dt, device)
 
     # Family- and step-level roofline (outside the timed region, rank 0): a few more steps with EVERY gather-GEMM and
     # weight-gradient launch bracketed by HIP events on its launch stream (vc_trace_begin direction -1)
     fam = None
-    if args.family_steps > 0:          # every rank steps (the gradient all-reduce is collective); rank 0 records
+    if args.family_steps > 0 and can_trace:          # every rank steps (the gradient all-reduce is collective); rank 0 records
         if rank == 0:
             be.trace_begin("all", 0, 0, max_records=256 * args.family_steps)
         for _ in range(args.family_steps):
             train_step(ddp, optimizer, batch, lw, grad_sync, raw)
-        torch.cuda.synchronize()
+        sync()
         if rank == 0:
             fam = be.trace_end()
     # The traced kernel also FINISHES the BatchNorm statistics of its output since round 3 (arrival tickets in its last blocks: a
     # 3-9 us tail that replaces two launches).  For a like-for-like number of the GEMM itself: the same kernel over a few more
     # steps with the sums left to the BatchNorm kernels (vc_debug_set conv_bn_finish = 0), outside the timed region.
     plain = None
-    if args.family_steps > 0 and args.operand == "f32":
+    if args.family_steps > 0 and args.operand == "f32" and can_trace:
         assert be.lib.vc_debug_set(b"conv_bn_finish", 0) == 0
         if rank == 0:
             be.trace_begin(tdir, int(tck), int(tcn))
         for _ in range(args.family_steps):
             train_step(ddp, optimizer, batch, lw, grad_sync, raw)
-        torch.cuda.synchronize()
+        sync()
         if rank == 0:
             plain = be.trace_end()
         assert be.lib.vc_debug_set(b"conv_bn_finish", 1) == 0

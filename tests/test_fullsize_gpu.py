@@ -534,6 +534,73 @@ def test_exact_bench_batch_bs4_train_step_vs_oracle(hip_backend, monkeypatch):
     print(f"[parity bench batch bs 4] loss {lh:.6f} vs {lo:.6f}; gradient vector |hip - oracle_f32| / |oracle_f32| = {rel:.2e}")
 
 
+def test_bench_train_step_itself_bs4_vs_float64_oracle_with_forced_masks(hip_backend, monkeypatch):
+    """Parity AT THE TIMED SHAPE THROUGH THE TIMED CODE: `bench.train_step` -- zero_grad, forward, the stand-in loss
+    through ops.weighted_sum, backward, clip_grad_norm_(10) (train_utils.py:50), AdamW step -- on the exact bench batch (frames 0-3,
+    133 578 input voxels, model seeded as bench.py seeds it, layer discard 0.1) against ONE float64 oracle run of the SAME
+    function on the CPU oracle backend, with the HIP run's keeps injected and its ReLU masks forced (so the bound needs no
+    allowance for pre-activations within rounding of zero; the masks themselves are compared with float64 ones at bs 2 above).
+    Bound per tensor, no allowance: clipped gradients <= 1e-4 * max|g| of the float64 ones; loss 1e-2 absolute; every updated
+    parameter within 1e-5 * max|p| + 1e-7.  Slow (minutes of CPU float64 on the host): kept in -m gpu on purpose."""
+    dev = torch.device("cuda", 0)
+    batch = bench.make_batch([0, 1, 2, 3], dev, training=True)
+    assert batch["voxel_features"].shape[0] > 120000
+    lw = bench.make_loss_weights(dev)
+    torch.manual_seed(0)
+    model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).to(dev).train()
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, fused=True)
+    rec = _record_discards(monkeypatch)
+    torch.manual_seed(100)
+    loss_h = float(bench.train_step(model, opt, batch, lw).detach())          # THE timed function
+    torch.cuda.synchronize()
+    keeps = dict(rec)
+    assert set(keeps) == {"x_conv1", "x_conv2", "x_conv3"}
+    grads_h = {k: p.grad.detach().cpu().double().numpy() for k, p in model.named_parameters()}
+    params_h = {k: p.detach().cpu().double().numpy() for k, p in model.named_parameters()}
+    # the HIP masks (node-by-node rerun, bit-identical to the native pass) ...
+    bh = dict(batch)
+    bh["layer_discard_keep"] = {k: v.to(dev) for k, v in keeps.items()}
+    masks_h, _ = _hip_masks(hip_backend, VirConvL8x, bench.MODEL_CFG, state, bh, lw, monkeypatch)
+    # ... forced on the float64 oracle run of the same function
+    m64 = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).train().double()
+    m64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in state.items()})
+    o64 = torch.optim.AdamW(m64.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01)
+    b64 = {}
+    for k, v in batch.items():
+        if torch.is_tensor(v):
+            v = v.cpu()
+            if v.is_floating_point() and not k.startswith("voxel_coords"):
+                v = v.double()
+        b64[k] = v
+    b64.pop("inputs_ready_event", None)
+    b64["layer_discard_keep"] = keeps
+    lw64 = {k: v.cpu().double() for k, v in lw.items()}
+    with ops.use_backend(OracleBackend()), ReluMasks(forced=masks_h):
+        loss_o = float(bench.train_step(m64, o64, b64, lw64).detach())
+    assert abs(loss_h - loss_o) <= 1e-2, (loss_h, loss_o)
+    rows, worst_g, worst_p = [], 0.0, 0.0
+    for k, p in m64.named_parameters():
+        g = p.grad.detach().numpy()
+        scale = max(float(np.abs(g).max()), 1e-12)
+        e = float(np.abs(grads_h[k] - g).max()) / scale
+        worst_g = max(worst_g, e)
+        pp = p.detach().numpy()
+        ep = float(np.abs(params_h[k] - pp).max())
+        worst_p = max(worst_p, ep / (1e-5 * max(float(np.abs(pp).max()), 1e-12) + 1e-7))
+        rows.append(f"{k:34s} n={g.size:7d} max|g|={scale:9.3e} hip-f64={e:8.2e} param diff={ep:8.2e} {'ok' if e <= 1e-4 else 'FAIL'}")
+    rows.append(f"bench.train_step bs 4: loss {loss_h:.6f} vs {loss_o:.6f}; worst clipped-gradient error {worst_g:.2e} of max (bound 1e-4); "
+                f"worst updated-parameter error {worst_p:.2f} of its bound")
+    import os
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "parity_bench_train_step_bs4.txt"), "w") as fh_:
+        fh_.write("\n".join(rows) + "\n")
+    print(rows[-1])
+    assert worst_g <= 1e-4, rows
+    assert worst_p <= 1.0, rows
+
+
 def test_fullsize_virconv8x_train_vs_oracle(hip_backend, monkeypatch):
     """BASELINE configs[3] backbone shape: VirConv8x (LiDAR stream + MM stream), train, bs 2, 16 000 + 16 000 voxels per
     frame, layer discard 0.15 (injected), plan-ahead: outputs and every gradient vs the oracle.
