@@ -541,7 +541,10 @@ def test_bench_train_step_itself_bs4_vs_float64_oracle_with_forced_masks(hip_bac
     function on the CPU oracle backend, with the HIP run's keeps injected and its ReLU masks forced (so the bound needs no
     allowance for pre-activations within rounding of zero; the masks themselves are compared with float64 ones at bs 2 above).
     Bound per tensor, no allowance: clipped gradients <= 1e-4 * max|g| of the float64 ones; loss 1e-2 absolute; every updated
-    parameter within 1e-5 * max|p| + 1e-7.  Slow (minutes of CPU float64 on the host): kept in -m gpu on purpose."""
+    parameter equals the AdamW formula applied in float64 to the step's OWN (HIP) gradient within 1e-3 * lr + fp32 rounding of p.
+    (Updated parameters are not compared entry-wise with the float64 run: the first AdamW step moves an entry by
+    lr * g / (|g| + 1e-8), so an entry whose gradient is within rounding of zero has no determined direction -- measured up to
+    0.12 * lr on one of 110 592 entries while every gradient agrees to 2.7e-6 of max.)  Slow (minutes of CPU float64 on the host): kept in -m gpu on purpose."""
     dev = torch.device("cuda", 0)
     batch = bench.make_batch([0, 1, 2, 3], dev, training=True)
     assert batch["voxel_features"].shape[0] > 120000
@@ -587,8 +590,10 @@ def test_bench_train_step_itself_bs4_vs_float64_oracle_with_forced_masks(hip_bac
         worst_g = max(worst_g, e)
         pp = p.detach().numpy()
         ep = float(np.abs(params_h[k] - pp).max())
-        worst_p = max(worst_p, ep / (1e-5 * max(float(np.abs(pp).max()), 1e-12) + 1e-7))
-        rows.append(f"{k:34s} n={g.size:7d} max|g|={scale:9.3e} hip-f64={e:8.2e} param diff={ep:8.2e} {'ok' if e <= 1e-4 else 'FAIL'}")
+        p0 = state[k].double().numpy()
+        want = p0 * (1.0 - 1e-3 * 0.01) - 1e-3 * grads_h[k] / (np.abs(grads_h[k]) + 1e-8)      # AdamW, step 1: m^ = g, v^ = g^2
+        worst_p = max(worst_p, float((np.abs(params_h[k] - want) / (1e-3 * 1e-3 + 2e-7 * np.abs(want))).max()))
+        rows.append(f"{k:34s} n={g.size:7d} max|g|={scale:9.3e} hip-f64={e:8.2e} vs f64 params={ep:8.2e} {'ok' if e <= 1e-4 else 'FAIL'}")
     rows.append(f"bench.train_step bs 4: loss {loss_h:.6f} vs {loss_o:.6f}; worst clipped-gradient error {worst_g:.2e} of max (bound 1e-4); "
                 f"worst updated-parameter error {worst_p:.2f} of its bound")
     import os
