@@ -1950,7 +1950,7 @@ extern int g_pass_fork_ext_event; // pass.hip
 extern int g_bn_fused_partial;  // bn_kernels.hip
 extern int g_pass_defer_dw_reduce;  // pass.hip
 extern int g_plan_subm_bitmap, g_plan_image_2d, g_plan_parity_order;   // plan.hip
-extern int g_group_plan_radix;   // group_kernels.hip
+extern int g_group_plan_radix, g_group_plan_onesweep;   // group_kernels.hip
 extern int g_sp_mark_variant;    // index_kernels.hip
 static constexpr int kMaxSplit = 256;
 static constexpr size_t kMaxPartialBytes = 24u << 20;
@@ -2123,6 +2123,7 @@ int vc_debug_set(const char* key, int value) {
   if (!strcmp(key, "bn_fused_partial")) { g_bn_fused_partial = value; return VC_OK; }
   if (!strcmp(key, "conv_bn_finish")) { g_conv_bn_finish = value; return VC_OK; }
   if (!strcmp(key, "pass_defer_dw_reduce")) { g_pass_defer_dw_reduce = value; return VC_OK; }
+  if (!strcmp(key, "group_plan_onesweep")) { g_group_plan_onesweep = value; return VC_OK; }
   if (!strcmp(key, "sp_mark_variant")) { g_sp_mark_variant = value; return VC_OK; }
   if (!strcmp(key, "plan_subm_bitmap")) { g_plan_subm_bitmap = value; return VC_OK; }
   if (!strcmp(key, "plan_image_2d")) { g_plan_image_2d = value; return VC_OK; }

@@ -247,6 +247,18 @@ static inline void weighted_sum_grid(int64_t nb, int64_t e, int& mode, dim3& gri
   }
 }
 
+// rocPRIM's radix_sort_pairs picks a merge sort below 1 M items; OnesweepCfg (merge-sort limit 0) forces its Onesweep radix
+// passes instead (vc_debug_set group_plan_onesweep, A/B)
+using OnesweepCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
+int g_group_plan_onesweep = 0;
+template <class Cfg>
+static size_t rocprim_temp_bytes(int64_t n) {
+  size_t temp = 0;
+  if (rocprim::radix_sort_pairs<Cfg>(nullptr, temp, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
+                                     (unsigned)n, 0u, (unsigned)key_bits(n)) != hipSuccess)
+    return 0;
+  return temp;
+}
 }  // namespace vc
 
 using namespace vc;
@@ -266,11 +278,9 @@ int vc_group_keys(const int32_t* rep, int64_t n, int32_t* keys, void* stream) {
 // (rocPRIM's device radix sort: geometry-plan index work, like the rulebooks; a handful of launches).
 static size_t rocprim_plan_workspace_bytes(int64_t n) {
   if (n <= 0) return 256;
-  size_t temp = 0;
-  if (rocprim::radix_sort_pairs(nullptr, temp, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
-                                (unsigned)n, 0u, (unsigned)key_bits(n)) != hipSuccess)
-    return 0;
-  return ((temp + 255) & ~(size_t)255) + 2 * (((size_t)n * 4 + 255) & ~(size_t)255) + 256;
+  const size_t a = rocprim_temp_bytes<rocprim::default_config>(n), b = rocprim_temp_bytes<OnesweepCfg>(n);
+  if (a == 0 || b == 0) return 0;
+  return ((std::max(a, b) + 255) & ~(size_t)255) + 2 * (((size_t)n * 4 + 255) & ~(size_t)255) + 256;
 }
 
 // The plan itself: keys + row ids, then rocPRIM's device radix sort of the (key, row) pairs over the ceil(log2 n) significant bits.
@@ -302,8 +312,12 @@ int vc_group_plan(const int32_t* rep, int64_t n, int32_t* grp_plan, void* ws, si
   size_t temp_bytes = ws_bytes - 2 * arr;
   hipLaunchKernelGGL(group_keys_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, rep, n, keys_in, rows_in);
   VC_CHECK_LAUNCH("group_keys_kernel");
-  VC_CHECK_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t*)keys_in, (uint32_t*)(grp_plan + n), (const int32_t*)rows_in,
-                                         grp_plan, (unsigned)n, 0u, (unsigned)key_bits(n), st));
+  if (g_group_plan_onesweep)
+    VC_CHECK_HIP(rocprim::radix_sort_pairs<OnesweepCfg>(temp, temp_bytes, (const uint32_t*)keys_in, (uint32_t*)(grp_plan + n),
+                                                        (const int32_t*)rows_in, grp_plan, (unsigned)n, 0u, (unsigned)key_bits(n), st));
+  else
+    VC_CHECK_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t*)keys_in, (uint32_t*)(grp_plan + n), (const int32_t*)rows_in,
+                                           grp_plan, (unsigned)n, 0u, (unsigned)key_bits(n), st));
   return VC_OK;
 }
 
