@@ -203,3 +203,31 @@ def test_train_step_with_the_native_plan_matches_the_operator_by_operator_plan(h
         assert torch.equal(g_py[k], g_n0[k]), k
         scale = float(g_py[k].abs().max()) + 1e-30
         assert float((g_py[k] - g_n1[k]).abs().max()) <= 1e-5 * scale, k
+
+
+def test_native_plan_of_virconv8x_equals_the_operator_by_operator_plan(hip_backend, monkeypatch):
+    """VirConv8x, training (spconv_backbone.py:339-535): the LiDAR stream (conv_input / conv1..4 / conv_out: one SubM table per
+    stage, no image-space branch) and the virtual-point stream (input discard :488-489 + four NRConvBlocks + layer discards) are
+    one native chain plan each; every structure equals the operator-by-operator plan's."""
+    from virconv_amd.backbone import VirConv8x
+    dev = torch.device("cuda", 0)
+    batch = bench.make_batch_8x([0, 1], dev)
+    model = VirConv8x(bench.MODEL_CFG_8X, 8, synth.GRID_SIZE).cuda().train()
+    assert model._discard_active() and model.mm
+    plans = []
+    for native in (True, False):
+        monkeypatch.setattr(native_plan, "NATIVE_PLAN", native)
+        torch.manual_seed(9)
+        p = model.build_plan(batch, [""], 2, batch["calib"])
+        torch.cuda.synchronize()
+        assert ("_arenas" in p) == native
+        plans.append(p)
+    pn, pp = plans
+    (idx_n, rbs_n), (idx_p, rbs_p) = pn["lidar"][""], pp["lidar"][""]
+    assert torch.equal(idx_n, idx_p) and rbs_n.keys() == rbs_p.keys()
+    for key in rbs_n:
+        _assert_same_rulebook(rbs_n[key], rbs_p[key], f"lidar {key}")
+    mn, mp_ = pn["mm"][""], pp["mm"][""]
+    assert torch.equal(mn["keep0"], mp_["keep0"]) and torch.equal(mn["in_indices"], mp_["in_indices"])
+    _assert_same_plan({"in_indices": mn["in_indices"], "stages": mn["stages"], "conv_out": {}},
+                      {"in_indices": mp_["in_indices"], "stages": mp_["stages"], "conv_out": {}}, "8x mm")

@@ -611,10 +611,25 @@ class VirConv8x(nn.Module):
 
     # ---- geometry plan (same idea as VirConvL8x.build_plan): every rulebook of both streams, the eval-time slab splits and
     # the discard permutations are functions of the coordinates only and are built first, on the plan stream
-    def _plan_lidar(self, idx, shape, batch_size):
-        """{indice_key: Rulebook} of the LiDAR stream + the coordinates of x3, x4 and the output."""
+    def _plan_lidar(self, idx, shape, batch_size, batch_dict=None, arenas=None):
+        """{indice_key: Rulebook} of the LiDAR stream + the coordinates of x2, x3, x4 and the output.  One native chain plan (three
+        C calls, one count read: native_plan.build_chain) when available, operator by operator otherwise."""
+        first, co = self.conv_input[0], self.conv_out[0]
+        stages = (self.conv2, self.conv3, self.conv4)
+        if batch_dict is not None and list(shape) == list(self.sparse_shape) and native_plan.usable(idx):
+            chain = [native_plan.ChainBlock(None, first)] + [native_plan.ChainBlock(seq[0][0], seq[1][0]) for seq in stages]
+            res, rb_tail, _, _, ar = native_plan.build_chain(self, "8x-lidar", chain, co, idx, batch_size, None, None, [None] * 4, 0.0,
+                                                             batch_dict, NRConvBlock.IMAGE_SHAPE)
+            if arenas is not None:
+                arenas.extend(ar)
+            rbs, coords = {first.indice_key: res[0]["subm3d"]}, {}
+            for name, seq, r in zip(("x2", "x3", "x4"), stages, res[1:]):
+                rbs[seq[0][0].indice_key], rbs[seq[1][0].indice_key] = r["down"], r["subm3d"]
+                coords[name] = (r["out_indices"], list(r["out_shape"]))
+            rbs[co.indice_key] = rb_tail
+            coords["out"] = (rb_tail.out_indices, list(rb_tail.out_shape))
+            return rbs, coords
         rbs = {}
-        first = self.conv_input[0]
         rbs[first.indice_key] = ops.build_subm_rulebook(idx, shape, first.kernel_size, first.dilation, False)
         cur, cur_shape, coords = idx, list(shape), {}
         for name, seq in (("x2", self.conv2), ("x3", self.conv3), ("x4", self.conv4)):
@@ -624,7 +639,6 @@ class VirConv8x(nn.Module):
             cur, cur_shape = rb.out_indices, list(rb.out_shape)
             rbs[subm.indice_key] = ops.build_subm_rulebook(cur, cur_shape, subm.kernel_size, subm.dilation, False)
             coords[name] = (cur, cur_shape)
-        co = self.conv_out[0]
         rb = ops.build_sparse_rulebook(cur, cur_shape, batch_size, co.kernel_size, co.stride, co.padding, co.dilation)
         rbs[co.indice_key] = rb
         coords["out"] = (rb.out_indices, list(rb.out_shape))
@@ -644,13 +658,18 @@ class VirConv8x(nn.Module):
     def build_plan(self, batch_dict, rids, batch_size, calib):
         ref = batch_dict["voxel_coords"]
         plan = {"lidar": {}, "split": {}, "mm": {}}
+        arenas, native_only = [], True     # every structure of a native chain plan is a view of one of its two arenas
         with _PlanScope(ref, batch_dict) as scope:
             if self.training:
                 for rid in rids:
                     idx = batch_dict["voxel_coords" + rid].int()
-                    rbs, _ = self._plan_lidar(idx, self.sparse_shape, batch_size)
+                    n0 = len(arenas)
+                    rbs, _ = self._plan_lidar(idx, self.sparse_shape, batch_size, batch_dict, arenas)
+                    native_only = native_only and len(arenas) > n0
+                    arenas.append(idx)
                     plan["lidar"][rid] = (idx, rbs)
             else:
+                native_only = False
                 coords = []
                 for i, rid in enumerate(rids):
                     c = batch_dict["voxel_coords" + rid].clone()
@@ -667,17 +686,30 @@ class VirConv8x(nn.Module):
                 active = self._discard_active()
                 for i, rid in enumerate(rids):
                     idx = batch_dict["voxel_coords_mm" + rid].int()
-                    keep0 = None
-                    if active:  # the MM stream also discards its input (spconv_backbone.py:488-489)
-                        keep0 = _draw_keep(self.layer_discard_rate, idx.shape[0], batch_dict, f"mm_input{rid}", idx.device)
-                        _, idx = ops.get_backend().gather_rows(None, idx, keep0)
                     trans_param = batch_dict.get("aug_param")
                     if "transform_param" in batch_dict:
                         trans_param = batch_dict["transform_param"][:, i, :]
                     tags = [f"mm_x_conv{bi + 1}{rid}" if (bi < 3 and active) else None for bi in range(4)]
+                    if native_plan.usable(idx, blocks):
+                        # input discard (spconv_backbone.py:488-489) + the four blocks + their layer discards: one native chain plan
+                        stages, _, keep0, kept0, ar = native_plan.build(self, blocks, None, idx, batch_size, calib, trans_param, tags,
+                                                                        self.layer_discard_rate, batch_dict, NRConvBlock.IMAGE_SHAPE,
+                                                                        input_discard_tag=(f"mm_input{rid}" if active else None))
+                        arenas.extend(ar)
+                        arenas.append(idx)
+                        plan["mm"][rid] = {"keep0": keep0, "in_indices": kept0 if active else idx, "stages": stages,
+                                           "trans_param": trans_param}
+                        continue
+                    native_only = False
+                    keep0 = None
+                    if active:  # the MM stream also discards its input (spconv_backbone.py:488-489)
+                        keep0 = _draw_keep(self.layer_discard_rate, idx.shape[0], batch_dict, f"mm_input{rid}", idx.device)
+                        _, idx = ops.get_backend().gather_rows(None, idx, keep0)
                     stages, _, _, _ = _plan_nrconv_chain(blocks, idx, list(self.sparse_shape), batch_size, calib, trans_param,
                                                          tags, self.layer_discard_rate, batch_dict)
                     plan["mm"][rid] = {"keep0": keep0, "in_indices": idx, "stages": stages, "trans_param": trans_param}
+            if native_only and arenas:
+                plan["_arenas"] = arenas
         return scope.publish(plan)
 
     @staticmethod

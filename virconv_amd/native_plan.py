@@ -30,35 +30,52 @@ def _conv_geom(dst: _lib.PlanConv, conv) -> None:
         dst.padding[a], dst.dilation[a] = int(conv.padding[a]), int(conv.dilation[a])
 
 
-def _static_desc(blocks, tail, sparse_shape, image_shape) -> _lib.PlanDesc:
+class ChainBlock:
+    """One block of a chain: an optional strided conv (`down`), the 3-D SubM conv whose rulebook the block's SubM convs share
+    (`subm`), and optionally the image-space branch (`conv2d` + the index2uv stride)."""
+    __slots__ = ("down", "subm", "conv2d", "uv_stride")
+
+    def __init__(self, down, subm, conv2d=None, uv_stride=1):
+        self.down, self.subm, self.conv2d, self.uv_stride = down, subm, conv2d, int(uv_stride)
+
+
+def nrconv_blocks(blocks):
+    """[(NRConvBlock, uv stride)] -> [ChainBlock]"""
+    return [ChainBlock(blk.down_layer[0] if blk.stride > 1 else None, blk.d3_conv1[0], blk.d2_conv1[0], uv) for blk, uv in blocks]
+
+
+def _static_desc(chain, tail, sparse_shape, image_shape) -> _lib.PlanDesc:
     d = _lib.PlanDesc()
-    d.n_blocks = len(blocks)
+    d.n_blocks = len(chain)
     for a in range(3):
         d.spatial_shape[a] = int(sparse_shape[a])
     d.image_shape[0], d.image_shape[1] = int(image_shape[0]), int(image_shape[1])
-    for b, (blk, uv_stride) in enumerate(blocks):
+    for b, cb in enumerate(chain):
         B = d.blocks[b]
-        B.has_down = 1 if blk.stride > 1 else 0
-        if blk.stride > 1:
-            _conv_geom(B.down, blk.down_layer[0])
-        c3, c2 = blk.d3_conv1[0], blk.d2_conv1[0]
+        B.has_down = 1 if cb.down is not None else 0
+        if cb.down is not None:
+            _conv_geom(B.down, cb.down)
         for a in range(3):
-            B.subm_ksize[a], B.subm_dilation[a] = int(c3.kernel_size[a]), int(c3.dilation[a])
-        B.has_2d, B.uv_stride = 1, int(uv_stride)
-        for a in range(2):
-            B.ksize2d[a], B.dilation2d[a] = int(c2.kernel_size[a]), int(c2.dilation[a])
+            B.subm_ksize[a], B.subm_dilation[a] = int(cb.subm.kernel_size[a]), int(cb.subm.dilation[a])
+        B.has_2d, B.uv_stride = (1 if cb.conv2d is not None else 0), cb.uv_stride
+        if cb.conv2d is not None:
+            for a in range(2):
+                B.ksize2d[a], B.dilation2d[a] = int(cb.conv2d.kernel_size[a]), int(cb.conv2d.dilation[a])
     d.has_tail = 1 if tail is not None else 0
     if tail is not None:
         _conv_geom(d.tail, tail)
     return d
 
 
-def usable(coords: torch.Tensor, blocks) -> bool:
+def usable(coords: torch.Tensor, blocks=None) -> bool:
     be = ops.get_backend()
     from .backbone import FAST_RANDOM_KEEP
-    return bool(NATIVE_PLAN and getattr(be, "native_plan", False) and coords.is_cuda and coords.shape[0] > 0 and FAST_RANDOM_KEEP
-                and ops.ROW_ORDER in ("bwd", "strided") and not ops.WINDOW_GATHER and len(blocks) <= _lib.PLAN_MAX_BLOCKS
-                and all(not blk.conv_depth and blk.d3_conv1[0].ndim == 3 and blk.d2_conv1[0].ndim == 2 for blk, _ in blocks))
+    ok = bool(NATIVE_PLAN and getattr(be, "native_plan", False) and coords.is_cuda and coords.shape[0] > 0 and FAST_RANDOM_KEEP
+              and ops.ROW_ORDER in ("bwd", "strided") and not ops.WINDOW_GATHER)
+    if ok and blocks is not None:
+        ok = len(blocks) <= _lib.PLAN_MAX_BLOCKS and all(not blk.conv_depth and blk.d3_conv1[0].ndim == 3 and blk.d2_conv1[0].ndim == 2
+                                                         for blk, _ in blocks)
+    return ok
 
 
 def _view(arenas, v: _lib.PlanView, external=None):
@@ -96,22 +113,23 @@ def _table(arenas, t: _lib.PlanTableOut, kind, in_shape, conv, in_idx) -> ops.Ru
     return rb
 
 
-def build(model, blocks, tail, idx: torch.Tensor, batch_size: int, calib, trans_param, discard_tags, rate: float, batch_dict,
-          image_shape, input_discard_tag=None):
-    """-> (stages, tail Rulebook | None, input keep | None, kept input indices | None, [arena_a, arena_b]) for the chain `blocks`
-    (+ `tail`: the strided conv behind it) over the coordinates `idx` (N, 4) int32; `discard_tags[b]`: the batch_dict tag of
-    the layer discard after block b or None; `input_discard_tag`: discard of the chain's input (VirConv8x MM stream)."""
+def build_chain(model, kind: str, chain, tail, idx: torch.Tensor, batch_size: int, calib, trans_param, discard_tags, rate: float,
+                batch_dict, image_shape, input_discard_tag=None):
+    """The native plan of a chain of ChainBlocks (+ `tail`: the strided conv behind it) over the coordinates `idx` (N, 4) int32.
+    `discard_tags[b]`: the batch_dict tag of the layer discard after block b or None; `input_discard_tag`: discard of the chain's
+    input (VirConv8x MM stream).  `kind`: cache key of the chain's static description on `model`.
+    -> (per block: {"down", "subm3d", "uv", "subm2d", "out_indices", "out_shape", "keep", "kept_indices"}, tail Rulebook | None,
+        input keep | None, kept input indices | None, [arena_a, arena_b])"""
     be = ops.get_backend()
     lib = be.lib
     dev = idx.device
-    key = (len(blocks), tail is not None)
     cache = _DESCS.setdefault(model, {})
-    if key not in cache:
-        cache[key] = _static_desc(blocks, tail, model.sparse_shape, image_shape)
-    d = cache[key]
+    if kind not in cache:
+        cache[kind] = _static_desc(chain, tail, model.sparse_shape, image_shape)
+    d = cache[kind]
     hold = [idx, calib]
     d.indices, d.n, d.batch_size = idx.data_ptr(), idx.shape[0], int(batch_size)
-    d.calib = calib.data_ptr()
+    d.calib = calib.data_ptr() if calib is not None else None
     if trans_param is not None:
         trans_param = torch.as_tensor(trans_param, dtype=torch.float32, device=dev).reshape(batch_size, 3).contiguous()
         hold.append(trans_param)
@@ -168,29 +186,49 @@ def build(model, blocks, tail, idx: torch.Tensor, batch_size: int, calib, trans_
                "vc_plan_finish")
     del hold
     arenas = (arena_a, arena_b)
-    stages = []
+    res = []
     in_keep = in_kept = None
     cur_idx, shape = idx, list(model.sparse_shape)
     if input_discard_tag is not None:
         in_keep, in_kept = _keep_view(arenas, out.input_keep), _view(arenas, out.input_kept_indices)
         cur_idx = in_kept
-    for b, ((blk, _), tag) in enumerate(zip(blocks, discard_tags)):
+    for b, (cb, tag) in enumerate(zip(chain, discard_tags)):
         O = out.blocks[b]
+        r = {"down": None, "uv": None, "subm2d": None, "keep": None}
+        if cb.down is not None:
+            r["down"] = _table(arenas, O.down, "sparse", shape, cb.down, cur_idx)
+            cur_idx, shape = r["down"].out_indices, list(r["down"].out_shape)
+        r["subm3d"] = _table(arenas, O.subm3d, "subm", shape, cb.subm, cur_idx)
+        if cb.conv2d is not None:
+            r["uv"] = _view(arenas, O.uv)
+            r["subm2d"] = _table(arenas, O.subm2d, "subm", image_shape, cb.conv2d, r["uv"])
+        r["out_indices"], r["out_shape"] = cur_idx, shape
+        if tag is not None:
+            r["keep"] = _keep_view(arenas, O.keep)
+            r["kept_indices"] = _view(arenas, O.kept_indices)
+            cur_idx = r["kept_indices"]
+        res.append(r)
+    rb_tail = _table(arenas, out.tail, "sparse", shape, tail, cur_idx) if tail is not None else None
+    return res, rb_tail, in_keep, in_kept, [arena_a, arena_b]
+
+
+def build(model, blocks, tail, idx: torch.Tensor, batch_size: int, calib, trans_param, discard_tags, rate: float, batch_dict,
+          image_shape, input_discard_tag=None):
+    """The plan of a chain of NRConvBlocks `blocks` = [(block, uv stride)] in the form backbone._plan_nrconv_chain returns:
+    -> (stages, tail Rulebook | None, input keep | None, kept input indices | None, [arena_a, arena_b])."""
+    res, rb_tail, in_keep, in_kept, arenas = build_chain(model, ("nrconv", len(blocks), tail is not None, input_discard_tag is not None),
+                                                         nrconv_blocks(blocks), tail, idx, batch_size, calib, trans_param,
+                                                         discard_tags, rate, batch_dict, image_shape, input_discard_tag)
+    stages = []
+    for (blk, _), r in zip(blocks, res):
         kd, k3, k2 = blk._keys()
         rbs3 = {}
-        if blk.stride > 1:
-            rb = _table(arenas, O.down, "sparse", shape, blk.down_layer[0], cur_idx)
-            rbs3[kd] = rb
-            cur_idx, shape = rb.out_indices, list(rb.out_shape)
-        rb3 = _table(arenas, O.subm3d, "subm", shape, blk.d3_conv1[0], cur_idx)
-        rbs3[k3] = rb3
-        uv = _view(arenas, O.uv)
-        rb2 = _table(arenas, O.subm2d, "subm", image_shape, blk.d2_conv1[0], uv)
-        st_ = {"rb3d": rbs3, "uv": uv, "rb2d": {k2: rb2}, "out_indices": cur_idx, "out_shape": shape, "keep": None}
-        if tag is not None:
-            st_["keep"] = _keep_view(arenas, O.keep)
-            st_["kept_indices"] = _view(arenas, O.kept_indices)
-            cur_idx = st_["kept_indices"]
+        if r["down"] is not None:
+            rbs3[kd] = r["down"]
+        rbs3[k3] = r["subm3d"]
+        st_ = {"rb3d": rbs3, "uv": r["uv"], "rb2d": {k2: r["subm2d"]}, "out_indices": r["out_indices"], "out_shape": r["out_shape"],
+               "keep": r["keep"]}
+        if r["keep"] is not None:
+            st_["kept_indices"] = r["kept_indices"]
         stages.append(st_)
-    rb_tail = _table(arenas, out.tail, "sparse", shape, tail, cur_idx) if tail is not None else None
-    return stages, rb_tail, in_keep, in_kept, [arena_a, arena_b]
+    return stages, rb_tail, in_keep, in_kept, arenas
