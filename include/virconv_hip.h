@@ -518,6 +518,20 @@ size_t vc_nms_workspace_bytes(int64_t n);
 int vc_nms(const float* boxes, int64_t n, float thresh, int rotated, int64_t* keep, int64_t* num_out, void* ws, size_t ws_bytes,
            void* stream);
 
+/* ------------------------------------------------------------------------------------------------ f3: first BEV conv on the sparse rows
+ * SURVEY 8f rank 3, "fused": ZeroPad2d(1) + Conv2d(C*D -> 64, k3) of BaseBEVBackbone's first block (base_bev_backbone.py:31-38) over
+ * the map HeightCompression builds (height_compression.py:27-31) is a sparse conv from the encoded tensor's (b, z, y, x) rows onto
+ * the (b, y, x) cells with kernel (D, ky, kx): offset (z, a, c) of cell (y, x) reads the voxel at height z of (y + a - ky/2,
+ * x + c - kx/2).  vc_bev_pairs writes that pair table, (D * ky * kx, B * H * W) int32, for EVERY cell in dense (b, y, x) order
+ * (ws: B * D * H * W int32 row-id volume): no compaction and no count read; vc_conv_forward / vc_conv_backward_input over it
+ * produce the NHWC map directly (cells that see no voxel cost a table read).  vc_nhwc_to_nchw turns (B * HW, C) rows into the
+ * (B, C, HW) map, optionally with y = x * scale[c] + shift[c] (the BatchNorm2d behind the conv, :37) and a ReLU (:38).     */
+size_t vc_bev_pairs_workspace_bytes(int batch_size, const int32_t* host_spatial_shape /* D, H, W */);
+int vc_bev_pairs(const int32_t* indices, int64_t n, int batch_size, const int32_t* host_spatial_shape, int ky, int kx, int32_t* pair,
+                 void* ws, size_t ws_bytes, void* stream);
+int vc_nhwc_to_nchw(const float* x, int batch_size, int64_t hw, int c, const float* scale /* nullable */, const float* shift,
+                    int relu, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ geometry plan
  * Every index structure of a chain of NRConvBlocks (spconv_backbone.py:150-229) -- per block: the strided-conv rulebook of its
  * down_layer (:164-171) with the block's output coordinates, the 3-D SubM rulebook shared by d3_conv1/2 (:186,199), the pixel

@@ -121,3 +121,90 @@ def test_bev_stem_on_hip_equals_the_oracle_recipe(hip_backend):
     got = fused.cpu().numpy()
     err = np.abs(got - want)
     assert np.all(err <= 1e-4 * np.abs(want) + 1e-5 * max(1.0, np.abs(want).max())), float(err.max())
+
+
+# ------------------------------------------------------------------------------------------------ f3 for real: the sparse stem
+class _TinyBEV(nn.Module):
+    """BaseBEVBackbone's `blocks` (base_bev_backbone.py:29-45) restated: what adapt_bev_backbone touches."""
+
+    def __init__(self):
+        super().__init__()
+        blk = list(_first_block())
+        blk += [nn.Conv2d(64, 64, 3, padding=1, bias=False), nn.BatchNorm2d(64, eps=1e-3, momentum=0.01), nn.ReLU()]
+        self.blocks = nn.ModuleList([nn.Sequential(*blk)])
+
+    def forward(self, x):
+        return self.blocks[0](x)
+
+
+def test_sparse_stem_adaptation_keeps_parameters_and_results_on_the_cpu(oracle_backend):
+    """adapt_bev_backbone(sparse_stem=True): same state_dict keys, the parameters still belong to the BEV backbone, and on a backend
+    without the sparse kernels (the CPU oracle) the stem runs the reference recipe -- identical output."""
+    bd = _backbone_out("cpu")
+    torch.manual_seed(1)
+    bev = _TinyBEV().eval()
+    keys = list(bev.state_dict().keys())
+    with torch.no_grad():
+        want = bev(HeightCompression({"NUM_BEV_FEATURES": 256})(dict(bd))["spatial_features"])
+    hc = HeightCompression({"NUM_BEV_FEATURES": 256})
+    adapt_bev_backbone(bev, pad=1, height_compression=hc, sparse_stem=True)
+    assert list(bev.state_dict().keys()) == keys and len(list(hc.parameters())) == 0
+    with torch.no_grad():
+        out = hc(dict(bd))
+        assert out["spatial_features"].shape == (2, 64, 200, 176)
+        got = bev(out["spatial_features"])
+    assert torch.equal(got, want)
+
+
+def test_stem_weight_packing_matches_the_height_compression_channel_order():
+    """pack_stem_weight: Conv2d input channel c * D + z (the view of height_compression.py:30) -> sparse offset (z, ky, kx)."""
+    from virconv_amd.bev_stem import pack_stem_weight
+    w = torch.arange(64 * 256 * 9, dtype=torch.float32).view(64, 256, 3, 3)
+    passes = pack_stem_weight(w, 4)
+    assert [tuple(p.shape) for p in passes] == [(64, 27, 64), (64, 9, 64)]
+    full = torch.cat(passes, 1)          # (C, 36, Cout)
+    for (c, z, ky, kx, o) in [(0, 0, 0, 0, 0), (5, 3, 2, 1, 7), (63, 1, 1, 2, 63), (17, 2, 0, 2, 40)]:
+        assert float(full[c, z * 9 + ky * 3 + kx, o]) == float(w[o, c * 4 + z, ky, kx])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["eval", "train_stats_no_grad"])
+def test_sparse_bev_stem_on_hip_equals_the_dense_recipe(hip_backend, mode):
+    """SparseBEVStem on the HIP backend (vc_bev_pairs + gather-GEMM passes + vc_nhwc_to_nchw) against (a) the dense recipe on the
+    same GPU and (b) the CPU reference recipe on the oracle backbone's output: element-wise 1e-4 (north_star tolerance), running
+    statistics updated as nn.BatchNorm2d does in train mode."""
+    from oracle.backend import OracleBackend
+    from virconv_amd.bev_stem import SparseBEVStem
+    bd_h = _backbone_out("cuda")
+    t = bd_h["encoded_spconv_tensor"]
+    blk_d, blk_s = _first_block().cuda(), _first_block().cuda()
+    training = mode != "eval"
+    blk_d.train(training), blk_s.train(training)
+    stem = SparseBEVStem(blk_s)
+    with torch.no_grad():
+        assert stem.sparse_path_usable(t)
+        got = stem(t)
+        again = stem(t) if not training else None
+        want = blk_d(HeightCompression({"NUM_BEV_FEATURES": 256})(dict(bd_h))["spatial_features"])
+    assert got.shape == want.shape == (2, 64, 200, 176)
+    err = (got - want).abs()
+    assert bool((err <= 1e-4 * want.abs() + 1e-5 * max(1.0, float(want.abs().max()))).all()), float(err.max())
+    if again is not None:
+        assert torch.equal(got, again), "not bit-stable run to run"
+    if training:
+        for name in ("running_mean", "running_var"):
+            a, b = getattr(blk_s[2], name), getattr(blk_d[2], name)
+            assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max())), name
+        assert int(blk_s[2].num_batches_tracked) == int(blk_d[2].num_batches_tracked) == 1
+    else:
+        with ops.use_backend(OracleBackend()), torch.no_grad():
+            bd_o = _backbone_out("cpu")
+            ref = _first_block()(HeightCompression({"NUM_BEV_FEATURES": 256})(dict(bd_o))["spatial_features"]).numpy()
+        e = np.abs(got.cpu().numpy() - ref)
+        assert np.all(e <= 1e-4 * np.abs(ref) + 1e-5 * max(1.0, np.abs(ref).max())), float(e.max())
+    # with a gradient required the stem takes the dense recipe (training is unchanged)
+    t.features.requires_grad_(True)
+    assert not stem.sparse_path_usable(t)
+    y = stem(t)
+    y.sum().backward()
+    assert t.features.grad is not None and blk_s[1].weight.grad is not None

@@ -5,7 +5,9 @@ measured end to end from the backbone's sparse output on one GPU:
 
   A  reference recipe   .dense() (write-once fill) -> view (B, 256, 200, 176) -> nn.ZeroPad2d(1) -> conv
   B  fused border       vc_to_dense_fill_padded -> (B, 256, 202, 178) -> conv (padding 0, no pad kernel)
-each in NCHW and channels_last (what MIOpen picks differs per layout), forward and forward+backward.
+each in NCHW and channels_last (what MIOpen picks differs per layout), forward and forward+backward, and
+  C  sparse stem        vc_bev_pairs -> gather-GEMM passes over the sparse rows -> vc_nhwc_to_nchw (forward; virconv_amd/bev_stem.py),
+                        conv only and conv + BatchNorm(eval) + ReLU, against the same ops on the dense map.
 """
 from __future__ import annotations
 
@@ -85,6 +87,28 @@ def main():
         only_conv = timeit(lambda: conv_f(ya.new_zeros((bs, 256, 202, 178)).contiguous(memory_format=fmt)))
         print(f"{fmt_name:14s} forward: dense+ZeroPad2d+conv {ta:8.1f} us | padded dense+conv {tb:8.1f} us ({ta - tb:+.1f}) ; "
               f"fwd+bwd: {tta:8.1f} vs {ttb:8.1f} us ({tta - ttb:+.1f}) ; zeros+conv alone {only_conv:8.1f} us")
+
+
+    # ---- C: the conv (and conv + BN + ReLU) on the sparse rows
+    from virconv_amd.bev_stem import SparseBEVStem, pack_stem_weight
+    be = ops.get_backend()
+    passes = pack_stem_weight(conv.weight, int(shape[0]))
+    with torch.no_grad():
+        dense_map = ops.to_dense(feats, idx, shape, bs, pad=(1, 1))
+        want = conv(dense_map.view(bs, -1, dense_map.shape[-2], dense_map.shape[-1]))
+        got = be.bev_stem_conv(feats, idx, shape, bs, passes, 64)
+        err = float((got - want).abs().max() / want.abs().max())
+        t_sparse = timeit(lambda: be.bev_stem_conv(feats, idx, shape, bs, passes, 64))
+        t_dense = timeit(lambda: conv(ops.to_dense(feats, idx, shape, bs, pad=(1, 1)).view(bs, -1, 202, 178)))
+        blk = torch.nn.Sequential(torch.nn.ZeroPad2d(1), conv, torch.nn.BatchNorm2d(64, eps=1e-3, momentum=0.01).to(dev), torch.nn.ReLU()).eval()
+        stem = SparseBEVStem(blk)
+
+        class _T:   # the three attributes the stem reads
+            features, indices, spatial_shape, batch_size = feats, idx, shape, bs
+        t_stem = timeit(lambda: stem(_T))
+        t_blk = timeit(lambda: blk[3](blk[2](conv(ops.to_dense(feats, idx, shape, bs, pad=(1, 1)).view(bs, -1, 202, 178)))))
+    print(f"sparse stem    forward: conv on the sparse rows {t_sparse:8.1f} us vs padded dense + MIOpen conv {t_dense:8.1f} us "
+          f"(max rel diff {err:.1e}); conv+BN+ReLU {t_stem:8.1f} us vs {t_blk:8.1f} us")
 
 
 if __name__ == "__main__":

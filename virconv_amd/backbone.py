@@ -821,17 +821,24 @@ class HeightCompression(nn.Module):
     SURVEY 8f rank 3: with ``BEV_PAD: 1`` in the config the BEV map is emitted WITH the zero border the first BEV conv needs --
     (B, C*D, H + 2, W + 2), border and interior written once by the same kernel (vc_to_dense_fill_padded) -- so that the
     ``nn.ZeroPad2d(1)`` in front of ``Conv2d(k3, padding=0)`` (base_bev_backbone.py:31-36), a full copy of the 36 MB-per-frame
-    map, disappears: ``adapt_bev_backbone`` drops that pad module from a BaseBEVBackbone.  Default (0): the reference's layout."""
+    map, disappears: ``adapt_bev_backbone`` drops that pad module from a BaseBEVBackbone.  Default (0): the reference's layout.
+    ``adapt_bev_backbone(..., height_compression=self, sparse_stem=True)`` goes one step further: the first BEV block's
+    conv + BatchNorm + ReLU run HERE, on the sparse rows (virconv_amd/bev_stem.py), and ``spatial_features`` is their output."""
 
     def __init__(self, model_cfg=None, **kwargs):
         super().__init__()
         self.model_cfg = model_cfg
         self.num_bev_features = _cfg_get(model_cfg, "NUM_BEV_FEATURES", 256) if model_cfg is not None else 256
         self.bev_pad = int(_cfg_get(model_cfg, "BEV_PAD", 0)) if model_cfg is not None else 0
+        self.bev_stem = None      # SparseBEVStem, attached by adapt_bev_backbone(sparse_stem=True)
 
     def forward(self, batch_dict):
         batch_dict["spatial_features_stride"] = batch_dict["encoded_spconv_tensor_stride"]
         t = batch_dict["encoded_spconv_tensor"]
+        if self.bev_stem is not None:
+            batch_dict["spatial_features"] = self.bev_stem(t)       # (B, 64, H, W): the first BEV conv + BN + ReLU already applied
+            batch_dict["spatial_features_pad"] = 0
+            return batch_dict
         sp = t.dense(pad=(self.bev_pad, self.bev_pad)) if self.bev_pad else t.dense()
         n, c, d, h, w = sp.shape
         batch_dict["spatial_features"] = sp.view(n, c * d, h, w)
@@ -839,13 +846,24 @@ class HeightCompression(nn.Module):
         return batch_dict
 
 
-def adapt_bev_backbone(bev_backbone: nn.Module, pad: int = 1) -> nn.Module:
-    """Make a BaseBEVBackbone (pcdet/models/backbones_2d/base_bev_backbone.py:27-43) consume the pre-padded BEV map of
-    ``HeightCompression(BEV_PAD=pad)``: its first block begins with ``nn.ZeroPad2d(1)`` followed by ``Conv2d(k3, padding=0)``;
-    the pad module is replaced by an identity (state_dict keys are unchanged: ZeroPad2d has no parameters, indices stay)."""
+def adapt_bev_backbone(bev_backbone: nn.Module, pad: int = 1, height_compression: Optional["HeightCompression"] = None,
+                       sparse_stem: bool = False) -> nn.Module:
+    """Make a BaseBEVBackbone (pcdet/models/backbones_2d/base_bev_backbone.py:27-43) consume what this package's
+    ``HeightCompression`` hands over.  Default: the pre-padded BEV map of ``HeightCompression(BEV_PAD=pad)`` -- the first block's
+    ``nn.ZeroPad2d(1)`` is replaced by an identity (state_dict keys are unchanged: ZeroPad2d has no parameters, indices stay).
+    ``sparse_stem=True`` (needs ``height_compression``): the first block's pad + conv + BatchNorm + ReLU move into
+    ``height_compression`` as a ``SparseBEVStem`` over the sparse rows; the block keeps its modules (same state_dict keys, the
+    parameters are still the BEV backbone's) but its forward starts behind them."""
     first = bev_backbone.blocks[0]
     assert isinstance(first[0], nn.ZeroPad2d) and tuple(first[0].padding) == (pad,) * 4, "first BEV block does not start with ZeroPad2d"
     assert isinstance(first[1], nn.Conv2d) and first[1].padding == (0, 0) and first[1].kernel_size == (2 * pad + 1,) * 2
+    if sparse_stem:
+        from .bev_stem import SparseBEVStem, _StemSkippingBlock
+        assert height_compression is not None, "sparse_stem=True needs the HeightCompression module that will run the stem"
+        block = _StemSkippingBlock(*list(first))
+        bev_backbone.blocks[0] = block
+        height_compression.bev_stem = SparseBEVStem(block)
+        return bev_backbone
     first[0] = nn.Identity()
     return bev_backbone
 

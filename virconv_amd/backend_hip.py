@@ -546,6 +546,55 @@ class HipBackend:
               "vc_to_dense")
         return dense
 
+    def bev_stem_conv(self, features: torch.Tensor, indices: torch.Tensor, spatial_shape, batch_size: int, w_passes, cout: int,
+                      scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, relu: bool = False,
+                      want_nhwc: bool = False):
+        """First BEV conv on the sparse rows (base_bev_backbone.py:31-38 over height_compression.py:27-31):
+        features (n, C) at indices (n, 4) [b, z, y, x] of a (D, H, W) grid -> (B, cout, H, W) = Conv2d(C * D -> cout, k, pad k // 2)
+        of the height-compressed map, then y * scale + shift (BatchNorm) and ReLU folded into the layout pass.
+        `w_passes`: the conv weight cut into passes of <= 32 kernel offsets, each (C, kv_pass, cout) contiguous (see
+        bev_stem.pack_stem_weight).  No host synchronisation: the pair table covers every BEV cell."""
+        features = _need(features, torch.float32, "features")
+        indices = _need(indices, torch.int32, "indices")
+        n, c = features.shape
+        D, H, W = (int(v) for v in spatial_shape)
+        dev = features.device
+        cells = batch_size * H * W
+        kv_total = sum(int(w.shape[1]) for w in w_passes)
+        assert kv_total % D == 0
+        k2 = kv_total // D
+        ky = kx = int(round(k2 ** 0.5))
+        assert ky * kx == k2, "square 2-D kernels only"
+        shp = i32arr((D, H, W))
+        st = _stream()
+        pair = torch.empty((kv_total, cells), dtype=torch.int32, device=dev)
+        ws_bytes = self.lib.vc_bev_pairs_workspace_bytes(batch_size, shp)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        check(self.lib.vc_bev_pairs(_ptr(indices), n, batch_size, shp, ky, kx, _ptr(pair), _ptr(ws), ws_bytes, st), "vc_bev_pairs")
+        acc, k0 = None, 0
+        for w in w_passes:
+            w = _need(w, torch.float32, "stem weight pass")
+            kvp = int(w.shape[1])
+            assert w.shape[0] == c and w.shape[2] == cout and kvp <= 32
+            tbl = pair[k0:k0 + kvp]
+            out = torch.empty((cells, cout), dtype=torch.float32, device=dev)
+            if acc is None:
+                # the backward-input form of the gather-GEMM reads its weight as (source channels, offsets, output channels):
+                # exactly the layout of a pass
+                check(self.lib.vc_conv_backward_input(_ptr(features), None, n, _ptr(tbl), cells, kvp, _ptr(w), cout, c, 0, -1, None,
+                                                      None, OPERAND_TYPES["f32"], 0, _ptr(out), st), "vc_conv_backward_input")
+            else:
+                check(self.lib.vc_conv_backward_input_epilogue(_ptr(features), None, n, _ptr(tbl), cells, kvp, _ptr(w), cout, c, 0, -1,
+                                                               None, None, 0, _ptr(acc), cout, 0, None, None, None, None, None, 0.0, 0,
+                                                               None, _ptr(out), st), "vc_conv_backward_input_epilogue")
+            acc, k0 = out, k0 + kvp
+        if want_nhwc:
+            return acc
+        dense = torch.empty((batch_size, cout, H, W), dtype=torch.float32, device=dev)
+        check(self.lib.vc_nhwc_to_nchw(_ptr(acc), batch_size, H * W, cout, _ptr(scale), _ptr(shift), 1 if relu else 0, _ptr(dense), st),
+              "vc_nhwc_to_nchw")
+        return dense
+
     def from_dense(self, dense: torch.Tensor, indices: torch.Tensor, spatial_shape, batch_size: int, pad=(0, 0)) -> torch.Tensor:
         dense = _need(dense, torch.float32, "dense")
         indices = _need(indices, torch.int32, "indices")

@@ -1,0 +1,107 @@
+"""The first BEV conv on the sparse rows ("HeightCompression + first BaseBEVBackbone conv fused").
+
+Reference: ``HeightCompression.forward`` folds the height axis of ``encoded_spconv_tensor.dense()`` into the channels
+(pcdet/models/backbones_2d/map_to_bev/height_compression.py:27-31: (B, 64, 4, 200, 176) -> (B, 256, 200, 176)) and the first block of
+``BaseBEVBackbone`` runs ``ZeroPad2d(1) + Conv2d(256 -> 64, k3, bias=False) + BatchNorm2d(eps 1e-3, momentum 0.01) + ReLU`` over it
+(pcdet/models/backbones_2d/base_bev_backbone.py:31-38) -- a dense 41.5 GFLOP conv over a map in which ~70 % of the cells hold no
+voxel.  Seen from the sparse tensor it is a sparse conv from the (b, z, y, x) rows onto the (b, y, x) cells with kernel (4, 3, 3):
+4.7 GFLOP on the synthetic KITTI frames.  ``SparseBEVStem`` runs it that way (vc_bev_pairs -> the gather-GEMM in two passes of 18
+kernel offsets -> vc_nhwc_to_nchw with BatchNorm + ReLU folded in) whenever no gradient is needed (inference, BASELINE configs[1]);
+when a gradient IS needed it runs the reference recipe on the dense map (HeightCompression(BEV_PAD=1) form), so training is
+unchanged.  Parameters stay where they are (the BaseBEVBackbone's own Conv2d / BatchNorm2d: same state_dict keys).
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import ops
+
+MAX_PASS_OFFSETS = 32      # the gather-GEMM walks a 32-bit mask of kernel offsets per block
+
+
+def pack_stem_weight(weight: torch.Tensor, depth: int):
+    """Conv2d weight (Cout, C * D, ky, kx) over the height-compressed map (channel = c * D + z, height_compression.py:30) -> passes
+    [(C, kv_pass, Cout), ...] of the sparse form: offset index (z, ky, kx) row-major, z split so that a pass has <= 32 offsets."""
+    cout, cd, ky, kx = weight.shape
+    assert cd % depth == 0
+    c = cd // depth
+    w = weight.detach().view(cout, c, depth, ky, kx).permute(1, 2, 3, 4, 0).contiguous()      # (C, D, ky, kx, Cout)
+    z_per = max(1, MAX_PASS_OFFSETS // (ky * kx))
+    return [w[:, z0:z0 + z_per].reshape(c, -1, cout).contiguous() for z0 in range(0, depth, z_per)]
+
+
+class SparseBEVStem(nn.Module):
+    """``stem(encoded_spconv_tensor) -> (B, Cout, H, W)``: conv + BatchNorm2d + ReLU of the first BEV block, given that block
+    (``nn.Sequential(ZeroPad2d(1), Conv2d, BatchNorm2d, ReLU, ...)``).  Holds no parameters of its own."""
+
+    def __init__(self, first_block: nn.Sequential):
+        super().__init__()
+        pad, conv, bn, relu = first_block[0], first_block[1], first_block[2], first_block[3]
+        assert isinstance(conv, nn.Conv2d) and conv.bias is None and conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+        assert conv.kernel_size[0] == conv.kernel_size[1] and conv.kernel_size[0] % 2 == 1
+        assert isinstance(bn, nn.BatchNorm2d) and isinstance(relu, nn.ReLU)
+        k = conv.kernel_size[0]
+        assert (isinstance(pad, nn.ZeroPad2d) and tuple(pad.padding) == (k // 2,) * 4 and conv.padding == (0, 0)) or \
+               (isinstance(pad, nn.Identity) and conv.padding in ((0, 0), (k // 2, k // 2)))
+        object.__setattr__(self, "_block", first_block)       # not a submodule: the parameters belong to the BEV backbone
+        self._packed = None
+
+    def _passes(self, depth: int):
+        conv = self._block[1]
+        key = (conv.weight.data_ptr(), conv.weight._version, depth, conv.weight.device)
+        if self._packed is None or self._packed[0] != key:
+            self._packed = (key, pack_stem_weight(conv.weight, depth))
+        return self._packed[1]
+
+    def sparse_path_usable(self, t) -> bool:
+        conv, bn = self._block[1], self._block[2]
+        be = ops.get_backend()
+        needs_grad = torch.is_grad_enabled() and (t.features.requires_grad or conv.weight.requires_grad)
+        return bool(hasattr(be, "bev_stem_conv") and t.features.is_cuda and not needs_grad and t.features.shape[1] in (16, 32, 64)
+                    and conv.out_channels in (16, 32, 64) and len(t.spatial_shape) == 3 and t.features.dtype == torch.float32
+                    and conv.in_channels == t.features.shape[1] * t.spatial_shape[0] and not (bn.training and bn.track_running_stats is False))
+
+    def forward(self, t):
+        conv, bn = self._block[1], self._block[2]
+        if not self.sparse_path_usable(t):
+            # the reference recipe on the dense map, border written by the dense pass (HeightCompression(BEV_PAD) form)
+            k = conv.kernel_size[0]
+            d = t.dense(pad=(k // 2, k // 2)) if conv.padding == (0, 0) else t.dense()
+            x = d.view(d.shape[0], -1, d.shape[-2], d.shape[-1])
+            return self._block[3](bn(conv(x)))
+        be = ops.get_backend()
+        depth = int(t.spatial_shape[0])
+        passes = self._passes(depth)
+        if bn.training:   # batch statistics over the WHOLE map (zeros of the empty cells included): the NHWC rows hold every cell
+            y = be.bev_stem_conv(t.features, t.indices, t.spatial_shape, t.batch_size, passes, conv.out_channels, want_nhwc=True)
+            with torch.no_grad():
+                var, mean = torch.var_mean(y, dim=0, unbiased=False)
+                if bn.track_running_stats:
+                    m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                    n = y.shape[0]
+                    bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+                    bn.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
+                    bn.num_batches_tracked += 1
+            scale = bn.weight.detach() * torch.rsqrt(var + bn.eps)
+            shift = bn.bias.detach() - mean * scale
+            dense = torch.empty((t.batch_size, conv.out_channels, int(t.spatial_shape[1]), int(t.spatial_shape[2])),
+                                dtype=torch.float32, device=y.device)
+            from ._lib import check
+            check(be.lib.vc_nhwc_to_nchw(y.data_ptr(), t.batch_size, dense.shape[2] * dense.shape[3], conv.out_channels,
+                                         scale.contiguous().data_ptr(), shift.contiguous().data_ptr(), 1, dense.data_ptr(), be.stream()),
+                  "vc_nhwc_to_nchw")
+            return dense
+        scale = (bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)).contiguous()
+        shift = (bn.bias.detach() - bn.running_mean * scale).contiguous()
+        return be.bev_stem_conv(t.features.detach(), t.indices, t.spatial_shape, t.batch_size, passes, conv.out_channels, scale, shift, True)
+
+
+class _StemSkippingBlock(nn.Sequential):
+    """The first block of a BaseBEVBackbone whose first four modules (pad, conv, BatchNorm, ReLU) already ran inside
+    HeightCompression (SparseBEVStem): same children, same state_dict keys, forward starts at the fifth module."""
+
+    def forward(self, x):
+        for m in list(self)[4:]:
+            x = m(x)
+        return x

@@ -674,6 +674,58 @@ __global__ void __launch_bounds__(256) dense_fill_kernel(const float* __restrict
     for (int ch = wave; ch < c; ch += 4) out[ch * plane + lane] = f_tile[lane * ld + ch];
 }
 
+// ------------------------------------------------------------------------------------------ f3: first BEV conv on the sparse rows
+// HeightCompression folds the height axis into the channels (height_compression.py:27-31: (B, C, D, H, W) -> (B, C*D, H, W)) and the
+// first block of BaseBEVBackbone runs ZeroPad2d(1) + Conv2d(C*D -> 64, k3) over that map (base_bev_backbone.py:31-38) although
+// ~70 % of its cells hold no voxel.  Seen from the sparse tensor that conv is a sparse conv from the (b, z, y, x) rows onto the
+// (b, y, x) cells with kernel (D, 3, 3): offset (z, ky, kx) of cell (y, x) reads the voxel at height z (absolute) of cell
+// (y + ky - 1, x + kx - 1).  bev_pairs_kernel writes its pair table for EVERY cell of the BEV grid in dense (b, y, x) order --
+// no compaction, no count read: the gather-GEMM's output rows are then the NHWC dense map itself (blocks whose 64 cells see no
+// voxel return at once), and nhwc_to_nchw_kernel turns it into the NCHW map the rest of the 2-D backbone reads, with the
+// BatchNorm (+ReLU) that follows the conv folded into the same pass.
+__global__ void __launch_bounds__(256) bev_pairs_kernel(const int32_t* __restrict__ rowid, int B, int D, int H, int W, int ky, int kx,
+                                                        int32_t* __restrict__ pair) {
+  const int64_t cells = (int64_t)B * H * W;
+  const int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (cell >= cells) return;
+  const int x = (int)(cell % W);
+  const int64_t t = cell / W;
+  const int y = (int)(t % H), b = (int)(t / H);
+  int k = 0;
+  for (int z = 0; z < D; ++z)
+    for (int a = 0; a < ky; ++a)
+      for (int c = 0; c < kx; ++c, ++k) {
+        const int yy = y + a - ky / 2, xx = x + c - kx / 2;
+        int r = 0;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) r = rowid[(((int64_t)b * D + z) * H + yy) * W + xx];
+        pair[(int64_t)k * cells + cell] = r - 1;
+      }
+}
+
+// out[b][ch][p] = act(x[b * HW + p][ch] * scale[ch] + shift[ch]); x is (B * HW, C) row-major (NHWC), out (B, C, HW) (NCHW).
+// Block = 64 consecutive cells x all channels through an LDS tile: rows are read coalesced, every store instruction writes 64
+// consecutive cells of one channel plane.
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const float* __restrict__ x, int64_t hw, int c, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int relu, float* __restrict__ out) {
+  extern __shared__ float t_tile[];   // [64][c + 1]
+  const int ld = c + 1;
+  const int64_t tiles_per_sample = (hw + 63) / 64;
+  const int64_t b = blockIdx.x / tiles_per_sample;
+  const int64_t p0 = (blockIdx.x - b * tiles_per_sample) * 64;
+  const int cells = (int)min((int64_t)64, hw - p0);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = wave; r < cells; r += 4)
+    for (int col = lane; col < c; col += 64) t_tile[r * ld + col] = x[(b * hw + p0 + r) * c + col];
+  __syncthreads();
+  if (lane < cells)
+    for (int ch = wave; ch < c; ch += 4) {
+      float v = t_tile[lane * ld + ch];
+      if (scale != nullptr) v = v * scale[ch] + shift[ch];
+      if (relu) v = fmaxf(v, 0.f);
+      out[(b * c + ch) * hw + p0 + lane] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ generic int scan (flags)
 __global__ void __launch_bounds__(256) flag_blocksum_kernel(const int32_t* __restrict__ flags, int64_t n,
                                                             int32_t* __restrict__ blocksum) {
@@ -1348,6 +1400,46 @@ int vc_to_dense_fill_padded(const float* features, const int32_t* indices, int64
   hipLaunchKernelGGL(dense_fill_kernel, dim3((unsigned)(lines * tiles)), dim3(256), lds, st, features, rowid, c, d.D, d.H, d.W,
                      tiles, dense, pad_h, pad_w);
   VC_CHECK_LAUNCH("dense_fill_kernel");
+  return VC_OK;
+}
+
+size_t vc_bev_pairs_workspace_bytes(int batch_size, const int32_t* shape) {
+  if (!shape || batch_size < 1) return 0;
+  return (size_t)batch_size * shape[0] * shape[1] * shape[2] * sizeof(int32_t);
+}
+
+int vc_bev_pairs(const int32_t* indices, int64_t n, int batch_size, const int32_t* shape, int ky, int kx, int32_t* pair, void* ws,
+                 size_t ws_bytes, void* stream) {
+  VC_REQUIRE(shape && batch_size >= 1 && pair && ws && ky >= 1 && kx >= 1 && ky % 2 == 1 && kx % 2 == 1, "vc_bev_pairs: invalid argument");
+  VC_REQUIRE(n == 0 || indices, "vc_bev_pairs: null indices");
+  const int D = shape[0], H = shape[1], W = shape[2];
+  VC_REQUIRE(D >= 1 && H >= 1 && W >= 1 && (int64_t)D * ky * kx <= 128, "vc_bev_pairs: kernel volume D * ky * kx must be <= 128");
+  if (ws_bytes < vc_bev_pairs_workspace_bytes(batch_size, shape)) { set_error("vc_bev_pairs: workspace too small"); return VC_ECAPACITY; }
+  VC_REQUIRE(n < (1LL << 31) - 1 && (int64_t)batch_size * H * W < (1LL << 31), "vc_bev_pairs: tensor too large");
+  hipStream_t st = (hipStream_t)stream;
+  int32_t* rowid = (int32_t*)ws;
+  VC_CHECK_HIP(hipMemsetAsync(rowid, 0, vc_bev_pairs_workspace_bytes(batch_size, shape), st));
+  if (n > 0) {
+    hipLaunchKernelGGL(dense_rowid_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, indices, n, 3, D, H, W, rowid);
+    VC_CHECK_LAUNCH("dense_rowid_kernel");
+  }
+  const int64_t cells = (int64_t)batch_size * H * W;
+  hipLaunchKernelGGL(bev_pairs_kernel, dim3((unsigned)cdiv(cells, 256)), dim3(256), 0, st, (const int32_t*)rowid, batch_size, D, H, W, ky, kx,
+                     pair);
+  VC_CHECK_LAUNCH("bev_pairs_kernel");
+  return VC_OK;
+}
+
+int vc_nhwc_to_nchw(const float* x, int batch_size, int64_t hw, int c, const float* scale, const float* shift, int relu, float* out,
+                    void* stream) {
+  VC_REQUIRE(x && out && batch_size >= 1 && hw >= 1 && c >= 1, "vc_nhwc_to_nchw: invalid argument");
+  VC_REQUIRE((scale == nullptr) == (shift == nullptr), "vc_nhwc_to_nchw: scale and shift come together");
+  const size_t lds = (size_t)64 * (c + 1) * sizeof(float);
+  VC_REQUIRE(lds <= 60 * 1024, "vc_nhwc_to_nchw: channel count %d too large", c);
+  const int64_t blocks = (int64_t)batch_size * ((hw + 63) / 64);
+  VC_REQUIRE(blocks < (1LL << 31), "vc_nhwc_to_nchw: tensor too large");
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, hw, c, scale, shift, relu, out);
+  VC_CHECK_LAUNCH("nhwc_to_nchw_kernel");
   return VC_OK;
 }
 
