@@ -264,7 +264,7 @@ def _pmc_traffic(tdir, tck, tcn):
     runs of this same command and corrected as MI355X_MICROARCH.md prescribes; summary committed under profiles/).
     PMC counters cannot be read from inside the process: the number is the one of the newest committed profile of this command,
     and the JSON line says so (`traffic_source`); (None, None) if absent."""
-    for tag in ("r03", "r02"):
+    for tag in ("r04", "r03", "r02"):
         rel = os.path.join("profiles", f"{tag}_traffic_gather_gemm_{tck}_{tcn}_{tdir}.json")
         try:
             with open(os.path.join(ROOT, rel)) as f:

@@ -27,7 +27,7 @@ FAMILIES = [
     ("gather_gemm (conv fwd + bwd-input)", r"gather_gemm"),
     ("bwd_weight (+reduce)", r"bwd_weight"),
     ("bn_*", r"vc::bn_"),
-    ("rulebook (hash/subm/sp_*/row_order)", r"vc::(hash_|subm_|sp_|scan_|row_order|flag_)"),
+    ("rulebook / geometry plan (hash/subm/sp_*/image_*/parity/row_order/keep)", r"vc::(hash_|subm_|sp_|scan_|row_order|flag_|image_|parity_|keep_count|random_keep|gather_coords|set_count|bev_pairs)"),
     ("group_sum (seg_sum / seg_fixup / plan keys; r1-r2: fixed-point + absmax + convert)", r"vc::(group_|seg_|absmax)"),
     ("sort (rocPRIM radix sort of the duplicate-pixel group plans)", r"rocprim"),
     ("loss (vc_weighted_sum: the benchmark's stand-in loss, fused product + reduction)", r"weighted_sum"),
