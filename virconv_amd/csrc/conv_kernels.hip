@@ -1281,6 +1281,175 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
   for (int e = threadIdx.x; e < CI * CO; e += 256) dst[e] = red[e];
 }
 
+// --------------------------------------------------------------------------------------------- K8 small channels (round 4)
+// bwd_weight_kernel feeds v_mfma_f32_16x16x4_f32 with ONE channel per lane per operand: at C = 16 that is a 4-byte gather per lane
+// and two vector-memory instructions for every MFMA (16 matrix-pipe cycles per load instruction; 9-16 % of the fp32 peak on the
+// 16-channel layers, 1.2 % at C = 8 -- profiles/r04_kbench.txt).  v_mfma_f32_4x4x1_16B_f32 turns the shape around: 16 independent
+// 4 x 4 x 1 outer products per instruction, one per PAIR.  Lane (p, i), p = lane / 4 the pair slot, i = lane % 4, loads VA = CI / 4
+// CONTIGUOUS input channels [VA i, VA i + VA) of pair p's input row and VB = CO / 4 contiguous channels of its gradient row -- at
+// C = 16 one 16-byte load each, a whole 64-byte row per 4 lanes -- and instruction (t, u) multiplies channel VA i + t of x by channel
+// VB j + u of dy for all 16 pairs at once: VA VB instructions of 8 cycles per 16 pairs = the same matrix-pipe time as before, with 2
+// (3 at 32 x 16) load instructions per 16 pairs instead of 8.  Each pair slot accumulates its own 4 x 4 tiles; the 16 slots are added
+// once per wave at the end (xor-butterfly over lane / 4: a fixed tree).  Served shapes: CI, CO in {4, 8, 16, 32} with CI CO <= 512
+// (VA VB <= 32 accumulator quads per lane).  Same queue compaction, block order, partial layout and split-N reduction as above;
+// results differ from bwd_weight_kernel only in the order of the fp32 additions (bit-stable run to run).
+template <int V>
+__device__ __forceinline__ void ld_contig(const float* p, float* o) {
+  if constexpr (V == 8) { VecLoad<4>::ld(p, o); VecLoad<4>::ld(p + 4, o + 4); }
+  else VecLoad<V>::ld(p, o);
+}
+
+template <int CI, int CO>
+__global__ void __launch_bounds__(256) bwd_weight_small_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               const int32_t* __restrict__ tbl, int64_t n_out, int kv,
+                                                               int64_t rows_per_block, int nsplit, int legacy_order,
+                                                               float* __restrict__ partial, const int32_t* __restrict__ rep,
+                                                               int centre, const float* __restrict__ dy_grp, int d_rows_on_lanes) {
+  constexpr int VA = CI / 4, VB = CO / 4;
+  static_assert(CI % 4 == 0 && CO % 4 == 0 && VA <= 8 && VB <= 8 && VA * VB <= 32, "small-channel weight gradient: CI CO <= 512");
+  constexpr int U = (VA * VB >= 16) ? 1 : 2;          // groups of 16 pairs requested per trip
+  __shared__ int q_in[4][160];
+  __shared__ int q_out[4][160];
+  __shared__ __attribute__((aligned(16))) float s_part[16 * (CI * CO + 16)];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = lane >> 2, i = lane & 3;
+  int k, split;
+  if (legacy_order) {
+    k = blockIdx.x / nsplit;
+    split = blockIdx.x - k * nsplit;
+  } else {   // the kv offset-blocks of one row range adjacent in launch order and on one XCD (see bwd_weight_kernel)
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int rl = j / kv;
+    k = j - rl * kv;
+    split = rl * 8 + xcd;
+  }
+  if (split >= nsplit) return;
+  const bool reps_only = rep != nullptr && k != centre;
+  if (reps_only) dy = dy_grp;
+  const int64_t brow0 = (int64_t)split * rows_per_block;
+  const int64_t bend = min(brow0 + rows_per_block, n_out);
+  const int64_t rpw = rows_per_block / 4;
+  const int64_t wstart = brow0 + wave * rpw;
+  const int64_t wend = min(wstart + rpw, bend);
+
+  f32x4 acc[VA][VB];
+#pragma unroll
+  for (int t = 0; t < VA; ++t)
+#pragma unroll
+    for (int u = 0; u < VB; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int* qi = q_in[wave];
+  int* qo = q_out[wave];
+  int qlen = 0;
+  auto entry = [&](int64_t r) -> int {
+    if (r >= wend) return -1;
+    const int v = tbl[(int64_t)k * n_out + r];
+    return (reps_only && rep[r] != (int32_t)r) ? -1 : v;
+  };
+  auto consume = [&](const float (&a)[VA], const float (&b)[VB]) {
+#pragma unroll
+    for (int t = 0; t < VA; ++t)
+#pragma unroll
+      for (int u = 0; u < VB; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[t], b[u], acc[t][u], 0, 0, 0);
+  };
+  int v_next = entry(wstart + lane);
+  for (int64_t base = wstart; base < wend; base += 64) {
+    const int64_t r = base + lane;
+    const int v = v_next;
+    v_next = entry(r + 64);
+    const bool valid = v >= 0;
+    const unsigned long long m = __ballot(valid);
+    if (m == 0ULL) continue;
+    const int pos = __popcll(m & ((1ULL << lane) - 1ULL));
+    if (valid) { qi[qlen + pos] = v; qo[qlen + pos] = (int)r; }
+    qlen += __popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    const int ng = qlen >> 4;
+    int g = 0;
+    for (; g + U <= ng; g += U) {
+      float a[U][VA], b[U][VB];
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) {
+        const int pin = qi[(g + uu) * 16 + p], pout = qo[(g + uu) * 16 + p];
+        ld_contig<VA>(x + (int64_t)pin * CI + VA * i, a[uu]);
+        ld_contig<VB>(dy + (int64_t)pout * CO + VB * i, b[uu]);
+      }
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) consume(a[uu], b[uu]);
+    }
+    for (; g < ng; ++g) {
+      const int pin = qi[g * 16 + p], pout = qo[g * 16 + p];
+      float a[VA], b[VB];
+      ld_contig<VA>(x + (int64_t)pin * CI + VA * i, a);
+      ld_contig<VB>(dy + (int64_t)pout * CO + VB * i, b);
+      consume(a, b);
+    }
+    const int rem = qlen & 15;
+    const int done = qlen - rem;
+    int t1 = 0, t2 = 0;
+    if (lane < rem) { t1 = qi[done + lane]; t2 = qo[done + lane]; }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < rem) { qi[lane] = t1; qo[lane] = t2; }
+    qlen = rem;
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (qlen > 0) {   // tail group: the pair slots beyond the queue contribute zeros
+    const bool ok = p < qlen;
+    const int pin = ok ? qi[p] : 0, pout = ok ? qo[p] : 0;
+    float a[VA], b[VB];
+    if (ok) {
+      ld_contig<VA>(x + (int64_t)pin * CI + VA * i, a);
+      ld_contig<VB>(dy + (int64_t)pout * CO + VB * i, b);
+    } else {
+#pragma unroll
+      for (int t = 0; t < VA; ++t) a[t] = 0.f;
+#pragma unroll
+      for (int u = 0; u < VB; ++u) b[u] = 0.f;
+    }
+    consume(a, b);
+  }
+  // Every pair slot holds its own partial tiles: 16 slots x 4 waves to add per element.  Through LDS, wave after wave: the wave's
+  // lanes store their VA VB accumulator quads slot-major, then thread e adds the 16 slots of element e in slot order (a fixed
+  // order: wave 0 slots 0..15, wave 1 slots 0..15, ...).  (A first cut reduced the slots with a shuffle butterfly and let four
+  // lanes per wave walk all elements serially: 64-128 dependent LDS read-modify-writes per block -- 2-8x SLOWER than
+  // bwd_weight_kernel on every shape, profiles/r04_dw_small_channels.md.)
+  // Tile (t, u), accumulator register r, lane % 4 = l holds D[row r][col l] = dW[ci = VA r + t][co = VB l + u].
+  constexpr int E = CI * CO, SLOT = E + 16, EPT = (E + 255) / 256;
+  float tot[EPT];
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) tot[j] = 0.f;
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int t = 0; t < VA; ++t)
+#pragma unroll
+        for (int u = 0; u < VB; ++u)
+          *reinterpret_cast<f32x4*>(&s_part[p * SLOT + ((t * VB + u) * 4 + i) * 4]) = acc[t][u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+      const int e = threadIdx.x + 256 * j;
+      if (e < E) {
+#pragma unroll
+        for (int sl = 0; sl < 16; ++sl) tot[j] += s_part[sl * SLOT + e];
+      }
+    }
+    __syncthreads();
+  }
+  float* dst = partial + ((int64_t)split * kv + k) * (CI * CO);
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) {
+    const int e = threadIdx.x + 256 * j;
+    if (e < E) {
+      const int tile = e >> 4, l = (e >> 2) & 3, r = e & 3;
+      const int t = tile / VB, u = tile - t * VB;
+      (void)d_rows_on_lanes;   // D[row][col] of a 4x4 block: row = accumulator register, col = lane % 4 (confirmed on gfx950, r4m)
+      dst[(VA * r + t) * CO + VB * l + u] = tot[j];
+    }
+  }
+}
+
 #ifdef VC_EXPERIMENTS
 #include "experiments/bwd_weight_v2.inc"
 #endif
@@ -1943,6 +2112,7 @@ static int dispatch_ck(int ck, int cn, const float* src, const float* src_centre
 
 int g_bw_rows_per_split = 1024;  // weight gradient: target rows per block (vc_debug_set bw_rows_per_split); more rows = fewer, longer blocks and fewer partial sums
 int g_bw_legacy_order = 0;      // debug: 1 = offset-major block order of the weight-gradient kernel
+int g_bw_small = 1;             // vc_debug_set bw_small: 0 = bwd_weight_kernel for every shape; 1 = bwd_weight_small_kernel where it measured faster; 3 = wherever it applies
 int g_bw_variant = 1;           // vc_debug_set bw_variant: 1 = bwd_weight_kernel, 2 = bwd_weight_v2_kernel (dy window in LDS) where it applies
 extern int g_pass_dw_main_tail; // pass.hip
 extern int g_pass_bwd_epilogue;
@@ -2006,8 +2176,18 @@ static int launch_bw(const float* x, const float* dy, const int32_t* tbl, int64_
   const unsigned nblocks = g_bw_legacy_order ? (unsigned)(nsplit * kv) : (unsigned)(cdiv(nsplit, 8) * 8 * kv);
 #define VC_ARGS x, dy, tbl, n_out, kv, rpb, nsplit, g_bw_legacy_order, partial, rep, centre, dy_grp
   bool launched = false;
+  if constexpr (CI <= 32 && CO <= 32 && CI * CO <= 512) {   // small channels: 16 pairs per v_mfma_f32_4x4x1_16B, 16-byte operand loads
+    // measured (profiles/r04_dw_small_channels.md): wins at 8 x 8 (25.6 -> 19.2-20.4 us) and on the 16 x 16 duplicate-pixel tables
+    // (44.9 -> 39.2), loses from 16 x 16 SubM upward (71 -> 80, 32 x 16: 90 -> 138, the sparse 16 x 32 strided table 38 -> 86): the
+    // 4x4x1 form runs below the fp32 matrix-pipe rate of the 16x16x4 form here.  Default: C_in C_out <= 64 only; 3 = every served shape.
+    if (ot == VC_OPERAND_F32 && (g_bw_small == 3 || (g_bw_small == 1 && CI * CO <= 64))) {
+      hipLaunchKernelGGL((bwd_weight_small_kernel<CI, CO>), dim3(nblocks), dim3(256), 0, st, VC_ARGS, 0);
+      launched = true;
+    }
+  }
   if constexpr (CI >= 16 && CO >= 16) {  // 16-bit operands only where both channel counts are >= 16 (as in the gather-GEMM)
-    if (ot == VC_OPERAND_F16) {
+    if (launched) {
+    } else if (ot == VC_OPERAND_F16) {
       hipLaunchKernelGGL((bwd_weight_kernel<CI, CO, VC_OPERAND_F16>), dim3(nblocks), dim3(256), 0, st, VC_ARGS);
       launched = true;
     } else if (ot == VC_OPERAND_BF16) {
@@ -2116,6 +2296,7 @@ int vc_debug_set(const char* key, int value) {
   if (!strcmp(key, "conv_window")) { g_conv_window = value; return VC_OK; }
   if (!strcmp(key, "conv_nw")) { g_conv_nw = (value == 8 || value == 4) ? value : 0; return VC_OK; }
   if (!strcmp(key, "bw_legacy_order")) { g_bw_legacy_order = value; return VC_OK; }
+  if (!strcmp(key, "bw_small")) { g_bw_small = value; return VC_OK; }
   if (!strcmp(key, "bw_rows_per_split")) { if (value >= 256) g_bw_rows_per_split = value; return VC_OK; }
   if (!strcmp(key, "pass_dw_main_tail")) { g_pass_dw_main_tail = value; return VC_OK; }
   if (!strcmp(key, "pass_bwd_epilogue")) { g_pass_bwd_epilogue = value; return VC_OK; }
