@@ -545,7 +545,11 @@ int vc_nhwc_to_nchw(const float* x, int batch_size, int64_t hw, int c, const flo
  *                   first block that has no strided conv (its row count is the caller's); then the counts' copy to
  *                   `host_counts` (pinned host memory, >= 64 int32) and an event.
  *   vc_plan_wait    polls that event; checks injected keeps against the counts.  The ONE host synchronisation of the plan.
- *   vc_plan_finish  enqueues every remaining table with exact row counts into `arena_b`.
+ *   vc_plan_finish  enqueues every remaining table a FORWARD pass reads, with exact row counts, into `arena_b` (all views of
+ *                   `vc_plan_out` are final; those named next are filled by the call after it).
+ *   vc_plan_finish_backward  enqueues what only backward passes read -- the duplicate-pixel group plans (`grp_plan`, the sorts:
+ *                   a third of the plan's stream time) and the backward row orders (`order_bwd`).  A caller records an event
+ *                   between the two calls and lets the forward pass wait for that one only.  No-op when need_grad == 0.
  * Host-side composition of the operators above plus index kernels that exploit what the chain knows (plan.hip): the coordinates
  * of a strided conv's output are the set bits of its bitmap in ascending order, so the SubM rulebook of that tensor ranks
  * neighbours in the SAME bitmap (no hash build); the pixel tensors index a dense per-sample image (no hash build, 6x fewer
@@ -602,6 +606,8 @@ int vc_plan_wait(const vc_plan_desc* desc, vc_plan_state* state);
 size_t vc_plan_finish_arena_bytes(const vc_plan_desc* desc, const vc_plan_state* state);
 int vc_plan_finish(const vc_plan_desc* desc, vc_plan_state* state, void* arena_a, void* arena_b, size_t arena_b_bytes,
                    vc_plan_out* out, void* stream);
+int vc_plan_finish_backward(const vc_plan_desc* desc, vc_plan_state* state, void* arena_a, void* arena_b, size_t arena_b_bytes,
+                            void* stream);
 
 #ifdef __cplusplus
 }

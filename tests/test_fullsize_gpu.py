@@ -290,9 +290,9 @@ def _record_discards(monkeypatch):
     orig_build = npn.build
 
     def recording_build(model, blocks, tail, idx, batch_size, calib, trans_param, discard_tags, rate, batch_dict, image_shape,
-                        input_discard_tag=None):
+                        input_discard_tag=None, deferred=None):
         res = orig_build(model, blocks, tail, idx, batch_size, calib, trans_param, discard_tags, rate, batch_dict, image_shape,
-                         input_discard_tag)
+                         input_discard_tag, deferred)
         for st, tag in zip(res[0], discard_tags):
             if tag is not None:
                 rec[tag] = st["keep"].detach().cpu().clone()

@@ -13,6 +13,7 @@ import torch
 import bench
 from helpers import GRID, MODEL_CFG, golden_batch, load_golden
 from virconv_amd import native_plan, ops, synth
+from virconv_amd import backbone as bb
 from virconv_amd.backbone import VirConvL8x
 
 pytestmark = pytest.mark.gpu
@@ -72,6 +73,7 @@ def _plans(model, batch, monkeypatch, seed=5):
         monkeypatch.setattr(native_plan, "NATIVE_PLAN", native)
         torch.manual_seed(seed)
         p = model.build_plan(bd["voxel_coords"], bd["batch_size"], calib, bd.get("aug_param"), bd)
+        bb.join_plan(p)   # the backward-only structures are enqueued at the end of a forward pass
         torch.cuda.synchronize()
         assert ("_arenas" in p) == native
         out.append(p)
@@ -133,6 +135,7 @@ def test_plan_kernel_switches_do_not_change_any_table(hip_backend, monkeypatch, 
             assert lib.vc_debug_set(key.encode(), v) == 0
             torch.manual_seed(11)
             plans.append(model.build_plan(batch["voxel_coords"], 2, batch["calib"], batch["aug_param"], batch))
+            bb.join_plan(plans[-1])
             torch.cuda.synchronize()
     finally:
         assert lib.vc_debug_set(key.encode(), 2 if key == "sp_mark_variant" else 1) == 0
@@ -219,6 +222,7 @@ def test_native_plan_of_virconv8x_equals_the_operator_by_operator_plan(hip_backe
         monkeypatch.setattr(native_plan, "NATIVE_PLAN", native)
         torch.manual_seed(9)
         p = model.build_plan(batch, [""], 2, batch["calib"])
+        bb.join_plan(p)
         torch.cuda.synchronize()
         assert ("_arenas" in p) == native
         plans.append(p)

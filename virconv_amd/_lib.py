@@ -117,6 +117,7 @@ SIGNATURES = {
     "vc_plan_wait": (_I, [_P, _P]),
     "vc_plan_finish_arena_bytes": (_SZ, [_P, _P]),
     "vc_plan_finish": (_I, [_P, _P, _P, _P, _SZ, _P, _P]),
+    "vc_plan_finish_backward": (_I, [_P, _P, _P, _P, _SZ, _P]),
 }
 
 

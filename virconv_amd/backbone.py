@@ -243,6 +243,8 @@ def _record_stream(obj, stream):
 
 
 _PLAN_STREAMS = {}
+# backward-only structures of a native plan are enqueued behind the event the forward pass waits for (VIRCONV_PLAN_DEFER_BACKWARD=0: A/B)
+PLAN_DEFER_BACKWARD = os.environ.get("VIRCONV_PLAN_DEFER_BACKWARD", "1") != "0"
 
 
 def _plan_stream(device):
@@ -280,6 +282,8 @@ class _PlanScope:
 
     def __init__(self, ref_tensor, batch_dict):
         self.on_gpu = ref_tensor.is_cuda
+        # closures that enqueue what only backward passes read (native_plan.build_chain): run AFTER the event the forward waits for
+        self.deferred = [] if (ref_tensor.is_cuda and PLAN_DEFER_BACKWARD) else None
         if self.on_gpu:
             self.main = torch.cuda.current_stream()
             _bound_run_ahead(ref_tensor.device, self.main)
@@ -303,10 +307,31 @@ class _PlanScope:
 
     def publish(self, plan):
         if self.on_gpu:
-            self.main.wait_stream(self.side)
+            if self.deferred:
+                # the forward pass waits for the tables IT reads.  The group-plan sorts and backward row orders are ENQUEUED by
+                # join_plan -- after the forward pass is on the main stream: their ~50 launches cost the host 0.2 ms that used to
+                # stand between the row counts and the first forward kernel -- and run on the plan stream underneath the forward
+                fwd_ready = torch.cuda.Event()
+                fwd_ready.record(self.side)
+                self.main.wait_event(fwd_ready)
+                plan["_deferred"] = (self.side, self.deferred)
+            else:
+                self.main.wait_stream(self.side)
             # a native plan lives in two arenas (every structure is a view of one of them): marking those is marking everything
             _record_stream(plan["_arenas"] if (isinstance(plan, dict) and "_arenas" in plan) else plan, self.main)
         return plan
+
+
+def join_plan(plan):
+    """End of a forward pass: enqueue what only backward passes read (native_plan.build_chain's `deferred` closures) on the plan
+    stream, and let everything behind this point on the current stream (the loss, the backward pass) wait for it."""
+    d = plan.pop("_deferred", None) if isinstance(plan, dict) else None
+    if d is not None:
+        side, fns = d
+        with torch.cuda.stream(side):
+            for fn in fns:
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
 
 
 def _draw_keep(rate, n, batch_dict, tag, device):
@@ -441,7 +466,8 @@ class VirConvL8x(nn.Module):
             if native_plan.usable(idx, blocks):
                 # the whole plan as three native calls around ONE count read (csrc/plan.hip)
                 stages, rb_out, _, _, arenas = native_plan.build(self, blocks, co, idx, batch_size, calib, trans_param, tags,
-                                                                 self.layer_discard_rate, batch_dict, NRConvBlock.IMAGE_SHAPE)
+                                                                 self.layer_discard_rate, batch_dict, NRConvBlock.IMAGE_SHAPE,
+                                                                 deferred=scope.deferred)
                 plan = {"in_indices": idx, "stages": stages, "conv_out": {co.indice_key: rb_out}, "_arenas": arenas + [idx]}
             else:
                 stages, in_idx, shape, begun = _plan_nrconv_chain(blocks, idx, list(self.sparse_shape), batch_size, calib,
@@ -509,6 +535,8 @@ class VirConvL8x(nn.Module):
                 x4 = self.vir_conv4(x3, batch_size, calib, 8, None, trans_param)
                 out = self.conv_out(x4)
 
+            if self.plan_ahead:
+                join_plan(plan)
             batch_dict.update({
                 "encoded_spconv_tensor" + rid: out,
                 "encoded_spconv_tensor_stride" + rid: 8,
@@ -611,7 +639,7 @@ class VirConv8x(nn.Module):
 
     # ---- geometry plan (same idea as VirConvL8x.build_plan): every rulebook of both streams, the eval-time slab splits and
     # the discard permutations are functions of the coordinates only and are built first, on the plan stream
-    def _plan_lidar(self, idx, shape, batch_size, batch_dict=None, arenas=None):
+    def _plan_lidar(self, idx, shape, batch_size, batch_dict=None, arenas=None, deferred=None):
         """{indice_key: Rulebook} of the LiDAR stream + the coordinates of x2, x3, x4 and the output.  One native chain plan (three
         C calls, one count read: native_plan.build_chain) when available, operator by operator otherwise."""
         first, co = self.conv_input[0], self.conv_out[0]
@@ -619,7 +647,7 @@ class VirConv8x(nn.Module):
         if batch_dict is not None and list(shape) == list(self.sparse_shape) and native_plan.usable(idx):
             chain = [native_plan.ChainBlock(None, first)] + [native_plan.ChainBlock(seq[0][0], seq[1][0]) for seq in stages]
             res, rb_tail, _, _, ar = native_plan.build_chain(self, "8x-lidar", chain, co, idx, batch_size, None, None, [None] * 4, 0.0,
-                                                             batch_dict, NRConvBlock.IMAGE_SHAPE)
+                                                             batch_dict, NRConvBlock.IMAGE_SHAPE, deferred=deferred)
             if arenas is not None:
                 arenas.extend(ar)
             rbs, coords = {first.indice_key: res[0]["subm3d"]}, {}
@@ -664,7 +692,7 @@ class VirConv8x(nn.Module):
                 for rid in rids:
                     idx = batch_dict["voxel_coords" + rid].int()
                     n0 = len(arenas)
-                    rbs, _ = self._plan_lidar(idx, self.sparse_shape, batch_size, batch_dict, arenas)
+                    rbs, _ = self._plan_lidar(idx, self.sparse_shape, batch_size, batch_dict, arenas, scope.deferred)
                     native_only = native_only and len(arenas) > n0
                     arenas.append(idx)
                     plan["lidar"][rid] = (idx, rbs)
@@ -694,7 +722,8 @@ class VirConv8x(nn.Module):
                         # input discard (spconv_backbone.py:488-489) + the four blocks + their layer discards: one native chain plan
                         stages, _, keep0, kept0, ar = native_plan.build(self, blocks, None, idx, batch_size, calib, trans_param, tags,
                                                                         self.layer_discard_rate, batch_dict, NRConvBlock.IMAGE_SHAPE,
-                                                                        input_discard_tag=(f"mm_input{rid}" if active else None))
+                                                                        input_discard_tag=(f"mm_input{rid}" if active else None),
+                                                                        deferred=scope.deferred)
                         arenas.extend(ar)
                         arenas.append(idx)
                         plan["mm"][rid] = {"keep0": keep0, "in_indices": kept0 if active else idx, "stages": stages,
@@ -812,6 +841,8 @@ class VirConv8x(nn.Module):
                 batch_dict.update({"encoded_spconv_tensor_stride_mm" + rid: 8,
                                    "multi_scale_3d_features_mm" + rid: {"x_conv1": m1, "x_conv2": m2, "x_conv3": m3, "x_conv4": m4},
                                    "multi_scale_3d_strides" + rid: dict(strides)})
+        if plan is not None:
+            join_plan(plan)
         return batch_dict
 
 

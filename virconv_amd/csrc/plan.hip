@@ -241,7 +241,7 @@ struct Blk {
 };
 struct PlanState {
   uint64_t magic;
-  int n_counts, ev_slot, waited, params_ready;
+  int n_counts, ev_slot, waited, params_ready, finished;
   int32_t* host_counts;
   int64_t counts_off, params_off;
   int64_t in_keep_off, in_kept_off, cap_in_keep, n_in_keep;   // discard of the chain's input
@@ -378,7 +378,9 @@ struct TableArena {
 static const vc_plan_view kAbsent = {-1, 0, 0, 0};
 
 static int conv_tables(const vc_plan_desc* d, const PlanState& S, const Conv& C, const vc_plan_conv& g, const int32_t* in_coords,
-                       const vc_plan_view& in_view, char* arena_a, TableArena& A, bool dry, vc_plan_table_out& T, hipStream_t st) {
+                       const vc_plan_view& in_view, char* arena_a, TableArena& A, bool dry, vc_plan_table_out& T, hipStream_t st, int phase) {
+  // phase 0: what a forward pass reads (pair tables, forward row order); phase 1: the rest (backward row order).  Both phases walk
+  // the same allocations, so that the offsets agree.
   const int64_t n_in = C.n_in, n_out = C.n_out;
   T = vc_plan_table_out{};
   T.present = 1;
@@ -399,10 +401,13 @@ static int conv_tables(const vc_plan_desc* d, const PlanState& S, const Conv& C,
   if (want_bwd_order) { ob = A.bump->take((size_t)std::max<int64_t>(n_in, 1) * 4); T.order_bwd = vc_plan_view{A.id, 1, ob, n_in}; }
   if (want_fwd_order) { of = A.bump->take((size_t)std::max<int64_t>(n_out, 1) * 4); T.order_fwd = vc_plan_view{A.id, 1, of, n_out}; }
   if (dry) return VC_OK;
-  int rc = vc_spconv_pairs(in_coords, n_in, 3, d->batch_size, C.out_shape, g.ksize, g.stride, g.padding, g.dilation, arena_a + C.ws_off,
-                           C.ws_bytes, n_out, (int32_t*)(A.base + pf), (int32_t*)(A.base + pb), st);
-  if (rc != VC_OK) return rc;
-  if (want_bwd_order && n_in > 0) {
+  int rc = VC_OK;
+  if (phase == 0) {
+    rc = vc_spconv_pairs(in_coords, n_in, 3, d->batch_size, C.out_shape, g.ksize, g.stride, g.padding, g.dilation, arena_a + C.ws_off,
+                         C.ws_bytes, n_out, (int32_t*)(A.base + pf), (int32_t*)(A.base + pb), st);
+    if (rc != VC_OK) return rc;
+  }
+  if (phase == 1 && want_bwd_order && n_in > 0) {
     const int nc = g.stride[0] * g.stride[1] * g.stride[2];
     if (g_plan_parity_order && nc <= 16 && g.dilation[0] == 1 && g.dilation[1] == 1 && g.dilation[2] == 1) {
       hipLaunchKernelGGL((parity_order_kernel<512>), dim3((unsigned)cdiv(n_in, 2048)), dim3(512), 0, st, in_coords, n_in, g.stride[0],
@@ -413,7 +418,7 @@ static int conv_tables(const vc_plan_desc* d, const PlanState& S, const Conv& C,
       if (rc != VC_OK) return rc;
     }
   }
-  if (want_fwd_order && n_out > 0) {
+  if (phase == 0 && want_fwd_order && n_out > 0) {
     rc = vc_row_order((const int32_t*)(A.base + pf), n_out, C.kv, nullptr, -1, 2048, (int32_t*)(A.base + of), st);
     if (rc != VC_OK) return rc;
   }
@@ -422,7 +427,9 @@ static int conv_tables(const vc_plan_desc* d, const PlanState& S, const Conv& C,
 }
 
 static int block_tables(const vc_plan_desc* d, const PlanState& S, int b, const int32_t* coords, const vc_plan_view& coords_view,
-                        char* arena_a, TableArena& A, bool dry, vc_plan_block_out& O, hipStream_t st) {
+                        char* arena_a, TableArena& A, bool dry, vc_plan_block_out& O, hipStream_t st, int phase) {
+  // phase 0: the tables a forward pass reads; phase 1: the duplicate-pixel group plan (read by backward passes only: the sorts are
+  // a third of the plan's stream time and no longer stand between the counts and the first forward kernel)
   const vc_plan_block& B = d->blocks[b];
   const Blk& K = S.blk[b];
   const int64_t n = K.n;
@@ -480,6 +487,13 @@ static int block_tables(const vc_plan_desc* d, const PlanState& S, int b, const 
   }
   if (dry || n == 0) return VC_OK;
   int rc;
+  if (phase == 1) {
+    if (B.has_2d && d->need_grad) {
+      rc = vc_group_plan((const int32_t*)(A.base + repo), n, (int32_t*)(A.base + gpo), A.base + gwo, gw_bytes, st);
+      if (rc != VC_OK) return rc;
+    }
+    return VC_OK;
+  }
   int32_t* pair3 = (int32_t*)(A.base + p3);
   if (by_bitmap) {
     const unsigned long long* bitmap = (const unsigned long long*)(arena_a + K.down.ws_off);
@@ -516,11 +530,6 @@ static int block_tables(const vc_plan_desc* d, const PlanState& S, int b, const 
       rc = vc_subm_rulebook(uv, n, 2, d->image_shape, B.ksize2d, B.dilation2d, A.base + h2o, h2_bytes, pair2, rep, st);
       if (rc != VC_OK) return rc;
     }
-    if (d->need_grad) {
-      int32_t* gp = (int32_t*)(A.base + gpo);
-      rc = vc_group_plan(rep, n, gp, A.base + gwo, gw_bytes, st);
-      if (rc != VC_OK) return rc;
-    }
   }
   return VC_OK;
 }
@@ -550,7 +559,7 @@ size_t vc_plan_begin_arena_bytes(const vc_plan_desc* d) {
   for (int b = 0; b < d->n_blocks; ++b)
     if (S.blk[b].early) {
       vc_plan_block_out O{};
-      if (block_tables(d, S, b, nullptr, kAbsent, nullptr, A, true, O, nullptr) != VC_OK) return 0;
+      if (block_tables(d, S, b, nullptr, kAbsent, nullptr, A, true, O, nullptr, 0) != VC_OK) return 0;
     }
   return bump.off + 256;
 }
@@ -687,7 +696,7 @@ int vc_plan_begin(const vc_plan_desc* d, void* arena_a, size_t arena_a_bytes, in
     if (!K.early) continue;
     const int32_t* coords = K.coords_off < 0 ? d->indices : (const int32_t*)(A + K.coords_off);
     const vc_plan_view cv = K.coords_off < 0 ? kAbsent : vc_plan_view{0, 4, K.coords_off, K.n};
-    rc = block_tables(d, S, b, coords, cv, A, TA, false, S.early_out.blocks[b], st);
+    rc = block_tables(d, S, b, coords, cv, A, TA, false, S.early_out.blocks[b], st, 0);
     if (rc != VC_OK) return rc;
   }
   S.magic = kPlanMagic;
@@ -736,7 +745,7 @@ int vc_plan_wait(const vc_plan_desc* d, vc_plan_state* state) {
 }
 
 static int finish_impl(const vc_plan_desc* d, PlanState& S, char* arena_a, char* arena_b, size_t arena_b_bytes, vc_plan_out* out, bool dry,
-                       size_t* need, hipStream_t st) {
+                       size_t* need, hipStream_t st, int phase) {
   Bump2 bump;
   TableArena TB{arena_b, 1, &bump};
   vc_plan_out O = S.early_out;
@@ -754,7 +763,7 @@ static int finish_impl(const vc_plan_desc* d, PlanState& S, char* arena_a, char*
     vc_plan_block_out& BO = O.blocks[b];
     int rc;
     if (B.has_down) {
-      rc = conv_tables(d, S, K.down, B.down, cur, cur_view, arena_a, TB, dry, BO.down, st);
+      rc = conv_tables(d, S, K.down, B.down, cur, cur_view, arena_a, TB, dry, BO.down, st, phase);
       if (rc != VC_OK) return rc;
       cur = (const int32_t*)(arena_a + K.down.out_idx_off);
       cur_view = vc_plan_view{0, 4, K.down.out_idx_off, K.down.n_out};
@@ -762,7 +771,7 @@ static int finish_impl(const vc_plan_desc* d, PlanState& S, char* arena_a, char*
       BO.down = vc_plan_table_out{};
     }
     if (!K.early) {
-      rc = block_tables(d, S, b, cur, cur_view, arena_a, TB, dry, BO, st);
+      rc = block_tables(d, S, b, cur, cur_view, arena_a, TB, dry, BO, st, phase);
       if (rc != VC_OK) return rc;
     }
     BO.n = K.n;
@@ -777,7 +786,7 @@ static int finish_impl(const vc_plan_desc* d, PlanState& S, char* arena_a, char*
   }
   O.tail = vc_plan_table_out{};
   if (d->has_tail) {
-    const int rc = conv_tables(d, S, S.tail, d->tail, cur, cur_view, arena_a, TB, dry, O.tail, st);
+    const int rc = conv_tables(d, S, S.tail, d->tail, cur, cur_view, arena_a, TB, dry, O.tail, st, phase);
     if (rc != VC_OK) return rc;
   }
   if (need) *need = bump.off + 256;
@@ -793,7 +802,7 @@ size_t vc_plan_finish_arena_bytes(const vc_plan_desc* d, const vc_plan_state* st
   PlanState S = *reinterpret_cast<const PlanState*>(state);
   if (S.magic != kPlanMagic || !S.waited) { set_error("vc_plan_finish_arena_bytes: call vc_plan_wait first"); return 0; }
   size_t need = 0;
-  if (finish_impl(d, S, nullptr, nullptr, 0, nullptr, true, &need, nullptr) != VC_OK) return 0;
+  if (finish_impl(d, S, nullptr, nullptr, 0, nullptr, true, &need, nullptr, 0) != VC_OK) return 0;
   return need;
 }
 
@@ -807,11 +816,39 @@ int vc_plan_finish(const vc_plan_desc* d, vc_plan_state* state, void* arena_a, v
   size_t need = 0;
   {
     PlanState T = S;
-    rc = finish_impl(d, T, nullptr, nullptr, 0, nullptr, true, &need, nullptr);
+    rc = finish_impl(d, T, nullptr, nullptr, 0, nullptr, true, &need, nullptr, 0);
     if (rc != VC_OK) return rc;
   }
   if (arena_b_bytes < need) { set_error("vc_plan_finish: arena_b too small (%zu < %zu)", arena_b_bytes, need); return VC_ECAPACITY; }
-  return finish_impl(d, S, (char*)arena_a, (char*)arena_b, arena_b_bytes, out, false, nullptr, (hipStream_t)stream);
+  rc = finish_impl(d, S, (char*)arena_a, (char*)arena_b, arena_b_bytes, out, false, nullptr, (hipStream_t)stream, 0);
+  if (rc == VC_OK) S.finished = 1;
+  return rc;
+}
+
+int vc_plan_finish_backward(const vc_plan_desc* d, vc_plan_state* state, void* arena_a, void* arena_b, size_t arena_b_bytes, void* stream) {
+  int rc = check_desc(d);
+  if (rc != VC_OK) return rc;
+  VC_REQUIRE(state && arena_a && arena_b, "vc_plan_finish_backward: null argument");
+  PlanState& S = *reinterpret_cast<PlanState*>(state);
+  VC_REQUIRE(S.magic == kPlanMagic && S.finished, "vc_plan_finish_backward: call vc_plan_finish first");
+  if (!d->need_grad) return VC_OK;
+  hipStream_t st = (hipStream_t)stream;
+  {  // blocks whose forward tables vc_plan_begin built in arena A: the same walk over the same layout
+    PlanState T = S;
+    Bump2 bump;
+    layout_chain(d, T, bump);
+    TableArena TA{(char*)arena_a, 0, &bump};
+    for (int b = 0; b < d->n_blocks; ++b) {
+      const Blk& K = S.blk[b];
+      if (!K.early) continue;
+      const int32_t* coords = K.coords_off < 0 ? d->indices : (const int32_t*)((char*)arena_a + K.coords_off);
+      vc_plan_block_out O{};
+      rc = block_tables(d, S, b, coords, kAbsent, (char*)arena_a, TA, false, O, st, 1);
+      if (rc != VC_OK) return rc;
+    }
+  }
+  PlanState T = S;
+  return finish_impl(d, T, (char*)arena_a, (char*)arena_b, arena_b_bytes, nullptr, false, nullptr, st, 1);
 }
 
 }  // extern "C"

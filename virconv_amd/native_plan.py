@@ -114,12 +114,15 @@ def _table(arenas, t: _lib.PlanTableOut, kind, in_shape, conv, in_idx) -> ops.Ru
 
 
 def build_chain(model, kind: str, chain, tail, idx: torch.Tensor, batch_size: int, calib, trans_param, discard_tags, rate: float,
-                batch_dict, image_shape, input_discard_tag=None):
+                batch_dict, image_shape, input_discard_tag=None, deferred=None):
     """The native plan of a chain of ChainBlocks (+ `tail`: the strided conv behind it) over the coordinates `idx` (N, 4) int32.
     `discard_tags[b]`: the batch_dict tag of the layer discard after block b or None; `input_discard_tag`: discard of the chain's
     input (VirConv8x MM stream).  `kind`: cache key of the chain's static description on `model`.
     -> (per block: {"down", "subm3d", "uv", "subm2d", "out_indices", "out_shape", "keep", "kept_indices"}, tail Rulebook | None,
-        input keep | None, kept input indices | None, [arena_a, arena_b])"""
+        input keep | None, kept input indices | None, [arena_a, arena_b])
+    `deferred`: None -> everything is enqueued here.  A list -> only what a FORWARD pass reads is enqueued; a closure that enqueues
+    the rest (group plans, backward row orders: vc_plan_finish_backward) on the then-current stream is appended, and the caller
+    runs it after recording the event the forward pass waits for (backbone._PlanScope.publish)."""
     be = ops.get_backend()
     lib = be.lib
     dev = idx.device
@@ -184,6 +187,18 @@ def build_chain(model, kind: str, chain, tail, idx: torch.Tensor, batch_size: in
     out = _lib.PlanOut()
     _lib.check(lib.vc_plan_finish(dref, sref, arena_a.data_ptr(), arena_b.data_ptr(), arena_b.numel() * 4, C.byref(out), st),
                "vc_plan_finish")
+    if d.need_grad:
+        if deferred is None:
+            _lib.check(lib.vc_plan_finish_backward(dref, sref, arena_a.data_ptr(), arena_b.data_ptr(), arena_b.numel() * 4, st),
+                       "vc_plan_finish_backward")
+        else:
+            d_own = _lib.PlanDesc.from_buffer_copy(d)   # the cached description is rewritten by the next build of this kind
+
+            def finish_backward(d_own=d_own, state=state, hold=hold, arena_a=arena_a, arena_b=arena_b):
+                _lib.check(lib.vc_plan_finish_backward(C.byref(d_own), C.byref(state), arena_a.data_ptr(), arena_b.data_ptr(),
+                                                       arena_b.numel() * 4, be.stream()), "vc_plan_finish_backward")
+
+            deferred.append(finish_backward)
     del hold
     arenas = (arena_a, arena_b)
     res = []
@@ -213,12 +228,12 @@ def build_chain(model, kind: str, chain, tail, idx: torch.Tensor, batch_size: in
 
 
 def build(model, blocks, tail, idx: torch.Tensor, batch_size: int, calib, trans_param, discard_tags, rate: float, batch_dict,
-          image_shape, input_discard_tag=None):
+          image_shape, input_discard_tag=None, deferred=None):
     """The plan of a chain of NRConvBlocks `blocks` = [(block, uv stride)] in the form backbone._plan_nrconv_chain returns:
     -> (stages, tail Rulebook | None, input keep | None, kept input indices | None, [arena_a, arena_b])."""
     res, rb_tail, in_keep, in_kept, arenas = build_chain(model, ("nrconv", len(blocks), tail is not None, input_discard_tag is not None),
                                                          nrconv_blocks(blocks), tail, idx, batch_size, calib, trans_param,
-                                                         discard_tags, rate, batch_dict, image_shape, input_discard_tag)
+                                                         discard_tags, rate, batch_dict, image_shape, input_discard_tag, deferred)
     stages = []
     for (blk, _), r in zip(blocks, res):
         kd, k3, k2 = blk._keys()
