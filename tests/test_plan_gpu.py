@@ -208,6 +208,47 @@ def test_train_step_with_the_native_plan_matches_the_operator_by_operator_plan(h
         assert float((g_py[k] - g_n1[k]).abs().max()) <= 1e-5 * scale, k
 
 
+def test_training_with_the_plan_built_a_step_ahead_is_bit_identical(hip_backend):
+    """VirConvL8x.plan_ahead_begin / _finish (bench.train_step(next_batch=...)): the plan of step t + 1 begun before step t's forward
+    and finished behind its backward.  With the layer discards injected (the random draws would otherwise be consumed in a different
+    order) three optimiser steps give the same losses and the same parameters, bit for bit; a batch the early plan was NOT begun for
+    falls back to the in-place plan."""
+    dev = torch.device("cuda", 0)
+    batch = bench.make_batch([0, 1], dev, training=True)
+    other = bench.make_batch([2, 3], dev, training=True)
+    lw = bench.make_loss_weights(dev)
+    torch.manual_seed(3)
+    probe = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).cuda().train()
+    for b in (batch, other):
+        p0 = probe.build_plan(b["voxel_coords"], 2, b["calib"], b["aug_param"], b)
+        bb.join_plan(p0)
+        b["layer_discard_keep"] = {f"x_conv{bi + 1}": p0["stages"][bi]["keep"].clone() for bi in range(3)}
+    torch.cuda.synchronize()
+
+    def run(ahead):
+        torch.manual_seed(0)
+        model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).cuda().train()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, fused=True)
+        seq = [batch, batch, other, batch]
+        losses, took = [], 0
+        for t, b in enumerate(seq):
+            nxt = seq[t + 1] if (ahead and t + 1 < len(seq)) else None
+            if ahead and t == 1:
+                nxt = batch          # a WRONG guess: step 2 runs `other`, the early plan must be dropped
+            had = len(model._ahead) > 0
+            losses.append(float(bench.train_step(model, opt, b, lw, next_batch=nxt)))
+            took += int(had)
+        torch.cuda.synchronize()
+        return losses, {k: p.detach().clone() for k, p in model.named_parameters()}, took
+
+    l0, p0_, _ = run(False)
+    l1, p1_, took = run(True)
+    assert took == 3                      # steps 1, 2 (dropped: wrong batch), 3 entered forward with an early plan pending
+    assert l0 == l1
+    for k in p0_:
+        assert torch.equal(p0_[k], p1_[k]), k
+
+
 def test_native_plan_of_virconv8x_equals_the_operator_by_operator_plan(hip_backend, monkeypatch):
     """VirConv8x, training (spconv_backbone.py:339-535): the LiDAR stream (conv_input / conv1..4 / conv_out: one SubM table per
     stage, no image-space branch) and the virtual-point stream (input discard :488-489 + four NRConvBlocks + layer discards) are

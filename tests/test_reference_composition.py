@@ -35,9 +35,9 @@ def test_fixture_regenerates_from_reference_code():
 def test_reference_backbone_runs_unmodified_on_facade_and_matches_ours():
     """The drop-in claim: reference VirConvL8x (unmodified) and virconv_amd VirConvL8x share state_dict keys/shapes."""
     from helpers import GRID, MODEL_CFG
-    from easydict import EasyDict
     from virconv_amd.backbone import VirConvL8x
-    ref = refharness.import_reference_backbone()
+    ref = refharness.import_reference_backbone()   # (installs the stub modules the reference imports: easydict, numba, ...)
+    from easydict import EasyDict
     a = ref.VirConvL8x(EasyDict(MODEL_CFG), input_channels=8, grid_size=GRID)
     b = VirConvL8x(MODEL_CFG, input_channels=8, grid_size=GRID)
     sa, sb = a.state_dict(), b.state_dict()
@@ -54,11 +54,11 @@ def test_reference_voxel_generator_wrapper_and_meanvfe_run_unmodified_on_the_fac
     (mean_vfe.py:39-49) are driven through the facade (oracle operators here; tests/test_ops_gpu.py does the same
     protocol on HIP) and must reproduce the oracle voxeliser + MeanVFE bit for bit."""
     import importlib
-    from easydict import EasyDict
     from oracle import geometry
     from oracle.backend import OracleBackend
     from virconv_amd import data, ops, synth
     refharness.import_reference_backbone()  # install() facade + cumm shim + stubs + sys.path
+    from easydict import EasyDict
     dp = importlib.import_module("pcdet.datasets.processor.data_processor")
     assert dp.tv is not None, "the cumm.tensorview shim was not picked up by the reference's data_processor"
     fr = synth.make_frame(3)

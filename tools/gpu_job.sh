@@ -11,7 +11,7 @@
 #   hostprof | phases | kbench[:<args>] | bevbench | gaps
 #   stats                     rocprofv3 --kernel-trace --stats of the bench command (+ trace_gaps)
 #   pmc                       FETCH_SIZE / WRITE_SIZE passes of the bench command (separate runs, no other tracing)
-#   mfma                      MFMA-busy counters of the traced kernel and a strided forward (kbench)
+#   mfma | mfmadw             MFMA-busy counters of the traced kernel and a strided forward | of two weight-gradient launches (kbench)
 #   py:<file>[:<args>]        python <file> <args>
 R="${GRAFT_REPO_ROOT:-$PWD}"; cd "$R" || exit 1
 TAG="${1:-job}"; shift
@@ -54,6 +54,10 @@ for step in "$@"; do
       ( cd /tmp && export TMPDIR=/tmp && timeout 120 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY \
           SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE -d "$R/$D/mfma" -o r --output-format csv -- \
           python "$R/tools/kbench.py" --layers s3.d3_conv1,s3.down --only fwd --iters 5 --autopack ${arg} > "$R/$D/p_mfma.log" 2>&1 ); echo done ;;
+    mfmadw)
+      ( cd /tmp && export TMPDIR=/tmp && timeout 120 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY \
+          SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE -d "$R/$D/mfmadw" -o r --output-format csv -- \
+          python "$R/tools/kbench.py" --layers s3.d3_conv1,s3.d3_conv2 --only dw --iters 5 ${arg} > "$R/$D/p_mfmadw.log" 2>&1 ); echo done ;;
     py) f="${arg%%:*}"; a=""; [ "$arg" != "$f" ] && a="${arg#*:}"; timeout 600 python "$f" $a > "$D/$(basename "$f" .py).txt" 2>&1; echo "rc=$?"; tail -n 5 "$D/$(basename "$f" .py).txt" ;;
     *) echo "unknown step $step" ;;
   esac

@@ -280,13 +280,14 @@ class _PlanScope:
     """Run the geometry plan on the high-priority side stream (see VirConvL8x.build_plan) and hand the result to the main
     stream.  CPU tensors: a no-op scope."""
 
-    def __init__(self, ref_tensor, batch_dict):
+    def __init__(self, ref_tensor, batch_dict, ahead=False):
         self.on_gpu = ref_tensor.is_cuda
         # closures that enqueue what only backward passes read (native_plan.build_chain): run AFTER the event the forward waits for
         self.deferred = [] if (ref_tensor.is_cuda and PLAN_DEFER_BACKWARD) else None
         if self.on_gpu:
             self.main = torch.cuda.current_stream()
-            _bound_run_ahead(ref_tensor.device, self.main)
+            if not ahead:   # (a plan begun a step ahead is bounded by the training loop itself)
+                _bound_run_ahead(ref_tensor.device, self.main)
             self.side = _plan_stream(ref_tensor.device)
             ready = batch_dict.get("inputs_ready_event")
             if ready is not None:
@@ -419,6 +420,8 @@ class VirConvL8x(nn.Module):
         self.layer_discard_mode = _cfg_get(model_cfg, "LAYER_DISCARD_MODE", "spconv2_noop")
         assert self.layer_discard_mode in ("spconv1_inplace", "spconv2_noop")
         self.plan_ahead = bool(_cfg_get(model_cfg, "PLAN_AHEAD", True))
+        self._ahead = []        # plans begun for coming batches (plan_ahead_begin), oldest first; at most two
+        self._fwd_count = 0     # forward passes so far: a plan begun during step t serves a LATER forward, never step t's own
         num_filters = _cfg_get(model_cfg, "NUM_FILTERS")
         norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
         self.sparse_shape = [int(v) for v in (np.asarray(grid_size)[::-1] + [1, 0, 0])]
@@ -476,6 +479,95 @@ class VirConvL8x(nn.Module):
                 plan = {"in_indices": idx, "stages": stages, "conv_out": {co.indice_key: rb_out}}
         return scope.publish(plan)
 
+    # ---- plan-ahead: the geometry plan of the NEXT batch under the current training step.  The plan depends on the batch's
+    # coordinates (and calibration / augmentation parameters / discard seeds) only, not on the weights, so a training loop that holds
+    # batch t + 1 while it runs step t -- any prefetching loader does -- can build it a step early:
+    #     model.plan_ahead_begin(next_batch)      # before the forward of step t: coordinates, keeps, row counts (no host sync)
+    #     ... forward / backward of step t ...
+    #     model.plan_ahead_finish()               # counts arrived long ago: the tables go onto the plan stream, under step t's tail
+    #     optimizer.step()
+    # and forward(next_batch) finds its plan finished (matched by the identity and version of its voxel_coords tensor; a mismatch of
+    # any kind just discards the early plan and builds one in place).  One plan is built per step either way -- it only moves off the
+    # critical path between two steps (bench.py reports the step time with and without it).
+    def _rot_inputs(self, batch_dict):
+        rot_num = batch_dict["transform_param"].shape[1] if "transform_param" in batch_dict else 1
+        for i in range(rot_num):
+            rid = "" if i == 0 else str(i)
+            trans_param = batch_dict["aug_param"] if "aug_param" in batch_dict else None
+            if "transform_param" in batch_dict:
+                trans_param = batch_dict["transform_param"][:, i, :]
+            yield rid, trans_param
+
+    def _ahead_mode(self):
+        return (self.training, torch.is_grad_enabled(), self._discard_active(), ops.ROW_ORDER)
+
+    def plan_ahead_begin(self, batch_dict) -> bool:
+        coords0 = batch_dict["voxel_coords"]
+        if not (self.plan_ahead and coords0.is_cuda):
+            return False
+        calib = batch_dict["calib"]
+        if not torch.is_tensor(calib):
+            calib = ops.calib_tensor(calib, coords0.device)
+        batch_size = batch_dict["batch_size"]
+        blocks = [(self.vir_conv1, 1), (self.vir_conv2, 2), (self.vir_conv3, 4), (self.vir_conv4, 8)]
+        co = self.conv_out[0]
+        active = self._discard_active()
+        entries = {}
+        scope = _PlanScope(coords0, batch_dict, ahead=True)
+        with scope:
+            for rid, trans_param in self._rot_inputs(batch_dict):
+                coords = batch_dict["voxel_coords" + rid]
+                idx = coords.int()
+                if not native_plan.usable(idx, blocks):
+                    return False
+                tags = [f"x_conv{bi + 1}{rid}" if (bi < 3 and active) else None for bi in range(4)]
+                cp = native_plan.ChainPlan(self, native_plan.nrconv_kind(blocks, co, None), native_plan.nrconv_blocks(blocks), co, idx,
+                                           batch_size, calib, trans_param, tags, self.layer_discard_rate, batch_dict,
+                                           NRConvBlock.IMAGE_SHAPE, None, scope.deferred)
+                entries[rid] = (coords, coords._version, idx, cp)
+        self._ahead.append({"entries": entries, "scope": scope, "mode": self._ahead_mode(), "blocks": blocks, "fwd_ready": None,
+                            "born": self._fwd_count})
+        del self._ahead[:-2]      # the current step's and the next one's; anything older was never consumed
+        return True
+
+    @staticmethod
+    def _finish_ahead(a) -> None:
+        if a["fwd_ready"] is None:
+            with torch.cuda.stream(a["scope"].side):
+                for _, _, _, cp in a["entries"].values():
+                    cp.finish()
+                a["fwd_ready"] = torch.cuda.Event()
+                a["fwd_ready"].record()
+
+    def plan_ahead_finish(self) -> None:
+        """Enqueue the tables of every begun plan (no-op for those already finished)."""
+        for a in self._ahead:
+            self._finish_ahead(a)
+
+    def _take_ahead(self, coords, rid):
+        mode = self._ahead_mode()
+        for a in self._ahead:
+            e = a["entries"].get(rid)
+            if e is not None and e[0] is coords and e[1] == coords._version and a["mode"] == mode and a["born"] < self._fwd_count:
+                break
+        else:
+            return None            # no early plan for this batch (or not in this mode): the caller plans in place
+        self._finish_ahead(a)
+        _, _, idx, cp = a["entries"].pop(rid)
+        res, rb_out, _, _, arenas = cp.finish()
+        plan = {"in_indices": idx, "stages": native_plan.nrconv_stages(a["blocks"], res),
+                "conv_out": {self.conv_out[0].indice_key: rb_out}, "_arenas": arenas + [idx]}
+        scope = a["scope"]
+        main = torch.cuda.current_stream()
+        main.wait_event(a["fwd_ready"])
+        if scope.deferred:
+            plan["_deferred"] = (scope.side, scope.deferred)
+            scope.deferred = []
+        _record_stream(plan["_arenas"], main)
+        if not a["entries"]:
+            self._ahead.remove(a)
+        return plan
+
     def forward(self, batch_dict):
         if "transform_param" in batch_dict:
             rot_num = batch_dict["transform_param"].shape[1]
@@ -499,7 +591,9 @@ class VirConvL8x(nn.Module):
                 trans_param = batch_dict["transform_param"][:, i, :]
 
             if self.plan_ahead:
-                plan = self.build_plan(coords, batch_size, calib, trans_param, batch_dict, rid)
+                plan = self._take_ahead(coords, rid)
+                if plan is None:
+                    plan = self.build_plan(coords, batch_size, calib, trans_param, batch_dict, rid)
                 native = feature_pass.run(self, feats, plan) if feature_pass.usable(self, feats, plan) else None
                 if native is not None:
                     # the whole chain below as ONE native call per direction (virconv_amd/feature_pass.py): same kernels, same order
@@ -543,6 +637,7 @@ class VirConvL8x(nn.Module):
                 "multi_scale_3d_features" + rid: {"x_conv1": x1, "x_conv2": x2, "x_conv3": x3, "x_conv4": x4},
                 "multi_scale_3d_strides" + rid: {"x_conv1": 1, "x_conv2": 2, "x_conv3": 4, "x_conv4": 8},
             })
+        self._fwd_count += 1
         return batch_dict
 
 

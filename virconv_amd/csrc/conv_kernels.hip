@@ -1114,7 +1114,10 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
   // non-centre offsets walk the representatives only (19-53 % of the rows) against dy_grp, the centre offset every row against dy.
   constexpr int VA = (CI >= 16) ? CI / 16 : 1, VB = (CO >= 16) ? CO / 16 : 1;
   constexpr int MA = (CI >= 16) ? 16 : CI, NB = (CO >= 16) ? 16 : CO;  // lanes of the tile that carry data
-  constexpr int U = (VA * VB >= 8) ? 2 : 4;                            // groups of 4 pairs gathered per iteration
+#ifndef VC_BW_UMUL
+#define VC_BW_UMUL 1   // A/B builds: groups per trip x 2 (profiles/r04_dw_trip_depth.md)
+#endif
+  constexpr int U = ((VA * VB >= 8) ? 2 : 4) * VC_BW_UMUL;             // groups of 4 pairs gathered per iteration
   constexpr int GP = (OT == VC_OPERAND_F32) ? 4 : 16;                  // pairs per MFMA K-step
   __shared__ int q_in[4][136];
   __shared__ int q_out[4][136];

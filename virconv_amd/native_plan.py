@@ -113,127 +113,148 @@ def _table(arenas, t: _lib.PlanTableOut, kind, in_shape, conv, in_idx) -> ops.Ru
     return rb
 
 
-def build_chain(model, kind: str, chain, tail, idx: torch.Tensor, batch_size: int, calib, trans_param, discard_tags, rate: float,
-                batch_dict, image_shape, input_discard_tag=None, deferred=None):
-    """The native plan of a chain of ChainBlocks (+ `tail`: the strided conv behind it) over the coordinates `idx` (N, 4) int32.
+class ChainPlan:
+    """The native plan of a chain of ChainBlocks (+ `tail`: the strided conv behind it) over the coordinates `idx` (N, 4) int32, in
+    two steps.  The constructor enqueues vc_plan_begin on the current stream (coordinates, keeps and row counts of every level;
+    no host synchronisation); `finish()` polls the counts (vc_plan_wait: the ONE host synchronisation), enqueues the tables and
+    returns the result.  `build_chain` does both back to back; `backbone.VirConvL8x.plan_ahead_begin / _finish` put a training step
+    between them (the counts have long arrived when finish() asks for them).
     `discard_tags[b]`: the batch_dict tag of the layer discard after block b or None; `input_discard_tag`: discard of the chain's
     input (VirConv8x MM stream).  `kind`: cache key of the chain's static description on `model`.
-    -> (per block: {"down", "subm3d", "uv", "subm2d", "out_indices", "out_shape", "keep", "kept_indices"}, tail Rulebook | None,
-        input keep | None, kept input indices | None, [arena_a, arena_b])
-    `deferred`: None -> everything is enqueued here.  A list -> only what a FORWARD pass reads is enqueued; a closure that enqueues
+    `deferred`: None -> finish() enqueues everything.  A list -> only what a FORWARD pass reads is enqueued; a closure that enqueues
     the rest (group plans, backward row orders: vc_plan_finish_backward) on the then-current stream is appended, and the caller
-    runs it after recording the event the forward pass waits for (backbone._PlanScope.publish)."""
-    be = ops.get_backend()
-    lib = be.lib
-    dev = idx.device
-    cache = _DESCS.setdefault(model, {})
-    if kind not in cache:
-        cache[kind] = _static_desc(chain, tail, model.sparse_shape, image_shape)
-    d = cache[kind]
-    hold = [idx, calib]
-    d.indices, d.n, d.batch_size = idx.data_ptr(), idx.shape[0], int(batch_size)
-    d.calib = calib.data_ptr() if calib is not None else None
-    if trans_param is not None:
-        trans_param = torch.as_tensor(trans_param, dtype=torch.float32, device=dev).reshape(batch_size, 3).contiguous()
-        hold.append(trans_param)
-        d.trans = trans_param.data_ptr()
-    else:
-        d.trans = None
-    d.discard_rate = float(rate) if (any(t is not None for t in discard_tags) or input_discard_tag is not None) else 0.0
-    d.need_grad = 1 if torch.is_grad_enabled() else 0
-    d.row_order_fwd = 1 if ops.ROW_ORDER == "strided" else 0
-    inj = batch_dict.get("layer_discard_keep")
+    runs it after the forward pass is on its stream (backbone.join_plan)."""
 
-    def keep_source(tag):
-        """(seed, injected tensor | None): the injected permutation prefix, or a seed drawn from torch's CPU generator exactly as
-        backbone.draw_random_keep does (same sequence of draws => same kept rows as the Python plan)."""
-        if inj is not None:
-            k = inj[tag].to(device=dev, dtype=torch.int64).contiguous()
-            hold.append(k)
-            return 0, k
-        return int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF, None
-
-    d.input_discard = 0
-    if input_discard_tag is not None:
-        seed, k = keep_source(input_discard_tag)
-        d.input_discard, d.input_keep_seed = 1, seed
-        d.input_keep, d.input_keep_rows = (k.data_ptr(), k.shape[0]) if k is not None else (None, 0)
-    for b, tag in enumerate(discard_tags):
-        B = d.blocks[b]
-        B.discard = 1 if tag is not None else 0
-        B.keep, B.keep_rows, B.keep_seed = None, 0, 0
-        if tag is not None:
-            seed, k = keep_source(tag)
-            B.keep_seed = seed
-            if k is not None:
-                B.keep, B.keep_rows = k.data_ptr(), k.shape[0]
-    dref = C.byref(d)
-    st = be.stream()
-    na = lib.vc_plan_begin_arena_bytes(dref)
-    if na == 0:
-        _lib.check(_lib.VC_EINVAL, "vc_plan_begin_arena_bytes")
-    arena_a = torch.empty(((na + 3) >> 2,), dtype=torch.int32, device=dev)
-    pinned = _PINNED.get(dev.index)
-    if pinned is None:
-        pinned = _PINNED[dev.index] = torch.empty((64,), dtype=torch.int32).pin_memory()
-    state = _lib.PlanState()
-    sref = C.byref(state)
-    _lib.check(lib.vc_plan_begin(dref, arena_a.data_ptr(), arena_a.numel() * 4, pinned.data_ptr(), sref, st), "vc_plan_begin")
-    _lib.check(lib.vc_plan_wait(dref, sref), "vc_plan_wait")          # the ONE host synchronisation of the plan
-    nb = lib.vc_plan_finish_arena_bytes(dref, sref)
-    if nb == 0:
-        _lib.check(_lib.VC_EINVAL, "vc_plan_finish_arena_bytes")
-    arena_b = torch.empty(((nb + 3) >> 2,), dtype=torch.int32, device=dev)
-    out = _lib.PlanOut()
-    _lib.check(lib.vc_plan_finish(dref, sref, arena_a.data_ptr(), arena_b.data_ptr(), arena_b.numel() * 4, C.byref(out), st),
-               "vc_plan_finish")
-    if d.need_grad:
-        if deferred is None:
-            _lib.check(lib.vc_plan_finish_backward(dref, sref, arena_a.data_ptr(), arena_b.data_ptr(), arena_b.numel() * 4, st),
-                       "vc_plan_finish_backward")
+    def __init__(self, model, kind: str, chain, tail, idx: torch.Tensor, batch_size: int, calib, trans_param, discard_tags, rate: float,
+                 batch_dict, image_shape, input_discard_tag=None, deferred=None):
+        be = ops.get_backend()
+        lib = be.lib
+        dev = idx.device
+        cache = _DESCS.setdefault(model, {})
+        if kind not in cache:
+            cache[kind] = _static_desc(chain, tail, model.sparse_shape, image_shape)
+        d = _lib.PlanDesc.from_buffer_copy(cache[kind])   # private copy: plans of one kind may be in flight together (plan-ahead, rids)
+        hold = [idx, calib]
+        d.indices, d.n, d.batch_size = idx.data_ptr(), idx.shape[0], int(batch_size)
+        d.calib = calib.data_ptr() if calib is not None else None
+        if trans_param is not None:
+            trans_param = torch.as_tensor(trans_param, dtype=torch.float32, device=dev).reshape(batch_size, 3).contiguous()
+            hold.append(trans_param)
+            d.trans = trans_param.data_ptr()
         else:
-            d_own = _lib.PlanDesc.from_buffer_copy(d)   # the cached description is rewritten by the next build of this kind
+            d.trans = None
+        d.discard_rate = float(rate) if (any(t is not None for t in discard_tags) or input_discard_tag is not None) else 0.0
+        d.need_grad = 1 if torch.is_grad_enabled() else 0
+        d.row_order_fwd = 1 if ops.ROW_ORDER == "strided" else 0
+        inj = batch_dict.get("layer_discard_keep")
 
-            def finish_backward(d_own=d_own, state=state, hold=hold, arena_a=arena_a, arena_b=arena_b):
-                _lib.check(lib.vc_plan_finish_backward(C.byref(d_own), C.byref(state), arena_a.data_ptr(), arena_b.data_ptr(),
-                                                       arena_b.numel() * 4, be.stream()), "vc_plan_finish_backward")
+        def keep_source(tag):
+            """(seed, injected tensor | None): the injected permutation prefix, or a seed drawn from torch's CPU generator exactly as
+            backbone.draw_random_keep does (same sequence of draws => same kept rows as the Python plan)."""
+            if inj is not None:
+                k = inj[tag].to(device=dev, dtype=torch.int64).contiguous()
+                hold.append(k)
+                return 0, k
+            return int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF, None
 
-            deferred.append(finish_backward)
-    del hold
-    arenas = (arena_a, arena_b)
-    res = []
-    in_keep = in_kept = None
-    cur_idx, shape = idx, list(model.sparse_shape)
-    if input_discard_tag is not None:
-        in_keep, in_kept = _keep_view(arenas, out.input_keep), _view(arenas, out.input_kept_indices)
-        cur_idx = in_kept
-    for b, (cb, tag) in enumerate(zip(chain, discard_tags)):
-        O = out.blocks[b]
-        r = {"down": None, "uv": None, "subm2d": None, "keep": None}
-        if cb.down is not None:
-            r["down"] = _table(arenas, O.down, "sparse", shape, cb.down, cur_idx)
-            cur_idx, shape = r["down"].out_indices, list(r["down"].out_shape)
-        r["subm3d"] = _table(arenas, O.subm3d, "subm", shape, cb.subm, cur_idx)
-        if cb.conv2d is not None:
-            r["uv"] = _view(arenas, O.uv)
-            r["subm2d"] = _table(arenas, O.subm2d, "subm", image_shape, cb.conv2d, r["uv"])
-        r["out_indices"], r["out_shape"] = cur_idx, shape
-        if tag is not None:
-            r["keep"] = _keep_view(arenas, O.keep)
-            r["kept_indices"] = _view(arenas, O.kept_indices)
-            cur_idx = r["kept_indices"]
-        res.append(r)
-    rb_tail = _table(arenas, out.tail, "sparse", shape, tail, cur_idx) if tail is not None else None
-    return res, rb_tail, in_keep, in_kept, [arena_a, arena_b]
+        d.input_discard = 0
+        if input_discard_tag is not None:
+            seed, k = keep_source(input_discard_tag)
+            d.input_discard, d.input_keep_seed = 1, seed
+            d.input_keep, d.input_keep_rows = (k.data_ptr(), k.shape[0]) if k is not None else (None, 0)
+        for b, tag in enumerate(discard_tags):
+            B = d.blocks[b]
+            B.discard = 1 if tag is not None else 0
+            B.keep, B.keep_rows, B.keep_seed = None, 0, 0
+            if tag is not None:
+                seed, k = keep_source(tag)
+                B.keep_seed = seed
+                if k is not None:
+                    B.keep, B.keep_rows = k.data_ptr(), k.shape[0]
+        dref = C.byref(d)
+        na = lib.vc_plan_begin_arena_bytes(dref)
+        if na == 0:
+            _lib.check(_lib.VC_EINVAL, "vc_plan_begin_arena_bytes")
+        arena_a = torch.empty(((na + 3) >> 2,), dtype=torch.int32, device=dev)
+        ring = _PINNED.get(dev.index)
+        if ring is None:   # a ring of count buffers: up to 8 plans between their begin and their finish
+            ring = _PINNED[dev.index] = [torch.empty((8, 64), dtype=torch.int32).pin_memory(), 0]
+        pinned = ring[0][ring[1] % 8]
+        ring[1] += 1
+        state = _lib.PlanState()
+        _lib.check(lib.vc_plan_begin(dref, arena_a.data_ptr(), arena_a.numel() * 4, pinned.data_ptr(), C.byref(state), be.stream()),
+                   "vc_plan_begin")
+        self.model, self.chain, self.tail, self.idx, self.discard_tags, self.input_discard_tag = model, chain, tail, idx, discard_tags, input_discard_tag
+        self.image_shape, self.deferred = image_shape, deferred
+        self.d, self.state, self.hold, self.arena_a, self.pinned = d, state, hold, arena_a, pinned
+        self.result = None
+
+    def finish(self):
+        """-> (per block: {"down", "subm3d", "uv", "subm2d", "out_indices", "out_shape", "keep", "kept_indices"}, tail Rulebook | None,
+        input keep | None, kept input indices | None, [arena_a, arena_b])"""
+        if self.result is not None:
+            return self.result
+        be = ops.get_backend()
+        lib = be.lib
+        d, state, arena_a, hold = self.d, self.state, self.arena_a, self.hold
+        dref, sref = C.byref(d), C.byref(state)
+        st = be.stream()
+        _lib.check(lib.vc_plan_wait(dref, sref), "vc_plan_wait")          # the ONE host synchronisation of the plan
+        nb = lib.vc_plan_finish_arena_bytes(dref, sref)
+        if nb == 0:
+            _lib.check(_lib.VC_EINVAL, "vc_plan_finish_arena_bytes")
+        arena_b = torch.empty(((nb + 3) >> 2,), dtype=torch.int32, device=self.idx.device)
+        out = _lib.PlanOut()
+        _lib.check(lib.vc_plan_finish(dref, sref, arena_a.data_ptr(), arena_b.data_ptr(), arena_b.numel() * 4, C.byref(out), st),
+                   "vc_plan_finish")
+        if d.need_grad:
+            if self.deferred is None:
+                _lib.check(lib.vc_plan_finish_backward(dref, sref, arena_a.data_ptr(), arena_b.data_ptr(), arena_b.numel() * 4, st),
+                           "vc_plan_finish_backward")
+            else:
+                def finish_backward(d=d, state=state, hold=hold, arena_a=arena_a, arena_b=arena_b):
+                    _lib.check(lib.vc_plan_finish_backward(C.byref(d), C.byref(state), arena_a.data_ptr(), arena_b.data_ptr(),
+                                                           arena_b.numel() * 4, be.stream()), "vc_plan_finish_backward")
+
+                self.deferred.append(finish_backward)
+        arenas = (arena_a, arena_b)
+        res = []
+        in_keep = in_kept = None
+        cur_idx, shape = self.idx, list(self.model.sparse_shape)
+        if self.input_discard_tag is not None:
+            in_keep, in_kept = _keep_view(arenas, out.input_keep), _view(arenas, out.input_kept_indices)
+            cur_idx = in_kept
+        for b, (cb, tag) in enumerate(zip(self.chain, self.discard_tags)):
+            O = out.blocks[b]
+            r = {"down": None, "uv": None, "subm2d": None, "keep": None}
+            if cb.down is not None:
+                r["down"] = _table(arenas, O.down, "sparse", shape, cb.down, cur_idx)
+                cur_idx, shape = r["down"].out_indices, list(r["down"].out_shape)
+            r["subm3d"] = _table(arenas, O.subm3d, "subm", shape, cb.subm, cur_idx)
+            if cb.conv2d is not None:
+                r["uv"] = _view(arenas, O.uv)
+                r["subm2d"] = _table(arenas, O.subm2d, "subm", self.image_shape, cb.conv2d, r["uv"])
+            r["out_indices"], r["out_shape"] = cur_idx, shape
+            if tag is not None:
+                r["keep"] = _keep_view(arenas, O.keep)
+                r["kept_indices"] = _view(arenas, O.kept_indices)
+                cur_idx = r["kept_indices"]
+            res.append(r)
+        rb_tail = _table(arenas, out.tail, "sparse", shape, self.tail, cur_idx) if self.tail is not None else None
+        self.hold = None   # the keeps / calibration were consumed by the launches enqueued above (stream order keeps them valid)
+        self.result = (res, rb_tail, in_keep, in_kept, [arena_a, arena_b])
+        return self.result
 
 
-def build(model, blocks, tail, idx: torch.Tensor, batch_size: int, calib, trans_param, discard_tags, rate: float, batch_dict,
-          image_shape, input_discard_tag=None, deferred=None):
-    """The plan of a chain of NRConvBlocks `blocks` = [(block, uv stride)] in the form backbone._plan_nrconv_chain returns:
-    -> (stages, tail Rulebook | None, input keep | None, kept input indices | None, [arena_a, arena_b])."""
-    res, rb_tail, in_keep, in_kept, arenas = build_chain(model, ("nrconv", len(blocks), tail is not None, input_discard_tag is not None),
-                                                         nrconv_blocks(blocks), tail, idx, batch_size, calib, trans_param,
-                                                         discard_tags, rate, batch_dict, image_shape, input_discard_tag, deferred)
+def build_chain(model, kind: str, chain, tail, idx: torch.Tensor, batch_size: int, calib, trans_param, discard_tags, rate: float,
+                batch_dict, image_shape, input_discard_tag=None, deferred=None):
+    """ChainPlan begun and finished back to back (see there)."""
+    return ChainPlan(model, kind, chain, tail, idx, batch_size, calib, trans_param, discard_tags, rate, batch_dict, image_shape,
+                     input_discard_tag, deferred).finish()
+
+
+def nrconv_stages(blocks, res):
+    """ChainPlan result of a chain of NRConvBlocks -> the per-block dictionaries backbone._plan_nrconv_chain returns."""
     stages = []
     for (blk, _), r in zip(blocks, res):
         kd, k3, k2 = blk._keys()
@@ -246,4 +267,18 @@ def build(model, blocks, tail, idx: torch.Tensor, batch_size: int, calib, trans_
         if r["keep"] is not None:
             st_["kept_indices"] = r["kept_indices"]
         stages.append(st_)
-    return stages, rb_tail, in_keep, in_kept, arenas
+    return stages
+
+
+def nrconv_kind(blocks, tail, input_discard_tag):
+    return ("nrconv", len(blocks), tail is not None, input_discard_tag is not None)
+
+
+def build(model, blocks, tail, idx: torch.Tensor, batch_size: int, calib, trans_param, discard_tags, rate: float, batch_dict,
+          image_shape, input_discard_tag=None, deferred=None):
+    """The plan of a chain of NRConvBlocks `blocks` = [(block, uv stride)] in the form backbone._plan_nrconv_chain returns:
+    -> (stages, tail Rulebook | None, input keep | None, kept input indices | None, [arena_a, arena_b])."""
+    res, rb_tail, in_keep, in_kept, arenas = build_chain(model, nrconv_kind(blocks, tail, input_discard_tag),
+                                                         nrconv_blocks(blocks), tail, idx, batch_size, calib, trans_param,
+                                                         discard_tags, rate, batch_dict, image_shape, input_discard_tag, deferred)
+    return nrconv_stages(blocks, res), rb_tail, in_keep, in_kept, arenas
