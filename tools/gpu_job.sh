@@ -5,7 +5,7 @@
 #
 # Raw output goes to gpurun_out/<tag>/ (scratch, merged back by gpurun); tools/make_profiles.py turns the rocprof output into the
 # summaries committed under profiles/.  Steps (each is bounded by its own timeout so that a hang cannot eat the call):
-#   tests[:<pytest -k expr>]  GPU test-suite (or the selected tests)          smoke      __graft_entry__.smoke()
+#   tests[:<pytest -k expr>]  GPU test-suite, -x (or the selected tests); testsall: without -x    smoke      __graft_entry__.smoke()
 #   bench                     python bench.py --gpus 1 --steps 20 --warmup 5  bench40    40 steps / 12 warm-up, no CPU baseline
 #   benchenv:<K=V,...>        bench40 with environment variables set (A/B)    bench8x | benchf16 | benchfront | infer1 | infer4
 #   hostprof | phases | kbench[:<args>] | bevbench | gaps
@@ -25,6 +25,7 @@ for step in "$@"; do
     tests)
       if [ -n "$arg" ]; then timeout 1500 python -m pytest tests -m gpu -q -x -k "$arg" > "$D/tests_sel.log" 2>&1; echo "rc=$?"; tail -n 4 "$D/tests_sel.log"
       else timeout 1700 python -m pytest tests -m gpu -q -x > "$D/tests.log" 2>&1; echo "rc=$?"; tail -n 4 "$D/tests.log"; fi ;;
+    testsall) timeout 1700 python -m pytest tests -m gpu -q > "$D/tests.log" 2>&1; echo "rc=$?"; tail -n 6 "$D/tests.log" ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$D/smoke.log" 2>&1; tail -n 2 "$D/smoke.log" ;;
     bench) timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > "$D/bench_driver_form.log" 2>&1; line "$D/bench_driver_form.log" ;;
     bench40) timeout 300 python bench.py $BENCH40 > "$D/bench40.log" 2>&1; line "$D/bench40.log" ;;
@@ -57,7 +58,11 @@ for step in "$@"; do
     mfmadw)
       ( cd /tmp && export TMPDIR=/tmp && timeout 120 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY \
           SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE -d "$R/$D/mfmadw" -o r --output-format csv -- \
-          python "$R/tools/kbench.py" --layers s3.d3_conv1,s3.d3_conv2 --only dw --iters 5 ${arg} > "$R/$D/p_mfmadw.log" 2>&1 ); echo done ;;
+          python "$R/tools/kbench.py" --layers s3.d3_conv1,s3.d3_conv2 --only dw --iters 5 ${arg} > "$R/$D/p_mfmadw.log" 2>&1 )
+      ( cd /tmp && export TMPDIR=/tmp && timeout 120 rocprofv3 --kernel-trace --pmc TA_TA_BUSY_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE \
+          -d "$R/$D/tadw" -o r --output-format csv -- \
+          python "$R/tools/kbench.py" --layers s3.d3_conv1,s3.d3_conv2 --only dw --iters 5 ${arg} > "$R/$D/p_tadw.log" 2>&1 )
+      find "$D" -name '*kernel_trace.csv' -size +20M -delete; echo done ;;
     py) f="${arg%%:*}"; a=""; [ "$arg" != "$f" ] && a="${arg#*:}"; timeout 600 python "$f" $a > "$D/$(basename "$f" .py).txt" 2>&1; echo "rc=$?"; tail -n 5 "$D/$(basename "$f" .py).txt" ;;
     *) echo "unknown step $step" ;;
   esac

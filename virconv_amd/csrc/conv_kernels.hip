@@ -2183,7 +2183,8 @@ static int launch_bw(const float* x, const float* dy, const int32_t* tbl, int64_
     // measured (profiles/r04_dw_small_channels.md): wins at 8 x 8 (25.6 -> 19.2-20.4 us) and on the 16 x 16 duplicate-pixel tables
     // (44.9 -> 39.2), loses from 16 x 16 SubM upward (71 -> 80, 32 x 16: 90 -> 138, the sparse 16 x 32 strided table 38 -> 86): the
     // 4x4x1 form runs below the fp32 matrix-pipe rate of the 16x16x4 form here.  Default: C_in C_out <= 64 only; 3 = every served shape.
-    if (ot == VC_OPERAND_F32 && (g_bw_small == 3 || (g_bw_small == 1 && CI * CO <= 64))) {
+    const bool f32_operands = ot == VC_OPERAND_F32 || CI < 16 || CO < 16;   // reduced operands apply from 16 channels up only
+    if (f32_operands && (g_bw_small == 3 || (g_bw_small == 1 && CI * CO <= 64))) {
       hipLaunchKernelGGL((bwd_weight_small_kernel<CI, CO>), dim3(nblocks), dim3(256), 0, st, VC_ARGS, 0);
       launched = true;
     }

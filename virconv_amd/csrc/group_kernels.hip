@@ -12,7 +12,7 @@
 //                        keys in a register (plain fp32 adds in ascending sorted position), stores a run that begins and ends
 //                        inside the chunk straight to dy_grp[key] and a run cut by a chunk border as a partial
 //                        (slot 0: the run came in from the previous chunk, slot 1: it began here and continues);
-//   * seg_fixup_kernel   per chunk whose last run began there and continues (found by a scan of the block's chunk range): binary-searches the end of the run and adds the
+//   * seg_fixup_kernel   block = a chunk whose last run began there and continues: binary-searches the end of the run and adds the
 //                        continuation partials of the following chunks in a fixed interleaved order (256 / c lanes per channel).
 // No atomics, no absmax pass, no accumulator buffer, no convert pass; every group's additions happen in one fixed order, so
 // the result is bit-stable run to run.  HBM-bound: one gathered read of dy (rows are 32-256 B contiguous) + 8 B of plan per row.
@@ -69,98 +69,47 @@ __global__ void __launch_bounds__(256) seg_sum_kernel(const float* __restrict__ 
   flush(cur == nextkey);
 }
 
-// Only a chunk whose last run BEGAN there and continues has anything to fix up (a few hundred to a few thousand of ~10 000 chunks).
-// Each block scans a contiguous range of chunks -- one thread per chunk: is it such a head, and over how many following chunks does
-// its run continue (the run continues into chunk q iff keys[32 q] == key; up to S = 256 / c probed, independent loads) -- and lists the
-// heads in LDS.  SHORT runs (<= S continuation partials: all but the border-pixel groups) are then summed by c threads each, 256 / c
-// heads at a time: own piece, then the continuation partials in ascending chunk order.  LONG runs take the whole block as in round 3:
-// parallel probe for the end, the partials split over S segment lanes per channel -- lane s adds partials s, s + S, ... in that order --
-// and the S lane sums combined in lane order.  For a run of <= S partials both routes add the same numbers in the same order, so
-// every group's arithmetic is what the one-block-per-chunk kernel of round 3 did (bit-identical results), without dispatching
-// ~10 000 blocks that return at once (12 us per call) and without serialising the heads of a block.
+// One 256-thread block per chunk; only a chunk whose last run BEGAN there and continues does anything.  The continuation partials
+// (one per following chunk; hundreds for the border-pixel groups that collect thousands of rows) are split over 256 / c
+// segment lanes per channel -- lane s adds partials s, s + S, ... in that order -- and the S lane sums are combined in lane
+// order: a fixed tree for a given run length, hence bit-stable.  (The first version gave a whole run to ONE thread per channel:
+// 23 us per launch, almost all of it the 600-partial chain of the biggest group.)
 __global__ void __launch_bounds__(256) seg_fixup_kernel(const int32_t* __restrict__ keys, int64_t n, int c, int lg_c,
-                                                        const float* __restrict__ part, float* __restrict__ grp, int chunks_per_block) {
+                                                        const float* __restrict__ part, float* __restrict__ grp) {
   __shared__ float red[256];
-  __shared__ int short_heads[256], short_len[256], long_heads[256];
-  __shared__ int n_short, n_long, first_bad;
-  const int64_t n_chunks = (n + kSegRows - 1) / kSegRows;
-  const int64_t c_lo = (int64_t)blockIdx.x * chunks_per_block, c_hi = min(c_lo + chunks_per_block, n_chunks - 1);  // last chunk: no open run
-  const int S = 256 >> lg_c;
-  for (int64_t base = c_lo; base < c_hi; base += 256) {
-    if (threadIdx.x == 0) { n_short = 0; n_long = 0; }
-    __syncthreads();
-    {
-      const int64_t chunk = base + threadIdx.x;
-      if (chunk < c_hi) {
-        const int64_t j0 = chunk * kSegRows, j1 = j0 + kSegRows;   // j1 < n
-        const int key = keys[j1 - 1];
-        const bool head = keys[j1] == key &&                                     // the last run continues ...
-                          !(keys[j0] == key && j0 > 0 && keys[j0 - 1] == key);   // ... and began in this chunk
-        if (head) {
-          int len = 1;                                   // continuation partials: chunk + 1 .. chunk + len
-          while (len <= S && chunk + 1 + len < n_chunks && keys[(chunk + 1 + len) * kSegRows] == key) ++len;
-          if (len <= S) {
-            const int slot = atomicAdd(&n_short, 1);
-            short_heads[slot] = (int)(chunk - base);
-            short_len[slot] = len;
-          } else {
-            long_heads[atomicAdd(&n_long, 1)] = (int)(chunk - base);
-          }
-        }
-      }
-    }
-    __syncthreads();
-    {  // short runs: c threads per head
-      const int ch = threadIdx.x & (c - 1), slot0 = threadIdx.x >> lg_c;
-      const int ns = n_short;
-      for (int h = slot0; h < ns; h += S) {
-        const int64_t chunk = base + short_heads[h];
-        const int len = short_len[h];
-        const int key = keys[(chunk + 1) * kSegRows - 1];
-        float total = part[(chunk * 2 + 1) * c + ch];
-        for (int t = 1; t <= len; ++t) total += part[((chunk + t) * 2) * c + ch];
-        grp[(int64_t)key * c + ch] = total;
-      }
-    }
-    const int nl = n_long;
-    for (int h = 0; h < nl; ++h) {
-      const int64_t chunk = base + long_heads[h];
-      const int key = keys[(chunk + 1) * kSegRows - 1];
-      // last chunk holding rows of the run: the run continues into chunk q iff keys[32 q] == key; 256 chunks probed per round (the
-      // round-3 binary search was 17 dependent loads, ~10 us on its own)
-      int64_t c_end = chunk;
-      for (int64_t off = 0;; off += 256) {
-        if (threadIdx.x == 0) first_bad = 256;
-        __syncthreads();
-        const int64_t qq = chunk + 1 + off + threadIdx.x;
-        if (!(qq < n_chunks && keys[qq * kSegRows] == key)) atomicMin(&first_bad, (int)threadIdx.x);
-        __syncthreads();
-        const int fb = first_bad;
-        __syncthreads();
-        c_end = chunk + off + fb;
-        if (fb < 256) break;
-      }
-      const int ch = threadIdx.x & (c - 1), seg = threadIdx.x >> lg_c;
-      float acc = 0.f;
-      int64_t q = chunk + 1 + seg;
-      for (; q + 3 * (int64_t)S <= c_end; q += 4 * (int64_t)S) {
-        const float v0 = part[(q * 2) * c + ch], v1 = part[((q + S) * 2) * c + ch];
-        const float v2 = part[((q + 2 * S) * 2) * c + ch], v3 = part[((q + 3 * S) * 2) * c + ch];
-        acc += v0; acc += v1; acc += v2; acc += v3;
-      }
-      for (; q <= c_end; q += S) acc += part[(q * 2) * c + ch];
-      __syncthreads();
-      red[threadIdx.x] = acc;
-      __syncthreads();
-      if (seg == 0) {
-        float total = part[(chunk * 2 + 1) * c + ch];   // the run's own first piece, then the segment sums in lane order
-        for (int u = 0; u < S; ++u) total += red[(u << lg_c) + ch];
-        grp[(int64_t)key * c + ch] = total;
-      }
-    }
-    __syncthreads();
+  const int64_t chunk = blockIdx.x;
+  const int64_t j0 = chunk * kSegRows, j1 = j0 + kSegRows;
+  if (j1 >= n) return;                        // the last chunk cannot have an open run
+  const int key = keys[j1 - 1];
+  if (keys[j1] != key) return;                // last run ends with the chunk
+  if (keys[j0] == key && j0 > 0 && keys[j0 - 1] == key) return;   // the whole chunk is a continuation: not the run's first chunk
+  // end of the run: first position e in (j1, n] with keys[e] != key (keys ascending); every thread searches for itself (uniform)
+  int64_t lo = j1, hi = n;                    // invariant: keys[lo] == key, (hi == n or keys[hi] != key)
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (keys[mid] == key) lo = mid; else hi = mid;
+  }
+  const int64_t c_end = (hi - 1) / kSegRows;  // last chunk holding rows of the run
+  const int ch = threadIdx.x & (c - 1), seg = threadIdx.x >> lg_c, S = 256 >> lg_c;
+  float acc = 0.f;
+  int64_t q = chunk + 1 + seg;
+  for (; q + 3 * (int64_t)S <= c_end; q += 4 * (int64_t)S) {
+    const float v0 = part[(q * 2) * c + ch], v1 = part[((q + S) * 2) * c + ch];
+    const float v2 = part[((q + 2 * S) * 2) * c + ch], v3 = part[((q + 3 * S) * 2) * c + ch];
+    acc += v0; acc += v1; acc += v2; acc += v3;
+  }
+  for (; q <= c_end; q += S) acc += part[(q * 2) * c + ch];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (seg == 0) {
+    float total = part[(chunk * 2 + 1) * c + ch];   // the run's own first piece, then the segment sums in lane order
+    for (int u = 0; u < S; ++u) total += red[(u << lg_c) + ch];
+    grp[(int64_t)key * c + ch] = total;
   }
 }
+// (Round 4 tried blocks that scan chunk ranges for such heads -- <= 1024 blocks instead of ~10 000 that return at once, short runs
+// summed by c threads each, a parallel probe for the end of long runs; bit-identical, and 15.3 us per call in-step (rocprof, r4F2)
+// against 12.2 us for this form (r4p): the dispatch of empty blocks is cheaper than the scan's dependent loads.  LOG.md A.12.)
 
 // keys[i] = rep[i] < 0 ? i : rep[i]  (what the plan sorts; rep = -1 marks "own representative" in some tables); rows[i] = i
 __global__ void __launch_bounds__(256) group_keys_kernel(const int32_t* __restrict__ rep, int64_t n, uint32_t* __restrict__ keys,
@@ -397,10 +346,8 @@ int vc_group_sum_sorted(const float* dy, const int32_t* grp_plan, int64_t n, int
     hipLaunchKernelGGL(seg_sum_kernel, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, st, dy, order, keys, n, c, lg, dy_grp,
                        (float*)ws);
     VC_CHECK_LAUNCH("seg_sum_kernel");
-    const int64_t n_chunks = cdiv(n, kSegRows);
-    const int cpb = (int)std::max<int64_t>(32, cdiv(n_chunks - 1, 1024));   // <= 1024 blocks, >= 32 chunks each
-    VC_LAUNCH_WITH_STOP_EVENT(seg_fixup_kernel, dim3((unsigned)cdiv(n_chunks - 1, cpb)), dim3(256), 0, st, keys, n, c, lg,
-                              (const float*)ws, dy_grp, cpb);
+    VC_LAUNCH_WITH_STOP_EVENT(seg_fixup_kernel, dim3((unsigned)(cdiv(n, kSegRows) - 1)), dim3(256), 0, st, keys, n, c, lg,
+                              (const float*)ws, dy_grp);
     VC_CHECK_LAUNCH("seg_fixup_kernel");
   } else {
     VC_LAUNCH_WITH_STOP_EVENT(seg_sum_kernel, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, st, dy, order, keys, n, c, lg, dy_grp,
