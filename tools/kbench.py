@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--v5", type=int, default=0, help="loader / MFMA wave-role gather-GEMM (vc_debug_set conv_v5; needs --autopack)")
     ap.add_argument("--dxs", type=int, default=-1, help="dx shift in the LDS-staged kernel (vc_debug_set conv_dxs): 0 | 1; -1 = library default; needs --autopack")
     ap.add_argument("--layers", default="", help="comma-separated substrings: only time layers whose name contains one of them")
+    ap.add_argument("--split", type=int, default=0, help="fp32 products as six bf16 MFMA terms (vc_debug_set f32_split; implies --autopack): also prints each layer's max deviation from the exact-fp32 kernels")
+    ap.add_argument("--bwsplit", type=int, default=0, help="weight-gradient products as six bf16 MFMA terms (vc_debug_set bw_split); prints each layer's deviation from the exact-fp32 kernel")
     ap.add_argument("--il", action="store_true", help="forward convs (channel counts multiples of 16) also with the source features in the 16-row interleaved layout (VC_CONV_SRC_INTERLEAVED; implies --autopack)")
     args = ap.parse_args()
     ops.WINDOW_GATHER = bool(args.window)
@@ -74,7 +76,9 @@ def main():
         assert be.lib.vc_debug_set(b"conv_nw", args.nw) == 0
     if args.v4 >= 0:
         assert be.lib.vc_debug_set(b"conv_v4", args.v4) == 0
-    assert be.lib.vc_debug_set(b"conv_autopack", 1 if (args.autopack or args.il) else 0) == 0
+    assert be.lib.vc_debug_set(b"conv_autopack", 1 if (args.autopack or args.il or args.split) else 0) == 0
+    assert be.lib.vc_debug_set(b"f32_split", args.split) == 0
+    assert be.lib.vc_debug_set(b"bw_split", args.bwsplit) == 0
     assert be.lib.vc_debug_set(b"conv_v4_ablate", args.ablate) == 0
     assert be.lib.vc_debug_set(b"conv_v4_pf", args.pf) == 0
     assert be.lib.vc_debug_set(b"conv_v5", args.v5) == 0
@@ -144,6 +148,21 @@ def main():
         byts = 4.0 * (rb.n_in * cin + rb.n_out * cout + kv * cin * cout) + 4.0 * kv * rb.n_out
         res = {}
         srt = rb.sorted_rows and not args.no_window
+        dev_note = ""
+        if args.split and args.only in ("all", "fwd", "bwd"):
+            def both(fn):
+                assert be.lib.vc_debug_set(b"f32_split", 0) == 0
+                a = fn()
+                assert be.lib.vc_debug_set(b"f32_split", args.split) == 0
+                b = fn()
+                return float((a - b).abs().max() / a.abs().max())
+            if args.only in ("all", "fwd"):
+                dev_note += f" | split dev fwd {both(lambda: be.conv_forward(x, w, rb.pair_fwd, order=rb.order_fwd)):.1e}"
+            if args.only in ("all", "bwd"):
+                if rb.kind == "subm":
+                    dev_note += f" bwd {both(lambda: be.conv_backward_input(dy, w, rb.pair_fwd, rb.n_in, True, rb.centre, rb.rep, order=rb.order_bwd, grp_plan=rb.grp_plan)):.1e}"
+                else:
+                    dev_note += f" bwd {both(lambda: be.conv_backward_input(dy, w, rb.pair_bwd, rb.n_in, False, order=rb.order_bwd)):.1e}"
         if args.only in ("all", "fwd"):
             res["fwd"] = timeit(lambda: be.conv_forward(x, w, rb.pair_fwd, order=rb.order_fwd, operand=args.operand, sorted_rows=srt), args.iters)
         if args.il and args.only in ("all", "fwd") and cin % 16 == 0 and cout % 16 == 0:
@@ -158,6 +177,12 @@ def main():
                 res["bwd"] = timeit(lambda: be.conv_backward_input(dy, w, rb.pair_fwd, rb.n_in, True, rb.centre, rb.rep, order=rb.order_bwd, operand=args.operand, sorted_rows=srt, grp_plan=rb.grp_plan), args.iters)
             else:
                 res["bwd"] = timeit(lambda: be.conv_backward_input(dy, w, rb.pair_bwd, rb.n_in, False, order=rb.order_bwd, operand=args.operand), args.iters)
+        if args.bwsplit and args.only in ("all", "dw") and not (rb.kind == "subm" and rb.rep is not None):
+            assert be.lib.vc_debug_set(b"bw_split", 0) == 0
+            d0 = be.conv_backward_weight(x, dy, rb.pair_fwd, w.shape)
+            assert be.lib.vc_debug_set(b"bw_split", args.bwsplit) == 0
+            d1 = be.conv_backward_weight(x, dy, rb.pair_fwd, w.shape)
+            dev_note += f" | dW split dev {float((d0 - d1).abs().max() / d0.abs().max()):.1e}"
         if args.only in ("all", "dw"):
             if rb.kind == "subm" and rb.rep is not None and rb.grp_plan is not None:   # duplicate-pixel table: dW over representatives
                 grp = be.group_sum_sorted(dy, rb.grp_plan)
@@ -176,7 +201,8 @@ def main():
         line += (f"{d:8.1f} {tf(d):6.2f} {100 * tf(d) / PEAK:5.1f}" if d else "")
         if res.get("il"):
             line += f" | fwd interleaved src {res['il']:8.1f} us ({100 * tf(res['il']) / PEAK:4.1f} %pk, {res['fwd'] / res['il']:.2f}x)"
-        if ops.ROW_ORDER != "none" and not args.layers:
+        line += dev_note
+        if ops.ROW_ORDER != "none" and not args.layers and not args.split:
             line += f" | ord {timeit(lambda: be.row_order(rb.pair_fwd, window=ops.ROW_ORDER_WINDOW), args.iters):6.1f}"
         print(line)
         for k in ("fwd", "bwd", "dw"):

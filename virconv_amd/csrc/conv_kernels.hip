@@ -75,6 +75,33 @@ __device__ __forceinline__ f32x4 mfma16(u32x2 a, u32x2 b, f32x4 c) {
   }
 }
 
+// fp32-accurate products on the bf16 matrix cores (round 4, "f32_split"): x = h + m + l EXACTLY, three bf16 values of 8 significant bits
+// each obtained by truncation (v_and / v_sub: the differences are exact), and x y ~ l_x h_y + h_x l_y + m_x m_y + m_x h_y + h_x m_y +
+// h_x h_y: the three dropped terms are <= 2^-24 |x y| each, i.e. of the size of ONE fp32 rounding of the product.  Six
+// v_mfma_f32_16x16x32_bf16 (~17 cycles each per SIMD) per 32 channels instead of eight v_mfma_f32_16x16x4_f32 (32 cycles each):
+// 0.4x the matrix-pipe time, paid for with ~5.5 VALU operations per gathered element.  Tensors and accumulation stay fp32.
+static constexpr int VC_OPERAND_X6 = 3;   // internal operand type: selected by vc_debug_set f32_split for operand_type VC_OPERAND_F32
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split3(const float* f, u32x2& h, u32x2& m, u32x2& l) {
+  unsigned uh[4], um[4], ul[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned u = __float_as_uint(f[j]);
+    const float r1 = f[j] - __uint_as_float(u & 0xFFFF0000u);          // exact: the low 16 bits of the significand
+    const unsigned u1 = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(u1 & 0xFFFF0000u);           // exact: <= 8 significant bits, a bf16 value
+    uh[j] = u; um[j] = u1; ul[j] = __float_as_uint(r2);
+  }
+  // v_perm_b32: the high halves of two registers side by side = two truncated bf16 values (element 0 in the low half)
+  h.x = __builtin_amdgcn_perm(uh[1], uh[0], 0x07060302u); h.y = __builtin_amdgcn_perm(uh[3], uh[2], 0x07060302u);
+  m.x = __builtin_amdgcn_perm(um[1], um[0], 0x07060302u); m.y = __builtin_amdgcn_perm(um[3], um[2], 0x07060302u);
+  l.x = __builtin_amdgcn_perm(ul[1], ul[0], 0x07060302u); l.y = __builtin_amdgcn_perm(ul[3], ul[2], 0x07060302u);
+}
+__device__ __forceinline__ f32x4 mfma32bf(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 template <int V>
 struct VecLoad;
 template <>
@@ -591,15 +618,16 @@ static constexpr int VC_EPI_BWD = 3;  // internal (not part of vc_epilogue: sele
 // kernels with 64 output channels sat on or just below the 64-VGPR line (8 waves) before the in-kernel BatchNorm finish was
 // added; with the tail inlined the allocator takes 74.  Pinned back: the main loop is unaffected, the tail (run by every
 // block once, its reduction levels by a few blocks per launch) spills 44-52 bytes (tools/vgpr_table.py).
-template <int CK, int CN, int EPI, int NW, bool PK, bool DXS>
+template <int CK, int CN, int EPI, int NW, bool PK, bool DXS, int OT = VC_OPERAND_F32>
 constexpr int v2_min_waves() {
+  if (OT != VC_OPERAND_F32) return 1;
   if (DXS || CN != 64 || !(EPI == 1 /* STATS */ || EPI == 3 /* VC_EPI_BWD */)) return 1;
   if (CK <= 32) return (EPI == 3 && CK == 32 && NW == 4 && !PK) ? 1 : 8;   // were 42-64 VGPRs without the tail
   return (NW == 8 && PK) ? 7 : 1;                                           // 64 -> 64, 8 waves: was 72
 }
 
 template <int CK, int CN, bool BWD, int RT, int OT, int EPI, int NW = 4, bool PK = false, bool DXS = false, bool IL = false>
-__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(v2_min_waves<CK, CN, EPI, NW, PK, DXS>())))
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(v2_min_waves<CK, CN, EPI, NW, PK, DXS, OT>())))
 gather_gemm_v2_kernel(const float* __restrict__ src,
                                                              const float* __restrict__ src_centre, int64_t n_src,
                                                              const int32_t* __restrict__ tbl,
@@ -608,7 +636,8 @@ gather_gemm_v2_kernel(const float* __restrict__ src,
                                                              const int32_t* __restrict__ order, int64_t n_out, int kv,
                                                              int centre, int mirror, ConvEpilogue epi) {
   static_assert(EPI == VC_EPI_NONE || RT == 1, "epilogues exist for the one-tile-per-wave kernel only");
-  static_assert(!PK || (CK % 16 == 0 && OT == VC_OPERAND_F32), "packed weight images: fp32 operands, 16-channel K chunks");
+  static_assert(!PK || (CK % 16 == 0 && (OT == VC_OPERAND_F32 || OT == VC_OPERAND_X6)), "packed weight images: fp32 operands, 16-channel K chunks");
+  static_assert(OT != VC_OPERAND_X6 || (RT == 1 && CK % 16 == 0 && !DXS && !IL), "split-bf16 products: one tile per wave, 16-channel K chunks");
   static_assert(!DXS || (RT == 1 && CK % 16 == 0 && OT == VC_OPERAND_F32), "dx shift: one tile per wave, 16-byte row chunks, fp32");
   static_assert(!IL || (CK % 16 == 0 && !DXS), "interleaved source: 16-byte row chunks");
   static_assert(EPI == VC_EPI_NONE || (EPI == VC_EPI_BWD) == BWD, "STATS / AFFINE: forward kernel; BWD: backward-input kernel");
@@ -621,7 +650,8 @@ gather_gemm_v2_kernel(const float* __restrict__ src,
   constexpr int TM = 16 * NW * RT;                       // output rows per block: NW waves x RT tiles of 16
   constexpr int NFRAG = NCH * NT * 64;                   // fragment vectors (V floats each) of one W_k image
   constexpr int BF = NFRAG * V;
-  constexpr int BBYTES = BF * (OT == VC_OPERAND_F32 ? 4 : 2);  // one W_k image in LDS (fp32, or 16-bit operands)
+  constexpr int BBYTES = BF * (OT == VC_OPERAND_F32 ? 4 : (OT == VC_OPERAND_X6 ? 6 : 2));  // one W_k image in LDS (fp32, 16-bit operands, or three bf16 planes)
+  constexpr int XPL = NFRAG * 8;                               // X6: bytes of one bf16 plane
   constexpr int BLD = (NFRAG + NTHR - 1) / NTHR;               // fragment vectors staged per thread
   static_assert(OT == VC_OPERAND_F32 || V == 4, "16-bit MFMA operands need >= 16 source channels");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -729,6 +759,16 @@ gather_gemm_v2_kernel(const float* __restrict__ src,
         if constexpr (OT == VC_OPERAND_F32) {                                                      \
           float* d_ = reinterpret_cast<float*>(s_b + (BUF) * BBYTES) + f * V;                      \
           _Pragma("unroll") for (int j = 0; j < V; ++j) d_[j] = breg[u][j];                        \
+        } else if constexpr (OT == VC_OPERAND_X6) {                                                \
+          /* three bf16 planes; with an even chunk count the fragments of chunks 2c and 2c+1 sit side by side (one 16-byte read) */ \
+          u32x2 h_, m_, l_;                                                                        \
+          split3(breg[u], h_, m_, l_);                                                             \
+          const int fl_ = f & 63, nt_ = (f >> 6) % NT, ch_ = (f >> 6) / NT;                        \
+          const int off_ = (NCH % 2 == 0) ? ((((ch_ >> 1) * NT + nt_) * 64 + fl_) * 16 + (ch_ & 1) * 8) : f * 8; \
+          unsigned char* d_ = s_b + (BUF) * BBYTES + off_;                                         \
+          *reinterpret_cast<u32x2*>(d_) = h_;                                                      \
+          *reinterpret_cast<u32x2*>(d_ + XPL) = m_;                                                \
+          *reinterpret_cast<u32x2*>(d_ + 2 * XPL) = l_;                                            \
         } else {                                                                                   \
           *reinterpret_cast<u32x2*>(s_b + (BUF) * BBYTES + f * 8) = Pack4<OT == VC_OPERAND_F32 ? VC_OPERAND_F16 : OT>::cvt(breg[u]); \
         }                                                                                          \
@@ -775,6 +815,45 @@ gather_gemm_v2_kernel(const float* __restrict__ src,
                 _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                  \
                     _Pragma("unroll") for (int j = 0; j < V; ++j)                                  \
                         acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[t][ch][j], b[ch][nt][j], acc[t][nt], 0, 0, 0); \
+          }                                                                                        \
+        }                                                                                          \
+      }                                                                                            \
+    } else if constexpr (OT == VC_OPERAND_X6) {                                                    \
+      const unsigned char* __restrict__ B_ = s_b + (BUF) * BBYTES;                                 \
+      _Pragma("unroll") for (int t = 0; t < RT; ++t) {                                             \
+        if (ACT[t]) {                                                                              \
+          if constexpr (NCH % 2 == 0) {                                                            \
+            _Pragma("unroll") for (int cp = 0; cp < NCH / 2; ++cp) {                               \
+              u32x2 h0_, m0_, l0_, h1_, m1_, l1_;                                                  \
+              split3(A[t][2 * cp], h0_, m0_, l0_);                                                 \
+              split3(A[t][2 * cp + 1], h1_, m1_, l1_);                                             \
+              const u32x4 ah = {h0_.x, h0_.y, h1_.x, h1_.y}, am = {m0_.x, m0_.y, m1_.x, m1_.y},    \
+                          al = {l0_.x, l0_.y, l1_.x, l1_.y};                                       \
+              _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                  \
+                const unsigned char* p_ = B_ + ((cp * NT + nt) * 64 + lane) * 16;                  \
+                const u32x4 bh = *reinterpret_cast<const u32x4*>(p_), bm = *reinterpret_cast<const u32x4*>(p_ + XPL), \
+                            bl = *reinterpret_cast<const u32x4*>(p_ + 2 * XPL);                    \
+                f32x4 c_ = acc[t][nt];                                                             \
+                c_ = mfma32bf(al, bh, c_); c_ = mfma32bf(ah, bl, c_); c_ = mfma32bf(am, bm, c_);   \
+                c_ = mfma32bf(am, bh, c_); c_ = mfma32bf(ah, bm, c_); c_ = mfma32bf(ah, bh, c_);   \
+                acc[t][nt] = c_;                                                                   \
+              }                                                                                    \
+            }                                                                                      \
+          } else {                                                                                 \
+            _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch) {                                   \
+              u32x2 ah, am, al;                                                                    \
+              split3(A[t][ch], ah, am, al);                                                        \
+              _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                  \
+                const unsigned char* p_ = B_ + ((ch * NT + nt) * 64 + lane) * 8;                   \
+                const u32x2 bh = *reinterpret_cast<const u32x2*>(p_), bm = *reinterpret_cast<const u32x2*>(p_ + XPL), \
+                            bl = *reinterpret_cast<const u32x2*>(p_ + 2 * XPL);                    \
+                f32x4 c_ = acc[t][nt];                                                             \
+                c_ = mfma16<VC_OPERAND_BF16>(al, bh, c_); c_ = mfma16<VC_OPERAND_BF16>(ah, bl, c_); \
+                c_ = mfma16<VC_OPERAND_BF16>(am, bm, c_); c_ = mfma16<VC_OPERAND_BF16>(am, bh, c_); \
+                c_ = mfma16<VC_OPERAND_BF16>(ah, bm, c_); c_ = mfma16<VC_OPERAND_BF16>(ah, bh, c_); \
+                acc[t][nt] = c_;                                                                   \
+              }                                                                                    \
+            }                                                                                      \
           }                                                                                        \
         }                                                                                          \
       }                                                                                            \
@@ -1100,6 +1179,58 @@ __device__ __forceinline__ void bw_group16(const float* __restrict__ x, const fl
     for (int jb = 0; jb < VB; ++jb) acc[ja][jb] = mfma16<OT_>(ah[ja], bh[jb], acc[ja][jb]);
 }
 
+// OT = VC_OPERAND_X6 (fp32 products as six bf16 terms, see split3): 32 pairs per step on v_mfma_f32_16x16x32_bf16; lane (i, q) loads the
+// rows of the 8 pairs 8q..8q+7 of the group; per channel those 8 values are cut into three bf16 octets.  The gradient rows' pieces are
+// formed once per group, the input rows' pieces per channel column (register pressure: 8 (VA + VB) operand floats + 12 VB piece
+// registers are live beside the VA VB accumulator quads).
+template <int CI, int CO>
+__device__ __forceinline__ void bw_group32_x6(const float* __restrict__ x, const float* __restrict__ dy, const int* qi, const int* qo,
+                                              int npairs, int i, int q, bool a_ok, bool b_ok,
+                                              f32x4 (&acc)[(CI >= 16) ? CI / 16 : 1][(CO >= 16) ? CO / 16 : 1]) {
+  constexpr int VA = (CI >= 16) ? CI / 16 : 1, VB = (CO >= 16) ? CO / 16 : 1;
+  float a[8][VA], b[8][VB];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int slot = q * 8 + r;
+    const bool ok = slot < npairs;
+    const int pin = ok ? qi[slot] : 0, pout = ok ? qo[slot] : 0;
+    if (ok && a_ok) VecLoad<VA>::ld(x + (int64_t)pin * CI + VA * i, a[r]);
+    else {
+#pragma unroll
+      for (int j = 0; j < VA; ++j) a[r][j] = 0.f;
+    }
+    if (ok && b_ok) VecLoad<VB>::ld(dy + (int64_t)pout * CO + VB * i, b[r]);
+    else {
+#pragma unroll
+      for (int j = 0; j < VB; ++j) b[r][j] = 0.f;
+    }
+  }
+  u32x4 bh[VB], bm[VB], bl[VB];
+#pragma unroll
+  for (int j = 0; j < VB; ++j) {
+    const float t0[4] = {b[0][j], b[1][j], b[2][j], b[3][j]}, t1[4] = {b[4][j], b[5][j], b[6][j], b[7][j]};
+    u32x2 h0, m0, l0, h1, m1, l1;
+    split3(t0, h0, m0, l0);
+    split3(t1, h1, m1, l1);
+    bh[j] = u32x4{h0.x, h0.y, h1.x, h1.y}; bm[j] = u32x4{m0.x, m0.y, m1.x, m1.y}; bl[j] = u32x4{l0.x, l0.y, l1.x, l1.y};
+  }
+#pragma unroll
+  for (int ja = 0; ja < VA; ++ja) {
+    const float t0[4] = {a[0][ja], a[1][ja], a[2][ja], a[3][ja]}, t1[4] = {a[4][ja], a[5][ja], a[6][ja], a[7][ja]};
+    u32x2 h0, m0, l0, h1, m1, l1;
+    split3(t0, h0, m0, l0);
+    split3(t1, h1, m1, l1);
+    const u32x4 ah = {h0.x, h0.y, h1.x, h1.y}, am = {m0.x, m0.y, m1.x, m1.y}, al = {l0.x, l0.y, l1.x, l1.y};
+#pragma unroll
+    for (int jb = 0; jb < VB; ++jb) {
+      f32x4 c = acc[ja][jb];
+      c = mfma32bf(al, bh[jb], c); c = mfma32bf(ah, bl[jb], c); c = mfma32bf(am, bm[jb], c);
+      c = mfma32bf(am, bh[jb], c); c = mfma32bf(ah, bm[jb], c); c = mfma32bf(ah, bh[jb], c);
+      acc[ja][jb] = c;
+    }
+  }
+}
+
 // OT != VC_OPERAND_F32: 16 pairs per MFMA step (v_mfma_f32_16x16x16_{f16,bf16}); lane (i, q) loads the rows of the 4 pairs
 // 4q..4q+3 of the group and packs, per channel, those 4 values (rounded to 16 bit) into one operand.
 template <int CI, int CO, int OT>
@@ -1118,7 +1249,7 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
 #define VC_BW_UMUL 1   // A/B builds: groups per trip x 2 (profiles/r04_dw_trip_depth.md)
 #endif
   constexpr int U = ((VA * VB >= 8) ? 2 : 4) * VC_BW_UMUL;             // groups of 4 pairs gathered per iteration
-  constexpr int GP = (OT == VC_OPERAND_F32) ? 4 : 16;                  // pairs per MFMA K-step
+  constexpr int GP = (OT == VC_OPERAND_F32) ? 4 : (OT == VC_OPERAND_X6 ? 32 : 16);   // pairs per MFMA K-step
   __shared__ int q_in[4][136];
   __shared__ int q_out[4][136];
   __shared__ float red[CI * CO];
@@ -1224,6 +1355,9 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
           for (int jb = 0; jb < VB; ++jb)
             acc[ja][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ja], b[jb], acc[ja][jb], 0, 0, 0);
       }
+    } else if constexpr (OT == VC_OPERAND_X6) {
+      const int ng = qlen >> 5;
+      for (int g = 0; g < ng; ++g) bw_group32_x6<CI, CO>(x, dy, qi + g * 32, qo + g * 32, 32, i, q, a_ok, b_ok, acc);
     } else {
       const int ng = qlen >> 4;
       for (int g = 0; g < ng; ++g) bw_group16<CI, CO, OT>(x, dy, qi + g * 16, qo + g * 16, 16, i, q, a_ok, b_ok, acc);
@@ -1257,6 +1391,8 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
 #pragma unroll
         for (int jb = 0; jb < VB; ++jb)
           acc[ja][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ja], b[jb], acc[ja][jb], 0, 0, 0);
+    } else if constexpr (OT == VC_OPERAND_X6) {
+      bw_group32_x6<CI, CO>(x, dy, qi, qo, qlen, i, q, a_ok, b_ok, acc);
     } else {
       bw_group16<CI, CO, OT>(x, dy, qi, qo, qlen, i, q, a_ok, b_ok, acc);
     }
@@ -1639,6 +1775,13 @@ int g_conv_v4 = 0;   // off: inside the train step (weight-gradient stream conte
 // VGPRs; forcing 6 waves spills), but the 32-channel shapes keep all eight and lose as well: the 32 DPP / select operations per
 // side offset sit between the loads' arrival and the MFMAs.  Fewer gathered rows alone do not buy time.
 int g_conv_dxs = 0;
+// vc_debug_set f32_split: 0 = fp32 products on v_mfma_f32_16x16x4_f32 (exact); 1 = on the bf16 matrix cores as six split terms (split3)
+// for the shapes f32_split_pays names; 2 = for every shape with 16-multiple channel counts
+int g_f32_split = 1;
+static inline bool f32_split_pays(int ck, int cn, bool bwd) {
+  (void)ck; (void)cn; (void)bwd;
+  return true;
+}
 int g_conv_v5 = 0;             // developer: loader / MFMA wave-role kernel (plain launches with a weight image)
 int g_conv_v4_pf = 1;          // developer: gather prefetch distance of the v4 kernel (1 | 2 | 4), plain launches with an image only
 int g_conv_v4_ablate = 0;      // developer ablations of the v4 kernel (see its ABL parameter); results are wrong when set
@@ -1784,7 +1927,7 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
   if constexpr (CK % 16 == 0 && CN % 16 == 0) {
     if (ot == VC_OPERAND_F32 && kv <= 32) {
       wpk = packed_lookup(w, BWD);
-      if (wpk == nullptr && g_conv_autopack) {
+      if (wpk == nullptr && (g_conv_autopack || g_f32_split)) {   // (split products read the fragment-ordered image on every route)
         float* scratch = autopack_scratch(BWD);
         if (scratch != nullptr && (size_t)kv * CK * CN * sizeof(float) <= kAutopackBytes) {
           PackArgs pa;
@@ -1956,6 +2099,41 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
     constexpr int V = (CK >= 16) ? 4 : CK / 4;
     constexpr int NCH = CK / (4 * V);
     constexpr int NT = (CN + 15) / 16;
+    // fp32 products as six bf16 MFMA terms (vc_debug_set f32_split; see split3): the same block shapes, epilogues and weight image as
+    // the fp32 kernels below, operand type X6
+    if constexpr (CK % 16 == 0 && CN % 16 == 0) {
+      if (g_f32_split && ot == VC_OPERAND_F32 && wpk != nullptr && f32_split_pays(CK, CN, BWD)) {
+        const bool w8 = conv_block_waves(CK, CN, BWD, n_out, order != nullptr) == 8 && epi_kind != VC_EPI_AFFINE;
+        size_t ldsx = (size_t)2 * NCH * NT * 64 * V * 6 + (size_t)(kv + 1) * (w8 ? 128 : 64) * sizeof(int) + 16;
+        const dim3 gridx((unsigned)cdiv(n_out, w8 ? 128 : 64));
+        fin_attach(epi, epi_kind, gridx.x, w8 ? 8 : 4, CN, ldsx);
+#define VC_LX(B_, E_)                                                                                                             \
+  do {                                                                                                                            \
+    if (w8) hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, B_, 1, VC_OPERAND_X6, E_, 8, true>), gridx, dim3(512), ldsx, st, src, \
+                               src_centre, n_src, tbl, wpk, out, rep, order, n_out, kv, centre, mirror, epi);                    \
+    else hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, B_, 1, VC_OPERAND_X6, E_, 4, true>), gridx, dim3(256), ldsx, st, src,  \
+                            src_centre, n_src, tbl, wpk, out, rep, order, n_out, kv, centre, mirror, epi);                       \
+  } while (0)
+        bool done = true;
+        if constexpr (BWD) {
+          if (epi_kind == VC_EPI_BWD) VC_LX(true, VC_EPI_BWD);
+          else if (epi_kind == VC_EPI_NONE) VC_LX(true, VC_EPI_NONE);
+          else done = false;
+        } else {
+          if (epi_kind == VC_EPI_STATS) VC_LX(false, VC_EPI_STATS);
+          else if (epi_kind == VC_EPI_AFFINE) hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, false, 1, VC_OPERAND_X6, VC_EPI_AFFINE, 4, true>),
+                                                                 gridx, dim3(256), ldsx, st, src, src_centre, n_src, tbl, wpk, out, rep, order,
+                                                                 n_out, kv, centre, mirror, epi);
+          else if (epi_kind == VC_EPI_NONE) VC_LX(false, VC_EPI_NONE);
+          else done = false;
+        }
+#undef VC_LX
+        if (done) {
+          VC_CHECK_LAUNCH("gather_gemm_v2_kernel<split bf16>");
+          return VC_OK;
+        }
+      }
+    }
     // finer blocks fill the last round of the grid better and raise occupancy; coarser blocks reuse W_k more
     // rows per block = 64 * rt.  Measured (tools/kbench.py): rt = 1 wins or ties everywhere -- the kernel is bound by
     // L2 latency / occupancy, not by the W_k re-staging traffic: a variant looping 2/4/8 row tiles per staged W_k (W
@@ -2115,6 +2293,7 @@ static int dispatch_ck(int ck, int cn, const float* src, const float* src_centre
 
 int g_bw_rows_per_split = 1024;  // weight gradient: target rows per block (vc_debug_set bw_rows_per_split); more rows = fewer, longer blocks and fewer partial sums
 int g_bw_legacy_order = 0;      // debug: 1 = offset-major block order of the weight-gradient kernel
+int g_bw_split = 0;             // vc_debug_set bw_split: 1 = weight-gradient products on the bf16 matrix cores as six split terms (bw_group32_x6)
 int g_bw_small = 1;             // vc_debug_set bw_small: 0 = bwd_weight_kernel for every shape; 1 = bwd_weight_small_kernel where it measured faster; 3 = wherever it applies
 int g_bw_variant = 1;           // vc_debug_set bw_variant: 1 = bwd_weight_kernel, 2 = bwd_weight_v2_kernel (dy window in LDS) where it applies
 extern int g_pass_dw_main_tail; // pass.hip
@@ -2191,6 +2370,9 @@ static int launch_bw(const float* x, const float* dy, const int32_t* tbl, int64_
   }
   if constexpr (CI >= 16 && CO >= 16) {  // 16-bit operands only where both channel counts are >= 16 (as in the gather-GEMM)
     if (launched) {
+    } else if (ot == VC_OPERAND_F32 && g_bw_split) {   // fp32 products as six bf16 terms (vc_debug_set bw_split)
+      hipLaunchKernelGGL((bwd_weight_kernel<CI, CO, VC_OPERAND_X6>), dim3(nblocks), dim3(256), 0, st, VC_ARGS);
+      launched = true;
     } else if (ot == VC_OPERAND_F16) {
       hipLaunchKernelGGL((bwd_weight_kernel<CI, CO, VC_OPERAND_F16>), dim3(nblocks), dim3(256), 0, st, VC_ARGS);
       launched = true;
@@ -2286,6 +2468,7 @@ int vc_debug_set(const char* key, int value) {
   VC_REQUIRE(key, "vc_debug_set: null key");
   if (!strcmp(key, "conv_variant")) { g_conv_variant = value; return VC_OK; }
   if (!strcmp(key, "conv_rt")) { g_conv_rt = value; return VC_OK; }
+  if (!strcmp(key, "f32_split")) { g_f32_split = value; return VC_OK; }
   if (!strcmp(key, "conv_autopack")) { g_conv_autopack = value; return VC_OK; }
   if (!strcmp(key, "conv_v4")) return experiment_key(key, value, 0, &g_conv_v4);
   if (!strcmp(key, "conv_v4_ablate")) return experiment_key(key, value, 0, &g_conv_v4_ablate);
@@ -2301,6 +2484,7 @@ int vc_debug_set(const char* key, int value) {
   if (!strcmp(key, "conv_nw")) { g_conv_nw = (value == 8 || value == 4) ? value : 0; return VC_OK; }
   if (!strcmp(key, "bw_legacy_order")) { g_bw_legacy_order = value; return VC_OK; }
   if (!strcmp(key, "bw_small")) { g_bw_small = value; return VC_OK; }
+  if (!strcmp(key, "bw_split")) { g_bw_split = value; return VC_OK; }
   if (!strcmp(key, "bw_rows_per_split")) { if (value >= 256) g_bw_rows_per_split = value; return VC_OK; }
   if (!strcmp(key, "pass_dw_main_tail")) { g_pass_dw_main_tail = value; return VC_OK; }
   if (!strcmp(key, "pass_bwd_epilogue")) { g_pass_bwd_epilogue = value; return VC_OK; }
