@@ -150,8 +150,8 @@ def synthetic_loss(out, lw):
 def train_step(model, optimizer, batch, lw, grad_sync=None, raw=None, next_batch=None):
     """fwd + bwd + Adam.  loss = (out.dense()*G).sum() + sum_i (x_conv_i.features * g_i).sum()  (heads out of scope).
     `raw`: run the data front-end on the raw points first (the --frontend workload); `batch` then only carries calib / aug.
-    `next_batch`: the batch of the NEXT step, as a prefetching loader holds it: its geometry plan is begun before this step's forward
-    and finished behind this step's backward (VirConvL8x.plan_ahead_begin / _finish); the next call finds it ready."""
+    `next_batch`: the batch of the NEXT step, as a prefetching loader holds it: the first half of its geometry plan (coordinates,
+    keeps, row counts: VirConvL8x.plan_ahead_begin) is enqueued before this step's forward; the next call finishes and uses it."""
     optimizer.zero_grad(set_to_none=True)
     if raw is not None:
         bd = front_end(raw, batch)
@@ -164,8 +164,6 @@ def train_step(model, optimizer, batch, lw, grad_sync=None, raw=None, next_batch
     out = model(bd)
     loss = synthetic_loss(out, lw)
     loss.backward()
-    if next_batch is not None:
-        base.plan_ahead_finish()
     if grad_sync is not None:
         grad_sync()  # data-parallel exchange: one flat RCCL all-reduce of the gradients
     torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)  # train_utils.py:50
@@ -246,13 +244,32 @@ def run_infer(args, model, batch, device, rank, world):
         return {"metric": "KITTI frames/sec (forward only) VirConv-L backbone", "value": round(bs * world * args.steps / dt, 3),
                           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "vs_baseline": None, "dtype": _dtype(ops.get_backend(), args.operand), "data": "synthetic",
                           "config": {"workload": "BASELINE configs[1]: VirConv-L forward only, eval mode, + dense(); two frames in "
                                                  "flight (plan of the next frame over the feature pass of this one)",
                                      "frames_per_gpu": bs, "voxels_rank0": int(batch["voxel_features"].shape[0]),
                                      "single_step_latency_ms": round(lat_ms, 3)},
                           "roofline": _traced_roofline(trace, args, tdir, tck, tcn, pmc=False), "cpu_baseline": None}
     return None
+
+
+def _f32_split(be) -> int:
+    import ctypes
+    v = ctypes.c_int64(0)
+    if not hasattr(be, "lib") or be.lib.vc_debug_get(b"f32_split", ctypes.byref(v)) != 0:
+        return 0
+    return int(v.value)
+
+
+def _dtype(be, operand: str) -> str:
+    """The arithmetic type of the path.  f32 tensors and f32 accumulation always; the conv products are either exact fp32 products on
+    v_mfma_f32_16x16x4_f32 or -- the library default since round 4 -- six exact bf16 x bf16 cross terms of operands cut exactly into
+    three bf16 pieces (fp32-exact to 2^-23 relative; tests/test_split_gpu.py holds it against float64)."""
+    if operand != "f32":
+        return f"{operand} MFMA operands, f32 accumulate, f32 tensors"
+    if _f32_split(be):
+        return "f32 (f32 tensors and accumulation; conv products as a 6-term exact bf16 split on the MFMA, f32-exact to 2^-23)"
+    return "f32"
 
 
 def _emit(res):
@@ -325,9 +342,9 @@ def main(argv=None, plumbing=False):
                          "streams), the backbone of BASELINE configs[3], bs 2 per GPU unless --batch-size is given")
     ap.add_argument("--family-steps", type=int, default=3,
                     help="extra untimed steps after the timed region with every conv launch event-bracketed (family / step roofline)")
-    ap.add_argument("--plan-ahead-steps", type=int, default=1, choices=[0, 1],
-                    help="1: after the timed region, time the same K steps again with the geometry plan built a step ahead "
-                         "(reported as `plan_ahead`, never as `value`)")
+    ap.add_argument("--exact-steps", type=int, default=1, choices=[0, 1],
+                    help="1: after the timed region, time the same K steps with exact-fp32 MFMA products (vc_debug_set f32_split=0; "
+                         "reported as `exact_f32_mfma`)")
     ap.add_argument("--frontend", action="store_true",
                     help="include the GPU data front-end (input point discard + LiDAR-first voxeliser + MeanVFE from raw "
                          "device-resident points) in every timed step (model L)")
@@ -442,25 +459,30 @@ def main(argv=None, plumbing=False):
     trace = be.trace_end() if can_trace else []
     dt = parallel.max_over_ranks(dt, device)
 
-    # Second timed loop (reported beside the headline, never as `value`): the same K steps with the geometry plan of step t + 1 begun
-    # before the forward of step t and finished behind its backward -- what a training loop with a prefetching loader can do.  Every
-    # step still builds exactly one plan inside the timed region; it only leaves the critical path between two steps.
-    ahead = None
-    if args.plan_ahead_steps and args.model == "L" and raw is None and not plumbing and hasattr(model, "plan_ahead_begin"):
-        for _ in range(args.warmup):
-            train_step(ddp, optimizer, batch, lw, grad_sync, raw, next_batch=batch)
-        parallel.barrier()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            train_step(ddp, optimizer, batch, lw, grad_sync, raw, next_batch=batch)
-        sync()
-        parallel.barrier()
-        dt_a = parallel.max_over_ranks(time.perf_counter() - t0, device)
-        model._ahead.clear()    # the plan begun for a step that will not run
-        ahead = {"ms_per_step": round(dt_a / args.steps * 1e3, 3), "value": round(bs * world * args.steps / dt_a, 3), "unit": "frames/s",
-                 "note": "same K steps, geometry plan of step t+1 begun before step t's forward and finished behind its backward "
-                         "(VirConvL8x.plan_ahead_begin/_finish; one plan per step, inside the timed region)"}
+    # Second timed loop (reported beside the headline): the same K steps with the conv products on v_mfma_f32_16x16x4_f32 (exact fp32
+    # products) instead of the six-term bf16 split that is the library default (csrc/conv_kernels.hip, split3: operands cut EXACTLY into
+    # three bf16 pieces, six cross terms on v_mfma_f32_16x16x32_bf16, fp32 accumulation; <= 2^-23 relative per product, measured against
+    # float64 in tests/test_split_gpu.py).  Tensors, accumulation and every other kernel are the same in both.
+    exact = None
+    if args.exact_steps and args.operand == "f32" and not plumbing and args.mode == "train":
+        import ctypes
+        cur, cur_w = ctypes.c_int64(0), ctypes.c_int64(0)
+        assert be.lib.vc_debug_get(b"f32_split", ctypes.byref(cur)) == 0 and be.lib.vc_debug_get(b"bw_split", ctypes.byref(cur_w)) == 0
+        if cur.value != 0 or cur_w.value != 0:
+            assert be.lib.vc_debug_set(b"f32_split", 0) == 0 and be.lib.vc_debug_set(b"bw_split", 0) == 0
+            for _ in range(args.warmup):
+                train_step(ddp, optimizer, batch, lw, grad_sync, raw)
+            parallel.barrier()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                train_step(ddp, optimizer, batch, lw, grad_sync, raw)
+            sync()
+            parallel.barrier()
+            dt_e = parallel.max_over_ranks(time.perf_counter() - t0, device)
+            assert be.lib.vc_debug_set(b"f32_split", int(cur.value)) == 0 and be.lib.vc_debug_set(b"bw_split", int(cur_w.value)) == 0
+            exact = {"ms_per_step": round(dt_e / args.steps * 1e3, 3), "value": round(bs * world * args.steps / dt_e, 3), "unit": "frames/s",
+                     "note": "same K steps with vc_debug_set f32_split = 0, bw_split = 0: every conv product on v_mfma_f32_16x16x4_f32 (the round 1-3 kernels)"}
 
     # Family- and step-level roofline (outside the timed region, rank 0): a few more steps with EVERY gather-GEMM and
     # weight-gradient launch bracketed by HIP events on its launch stream (vc_trace_begin direction -1)
@@ -495,6 +517,10 @@ def main(argv=None, plumbing=False):
     roof = _traced_roofline(trace, args, tdir, tck, tcn, pmc=True)
     if roof is not None:
         peak = roof["peak"]
+        if _f32_split(be) and args.operand == "f32":
+            roof["products_note"] = ("algorithmic fp32 flops against the fp32 MFMA peak (157.3 TF) as in rounds 1-3; the products of this "
+                                     "kernel run as six v_mfma_f32_16x16x32_bf16 terms (2.5 PF dense / 6 = 417 TF fp32-equivalent); "
+                                     "`exact_f32_mfma` has the step on v_mfma_f32_16x16x4_f32")
         roof["kernel_note"] = ("this launch also finishes the BatchNorm statistics of its output (conv_finish_tail: a 3-9 us tail "
                                "instead of two more launches): `frac` prices its whole duration against the GEMM flops alone")
         if plain:
@@ -565,7 +591,7 @@ def main(argv=None, plumbing=False):
         "metric": metric, "value": round(frames / dt, 3), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.operand == "f32" else f"{args.operand} MFMA operands, f32 accumulate, f32 tensors",
+        "dtype": _dtype(be, args.operand),
         "data": "synthetic",
         "config": {"workload": workload,
                    "frames_per_gpu": bs, "global_batch": bs * world,
@@ -577,7 +603,7 @@ def main(argv=None, plumbing=False):
                                      "streams": "main + geometry plan (high priority) + weight-gradient side stream",
                                      "row_order": ops.ROW_ORDER}},
         "roofline": roof,
-        "plan_ahead": ahead,
+        "exact_f32_mfma": exact,
     }
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline()

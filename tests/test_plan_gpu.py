@@ -209,8 +209,8 @@ def test_train_step_with_the_native_plan_matches_the_operator_by_operator_plan(h
 
 
 def test_training_with_the_plan_built_a_step_ahead_is_bit_identical(hip_backend):
-    """VirConvL8x.plan_ahead_begin / _finish (bench.train_step(next_batch=...)): the plan of step t + 1 begun before step t's forward
-    and finished behind its backward.  With the layer discards injected (the random draws would otherwise be consumed in a different
+    """VirConvL8x.plan_ahead_begin (bench.train_step(next_batch=...)): the first half of the plan of step t + 1 enqueued before step t's
+    forward, the tables built when step t + 1 asks for them.  With the layer discards injected (the random draws would otherwise be consumed in a different
     order) three optimiser steps give the same losses and the same parameters, bit for bit; a batch the early plan was NOT begun for
     falls back to the in-place plan."""
     dev = torch.device("cuda", 0)

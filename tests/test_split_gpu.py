@@ -75,6 +75,41 @@ def test_split_products_are_as_accurate_as_fp32_mfma(hip_backend, cin, cout, dec
         assert e1 < 1e-5, err
 
 
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 16), (32, 32), (64, 32), (64, 64)])
+@pytest.mark.parametrize("decades", [0, 8])
+def test_split_weight_gradient_is_as_accurate_as_fp32_mfma(hip_backend, cin, cout, decades):
+    """dW_k = sum over pairs of x[in]^T dy[out] (vc_debug_set bw_split: 32 pairs per v_mfma_f32_16x16x32_bf16 step) against float64."""
+    lib = hip_backend.lib
+    rng = np.random.default_rng(cin * 17 + cout + decades)
+    idx = torch.from_numpy(synth.small_scene_indices(6, 6000, SHAPE3, 2)).cuda()
+    n = idx.shape[0]
+    pair, _ = hip_backend.subm_rulebook(idx, SHAPE3, (3, 3, 3), (1, 1, 1), want_rep=False)
+    x = torch.from_numpy(_scaled(rng, (n, cin), decades)).cuda()
+    g = torch.from_numpy(_scaled(rng, (n, cout), decades)).cuda()
+    kv = pair.shape[0]
+    ref = torch.zeros((cout, kv, cin), dtype=torch.float64, device="cuda")
+    for k in range(kv):
+        ii = pair[k].long()
+        ok = ii >= 0
+        ref[:, k, :] = g.double()[ok].T @ x.double()[ii[ok]]
+    # every entry against the size of the sum it is (sum of |terms|): a cancelling sum has no meaningful error relative to itself
+    mag = torch.zeros_like(ref)
+    for k in range(kv):
+        ii = pair[k].long()
+        ok = ii >= 0
+        mag[:, k, :] = g.double()[ok].abs().T @ x.double()[ii[ok]].abs()
+    err = {}
+    try:
+        for split in (0, 1):
+            assert lib.vc_debug_set(b"bw_split", split) == 0
+            dw = hip_backend.conv_backward_weight(x, g, pair, (cout, 3, 3, 3, cin)).reshape(cout, kv, cin)
+            err[split] = float(((dw.double() - ref).abs() / mag.clamp_min(1e-300)).max())
+    finally:
+        assert lib.vc_debug_set(b"bw_split", 1) == 0
+    assert err[1] <= 2.0 * err[0] + 1.2e-7, (err, cin, cout, decades)
+    assert err[1] < 1e-5, err
+
+
 def test_split_is_exact_on_delicate_values(hip_backend):
     """One active pair per row, K = 16 channels of which ONE is non-zero: the conv output is a single product x * w, so the split
     kernel's result can be compared with the exact product directly: the dropped terms (<= 3 x 2^-24) and the six fp32 accumulations

@@ -479,16 +479,15 @@ class VirConvL8x(nn.Module):
                 plan = {"in_indices": idx, "stages": stages, "conv_out": {co.indice_key: rb_out}}
         return scope.publish(plan)
 
-    # ---- plan-ahead: the geometry plan of the NEXT batch under the current training step.  The plan depends on the batch's
-    # coordinates (and calibration / augmentation parameters / discard seeds) only, not on the weights, so a training loop that holds
-    # batch t + 1 while it runs step t -- any prefetching loader does -- can build it a step early:
-    #     model.plan_ahead_begin(next_batch)      # before the forward of step t: coordinates, keeps, row counts (no host sync)
-    #     ... forward / backward of step t ...
-    #     model.plan_ahead_finish()               # counts arrived long ago: the tables go onto the plan stream, under step t's tail
-    #     optimizer.step()
-    # and forward(next_batch) finds its plan finished (matched by the identity and version of its voxel_coords tensor; a mismatch of
-    # any kind just discards the early plan and builds one in place).  One plan is built per step either way -- it only moves off the
-    # critical path between two steps (bench.py reports the step time with and without it).
+    # ---- plan-ahead: the first half of the geometry plan of the NEXT batch under the current step's forward.  The plan depends on the
+    # batch's coordinates (and calibration / augmentation parameters / discard seeds) only, not on the weights, so a training loop that
+    # holds batch t + 1 while it runs step t -- any prefetching loader does -- can enqueue its coordinate / keep / row-count chain
+    # (vc_plan_begin: no host synchronisation) a step early:
+    #     model.plan_ahead_begin(next_batch)      # before the forward of step t
+    # forward(next_batch) then finds the counts on the host without waiting, builds the tables and runs (matched by the identity and
+    # version of its voxel_coords tensor; a mismatch of any kind just discards the early half and plans in place).  Measured neutral on
+    # MI355X (the plan costs kernel work, not latency: LOG.md A.10).  The TABLES are deliberately not built under the previous step's
+    # backward: with that overlap a few waves of the pixel projection came out wrong (LOG.md A.15, cause not found).
     def _rot_inputs(self, batch_dict):
         rot_num = batch_dict["transform_param"].shape[1] if "transform_param" in batch_dict else 1
         for i in range(rot_num):
@@ -538,11 +537,6 @@ class VirConvL8x(nn.Module):
                     cp.finish()
                 a["fwd_ready"] = torch.cuda.Event()
                 a["fwd_ready"].record()
-
-    def plan_ahead_finish(self) -> None:
-        """Enqueue the tables of every begun plan (no-op for those already finished)."""
-        for a in self._ahead:
-            self._finish_ahead(a)
 
     def _take_ahead(self, coords, rid):
         mode = self._ahead_mode()

@@ -2293,7 +2293,7 @@ static int dispatch_ck(int ck, int cn, const float* src, const float* src_centre
 
 int g_bw_rows_per_split = 1024;  // weight gradient: target rows per block (vc_debug_set bw_rows_per_split); more rows = fewer, longer blocks and fewer partial sums
 int g_bw_legacy_order = 0;      // debug: 1 = offset-major block order of the weight-gradient kernel
-int g_bw_split = 0;             // vc_debug_set bw_split: 1 = weight-gradient products on the bf16 matrix cores as six split terms (bw_group32_x6)
+int g_bw_split = 1;             // vc_debug_set bw_split: 1 (default) = weight-gradient products on the bf16 matrix cores as six split terms (bw_group32_x6); 0 = v_mfma_f32_16x16x4_f32
 int g_bw_small = 1;             // vc_debug_set bw_small: 0 = bwd_weight_kernel for every shape; 1 = bwd_weight_small_kernel where it measured faster; 3 = wherever it applies
 int g_bw_variant = 1;           // vc_debug_set bw_variant: 1 = bwd_weight_kernel, 2 = bwd_weight_v2_kernel (dy window in LDS) where it applies
 extern int g_pass_dw_main_tail; // pass.hip
@@ -2437,6 +2437,8 @@ extern "C" {
 int vc_debug_get(const char* key, int64_t* value) {
   VC_REQUIRE(key && value, "vc_debug_get: null argument");
   if (!strcmp(key, "conv_bn_finish_launches")) { *value = (int64_t)g_fin_launches.load(std::memory_order_relaxed); return VC_OK; }
+  if (!strcmp(key, "f32_split")) { *value = g_f32_split; return VC_OK; }
+  if (!strcmp(key, "bw_split")) { *value = g_bw_split; return VC_OK; }
   if (!strcmp(key, "experiments")) {   // 1: the library carries the measured-and-rejected variants of csrc/experiments/
 #ifdef VC_EXPERIMENTS
     *value = 1;

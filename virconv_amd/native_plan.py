@@ -117,8 +117,8 @@ class ChainPlan:
     """The native plan of a chain of ChainBlocks (+ `tail`: the strided conv behind it) over the coordinates `idx` (N, 4) int32, in
     two steps.  The constructor enqueues vc_plan_begin on the current stream (coordinates, keeps and row counts of every level;
     no host synchronisation); `finish()` polls the counts (vc_plan_wait: the ONE host synchronisation), enqueues the tables and
-    returns the result.  `build_chain` does both back to back; `backbone.VirConvL8x.plan_ahead_begin / _finish` put a training step
-    between them (the counts have long arrived when finish() asks for them).
+    returns the result.  `build_chain` does both back to back; `backbone.VirConvL8x.plan_ahead_begin` enqueues the first half a
+    training step early (the counts have long arrived when finish() asks for them).
     `discard_tags[b]`: the batch_dict tag of the layer discard after block b or None; `input_discard_tag`: discard of the chain's
     input (VirConv8x MM stream).  `kind`: cache key of the chain's static description on `model`.
     `deferred`: None -> finish() enqueues everything.  A list -> only what a FORWARD pass reads is enqueued; a closure that enqueues
