@@ -44,7 +44,10 @@ typedef enum vc_status {
 
 /* arithmetic type of the MFMA operands of the conv kernels (accumulation is always fp32; tensors are always fp32) */
 typedef enum vc_operand {
-  VC_OPERAND_F32 = 0, /* v_mfma_f32_16x16x4_f32  : exact fp32, the default, the 1e-4 parity path */
+  VC_OPERAND_F32 = 0, /* fp32 products, the default, the 1e-4 parity path: operands cut EXACTLY into three bf16 pieces, six of the nine
+                         cross terms on v_mfma_f32_16x16x32_bf16 (the dropped ones are <= 2^-24 of a product), fp32 accumulation --
+                         or, for layers with fewer than 16 channels and with vc_debug_set("f32_split" / "bw_split", 0), exact products
+                         on v_mfma_f32_16x16x4_f32 */
   VC_OPERAND_F16 = 1, /* v_mfma_f32_16x16x16_f16 : operands rounded to fp16 in registers */
   VC_OPERAND_BF16 = 2 /* v_mfma_f32_16x16x16_bf16: operands rounded to bf16 in registers */
 } vc_operand;
@@ -124,8 +127,8 @@ int vc_spconv_pairs(const int32_t* indices, int64_t n, int ndim, int batch_size,
  *   Duplicate-coordinate SubM backward (2-D image-space branch): src_centre = dy is used for the
  *   centre tap, src = group-summed dy (vc_group_sum_sorted) for the others, and rows with rep[o] != o take the centre
  *   tap only.  Pass centre = -1, rep = NULL, src_centre = NULL when not needed.
- *   operand_type: VC_OPERAND_F32 (exact fp32 MFMA; the parity path) | VC_OPERAND_F16 | VC_OPERAND_BF16 -- tensors stay fp32
- *   in memory, the MFMA operands are rounded (RNE) to 16 bit in registers and accumulate in fp32 (BASELINE configs[4],
+ *   operand_type: VC_OPERAND_F32 (fp32 products, see vc_operand; the parity path) | VC_OPERAND_F16 | VC_OPERAND_BF16 -- tensors stay
+ *   fp32 in memory; with F16 / BF16 the MFMA operands are rounded (RNE) to 16 bit in registers and accumulate in fp32 (BASELINE configs[4],
  *   "fp16 MFMA contraction"; the reference has no reduced-precision path, tolerance 2e-2 relative).  Layers with fewer than
  *   16 channels on either side always contract in fp32.
  *   row_order (optional, NULL = natural order): a permutation of [0, n_out) from vc_row_order; tile slot s computes output

@@ -16,7 +16,7 @@
 R="${GRAFT_REPO_ROOT:-$PWD}"; cd "$R" || exit 1
 TAG="${1:-job}"; shift
 D="gpurun_out/$TAG"; mkdir -p "$D"
-BENCH40="--steps 40 --warmup 12 --no-cpu-baseline --family-steps 0"
+BENCH40="--steps 40 --warmup 12 --no-cpu-baseline --family-steps 0 --exact-steps 0"
 line() { for f in "$@"; do echo "$f $(grep -o '"ms_per_step": [0-9.]*' "$f" | head -1) $(grep -o '"value": [0-9.]*' "$f" | head -1)"; done; }
 for step in "$@"; do
   name="${step%%:*}"; arg=""; [ "$step" != "$name" ] && arg="${step#*:}"
@@ -43,13 +43,13 @@ for step in "$@"; do
     bevbench) timeout 200 python tools/bevbench.py > "$D/bevbench.txt" 2>&1; tail -n 6 "$D/bevbench.txt" ;;
     stats)
       ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$D/stats" -o x -- \
-          python "$R/bench.py" --steps 10 --warmup 5 --no-cpu-baseline --family-steps 0 > "$R/$D/p_stats.log" 2>&1 )
+          python "$R/bench.py" --steps 10 --warmup 5 --no-cpu-baseline --family-steps 0 --exact-steps 0 > "$R/$D/p_stats.log" 2>&1 )
       python tools/trace_gaps.py "$(find "$D/stats" -name '*kernel_trace.csv' | head -1)" > "$D/gaps.txt" 2>&1
       find "$D" -name '*kernel_trace.csv' -size +20M -delete; line "$D/p_stats.log" ;;
     pmc)
       for c in FETCH_SIZE WRITE_SIZE; do
         ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$R/$D/pmc_$c" -o x -- \
-            python "$R/bench.py" --steps 5 --warmup 3 --no-cpu-baseline --family-steps 0 > "$R/$D/p_$c.log" 2>&1 ); done
+            python "$R/bench.py" --steps 5 --warmup 3 --no-cpu-baseline --family-steps 0 --exact-steps 0 > "$R/$D/p_$c.log" 2>&1 ); done
       echo done ;;
     mfma)
       ( cd /tmp && export TMPDIR=/tmp && timeout 120 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY \
