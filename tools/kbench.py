@@ -60,8 +60,8 @@ def main():
     ap.add_argument("--v5", type=int, default=0, help="loader / MFMA wave-role gather-GEMM (vc_debug_set conv_v5; needs --autopack)")
     ap.add_argument("--dxs", type=int, default=-1, help="dx shift in the LDS-staged kernel (vc_debug_set conv_dxs): 0 | 1; -1 = library default; needs --autopack")
     ap.add_argument("--layers", default="", help="comma-separated substrings: only time layers whose name contains one of them")
-    ap.add_argument("--split", type=int, default=0, help="fp32 products as six bf16 MFMA terms (vc_debug_set f32_split; implies --autopack): also prints each layer's max deviation from the exact-fp32 kernels")
-    ap.add_argument("--bwsplit", type=int, default=0, help="weight-gradient products as six bf16 MFMA terms (vc_debug_set bw_split); prints each layer's deviation from the exact-fp32 kernel")
+    ap.add_argument("--split", type=int, default=1, help="gather-GEMM products: 1 (library default) = six bf16 split terms on the MFMA (vc_debug_set f32_split; needs a weight image: implies --autopack), also prints each layer's max deviation from the exact-fp32 kernels; 0 = v_mfma_f32_16x16x4_f32")
+    ap.add_argument("--bwsplit", type=int, default=1, help="weight-gradient products: 1 (library default) = six bf16 split terms (vc_debug_set bw_split), prints each layer's deviation from the exact-fp32 kernel; 0 = v_mfma_f32_16x16x4_f32")
     ap.add_argument("--il", action="store_true", help="forward convs (channel counts multiples of 16) also with the source features in the 16-row interleaved layout (VC_CONV_SRC_INTERLEAVED; implies --autopack)")
     args = ap.parse_args()
     ops.WINDOW_GATHER = bool(args.window)
