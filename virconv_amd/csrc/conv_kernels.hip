@@ -2298,6 +2298,7 @@ int g_bw_small = 1;             // vc_debug_set bw_small: 0 = bwd_weight_kernel 
 int g_bw_variant = 1;           // vc_debug_set bw_variant: 1 = bwd_weight_kernel, 2 = bwd_weight_v2_kernel (dy window in LDS) where it applies
 extern int g_pass_dw_main_tail; // pass.hip
 extern int g_pass_bwd_epilogue;
+extern int g_pass_pack_all;
 extern int g_pass_fork_ext_event; // pass.hip
 extern int g_bn_fused_partial;  // bn_kernels.hip
 extern int g_pass_defer_dw_reduce;  // pass.hip
@@ -2490,6 +2491,7 @@ int vc_debug_set(const char* key, int value) {
   if (!strcmp(key, "bw_rows_per_split")) { if (value >= 256) g_bw_rows_per_split = value; return VC_OK; }
   if (!strcmp(key, "pass_dw_main_tail")) { g_pass_dw_main_tail = value; return VC_OK; }
   if (!strcmp(key, "pass_bwd_epilogue")) { g_pass_bwd_epilogue = value; return VC_OK; }
+  if (!strcmp(key, "pass_pack_all")) { g_pass_pack_all = value; return VC_OK; }
   if (!strcmp(key, "pass_fork_ext_event")) { g_pass_fork_ext_event = value; return VC_OK; }
   if (!strcmp(key, "bn_fused_partial")) { g_bn_fused_partial = value; return VC_OK; }
   if (!strcmp(key, "conv_bn_finish")) { g_conv_bn_finish = value; return VC_OK; }
