@@ -264,11 +264,12 @@ def _f32_split(be) -> int:
 def _dtype(be, operand: str) -> str:
     """The arithmetic type of the path.  f32 tensors and f32 accumulation always; the conv products are either exact fp32 products on
     v_mfma_f32_16x16x4_f32 or -- the library default since round 4 -- six exact bf16 x bf16 cross terms of operands cut exactly into
-    three bf16 pieces (fp32-exact to 2^-23 relative; tests/test_split_gpu.py holds it against float64)."""
+    three bf16 pieces (within 2^-24 of the exact product, half an fp32 ulp: oracle/split_ref.py; tests/test_split_gpu.py holds the kernels
+    against float64)."""
     if operand != "f32":
         return f"{operand} MFMA operands, f32 accumulate, f32 tensors"
     if _f32_split(be):
-        return "f32 (f32 tensors and accumulation; conv products as a 6-term exact bf16 split on the MFMA, f32-exact to 2^-23)"
+        return "f32 (f32 tensors and accumulation; conv products as a 6-term exact bf16 split on the MFMA, within 2^-24 of the exact product)"
     return "f32"
 
 
@@ -461,8 +462,8 @@ def main(argv=None, plumbing=False):
 
     # Second timed loop (reported beside the headline): the same K steps with the conv products on v_mfma_f32_16x16x4_f32 (exact fp32
     # products) instead of the six-term bf16 split that is the library default (csrc/conv_kernels.hip, split3: operands cut EXACTLY into
-    # three bf16 pieces, six cross terms on v_mfma_f32_16x16x32_bf16, fp32 accumulation; <= 2^-23 relative per product, measured against
-    # float64 in tests/test_split_gpu.py).  Tensors, accumulation and every other kernel are the same in both.
+    # three bf16 pieces, six cross terms on v_mfma_f32_16x16x32_bf16, fp32 accumulation; within 2^-24 of the exact product, measured
+    # against float64 in tests/test_split_gpu.py).  Tensors, accumulation and every other kernel are the same in both.
     exact = None
     if args.exact_steps and args.operand == "f32" and not plumbing and args.mode == "train":
         import ctypes

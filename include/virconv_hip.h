@@ -45,7 +45,7 @@ typedef enum vc_status {
 /* arithmetic type of the MFMA operands of the conv kernels (accumulation is always fp32; tensors are always fp32) */
 typedef enum vc_operand {
   VC_OPERAND_F32 = 0, /* fp32 products, the default, the 1e-4 parity path: operands cut EXACTLY into three bf16 pieces, six of the nine
-                         cross terms on v_mfma_f32_16x16x32_bf16 (the dropped ones are <= 2^-24 of a product), fp32 accumulation --
+                         cross terms on v_mfma_f32_16x16x32_bf16 (the dropped ones stay below 2^-24 of a product), fp32 accumulation --
                          or, for layers with fewer than 16 channels and with vc_debug_set("f32_split" / "bw_split", 0), exact products
                          on v_mfma_f32_16x16x4_f32 */
   VC_OPERAND_F16 = 1, /* v_mfma_f32_16x16x16_f16 : operands rounded to fp16 in registers */

@@ -1,6 +1,6 @@
 """fp32 products on the bf16 matrix cores (vc_debug_set f32_split, csrc/conv_kernels.hip split3): every operand is cut EXACTLY into
-three bf16 values, six of the nine cross products are issued on v_mfma_f32_16x16x32_bf16 and accumulate in fp32; the three dropped
-terms are <= 2^-24 of a product each.  These tests hold that claim against float64: the split kernels' error is the exact-fp32
+three bf16 values (round to nearest), six of the nine cross products are issued on v_mfma_f32_16x16x32_bf16 and accumulate in fp32; the
+three dropped terms together stay below 2^-24 of a product (oracle/split_ref.py, tests/test_split_cpu.py).  These tests hold that claim against float64: the split kernels' error is the exact-fp32
 kernels' error (accumulation order), not a reduced-precision error -- on unit-scale data, on data spanning 12 decades, and on the
 values where truncation splits are delicate (negative numbers, powers of two, denormal-adjacent magnitudes)."""
 import numpy as np

@@ -76,27 +76,29 @@ __device__ __forceinline__ f32x4 mfma16(u32x2 a, u32x2 b, f32x4 c) {
 }
 
 // fp32-accurate products on the bf16 matrix cores (round 4, "f32_split"): x = h + m + l EXACTLY, three bf16 values of 8 significant bits
-// each obtained by truncation (v_and / v_sub: the differences are exact), and x y ~ l_x h_y + h_x l_y + m_x m_y + m_x h_y + h_x m_y +
-// h_x h_y: the three dropped terms are <= 2^-24 |x y| each, i.e. of the size of ONE fp32 rounding of the product.  Six
-// v_mfma_f32_16x16x32_bf16 (~17 cycles each per SIMD) per 32 channels instead of eight v_mfma_f32_16x16x4_f32 (32 cycles each):
+// each obtained by rounding to nearest even (v_cvt_pk_bf16_f32; the differences x - h and (x - h) - m are exact in fp32, |m| <= 2^-8 |x|,
+// |l| <= 2^-16 |x|), and x y ~ l_x h_y + h_x l_y + m_x m_y + m_x h_y + h_x m_y + h_x h_y: the three dropped terms together stay below
+// 2^-24 |x y|, HALF an fp32 ulp of the product (oracle/split_ref.py, tests/test_split_cpu.py; a truncating split would drop up to 2^-20).
+// Six v_mfma_f32_16x16x32_bf16 (~17 cycles each per SIMD) per 32 channels instead of eight v_mfma_f32_16x16x4_f32 (32 cycles each):
 // 0.4x the matrix-pipe time, paid for with ~5.5 VALU operations per gathered element.  Tensors and accumulation stay fp32.
 static constexpr int VC_OPERAND_X6 = 3;   // internal operand type: selected by vc_debug_set f32_split for operand_type VC_OPERAND_F32
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned pk_bf16_rne(float a, float b) {   // a in the low half
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
 __device__ __forceinline__ void split3(const float* f, u32x2& h, u32x2& m, u32x2& l) {
-  unsigned uh[4], um[4], ul[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const unsigned u = __float_as_uint(f[j]);
-    const float r1 = f[j] - __uint_as_float(u & 0xFFFF0000u);          // exact: the low 16 bits of the significand
-    const unsigned u1 = __float_as_uint(r1);
-    const float r2 = r1 - __uint_as_float(u1 & 0xFFFF0000u);           // exact: <= 8 significant bits, a bf16 value
-    uh[j] = u; um[j] = u1; ul[j] = __float_as_uint(r2);
-  }
-  // v_perm_b32: the high halves of two registers side by side = two truncated bf16 values (element 0 in the low half)
-  h.x = __builtin_amdgcn_perm(uh[1], uh[0], 0x07060302u); h.y = __builtin_amdgcn_perm(uh[3], uh[2], 0x07060302u);
-  m.x = __builtin_amdgcn_perm(um[1], um[0], 0x07060302u); m.y = __builtin_amdgcn_perm(um[3], um[2], 0x07060302u);
-  l.x = __builtin_amdgcn_perm(ul[1], ul[0], 0x07060302u); l.y = __builtin_amdgcn_perm(ul[3], ul[2], 0x07060302u);
+  h.x = pk_bf16_rne(f[0], f[1]);
+  h.y = pk_bf16_rne(f[2], f[3]);
+  const float r0 = f[0] - __uint_as_float(h.x << 16), r1 = f[1] - __uint_as_float(h.x & 0xFFFF0000u);   // exact
+  const float r2 = f[2] - __uint_as_float(h.y << 16), r3 = f[3] - __uint_as_float(h.y & 0xFFFF0000u);
+  m.x = pk_bf16_rne(r0, r1);
+  m.y = pk_bf16_rne(r2, r3);
+  const float s0 = r0 - __uint_as_float(m.x << 16), s1 = r1 - __uint_as_float(m.x & 0xFFFF0000u);       // exact, bf16 values
+  const float s2 = r2 - __uint_as_float(m.y << 16), s3 = r3 - __uint_as_float(m.y & 0xFFFF0000u);
+  l.x = pk_bf16_rne(s0, s1);
+  l.y = pk_bf16_rne(s2, s3);
 }
 __device__ __forceinline__ f32x4 mfma32bf(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
