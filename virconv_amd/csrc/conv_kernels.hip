@@ -1248,7 +1248,7 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
   constexpr int VA = (CI >= 16) ? CI / 16 : 1, VB = (CO >= 16) ? CO / 16 : 1;
   constexpr int MA = (CI >= 16) ? 16 : CI, NB = (CO >= 16) ? 16 : CO;  // lanes of the tile that carry data
 #ifndef VC_BW_UMUL
-#define VC_BW_UMUL 1   // A/B builds: groups per trip x 2 (profiles/r04_dw_trip_depth.md)
+#define VC_BW_UMUL 1   // A/B builds: groups per trip x 2 (LOG.md A.13: every layer within 1 %)
 #endif
   constexpr int U = ((VA * VB >= 8) ? 2 : 4) * VC_BW_UMUL;             // groups of 4 pairs gathered per iteration
   constexpr int GP = (OT == VC_OPERAND_F32) ? 4 : (OT == VC_OPERAND_X6 ? 32 : 16);   // pairs per MFMA K-step
@@ -1445,7 +1445,7 @@ __global__ void __launch_bounds__(256) bwd_weight_small_kernel(const float* __re
                                                                const int32_t* __restrict__ tbl, int64_t n_out, int kv,
                                                                int64_t rows_per_block, int nsplit, int legacy_order,
                                                                float* __restrict__ partial, const int32_t* __restrict__ rep,
-                                                               int centre, const float* __restrict__ dy_grp, int d_rows_on_lanes) {
+                                                               int centre, const float* __restrict__ dy_grp) {
   constexpr int VA = CI / 4, VB = CO / 4;
   static_assert(CI % 4 == 0 && CO % 4 == 0 && VA <= 8 && VB <= 8 && VA * VB <= 32, "small-channel weight gradient: CI CO <= 512");
   constexpr int U = (VA * VB >= 16) ? 1 : 2;          // groups of 16 pairs requested per trip
@@ -1585,7 +1585,7 @@ __global__ void __launch_bounds__(256) bwd_weight_small_kernel(const float* __re
     if (e < E) {
       const int tile = e >> 4, l = (e >> 2) & 3, r = e & 3;
       const int t = tile / VB, u = tile - t * VB;
-      (void)d_rows_on_lanes;   // D[row][col] of a 4x4 block: row = accumulator register, col = lane % 4 (confirmed on gfx950, r4m)
+      // D[row][col] of a 4x4 block: row = accumulator register, col = lane % 4 (confirmed on gfx950, r4m)
       dst[(VA * r + t) * CO + VB * l + u] = tot[j];
     }
   }
@@ -1777,13 +1777,10 @@ int g_conv_v4 = 0;   // off: inside the train step (weight-gradient stream conte
 // VGPRs; forcing 6 waves spills), but the 32-channel shapes keep all eight and lose as well: the 32 DPP / select operations per
 // side offset sit between the loads' arrival and the MFMAs.  Fewer gathered rows alone do not buy time.
 int g_conv_dxs = 0;
-// vc_debug_set f32_split: 0 = fp32 products on v_mfma_f32_16x16x4_f32 (exact); 1 = on the bf16 matrix cores as six split terms (split3)
-// for the shapes f32_split_pays names; 2 = for every shape with 16-multiple channel counts
+// vc_debug_set f32_split: 1 (default) = fp32 products of the gather-GEMM on the bf16 matrix cores as six split terms (split3) for every
+// shape whose channel counts are multiples of 16 (measured per layer: never slower, profiles/r04_split_products.md);
+// 0 = v_mfma_f32_16x16x4_f32 (exact products, the round 1-3 kernels)
 int g_f32_split = 1;
-static inline bool f32_split_pays(int ck, int cn, bool bwd) {
-  (void)ck; (void)cn; (void)bwd;
-  return true;
-}
 int g_conv_v5 = 0;             // developer: loader / MFMA wave-role kernel (plain launches with a weight image)
 int g_conv_v4_pf = 1;          // developer: gather prefetch distance of the v4 kernel (1 | 2 | 4), plain launches with an image only
 int g_conv_v4_ablate = 0;      // developer ablations of the v4 kernel (see its ABL parameter); results are wrong when set
@@ -2104,7 +2101,7 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
     // fp32 products as six bf16 MFMA terms (vc_debug_set f32_split; see split3): the same block shapes, epilogues and weight image as
     // the fp32 kernels below, operand type X6
     if constexpr (CK % 16 == 0 && CN % 16 == 0) {
-      if (g_f32_split && ot == VC_OPERAND_F32 && wpk != nullptr && f32_split_pays(CK, CN, BWD)) {
+      if (g_f32_split && ot == VC_OPERAND_F32 && wpk != nullptr) {
         const bool w8 = conv_block_waves(CK, CN, BWD, n_out, order != nullptr) == 8 && epi_kind != VC_EPI_AFFINE;
         size_t ldsx = (size_t)2 * NCH * NT * 64 * V * 6 + (size_t)(kv + 1) * (w8 ? 128 : 64) * sizeof(int) + 16;
         const dim3 gridx((unsigned)cdiv(n_out, w8 ? 128 : 64));
@@ -2367,7 +2364,7 @@ static int launch_bw(const float* x, const float* dy, const int32_t* tbl, int64_
     // 4x4x1 form runs below the fp32 matrix-pipe rate of the 16x16x4 form here.  Default: C_in C_out <= 64 only; 3 = every served shape.
     const bool f32_operands = ot == VC_OPERAND_F32 || CI < 16 || CO < 16;   // reduced operands apply from 16 channels up only
     if (f32_operands && (g_bw_small == 3 || (g_bw_small == 1 && CI * CO <= 64))) {
-      hipLaunchKernelGGL((bwd_weight_small_kernel<CI, CO>), dim3(nblocks), dim3(256), 0, st, VC_ARGS, 0);
+      hipLaunchKernelGGL((bwd_weight_small_kernel<CI, CO>), dim3(nblocks), dim3(256), 0, st, VC_ARGS);
       launched = true;
     }
   }
