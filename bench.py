@@ -224,6 +224,8 @@ def run_infer(args, model, batch, device, rank, world):
     # forward-only step (measured 1.90 vs 1.76 ms at bs 4), which they are not of the 5.4 ms train step
     be = ops.get_backend()
     tdir, tck, tcn = args.trace.split(",")
+    if tdir == "dw":      # the train default; a forward-only loop has no weight gradient: the round 1-4 traced kernel
+        tdir, tck, tcn = "fwd", "64", "32"
     be.trace_begin(tdir, int(tck), int(tcn))
     for _ in range(10):
         step()
@@ -284,13 +286,22 @@ def _emit(res):
     print(json.dumps(res), flush=True)
 
 
+def _kernel_name(tdir, tck, tcn, windowed=False):
+    if tdir == "dw":
+        return f"bwd_weight_kernel<CI={tck},CO={tcn}>"
+    if windowed:
+        return f"gather_gemm_v3_kernel<CK={tck},CN={tcn},BWD={'true' if tdir == 'bwd' else 'false'}> (LDS row windows)"
+    return f"gather_gemm_v2_kernel<CK={tck},CN={tcn},BWD={'true' if tdir == 'bwd' else 'false'},RT=1>"
+
+
 def _pmc_traffic(tdir, tck, tcn):
     """HBM bytes per launch of the traced kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected in separate
     runs of this same command and corrected as MI355X_MICROARCH.md prescribes; summary committed under profiles/).
     PMC counters cannot be read from inside the process: the number is the one of the newest committed profile of this command,
     and the JSON line says so (`traffic_source`); (None, None) if absent."""
-    for tag in ("r04", "r03", "r02"):
-        rel = os.path.join("profiles", f"{tag}_traffic_gather_gemm_{tck}_{tcn}_{tdir}.json")
+    stem = f"bwd_weight_{tck}_{tcn}" if tdir == "dw" else f"gather_gemm_{tck}_{tcn}_{tdir}"
+    for tag in ("r05", "r04", "r03", "r02"):
+        rel = os.path.join("profiles", f"{tag}_traffic_{stem}.json")
         try:
             with open(os.path.join(ROOT, rel)) as f:
                 return float(json.load(f)["hbm_bytes_per_launch_corrected"]), rel + " (rocprofv3 --pmc passes of this command, not this run)"
@@ -312,9 +323,7 @@ def _traced_roofline(trace, args, tdir, tck, tcn, pmc):
     traffic, traffic_src = _pmc_traffic(tdir, tck, tcn) if (pmc and args.operand == "f32") else (None, None)
     return {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
             "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": (f"gather_gemm_v3_kernel<CK={tck},CN={tcn},BWD={'true' if tdir == 'bwd' else 'false'}> (LDS row windows)"
-                       if all(e["windowed"] for e in trace) else
-                       f"gather_gemm_v2_kernel<CK={tck},CN={tcn},BWD={'true' if tdir == 'bwd' else 'false'},RT=1>"),
+            "kernel": _kernel_name(tdir, tck, tcn, all(e["windowed"] for e in trace)),
             "launches": n_launch, "avg_us": round(t_ms / n_launch * 1e3, 2),
             "algorithmic_gflop_per_launch": round(flops / n_launch / 1e9, 4),
             "algorithmic_mb_per_launch": round(byts / n_launch / 1e6, 3),
@@ -337,7 +346,10 @@ def main(argv=None, plumbing=False):
                     help="MFMA operand type of the conv kernels.  f32 (default) is the headline / parity configuration; f16 | "
                          "bf16 = BASELINE configs[4] 'fp16 MFMA contraction' experiment (fp32 tensors, fp32 accumulate), "
                          "reported with its own dtype and a 16-bit MFMA peak, never as the headline number")
-    ap.add_argument("--trace", default="fwd,64,32", help="gather-GEMM instantiation timed for the roofline: dir,CK,CN")
+    ap.add_argument("--trace", default="dw,32,32",
+                    help="conv kernel instantiation bracketed by HIP events INSIDE the timed steps for the roofline: dir,CK,CN with dir = "
+                         "fwd | bwd (gather-GEMM) | dw (weight gradient).  Default: the kernel with the largest share of the step's conv "
+                         "kernel time (checked against the per-shape table of the family steps: `roofline.kernel_is_dominant`)")
     ap.add_argument("--model", default="L", choices=["L", "8x"],
                     help="L = VirConvL8x, BASELINE configs[2] (default, the headline); 8x = VirConv8x (LiDAR + virtual-point "
                          "streams), the backbone of BASELINE configs[3], bs 2 per GPU unless --batch-size is given")
@@ -500,7 +512,7 @@ def main(argv=None, plumbing=False):
     # 3-9 us tail that replaces two launches).  For a like-for-like number of the GEMM itself: the same kernel over a few more
     # steps with the sums left to the BatchNorm kernels (vc_debug_set conv_bn_finish = 0), outside the timed region.
     plain = None
-    if args.family_steps > 0 and args.operand == "f32" and can_trace:
+    if args.family_steps > 0 and args.operand == "f32" and can_trace and tdir != "dw":
         assert be.lib.vc_debug_set(b"conv_bn_finish", 0) == 0
         if rank == 0:
             be.trace_begin(tdir, int(tck), int(tcn))
@@ -512,25 +524,45 @@ def main(argv=None, plumbing=False):
         assert be.lib.vc_debug_set(b"conv_bn_finish", 1) == 0
     parallel.barrier()
 
+    # Host side of a step, for the record next to ms_per_step (which side bounds the step?): K steps ENQUEUED from an idle,
+    # synchronised GPU without any synchronisation, wall time / K.  The host may run up to two forwards ahead of the GPU
+    # (backbone._bound_run_ahead), so over 5 steps it is never throttled; the one count read per step (vc_plan_wait) is part of it.
+    host_ms = None
+    if not plumbing:
+        sync()
+        k_host = 5
+        t0 = time.perf_counter()
+        for _ in range(k_host):
+            train_step(ddp, optimizer, batch, lw, grad_sync, raw)
+        host_ms = (time.perf_counter() - t0) / k_host * 1e3
+        sync()
+    parallel.barrier()
+
     if rank != 0:
         return None
     frames = bs * world * args.steps
-    roof = _traced_roofline(trace, args, tdir, tck, tcn, pmc=True)
-    if roof is not None:
-        peak = roof["peak"]
-        if _f32_split(be) and args.operand == "f32":
-            roof["products_note"] = ("algorithmic fp32 flops against the fp32 MFMA peak (157.3 TF) as in rounds 1-3; the products of this "
-                                     "kernel run as six v_mfma_f32_16x16x32_bf16 terms (2.5 PF dense / 6 = 417 TF fp32-equivalent); "
-                                     "`exact_f32_mfma` has the step on v_mfma_f32_16x16x4_f32")
-        roof["kernel_note"] = ("this launch also finishes the BatchNorm statistics of its output (conv_finish_tail: a 3-9 us tail "
-                               "instead of two more launches): `frac` prices its whole duration against the GEMM flops alone")
-        if plain:
-            pr = _traced_roofline(plain, args, tdir, tck, tcn, pmc=False)
-            if pr is not None:
-                roof["frac_gemm_only"] = pr["frac"]
-                roof["avg_us_gemm_only"] = pr["avg_us"]
-                roof["gemm_only_note"] = (f"{args.family_steps} extra steps after the timed region with vc_debug_set conv_bn_finish = 0 "
-                                          "(the same kernel without the tail; the step is then ~0.1 ms slower)")
+    split_on = bool(_f32_split(be)) and args.operand == "f32"
+    issue_peak = MFMA_16BIT_PEAK_TFLOPS / 6.0   # six bf16 x bf16 terms per fp32 product on v_mfma_f32_16x16x32_bf16
+    traced = _traced_roofline(trace, args, tdir, tck, tcn, pmc=True)
+    roof = None
+    if traced is not None:
+        peak = traced["peak"]
+        uses_split = split_on and int(tck) >= 16 and int(tcn) >= 16     # C < 16 layers stay on v_mfma_f32_16x16x4_f32
+        # FLAT keys first (the driver's record keeps the leading scalar keys of this object): the kernel measured inside the timed
+        # steps, both fractions, the step-level fraction; tables and notes behind them
+        roof = {"bound": "mfma", "achieved": traced["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": traced["frac"],
+                "traffic": traced["traffic"], "kernel": traced["kernel"],
+                "frac_issue_pipe": round(traced["achieved"] / issue_peak, 4) if uses_split else traced["frac"],
+                "issue_pipe_peak": round(issue_peak, 1) if uses_split else peak,
+                "step_frac": None, "family_frac": None, "kernel_is_dominant": None, "kernel_ms_per_step": round(
+                    sum(e["ms"] for e in trace) / args.steps, 3), "launches_per_step": round(len(trace) / args.steps, 1),
+                "avg_us": traced["avg_us"], "algorithmic_gflop_per_launch": traced["algorithmic_gflop_per_launch"],
+                "algorithmic_mb_per_launch": traced["algorithmic_mb_per_launch"], "traffic_source": traced["traffic_source"],
+                "measured": "HIP events around every launch of this kernel inside the K timed steps, on its launch stream",
+                "frac_note": ("frac = algorithmic fp32 flops / time / 157.3 TF (v_mfma_f32_16x16x4_f32, the path's arithmetic type); "
+                              "frac_issue_pipe = the same / (2500 / 6) TF: this kernel issues each fp32 product as six "
+                              "v_mfma_f32_16x16x32_bf16 terms" if uses_split else
+                              "frac = algorithmic flops / time / the dense MFMA peak of the operand type")}
         if fam:
             # family: all conv kernels of the step (forward, backward-input, weight gradient) -- algorithmic flops / kernel time;
             # step: the same flops over the WALL time of a step (everything else -- BatchNorm, rulebooks, optimizer -- counts as loss)
@@ -545,37 +577,42 @@ def main(argv=None, plumbing=False):
             # on a second stream: their bracketed durations inflate each other, the union does not double-count)
             iv = sorted((e["t0_ms"], e["t0_ms"] + e["ms"]) for e in fam)
             union, cur_a, cur_b = 0.0, iv[0][0], iv[0][1]
-            for a, b in iv[1:]:
-                if a > cur_b:
+            for a_, b_ in iv[1:]:
+                if a_ > cur_b:
                     union += cur_b - cur_a
-                    cur_a, cur_b = a, b
+                    cur_a, cur_b = a_, b_
                 else:
-                    cur_b = max(cur_b, b)
+                    cur_b = max(cur_b, b_)
             union += cur_b - cur_a
-            # the kernel shape with the largest share of the step's conv kernel time, so that the traced kernel's `frac` cannot be
-            # read as "the step runs at that fraction" 
+            # per kernel shape: ms per step, launches, fraction -- the row with the most time is the dominant kernel
             by_shape = {}
             for e in fam:
-                kname = (f"bwd_weight_kernel<{e['ck']},{e['cn']}>" if e["dir"] == "dw" else
-                         f"gather_gemm_v2_kernel<{e['ck']},{e['cn']},{'bwd' if e['dir'] == 'bwd' else 'fwd'}>")
-                d = by_shape.setdefault(kname, [0.0, 0.0, 0])
+                d = by_shape.setdefault((e["dir"], e["ck"], e["cn"]), [0.0, 0.0, 0])
                 d[0] += e["flops"]; d[1] += e["ms"]; d[2] += 1
-            dom_name, dom = max(by_shape.items(), key=lambda kv_: kv_[1][1])
-            roof["dominant_by_time"] = {"kernel": dom_name, "ms_per_step": round(dom[1] / k, 3), "launches_per_step": round(dom[2] / k, 1),
-                                        "frac": round(dom[0] / (dom[1] * 1e-3) / 1e12 / peak, 4),
-                                        "note": "largest ms/step row of the conv family (in-step durations: the weight gradients and the "
-                                                "backward-input convs share the chip, so each is slower than stand-alone)"}
+            (ddir, dck, dcn), dom = max(by_shape.items(), key=lambda kv_: kv_[1][1])
+            roof["kernel_is_dominant"] = (ddir, str(dck), str(dcn)) == (tdir, str(tck), str(tcn))
+            roof["step_frac"] = round(f_flops / k / (dt / args.steps) / 1e12 / peak, 4)
+            roof["family_frac"] = round(f_flops / (union * 1e-3) / 1e12 / peak, 4)
             roof.update({
-                "family_frac": round(f_flops / (union * 1e-3) / 1e12 / peak, 4),
                 "family_tflops": round(f_flops / (union * 1e-3) / 1e12, 2),
                 "family_busy_ms_per_step": round(union / k, 3),
                 "family_frac_of_summed_kernel_time": round(f_flops / (f_ms * 1e-3) / 1e12 / peak, 4),
-                "family_kernel_ms_per_step": {d: round(v[1] / k, 3) for d, v in per_dir.items()},
                 "family_gflop_per_step": round(f_flops / k / 1e9, 2),
-                "step_frac": round(f_flops / k / (dt / args.steps) / 1e12 / peak, 4),
+                "dominant_by_time": {"kernel": _kernel_name(ddir, dck, dcn), "ms_per_step": round(dom[1] / k, 3),
+                                     "launches_per_step": round(dom[2] / k, 1), "frac": round(dom[0] / (dom[1] * 1e-3) / 1e12 / peak, 4)},
+                "family_kernel_ms_per_step": {d: round(v[1] / k, 3) for d, v in per_dir.items()},
+                "per_shape_ms_per_step": {f"{d_}<{c1},{c2}>": round(v[1] / k, 3) for (d_, c1, c2), v in
+                                          sorted(by_shape.items(), key=lambda kv_: -kv_[1][1])[:8]},
                 "family_note": f"{k} extra steps after the timed region, HIP events around every conv launch on its own stream; "
                                "family_frac = algorithmic flops of all conv kernels (forward, backward-input, weight gradient) / "
                                "wall time with at least one of them running; step_frac = the same flops / ms_per_step"})
+        if plain and tdir != "dw":
+            pr = _traced_roofline(plain, args, tdir, tck, tcn, pmc=False)
+            if pr is not None:
+                roof["frac_gemm_only"] = pr["frac"]
+                roof["avg_us_gemm_only"] = pr["avg_us"]
+                roof["gemm_only_note"] = (f"{args.family_steps} extra steps after the timed region with vc_debug_set conv_bn_finish = 0 "
+                                          "(the same kernel without its BatchNorm-statistics tail)")
     if args.model == "8x":
         metric = "KITTI frames/sec (fwd+bwd) VirConv8x backbone (VirConv-T/S)"
         workload = ("BASELINE configs[3] backbone: VirConv8x (LiDAR stream + virtual-point MM stream) train step (fwd+bwd+Adam), "
@@ -591,6 +628,7 @@ def main(argv=None, plumbing=False):
     res = {
         "metric": metric, "value": round(frames / dt, 3), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "host_enqueue_ms_per_step": None if host_ms is None else round(host_ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": _dtype(be, args.operand),
         "data": "synthetic",

@@ -461,8 +461,8 @@ int vc_pass_backward(const vc_pass_program* prog, const void* fwd_arena, size_t 
                      void* arena, size_t arena_bytes, void* side_stream /* nullable */, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ kernel timing
- * Brackets every launch of ONE gather-GEMM instantiation (direction: 0 forward, 1 backward-input; ck, cn = its gathered /
- * produced channel counts) with HIP events on the launch stream, inside whatever call issues it (vc_conv_*,
+ * Brackets every launch of ONE conv kernel instantiation (direction: 0 forward, 1 backward-input gather-GEMM with ck, cn = its
+ * gathered / produced channel counts; 2 the weight gradient with ck = cin, cn = cout) with HIP events on the launch stream, inside whatever call issues it (vc_conv_*,
  * vc_post_act_block_*, vc_pass_*), and counts the table's active pairs on the device right after it (outside the
  * bracket; the first 16 records of a one-kernel trace (128 with direction -1) count exactly, later ones take the pairs-per-row ratio of the last counted launch of the
  * same shape -- the count is measurement work inside the timed step).  bench.py's roofline figure comes from here.
@@ -585,6 +585,17 @@ typedef struct vc_plan_desc {
   double discard_rate;
   int32_t need_grad;                        /* also build what only a backward pass needs: group plans, backward row orders */
   int32_t row_order_fwd;                    /* 1: also a row order for the strided convs' FORWARD tables */
+  int32_t defer_early_tables;               /* 1: vc_plan_begin builds NO table (also not those of a first block whose row count is the
+                                               caller's): vc_plan_finish builds them all.  For callers that begin several plans -- or one
+                                               plan a step early -- before finishing any */
+  int32_t reserved_;
+  void* tables_wait_event;                  /* hipEvent_t or NULL: the stream waits for it after the coordinate / count chain and
+                                               BEFORE its first table kernel (projection, pair tables): vc_plan_begin waits in front of the
+                                               early tables, vc_plan_finish at its start (the value may differ between the two calls).
+                                               The caller records it behind the previous step's backward pass: tables are never built
+                                               beside one (LOG.md A.15) */
+  void* debug_buf; int64_t debug_bytes;     /* developer diagnostics (tools/det_check.py) or NULL: a golden copy of the projection
+                                               parameters + a log of every projection thread that read something else */
 } vc_plan_desc;
 typedef struct vc_plan_view { int32_t arena /* 0: arena_a, 1: arena_b, -1: absent */; int32_t cols; int64_t offset /* bytes */; int64_t rows; } vc_plan_view;
 typedef struct vc_plan_table_out {

@@ -1,0 +1,68 @@
+"""Worker of tests/test_rccl_gpu.py: ONE rank, RCCL ('nccl') process group (VIRCONV_FORCE_DDP=1), the real backbone on the GPU.
+Gradients of (a) the plain model, (b) the model + parallel.FlatGradAllReduce (the exchange bench.py uses), (c) the model under stock
+DistributedDataParallel (tools/train.py:141) must agree bit for bit -- a one-rank mean is the identity -- and the process must
+leave without the RCCL watchdog tripping over HIP's teardown."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["VIRCONV_FORCE_DDP"] = "1"
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", sys.argv[1] if len(sys.argv) > 1 else "29511")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import bench  # noqa: E402
+from virconv_amd import parallel, synth  # noqa: E402
+from virconv_amd.backbone import VirConvL8x  # noqa: E402
+
+rank, local_rank, world = parallel.init_distributed()
+assert (rank, world) == (0, 1) and dist.is_initialized() and dist.get_backend() == "nccl", (rank, world, dist.is_initialized())
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+batch = bench.make_batch([0, 1], dev, training=True)
+lw = bench.make_loss_weights(dev)
+
+
+def grads_of(mode):
+    torch.manual_seed(0)
+    model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).to(dev).train()
+    wrapped, sync = model, None
+    if mode == "flat":
+        sync = parallel.FlatGradAllReduce(model)
+        assert sync.active
+    elif mode == "ddp":
+        wrapped = parallel.wrap_ddp(model, dev)
+        assert isinstance(wrapped, torch.nn.parallel.DistributedDataParallel)
+    torch.manual_seed(77)                      # the layer-discard seeds
+    bd = dict(batch)
+    bd["voxel_features"] = batch["voxel_features"].clone()
+    loss = bench.synthetic_loss(wrapped(bd), lw)
+    loss.backward()
+    if sync is not None:
+        sync()
+    torch.cuda.synchronize()
+    return float(loss), [p.grad.detach().clone() for p in model.parameters()]
+
+
+l0, g0 = grads_of("plain")
+for mode in ("flat", "ddp"):
+    l1, g1 = grads_of(mode)
+    assert l1 == l0, (mode, l0, l1)
+    bad = [i for i, (a, b) in enumerate(zip(g0, g1)) if not torch.equal(a, b)]
+    assert not bad, f"{mode}: gradients of parameters {bad} differ from the plain run"
+    print(f"{mode}: loss {l1:.6f}, {len(g1)} gradients bit-identical to the run without a process group", flush=True)
+# one full train step of the benchmark with the collective in it
+torch.manual_seed(0)
+model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).to(dev).train()
+opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, fused=True)
+sync = parallel.FlatGradAllReduce(model)
+for _ in range(3):
+    loss = bench.train_step(model, opt, batch, lw, sync)
+torch.cuda.synchronize()
+assert torch.isfinite(loss)
+parallel.shutdown()
+assert not dist.is_initialized()
+print("RCCL_WORLD1_OK", flush=True)

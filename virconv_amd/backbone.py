@@ -266,7 +266,7 @@ def _bound_run_ahead(device, main):
     2.8-5.2 ms/frame depending on which side of that edge the host happens to sit.  Every forward marks the main stream on
     entry (= "everything up to the previous frame is enqueued before this point") and waits for the PREVIOUS forward's mark:
     at most two frames are ever in flight (plan of frame f over the feature pass of frame f - 1).  In training the mark is
-    a step old and long complete."""
+    a step old and long complete.  -> this forward's mark."""
     key = torch.device(device).index
     prev = _FRAME_MARKS.get(key)
     mark = torch.cuda.Event()
@@ -274,26 +274,54 @@ def _bound_run_ahead(device, main):
     _FRAME_MARKS[key] = mark
     if prev is not None:
         prev.synchronize()
+    return mark
+
+
+# LOG.md A.15: with the TABLES of a plan (pixel projection, pair tables) built on the plan stream while a backward pass was still
+# running on the main / weight-gradient streams, runs of rows of `uv` came out wrong in 24 of 32 four-step runs; the cause is
+# narrowed down in LOG.md A.17 but whatever it is, tables and backward passes do not share the chip any more:
+#   1 (default): the plan stream waits, between the coordinate / count chain and its first table kernel, for an event recorded on
+#       the main stream at the start of this forward (behind the previous step's backward pass, clip and optimizer).  The chain and
+#       the counts' trip to the host still overlap the previous step; nothing the host waits for is held back.
+#   2: the whole plan waits for that event (serial; A/B only).        0: no guard (the round-4 loop; A/B and tools/det_check.py).
+# A plan is guarded when it is built with gradients enabled or when a backward pass was enqueued since the last guarded plan.
+PLAN_GUARD = int(os.environ.get("VIRCONV_PLAN_GUARD", "1"))
+_GUARD_SEEN = {}          # device index -> ops.BACKWARD_LAUNCHES at the last guarded plan
+
+
+def _guard_wanted(device) -> bool:
+    if not PLAN_GUARD:
+        return False
+    key = torch.device(device).index
+    seen = _GUARD_SEEN.get(key, 0)
+    _GUARD_SEEN[key] = ops.BACKWARD_LAUNCHES
+    return torch.is_grad_enabled() or ops.BACKWARD_LAUNCHES != seen
 
 
 class _PlanScope:
     """Run the geometry plan on the high-priority side stream (see VirConvL8x.build_plan) and hand the result to the main
-    stream.  CPU tensors: a no-op scope."""
+    stream.  CPU tensors: a no-op scope.  `guard`: the event the plan's TABLE kernels wait for (see PLAN_GUARD), or None."""
 
     def __init__(self, ref_tensor, batch_dict, ahead=False):
         self.on_gpu = ref_tensor.is_cuda
+        self.guard = None
         # closures that enqueue what only backward passes read (native_plan.build_chain): run AFTER the event the forward waits for
         self.deferred = [] if (ref_tensor.is_cuda and PLAN_DEFER_BACKWARD) else None
         if self.on_gpu:
             self.main = torch.cuda.current_stream()
+            mark = None
             if not ahead:   # (a plan begun a step ahead is bounded by the training loop itself)
-                _bound_run_ahead(ref_tensor.device, self.main)
+                mark = _bound_run_ahead(ref_tensor.device, self.main)
             self.side = _plan_stream(ref_tensor.device)
+            if not ahead and _guard_wanted(ref_tensor.device):   # (a plan begun ahead builds no table: its finish names the guard)
+                self.guard = mark
             ready = batch_dict.get("inputs_ready_event")
             if ready is not None:
                 self.side.wait_event(ready)  # inputs were produced before this event: no need to wait for the stream tail
             else:
                 self.side.wait_stream(self.main)
+            if self.guard is not None and PLAN_GUARD >= 2:
+                self.side.wait_event(self.guard)
             self.ctx = torch.cuda.stream(self.side)
         else:
             import contextlib
@@ -305,6 +333,11 @@ class _PlanScope:
 
     def __exit__(self, *exc):
         return self.ctx.__exit__(*exc)
+
+    def guard_tables(self):
+        """Python-composed plans (the fallback of native_plan): everything enqueued on the plan stream from here on waits for the guard."""
+        if self.on_gpu and self.guard is not None:
+            self.side.wait_event(self.guard)
 
     def publish(self, plan):
         if self.on_gpu:
@@ -470,9 +503,10 @@ class VirConvL8x(nn.Module):
                 # the whole plan as three native calls around ONE count read (csrc/plan.hip)
                 stages, rb_out, _, _, arenas = native_plan.build(self, blocks, co, idx, batch_size, calib, trans_param, tags,
                                                                  self.layer_discard_rate, batch_dict, NRConvBlock.IMAGE_SHAPE,
-                                                                 deferred=scope.deferred)
+                                                                 deferred=scope.deferred, guard=scope.guard)
                 plan = {"in_indices": idx, "stages": stages, "conv_out": {co.indice_key: rb_out}, "_arenas": arenas + [idx]}
             else:
+                scope.guard_tables()
                 stages, in_idx, shape, begun = _plan_nrconv_chain(blocks, idx, list(self.sparse_shape), batch_size, calib,
                                                                   trans_param, tags, self.layer_discard_rate, batch_dict, tail=co)
                 rb_out = ops.finish_sparse_rulebook(begun)
@@ -522,7 +556,7 @@ class VirConvL8x(nn.Module):
                 tags = [f"x_conv{bi + 1}{rid}" if (bi < 3 and active) else None for bi in range(4)]
                 cp = native_plan.ChainPlan(self, native_plan.nrconv_kind(blocks, co, None), native_plan.nrconv_blocks(blocks), co, idx,
                                            batch_size, calib, trans_param, tags, self.layer_discard_rate, batch_dict,
-                                           NRConvBlock.IMAGE_SHAPE, None, scope.deferred)
+                                           NRConvBlock.IMAGE_SHAPE, None, scope.deferred, None, True)
                 entries[rid] = (coords, coords._version, idx, cp)
         self._ahead.append({"entries": entries, "scope": scope, "mode": self._ahead_mode(), "blocks": blocks, "fwd_ready": None,
                             "born": self._fwd_count})
@@ -531,10 +565,16 @@ class VirConvL8x(nn.Module):
 
     @staticmethod
     def _finish_ahead(a) -> None:
+        """Second half of a plan begun ahead: EVERY table, at the start of the step that uses it, behind the guard event recorded now on
+        the main stream (i.e. behind the previous step's backward pass; PLAN_GUARD)."""
         if a["fwd_ready"] is None:
+            guard = None
+            if _guard_wanted(a["scope"].side.device):
+                guard = torch.cuda.Event()
+                guard.record(torch.cuda.current_stream())
             with torch.cuda.stream(a["scope"].side):
                 for _, _, _, cp in a["entries"].values():
-                    cp.finish()
+                    cp.finish(guard)
                 a["fwd_ready"] = torch.cuda.Event()
                 a["fwd_ready"].record()
 
@@ -588,6 +628,8 @@ class VirConvL8x(nn.Module):
                 plan = self._take_ahead(coords, rid)
                 if plan is None:
                     plan = self.build_plan(coords, batch_size, calib, trans_param, batch_dict, rid)
+                if "plan_observer" in batch_dict:      # tests: hand the step's geometry plan out (tests/test_plan_stress_gpu.py)
+                    batch_dict["plan_observer"](rid, plan)
                 native = feature_pass.run(self, feats, plan) if feature_pass.usable(self, feats, plan) else None
                 if native is not None:
                     # the whole chain below as ONE native call per direction (virconv_amd/feature_pass.py): same kernels, same order
@@ -728,24 +770,34 @@ class VirConv8x(nn.Module):
 
     # ---- geometry plan (same idea as VirConvL8x.build_plan): every rulebook of both streams, the eval-time slab splits and
     # the discard permutations are functions of the coordinates only and are built first, on the plan stream
-    def _plan_lidar(self, idx, shape, batch_size, batch_dict=None, arenas=None, deferred=None):
-        """{indice_key: Rulebook} of the LiDAR stream + the coordinates of x2, x3, x4 and the output.  One native chain plan (three
-        C calls, one count read: native_plan.build_chain) when available, operator by operator otherwise."""
+    def _lidar_chain(self):
         first, co = self.conv_input[0], self.conv_out[0]
         stages = (self.conv2, self.conv3, self.conv4)
-        if batch_dict is not None and list(shape) == list(self.sparse_shape) and native_plan.usable(idx):
-            chain = [native_plan.ChainBlock(None, first)] + [native_plan.ChainBlock(seq[0][0], seq[1][0]) for seq in stages]
-            res, rb_tail, _, _, ar = native_plan.build_chain(self, "8x-lidar", chain, co, idx, batch_size, None, None, [None] * 4, 0.0,
-                                                             batch_dict, NRConvBlock.IMAGE_SHAPE, deferred=deferred)
-            if arenas is not None:
-                arenas.extend(ar)
-            rbs, coords = {first.indice_key: res[0]["subm3d"]}, {}
-            for name, seq, r in zip(("x2", "x3", "x4"), stages, res[1:]):
-                rbs[seq[0][0].indice_key], rbs[seq[1][0].indice_key] = r["down"], r["subm3d"]
-                coords[name] = (r["out_indices"], list(r["out_shape"]))
-            rbs[co.indice_key] = rb_tail
-            coords["out"] = (rb_tail.out_indices, list(rb_tail.out_shape))
-            return rbs, coords
+        chain = [native_plan.ChainBlock(None, first)] + [native_plan.ChainBlock(seq[0][0], seq[1][0]) for seq in stages]
+        return first, co, stages, chain
+
+    def _begin_lidar(self, idx, batch_size, batch_dict, deferred):
+        """First half of the LiDAR stream's native chain plan: coordinates and row counts, no table (native_plan.ChainPlan)."""
+        _, co, _, chain = self._lidar_chain()
+        return native_plan.ChainPlan(self, "8x-lidar", chain, co, idx, batch_size, None, None, [None] * 4, 0.0, batch_dict,
+                                     NRConvBlock.IMAGE_SHAPE, None, deferred, None, True)
+
+    def _finish_lidar(self, cp, guard, arenas):
+        first, co, stages, _ = self._lidar_chain()
+        res, rb_tail, _, _, ar = cp.finish(guard)
+        arenas.extend(ar)
+        rbs, coords = {first.indice_key: res[0]["subm3d"]}, {}
+        for name, seq, r in zip(("x2", "x3", "x4"), stages, res[1:]):
+            rbs[seq[0][0].indice_key], rbs[seq[1][0].indice_key] = r["down"], r["subm3d"]
+            coords[name] = (r["out_indices"], list(r["out_shape"]))
+        rbs[co.indice_key] = rb_tail
+        coords["out"] = (rb_tail.out_indices, list(rb_tail.out_shape))
+        return rbs, coords
+
+    def _plan_lidar(self, idx, shape, batch_size):
+        """{indice_key: Rulebook} of the LiDAR stream + the coordinates of x2, x3, x4 and the output, operator by operator (the eval
+        path over the x-concatenated tensor, and the fallback of the native chain plan)."""
+        first, co = self.conv_input[0], self.conv_out[0]
         rbs = {}
         rbs[first.indice_key] = ops.build_subm_rulebook(idx, shape, first.kernel_size, first.dilation, False)
         cur, cur_shape, coords = idx, list(shape), {}
@@ -775,18 +827,52 @@ class VirConv8x(nn.Module):
     def build_plan(self, batch_dict, rids, batch_size, calib):
         ref = batch_dict["voxel_coords"]
         plan = {"lidar": {}, "split": {}, "mm": {}}
-        arenas, native_only = [], True     # every structure of a native chain plan is a view of one of its two arenas
+        arenas = []     # every structure of a native chain plan is a view of one of its two arenas
+        blocks = [(self.vir_conv1, 1), (self.vir_conv2, 2), (self.vir_conv3, 4), (self.vir_conv4, 8)]
+        active = self._discard_active()
+
+        def mm_inputs(i, rid):
+            trans_param = batch_dict.get("aug_param")
+            if "transform_param" in batch_dict:
+                trans_param = batch_dict["transform_param"][:, i, :]
+            tags = [f"mm_x_conv{bi + 1}{rid}" if (bi < 3 and active) else None for bi in range(4)]
+            return trans_param, tags
+
         with _PlanScope(ref, batch_dict) as scope:
+            idx_l = {rid: batch_dict["voxel_coords" + rid].int() for rid in rids} if self.training else {}
+            idx_m = {rid: batch_dict["voxel_coords_mm" + rid].int() for rid in rids} if self.mm else {}
+            if (self.training and all(native_plan.usable(v) for v in idx_l.values())
+                    and all(native_plan.usable(v, blocks) for v in idx_m.values())):
+                # every chain natively, in two sweeps: first the coordinate / count chain of EVERY plan (vc_plan_begin, no tables), then
+                # -- the counts have arrived meanwhile -- every plan's tables behind the guard event (PLAN_GUARD: a table kernel
+                # never runs beside the previous step's backward pass, and no count read waits behind the guard)
+                begun_l = [(rid, self._begin_lidar(idx_l[rid], batch_size, batch_dict, scope.deferred)) for rid in rids]
+                begun_m = []
+                for i, rid in enumerate(rids if self.mm else []):
+                    trans_param, tags = mm_inputs(i, rid)
+                    cp = native_plan.begin(self, blocks, None, idx_m[rid], batch_size, calib, trans_param, tags, self.layer_discard_rate,
+                                           batch_dict, NRConvBlock.IMAGE_SHAPE,
+                                           input_discard_tag=(f"mm_input{rid}" if active else None), deferred=scope.deferred)
+                    begun_m.append((rid, cp, trans_param))
+                for rid, cp in begun_l:
+                    rbs, _ = self._finish_lidar(cp, scope.guard, arenas)
+                    arenas.append(idx_l[rid])
+                    plan["lidar"][rid] = (idx_l[rid], rbs)
+                for rid, cp, trans_param in begun_m:
+                    stages, _, keep0, kept0, ar = native_plan.finish_nrconv(cp, blocks, scope.guard)
+                    arenas.extend(ar)
+                    arenas.append(idx_m[rid])
+                    plan["mm"][rid] = {"keep0": keep0, "in_indices": kept0 if active else idx_m[rid], "stages": stages,
+                                       "trans_param": trans_param}
+                plan["_arenas"] = arenas
+                return scope.publish(plan)
+            # operator-by-operator plans (the eval path over the x-concatenated tensor; empty / CPU tensors): the whole plan waits
+            scope.guard_tables()
             if self.training:
                 for rid in rids:
-                    idx = batch_dict["voxel_coords" + rid].int()
-                    n0 = len(arenas)
-                    rbs, _ = self._plan_lidar(idx, self.sparse_shape, batch_size, batch_dict, arenas, scope.deferred)
-                    native_only = native_only and len(arenas) > n0
-                    arenas.append(idx)
-                    plan["lidar"][rid] = (idx, rbs)
+                    rbs, _ = self._plan_lidar(idx_l[rid], self.sparse_shape, batch_size)
+                    plan["lidar"][rid] = (idx_l[rid], rbs)
             else:
-                native_only = False
                 coords = []
                 for i, rid in enumerate(rids):
                     c = batch_dict["voxel_coords" + rid].clone()
@@ -799,26 +885,18 @@ class VirConv8x(nn.Module):
                 for i, rid in enumerate(rids):
                     plan["split"][rid] = {k: self._plan_split(co[k][0], co[k][1], i) for k in ("x3", "x4", "out")}
             if self.mm:
-                blocks = [(self.vir_conv1, 1), (self.vir_conv2, 2), (self.vir_conv3, 4), (self.vir_conv4, 8)]
-                active = self._discard_active()
                 for i, rid in enumerate(rids):
-                    idx = batch_dict["voxel_coords_mm" + rid].int()
-                    trans_param = batch_dict.get("aug_param")
-                    if "transform_param" in batch_dict:
-                        trans_param = batch_dict["transform_param"][:, i, :]
-                    tags = [f"mm_x_conv{bi + 1}{rid}" if (bi < 3 and active) else None for bi in range(4)]
+                    idx = idx_m[rid]
+                    trans_param, tags = mm_inputs(i, rid)
                     if native_plan.usable(idx, blocks):
                         # input discard (spconv_backbone.py:488-489) + the four blocks + their layer discards: one native chain plan
                         stages, _, keep0, kept0, ar = native_plan.build(self, blocks, None, idx, batch_size, calib, trans_param, tags,
                                                                         self.layer_discard_rate, batch_dict, NRConvBlock.IMAGE_SHAPE,
                                                                         input_discard_tag=(f"mm_input{rid}" if active else None),
                                                                         deferred=scope.deferred)
-                        arenas.extend(ar)
-                        arenas.append(idx)
                         plan["mm"][rid] = {"keep0": keep0, "in_indices": kept0 if active else idx, "stages": stages,
                                            "trans_param": trans_param}
                         continue
-                    native_only = False
                     keep0 = None
                     if active:  # the MM stream also discards its input (spconv_backbone.py:488-489)
                         keep0 = _draw_keep(self.layer_discard_rate, idx.shape[0], batch_dict, f"mm_input{rid}", idx.device)
@@ -826,8 +904,6 @@ class VirConv8x(nn.Module):
                     stages, _, _, _ = _plan_nrconv_chain(blocks, idx, list(self.sparse_shape), batch_size, calib, trans_param,
                                                          tags, self.layer_discard_rate, batch_dict)
                     plan["mm"][rid] = {"keep0": keep0, "in_indices": idx, "stages": stages, "trans_param": trans_param}
-            if native_only and arenas:
-                plan["_arenas"] = arenas
         return scope.publish(plan)
 
     @staticmethod

@@ -91,9 +91,9 @@ class HipBackend:
         stream, INSIDE the library (vc_trace_begin): whichever call issues the launch -- an operator, a post_act_block unit or
         the whole feature pass -- is timed as it runs in the product path.  The active pairs of each traced table are counted
         on the device right after the launch (outside the bracket)."""
-        assert direction in ("fwd", "bwd", "all")   # "all": every gather-GEMM and weight-gradient launch (ck, cn ignored)
+        assert direction in ("fwd", "bwd", "dw", "all")   # "dw": the weight gradient <CI, CO>; "all": every conv launch (ck, cn ignored)
         self._trace_pairs = torch.zeros((max_records,), dtype=torch.int64, device="cuda")
-        check(self.lib.vc_trace_begin({"fwd": 0, "bwd": 1, "all": -1}[direction], int(ck), int(cn), int(max_records),
+        check(self.lib.vc_trace_begin({"fwd": 0, "bwd": 1, "dw": 2, "all": -1}[direction], int(ck), int(cn), int(max_records),
                                       _ptr(self._trace_pairs)), "vc_trace_begin")
         self._trace_cap = int(max_records)
 

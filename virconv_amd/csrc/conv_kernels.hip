@@ -2301,7 +2301,7 @@ extern int g_pass_pack_all;
 extern int g_pass_fork_ext_event; // pass.hip
 extern int g_bn_fused_partial;  // bn_kernels.hip
 extern int g_pass_defer_dw_reduce;  // pass.hip
-extern int g_plan_subm_bitmap, g_plan_image_2d, g_plan_parity_order;   // plan.hip
+extern int g_plan_subm_bitmap, g_plan_image_2d, g_plan_parity_order, g_plan_params_pad, g_plan_reprepare;   // plan.hip
 extern int g_group_plan_radix, g_group_plan_onesweep;   // group_kernels.hip
 extern int g_sp_mark_variant;    // index_kernels.hip
 static constexpr int kMaxSplit = 256;
@@ -2500,6 +2500,8 @@ int vc_debug_set(const char* key, int value) {
   if (!strcmp(key, "plan_subm_bitmap")) { g_plan_subm_bitmap = value; return VC_OK; }
   if (!strcmp(key, "plan_image_2d")) { g_plan_image_2d = value; return VC_OK; }
   if (!strcmp(key, "plan_parity_order")) { g_plan_parity_order = value; return VC_OK; }
+  if (!strcmp(key, "plan_params_pad")) { g_plan_params_pad = value < 0 ? 0 : (value + 255) & ~255; return VC_OK; }
+  if (!strcmp(key, "plan_reprepare")) { g_plan_reprepare = value; return VC_OK; }
   if (!strcmp(key, "plan_radix_sort")) return experiment_key(key, value, 0, &g_group_plan_radix);
 #ifdef VC_EXPERIMENTS
   if (!strcmp(key, "conv_pc_ablate"))
@@ -2513,7 +2515,7 @@ int vc_debug_set(const char* key, int value) {
 }
 
 int vc_trace_begin(int direction, int ck, int cn, int max_records, int64_t* dev_pairs) {
-  VC_REQUIRE(((direction == -1) || ((direction == 0 || direction == 1) && ck >= 1 && cn >= 1)) && max_records >= 1 && dev_pairs,
+  VC_REQUIRE(((direction == -1) || ((direction >= 0 && direction <= 2) && ck >= 1 && cn >= 1)) && max_records >= 1 && dev_pairs,
              "vc_trace_begin: invalid argument");
   TraceState& T = g_trace;
   T.on = false;
@@ -2741,7 +2743,7 @@ static int conv_backward_weight_impl(const float* x, const float* dy, const int3
   }
   VC_REQUIRE(x && dy && pair_fwd, "vc_conv_backward_weight: null argument");
   float* partial = (float*)ws;
-  const int tr = trace_open(2, cin, cout, st);   // recorded only by the trace-everything mode (direction -1)
+  const int tr = trace_open(2, cin, cout, st);   // direction 2 (this shape) or the trace-everything mode (direction -1)
   int rc;
   switch (cin) {
     case 4: rc = dispatch_bw_co<4>(cout, x, dy, pair_fwd, n_out, kv, dweight, partial, operand_type, st, rep, centre, dy_grp); break;

@@ -470,11 +470,15 @@ __device__ __forceinline__ int sat_int(float f) {
   return (int)f;  // truncation toward zero
 }
 
+// DBG (developer diagnostics of LOG.md A.15, never on the product path): `dbg` = [0] record count, [1] launch tag, [64 ..
+// 64 + 32 B) a golden copy of the parameter block saved right behind project_prepare_kernel, then 32-int records.  A thread whose
+// loads of its sample's block differ from the golden copy logs what it saw, re-reads the block after a pause, and logs that too.
+template <bool DBG>
 __global__ void __launch_bounds__(256) project_uv_kernel(const int32_t* __restrict__ indices, int64_t n,
                                                          const float* __restrict__ params, int B, int stride,
                                                          float vsx, float vsy, float vsz, float minx, float miny,
                                                          float minz, int32_t* __restrict__ uv,
-                                                         float* __restrict__ depth) {
+                                                         float* __restrict__ depth, int32_t* dbg, int dbg_records) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int4 r = *reinterpret_cast<const int4*>(indices + i * 4);  // [b, z, y, x]
@@ -483,6 +487,30 @@ __global__ void __launch_bounds__(256) project_uv_kernel(const int32_t* __restri
   float dep = 0.0f;
   if (b >= 0 && b < B) {
     const float* P = params + b * 32;
+    if constexpr (DBG) {
+      const int32_t* Pi = reinterpret_cast<const int32_t*>(P);
+      const int32_t* G = dbg + 64 + b * 32;
+      int bad = -1;
+      for (int j = 0; j < 29; ++j)
+        if (Pi[j] != __builtin_nontemporal_load(G + j)) { bad = j; break; }
+      if (bad >= 0) {
+        const int slot = atomicAdd(dbg, 1);
+        if (slot < dbg_records) {
+          int32_t* R = dbg + 64 + B * 32 + slot * 32;
+          R[0] = (int32_t)i; R[1] = b; R[2] = (int32_t)blockIdx.x; R[3] = bad; R[4] = dbg[1];
+          R[5] = (int32_t)__builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));   // HW_REG_XCC_ID
+          const unsigned long long t0 = wall_clock64();
+          R[6] = (int32_t)(t0 & 0xffffffffu); R[7] = (int32_t)(t0 >> 32);
+          for (int j = 0; j < 8; ++j) R[8 + j] = Pi[24 + j];        // what this thread's ordinary loads returned
+          R[16] = Pi[0]; R[17] = Pi[11]; R[18] = Pi[12]; R[19] = Pi[23];
+          __builtin_amdgcn_s_sleep(127);
+          const volatile int32_t* Pv = reinterpret_cast<const volatile int32_t*>(P);
+          for (int j = 0; j < 8; ++j) R[20 + j] = Pv[24 + j];       // the same words a moment later
+          R[28] = (int32_t)(wall_clock64() - t0);
+          R[29] = stride; R[30] = (int32_t)(n & 0x7fffffff); R[31] = 0x600DF00D;
+        }
+      }
+    }
     float X = __fadd_rn(__fmul_rn((float)r.w, vsx), minx);
     float Y = __fadd_rn(__fmul_rn((float)r.z, vsy), miny);
     float Z = __fadd_rn(__fmul_rn((float)r.y, vsz), minz);
@@ -1078,6 +1106,19 @@ __global__ void __launch_bounds__(THREADS) row_order_kernel(const int32_t* __res
   }
 }
 
+// diagnostics form of vc_project_uv for the geometry plan (plan.hip, vc_plan_desc.debug_buf); see project_uv_kernel<true>
+int project_uv_debug(const int32_t* indices, int64_t n, const float* params, int batch_size, int stride, int32_t* uv, int32_t* dbg,
+                     int dbg_records, hipStream_t st) {
+  if (n == 0) return VC_OK;
+  const double vs = 0.05 * stride;
+  const float vsf = (float)vs;
+  const float minx = (float)(0.0 + vs / 2), miny = (float)(-40.0 + vs / 2), minz = (float)(-3.0 + vs / 2);
+  hipLaunchKernelGGL(project_uv_kernel<true>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, indices, n, params, batch_size, stride, vsf,
+                     vsf, vsf, minx, miny, minz, uv, (float*)nullptr, dbg, dbg_records);
+  VC_CHECK_LAUNCH("project_uv_kernel<debug>");
+  return VC_OK;
+}
+
 }  // namespace vc
 
 using namespace vc;
@@ -1313,11 +1354,12 @@ int vc_project_uv(const int32_t* indices, int64_t n, const float* params, int ba
   const double vs = 0.05 * stride;
   const float vsf = (float)vs;
   const float minx = (float)(0.0 + vs / 2), miny = (float)(-40.0 + vs / 2), minz = (float)(-3.0 + vs / 2);
-  hipLaunchKernelGGL(project_uv_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, indices, n,
-                     params, batch_size, stride, vsf, vsf, vsf, minx, miny, minz, uv, depth);
+  hipLaunchKernelGGL(project_uv_kernel<false>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, indices, n,
+                     params, batch_size, stride, vsf, vsf, vsf, minx, miny, minz, uv, depth, (int32_t*)nullptr, 0);
   VC_CHECK_LAUNCH("project_uv_kernel");
   return VC_OK;
 }
+
 
 int vc_gather_rows(const float* features, const int32_t* indices, int c, int icols, const int64_t* keep, int64_t n_keep,
                    float* features_out, int32_t* indices_out, void* stream) {

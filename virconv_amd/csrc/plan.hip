@@ -21,6 +21,7 @@
 // (A hand-written LDS radix sort for the group plans was built too and lost to rocPRIM on these keys: csrc/experiments/.)
 // Tables are bit-identical to the stand-alone operators on the same coordinates (tests/test_plan_gpu.py); row orders are hints.
 #include <algorithm>
+#include <mutex>
 
 #include "common.h"
 
@@ -29,6 +30,13 @@ namespace vc {
 int g_plan_subm_bitmap = 1;   // vc_debug_set plan_subm_bitmap: 0 = hash build + vc_subm_rulebook for every 3-D SubM table (A/B)
 int g_plan_image_2d = 1;      // vc_debug_set plan_image_2d:    0 = hash build + vc_subm_rulebook for the pixel tables (A/B)
 int g_plan_parity_order = 1;  // vc_debug_set plan_parity_order: 0 = vc_row_order on the pair table (A/B)
+// developer diagnostics of LOG.md A.15 (tools/det_check.py), both 0 on the product path:
+int g_plan_params_pad = 0;    // vc_debug_set plan_params_pad: bytes of padding in front of the projection parameter block (moves it: does the
+                              // damage follow the block or stay at the address?)
+int g_plan_reprepare = 0;     // vc_debug_set plan_reprepare: 1 = write the parameter block again right in front of every projection of
+                              // vc_plan_finish (damage to the block between the two calls is then repaired: is the block what is hit?)
+int project_uv_debug(const int32_t* indices, int64_t n, const float* params, int batch_size, int stride, int32_t* uv, int32_t* dbg,
+                     int dbg_records, hipStream_t st);   // index_kernels.hip
 
 static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -242,6 +250,7 @@ struct Blk {
 struct PlanState {
   uint64_t magic;
   int n_counts, ev_slot, waited, params_ready, finished;
+  uint64_t ev_gen;            // generation of the event slot this plan recorded (vc_plan_wait refuses a slot that moved on)
   int32_t* host_counts;
   int64_t counts_off, params_off;
   int64_t in_keep_off, in_kept_off, cap_in_keep, n_in_keep;   // discard of the chain's input
@@ -262,9 +271,11 @@ struct Bump2 {
   }
 };
 
+// output cells one input row can reach: per axis the kernel's EXTENT (k - 1) * dilation + 1 over the stride, rounded up -- with
+// gcd(dilation, stride) > 1 (k3 s2 d2) an input reaches 3 cells per axis, not 2 (sp_mark2 enumerates the same J)
 static inline int64_t conv_reach(const vc_plan_conv& g) {
   int64_t r = 1;
-  for (int a = 0; a < 3; ++a) r *= (g.ksize[a] + g.stride[a] - 1) / g.stride[a];
+  for (int a = 0; a < 3; ++a) r *= ((g.ksize[a] - 1) * g.dilation[a] + 1 + g.stride[a] - 1) / g.stride[a];
   return r;
 }
 static inline void conv_out_shape(const int32_t* in, const vc_plan_conv& g, int32_t* out) {
@@ -300,6 +311,7 @@ static int check_desc(const vc_plan_desc* d) {
 static void layout_chain(const vc_plan_desc* d, PlanState& S, Bump2& bump) {
   int nc = 0;
   S.counts_off = bump.take(kMaxCounts * sizeof(int32_t));
+  if (g_plan_params_pad > 0) (void)bump.take((size_t)g_plan_params_pad);
   S.params_off = bump.take((size_t)d->batch_size * 32 * sizeof(float));
   const double keep_frac = 1.0 - d->discard_rate;
   int64_t cur_cap = d->n;        // row capacity of the coordinates feeding the next thing
@@ -349,7 +361,7 @@ static void layout_chain(const vc_plan_desc* d, PlanState& S, Bump2& bump) {
     }
     K.cap = cur_cap;
     K.n = counts_known ? cur_cap : -1;
-    K.early = counts_known ? 1 : 0;
+    K.early = (counts_known && !d->defer_early_tables) ? 1 : 0;
     for (int a = 0; a < 3; ++a) K.shape[a] = shape[a];
     K.keep_off = K.kept_off = -1;
     K.cnt_keep = -1;
@@ -511,7 +523,15 @@ static int block_tables(const vc_plan_desc* d, const PlanState& S, int b, const 
   }
   if (B.has_2d) {
     int32_t* uv = (int32_t*)(A.base + uvo);
-    rc = vc_project_uv(coords, n, (const float*)(arena_a + S.params_off), d->batch_size, B.uv_stride, uv, nullptr, st);
+    if (g_plan_reprepare && A.id == 1) {   // diagnostics: the block written again right in front of its reader (vc_plan_finish only)
+      rc = vc_project_prepare(d->calib, d->trans, d->batch_size, (float*)(arena_a + S.params_off), st);
+      if (rc != VC_OK) return rc;
+    }
+    if (d->debug_buf)                      // diagnostics: every thread checks what it loads against the golden copy (vc_plan_begin)
+      rc = project_uv_debug(coords, n, (const float*)(arena_a + S.params_off), d->batch_size, B.uv_stride, uv, (int32_t*)d->debug_buf,
+                            (int)((d->debug_bytes - 256 - (int64_t)d->batch_size * 128) / 128), st);
+    else
+      rc = vc_project_uv(coords, n, (const float*)(arena_a + S.params_off), d->batch_size, B.uv_stride, uv, nullptr, st);
     if (rc != VC_OK) return rc;
     int32_t* pair2 = (int32_t*)(A.base + p2);
     int32_t* rep = (int32_t*)(A.base + repo);
@@ -534,15 +554,45 @@ static int block_tables(const vc_plan_desc* d, const PlanState& S, int b, const 
   return VC_OK;
 }
 
-static hipEvent_t* plan_events() {
-  static thread_local hipEvent_t ev[8] = {};
-  if (ev[0] == nullptr) {
-    for (int i = 0; i < 8; ++i)
-      if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { ev[0] = nullptr; return nullptr; }
+// Events of the counts' trip to the host: a process-wide ring (a plan may be begun on one host thread and waited for on another:
+// autograd worker, loader thread), each slot stamped with the generation of the plan that last recorded it.  vc_plan_wait
+// refuses a slot whose stamp moved on (more than kPlanEvents plans between their begin and their wait) instead of reading counts
+// that belong to another plan.
+static constexpr int kPlanEvents = 64;
+static std::mutex g_plan_ev_mutex;
+static hipEvent_t g_plan_ev[kPlanEvents] = {};
+static uint64_t g_plan_ev_gen[kPlanEvents] = {};
+static uint64_t g_plan_ev_next = 0;
+static int g_plan_ev_device = -1;
+
+// -> slot (>= 0) with S.ev_gen set, the event recorded on `st`; < 0: HIP error
+static int plan_event_record(PlanState& S, hipStream_t st) {
+  std::lock_guard<std::mutex> lock(g_plan_ev_mutex);
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  if (g_plan_ev_device != dev) {   // first use (or another device current): events belong to the device they were created on
+    for (int i = 0; i < kPlanEvents; ++i) {
+      if (g_plan_ev[i]) (void)hipEventDestroy(g_plan_ev[i]);
+      g_plan_ev[i] = nullptr;
+      if (hipEventCreateWithFlags(&g_plan_ev[i], hipEventDisableTiming) != hipSuccess) { g_plan_ev_device = -1; return -1; }
+      g_plan_ev_gen[i] = 0;
+    }
+    g_plan_ev_device = dev;
   }
-  return ev;
+  const uint64_t gen = ++g_plan_ev_next;
+  const int slot = (int)(gen % kPlanEvents);
+  if (hipEventRecord(g_plan_ev[slot], st) != hipSuccess) return -1;
+  g_plan_ev_gen[slot] = gen;
+  S.ev_slot = slot;
+  S.ev_gen = gen;
+  return slot;
 }
-static thread_local unsigned t_plan_ev_next = 0;
+// the plan's event, or nullptr when its slot has been recorded again by a later plan
+static hipEvent_t plan_event_of(const PlanState& S) {
+  std::lock_guard<std::mutex> lock(g_plan_ev_mutex);
+  if (S.ev_slot < 0 || S.ev_slot >= kPlanEvents || g_plan_ev_gen[S.ev_slot] != S.ev_gen) return nullptr;
+  return g_plan_ev[S.ev_slot];
+}
 
 }  // namespace vc
 
@@ -585,6 +635,10 @@ int vc_plan_begin(const vc_plan_desc* d, void* arena_a, size_t arena_a_bytes, in
   if (d->calib) {
     rc = vc_project_prepare(d->calib, d->trans, d->batch_size, (float*)(A + S.params_off), st);
     if (rc != VC_OK) return rc;
+    if (d->debug_buf) {   // diagnostics: golden copy at int32 [64, 64 + 32 B) of the buffer (project_uv_kernel<true>)
+      VC_REQUIRE(d->debug_bytes >= 256 + (int64_t)d->batch_size * 128 + 128, "vc_plan_begin: debug_buf too small");
+      VC_CHECK_HIP(hipMemcpyAsync((char*)d->debug_buf + 256, A + S.params_off, (size_t)d->batch_size * 128, hipMemcpyDeviceToDevice, st));
+    }
   }
   // ---- the chain: coordinates, keeps and counts of every level, nothing read back yet
   const int32_t* cur = d->indices;      // coordinates feeding the next strided conv / block
@@ -683,11 +737,13 @@ int vc_plan_begin(const vc_plan_desc* d, void* arena_a, size_t arena_a_bytes, in
     if (rc != VC_OK) return rc;
   }
   // ---- the counts' trip to the host starts here; the tables below run underneath it
-  hipEvent_t* evs = plan_events();
-  VC_REQUIRE(evs != nullptr, "vc_plan_begin: cannot create events");
-  S.ev_slot = (int)(t_plan_ev_next++ % 8);
   if (S.n_counts > 0) VC_CHECK_HIP(hipMemcpyAsync(host_counts, counts, (size_t)S.n_counts * 4, hipMemcpyDeviceToHost, st));
-  VC_CHECK_HIP(hipEventRecord(evs[S.ev_slot], st));
+  VC_REQUIRE(plan_event_record(S, st) >= 0, "vc_plan_begin: cannot create / record the counts' event");
+  // ---- nothing below (and nothing vc_plan_finish enqueues behind it on this stream) runs before the caller's event: the TABLES
+  // are not built beside the previous step's backward pass (LOG.md A.15); the chain above and the counts' trip are not held back
+  bool any_early = false;
+  for (int b = 0; b < d->n_blocks; ++b) any_early = any_early || S.blk[b].early;
+  if (d->tables_wait_event && any_early) VC_CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)d->tables_wait_event, 0));
   // ---- tables of the blocks whose row count is already known (the first block of VirConvL8x)
   S.early_out = vc_plan_out{};
   TableArena TA{A, 0, &bump};
@@ -707,12 +763,13 @@ int vc_plan_wait(const vc_plan_desc* d, vc_plan_state* state) {
   VC_REQUIRE(d && state, "vc_plan_wait: null argument");
   PlanState& S = *reinterpret_cast<PlanState*>(state);
   VC_REQUIRE(S.magic == kPlanMagic, "vc_plan_wait: state was not written by vc_plan_begin");
-  hipEvent_t* evs = plan_events();
-  VC_REQUIRE(evs != nullptr, "vc_plan_wait: no events");
+  hipEvent_t ev = plan_event_of(S);
+  VC_REQUIRE(ev != nullptr, "vc_plan_wait: this plan's event slot was recorded again by a later plan (more than %d plans between "
+             "vc_plan_begin and vc_plan_wait): its counts cannot be trusted", kPlanEvents);
   // poll (a blocking hipEventSynchronize parks the thread in the kernel driver: slower by the wake-up latency, and much slower with
   // an RCCL communicator alive in the process -- DESIGN.md 5)
   for (;;) {
-    const hipError_t e = hipEventQuery(evs[S.ev_slot]);
+    const hipError_t e = hipEventQuery(ev);
     if (e == hipSuccess) break;
     if (e != hipErrorNotReady) { set_error("vc_plan_wait: %s", hipGetErrorString(e)); return VC_EHIP; }
   }
@@ -725,6 +782,8 @@ int vc_plan_wait(const vc_plan_desc* d, vc_plan_state* state) {
     if (B.has_down) {
       K.down.n_in = cur_n;
       K.down.n_out = hc[K.down.cnt_out];
+      VC_REQUIRE(K.down.n_out >= 0 && K.down.n_out <= K.down.cap_out, "vc_plan_wait: block %d: strided conv emits %lld rows, capacity %lld", b,
+                 (long long)K.down.n_out, (long long)K.down.cap_out);
       cur_n = K.down.n_out;
     }
     K.n = cur_n;
@@ -733,12 +792,15 @@ int vc_plan_wait(const vc_plan_desc* d, vc_plan_state* state) {
       if (K.cnt_keep >= 0) K.n_keep = hc[K.cnt_keep];
       VC_REQUIRE(K.n_keep == want, "vc_plan_wait: block %d keeps %lld rows, expected int(%lld * (1 - rate)) = %lld", b, (long long)K.n_keep,
                  (long long)cur_n, (long long)want);
+      VC_REQUIRE(K.n_keep <= K.cap_keep, "vc_plan_wait: block %d keeps %lld rows, capacity %lld", b, (long long)K.n_keep, (long long)K.cap_keep);
       cur_n = K.n_keep;
     }
   }
   if (d->has_tail) {
     S.tail.n_in = cur_n;
     S.tail.n_out = hc[S.tail.cnt_out];
+    VC_REQUIRE(S.tail.n_out >= 0 && S.tail.n_out <= S.tail.cap_out, "vc_plan_wait: the tail conv emits %lld rows, capacity %lld",
+               (long long)S.tail.n_out, (long long)S.tail.cap_out);
   }
   S.waited = 1;
   return VC_OK;
@@ -820,6 +882,7 @@ int vc_plan_finish(const vc_plan_desc* d, vc_plan_state* state, void* arena_a, v
     if (rc != VC_OK) return rc;
   }
   if (arena_b_bytes < need) { set_error("vc_plan_finish: arena_b too small (%zu < %zu)", arena_b_bytes, need); return VC_ECAPACITY; }
+  if (d->tables_wait_event) VC_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)d->tables_wait_event, 0));
   rc = finish_impl(d, S, (char*)arena_a, (char*)arena_b, arena_b_bytes, out, false, nullptr, (hipStream_t)stream, 0);
   if (rc == VC_OK) S.finished = 1;
   return rc;

@@ -21,7 +21,16 @@ from . import _lib, ops
 
 NATIVE_PLAN = os.environ.get("VIRCONV_NATIVE_PLAN", "1") != "0"
 _DESCS = weakref.WeakKeyDictionary()      # model -> static part of its vc_plan_desc
-_PINNED = {}                              # device index -> pinned int32[64] for the counts
+_PINNED = {}                              # device index -> [pinned int32[RING, 64] for the counts, next slot, owners]
+_RING = 64                                # plans between their begin and their finish, per device (= the library's event ring)
+ARENA_ALLOC = None                        # developer hook (tools/det_check.py): callable(n int32 words) -> tensor, instead of torch.empty
+
+
+def _arena(nbytes: int, dev) -> torch.Tensor:
+    nwords = (nbytes + 3) >> 2
+    if ARENA_ALLOC is not None:
+        return ARENA_ALLOC(nwords)
+    return torch.empty((nwords,), dtype=torch.int32, device=dev)
 
 
 def _conv_geom(dst: _lib.PlanConv, conv) -> None:
@@ -123,10 +132,13 @@ class ChainPlan:
     input (VirConv8x MM stream).  `kind`: cache key of the chain's static description on `model`.
     `deferred`: None -> finish() enqueues everything.  A list -> only what a FORWARD pass reads is enqueued; a closure that enqueues
     the rest (group plans, backward row orders: vc_plan_finish_backward) on the then-current stream is appended, and the caller
-    runs it after the forward pass is on its stream (backbone.join_plan)."""
+    runs it after the forward pass is on its stream (backbone.join_plan).
+    `guard` (torch.cuda.Event | None): the stream waits for it in front of its first TABLE kernel (vc_plan_desc.tables_wait_event;
+    backbone.PLAN_GUARD).  `defer_tables`: vc_plan_begin builds no table at all -- for callers that begin several plans, or one a
+    step early, before they finish any (`finish(guard=...)` then names the event)."""
 
     def __init__(self, model, kind: str, chain, tail, idx: torch.Tensor, batch_size: int, calib, trans_param, discard_tags, rate: float,
-                 batch_dict, image_shape, input_discard_tag=None, deferred=None):
+                 batch_dict, image_shape, input_discard_tag=None, deferred=None, guard=None, defer_tables=False, debug_buf=None):
         be = ops.get_backend()
         lib = be.lib
         dev = idx.device
@@ -146,6 +158,15 @@ class ChainPlan:
         d.discard_rate = float(rate) if (any(t is not None for t in discard_tags) or input_discard_tag is not None) else 0.0
         d.need_grad = 1 if torch.is_grad_enabled() else 0
         d.row_order_fwd = 1 if ops.ROW_ORDER == "strided" else 0
+        d.defer_early_tables = 1 if defer_tables else 0
+        d.tables_wait_event = None
+        if guard is not None:
+            hold.append(guard)
+            d.tables_wait_event = guard.cuda_event
+        d.debug_buf, d.debug_bytes = None, 0
+        if debug_buf is not None:   # developer diagnostics (tools/det_check.py)
+            hold.append(debug_buf)
+            d.debug_buf, d.debug_bytes = debug_buf.data_ptr(), debug_buf.numel() * debug_buf.element_size()
         inj = batch_dict.get("layer_discard_keep")
 
         def keep_source(tag):
@@ -175,21 +196,27 @@ class ChainPlan:
         na = lib.vc_plan_begin_arena_bytes(dref)
         if na == 0:
             _lib.check(_lib.VC_EINVAL, "vc_plan_begin_arena_bytes")
-        arena_a = torch.empty(((na + 3) >> 2,), dtype=torch.int32, device=dev)
+        arena_a = _arena(na, dev)
         ring = _PINNED.get(dev.index)
-        if ring is None:   # a ring of count buffers: up to 8 plans between their begin and their finish
-            ring = _PINNED[dev.index] = [torch.empty((8, 64), dtype=torch.int32).pin_memory(), 0]
-        pinned = ring[0][ring[1] % 8]
+        if ring is None:   # a ring of count buffers: up to _RING plans between their begin and their finish
+            ring = _PINNED[dev.index] = [torch.empty((_RING, 64), dtype=torch.int32).pin_memory(), 0, [None] * _RING]
+        slot = ring[1] % _RING
+        owner = ring[2][slot]() if ring[2][slot] is not None else None
+        if owner is not None and owner.result is None and not owner.counts_read:
+            raise RuntimeError(f"virconv_amd geometry plan: {_RING} plans were begun on {dev} while an earlier one still waits for its "
+                               "row counts (its pinned count buffer would be overwritten); finish or drop plans begun ahead")
+        pinned = ring[0][slot]
         ring[1] += 1
+        ring[2][slot] = weakref.ref(self)
+        self.result, self.counts_read = None, False
         state = _lib.PlanState()
         _lib.check(lib.vc_plan_begin(dref, arena_a.data_ptr(), arena_a.numel() * 4, pinned.data_ptr(), C.byref(state), be.stream()),
                    "vc_plan_begin")
         self.model, self.chain, self.tail, self.idx, self.discard_tags, self.input_discard_tag = model, chain, tail, idx, discard_tags, input_discard_tag
         self.image_shape, self.deferred = image_shape, deferred
         self.d, self.state, self.hold, self.arena_a, self.pinned = d, state, hold, arena_a, pinned
-        self.result = None
 
-    def finish(self):
+    def finish(self, guard=None):
         """-> (per block: {"down", "subm3d", "uv", "subm2d", "out_indices", "out_shape", "keep", "kept_indices"}, tail Rulebook | None,
         input keep | None, kept input indices | None, [arena_a, arena_b])"""
         if self.result is not None:
@@ -199,11 +226,15 @@ class ChainPlan:
         d, state, arena_a, hold = self.d, self.state, self.arena_a, self.hold
         dref, sref = C.byref(d), C.byref(state)
         st = be.stream()
+        if guard is not None:
+            hold.append(guard)
+            d.tables_wait_event = guard.cuda_event
         _lib.check(lib.vc_plan_wait(dref, sref), "vc_plan_wait")          # the ONE host synchronisation of the plan
+        self.counts_read = True
         nb = lib.vc_plan_finish_arena_bytes(dref, sref)
         if nb == 0:
             _lib.check(_lib.VC_EINVAL, "vc_plan_finish_arena_bytes")
-        arena_b = torch.empty(((nb + 3) >> 2,), dtype=torch.int32, device=self.idx.device)
+        arena_b = _arena(nb, self.idx.device)
         out = _lib.PlanOut()
         _lib.check(lib.vc_plan_finish(dref, sref, arena_a.data_ptr(), arena_b.data_ptr(), arena_b.numel() * 4, C.byref(out), st),
                    "vc_plan_finish")
@@ -247,10 +278,10 @@ class ChainPlan:
 
 
 def build_chain(model, kind: str, chain, tail, idx: torch.Tensor, batch_size: int, calib, trans_param, discard_tags, rate: float,
-                batch_dict, image_shape, input_discard_tag=None, deferred=None):
+                batch_dict, image_shape, input_discard_tag=None, deferred=None, guard=None):
     """ChainPlan begun and finished back to back (see there)."""
     return ChainPlan(model, kind, chain, tail, idx, batch_size, calib, trans_param, discard_tags, rate, batch_dict, image_shape,
-                     input_discard_tag, deferred).finish()
+                     input_discard_tag, deferred, guard).finish()
 
 
 def nrconv_stages(blocks, res):
@@ -274,11 +305,23 @@ def nrconv_kind(blocks, tail, input_discard_tag):
     return ("nrconv", len(blocks), tail is not None, input_discard_tag is not None)
 
 
+def begin(model, blocks, tail, idx: torch.Tensor, batch_size: int, calib, trans_param, discard_tags, rate: float, batch_dict,
+          image_shape, input_discard_tag=None, deferred=None) -> ChainPlan:
+    """First half of `build` with every table left to the second (`finish_nrconv`): for callers with several plans per forward."""
+    return ChainPlan(model, nrconv_kind(blocks, tail, input_discard_tag), nrconv_blocks(blocks), tail, idx, batch_size, calib, trans_param,
+                     discard_tags, rate, batch_dict, image_shape, input_discard_tag, deferred, None, True)
+
+
+def finish_nrconv(cp: ChainPlan, blocks, guard=None):
+    res, rb_tail, in_keep, in_kept, arenas = cp.finish(guard)
+    return nrconv_stages(blocks, res), rb_tail, in_keep, in_kept, arenas
+
+
 def build(model, blocks, tail, idx: torch.Tensor, batch_size: int, calib, trans_param, discard_tags, rate: float, batch_dict,
-          image_shape, input_discard_tag=None, deferred=None):
+          image_shape, input_discard_tag=None, deferred=None, guard=None):
     """The plan of a chain of NRConvBlocks `blocks` = [(block, uv stride)] in the form backbone._plan_nrconv_chain returns:
     -> (stages, tail Rulebook | None, input keep | None, kept input indices | None, [arena_a, arena_b])."""
     res, rb_tail, in_keep, in_kept, arenas = build_chain(model, nrconv_kind(blocks, tail, input_discard_tag),
                                                          nrconv_blocks(blocks), tail, idx, batch_size, calib, trans_param,
-                                                         discard_tags, rate, batch_dict, image_shape, input_discard_tag, deferred)
+                                                         discard_tags, rate, batch_dict, image_shape, input_discard_tag, deferred, guard)
     return nrconv_stages(blocks, res), rb_tail, in_keep, in_kept, arenas
