@@ -544,12 +544,14 @@ int vc_nhwc_to_nchw(const float* x, int batch_size, int64_t hw, int c, const flo
  * indice generation does conv by conv inside VirConvL8x.forward (:609-699), with one device-to-host sync per strided conv.
  *
  *   vc_plan_begin   enqueues, with every row count still on the device: for each level the output-cell bitmap, its scan, the
- *                   coordinate emission (row CAPACITY buffers) and the layer discard's keep / kept coordinates; every table of a
- *                   first block that has no strided conv (its row count is the caller's); then the counts' copy to
- *                   `host_counts` (pinned host memory, >= 64 int32) and an event.
+ *                   coordinate emission (row CAPACITY buffers) and the layer discard's keep / kept coordinates; then the counts'
+ *                   copy to `host_counts` (pinned host memory, >= 64 int32) and an event; then the 3-D SubM table of a first
+ *                   block that has no strided conv (its row count is the caller's).
  *   vc_plan_wait    polls that event; checks injected keeps against the counts.  The ONE host synchronisation of the plan.
  *   vc_plan_finish  enqueues every remaining table a FORWARD pass reads, with exact row counts, into `arena_b` (all views of
- *                   `vc_plan_out` are final; those named next are filled by the call after it).
+ *                   `vc_plan_out` are final; those named next are filled by the call after it): first the integer tables, then --
+ *                   behind `tables_wait_event` -- the image-space branch of ALL blocks in three launches (one clear of the pixel
+ *                   images, projection + pixel marking, pair tables + representatives).
  *   vc_plan_finish_backward  enqueues what only backward passes read -- the duplicate-pixel group plans (`grp_plan`, the sorts:
  *                   a third of the plan's stream time) and the backward row orders (`order_bwd`).  A caller records an event
  *                   between the two calls and lets the forward pass wait for that one only.  No-op when need_grad == 0.
@@ -589,13 +591,14 @@ typedef struct vc_plan_desc {
                                                caller's): vc_plan_finish builds them all.  For callers that begin several plans -- or one
                                                plan a step early -- before finishing any */
   int32_t reserved_;
-  void* tables_wait_event;                  /* hipEvent_t or NULL: the stream waits for it after the coordinate / count chain and
-                                               BEFORE its first table kernel (projection, pair tables): vc_plan_begin waits in front of the
-                                               early tables, vc_plan_finish at its start (the value may differ between the two calls).
-                                               The caller records it behind the previous step's backward pass: tables are never built
-                                               beside one (LOG.md A.15) */
-  void* debug_buf; int64_t debug_bytes;     /* developer diagnostics (tools/det_check.py) or NULL: a golden copy of the projection
-                                               parameters + a log of every projection thread that read something else */
+  void* tables_wait_event;                  /* hipEvent_t or NULL: vc_plan_finish lets the stream wait for it between the integer tables and
+                                               the image-space branch (pixel projection -- the plan's only floating-point kernel -- and
+                                               the pixel tables of all blocks).  The caller records it behind the previous step's feature
+                                               passes: the projection never runs beside conv kernels (LOG.md A.15 / A.17).  May be set
+                                               between vc_plan_begin and vc_plan_finish */
+  void* debug_buf; int64_t debug_bytes;     /* developer diagnostics (tools/det_check.py) or NULL: zeroed int32 buffer: 64-int header ([3] = rows per stage of the
+                                               intermediates area, 0 = none), 4096 32-int records, then 4 x [3] x 8 floats; a log of
+                                               every projection thread that read "no augmentation" from a plan that has one */
 } vc_plan_desc;
 typedef struct vc_plan_view { int32_t arena /* 0: arena_a, 1: arena_b, -1: absent */; int32_t cols; int64_t offset /* bytes */; int64_t rows; } vc_plan_view;
 typedef struct vc_plan_table_out {

@@ -289,18 +289,29 @@ def _record_discards(monkeypatch):
     from virconv_amd import native_plan as npn
     orig_build = npn.build
 
-    def recording_build(model, blocks, tail, idx, batch_size, calib, trans_param, discard_tags, rate, batch_dict, image_shape,
-                        input_discard_tag=None, deferred=None):
-        res = orig_build(model, blocks, tail, idx, batch_size, calib, trans_param, discard_tags, rate, batch_dict, image_shape,
-                         input_discard_tag, deferred)
-        for st, tag in zip(res[0], discard_tags):
+    def note(stages, in_keep, discard_tags, input_discard_tag):
+        for st, tag in zip(stages, discard_tags):
             if tag is not None:
                 rec[tag] = st["keep"].detach().cpu().clone()
         if input_discard_tag is not None:
-            rec[input_discard_tag] = res[2].detach().cpu().clone()
+            rec[input_discard_tag] = in_keep.detach().cpu().clone()
+
+    def recording_build(model, blocks, tail, idx, batch_size, calib, trans_param, discard_tags, rate, batch_dict, image_shape,
+                        input_discard_tag=None, deferred=None, **kw):
+        res = orig_build(model, blocks, tail, idx, batch_size, calib, trans_param, discard_tags, rate, batch_dict, image_shape,
+                         input_discard_tag, deferred, **kw)
+        note(res[0], res[2], discard_tags, input_discard_tag)
+        return res
+
+    orig_finish = npn.finish_nrconv
+
+    def recording_finish(cp, blocks, guard=None):   # plans begun and finished in two sweeps (VirConv8x)
+        res = orig_finish(cp, blocks, guard)
+        note(res[0], res[2], cp.discard_tags, cp.input_discard_tag)
         return res
 
     monkeypatch.setattr(npn, "build", recording_build)
+    monkeypatch.setattr(npn, "finish_nrconv", recording_finish)
     return rec
 
 

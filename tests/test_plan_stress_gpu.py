@@ -117,7 +117,50 @@ def test_every_plan_of_64_unsynchronised_train_steps_is_bit_identical_to_a_synch
                 if int(got[k]) != int(checksum(ref[k])):
                     bad.append((t, k, "checksum"))
         seen[t] = None
-    assert not bad, f"{len(bad)} structures differ from the synchronised rebuild (guard {os.environ.get('VIRCONV_PLAN_GUARD', '1')}): {bad[:12]}"
+    names = sorted({k.split(".", 1)[1] if k[0] == "s" else k for _, k, _ in bad})
+    assert not bad, (f"{len(bad)} structures of {len({t for t, _, _ in bad})} steps differ from the synchronised rebuild (guard "
+                     f"{os.environ.get('VIRCONV_PLAN_GUARD', '1')}); kinds: {names}; first: {bad[:12]}")
+
+
+def test_every_plan_of_64_pipelined_inference_frames_is_bit_identical_to_a_synchronised_rebuild():
+    """Forward-only loop (BASELINE configs[1], bs 1): the plan of frame f + 1 runs beside the feature pass of frame f (two frames in
+    flight, backbone._bound_run_ahead).  No backward pass anywhere, so the guard of the training loop does not apply: this is the
+    statement that tables built beside FORWARD conv kernels are right."""
+    import bench
+    from virconv_amd import synth
+    from virconv_amd.backbone import VirConvL8x
+    dev = torch.device("cuda", 0)
+    batch = bench.make_batch([0], dev, training=False)
+    torch.manual_seed(0)
+    model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).to(dev).eval()
+    torch.cuda.synchronize()
+    batch["inputs_ready_event"] = torch.cuda.Event()
+    batch["inputs_ready_event"].record()
+    seen = []
+
+    def step(observe):
+        bd = dict(batch)
+        bd["voxel_features"] = batch["voxel_features"].clone()
+        if observe:
+            bd["plan_observer"] = lambda rid, plan: seen.append(plan)
+        with torch.no_grad():
+            return model(bd)["encoded_spconv_tensor"].dense()
+
+    for _ in range(5):
+        step(False)
+    for _ in range(STEPS):
+        step(True)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = model.build_plan(batch["voxel_coords"], 1, batch["calib"], batch["aug_param"], {k: v for k, v in batch.items()})
+    torch.cuda.synchronize()
+    ref = _structures(ref)
+    bad = []
+    for t, plan in enumerate(seen):
+        got = _structures(plan)
+        assert got.keys() == ref.keys()
+        bad += [(t, k) for k in ref if got[k].shape != ref[k].shape or not torch.equal(got[k], ref[k])]
+    assert not bad, f"{len(bad)} structures of {len({t for t, _ in bad})} frames differ from the synchronised rebuild: {bad[:12]}"
 
 
 def test_plan_with_every_table_deferred_to_finish_is_bit_identical():

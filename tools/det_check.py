@@ -11,9 +11,11 @@ structure of that plan with one built on an idle GPU.  Each variant changes one 
     exactmfma   vc_debug_set f32_split = 0, bw_split = 0 (the form that never failed)
     private     plan arenas from a private, never-freed pool (rules torch's caching allocator out)
     guard       the shipped guard (the plan stream waits for the backward pass in front of its first table kernel)
+    select      vc_debug_set plan_uv_mode = 1: project_uv_kernel<1>, no divergent branch on the loaded flag word (per-lane select)
+    argflag     vc_debug_set plan_uv_mode = 2: project_uv_kernel<2>, "has augmentation" as a kernel argument (the flag word is not read)
 
-Every projection runs as project_uv_kernel<true>: each thread compares the parameter block it loads with a golden copy saved behind
-project_prepare_kernel and logs what it saw (vc_plan_desc.debug_buf).  Usage:  python tools/det_check.py [--reps 12] [--bs 2] [variants ...]
+Every projection runs as project_uv_kernel<MODE, true>: a thread whose flag word P[28] reads "no augmentation" although the plan has
+one logs the bits it saw, its wave's ballot, and what the same word reads again (vc_plan_desc.debug_buf).  Usage:  python tools/det_check.py [--reps 12] [--bs 2] [variants ...]
 """
 import argparse
 import os
@@ -31,7 +33,7 @@ from virconv_amd.backbone import NRConvBlock, VirConvL8x  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=12)
 ap.add_argument("--bs", type=int, default=2)
-ap.add_argument("variants", nargs="*", default=["base", "reprepare", "pad", "dwmain", "exactmfma", "private", "guard"])
+ap.add_argument("variants", nargs="*", default=["base", "select", "argflag", "reprepare", "pad", "dwmain", "exactmfma", "private", "guard"])
 args = ap.parse_args()
 
 dev = torch.device("cuda", 0)
@@ -46,7 +48,8 @@ p0 = probe.build_plan(batch["voxel_coords"], bs, batch["calib"], batch["aug_para
 bb.join_plan(p0)
 batch["layer_discard_keep"] = {f"x_conv{bi + 1}": p0["stages"][bi]["keep"].clone() for bi in range(3)}
 torch.cuda.synchronize()
-DBG_INTS = 64 + bs * 32 + 32 * 4096
+SIDE_ROWS = 400_000
+DBG_INTS = 64 + 32 * 4096 + 4 * SIDE_ROWS * 8
 
 
 def dset(key, val):
@@ -61,6 +64,7 @@ def begin(model, guard=None):
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         dbg = torch.zeros((DBG_INTS,), dtype=torch.int32, device=dev)
+        dbg[3] = SIDE_ROWS
         idx = batch["voxel_coords"].int()
         tags = [f"x_conv{bi + 1}" if bi < 3 else None for bi in range(4)]
         cp = native_plan.ChainPlan(model, native_plan.nrconv_kind(blocks, co, None), native_plan.nrconv_blocks(blocks), co, idx, bs,
@@ -93,19 +97,16 @@ def show_records(dbg, label):
     n = int(dbg[0])
     if n == 0:
         return
-    recs = dbg[64 + bs * 32: 64 + bs * 32 + 32 * min(n, 4096)].view(-1, 32).cpu()
-    gold = dbg[64: 64 + bs * 32].view(bs, 32).cpu()
+    recs = dbg[64: 64 + 32 * min(n, 4096)].view(-1, 32).cpu()
     f = lambda v: struct.unpack("f", struct.pack("i", int(v)))[0]   # noqa: E731
-    print(f"      {label}: {n} projection threads read a parameter block that differs from the golden copy; first / last records:")
-    for r in list(recs[:4]) + list(recs[-2:]):
-        b = int(r[1])
-        print(f"        row {int(r[0])} sample {b} block {int(r[2])} first bad word {int(r[3])} xcd {int(r[5]) & 15} stride {int(r[29])} t {(int(r[7]) << 32) | (int(r[6]) & 0xffffffff)}"
-              f" | saw P[24:32] = {[round(f(v), 5) for v in r[8:16]]} | golden {[round(f(v), 5) for v in gold[b, 24:32]]}"
-              f" | {int(r[28])} ticks later: {[round(f(v), 5) for v in r[20:28]]} | P[0], P[11], P[12], P[23] = {[round(f(v), 4) for v in r[16:20]]}"
-              f" golden {[round(f(gold[b, j]), 4) for j in (0, 11, 12, 23)]}")
-    rows = recs[:, 0].long()
-    print(f"        rows {int(rows.min())} .. {int(rows.max())}, samples {sorted(set(recs[:, 1].tolist()))}, blocks {int(recs[:, 2].min())} .. {int(recs[:, 2].max())},"
-          f" strides {sorted(set(recs[:, 29].tolist()))}, bad words {sorted(set(recs[:, 3].tolist()))}")
+    print(f"      {label}: {n} projection threads took the flag word P[28] for 'no augmentation'; first / last records:")
+    for r in list(recs[:6]) + list(recs[-2:]):
+        bal = ((int(r[7]) & 0xffffffff) << 32) | (int(r[6]) & 0xffffffff)
+        print(f"        row {int(r[0])} sample {int(r[1])} block {int(r[2])} lane {int(r[3])} xcd {int(r[5]) & 15} stride {int(r[15])} mode {int(r[16])}"
+              f" | flag bits as used {int(r[4]) & 0xffffffff:#010x} | wave ballot(has) {bal:#018x} | re-read at once {int(r[8]) & 0xffffffff:#010x},"
+              f" later {int(r[9]) & 0xffffffff:#010x} | P[24:29] re-read {[round(f(v), 5) for v in r[10:15]]}")
+    print(f"        rows {int(recs[:, 0].min())} .. {int(recs[:, 0].max())}, lanes {sorted(set(recs[:, 3].tolist()))}, flag bits seen "
+          f"{sorted({hex(int(v) & 0xffffffff) for v in recs[:, 4].tolist()})}, strides {sorted(set(recs[:, 15].tolist()))}")
 
 
 class PrivatePool:
@@ -123,6 +124,7 @@ class PrivatePool:
 
 
 def run_variant(name):
+    dset("plan_uv_mode", {"select": 1, "argflag": 2, "rcp": 3}.get(name, 0))
     dset("plan_reprepare", 1 if name == "reprepare" else 0)
     dset("plan_params_pad", 4096 if name == "pad" else 0)
     exact = name == "exactmfma"
@@ -161,16 +163,38 @@ def run_variant(name):
         assert ta.keys() == tf.keys()
         bad = [(k, int((ta[k] != tf[k]).sum())) for k in ta if ta[k].shape != tf[k].shape or not torch.equal(ta[k], tf[k])]
         pa = cp.arena_a[(256 + (4096 if name == "pad" else 0)) // 4:][: bs * 32]
-        gold = dbg[64: 64 + bs * 32]
-        print(f"  [{name}] rep {rep}: {len(ta)} structures, differing: {bad}; parameter block now == golden copy: {bool(torch.equal(pa, gold))};"
-              f" threads that saw something else: beside backward {int(dbg[0])}, idle {int(dbg_f[0])}")
-        if name == "pad":   # the 4 KB in front of the moved block: poison check (vc_plan_begin never writes it)
-            padw = cp.arena_a[64: 64 + 1024]
-            print(f"      words of the padding changed since allocation cannot be told (uninitialised); nonzero now: {int((padw != 0).sum())}")
+        pf = cf.arena_a[(256 + (4096 if name == "pad" else 0)) // 4:][: bs * 32]
+        if bad or int(dbg[0]) or int(dbg_f[0]):
+            print(f"  [{name}] rep {rep}: {len(ta)} structures, differing: {bad}; parameter blocks of the two plans equal now: {bool(torch.equal(pa, pf))};"
+                  f" threads that took the flag word for 0: beside backward {int(dbg[0])}, idle {int(dbg_f[0])}")
         for k, _ in bad:
             if k.endswith(".uv"):
+                # which part of the inverse augmentation did the wrong rows lose?  Stand-alone projections of the same coordinates
+                # (idle GPU) with parts of the augmentation parameters [rot, flip, scale] neutralised
+                rows_ = (ta[k] != tf[k]).any(1).nonzero().squeeze(1)
+                si_ = int(k[1])
+                co_ = ta[f"s{si_}.out_indices"] if f"s{si_}.out_indices" in ta else idx
+                aug = batch["aug_param"].float()
+                hyp = {"no augmentation at all": None, "rotation lost": aug * torch.tensor([0., 1., 1.], device=dev),
+                       "flip lost": aug * torch.tensor([1., 0., 1.], device=dev),
+                       "scale lost": aug * torch.tensor([1., 1., 0.], device=dev) + torch.tensor([0., 0., 1.], device=dev),
+                       "rotation + flip lost": aug * torch.tensor([0., 0., 1.], device=dev)}
+                match = {}
+                for name_h, tp in hyp.items():
+                    alt = ops.project_uv(co_, batch["calib"], tp, bs, 2 ** si_)
+                    match[name_h] = int((alt[rows_] == ta[k][rows_]).all(1).sum())
+                torch.cuda.synchronize()
+                print(f"      {k}: of {rows_.numel()} wrong rows, equal to the projection with ... {match}")
+                # the intermediates both kernels wrote for these rows: [X, Y, Z after the inverse augmentation, rect xyz, hom x y]
+                sa_ = dbg[64 + 32 * 4096:].view(torch.float32).view(4, SIDE_ROWS, 8)[si_]
+                sf_ = dbg_f[64 + 32 * 4096:].view(torch.float32).view(4, SIDE_ROWS, 8)[si_]
+                for r_ in rows_[:3].tolist() + rows_[-1:].tolist():
+                    print(f"        row {r_} lane {r_ % 64} coords {co_[r_].tolist()}: beside {[round(float(x), 4) for x in sa_[r_]]}")
+                    print(f"        {'':>{len(str(r_)) + 30}} idle   {[round(float(x), 4) for x in sf_[r_]]}")
+                cols = (sa_[rows_] != sf_[rows_]).any(0).tolist()
+                print(f"        intermediates that differ in these rows (X Y Z | rect | hom): {cols}; rows whose X, Y, Z are bit-equal: {int((sa_[rows_, :3] == sf_[rows_, :3]).all(1).sum())}")
                 rows = (ta[k] != tf[k]).any(1).nonzero().squeeze(1)
-                print(f"      {k}: {rows.numel()} rows differ, span {int(rows.min())} .. {int(rows.max())}, samples {sorted(set(ta[k][rows, 0].tolist()))};"
+                print(f"      {k}: {rows.numel()} rows differ, span {int(rows.min())} .. {int(rows.max())}, lanes {sorted(set((rows % 64).tolist()))}, samples {sorted(set(ta[k][rows, 0].tolist()))};"
                       f" beside-backward {ta[k][rows[:3]].tolist()} idle {tf[k][rows[:3]].tolist()}")
         show_records(dbg, "beside backward")
         show_records(dbg_f, "idle")

@@ -277,30 +277,27 @@ def _bound_run_ahead(device, main):
     return mark
 
 
-# LOG.md A.15: with the TABLES of a plan (pixel projection, pair tables) built on the plan stream while a backward pass was still
-# running on the main / weight-gradient streams, runs of rows of `uv` came out wrong in 24 of 32 four-step runs; the cause is
-# narrowed down in LOG.md A.17 but whatever it is, tables and backward passes do not share the chip any more:
-#   1 (default): the plan stream waits, between the coordinate / count chain and its first table kernel, for an event recorded on
-#       the main stream at the start of this forward (behind the previous step's backward pass, clip and optimizer).  The chain and
-#       the counts' trip to the host still overlap the previous step; nothing the host waits for is held back.
-#   2: the whole plan waits for that event (serial; A/B only).        0: no guard (the round-4 loop; A/B and tools/det_check.py).
-# A plan is guarded when it is built with gradients enabled or when a backward pass was enqueued since the last guarded plan.
+# LOG.md A.15 / A.17: the pixel projection of a plan (project_uv: the plan's only floating-point kernel) computes wrong pixels in lanes
+# 48-63 of some waves when it runs on the plan stream beside the conv kernels of a feature pass -- forward or backward, training or
+# pipelined inference; measured in round 5: 675 structures of 57 out of 64 steps of the round-4 training loop differ from a plan
+# built on an idle GPU, 0 with the event below.  Memory, the parameter block, its flag word, the allocator, the third stream, packed
+# fp32 instructions and the IEEE division sequence were all ruled out (tools/det_check.py); the exact-fp32-MFMA conv kernels never
+# trigger it, the bf16-split ones do.  Whatever the silicon-level cause, the projection no longer shares the chip with them:
+#   1 (default): the plan stream waits, in front of the image-space branch of vc_plan_finish (projection + pixel tables of all blocks:
+#       three launches), for an event recorded on the main stream at the start of this forward -- behind everything the previous
+#       step / frame enqueued.  The coordinate / count chain, the counts' trip to the host and every integer table (strided-conv pair
+#       tables, 3-D SubM tables) still overlap the previous step.
+#   2: the whole plan waits for that event (serial; A/B only).        0: no event (the round-4 loop; A/B and tools/det_check.py).
 PLAN_GUARD = int(os.environ.get("VIRCONV_PLAN_GUARD", "1"))
-_GUARD_SEEN = {}          # device index -> ops.BACKWARD_LAUNCHES at the last guarded plan
 
 
 def _guard_wanted(device) -> bool:
-    if not PLAN_GUARD:
-        return False
-    key = torch.device(device).index
-    seen = _GUARD_SEEN.get(key, 0)
-    _GUARD_SEEN[key] = ops.BACKWARD_LAUNCHES
-    return torch.is_grad_enabled() or ops.BACKWARD_LAUNCHES != seen
+    return PLAN_GUARD != 0
 
 
 class _PlanScope:
     """Run the geometry plan on the high-priority side stream (see VirConvL8x.build_plan) and hand the result to the main
-    stream.  CPU tensors: a no-op scope.  `guard`: the event the plan's TABLE kernels wait for (see PLAN_GUARD), or None."""
+    stream.  CPU tensors: a no-op scope.  `guard`: the event the plan's image-space branch waits for (see PLAN_GUARD), or None."""
 
     def __init__(self, ref_tensor, batch_dict, ahead=False):
         self.on_gpu = ref_tensor.is_cuda
@@ -313,7 +310,7 @@ class _PlanScope:
             if not ahead:   # (a plan begun a step ahead is bounded by the training loop itself)
                 mark = _bound_run_ahead(ref_tensor.device, self.main)
             self.side = _plan_stream(ref_tensor.device)
-            if not ahead and _guard_wanted(ref_tensor.device):   # (a plan begun ahead builds no table: its finish names the guard)
+            if not ahead and _guard_wanted(ref_tensor.device):   # (a plan begun ahead names the event when it is finished)
                 self.guard = mark
             ready = batch_dict.get("inputs_ready_event")
             if ready is not None:
@@ -335,7 +332,8 @@ class _PlanScope:
         return self.ctx.__exit__(*exc)
 
     def guard_tables(self):
-        """Python-composed plans (the fallback of native_plan): everything enqueued on the plan stream from here on waits for the guard."""
+        """Python-composed plans (the fallback of native_plan; they interleave projections and tables): everything enqueued on the plan
+        stream from here on waits for the guard."""
         if self.on_gpu and self.guard is not None:
             self.side.wait_event(self.guard)
 

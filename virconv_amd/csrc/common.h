@@ -57,6 +57,36 @@ static inline Dims make_dims(int ndim, const int32_t* shape) {
   return d;
 }
 
+// The image-space (2-D) branch of every block of a geometry plan in ONE launch per step (plan.hip): stage s covers blocks
+// [block0[s], block0[s + 1]) of the fused grid.
+struct Uv2dStage {
+  const int32_t* coords;   // (n, 4) int32 [b, z, y, x]
+  int32_t* uv;             // (n, 3) int32 [b, u, v]
+  int32_t* img;            // (B, U, V) int32: 1 + highest row of the pixel, 0 = empty
+  int32_t* pair;           // (kv, n) pair table of the 2-D SubM conv
+  int32_t* rep;            // (n) representative row of each row's pixel
+  int64_t n;
+  int stride, U, V, SH, SW, ky, kx, dy, dx;
+  float vs, minx, miny, minz;
+  unsigned block0_mark;    // first block of the stage in the projection + mark grid (256 rows per block)
+  unsigned block0_rule;    // ... in the rulebook grid (64 rows per block)
+};
+struct Uv2dArgs {
+  Uv2dStage st[8];
+  int n_stages;
+  int B;
+  const float* params;     // (B, 32) projection parameters (project_prepare_kernel)
+};
+int uv_mark_multi(const Uv2dArgs& a, unsigned total_blocks, hipStream_t st);   // index_kernels.hip (-ffp-contract=off)
+// While one is alive (geometry plan only) vc_spconv_mark_count* / vc_spconv_pairs skip the fill of their bitmap / forward pair table:
+// the plan keeps those of all its convs in one zone each and fills the zone once.
+extern thread_local bool t_sp_skip_clear;
+struct SpSkipClear {
+  bool prev;
+  explicit SpSkipClear(bool on = true) : prev(t_sp_skip_clear) { if (on) t_sp_skip_clear = true; }
+  ~SpSkipClear() { t_sp_skip_clear = prev; }
+};
+
 struct Kern3 {  // kernel geometry in the internal 3-D view
   int k[3], s[3], p[3], d[3];
   int kv;

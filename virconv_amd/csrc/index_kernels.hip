@@ -11,6 +11,7 @@
 namespace vc {
 
 static thread_local char g_err[512] = "";
+thread_local bool t_sp_skip_clear = false;   // common.h, SpSkipClear
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -470,15 +471,19 @@ __device__ __forceinline__ int sat_int(float f) {
   return (int)f;  // truncation toward zero
 }
 
-// DBG (developer diagnostics of LOG.md A.15, never on the product path): `dbg` = [0] record count, [1] launch tag, [64 ..
-// 64 + 32 B) a golden copy of the parameter block saved right behind project_prepare_kernel, then 32-int records.  A thread whose
-// loads of its sample's block differ from the golden copy logs what it saw, re-reads the block after a pause, and logs that too.
-template <bool DBG>
+// MODE / DBG: developer diagnostics of LOG.md A.15 / A.17 (the product path is <0, false>).
+//   MODE 0: the flag word P[28] decides a divergent branch (v_cmp -> s_and_saveexec) around the inverse augmentation.
+//   MODE 1: no branch on loaded data: the inverse augmentation is always computed and selected per lane (v_cndmask).
+//   MODE 2: `has_trans` comes as a kernel argument (wave-uniform branch); the flag word in memory is not read at all.
+//   MODE 3: MODE 0 with the three divisions by the scale as multiplications by v_rcp_f32 (no v_div_scale / v_div_fmas in the block).
+// DBG: `dbg` = [0] record count, [2] 1 when the plan has augmentation parameters, [64 ..) 32-int records.  A thread whose flag word
+// reads "no augmentation" although the plan has one logs the bits it saw, the ballot of its wave, and re-reads the word.
+template <int MODE, bool DBG>
 __global__ void __launch_bounds__(256) project_uv_kernel(const int32_t* __restrict__ indices, int64_t n,
                                                          const float* __restrict__ params, int B, int stride,
                                                          float vsx, float vsy, float vsz, float minx, float miny,
                                                          float minz, int32_t* __restrict__ uv,
-                                                         float* __restrict__ depth, int32_t* dbg, int dbg_records) {
+                                                         float* __restrict__ depth, int32_t* dbg, int dbg_records, int has_trans_arg) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int4 r = *reinterpret_cast<const int4*>(indices + i * 4);  // [b, z, y, x]
@@ -487,36 +492,45 @@ __global__ void __launch_bounds__(256) project_uv_kernel(const int32_t* __restri
   float dep = 0.0f;
   if (b >= 0 && b < B) {
     const float* P = params + b * 32;
-    if constexpr (DBG) {
-      const int32_t* Pi = reinterpret_cast<const int32_t*>(P);
-      const int32_t* G = dbg + 64 + b * 32;
-      int bad = -1;
-      for (int j = 0; j < 29; ++j)
-        if (Pi[j] != __builtin_nontemporal_load(G + j)) { bad = j; break; }
-      if (bad >= 0) {
-        const int slot = atomicAdd(dbg, 1);
-        if (slot < dbg_records) {
-          int32_t* R = dbg + 64 + B * 32 + slot * 32;
-          R[0] = (int32_t)i; R[1] = b; R[2] = (int32_t)blockIdx.x; R[3] = bad; R[4] = dbg[1];
-          R[5] = (int32_t)__builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));   // HW_REG_XCC_ID
-          const unsigned long long t0 = wall_clock64();
-          R[6] = (int32_t)(t0 & 0xffffffffu); R[7] = (int32_t)(t0 >> 32);
-          for (int j = 0; j < 8; ++j) R[8 + j] = Pi[24 + j];        // what this thread's ordinary loads returned
-          R[16] = Pi[0]; R[17] = Pi[11]; R[18] = Pi[12]; R[19] = Pi[23];
-          __builtin_amdgcn_s_sleep(127);
-          const volatile int32_t* Pv = reinterpret_cast<const volatile int32_t*>(P);
-          for (int j = 0; j < 8; ++j) R[20 + j] = Pv[24 + j];       // the same words a moment later
-          R[28] = (int32_t)(wall_clock64() - t0);
-          R[29] = stride; R[30] = (int32_t)(n & 0x7fffffff); R[31] = 0x600DF00D;
-        }
-      }
-    }
     float X = __fadd_rn(__fmul_rn((float)r.w, vsx), minx);
     float Y = __fadd_rn(__fmul_rn((float)r.z, vsy), miny);
     float Z = __fadd_rn(__fmul_rn((float)r.y, vsz), minz);
-    if (P[28] != 0.0f) {
+    const float flag = (MODE == 2) ? (has_trans_arg ? 1.0f : 0.0f) : P[28];
+    const bool has = flag != 0.0f;
+    if constexpr (DBG) {
+      if (!has && dbg[2] != 0) {
+        const unsigned long long bal = __ballot(has);
+        const int slot = atomicAdd(dbg, 1);
+        if (slot < dbg_records) {
+          int32_t* R = dbg + 64 + slot * 32;
+          R[0] = (int32_t)i; R[1] = b; R[2] = (int32_t)blockIdx.x; R[3] = (int32_t)(threadIdx.x & 63);
+          R[4] = __float_as_int(flag);
+          R[5] = (int32_t)__builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));   // HW_REG_XCC_ID
+          R[6] = (int32_t)(bal & 0xffffffffu); R[7] = (int32_t)(bal >> 32);
+          const volatile int32_t* Pv = reinterpret_cast<const volatile int32_t*>(P);
+          R[8] = Pv[28];                                            // the same word again, at once
+          __builtin_amdgcn_s_sleep(64);
+          R[9] = Pv[28];                                            // ... and a moment later
+          for (int j = 0; j < 5; ++j) R[10 + j] = Pv[24 + j];
+          R[15] = stride; R[16] = MODE; R[31] = 0x600DF00D;
+        }
+      }
+    }
+    if constexpr (MODE == 1) {
+      const float sc = P[27], fl = P[26], ca = P[24], sa = P[25], nsa = -P[25];
+      float Xs = __fdiv_rn(X, sc), Ys = __fdiv_rn(Y, sc), Zs = __fdiv_rn(Z, sc);
+      if (fl != 0.0f) Ys = -Ys;
+      const float X2 = __fadd_rn(__fmul_rn(Xs, ca), __fmul_rn(Ys, nsa));
+      const float Y2 = __fadd_rn(__fmul_rn(Xs, sa), __fmul_rn(Ys, ca));
+      X = has ? X2 : X; Y = has ? Y2 : Y; Z = has ? Zs : Z;
+    } else if (has) {
       const float sc = P[27];
-      X = __fdiv_rn(X, sc); Y = __fdiv_rn(Y, sc); Z = __fdiv_rn(Z, sc);
+      if constexpr (MODE == 3) {   // diagnostics only (not the reference's rounding): no IEEE division sequence in the block
+        const float rs = __builtin_amdgcn_rcpf(sc);
+        X = __fmul_rn(X, rs); Y = __fmul_rn(Y, rs); Z = __fmul_rn(Z, rs);
+      } else {
+        X = __fdiv_rn(X, sc); Y = __fdiv_rn(Y, sc); Z = __fdiv_rn(Z, sc);
+      }
       if (P[26] != 0.0f) Y = -Y;
       const float ca = P[24], sa = P[25], nsa = -P[25];
       const float X2 = __fadd_rn(__fmul_rn(X, ca), __fmul_rn(Y, nsa));
@@ -536,12 +550,97 @@ __global__ void __launch_bounds__(256) project_uv_kernel(const int32_t* __restri
     u = sat_int(__fdiv_rn(hom[0], rect[2]));
     v = sat_int(__fdiv_rn(hom[1], rect[2]));
     dep = __fsub_rn(hom[2], P[21 + 2]);
+    if constexpr (DBG) {   // every row's intermediates, per stage (int 3 of the header: rows of capacity per stage region)
+      const int cap = dbg[3];
+      if (cap > 0 && i < cap) {
+        int lg = 0;
+        while ((1 << lg) < stride) ++lg;
+        float* S8 = reinterpret_cast<float*>(dbg + 64 + 32 * dbg_records) + ((int64_t)lg * cap + i) * 8;
+        S8[0] = X; S8[1] = Y; S8[2] = Z; S8[3] = rect[0]; S8[4] = rect[1]; S8[5] = rect[2]; S8[6] = hom[0]; S8[7] = hom[1];
+      }
+    }
   }
   u = min(max(u, 0), 1400 - 1) / stride;
   v = min(max(v, 0), 600 - 1) / stride;
   int32_t* o = uv + i * 3;
   o[0] = b; o[1] = u; o[2] = v;
   if (depth) depth[i] = dep;
+}
+
+// ---- the image-space branch of every block of a geometry plan in one launch (plan.hip; Uv2dArgs, common.h): projection
+// (the arithmetic of project_uv_kernel<0>, op for op: spconv_backbone.py:54-83) fused with the pixel marking of image_mark_kernel --
+// img[(b * U + u) * V + v] = 1 + the highest row of the pixel, runs of equal pixels in consecutive rows folded in the wave first.
+__device__ __forceinline__ void project_point(const int4 r, const float* __restrict__ params, int B, int stride, float vs, float minx,
+                                              float miny, float minz, int& u, int& v) {
+  const int b = r.x;
+  u = 0; v = 0;
+  if (b >= 0 && b < B) {
+    const float* P = params + b * 32;
+    float X = __fadd_rn(__fmul_rn((float)r.w, vs), minx);
+    float Y = __fadd_rn(__fmul_rn((float)r.z, vs), miny);
+    float Z = __fadd_rn(__fmul_rn((float)r.y, vs), minz);
+    if (P[28] != 0.0f) {
+      const float sc = P[27];
+      X = __fdiv_rn(X, sc); Y = __fdiv_rn(Y, sc); Z = __fdiv_rn(Z, sc);
+      if (P[26] != 0.0f) Y = -Y;
+      const float ca = P[24], sa = P[25], nsa = -P[25];
+      const float X2 = __fadd_rn(__fmul_rn(X, ca), __fmul_rn(Y, nsa));
+      const float Y2 = __fadd_rn(__fmul_rn(X, sa), __fmul_rn(Y, ca));
+      X = X2; Y = Y2;
+    }
+    float rect[3], hom[2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      rect[c] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(X, P[0 + c]), __fmul_rn(Y, P[3 + c])), __fmul_rn(Z, P[6 + c])),
+                          P[9 + c]);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      hom[c] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(rect[0], P[12 + c]), __fmul_rn(rect[1], P[15 + c])),
+                                   __fmul_rn(rect[2], P[18 + c])),
+                         P[21 + c]);
+    u = sat_int(__fdiv_rn(hom[0], rect[2]));
+    v = sat_int(__fdiv_rn(hom[1], rect[2]));
+  }
+  u = min(max(u, 0), 1400 - 1) / stride;
+  v = min(max(v, 0), 600 - 1) / stride;
+}
+
+__global__ void __launch_bounds__(256) uv_mark_multi_kernel(Uv2dArgs a) {
+  int s = 0;
+#pragma unroll
+  for (int t = 1; t < 8; ++t)
+    if (t < a.n_stages && blockIdx.x >= a.st[t].block0_mark) s = t;
+  const Uv2dStage& S = a.st[s];
+  const int64_t i = (int64_t)(blockIdx.x - S.block0_mark) * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  bool live = i < S.n;
+  int64_t key = -2 - lane;   // dead lanes: distinct, never equal to a real key
+  if (live) {
+    const int4 r = *reinterpret_cast<const int4*>(S.coords + i * 4);  // [b, z, y, x]
+    int u, v;
+    project_point(r, a.params, a.B, S.stride, S.vs, S.minx, S.miny, S.minz, u, v);
+    int32_t* o = S.uv + i * 3;
+    o[0] = r.x; o[1] = u; o[2] = v;
+    if (r.x >= 0 && r.x < a.B && u >= 0 && u < S.U && v >= 0 && v < S.V) key = ((int64_t)r.x * S.U + u) * S.V + v;
+    else live = false;
+  }
+  int row = live ? (int)i : -1;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int64_t ok = __shfl_up((long long)key, off, 64);
+    const int orow = __shfl_up(row, off, 64);
+    if (lane >= off && ok == key) row = max(row, orow);
+  }
+  const int64_t nk = __shfl_down((long long)key, 1, 64);
+  if (!live || (lane != 63 && nk == key)) return;
+  atomicMax(&S.img[key], row + 1);
+}
+
+int uv_mark_multi(const Uv2dArgs& a, unsigned total_blocks, hipStream_t st) {
+  if (total_blocks == 0) return VC_OK;
+  hipLaunchKernelGGL(uv_mark_multi_kernel, dim3(total_blocks), dim3(256), 0, st, a);
+  VC_CHECK_LAUNCH("uv_mark_multi_kernel");
+  return VC_OK;
 }
 
 // ------------------------------------------------------------------------------------------ K2 gather / scatter rows
@@ -1106,16 +1205,23 @@ __global__ void __launch_bounds__(THREADS) row_order_kernel(const int32_t* __res
   }
 }
 
-// diagnostics form of vc_project_uv for the geometry plan (plan.hip, vc_plan_desc.debug_buf); see project_uv_kernel<true>
+// diagnostics form of vc_project_uv for the geometry plan (plan.hip, vc_plan_desc.debug_buf / vc_debug_set plan_uv_mode)
 int project_uv_debug(const int32_t* indices, int64_t n, const float* params, int batch_size, int stride, int32_t* uv, int32_t* dbg,
-                     int dbg_records, hipStream_t st) {
+                     int dbg_records, int mode, int has_trans, hipStream_t st) {
   if (n == 0) return VC_OK;
   const double vs = 0.05 * stride;
   const float vsf = (float)vs;
   const float minx = (float)(0.0 + vs / 2), miny = (float)(-40.0 + vs / 2), minz = (float)(-3.0 + vs / 2);
-  hipLaunchKernelGGL(project_uv_kernel<true>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, indices, n, params, batch_size, stride, vsf,
-                     vsf, vsf, minx, miny, minz, uv, (float*)nullptr, dbg, dbg_records);
-  VC_CHECK_LAUNCH("project_uv_kernel<debug>");
+#define VC_UV_LAUNCH(M, D)                                                                                                         \
+  hipLaunchKernelGGL((project_uv_kernel<M, D>), dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, indices, n, params, batch_size, stride, \
+                     vsf, vsf, vsf, minx, miny, minz, uv, (float*)nullptr, dbg, dbg_records, has_trans)
+  if (dbg) {
+    if (mode == 1) VC_UV_LAUNCH(1, true); else if (mode == 2) VC_UV_LAUNCH(2, true); else if (mode == 3) VC_UV_LAUNCH(3, true); else VC_UV_LAUNCH(0, true);
+  } else {
+    if (mode == 1) VC_UV_LAUNCH(1, false); else if (mode == 2) VC_UV_LAUNCH(2, false); else if (mode == 3) VC_UV_LAUNCH(3, false); else VC_UV_LAUNCH(0, false);
+  }
+#undef VC_UV_LAUNCH
+  VC_CHECK_LAUNCH("project_uv_kernel<diagnostics>");
   return VC_OK;
 }
 
@@ -1235,7 +1341,7 @@ static int spconv_mark_count(const int32_t* indices, int64_t n, const int32_t* n
   unsigned long long* bitmap = (unsigned long long*)ws;
   uint32_t* prefix = (uint32_t*)(bitmap + nwords);
   int32_t* blocksum = (int32_t*)(prefix + nwords);
-  VC_CHECK_HIP(hipMemsetAsync(bitmap, 0, nwords * 8, st));
+  if (!t_sp_skip_clear) VC_CHECK_HIP(hipMemsetAsync(bitmap, 0, nwords * 8, st));
   Kern3 k = make_kern(ndim, ksize, stride_, padding, dilation);
   VC_REQUIRE(k.kv <= 128, "strided rulebook: kernel volume %d > 128", k.kv);
   SpGeom g = make_spgeom(o, k);
@@ -1329,7 +1435,7 @@ static int spconv_pairs(const int32_t* indices, int64_t n, int ndim, int batch_s
   Kern3 k = make_kern(ndim, ksize, stride_, padding, dilation);
   VC_REQUIRE(k.kv <= 128, "strided rulebook: kernel volume %d > 128", k.kv);
   SpGeom g = make_spgeom(o, k);
-  if (n_out > 0) VC_CHECK_HIP(hipMemsetAsync(pair_fwd, 0xFF, (size_t)k.kv * n_out * 4, st));
+  if (n_out > 0 && !t_sp_skip_clear) VC_CHECK_HIP(hipMemsetAsync(pair_fwd, 0xFF, (size_t)k.kv * n_out * 4, st));
   if (n > 0) {
     hipLaunchKernelGGL(sp_pairs_kernel, dim3((unsigned)cdiv(n, 64)), dim3(256), 0, st, indices, n, ndim, g,
                        bitmap, prefix, n_out, pair_fwd, pair_bwd);
@@ -1354,8 +1460,8 @@ int vc_project_uv(const int32_t* indices, int64_t n, const float* params, int ba
   const double vs = 0.05 * stride;
   const float vsf = (float)vs;
   const float minx = (float)(0.0 + vs / 2), miny = (float)(-40.0 + vs / 2), minz = (float)(-3.0 + vs / 2);
-  hipLaunchKernelGGL(project_uv_kernel<false>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, indices, n,
-                     params, batch_size, stride, vsf, vsf, vsf, minx, miny, minz, uv, depth, (int32_t*)nullptr, 0);
+  hipLaunchKernelGGL((project_uv_kernel<0, false>), dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, indices, n,
+                     params, batch_size, stride, vsf, vsf, vsf, minx, miny, minz, uv, depth, (int32_t*)nullptr, 0, 0);
   VC_CHECK_LAUNCH("project_uv_kernel");
   return VC_OK;
 }

@@ -35,8 +35,9 @@ int g_plan_params_pad = 0;    // vc_debug_set plan_params_pad: bytes of padding 
                               // damage follow the block or stay at the address?)
 int g_plan_reprepare = 0;     // vc_debug_set plan_reprepare: 1 = write the parameter block again right in front of every projection of
                               // vc_plan_finish (damage to the block between the two calls is then repaired: is the block what is hit?)
+int g_plan_uv_mode = 0;       // vc_debug_set plan_uv_mode: project_uv_kernel<MODE> of the plan's projections (0 = product kernel)
 int project_uv_debug(const int32_t* indices, int64_t n, const float* params, int batch_size, int stride, int32_t* uv, int32_t* dbg,
-                     int dbg_records, hipStream_t st);   // index_kernels.hip
+                     int dbg_records, int mode, int has_trans, hipStream_t st);   // index_kernels.hip
 
 static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -256,6 +257,8 @@ struct PlanState {
   int64_t in_keep_off, in_kept_off, cap_in_keep, n_in_keep;   // discard of the chain's input
   int cnt_in_keep;
   int64_t a_bytes;            // arena_a bytes of the chain part (early tables start here)
+  int64_t ws_zone_off;        // arena_a: the bitmap workspaces of all strided convs, adjacent (ONE clear per plan)
+  size_t ws_zone_bytes;
   Blk blk[VC_PLAN_MAX_BLOCKS];
   Conv tail;
   vc_plan_out early_out;      // views of the tables built at begin
@@ -327,6 +330,7 @@ static void layout_chain(const vc_plan_desc* d, PlanState& S, Bump2& bump) {
     cur_cap = S.cap_in_keep;
   }
   bool counts_known = true;      // every row count so far is known on the host
+  Bump2 wsb;                     // the convs' bitmap workspaces: one zone, cleared by one fill in vc_plan_begin
   auto plan_conv = [&](Conv& C, const vc_plan_conv& g) {
     C.present = 1;
     for (int a = 0; a < 3; ++a) C.in_shape[a] = shape[a];
@@ -336,7 +340,7 @@ static void layout_chain(const vc_plan_desc* d, PlanState& S, Bump2& bump) {
     const int64_t cells = (int64_t)d->batch_size * C.out_shape[0] * C.out_shape[1] * C.out_shape[2];
     C.cap_out = std::min<int64_t>(cur_cap * conv_reach(g), cells);
     C.ws_bytes = vc_spconv_workspace_bytes(d->batch_size, 3, C.out_shape);
-    C.ws_off = bump.take(C.ws_bytes);
+    C.ws_off = wsb.take(C.ws_bytes);     // relative to the zone, rebased below
     C.out_idx_off = bump.take((size_t)std::max<int64_t>(C.cap_out, 1) * 16);
     C.cnt_out = nc++;
     C.n_in = C.n_out = -1;
@@ -377,6 +381,11 @@ static void layout_chain(const vc_plan_desc* d, PlanState& S, Bump2& bump) {
   }
   S.tail = Conv{};
   if (d->has_tail) plan_conv(S.tail, d->tail);
+  S.ws_zone_bytes = wsb.off;
+  S.ws_zone_off = bump.take(wsb.off);
+  for (int b = 0; b < d->n_blocks; ++b)
+    if (S.blk[b].down.present) S.blk[b].down.ws_off += S.ws_zone_off;
+  if (S.tail.present) S.tail.ws_off += S.ws_zone_off;
   S.n_counts = nc;
   S.a_bytes = (int64_t)bump.off;
 }
@@ -390,7 +399,8 @@ struct TableArena {
 static const vc_plan_view kAbsent = {-1, 0, 0, 0};
 
 static int conv_tables(const vc_plan_desc* d, const PlanState& S, const Conv& C, const vc_plan_conv& g, const int32_t* in_coords,
-                       const vc_plan_view& in_view, char* arena_a, TableArena& A, bool dry, vc_plan_table_out& T, hipStream_t st, int phase) {
+                       const vc_plan_view& in_view, char* arena_a, TableArena& A, bool dry, vc_plan_table_out& T, hipStream_t st, int phase,
+                       Bump2* pf_zone = nullptr) {
   // phase 0: what a forward pass reads (pair tables, forward row order); phase 1: the rest (backward row order).  Both phases walk
   // the same allocations, so that the offsets agree.
   const int64_t n_in = C.n_in, n_out = C.n_out;
@@ -403,7 +413,9 @@ static int conv_tables(const vc_plan_desc* d, const PlanState& S, const Conv& C,
   T.rep = T.grp_plan = T.order_fwd = T.order_bwd = kAbsent;
   T.in_indices = in_view;
   T.out_indices = vc_plan_view{0, 4, C.out_idx_off, n_out};
-  const int64_t pf = A.bump->take((size_t)std::max<int64_t>(C.kv * n_out, 1) * 4);
+  const bool pf_prefilled = pf_zone != nullptr;
+  const int64_t pf = pf_zone ? pf_zone->take((size_t)std::max<int64_t>(C.kv * n_out, 1) * 4)
+                             : A.bump->take((size_t)std::max<int64_t>(C.kv * n_out, 1) * 4);
   const int64_t pb = A.bump->take((size_t)std::max<int64_t>(C.kv * n_in, 1) * 4);
   T.pair_fwd = vc_plan_view{A.id, (int32_t)n_out, pf, C.kv};
   T.pair_bwd = vc_plan_view{A.id, (int32_t)n_in, pb, C.kv};
@@ -415,6 +427,8 @@ static int conv_tables(const vc_plan_desc* d, const PlanState& S, const Conv& C,
   if (dry) return VC_OK;
   int rc = VC_OK;
   if (phase == 0) {
+    // (the forward pair tables of a plan sit in one zone that finish_impl fills with -1 in one go: pf_zone)
+    SpSkipClear skip_fill(pf_prefilled);
     rc = vc_spconv_pairs(in_coords, n_in, 3, d->batch_size, C.out_shape, g.ksize, g.stride, g.padding, g.dilation, arena_a + C.ws_off,
                          C.ws_bytes, n_out, (int32_t*)(A.base + pf), (int32_t*)(A.base + pb), st);
     if (rc != VC_OK) return rc;
@@ -438,10 +452,37 @@ static int conv_tables(const vc_plan_desc* d, const PlanState& S, const Conv& C,
   return VC_OK;
 }
 
-static int block_tables(const vc_plan_desc* d, const PlanState& S, int b, const int32_t* coords, const vc_plan_view& coords_view,
-                        char* arena_a, TableArena& A, bool dry, vc_plan_block_out& O, hipStream_t st, int phase) {
-  // phase 0: the tables a forward pass reads; phase 1: the duplicate-pixel group plan (read by backward passes only: the sorts are
-  // a third of the plan's stream time and no longer stand between the counts and the first forward kernel)
+// pair[k, i] / rep[i] of EVERY block's pixel tensor in one launch: image_rulebook_kernel per stage of Uv2dArgs (64 rows x 4 offset
+// groups per block of the fused grid)
+__global__ void __launch_bounds__(256) image_rulebook_multi_kernel(Uv2dArgs a) {
+  int s = 0;
+#pragma unroll
+  for (int t = 1; t < 8; ++t)
+    if (t < a.n_stages && blockIdx.x >= a.st[t].block0_rule) s = t;
+  const Uv2dStage& S = a.st[s];
+  const int64_t i = (int64_t)(blockIdx.x - S.block0_rule) * 64 + (threadIdx.x & 63);
+  if (i >= S.n) return;
+  const int kg = threadIdx.x >> 6;
+  const int kv = S.ky * S.kx, centre = (S.ky / 2) * S.kx + S.kx / 2;
+  const int b = S.uv[i * 3], u = S.uv[i * 3 + 1], v = S.uv[i * 3 + 2];
+  const bool inside = b >= 0 && b < a.B && u >= 0 && u < S.U && v >= 0 && v < S.V;
+  for (int k = kg; k < kv; k += 4) {
+    int r = -1;
+    if (k == centre) {
+      r = (int)i;
+      S.rep[i] = inside ? S.img[((int64_t)b * S.U + u) * S.V + v] - 1 : (int)i;
+    } else {
+      const int nu = u + (k / S.kx - S.ky / 2) * S.dy, nv = v + (k % S.kx - S.kx / 2) * S.dx;
+      if (b >= 0 && b < a.B && nu >= 0 && nu < S.SH && nv >= 0 && nv < S.SW && nu < S.U && nv < S.V) r = S.img[((int64_t)b * S.U + nu) * S.V + nv] - 1;
+    }
+    S.pair[(int64_t)k * S.n + i] = r;
+  }
+}
+
+// The 3-D SubM table of block b (coordinate -> row by the bitmap of the strided conv that produced the rows, or by a hash);
+// `launch` = false: layout only
+static int block_tables_3d(const vc_plan_desc* d, const PlanState& S, int b, const int32_t* coords, const vc_plan_view& coords_view,
+                           char* arena_a, TableArena& A, bool launch, vc_plan_block_out& O, hipStream_t st) {
   const vc_plan_block& B = d->blocks[b];
   const Blk& K = S.blk[b];
   const int64_t n = K.n;
@@ -456,56 +497,10 @@ static int block_tables(const vc_plan_desc* d, const PlanState& S, int b, const 
   T3.in_indices = T3.out_indices = coords_view;
   const int64_t p3 = A.bump->take((size_t)std::max<int64_t>(kv3 * n, 1) * 4);
   T3.pair_fwd = vc_plan_view{A.id, (int32_t)n, p3, kv3};
-  // coordinate -> row: the bitmap of the strided conv that produced these rows, or a hash
   const bool by_bitmap = g_plan_subm_bitmap && K.down.present;
   const size_t hbytes = by_bitmap ? 0 : vc_hash_workspace_bytes(n);
   const int64_t hoff = by_bitmap ? -1 : A.bump->take(hbytes);
-  O.uv = kAbsent;
-  O.subm2d = vc_plan_table_out{};
-  int64_t uvo = -1, p2 = -1, repo = -1, gpo = -1, imgo = -1, h2o = -1, gwo = -1;
-  size_t img_bytes = 0, h2_bytes = 0, gw_bytes = 0;
-  int kv2 = 0, U = 0, V = 0;
-  if (B.has_2d) {
-    kv2 = B.ksize2d[0] * B.ksize2d[1];
-    uvo = A.bump->take((size_t)std::max<int64_t>(n, 1) * 12);
-    p2 = A.bump->take((size_t)std::max<int64_t>(kv2 * n, 1) * 4);
-    repo = A.bump->take((size_t)std::max<int64_t>(n, 1) * 4);
-    O.uv = vc_plan_view{A.id, 3, uvo, n};
-    vc_plan_table_out& T2 = O.subm2d;
-    T2.present = 1;
-    T2.kv = kv2;
-    T2.n_in = T2.n_out = n;
-    T2.out_shape[0] = d->image_shape[0]; T2.out_shape[1] = d->image_shape[1]; T2.out_shape[2] = 0;
-    T2.pair_bwd = T2.order_fwd = T2.order_bwd = T2.grp_plan = kAbsent;
-    T2.in_indices = T2.out_indices = O.uv;
-    T2.pair_fwd = vc_plan_view{A.id, (int32_t)n, p2, kv2};
-    T2.rep = vc_plan_view{A.id, 1, repo, n};
-    // pixels are clamped to [0, 1399] x [0, 599] and divided by the stride (vc_project_uv, spconv_backbone.py:76-81)
-    U = std::min<int>(d->image_shape[0], (1400 - 1) / B.uv_stride + 1);
-    V = std::min<int>(d->image_shape[1], (600 - 1) / B.uv_stride + 1);
-    if (g_plan_image_2d) {
-      img_bytes = (size_t)d->batch_size * U * V * 4;
-      imgo = A.bump->take(img_bytes);
-    } else {
-      h2_bytes = vc_hash_workspace_bytes(n);
-      h2o = A.bump->take(h2_bytes);
-    }
-    if (d->need_grad) {
-      gpo = A.bump->take((size_t)std::max<int64_t>(2 * n, 1) * 4);
-      T2.grp_plan = vc_plan_view{A.id, (int32_t)n, gpo, 2};
-      gw_bytes = vc_group_plan_workspace_bytes(n);
-      gwo = A.bump->take(gw_bytes);
-    }
-  }
-  if (dry || n == 0) return VC_OK;
-  int rc;
-  if (phase == 1) {
-    if (B.has_2d && d->need_grad) {
-      rc = vc_group_plan((const int32_t*)(A.base + repo), n, (int32_t*)(A.base + gpo), A.base + gwo, gw_bytes, st);
-      if (rc != VC_OK) return rc;
-    }
-    return VC_OK;
-  }
+  if (!launch || n == 0) return VC_OK;
   int32_t* pair3 = (int32_t*)(A.base + p3);
   if (by_bitmap) {
     const unsigned long long* bitmap = (const unsigned long long*)(arena_a + K.down.ws_off);
@@ -516,38 +511,156 @@ static int block_tables(const vc_plan_desc* d, const PlanState& S, int b, const 
                        B.subm_dilation[2], bitmap, prefix, pair3);
     VC_CHECK_LAUNCH("subm_bitmap_rulebook_kernel");
   } else {
-    rc = vc_hash_build(coords, n, 3, K.shape, A.base + hoff, hbytes, st);
+    int rc = vc_hash_build(coords, n, 3, K.shape, A.base + hoff, hbytes, st);
     if (rc != VC_OK) return rc;
     rc = vc_subm_rulebook(coords, n, 3, K.shape, B.subm_ksize, B.subm_dilation, A.base + hoff, hbytes, pair3, nullptr, st);
     if (rc != VC_OK) return rc;
   }
-  if (B.has_2d) {
-    int32_t* uv = (int32_t*)(A.base + uvo);
-    if (g_plan_reprepare && A.id == 1) {   // diagnostics: the block written again right in front of its reader (vc_plan_finish only)
+  return VC_OK;
+}
+
+// The image-space branch of EVERY block (pixel coordinates, 2-D SubM pair tables, representatives, group plans), all in arena B:
+//   phase 2: the projection (the plan's only floating-point kernel) + pixel marking of all blocks in ONE launch, the pair tables in
+//            one more, behind one clear of all pixel images -- enqueued by vc_plan_finish BEHIND the caller's event (LOG.md A.15 /
+//            A.17: this kernel, and only this one, computes wrong pixels beside the conv kernels);
+//   phase 1: the group plans (sorts) -- vc_plan_finish_backward;    any other phase: layout only.
+// coords[b] / n of each block come from the caller's walk.
+static int tables_2d(const vc_plan_desc* d, const PlanState& S, const int32_t* const* coords, char* arena_a, TableArena& A, bool dry,
+                     vc_plan_out& O, hipStream_t st, int phase) {
+  struct L { int64_t uvo, p2, repo, gpo, gwo, h2o, imgo; size_t gw_bytes, h2_bytes, img_bytes; int kv2, U, V; };
+  L lay[VC_PLAN_MAX_BLOCKS] = {};
+  bool any = false;
+  for (int b = 0; b < d->n_blocks; ++b) {
+    const vc_plan_block& B = d->blocks[b];
+    vc_plan_block_out& BO = O.blocks[b];
+    BO.uv = kAbsent;
+    BO.subm2d = vc_plan_table_out{};
+    if (!B.has_2d) continue;
+    any = true;
+    const int64_t n = S.blk[b].n;
+    L& l = lay[b];
+    l.kv2 = B.ksize2d[0] * B.ksize2d[1];
+    l.uvo = A.bump->take((size_t)std::max<int64_t>(n, 1) * 12);
+    l.p2 = A.bump->take((size_t)std::max<int64_t>(l.kv2 * n, 1) * 4);
+    l.repo = A.bump->take((size_t)std::max<int64_t>(n, 1) * 4);
+    BO.uv = vc_plan_view{A.id, 3, l.uvo, n};
+    vc_plan_table_out& T2 = BO.subm2d;
+    T2.present = 1;
+    T2.kv = l.kv2;
+    T2.n_in = T2.n_out = n;
+    T2.out_shape[0] = d->image_shape[0]; T2.out_shape[1] = d->image_shape[1]; T2.out_shape[2] = 0;
+    T2.pair_bwd = T2.order_fwd = T2.order_bwd = T2.grp_plan = kAbsent;
+    T2.in_indices = T2.out_indices = BO.uv;
+    T2.pair_fwd = vc_plan_view{A.id, (int32_t)n, l.p2, l.kv2};
+    T2.rep = vc_plan_view{A.id, 1, l.repo, n};
+    // pixels are clamped to [0, 1399] x [0, 599] and divided by the stride (vc_project_uv, spconv_backbone.py:76-81)
+    l.U = std::min<int>(d->image_shape[0], (1400 - 1) / B.uv_stride + 1);
+    l.V = std::min<int>(d->image_shape[1], (600 - 1) / B.uv_stride + 1);
+    l.h2o = l.gpo = l.gwo = l.imgo = -1;
+    if (!g_plan_image_2d) {
+      l.h2_bytes = vc_hash_workspace_bytes(n);
+      l.h2o = A.bump->take(l.h2_bytes);
+    }
+    if (d->need_grad) {
+      l.gpo = A.bump->take((size_t)std::max<int64_t>(2 * n, 1) * 4);
+      T2.grp_plan = vc_plan_view{A.id, (int32_t)n, l.gpo, 2};
+      l.gw_bytes = vc_group_plan_workspace_bytes(n);
+      l.gwo = A.bump->take(l.gw_bytes);
+    }
+  }
+  // one zone for the pixel images of all blocks: one clear
+  int64_t zone = -1;
+  size_t zone_bytes = 0;
+  if (any && g_plan_image_2d) {
+    for (int b = 0; b < d->n_blocks; ++b)
+      if (d->blocks[b].has_2d) {
+        lay[b].img_bytes = al256((size_t)d->batch_size * lay[b].U * lay[b].V * 4);
+        zone_bytes += lay[b].img_bytes;
+      }
+    zone = A.bump->take(zone_bytes);
+    size_t o = 0;
+    for (int b = 0; b < d->n_blocks; ++b)
+      if (d->blocks[b].has_2d) { lay[b].imgo = zone + (int64_t)o; o += lay[b].img_bytes; }
+  }
+  if (dry || !any) return VC_OK;
+  int rc;
+  if (phase == 1) {
+    for (int b = 0; b < d->n_blocks; ++b)
+      if (d->blocks[b].has_2d && d->need_grad && S.blk[b].n > 0) {
+        rc = vc_group_plan((const int32_t*)(A.base + lay[b].repo), S.blk[b].n, (int32_t*)(A.base + lay[b].gpo), A.base + lay[b].gwo,
+                           lay[b].gw_bytes, st);
+        if (rc != VC_OK) return rc;
+      }
+    return VC_OK;
+  }
+  if (phase != 2) return VC_OK;
+  const float* params = (const float*)(arena_a + S.params_off);
+  const bool diagnostics = d->debug_buf != nullptr || g_plan_uv_mode != 0;
+  if (g_plan_image_2d && !diagnostics) {
+    VC_CHECK_HIP(hipMemsetAsync(A.base + zone, 0, zone_bytes, st));
+    Uv2dArgs a{};
+    a.B = d->batch_size;
+    a.params = params;
+    unsigned bm = 0, br = 0;
+    for (int b = 0; b < d->n_blocks; ++b) {
+      const vc_plan_block& B = d->blocks[b];
+      const int64_t n = S.blk[b].n;
+      if (!B.has_2d || n == 0) continue;
+      Uv2dStage& T = a.st[a.n_stages++];
+      const L& l = lay[b];
+      T.coords = coords[b];
+      T.uv = (int32_t*)(A.base + l.uvo);
+      T.img = (int32_t*)(A.base + l.imgo);
+      T.pair = (int32_t*)(A.base + l.p2);
+      T.rep = (int32_t*)(A.base + l.repo);
+      T.n = n;
+      T.stride = B.uv_stride; T.U = l.U; T.V = l.V; T.SH = d->image_shape[0]; T.SW = d->image_shape[1];
+      T.ky = B.ksize2d[0]; T.kx = B.ksize2d[1]; T.dy = B.dilation2d[0]; T.dx = B.dilation2d[1];
+      // hard-coded range / voxel size of the reference (spconv_backbone.py:8): python floats (fp64) rounded to fp32 on use
+      const double vs = 0.05 * B.uv_stride;
+      T.vs = (float)vs; T.minx = (float)(0.0 + vs / 2); T.miny = (float)(-40.0 + vs / 2); T.minz = (float)(-3.0 + vs / 2);
+      T.block0_mark = bm; T.block0_rule = br;
+      bm += (unsigned)cdiv(n, 256); br += (unsigned)cdiv(n, 64);
+    }
+    if (a.n_stages == 0) return VC_OK;
+    rc = uv_mark_multi(a, bm, st);
+    if (rc != VC_OK) return rc;
+    hipLaunchKernelGGL(image_rulebook_multi_kernel, dim3(br), dim3(256), 0, st, a);
+    VC_CHECK_LAUNCH("image_rulebook_multi_kernel");
+    return VC_OK;
+  }
+  // block by block: the coordinate-hash form (vc_debug_set plan_image_2d = 0: A/B) and the diagnostics forms of the projection
+  for (int b = 0; b < d->n_blocks; ++b) {
+    const vc_plan_block& B = d->blocks[b];
+    const int64_t n = S.blk[b].n;
+    if (!B.has_2d || n == 0) continue;
+    const L& l = lay[b];
+    int32_t* uv = (int32_t*)(A.base + l.uvo);
+    if (g_plan_reprepare) {   // diagnostics: the parameter block written again right in front of its reader
       rc = vc_project_prepare(d->calib, d->trans, d->batch_size, (float*)(arena_a + S.params_off), st);
       if (rc != VC_OK) return rc;
     }
-    if (d->debug_buf)                      // diagnostics: every thread checks what it loads against the golden copy (vc_plan_begin)
-      rc = project_uv_debug(coords, n, (const float*)(arena_a + S.params_off), d->batch_size, B.uv_stride, uv, (int32_t*)d->debug_buf,
-                            (int)((d->debug_bytes - 256 - (int64_t)d->batch_size * 128) / 128), st);
+    if (diagnostics)
+      rc = project_uv_debug(coords[b], n, params, d->batch_size, B.uv_stride, uv, (int32_t*)d->debug_buf, d->debug_buf ? 4096 : 0,
+                            g_plan_uv_mode, d->trans != nullptr, st);
     else
-      rc = vc_project_uv(coords, n, (const float*)(arena_a + S.params_off), d->batch_size, B.uv_stride, uv, nullptr, st);
+      rc = vc_project_uv(coords[b], n, params, d->batch_size, B.uv_stride, uv, nullptr, st);
     if (rc != VC_OK) return rc;
-    int32_t* pair2 = (int32_t*)(A.base + p2);
-    int32_t* rep = (int32_t*)(A.base + repo);
+    int32_t* pair2 = (int32_t*)(A.base + l.p2);
+    int32_t* rep = (int32_t*)(A.base + l.repo);
     if (g_plan_image_2d) {
-      int32_t* img = (int32_t*)(A.base + imgo);
-      VC_CHECK_HIP(hipMemsetAsync(img, 0, img_bytes, st));
-      hipLaunchKernelGGL(image_mark_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const int32_t*)uv, n, d->batch_size, U, V, img);
+      int32_t* img = (int32_t*)(A.base + l.imgo);
+      VC_CHECK_HIP(hipMemsetAsync(img, 0, l.img_bytes, st));
+      hipLaunchKernelGGL(image_mark_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const int32_t*)uv, n, d->batch_size, l.U, l.V, img);
       VC_CHECK_LAUNCH("image_mark_kernel");
-      hipLaunchKernelGGL(image_rulebook_kernel, dim3((unsigned)cdiv(n, 64)), dim3(256), 0, st, (const int32_t*)uv, n, d->batch_size, U, V,
+      hipLaunchKernelGGL(image_rulebook_kernel, dim3((unsigned)cdiv(n, 64)), dim3(256), 0, st, (const int32_t*)uv, n, d->batch_size, l.U, l.V,
                          d->image_shape[0], d->image_shape[1], B.ksize2d[0], B.ksize2d[1], B.dilation2d[0], B.dilation2d[1],
                          (const int32_t*)img, pair2, rep);
       VC_CHECK_LAUNCH("image_rulebook_kernel");
     } else {
-      rc = vc_hash_build(uv, n, 2, d->image_shape, A.base + h2o, h2_bytes, st);
+      rc = vc_hash_build(uv, n, 2, d->image_shape, A.base + l.h2o, l.h2_bytes, st);
       if (rc != VC_OK) return rc;
-      rc = vc_subm_rulebook(uv, n, 2, d->image_shape, B.ksize2d, B.dilation2d, A.base + h2o, h2_bytes, pair2, rep, st);
+      rc = vc_subm_rulebook(uv, n, 2, d->image_shape, B.ksize2d, B.dilation2d, A.base + l.h2o, l.h2_bytes, pair2, rep, st);
       if (rc != VC_OK) return rc;
     }
   }
@@ -609,7 +722,7 @@ size_t vc_plan_begin_arena_bytes(const vc_plan_desc* d) {
   for (int b = 0; b < d->n_blocks; ++b)
     if (S.blk[b].early) {
       vc_plan_block_out O{};
-      if (block_tables(d, S, b, nullptr, kAbsent, nullptr, A, true, O, nullptr, 0) != VC_OK) return 0;
+      if (block_tables_3d(d, S, b, nullptr, kAbsent, nullptr, A, false, O, nullptr) != VC_OK) return 0;
     }
   return bump.off + 256;
 }
@@ -635,9 +748,10 @@ int vc_plan_begin(const vc_plan_desc* d, void* arena_a, size_t arena_a_bytes, in
   if (d->calib) {
     rc = vc_project_prepare(d->calib, d->trans, d->batch_size, (float*)(A + S.params_off), st);
     if (rc != VC_OK) return rc;
-    if (d->debug_buf) {   // diagnostics: golden copy at int32 [64, 64 + 32 B) of the buffer (project_uv_kernel<true>)
-      VC_REQUIRE(d->debug_bytes >= 256 + (int64_t)d->batch_size * 128 + 128, "vc_plan_begin: debug_buf too small");
-      VC_CHECK_HIP(hipMemcpyAsync((char*)d->debug_buf + 256, A + S.params_off, (size_t)d->batch_size * 128, hipMemcpyDeviceToDevice, st));
+    if (d->debug_buf) {   // diagnostics: [2] = the plan has augmentation parameters (the caller zeroed the buffer)
+      VC_REQUIRE(d->debug_bytes >= 256 + 128 * 4096, "vc_plan_begin: debug_buf too small");
+      hipLaunchKernelGGL(set_count_kernel, dim3(1), dim3(64), 0, st, (int32_t*)d->debug_buf + 2, (int32_t)(d->trans != nullptr));
+      VC_CHECK_LAUNCH("set_count_kernel");
     }
   }
   // ---- the chain: coordinates, keeps and counts of every level, nothing read back yet
@@ -663,8 +777,10 @@ int vc_plan_begin(const vc_plan_desc* d, void* arena_a, size_t arena_a_bytes, in
     cur = (const int32_t*)(A + S.in_kept_off);
     cur_n = cur_cap = S.n_in_keep;
   }
+  if (S.ws_zone_bytes > 0) VC_CHECK_HIP(hipMemsetAsync(A + S.ws_zone_off, 0, S.ws_zone_bytes, st));   // every conv's bitmap, once
   auto run_conv = [&](Conv& C, const vc_plan_conv& g) -> int {
     int r;
+    SpSkipClear skip_clear;   // (the zone is clear: vc_spconv_mark_count* skip their own fill)
     if (cur_cnt < 0)
       r = vc_spconv_mark_count(cur, cur_n, 3, d->batch_size, C.out_shape, g.ksize, g.stride, g.padding, g.dilation, A + C.ws_off, C.ws_bytes,
                                counts + C.cnt_out, st);
@@ -739,12 +855,8 @@ int vc_plan_begin(const vc_plan_desc* d, void* arena_a, size_t arena_a_bytes, in
   // ---- the counts' trip to the host starts here; the tables below run underneath it
   if (S.n_counts > 0) VC_CHECK_HIP(hipMemcpyAsync(host_counts, counts, (size_t)S.n_counts * 4, hipMemcpyDeviceToHost, st));
   VC_REQUIRE(plan_event_record(S, st) >= 0, "vc_plan_begin: cannot create / record the counts' event");
-  // ---- nothing below (and nothing vc_plan_finish enqueues behind it on this stream) runs before the caller's event: the TABLES
-  // are not built beside the previous step's backward pass (LOG.md A.15); the chain above and the counts' trip are not held back
-  bool any_early = false;
-  for (int b = 0; b < d->n_blocks; ++b) any_early = any_early || S.blk[b].early;
-  if (d->tables_wait_event && any_early) VC_CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)d->tables_wait_event, 0));
-  // ---- tables of the blocks whose row count is already known (the first block of VirConvL8x)
+  // ---- the 3-D SubM tables of the blocks whose row count is already known (the first block of VirConvL8x): integer kernels, under the
+  // counts' trip.  Every image-space table (the projection is the plan's only floating-point kernel) belongs to vc_plan_finish.
   S.early_out = vc_plan_out{};
   TableArena TA{A, 0, &bump};
   for (int b = 0; b < d->n_blocks; ++b) {
@@ -752,7 +864,7 @@ int vc_plan_begin(const vc_plan_desc* d, void* arena_a, size_t arena_a_bytes, in
     if (!K.early) continue;
     const int32_t* coords = K.coords_off < 0 ? d->indices : (const int32_t*)(A + K.coords_off);
     const vc_plan_view cv = K.coords_off < 0 ? kAbsent : vc_plan_view{0, 4, K.coords_off, K.n};
-    rc = block_tables(d, S, b, coords, cv, A, TA, false, S.early_out.blocks[b], st, 0);
+    rc = block_tables_3d(d, S, b, coords, cv, A, TA, true, S.early_out.blocks[b], st);
     if (rc != VC_OK) return rc;
   }
   S.magic = kPlanMagic;
@@ -819,13 +931,22 @@ static int finish_impl(const vc_plan_desc* d, PlanState& S, char* arena_a, char*
   }
   const int32_t* cur = d->input_discard ? (const int32_t*)(arena_a + S.in_kept_off) : d->indices;
   vc_plan_view cur_view = d->input_discard ? O.input_kept_indices : kAbsent;
+  const int32_t* coords2d[VC_PLAN_MAX_BLOCKS] = {};   // each block's coordinates, for the image-space branch below
+  // the forward pair tables of all strided convs: one zone at the head of arena B, filled with -1 by ONE launch
+  size_t pf_total = 0;
+  for (int b = 0; b < d->n_blocks; ++b)
+    if (d->blocks[b].has_down) pf_total += al256((size_t)std::max<int64_t>(S.blk[b].down.kv * S.blk[b].down.n_out, 1) * 4);
+  if (d->has_tail) pf_total += al256((size_t)std::max<int64_t>(S.tail.kv * S.tail.n_out, 1) * 4);
+  Bump2 pfz;
+  pfz.off = (size_t)bump.take(pf_total);
+  if (!dry && phase == 0 && pf_total > 0) VC_CHECK_HIP(hipMemsetAsync(arena_b + pfz.off, 0xFF, pf_total, st));
   for (int b = 0; b < d->n_blocks; ++b) {
     const vc_plan_block& B = d->blocks[b];
     Blk& K = S.blk[b];
     vc_plan_block_out& BO = O.blocks[b];
     int rc;
     if (B.has_down) {
-      rc = conv_tables(d, S, K.down, B.down, cur, cur_view, arena_a, TB, dry, BO.down, st, phase);
+      rc = conv_tables(d, S, K.down, B.down, cur, cur_view, arena_a, TB, dry, BO.down, st, phase, &pfz);
       if (rc != VC_OK) return rc;
       cur = (const int32_t*)(arena_a + K.down.out_idx_off);
       cur_view = vc_plan_view{0, 4, K.down.out_idx_off, K.down.n_out};
@@ -833,9 +954,10 @@ static int finish_impl(const vc_plan_desc* d, PlanState& S, char* arena_a, char*
       BO.down = vc_plan_table_out{};
     }
     if (!K.early) {
-      rc = block_tables(d, S, b, cur, cur_view, arena_a, TB, dry, BO, st, phase);
+      rc = block_tables_3d(d, S, b, cur, cur_view, arena_a, TB, !dry && phase == 0, BO, st);
       if (rc != VC_OK) return rc;
     }
+    coords2d[b] = cur;
     BO.n = K.n;
     BO.n_keep = B.discard ? K.n_keep : 0;
     BO.keep = BO.kept_indices = kAbsent;
@@ -848,7 +970,11 @@ static int finish_impl(const vc_plan_desc* d, PlanState& S, char* arena_a, char*
   }
   O.tail = vc_plan_table_out{};
   if (d->has_tail) {
-    const int rc = conv_tables(d, S, S.tail, d->tail, cur, cur_view, arena_a, TB, dry, O.tail, st, phase);
+    const int rc = conv_tables(d, S, S.tail, d->tail, cur, cur_view, arena_a, TB, dry, O.tail, st, phase, &pfz);
+    if (rc != VC_OK) return rc;
+  }
+  {
+    const int rc = tables_2d(d, S, coords2d, arena_a, TB, dry, O, st, phase);
     if (rc != VC_OK) return rc;
   }
   if (need) *need = bump.off + 256;
@@ -882,8 +1008,16 @@ int vc_plan_finish(const vc_plan_desc* d, vc_plan_state* state, void* arena_a, v
     if (rc != VC_OK) return rc;
   }
   if (arena_b_bytes < need) { set_error("vc_plan_finish: arena_b too small (%zu < %zu)", arena_b_bytes, need); return VC_ECAPACITY; }
-  if (d->tables_wait_event) VC_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)d->tables_wait_event, 0));
+  // the integer tables (pair tables of the strided convs, 3-D SubM tables) right away: they may run beside anything
   rc = finish_impl(d, S, (char*)arena_a, (char*)arena_b, arena_b_bytes, out, false, nullptr, (hipStream_t)stream, 0);
+  if (rc != VC_OK) return rc;
+  // ... the image-space branch -- the projection, the plan's only floating-point kernel -- behind the caller's event: beside the conv
+  // kernels of a running feature pass it computes wrong pixels in lanes 48-63 of some waves (LOG.md A.15 / A.17)
+  if (d->tables_wait_event) VC_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)d->tables_wait_event, 0));
+  {
+    PlanState T = S;
+    rc = finish_impl(d, T, (char*)arena_a, (char*)arena_b, arena_b_bytes, nullptr, false, nullptr, (hipStream_t)stream, 2);
+  }
   if (rc == VC_OK) S.finished = 1;
   return rc;
 }
@@ -896,20 +1030,6 @@ int vc_plan_finish_backward(const vc_plan_desc* d, vc_plan_state* state, void* a
   VC_REQUIRE(S.magic == kPlanMagic && S.finished, "vc_plan_finish_backward: call vc_plan_finish first");
   if (!d->need_grad) return VC_OK;
   hipStream_t st = (hipStream_t)stream;
-  {  // blocks whose forward tables vc_plan_begin built in arena A: the same walk over the same layout
-    PlanState T = S;
-    Bump2 bump;
-    layout_chain(d, T, bump);
-    TableArena TA{(char*)arena_a, 0, &bump};
-    for (int b = 0; b < d->n_blocks; ++b) {
-      const Blk& K = S.blk[b];
-      if (!K.early) continue;
-      const int32_t* coords = K.coords_off < 0 ? d->indices : (const int32_t*)((char*)arena_a + K.coords_off);
-      vc_plan_block_out O{};
-      rc = block_tables(d, S, b, coords, kAbsent, (char*)arena_a, TA, false, O, st, 1);
-      if (rc != VC_OK) return rc;
-    }
-  }
   PlanState T = S;
   return finish_impl(d, T, (char*)arena_a, (char*)arena_b, arena_b_bytes, nullptr, false, nullptr, st, 1);
 }

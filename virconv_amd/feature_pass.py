@@ -322,7 +322,6 @@ class PassFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gouts):
-        ops.note_backward()
         be = ops.get_backend()
         lib = be.lib
         call = ctx.call

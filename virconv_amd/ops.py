@@ -175,15 +175,6 @@ def build_sparse_rulebook(indices: torch.Tensor, spatial_shape, batch_size: int,
     return finish_sparse_rulebook(begin_sparse_rulebook(indices, spatial_shape, batch_size, ksize, stride, padding, dilation))
 
 
-BACKWARD_LAUNCHES = 0   # backward passes enqueued so far (any autograd node of this file / feature_pass): backbone._PlanScope reads it
-
-
-def note_backward() -> None:
-    """Called by every backward node: the next geometry plan must not build its tables beside this backward pass (LOG.md A.15)."""
-    global BACKWARD_LAUNCHES
-    BACKWARD_LAUNCHES += 1
-
-
 class SparseConvFunction(torch.autograd.Function):
     """y = conv(features, weight | rulebook); replaces spconv's SparseConvFunction / SubMConvFunction /
     SparseImplicitGemmFunction."""
@@ -200,7 +191,6 @@ class SparseConvFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        note_backward()
         features, weight = ctx.saved_tensors
         dx, dw = _conv_backward(ctx.rb, ctx.inverse, features, weight, grad_out.contiguous(), ctx.needs_input_grad[0],
                                 ctx.needs_input_grad[1])
@@ -297,7 +287,6 @@ class ConvBNReLUFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        note_backward()
         be = get_backend()
         x, weight, y_raw, mean, var, gamma, beta = ctx.saved_tensors
         eps, relu = ctx.cfg
@@ -431,7 +420,6 @@ class GatherRowsFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        note_backward()
         (keep,) = ctx.saved_tensors
         return get_backend().scatter_rows(grad_out.contiguous(), keep, ctx.n_in), None
 
@@ -521,7 +509,6 @@ class BNReLUFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        note_backward()
         be = get_backend()
         x, mean, var, gamma, beta = ctx.saved_tensors
         training, eps, relu = ctx.cfg
