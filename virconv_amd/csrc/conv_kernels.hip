@@ -88,38 +88,15 @@ __device__ __forceinline__ unsigned pk_bf16_rne(float a, float b) {   // a in th
   const f32x2 v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
-// Round 5: the differences x - h and (x - h) - m as ONE instruction per element.  v_dot2c_f32_bf16 d, a, b computes
-// d += a.lo * b.lo + a.hi * b.hi on packed bf16 pairs: with a = (-1, 0) or (0, -1) it subtracts one half of the packed piece from the
-// fp32 value -- no shift / mask to widen the piece first (3.5 instead of 5.5 vector-ALU operations per element; the kernels issue-bound
-// on exactly these, profiles/r04_mfma_busy.md addendum 2).  The subtraction is exact as before (the products are exact, the sum has
-// one non-zero bf16 term and an fp32 term that differ by a representable amount).  -DVC_SPLIT_DOT2=0: the shift / mask form (A/B).
-#ifndef VC_SPLIT_DOT2
-#define VC_SPLIT_DOT2 1
-#endif
-__device__ __forceinline__ float sub_bf16_lo(float x, unsigned pk) {   // x - (low half of pk)
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, 0x0000BF80u), __builtin_bit_cast(bf16x2, pk), x, false);
-}
-__device__ __forceinline__ float sub_bf16_hi(float x, unsigned pk) {   // x - (high half of pk)
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, 0xBF800000u), __builtin_bit_cast(bf16x2, pk), x, false);
-}
 __device__ __forceinline__ void split3(const float* f, u32x2& h, u32x2& m, u32x2& l) {
   h.x = pk_bf16_rne(f[0], f[1]);
   h.y = pk_bf16_rne(f[2], f[3]);
-#if VC_SPLIT_DOT2
-  const float r0 = sub_bf16_lo(f[0], h.x), r1 = sub_bf16_hi(f[1], h.x);   // exact
-  const float r2 = sub_bf16_lo(f[2], h.y), r3 = sub_bf16_hi(f[3], h.y);
-  m.x = pk_bf16_rne(r0, r1);
-  m.y = pk_bf16_rne(r2, r3);
-  const float s0 = sub_bf16_lo(r0, m.x), s1 = sub_bf16_hi(r1, m.x);       // exact, bf16 values
-  const float s2 = sub_bf16_lo(r2, m.y), s3 = sub_bf16_hi(r3, m.y);
-#else
   const float r0 = f[0] - __uint_as_float(h.x << 16), r1 = f[1] - __uint_as_float(h.x & 0xFFFF0000u);   // exact
   const float r2 = f[2] - __uint_as_float(h.y << 16), r3 = f[3] - __uint_as_float(h.y & 0xFFFF0000u);
   m.x = pk_bf16_rne(r0, r1);
   m.y = pk_bf16_rne(r2, r3);
   const float s0 = r0 - __uint_as_float(m.x << 16), s1 = r1 - __uint_as_float(m.x & 0xFFFF0000u);       // exact, bf16 values
   const float s2 = r2 - __uint_as_float(m.y << 16), s3 = r3 - __uint_as_float(m.y & 0xFFFF0000u);
-#endif
   l.x = pk_bf16_rne(s0, s1);
   l.y = pk_bf16_rne(s2, s3);
 }

@@ -93,9 +93,10 @@ static constexpr int64_t kPackMinRows = 60000;
 // every route: a unit below the threshold would otherwise pack into the library's scratch right before its own launch), the
 // threshold above otherwise; 0 / 1 = never / always (A/B)
 int g_pass_pack_all = -1;
-extern int g_f32_split;   // conv_kernels.hip
-static inline int64_t pack_min_rows() {
-  const bool all = g_pass_pack_all < 0 ? g_f32_split != 0 : g_pass_pack_all != 0;
+static inline int64_t pack_min_rows(const vc_pass_program* p) {
+  // p->pack_all: the caller's snapshot of "split products on" at forward time (not the library global: a switch moved between the
+  // forward and the backward pass of one call would make their layouts disagree -- ADVICE r4)
+  const bool all = g_pass_pack_all < 0 ? p->pack_all != 0 : g_pass_pack_all != 0;
   return all ? 0 : kPackMinRows;
 }
 
@@ -121,7 +122,7 @@ static void fwd_layout(const vc_pass_program* p, FwdLayout& L) {
     const vc_pass_unit& u = p->units[o.unit];
     const vc_pass_table& t = p->tables[o.table];
     const int flags = t.sorted_rows ? VC_CONV_SORTED_ROWS : 0;
-    if (p->operand_type == VC_OPERAND_F32 && t.n_out >= pack_min_rows()) {
+    if (p->operand_type == VC_OPERAND_F32 && t.n_out >= pack_min_rows(p)) {
       const size_t pk = vc_conv_packed_weight_floats(u.cin, u.cout, t.kv, 0);
       if (pk) L.wpk_off[i] = (int64_t)bump.take(pk * sizeof(float));
     }
@@ -251,7 +252,7 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
     std::vector<float*> dst;
     for (int i = 0; i < p->n_ops; ++i) {
       const vc_pass_op& o = p->ops[i];
-      if (o.kind != VC_PASS_UNIT || !needs0[o.src] || p->tables[o.table].n_in < pack_min_rows()) continue;
+      if (o.kind != VC_PASS_UNIT || !needs0[o.src] || p->tables[o.table].n_in < pack_min_rows(p)) continue;
       const size_t pk = vc_conv_packed_weight_floats(p->units[o.unit].cin, p->units[o.unit].cout, p->tables[o.table].kv, 1);
       if (!pk) continue;
       idx.push_back(i);

@@ -1013,8 +1013,10 @@ int vc_plan_finish(const vc_plan_desc* d, vc_plan_state* state, void* arena_a, v
   if (rc != VC_OK) return rc;
   // ... the image-space branch -- the projection, the plan's only floating-point kernel -- behind the caller's event: beside the conv
   // kernels of a running feature pass it computes wrong pixels in lanes 48-63 of some waves (LOG.md A.15 / A.17)
-  if (d->tables_wait_event) VC_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)d->tables_wait_event, 0));
-  {
+  bool any2d = false;
+  for (int b = 0; b < d->n_blocks; ++b) any2d = any2d || d->blocks[b].has_2d != 0;
+  if (d->tables_wait_event && any2d) VC_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)d->tables_wait_event, 0));
+  if (any2d) {
     PlanState T = S;
     rc = finish_impl(d, T, (char*)arena_a, (char*)arena_b, arena_b_bytes, nullptr, false, nullptr, (hipStream_t)stream, 2);
   }

@@ -289,6 +289,10 @@ def _fill(P: _Program, feats, ctx, training: bool) -> Optional[_Call]:
     c_prog.tables, c_prog.n_tables = c_tables, len(tables)
     c_prog.keeps, c_prog.n_keeps = c_keeps, len(keeps)
     c_prog.training, c_prog.operand_type = 1 if training else 0, _lib.OPERAND_TYPES[ops.MFMA_OPERAND]
+    # snapshot of the split-products switch: the forward and the backward arena layout of this call both follow it
+    split = C.c_int64(0)
+    be_ = ops.get_backend()
+    c_prog.pack_all = 1 if (be_.lib.vc_debug_get(b"f32_split", C.byref(split)) == 0 and split.value != 0) else 0
     call.c_prog, call.c_bufs, call.c_units, call.c_tables, call.c_keeps = c_prog, c_bufs, c_units, c_tables, c_keeps
     call.keep_alive = (tables, keeps, feats)
     return call
