@@ -337,7 +337,10 @@ class _PlanScope:
         if self.on_gpu and self.guard is not None:
             self.side.wait_event(self.guard)
 
-    def publish(self, plan):
+    def publish(self, plan, defer_wait=False):
+        """`defer_wait`: the main stream does NOT wait here; the event goes into plan["_fwd_ready"] and the caller waits for it where it
+        first reads the plan (VirConv8x: the LiDAR stream's pass starts behind its own tables, plan["_lidar_ready"], while the guarded
+        image-space branch of the virtual-point stream is still behind the previous step)."""
         if self.on_gpu:
             if self.deferred:
                 # the forward pass waits for the tables IT reads.  The group-plan sorts and backward row orders are ENQUEUED by
@@ -345,8 +348,15 @@ class _PlanScope:
                 # stand between the row counts and the first forward kernel -- and run on the plan stream underneath the forward
                 fwd_ready = torch.cuda.Event()
                 fwd_ready.record(self.side)
-                self.main.wait_event(fwd_ready)
+                if defer_wait:
+                    plan["_fwd_ready"] = fwd_ready
+                else:
+                    self.main.wait_event(fwd_ready)
                 plan["_deferred"] = (self.side, self.deferred)
+            elif defer_wait:
+                fwd_ready = torch.cuda.Event()
+                fwd_ready.record(self.side)
+                plan["_fwd_ready"] = fwd_ready
             else:
                 self.main.wait_stream(self.side)
             # a native plan lives in two arenas (every structure is a view of one of them): marking those is marking everything
@@ -775,10 +785,10 @@ class VirConv8x(nn.Module):
         return first, co, stages, chain
 
     def _begin_lidar(self, idx, batch_size, batch_dict, deferred):
-        """First half of the LiDAR stream's native chain plan: coordinates and row counts, no table (native_plan.ChainPlan)."""
+        """First half of the LiDAR stream's native chain plan (native_plan.ChainPlan): coordinates, row counts, the first 3-D table."""
         _, co, _, chain = self._lidar_chain()
         return native_plan.ChainPlan(self, "8x-lidar", chain, co, idx, batch_size, None, None, [None] * 4, 0.0, batch_dict,
-                                     NRConvBlock.IMAGE_SHAPE, None, deferred, None, True)
+                                     NRConvBlock.IMAGE_SHAPE, None, deferred, None, False)
 
     def _finish_lidar(self, cp, guard, arenas):
         first, co, stages, _ = self._lidar_chain()
@@ -841,29 +851,30 @@ class VirConv8x(nn.Module):
             idx_m = {rid: batch_dict["voxel_coords_mm" + rid].int() for rid in rids} if self.mm else {}
             if (self.training and all(native_plan.usable(v) for v in idx_l.values())
                     and all(native_plan.usable(v, blocks) for v in idx_m.values())):
-                # every chain natively, in two sweeps: first the coordinate / count chain of EVERY plan (vc_plan_begin, no tables), then
-                # -- the counts have arrived meanwhile -- every plan's tables behind the guard event (PLAN_GUARD: a table kernel
-                # never runs beside the previous step's backward pass, and no count read waits behind the guard)
-                begun_l = [(rid, self._begin_lidar(idx_l[rid], batch_size, batch_dict, scope.deferred)) for rid in rids]
-                begun_m = []
-                for i, rid in enumerate(rids if self.mm else []):
-                    trans_param, tags = mm_inputs(i, rid)
-                    cp = native_plan.begin(self, blocks, None, idx_m[rid], batch_size, calib, trans_param, tags, self.layer_discard_rate,
-                                           batch_dict, NRConvBlock.IMAGE_SHAPE,
-                                           input_discard_tag=(f"mm_input{rid}" if active else None), deferred=scope.deferred)
-                    begun_m.append((rid, cp, trans_param))
-                for rid, cp in begun_l:
-                    rbs, _ = self._finish_lidar(cp, scope.guard, arenas)
+                # every chain natively, one after the other (begin -> one count read -> tables).  The LiDAR stream's tables are integer
+                # work and overlap the previous step freely; only the image-space branch of the virtual-point stream waits for the guard
+                # event (PLAN_GUARD), inside its own vc_plan_finish -- behind its coordinate chain and count read, so no host read ever
+                # waits behind the guard
+                for rid in rids:
+                    rbs, _ = self._finish_lidar(self._begin_lidar(idx_l[rid], batch_size, batch_dict, scope.deferred), None, arenas)
                     arenas.append(idx_l[rid])
                     plan["lidar"][rid] = (idx_l[rid], rbs)
-                for rid, cp, trans_param in begun_m:
-                    stages, _, keep0, kept0, ar = native_plan.finish_nrconv(cp, blocks, scope.guard)
+                begun_m = list(rids) if self.mm else []
+                if scope.on_gpu and begun_m:      # the LiDAR stream's pass need not wait for the guarded rest
+                    plan["_lidar_ready"] = torch.cuda.Event()
+                    plan["_lidar_ready"].record(scope.side)
+                for i, rid in enumerate(begun_m):
+                    trans_param, tags = mm_inputs(i, rid)
+                    stages, _, keep0, kept0, ar = native_plan.build(self, blocks, None, idx_m[rid], batch_size, calib, trans_param, tags,
+                                                                    self.layer_discard_rate, batch_dict, NRConvBlock.IMAGE_SHAPE,
+                                                                    input_discard_tag=(f"mm_input{rid}" if active else None),
+                                                                    deferred=scope.deferred, guard=scope.guard)
                     arenas.extend(ar)
                     arenas.append(idx_m[rid])
                     plan["mm"][rid] = {"keep0": keep0, "in_indices": kept0 if active else idx_m[rid], "stages": stages,
                                        "trans_param": trans_param}
                 plan["_arenas"] = arenas
-                return scope.publish(plan)
+                return scope.publish(plan, defer_wait="_lidar_ready" in plan)
             # operator-by-operator plans (the eval path over the x-concatenated tensor; empty / CPU tensors): the whole plan waits
             scope.guard_tables()
             if self.training:
@@ -921,6 +932,8 @@ class VirConv8x(nn.Module):
             if not torch.is_tensor(calib):
                 calib = ops.calib_tensor(calib, batch_dict["voxel_features_mm"].device)
         plan = self.build_plan(batch_dict, rids, batch_size, calib) if self.plan_ahead else None
+        if plan is not None and "_lidar_ready" in plan:
+            torch.cuda.current_stream().wait_event(plan.pop("_lidar_ready"))
 
         if self.training:
             for rid in rids:
@@ -974,6 +987,8 @@ class VirConv8x(nn.Module):
                     "multi_scale_3d_features" + rid: {"x_conv1": None, "x_conv2": None, "x_conv3": s3, "x_conv4": s4},
                     "multi_scale_3d_strides" + rid: dict(strides)})
 
+        if plan is not None and "_fwd_ready" in plan:     # everything else of the plan (the virtual-point stream's tables)
+            torch.cuda.current_stream().wait_event(plan.pop("_fwd_ready"))
         if self.mm:
             blocks = [(self.vir_conv1, 1), (self.vir_conv2, 2), (self.vir_conv3, 4), (self.vir_conv4, 8)]
             for i, rid in enumerate(rids):

@@ -21,7 +21,8 @@ SOURCES = {
     "index_kernels.hip": ["-ffp-contract=off"],
     # MFMA accumulators in VGPRs (gfx950 has a unified register file): hipcc's default keeps them in AGPRs and shuttles them with
     # v_accvgpr_read/write around every branch (48 moves in the hot loop of gather_gemm_v2<64,32>) -- 68 VGPR + 12 AGPR -> 68 VGPR,
-    # 6 -> 7 waves per SIMD, and these kernels' throughput follows their occupancy
+    # 6 -> 7 waves per SIMD, and these kernels' throughput follows their occupancy.  (Round 5 checked whether this flag is
+    # an ingredient of LOG.md A.17 -- VIRCONV_NO_VGPR_FORM=1 builds without it: it is not, the unguarded loop fails the same way.)
     "conv_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
     "bn_kernels.hip": [],
     "pool_kernels.hip": ["-ffp-contract=off"],
@@ -33,6 +34,8 @@ SOURCES = {
     "pass.hip": [],
     "plan.hip": [],
 }
+if os.environ.get("VIRCONV_NO_VGPR_FORM") == "1":   # A/B builds only (LOG.md A.17): MFMA accumulators in AGPRs
+    SOURCES["conv_kernels.hip"] = []
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 
 
