@@ -537,6 +537,12 @@ int vc_nms(const float* boxes, int64_t n, float thresh, int rotated, int64_t* ke
 size_t vc_bev_pairs_workspace_bytes(int batch_size, const int32_t* host_spatial_shape /* D, H, W */);
 int vc_bev_pairs(const int32_t* indices, int64_t n, int batch_size, const int32_t* host_spatial_shape, int ky, int kx, int32_t* pair,
                  void* ws, size_t ws_bytes, void* stream);
+/* The transposed pair table of vc_bev_pairs for the stem's backward pass: pair_bwd (D * ky * kx, n) int32, pair_bwd[k][i] = the BEV
+ * cell (b * H + y') * W + x' that voxel row i = (b, z, y, x) feeds through offset k = (kz, a, c) -- kz must be the row's own z -- or -1
+ * (training through base_bev_backbone.py:31-38: dX = a forward-form gather-GEMM of dY over this table, dW = the weight-gradient
+ * kernel over vc_bev_pairs' table).                                                                                          */
+int vc_bev_pairs_backward(const int32_t* indices, int64_t n, int batch_size, const int32_t* shape /* D, H, W */, int ky, int kx,
+                          int32_t* pair_bwd, void* stream);
 int vc_nhwc_to_nchw(const float* x, int batch_size, int64_t hw, int c, const float* scale /* nullable */, const float* shift,
                     int relu, float* out, void* stream);
 

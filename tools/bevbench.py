@@ -110,6 +110,27 @@ def main():
     print(f"sparse stem    forward: conv on the sparse rows {t_sparse:8.1f} us vs padded dense + MIOpen conv {t_dense:8.1f} us "
           f"(max rel diff {err:.1e}); conv+BN+ReLU {t_stem:8.1f} us vs {t_blk:8.1f} us")
 
+    # ---- D (round 5): TRAINING through the stem -- forward + backward (d features, d weight, BatchNorm in train mode), sparse vs dense
+    blk_t = torch.nn.Sequential(torch.nn.ZeroPad2d(1), conv, torch.nn.BatchNorm2d(64, eps=1e-3, momentum=0.01).to(dev), torch.nn.ReLU()).train()
+    stem_t = SparseBEVStem(blk_t)
+
+    def train_sparse():
+        f = feats.clone().requires_grad_(True)
+
+        class _Tt:
+            features, indices, spatial_shape, batch_size = f, idx, shape, bs
+        conv.weight.grad = None
+        stem_t(_Tt).sum().backward()
+
+    def train_dense():
+        f = feats.clone().requires_grad_(True)
+        conv.weight.grad = None
+        d = ops.to_dense(f, idx, shape, bs, pad=(1, 1))
+        blk_t[3](blk_t[2](conv(d.view(bs, -1, 202, 178)))).sum().backward()
+
+    t_ts, t_td = timeit(train_sparse, 10), timeit(train_dense, 10)
+    print(f"sparse stem    fwd+bwd (train-mode BatchNorm, d features + d weight): {t_ts:8.1f} us vs the dense recipe {t_td:8.1f} us")
+
 
 if __name__ == "__main__":
     main()

@@ -111,6 +111,7 @@ SIGNATURES = {
     "vc_bn_relu_backward": (_I, [_P, _P, _I, _I, _I64, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _SZ, _P]),
     "vc_bev_pairs_workspace_bytes": (_SZ, [_I, _P]),
     "vc_bev_pairs": (_I, [_P, _I64, _I, _P, _I, _I, _P, _P, _SZ, _P]),
+    "vc_bev_pairs_backward": (_I, [_P, _I64, _I, _P, _I, _I, _P, _P]),
     "vc_nhwc_to_nchw": (_I, [_P, _I, _I64, _I, _P, _P, _I, _P, _P]),
     "vc_plan_begin_arena_bytes": (_SZ, [_P]),
     "vc_plan_begin": (_I, [_P, _P, _SZ, _P, _P, _P]),

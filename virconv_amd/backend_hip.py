@@ -548,7 +548,7 @@ class HipBackend:
 
     def bev_stem_conv(self, features: torch.Tensor, indices: torch.Tensor, spatial_shape, batch_size: int, w_passes, cout: int,
                       scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, relu: bool = False,
-                      want_nhwc: bool = False):
+                      want_nhwc: bool = False, want_pairs: bool = False):
         """First BEV conv on the sparse rows (base_bev_backbone.py:31-38 over height_compression.py:27-31):
         features (n, C) at indices (n, 4) [b, z, y, x] of a (D, H, W) grid -> (B, cout, H, W) = Conv2d(C * D -> cout, k, pad k // 2)
         of the height-compressed map, then y * scale + shift (BatchNorm) and ReLU folded into the layout pass.
@@ -589,11 +589,44 @@ class HipBackend:
                                                                None, _ptr(out), st), "vc_conv_backward_input_epilogue")
             acc, k0 = out, k0 + kvp
         if want_nhwc:
-            return acc
+            return (acc, pair) if want_pairs else acc
         dense = torch.empty((batch_size, cout, H, W), dtype=torch.float32, device=dev)
         check(self.lib.vc_nhwc_to_nchw(_ptr(acc), batch_size, H * W, cout, _ptr(scale), _ptr(shift), 1 if relu else 0, _ptr(dense), st),
               "vc_nhwc_to_nchw")
         return dense
+
+    def bev_stem_conv_backward(self, features: torch.Tensor, indices: torch.Tensor, spatial_shape, batch_size: int, w_passes, cout: int,
+                               pair: torch.Tensor, gy: torch.Tensor, need_dx: bool, need_dw: bool):
+        """Backward of `bev_stem_conv(..., want_nhwc=True)`: gy (cells, cout) -> (d features (n, C) | None, per-pass weight gradients
+        [(cout, kv_pass, C), ...] | None).  dX: the forward-form gather-GEMM of gy over the transposed table (vc_bev_pairs_backward;
+        a pass (C, kv_pass, cout) is exactly the (output channels, offsets, source channels) layout that kernel reads);
+        dW: the weight-gradient kernel over the forward table `pair` (kept from the forward call)."""
+        features = _need(features, torch.float32, "features")
+        indices = _need(indices, torch.int32, "indices")
+        gy = _need(gy, torch.float32, "grad_out")
+        n, c = features.shape
+        D, H, W = (int(v) for v in spatial_shape)
+        kv_total = int(pair.shape[0])
+        k2 = kv_total // D
+        ky = kx = int(round(k2 ** 0.5))
+        dx, dws = None, None
+        if need_dx:
+            pair_bwd = torch.empty((kv_total, n), dtype=torch.int32, device=features.device)
+            check(self.lib.vc_bev_pairs_backward(_ptr(indices), n, batch_size, i32arr((D, H, W)), ky, kx, _ptr(pair_bwd), _stream()),
+                  "vc_bev_pairs_backward")
+            k0 = 0
+            for w in w_passes:
+                kvp = int(w.shape[1])
+                part = self.conv_forward(gy, w, pair_bwd[k0:k0 + kvp])       # (n, C)
+                dx = part if dx is None else dx + part
+                k0 += kvp
+        if need_dw:
+            dws, k0 = [], 0
+            for w in w_passes:
+                kvp = int(w.shape[1])
+                dws.append(self.conv_backward_weight(features, gy, pair[k0:k0 + kvp], (cout, kvp, c)))
+                k0 += kvp
+        return dx, dws
 
     def from_dense(self, dense: torch.Tensor, indices: torch.Tensor, spatial_shape, batch_size: int, pad=(0, 0)) -> torch.Tensor:
         dense = _need(dense, torch.float32, "dense")

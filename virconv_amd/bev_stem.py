@@ -6,9 +6,12 @@ Reference: ``HeightCompression.forward`` folds the height axis of ``encoded_spco
 (pcdet/models/backbones_2d/base_bev_backbone.py:31-38) -- a dense 41.5 GFLOP conv over a map in which ~70 % of the cells hold no
 voxel.  Seen from the sparse tensor it is a sparse conv from the (b, z, y, x) rows onto the (b, y, x) cells with kernel (4, 3, 3):
 4.7 GFLOP on the synthetic KITTI frames.  ``SparseBEVStem`` runs it that way (vc_bev_pairs -> the gather-GEMM in two passes of 18
-kernel offsets -> vc_nhwc_to_nchw with BatchNorm + ReLU folded in) whenever no gradient is needed (inference, BASELINE configs[1]);
-when a gradient IS needed it runs the reference recipe on the dense map (HeightCompression(BEV_PAD=1) form), so training is
-unchanged.  Parameters stay where they are (the BaseBEVBackbone's own Conv2d / BatchNorm2d: same state_dict keys).
+kernel offsets -> vc_nhwc_to_nchw with BatchNorm + ReLU folded in).  Round 5: also when a gradient is needed (training through the
+stem, tools/train_utils/train_utils.py:47): the conv is one autograd node over the sparse rows -- dX = a forward-form gather-GEMM of dY
+over the transposed table (vc_bev_pairs_backward), dW = the weight-gradient kernel over the forward table -- and BatchNorm2d + ReLU are
+the BEV backbone's own modules applied to the NHWC rows viewed as a channels-last (B, C, H, W) tensor (statistics over the dense
+extent, empty cells included, exactly as the dense recipe).  Parameters stay where they are (the BaseBEVBackbone's own Conv2d /
+BatchNorm2d: same state_dict keys).
 """
 from __future__ import annotations
 
@@ -18,6 +21,34 @@ from torch import nn
 from . import ops
 
 MAX_PASS_OFFSETS = 32      # the gather-GEMM walks a 32-bit mask of kernel offsets per block
+
+
+class _StemConvFunction(torch.autograd.Function):
+    """y (cells, Cout) = the first BEV conv over the sparse rows; cells = every (b, y, x) of the map in dense order (NHWC rows).
+    Backward: d features and d weight (the Conv2d parameter, (Cout, C * D, ky, kx)) through the sparse kernels."""
+
+    @staticmethod
+    def forward(ctx, feats, weight, indices, spatial_shape, batch_size, passes):
+        be = ops.get_backend()
+        y, pair = be.bev_stem_conv(feats, indices, spatial_shape, batch_size, passes, weight.shape[0], want_nhwc=True, want_pairs=True)
+        ctx.save_for_backward(feats, weight)
+        ctx.geom = (indices, tuple(int(v) for v in spatial_shape), int(batch_size), passes, pair)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        feats, weight = ctx.saved_tensors
+        indices, shape, bs, passes, pair = ctx.geom
+        be = ops.get_backend()
+        dx, dws = be.bev_stem_conv_backward(feats, indices, shape, bs, passes, weight.shape[0], pair, gy.contiguous(),
+                                            ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        dw = None
+        if dws is not None:
+            cout, cd, ky, kx = weight.shape
+            depth = shape[0]
+            full = torch.cat(dws, 1)                                           # (Cout, D * ky * kx, C), offsets (z, ky, kx) row-major
+            dw = full.view(cout, depth, ky, kx, cd // depth).permute(0, 4, 1, 2, 3).reshape(cout, cd, ky, kx)   # channel = c * D + z
+        return dx, dw, None, None, None, None
 
 
 def pack_stem_weight(weight: torch.Tensor, depth: int):
@@ -57,8 +88,7 @@ class SparseBEVStem(nn.Module):
     def sparse_path_usable(self, t) -> bool:
         conv, bn = self._block[1], self._block[2]
         be = ops.get_backend()
-        needs_grad = torch.is_grad_enabled() and (t.features.requires_grad or conv.weight.requires_grad)
-        return bool(hasattr(be, "bev_stem_conv") and t.features.is_cuda and not needs_grad and t.features.shape[1] in (16, 32, 64)
+        return bool(hasattr(be, "bev_stem_conv") and t.features.is_cuda and t.features.shape[1] in (16, 32, 64)
                     and conv.out_channels in (16, 32, 64) and len(t.spatial_shape) == 3 and t.features.dtype == torch.float32
                     and conv.in_channels == t.features.shape[1] * t.spatial_shape[0] and not (bn.training and bn.track_running_stats is False))
 
@@ -73,6 +103,13 @@ class SparseBEVStem(nn.Module):
         be = ops.get_backend()
         depth = int(t.spatial_shape[0])
         passes = self._passes(depth)
+        if torch.is_grad_enabled() and (t.features.requires_grad or conv.weight.requires_grad or
+                                        (bn.weight is not None and bn.weight.requires_grad)):
+            # training through the stem: the conv as one autograd node over the sparse rows, BatchNorm2d + ReLU as the BEV backbone's
+            # own modules on the NHWC rows seen as a channels-last (B, C, H, W) tensor (statistics over every cell of the map)
+            y = _StemConvFunction.apply(t.features, conv.weight, t.indices, t.spatial_shape, t.batch_size, passes)
+            y4 = y.view(t.batch_size, int(t.spatial_shape[1]), int(t.spatial_shape[2]), conv.out_channels).permute(0, 3, 1, 2)
+            return self._block[3](bn(y4))
         if bn.training:   # batch statistics over the WHOLE map (zeros of the empty cells included): the NHWC rows hold every cell
             y = be.bev_stem_conv(t.features, t.indices, t.spatial_shape, t.batch_size, passes, conv.out_channels, want_nhwc=True)
             with torch.no_grad():

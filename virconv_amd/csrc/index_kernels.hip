@@ -829,6 +829,26 @@ __global__ void __launch_bounds__(256) bev_pairs_kernel(const int32_t* __restric
       }
 }
 
+// The transposed table of bev_pairs_kernel, for the backward pass of the sparse BEV stem: pair_bwd[k][i] = the BEV cell that voxel row i
+// feeds through offset k = (kz, a, c) -- cell (b, y - (a - ky / 2), x - (c - kx / 2)) when kz is the row's own height z (the conv's
+// z "offset" is absolute: one weight slab per height, height_compression.py:30) and the cell is inside the map, -1 otherwise.
+__global__ void __launch_bounds__(256) bev_pairs_bwd_kernel(const int32_t* __restrict__ indices, int64_t n, int B, int D, int H, int W, int ky,
+                                                            int kx, int32_t* __restrict__ pair_bwd) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int4 r = *reinterpret_cast<const int4*>(indices + i * 4);   // [b, z, y, x]
+  const bool ok = r.x >= 0 && r.x < B && r.y >= 0 && r.y < D && r.z >= 0 && r.z < H && r.w >= 0 && r.w < W;
+  int k = 0;
+  for (int z = 0; z < D; ++z)
+    for (int a = 0; a < ky; ++a)
+      for (int c = 0; c < kx; ++c, ++k) {
+        const int yy = r.z - (a - ky / 2), xx = r.w - (c - kx / 2);
+        int cell = -1;
+        if (ok && z == r.y && yy >= 0 && yy < H && xx >= 0 && xx < W) cell = (int)(((int64_t)r.x * H + yy) * W + xx);
+        pair_bwd[(int64_t)k * n + i] = cell;
+      }
+}
+
 // out[b][ch][p] = act(x[b * HW + p][ch] * scale[ch] + shift[ch]); x is (B * HW, C) row-major (NHWC), out (B, C, HW) (NCHW).
 // Block = 64 consecutive cells x all channels through an LDS tile: rows are read coalesced, every store instruction writes 64
 // consecutive cells of one channel plane.
@@ -1575,6 +1595,20 @@ int vc_bev_pairs(const int32_t* indices, int64_t n, int batch_size, const int32_
   hipLaunchKernelGGL(bev_pairs_kernel, dim3((unsigned)cdiv(cells, 256)), dim3(256), 0, st, (const int32_t*)rowid, batch_size, D, H, W, ky, kx,
                      pair);
   VC_CHECK_LAUNCH("bev_pairs_kernel");
+  return VC_OK;
+}
+
+int vc_bev_pairs_backward(const int32_t* indices, int64_t n, int batch_size, const int32_t* shape, int ky, int kx, int32_t* pair_bwd,
+                          void* stream) {
+  VC_REQUIRE(shape && batch_size >= 1 && ky >= 1 && kx >= 1 && ky % 2 == 1 && kx % 2 == 1, "vc_bev_pairs_backward: invalid argument");
+  VC_REQUIRE(n >= 0 && (n == 0 || (indices && pair_bwd)), "vc_bev_pairs_backward: null argument");
+  const int D = shape[0], H = shape[1], W = shape[2];
+  VC_REQUIRE(D >= 1 && H >= 1 && W >= 1 && (int64_t)D * ky * kx <= 128, "vc_bev_pairs_backward: kernel volume D * ky * kx must be <= 128");
+  VC_REQUIRE((int64_t)batch_size * H * W < (1LL << 31), "vc_bev_pairs_backward: map too large");
+  if (n == 0) return VC_OK;
+  hipLaunchKernelGGL(bev_pairs_bwd_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, indices, n, batch_size, D, H, W,
+                     ky, kx, pair_bwd);
+  VC_CHECK_LAUNCH("bev_pairs_bwd_kernel");
   return VC_OK;
 }
 
