@@ -198,7 +198,11 @@ def train_step(model, optimizer, batch, lw, grad_sync=None, raw=None, next_batch
     loss.backward()
     if grad_sync is not None:
         grad_sync()  # data-parallel exchange: one flat RCCL all-reduce of the gradients
-    torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)  # train_utils.py:50
+    # train_utils.py:50.  The parameter list is taken once per model (walking the module tree for it costs 0.15 ms of host time per step)
+    params = getattr(base, "_bench_param_list", None)
+    if params is None:
+        params = base._bench_param_list = list(model.parameters())
+    torch.nn.utils.clip_grad_norm_(params, 10.0)
     optimizer.step()
     return loss
 

@@ -63,6 +63,10 @@ def test_new_entry_points_validate_their_arguments_without_gpu():
     lib = _lib.load()
     dummy = ctypes.c_void_p(64)  # never dereferenced on the host
     shp = _lib.i32arr([21, 400, 352])
+    # sparse BEV stem, transposed table: invalid kernel sizes / shapes are rejected before any launch; an empty tensor is a no-op
+    assert lib.vc_bev_pairs_backward(dummy, 10, 2, _lib.i32arr([4, 200, 176]), 2, 3, dummy, None) == _lib.VC_EINVAL
+    assert lib.vc_bev_pairs_backward(dummy, 10, 2, _lib.i32arr([40, 200, 176]), 3, 3, dummy, None) == _lib.VC_EINVAL and b"kernel volume" in lib.vc_last_error()
+    assert lib.vc_bev_pairs_backward(None, 0, 2, _lib.i32arr([4, 200, 176]), 3, 3, None, None) == _lib.VC_OK
     # row order: window and kernel-volume limits
     assert lib.vc_row_order(dummy, 10, 27, None, -1, 512, dummy, None) == _lib.VC_EINVAL and b"window" in lib.vc_last_error()
     assert lib.vc_row_order(dummy, 10, 33, None, -1, 1024, dummy, None) == _lib.VC_EINVAL

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 pytestmark = pytest.mark.gpu
-STEPS = 64
+STEPS = int(os.environ.get("VIRCONV_STRESS_STEPS", "64"))   # (a longer soak: VIRCONV_STRESS_STEPS=512; the kept-alive form holds every plan: ~0.35 GB per step)
 
 
 def _structures(plan):

@@ -16,8 +16,13 @@ from virconv_amd.backbone import VirConvL8x  # noqa: E402
 parallel.init_distributed()
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
-batch = bench.make_batch([0, 1, 2, 3], dev, True)
-model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).to(dev).train()
+if os.environ.get("MODEL") == "8x":      # MODEL=8x python tools/hostprof.py: the VirConv8x train step (bs 2)
+    from virconv_amd.backbone import VirConv8x
+    batch = bench.make_batch_8x([0, 1], dev)
+    model = VirConv8x(bench.MODEL_CFG_8X, 8, synth.GRID_SIZE).to(dev).train()
+else:
+    batch = bench.make_batch([0, 1, 2, 3], dev, True)
+    model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).to(dev).train()
 raw = model
 import os as _os
 gs = None
