@@ -61,3 +61,26 @@ def test_every_line_of_the_round_file_parses_and_names_its_workload():
             assert j["unit"] == "frames/s" and "workload" in j["config"] and "roofline" in j and "cpu_baseline" in j
             assert j["value"] > 0 and j["ms_per_step"] > 0
     assert n >= 10
+
+
+def test_round5_line_names_the_dominant_kernel_flat_and_the_host_side():
+    """the driver's record keeps the LEADING scalar keys of `roofline`; they must be the dominant kernel's (measured
+    inside the timed steps), both fractions and the step fraction; `host_enqueue_ms_per_step` is a top-level key."""
+    with open(os.path.join(ROOT, "profiles", "r05_bench.json")) as f:
+        j = json.loads(f.read())
+    assert j["unit"] == "frames/s" and j["n_gpus"] == 1 and j["steps"] == 20 and j["warmup"] == 5
+    assert j["value"] == pytest.approx(j["config"]["global_batch"] / (j["ms_per_step"] * 1e-3), rel=2e-3)
+    assert 0 < j["host_enqueue_ms_per_step"] < 2 * j["ms_per_step"]
+    r = j["roofline"]
+    lead = list(r.keys())[:12]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "frac_issue_pipe", "step_frac", "family_frac", "kernel_is_dominant"):
+        assert k in lead, (k, lead)
+    assert r["kernel"].startswith("bwd_weight_kernel") and r["kernel_is_dominant"] is True
+    assert r["kernel"] == r["dominant_by_time"]["kernel"]
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], abs=2e-4) and r["peak"] == bench.MFMA_F32_PEAK_TFLOPS
+    assert r["frac_issue_pipe"] == pytest.approx(r["achieved"] / (bench.MFMA_16BIT_PEAK_TFLOPS / 6), abs=2e-4)
+    assert 0 < r["frac_issue_pipe"] < r["step_frac"] < r["frac"] < r["family_frac"] + 0.1 < 1
+    assert r["traffic"] > r["algorithmic_mb_per_launch"] * 1e6 * 0.9 and "r05_traffic_bwd_weight_32_32" in r["traffic_source"]
+    assert j["exact_f32_mfma"]["ms_per_step"] > j["ms_per_step"]
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
