@@ -163,6 +163,58 @@ def test_every_plan_of_64_pipelined_inference_frames_is_bit_identical_to_a_synch
     assert not bad, f"{len(bad)} structures of {len({t for t, _ in bad})} frames differ from the synchronised rebuild: {bad[:12]}"
 
 
+def test_front_end_outputs_of_64_unsynchronised_steps_equal_a_synchronised_rerun():
+    """`bench.py --frontend`: the GPU data front-end (input point discard, LiDAR-first voxeliser, MeanVFE: floating-point kernels) runs on
+    the plan stream beside the previous step's conv kernels -- the situation in which the pixel projection went wrong (LOG.md A.17).  Its
+    outputs (voxel features, coordinates) of 64 consecutive unsynchronised train steps against a synchronised rerun with the same seeds."""
+    import bench
+    from virconv_amd import synth
+    from virconv_amd.backbone import VirConvL8x
+    dev = torch.device("cuda", 0)
+    raw, base = bench.make_raw_frames([0, 1, 2, 3], dev)
+    torch.manual_seed(0)
+    model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).to(dev).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, fused=True)
+    lw = bench.make_loss_weights(dev)
+    torch.cuda.synchronize()
+    base["inputs_ready_event"] = torch.cuda.Event()
+    base["inputs_ready_event"].record()
+    seen = []
+    orig = bench.front_end
+
+    def recording(raw_, base_, training=True):
+        bd = orig(raw_, base_, training)
+        seen.append((bd["voxel_features"], bd["voxel_coords"]))
+        return bd
+
+    bench.front_end = recording
+    try:
+        for t in range(3):
+            torch.manual_seed(7000 + t)
+            bench.train_step(model, opt, base, lw, None, raw)
+        del seen[:]
+        for t in range(STEPS):
+            torch.manual_seed(7000 + t)
+            bench.train_step(model, opt, base, lw, None, raw)
+        torch.cuda.synchronize()
+    finally:
+        bench.front_end = orig
+    assert len(seen) == STEPS
+    bad = []
+    for t, (f, c) in enumerate(seen):
+        torch.cuda.synchronize()
+        torch.manual_seed(7000 + t)
+        bd = orig(raw, base)
+        want = bd["voxel_features"].clone()
+        want[:, 4:7] = 0       # the backbone zeroed the RGB columns of the step's tensor in place (spconv_backbone.py:636)
+        torch.cuda.synchronize()
+        if f.shape != want.shape or not torch.equal(c, bd["voxel_coords"]):
+            bad.append((t, "coords", tuple(f.shape), tuple(want.shape)))
+        elif not torch.equal(f, want):
+            bad.append((t, "features", int((f != want).any(1).sum())))
+    assert not bad, f"front-end outputs of {len(bad)} of {STEPS} steps differ from the synchronised rerun: {bad[:8]}"
+
+
 def test_plan_with_every_table_deferred_to_finish_is_bit_identical():
     """vc_plan_desc.defer_early_tables (plans begun ahead / several plans per forward): same structures as the default split."""
     from virconv_amd import backbone as bb, native_plan

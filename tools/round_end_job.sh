@@ -1,3 +1,5 @@
+# The round-end measurement job of round 5 (gpurun call r5z: profiles/r05_README.md): full GPU suite, smoke, the bench lines, phases, the plan soak.
+#   gpurun --timeout 3400 -- bash tools/round_end_job.sh
 cd "$GRAFT_REPO_ROOT"; D=gpurun_out/r5z; mkdir -p $D
 line() { for f in "$@"; do echo "$f $(grep -o '"ms_per_step": [0-9.]*' "$f" | head -1) $(grep -o '"value": [0-9.]*' "$f" | head -1) $(grep -o '"host_enqueue_ms_per_step": [0-9.]*' "$f" | head -1)"; done; }
 timeout 1700 python -m pytest tests -m gpu -q > $D/tests.log 2>&1; echo "testsall rc=$?"; tail -n 2 $D/tests.log

@@ -1466,7 +1466,9 @@ static int spconv_pairs(const int32_t* indices, int64_t n, int ndim, int batch_s
 
 int vc_project_prepare(const float* calib, const float* trans, int batch_size, float* params, void* stream) {
   VC_REQUIRE(calib && params && batch_size >= 1, "vc_project_prepare: null/invalid argument");
-  hipLaunchKernelGGL(project_prepare_kernel, dim3((unsigned)cdiv(batch_size, 64)), dim3(64), 0, (hipStream_t)stream,
+  // 32 threads per block: this floating-point kernel runs at the head of the geometry plan, beside the previous step's conv kernels,
+  // and what LOG.md A.17 saw go wrong there were lanes 48-63 of a wave -- no sample's parameters are ever computed in those lanes
+  hipLaunchKernelGGL(project_prepare_kernel, dim3((unsigned)cdiv(batch_size, 32)), dim3(32), 0, (hipStream_t)stream,
                      calib, trans, batch_size, params);
   VC_CHECK_LAUNCH("project_prepare_kernel");
   return VC_OK;
