@@ -98,7 +98,7 @@ def test_every_plan_of_64_unsynchronised_train_steps_is_bit_identical_to_a_synch
     torch.cuda.synchronize()
     del batch["plan_observer"]
     assert len(seen) == STEPS
-    bad = []
+    bad, samples = [], []
     for t in range(STEPS):
         ref = _structures(_rebuild(model, batch, t))
         if form == "kept_alive":
@@ -107,6 +107,10 @@ def test_every_plan_of_64_unsynchronised_train_steps_is_bit_identical_to_a_synch
             for k in ref:
                 if got[k].shape != ref[k].shape or not torch.equal(got[k], ref[k]):
                     bad.append((t, k, int((got[k] != ref[k]).sum()) if got[k].shape == ref[k].shape else "shape"))
+                    if k.endswith(".uv") and got[k].shape == ref[k].shape and len(samples) < 6:
+                        rows = (got[k] != ref[k]).any(1).nonzero().squeeze(1)
+                        samples.append((t, k, rows[:3].tolist(), got[k][rows[:3]].tolist(), ref[k][rows[:3]].tolist(),
+                                        sorted(set((rows % 64).tolist()))[:4]))
         else:
             got = seen[t]
             # structures finished AFTER the observer ran (vc_plan_finish_backward: group plans, backward row orders) are not in the
@@ -119,7 +123,7 @@ def test_every_plan_of_64_unsynchronised_train_steps_is_bit_identical_to_a_synch
         seen[t] = None
     names = sorted({k.split(".", 1)[1] if k[0] == "s" else k for _, k, _ in bad})
     assert not bad, (f"{len(bad)} structures of {len({t for t, _, _ in bad})} steps differ from the synchronised rebuild (guard "
-                     f"{os.environ.get('VIRCONV_PLAN_GUARD', '1')}); kinds: {names}; first: {bad[:12]}")
+                     f"{os.environ.get('VIRCONV_PLAN_GUARD', '1')}); kinds: {names}; first: {bad[:12]}; wrong pixel rows (step, stage, rows, got, want, lanes): {samples}")
 
 
 def test_every_plan_of_64_pipelined_inference_frames_is_bit_identical_to_a_synchronised_rebuild():

@@ -33,6 +33,10 @@ from virconv_amd.backbone import NRConvBlock, VirConvL8x  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=12)
 ap.add_argument("--bs", type=int, default=2)
+ap.add_argument("--stress", type=int, default=0,
+                help="N > 0: instead of the variants, run the benchmark's own unsynchronised loop for N steps WITHOUT the guard (plans kept), "
+                     "compare every step's pixel coordinates with a rebuild on an idle GPU and match the wrong rows against an fp32 emulation "
+                     "of the projection with single steps of its arithmetic knocked out")
 ap.add_argument("variants", nargs="*", default=["base", "select", "argflag", "reprepare", "pad", "dwmain", "exactmfma", "private", "guard"])
 args = ap.parse_args()
 
@@ -204,5 +208,109 @@ def run_variant(name):
     native_plan.ARENA_ALLOC = None
 
 
+def emulate(coords, calib, aug, stride, knock):
+    """fp32 restatement of project_uv_kernel on the CPU, op for op (every product and sum rounded separately); `knock` names one
+    step of the inverse augmentation that is skipped or altered.  -> (n, 2) int64 [u, v]"""
+    f32 = torch.float32
+    c = coords.cpu()
+    b = c[:, 0].long()
+    vs = torch.tensor(0.05 * stride, dtype=torch.float64).to(f32)
+    mn = [torch.tensor(v + 0.05 * stride / 2, dtype=torch.float64).to(f32) for v in (0.0, -40.0, -3.0)]
+    X = c[:, 3].to(f32) * vs + mn[0]
+    Y = c[:, 2].to(f32) * vs + mn[1]
+    Z = c[:, 1].to(f32) * vs + mn[2]
+    cal = calib.cpu().to(f32)
+    v2c, r0, p2 = cal[:, :12].view(-1, 3, 4), cal[:, 12:21].view(-1, 3, 3), cal[:, 21:33].view(-1, 3, 4)
+    a = aug.cpu().to(f32)
+    ang = -(a[:, 0].double())
+    ca, sa = torch.cos(ang).to(f32)[b], torch.sin(ang).to(f32)[b]
+    flip, sc = (a[:, 1] != 0)[b], a[:, 2][b]
+    Xs, Ys, Zs = (X / sc, Y / sc, Z / sc) if knock != "scale" else (X, Y, Z)
+    if knock == "scale_z_only_kept":
+        Xs, Ys = X, Y
+    if knock != "flip":
+        Ys = torch.where(flip, -Ys, Ys)
+    nsa = -sa
+    X2 = Xs * ca + Ys * nsa
+    Y2 = Xs * sa + Ys * ca
+    if knock == "Y2=Y":
+        Y2 = Ys
+    elif knock == "X2=X":
+        X2 = Xs
+    elif knock == "rotation":
+        X2, Y2 = Xs, Ys
+    elif knock == "Y2=Xsa-Yca":
+        Y2 = Xs * sa - Ys * ca
+    elif knock == "X2=Xca+Ysa":
+        X2 = Xs * ca + Ys * sa
+    elif knock == "other sample":
+        bo = (b + 1) % a.shape[0]
+        ang2 = -(a[:, 0].double())
+        ca2, sa2 = torch.cos(ang2).to(f32)[bo], torch.sin(ang2).to(f32)[bo]
+        X2 = Xs * ca2 + Ys * (-sa2)
+        Y2 = Xs * sa2 + Ys * ca2
+    elif knock == "all":
+        X2, Y2, Zs = X, Y, Z
+    # M1 = V2C^T @ R0^T (4 x 3), per sample, each element three products summed in order
+    M1 = torch.zeros((cal.shape[0], 4, 3), dtype=f32)
+    for r in range(4):
+        for cc in range(3):
+            M1[:, r, cc] = (v2c[:, 0, r] * r0[:, cc, 0] + v2c[:, 1, r] * r0[:, cc, 1]) + v2c[:, 2, r] * r0[:, cc, 2]
+    P = M1[b]
+    rect = [((X2 * P[:, 0, k] + Y2 * P[:, 1, k]) + Zs * P[:, 2, k]) + P[:, 3, k] for k in range(3)]
+    p2t = p2[b]   # (n, 3, 4): P2T[r][c] = p2[c][r]
+    hom = [((rect[0] * p2t[:, k, 0] + rect[1] * p2t[:, k, 1]) + rect[2] * p2t[:, k, 2]) + p2t[:, k, 3] for k in range(2)]
+    u = torch.nan_to_num(hom[0] / rect[2], nan=0.0, posinf=2.0e9, neginf=-2.0e9).trunc().clamp(-2147483648, 2147483647).long()
+    v = torch.nan_to_num(hom[1] / rect[2], nan=0.0, posinf=2.0e9, neginf=-2.0e9).trunc().clamp(-2147483648, 2147483647).long()
+    u = u.clamp(0, 1399) // stride
+    v = v.clamp(0, 599) // stride
+    return torch.stack([u, v], 1)
+
+
+KNOCKS = ["none", "Y2=Y", "X2=X", "rotation", "Y2=Xsa-Yca", "X2=Xca+Ysa", "flip", "scale", "scale_z_only_kept", "other sample", "all"]
+
+
+def stress(n_steps):
+    import importlib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    tps = importlib.import_module("test_plan_stress_gpu")
+    _, _, b4, model, opt, lw4 = tps._setup()
+    seen = []
+    for t in range(3):
+        bench.train_step(model, opt, b4, lw4)
+    b4["plan_observer"] = lambda rid, plan: seen.append(plan)
+    for t in range(n_steps):
+        torch.manual_seed(5000 + t)
+        bench.train_step(model, opt, b4, lw4)
+    torch.cuda.synchronize()
+    del b4["plan_observer"]
+    tally = {k: 0 for k in KNOCKS}
+    total, emu_ok, emu_n = 0, 0, 0
+    for t in range(n_steps):
+        ref = tps._rebuild(model, b4, t)
+        for si, (st_g, st_r) in enumerate(zip(seen[t]["stages"], ref["stages"])):
+            g, r = st_g["uv"], st_r["uv"]
+            rows = (g != r).any(1).nonzero().squeeze(1)
+            if rows.numel() == 0:
+                continue
+            co = st_r["out_indices"][rows]
+            got = g[rows][:, 1:].cpu().long()
+            if emu_n < 4:   # the emulation itself against the kernel on rows that are right
+                some = torch.arange(0, r.shape[0], max(1, r.shape[0] // 2000), device=r.device)
+                e = emulate(st_r["out_indices"][some], b4["calib"], b4["aug_param"], 2 ** si, "none")
+                emu_ok += int((e == r[some][:, 1:].cpu().long()).all(1).sum())
+                emu_n += 1
+                print(f"  emulation vs kernel on {some.numel()} right rows of step {t} stage {si}: {int((e == r[some][:, 1:].cpu().long()).all(1).sum())} equal")
+            total += rows.numel()
+            for k in KNOCKS:
+                e = emulate(co, b4["calib"], b4["aug_param"], 2 ** si, k)
+                tally[k] += int((e == got).all(1).sum())
+        seen[t] = None
+    print(f"[stress {n_steps} steps, no guard] {total} wrong pixel rows; rows reproduced exactly by the emulation with ... {tally}")
+
+
+if args.stress:
+    stress(args.stress)
+    sys.exit(0)
 for v in args.variants:
     run_variant(v)

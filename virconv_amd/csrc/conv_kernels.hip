@@ -2301,7 +2301,7 @@ extern int g_pass_pack_all;
 extern int g_pass_fork_ext_event; // pass.hip
 extern int g_bn_fused_partial;  // bn_kernels.hip
 extern int g_pass_defer_dw_reduce;  // pass.hip
-extern int g_plan_subm_bitmap, g_plan_image_2d, g_plan_parity_order, g_plan_params_pad, g_plan_reprepare, g_plan_uv_mode;   // plan.hip
+extern int g_plan_subm_bitmap, g_plan_image_2d, g_plan_parity_order, g_plan_params_pad, g_plan_reprepare, g_plan_uv_mode, g_plan_uv_poison;   // plan.hip
 extern int g_group_plan_radix, g_group_plan_onesweep;   // group_kernels.hip
 extern int g_sp_mark_variant;    // index_kernels.hip
 static constexpr int kMaxSplit = 256;
@@ -2503,6 +2503,7 @@ int vc_debug_set(const char* key, int value) {
   if (!strcmp(key, "plan_params_pad")) { g_plan_params_pad = value < 0 ? 0 : (value + 255) & ~255; return VC_OK; }
   if (!strcmp(key, "plan_reprepare")) { g_plan_reprepare = value; return VC_OK; }
   if (!strcmp(key, "plan_uv_mode")) { g_plan_uv_mode = value; return VC_OK; }
+  if (!strcmp(key, "plan_uv_poison")) { g_plan_uv_poison = value; return VC_OK; }
   if (!strcmp(key, "plan_radix_sort")) return experiment_key(key, value, 0, &g_group_plan_radix);
 #ifdef VC_EXPERIMENTS
   if (!strcmp(key, "conv_pc_ablate"))

@@ -35,6 +35,7 @@ int g_plan_params_pad = 0;    // vc_debug_set plan_params_pad: bytes of padding 
                               // damage follow the block or stay at the address?)
 int g_plan_reprepare = 0;     // vc_debug_set plan_reprepare: 1 = write the parameter block again right in front of every projection of
                               // vc_plan_finish (damage to the block between the two calls is then repaired: is the block what is hit?)
+int g_plan_uv_poison = 0;     // vc_debug_set plan_uv_poison: 1 = every uv buffer is filled with 0x7F bytes in front of the projection (diagnostics)
 int g_plan_uv_mode = 0;       // vc_debug_set plan_uv_mode: project_uv_kernel<MODE> of the plan's projections (0 = product kernel)
 int project_uv_debug(const int32_t* indices, int64_t n, const float* params, int batch_size, int stride, int32_t* uv, int32_t* dbg,
                      int dbg_records, int mode, int has_trans, hipStream_t st);   // index_kernels.hip
@@ -623,6 +624,8 @@ static int tables_2d(const vc_plan_desc* d, const PlanState& S, const int32_t* c
       bm += (unsigned)cdiv(n, 256); br += (unsigned)cdiv(n, 64);
     }
     if (a.n_stages == 0) return VC_OK;
+    if (g_plan_uv_poison)
+      for (int t = 0; t < a.n_stages; ++t) VC_CHECK_HIP(hipMemsetAsync(a.st[t].uv, 0x7F, (size_t)a.st[t].n * 12, st));
     rc = uv_mark_multi(a, bm, st);
     if (rc != VC_OK) return rc;
     hipLaunchKernelGGL(image_rulebook_multi_kernel, dim3(br), dim3(256), 0, st, a);
