@@ -428,6 +428,13 @@ def main(argv=None, plumbing=False):
         torch.cuda.set_device(device)
         numa = parallel.bind_to_gpu_numa(device.index)  # one process per GPU, on the cores next to that GPU
         sync = torch.cuda.synchronize
+        # The loop runs on a HIGH-priority stream: HIP has two levels (high, normal) and the library's side streams -- above all the
+        # weight gradients, which overlap the backward sweep -- are meant to fill what the main stream leaves free, not to compete with
+        # it for dispatch (4.22 vs 4.30 ms per step, inference bs 1 0.80 vs 0.83; LOG.md A.20).  VIRCONV_MAIN_PRIORITY=default: the
+        # default stream (A/B); INTEGRATION.md section 10 says the same to a training loop.
+        main_prio = os.environ.get("VIRCONV_MAIN_PRIORITY", "-1")
+        if main_prio != "default":
+            torch.cuda.set_stream(torch.cuda.Stream(device=device, priority=int(main_prio)))
     be = ops.get_backend()
     ops.MFMA_OPERAND = args.operand
     for kv_ in filter(None, os.environ.get("VIRCONV_DEBUG_SET", "").split(",")):   # A/B switches: "key=value,key=value" -> vc_debug_set
@@ -682,7 +689,10 @@ def main(argv=None, plumbing=False):
                    "untimed_setup": {"settle_seconds_of_steps_before_warmup": settle, "allocator_priming_gib": 8,
                                      "gc_freeze": os.environ.get("VIRCONV_GC_FREEZE", "1") != "0",
                                      "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
-                                     "streams": "main + geometry plan (high priority) + weight-gradient side stream",
+                                     "streams": ("main (high priority) + geometry plan (high priority) + weight-gradient side stream (normal priority)"
+                                                 if os.environ.get("VIRCONV_MAIN_PRIORITY", "-1") == "-1" else
+                                                 "main + geometry plan (high priority) + weight-gradient side stream; main priority "
+                                                 + os.environ["VIRCONV_MAIN_PRIORITY"]),
                                      "row_order": ops.ROW_ORDER}},
         "roofline": roof,
         "exact_f32_mfma": exact,

@@ -121,7 +121,8 @@ def test_native_plan_equals_the_operator_by_operator_plan_full_size(hip_backend,
         assert bool((o[1:][same] > o[:-1][same]).all()), "the order is not stable inside a class"
 
 
-@pytest.mark.parametrize("key", ["plan_subm_bitmap", "plan_image_2d", "plan_parity_order", "sp_mark_variant"])
+@pytest.mark.parametrize("key", ["plan_subm_bitmap", "plan_image_2d", "plan_parity_order", "sp_mark_variant", "plan_group_multi",
+                                 "group_plan_multi_onesweep"])
 def test_plan_kernel_switches_do_not_change_any_table(hip_backend, monkeypatch, key):
     """Every chain-aware index kernel has the generic operator as its A/B alternative (vc_debug_set): same tables either way."""
     dev = torch.device("cuda", 0)

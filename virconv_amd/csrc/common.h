@@ -78,6 +78,22 @@ struct Uv2dArgs {
   const float* params;     // (B, 32) projection parameters (project_prepare_kernel)
 };
 int uv_mark_multi(const Uv2dArgs& a, unsigned total_blocks, hipStream_t st);   // index_kernels.hip (-ffp-contract=off)
+
+// The group plans (rows sorted by representative, group_kernels.hip) of ALL image-space tables of a plan by ONE sort: the key of
+// a row is (table index << key_bits) | representative, so the tables come out one after the other, each in the order its own
+// stable sort gives (bit-identical to vc_group_plan per table).  plan[s] = [order (n_s)][sorted keys (n_s)] as vc_group_plan writes it.
+struct GroupMulti {
+  const int32_t* rep[8];
+  int32_t* plan[8];
+  int64_t n[8];
+  int64_t off[8];       // first position of table s in the concatenated arrays
+  unsigned block0[8];   // first block of table s (blocks of 256 rows, whole blocks per table)
+  int n_tables;
+  int key_bits;
+};
+size_t group_plan_multi_workspace_bytes(int64_t total_rows);
+// fills off / block0 / key_bits from rep / plan / n / n_tables; VC_ECAPACITY when the keys do not fit 32 bits or the workspace is short
+int group_plan_multi(GroupMulti& g, void* ws, size_t ws_bytes, hipStream_t st);
 // While one is alive (geometry plan only) vc_spconv_mark_count* / vc_spconv_pairs skip the fill of their bitmap / forward pair table:
 // the plan keeps those of all its convs in one zone each and fills the zone once.
 extern thread_local bool t_sp_skip_clear;

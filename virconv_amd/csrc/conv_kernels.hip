@@ -2302,7 +2302,7 @@ extern int g_pass_fork_ext_event; // pass.hip
 extern int g_bn_fused_partial;  // bn_kernels.hip
 extern int g_pass_defer_dw_reduce;  // pass.hip
 extern int g_plan_subm_bitmap, g_plan_image_2d, g_plan_parity_order, g_plan_params_pad, g_plan_reprepare, g_plan_uv_mode, g_plan_uv_poison;   // plan.hip
-extern int g_group_plan_radix, g_group_plan_onesweep;   // group_kernels.hip
+extern int g_group_plan_radix, g_group_plan_onesweep, g_group_plan_multi_onesweep, g_plan_group_multi;   // group_kernels.hip
 extern int g_sp_mark_variant;    // index_kernels.hip
 static constexpr int kMaxSplit = 256;
 static constexpr size_t kMaxPartialBytes = 24u << 20;
@@ -2499,6 +2499,8 @@ int vc_debug_set(const char* key, int value) {
   if (!strcmp(key, "sp_mark_variant")) { g_sp_mark_variant = value; return VC_OK; }
   if (!strcmp(key, "plan_subm_bitmap")) { g_plan_subm_bitmap = value; return VC_OK; }
   if (!strcmp(key, "plan_image_2d")) { g_plan_image_2d = value; return VC_OK; }
+  if (!strcmp(key, "plan_group_multi")) { g_plan_group_multi = value; return VC_OK; }
+  if (!strcmp(key, "group_plan_multi_onesweep")) { g_group_plan_multi_onesweep = value; return VC_OK; }
   if (!strcmp(key, "plan_parity_order")) { g_plan_parity_order = value; return VC_OK; }
   if (!strcmp(key, "plan_params_pad")) { g_plan_params_pad = value < 0 ? 0 : (value + 255) & ~255; return VC_OK; }
   if (!strcmp(key, "plan_reprepare")) { g_plan_reprepare = value; return VC_OK; }

@@ -262,6 +262,89 @@ static size_t rocprim_temp_bytes(int64_t n) {
     return 0;
   return temp;
 }
+
+// ---- all tables of a plan by one sort (common.h GroupMulti)
+__global__ void __launch_bounds__(256) group_keys_multi_kernel(GroupMulti g, uint32_t* __restrict__ keys, int32_t* __restrict__ rows) {
+  int s = 0;
+#pragma unroll
+  for (int t = 1; t < 8; ++t)
+    if (t < g.n_tables && blockIdx.x >= g.block0[t]) s = t;
+  const int64_t i = (int64_t)(blockIdx.x - g.block0[s]) * 256 + threadIdx.x;
+  if (i >= g.n[s]) return;
+  const int r = g.rep[s][i];
+  keys[g.off[s] + i] = ((uint32_t)s << g.key_bits) | (r < 0 ? (uint32_t)i : (uint32_t)r);
+  rows[g.off[s] + i] = (int32_t)i;
+}
+
+__global__ void __launch_bounds__(256) group_split_multi_kernel(GroupMulti g, const uint32_t* __restrict__ keys,
+                                                                const int32_t* __restrict__ rows) {
+  int s = 0;
+#pragma unroll
+  for (int t = 1; t < 8; ++t)
+    if (t < g.n_tables && blockIdx.x >= g.block0[t]) s = t;
+  const int64_t i = (int64_t)(blockIdx.x - g.block0[s]) * 256 + threadIdx.x;
+  if (i >= g.n[s]) return;
+  // table s holds exactly n[s] keys with tag s, and the tags sort first: its rows are positions [off[s], off[s] + n[s])
+  int32_t* o = g.plan[s];
+  o[i] = rows[g.off[s] + i];
+  o[g.n[s] + i] = (int32_t)(keys[g.off[s] + i] & ((1u << g.key_bits) - 1u));
+}
+
+static size_t multi_temp_bytes(int64_t total) {
+  size_t a = 0, b = 0;
+  if (rocprim::radix_sort_pairs<rocprim::default_config>(nullptr, a, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int32_t*)nullptr,
+                                                         (int32_t*)nullptr, (unsigned)total, 0u, 32u) != hipSuccess) return 0;
+  if (rocprim::radix_sort_pairs<OnesweepCfg>(nullptr, b, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int32_t*)nullptr,
+                                             (int32_t*)nullptr, (unsigned)total, 0u, 32u) != hipSuccess) return 0;
+  return std::max(a, b);
+}
+
+size_t group_plan_multi_workspace_bytes(int64_t total) {
+  if (total <= 0) return 256;
+  const size_t t = multi_temp_bytes(total);
+  if (t == 0) return 0;
+  return al256(t) + 4 * al256((size_t)total * 4) + 256;
+}
+
+int g_group_plan_multi_onesweep = 1;   // vc_debug_set "group_plan_multi_onesweep": 0 = rocPRIM's own choice (merge sort below 1 M rows)
+
+int group_plan_multi(GroupMulti& g, void* ws, size_t ws_bytes, hipStream_t st) {
+  int64_t total = 0, nmax = 1;
+  unsigned blocks = 0;
+  for (int s = 0; s < g.n_tables; ++s) {
+    g.off[s] = total;
+    g.block0[s] = blocks;
+    total += g.n[s];
+    blocks += (unsigned)cdiv(g.n[s], 256);
+    nmax = std::max(nmax, g.n[s]);
+  }
+  if (total == 0) return VC_OK;
+  int tag_bits = 0;
+  while ((1 << tag_bits) < g.n_tables) ++tag_bits;
+  g.key_bits = key_bits(nmax);
+  if (g.key_bits + tag_bits > 32 || total >= (1LL << 31)) { set_error("group_plan_multi: keys do not fit 32 bits"); return VC_ECAPACITY; }
+  const size_t arr = al256((size_t)total * 4);
+  const size_t need = group_plan_multi_workspace_bytes(total);
+  if (need == 0 || ws_bytes < need) { set_error("group_plan_multi: workspace too small"); return VC_ECAPACITY; }
+  uint32_t* keys_in = (uint32_t*)ws;
+  int32_t* rows_in = (int32_t*)((char*)ws + arr);
+  uint32_t* keys_out = (uint32_t*)((char*)ws + 2 * arr);
+  int32_t* rows_out = (int32_t*)((char*)ws + 3 * arr);
+  void* temp = (char*)ws + 4 * arr;
+  size_t temp_bytes = ws_bytes - 4 * arr;
+  hipLaunchKernelGGL(group_keys_multi_kernel, dim3(blocks), dim3(256), 0, st, g, keys_in, rows_in);
+  VC_CHECK_LAUNCH("group_keys_multi_kernel");
+  const unsigned bits = (unsigned)(g.key_bits + tag_bits);
+  if (g_group_plan_multi_onesweep)
+    VC_CHECK_HIP(rocprim::radix_sort_pairs<OnesweepCfg>(temp, temp_bytes, (const uint32_t*)keys_in, keys_out, (const int32_t*)rows_in, rows_out,
+                                                        (unsigned)total, 0u, bits, st));
+  else
+    VC_CHECK_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t*)keys_in, keys_out, (const int32_t*)rows_in, rows_out,
+                                           (unsigned)total, 0u, bits, st));
+  hipLaunchKernelGGL(group_split_multi_kernel, dim3(blocks), dim3(256), 0, st, g, (const uint32_t*)keys_out, (const int32_t*)rows_out);
+  VC_CHECK_LAUNCH("group_split_multi_kernel");
+  return VC_OK;
+}
 }  // namespace vc
 
 using namespace vc;

@@ -28,6 +28,7 @@
 namespace vc {
 
 int g_plan_subm_bitmap = 1;   // vc_debug_set plan_subm_bitmap: 0 = hash build + vc_subm_rulebook for every 3-D SubM table (A/B)
+int g_plan_group_multi = 1;   // vc_debug_set plan_group_multi: 0 = one sort per image-space table (vc_group_plan) instead of one for all (A/B)
 int g_plan_image_2d = 1;      // vc_debug_set plan_image_2d:    0 = hash build + vc_subm_rulebook for the pixel tables (A/B)
 int g_plan_parity_order = 1;  // vc_debug_set plan_parity_order: 0 = vc_row_order on the pair table (A/B)
 // developer diagnostics of LOG.md A.15 (tools/det_check.py), both 0 on the product path:
@@ -569,6 +570,16 @@ static int tables_2d(const vc_plan_desc* d, const PlanState& S, const int32_t* c
       l.gwo = A.bump->take(l.gw_bytes);
     }
   }
+  // the group plans of all blocks by one sort (common.h GroupMulti): one shared workspace
+  int64_t gmo = -1;
+  size_t gm_bytes = 0;
+  if (any && d->need_grad && g_plan_group_multi) {
+    int64_t total = 0;
+    for (int b = 0; b < d->n_blocks; ++b)
+      if (d->blocks[b].has_2d) total += S.blk[b].n;
+    gm_bytes = group_plan_multi_workspace_bytes(total);
+    gmo = A.bump->take(gm_bytes);
+  }
   // one zone for the pixel images of all blocks: one clear
   int64_t zone = -1;
   size_t zone_bytes = 0;
@@ -586,6 +597,22 @@ static int tables_2d(const vc_plan_desc* d, const PlanState& S, const int32_t* c
   if (dry || !any) return VC_OK;
   int rc;
   if (phase == 1) {
+    if (gmo >= 0) {
+      GroupMulti g{};
+      for (int b = 0; b < d->n_blocks; ++b)
+        if (d->blocks[b].has_2d && d->need_grad && S.blk[b].n > 0 && g.n_tables < 8) {
+          g.rep[g.n_tables] = (const int32_t*)(A.base + lay[b].repo);
+          g.plan[g.n_tables] = (int32_t*)(A.base + lay[b].gpo);
+          g.n[g.n_tables++] = S.blk[b].n;
+        }
+      int n2d = 0;
+      for (int b = 0; b < d->n_blocks; ++b) n2d += d->blocks[b].has_2d && S.blk[b].n > 0;
+      if (g.n_tables == n2d) {   // (more than 8 image-space tables: the per-table route below)
+        if (g.n_tables == 0) return VC_OK;
+        rc = group_plan_multi(g, A.base + gmo, gm_bytes, st);
+        if (rc != VC_ECAPACITY) return rc;
+      }
+    }
     for (int b = 0; b < d->n_blocks; ++b)
       if (d->blocks[b].has_2d && d->need_grad && S.blk[b].n > 0) {
         rc = vc_group_plan((const int32_t*)(A.base + lay[b].repo), S.blk[b].n, (int32_t*)(A.base + lay[b].gpo), A.base + lay[b].gwo,
