@@ -250,6 +250,28 @@ def test_training_with_the_plan_built_a_step_ahead_is_bit_identical(hip_backend)
         assert torch.equal(p0_[k], p1_[k]), k
 
 
+def test_a_plan_begun_and_never_finished_does_not_block_the_count_ring(hip_backend):
+    """Plans begun ahead for batches that never come may stay referenced (the model <-> plan cycle waits for the cyclic collector).  The
+    pinned count ring then wraps onto their slot: the newer plan takes it, the abandoned one is marked stale -- finishing it raises,
+    a forward that finds it plans in place instead."""
+    dev = torch.device("cuda", 0)
+    batch = bench.make_batch([0], dev, training=True)
+    model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).cuda().train()
+    kept = []
+    for _ in range(native_plan._RING + 2):
+        assert model.plan_ahead_begin(batch)
+        kept.append(model._ahead[-1])          # keeps the begun plan alive although the model drops all but the last two
+    cps = [a["entries"][""][3] for a in kept]
+    assert cps[0].stale and cps[1].stale and not cps[-1].stale
+    with pytest.raises(RuntimeError, match="recycled"):
+        cps[0].finish()
+    model._ahead[:] = [kept[1]]                # the forward finds only a stale early plan for this batch
+    out = model(dict(batch, voxel_features=batch["voxel_features"].clone()))
+    assert out["encoded_spconv_tensor"].features.shape[0] > 0
+    assert not cps[1].counts_read              # ... and did not touch it
+    torch.cuda.synchronize()
+
+
 def test_native_plan_of_virconv8x_equals_the_operator_by_operator_plan(hip_backend, monkeypatch):
     """VirConv8x, training (spconv_backbone.py:339-535): the LiDAR stream (conv_input / conv1..4 / conv_out: one SubM table per
     stage, no image-space branch) and the virtual-point stream (input discard :488-489 + four NRConvBlocks + layer discards) are

@@ -590,7 +590,8 @@ class VirConvL8x(nn.Module):
         mode = self._ahead_mode()
         for a in self._ahead:
             e = a["entries"].get(rid)
-            if e is not None and e[0] is coords and e[1] == coords._version and a["mode"] == mode and a["born"] < self._fwd_count:
+            if (e is not None and e[0] is coords and e[1] == coords._version and a["mode"] == mode and a["born"] < self._fwd_count
+                    and not any(x[3].stale for x in a["entries"].values())):
                 break
         else:
             return None            # no early plan for this batch (or not in this mode): the caller plans in place

@@ -203,12 +203,13 @@ class ChainPlan:
         slot = ring[1] % _RING
         owner = ring[2][slot]() if ring[2][slot] is not None else None
         if owner is not None and owner.result is None and not owner.counts_read:
-            raise RuntimeError(f"virconv_amd geometry plan: {_RING} plans were begun on {dev} while an earlier one still waits for its "
-                               "row counts (its pinned count buffer would be overwritten); finish or drop plans begun ahead")
+            # a plan begun _RING plans ago and never finished (a plan begun ahead for a batch that never came, still referenced
+            # somewhere): its count buffer is recycled now, so it can no longer be finished -- it says so if anyone tries
+            owner.stale = True
         pinned = ring[0][slot]
         ring[1] += 1
         ring[2][slot] = weakref.ref(self)
-        self.result, self.counts_read = None, False
+        self.result, self.counts_read, self.stale = None, False, False
         state = _lib.PlanState()
         _lib.check(lib.vc_plan_begin(dref, arena_a.data_ptr(), arena_a.numel() * 4, pinned.data_ptr(), C.byref(state), be.stream()),
                    "vc_plan_begin")
@@ -221,6 +222,9 @@ class ChainPlan:
         input keep | None, kept input indices | None, [arena_a, arena_b])"""
         if self.result is not None:
             return self.result
+        if self.stale and not self.counts_read:
+            raise RuntimeError(f"virconv_amd geometry plan: this plan was begun more than {_RING} plans ago and never finished; its pinned "
+                               "count buffer has been recycled (begin it again)")
         be = ops.get_backend()
         lib = be.lib
         d, state, arena_a, hold = self.d, self.state, self.arena_a, self.hold
