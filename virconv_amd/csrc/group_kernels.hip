@@ -80,16 +80,22 @@ __global__ void __launch_bounds__(256) seg_fixup_kernel(const int32_t* __restric
   const int64_t chunk = blockIdx.x;
   const int64_t j0 = chunk * kSegRows, j1 = j0 + kSegRows;
   if (j1 >= n) return;                        // the last chunk cannot have an open run
-  const int key = keys[j1 - 1];
-  if (keys[j1] != key) return;                // last run ends with the chunk
-  if (keys[j0] == key && j0 > 0 && keys[j0 - 1] == key) return;   // the whole chunk is a continuation: not the run's first chunk
+  // everything the decision needs in ONE round of loads (they were three dependent rounds and, for a head, a binary search of ~18 more:
+  // with 2-6 rows per pixel most chunk borders cut a run, so most blocks are heads -- and most runs end inside the next chunk)
+  const int64_t jp = min(j1 + kSegRows - 1, n - 1);   // last position of the next chunk
+  const int key = keys[j1 - 1], k_next = keys[j1], k_first = keys[j0], k_before = j0 > 0 ? keys[j0 - 1] : 0, k_probe = keys[jp];
+  if (k_next != key) return;                  // last run ends with the chunk
+  if (k_first == key && j0 > 0 && k_before == key) return;   // the whole chunk is a continuation: not the run's first chunk
   // end of the run: first position e in (j1, n] with keys[e] != key (keys ascending); every thread searches for itself (uniform)
-  int64_t lo = j1, hi = n;                    // invariant: keys[lo] == key, (hi == n or keys[hi] != key)
-  while (hi - lo > 1) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (keys[mid] == key) lo = mid; else hi = mid;
+  int64_t c_end = chunk + 1;                  // k_probe != key: the run ends inside the next chunk
+  if (k_probe == key) {
+    int64_t lo = jp, hi = n;                  // invariant: keys[lo] == key, (hi == n or keys[hi] != key)
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (keys[mid] == key) lo = mid; else hi = mid;
+    }
+    c_end = (hi - 1) / kSegRows;              // last chunk holding rows of the run
   }
-  const int64_t c_end = (hi - 1) / kSegRows;  // last chunk holding rows of the run
   const int ch = threadIdx.x & (c - 1), seg = threadIdx.x >> lg_c, S = 256 >> lg_c;
   float acc = 0.f;
   int64_t q = chunk + 1 + seg;
