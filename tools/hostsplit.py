@@ -33,11 +33,8 @@ ON = [False]
 
 
 def wrap_native(lib):
-    import ctypes
-    for name in dir(lib):
-        pass
     from virconv_amd import _lib
-    for name in _lib.SIGNATURES if hasattr(_lib, "SIGNATURES") else []:
+    for name in _lib.SIGNATURES:
         fn = getattr(lib, name)
 
         def w(*a, _fn=fn, _n=name):
