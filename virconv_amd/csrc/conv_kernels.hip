@@ -2301,7 +2301,8 @@ extern int g_pass_pack_all;
 extern int g_pass_fork_ext_event; // pass.hip
 extern int g_bn_fused_partial;  // bn_kernels.hip
 extern int g_pass_defer_dw_reduce;  // pass.hip
-extern int g_plan_subm_bitmap, g_plan_image_2d, g_plan_parity_order, g_plan_params_pad, g_plan_reprepare, g_plan_uv_mode, g_plan_uv_poison;   // plan.hip
+extern int g_plan_subm_bitmap, g_plan_image_2d, g_plan_parity_order, g_plan_params_pad, g_plan_reprepare, g_plan_uv_mode, g_plan_uv_poison, g_plan_uv_lds;   // plan.hip
+int64_t a17_mismatch_read();   // index_kernels.hip
 extern int g_group_plan_radix, g_group_plan_onesweep, g_group_plan_multi_onesweep, g_plan_group_multi;   // group_kernels.hip
 extern int g_sp_mark_variant;    // index_kernels.hip
 static constexpr int kMaxSplit = 256;
@@ -2438,6 +2439,7 @@ int vc_debug_get(const char* key, int64_t* value) {
   VC_REQUIRE(key && value, "vc_debug_get: null argument");
   if (!strcmp(key, "conv_bn_finish_launches")) { *value = (int64_t)g_fin_launches.load(std::memory_order_relaxed); return VC_OK; }
   if (!strcmp(key, "f32_split")) { *value = g_f32_split; return VC_OK; }
+  if (!strcmp(key, "a17_mismatch")) { *value = a17_mismatch_read(); return VC_OK; }
   if (!strcmp(key, "bw_split")) { *value = g_bw_split; return VC_OK; }
   if (!strcmp(key, "experiments")) {   // 1: the library carries the measured-and-rejected variants of csrc/experiments/
 #ifdef VC_EXPERIMENTS
@@ -2505,6 +2507,7 @@ int vc_debug_set(const char* key, int value) {
   if (!strcmp(key, "plan_params_pad")) { g_plan_params_pad = value < 0 ? 0 : (value + 255) & ~255; return VC_OK; }
   if (!strcmp(key, "plan_reprepare")) { g_plan_reprepare = value; return VC_OK; }
   if (!strcmp(key, "plan_uv_mode")) { g_plan_uv_mode = value; return VC_OK; }
+  if (!strcmp(key, "plan_uv_lds")) { g_plan_uv_lds = value < 0 ? 0 : (value > 160 * 1024 ? 160 * 1024 : value); return VC_OK; }
   if (!strcmp(key, "plan_uv_poison")) { g_plan_uv_poison = value; return VC_OK; }
   if (!strcmp(key, "plan_radix_sort")) return experiment_key(key, value, 0, &g_group_plan_radix);
 #ifdef VC_EXPERIMENTS

@@ -471,7 +471,12 @@ __device__ __forceinline__ int sat_int(float f) {
   return (int)f;  // truncation toward zero
 }
 
+extern int g_plan_uv_mode, g_plan_uv_lds;   // plan.hip
+__device__ unsigned long long g_a17_mismatch = 0;   // MODE 6: threads whose two computations of the inverse augmentation disagreed (vc_debug_get a17_mismatch)
+
 // MODE / DBG: developer diagnostics of LOG.md A.15 / A.17 (the product path is <0, false>).
+//   MODE 4 / 5 / 6 (round 6, tools/a17_lab.py): 4 = MODE 0 at s_setprio 3; 5 = every arithmetic step of the inverse augmentation
+//   fenced by 16 wait states; 6 = the block computed twice from opaque copies and compared (mismatches counted in g_a17_mismatch).
 //   MODE 0: the flag word P[28] decides a divergent branch (v_cmp -> s_and_saveexec) around the inverse augmentation.
 //   MODE 1: no branch on loaded data: the inverse augmentation is always computed and selected per lane (v_cndmask).
 //   MODE 2: `has_trans` comes as a kernel argument (wave-uniform branch); the flag word in memory is not read at all.
@@ -484,6 +489,7 @@ __global__ void __launch_bounds__(256) project_uv_kernel(const int32_t* __restri
                                                          float vsx, float vsy, float vsz, float minx, float miny,
                                                          float minz, int32_t* __restrict__ uv,
                                                          float* __restrict__ depth, int32_t* dbg, int dbg_records, int has_trans_arg) {
+  if constexpr (MODE == 4) __builtin_amdgcn_s_setprio(3);   // round 6 lab: this wave wins every issue arbitration on its SIMD
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int4 r = *reinterpret_cast<const int4*>(indices + i * 4);  // [b, z, y, x]
@@ -525,6 +531,47 @@ __global__ void __launch_bounds__(256) project_uv_kernel(const int32_t* __restri
       X = has ? X2 : X; Y = has ? Y2 : Y; Z = has ? Zs : Z;
     } else if (has) {
       const float sc = P[27];
+      if constexpr (MODE == 5 || MODE >= 100) {   // round 6 lab: steps of the block fenced by 16 wait states (values pinned in VGPRs at each fence)
+        // MODE 5: every fence; MODE 100 + mask: 1 behind the parameter loads, 2 behind the divisions, 4 behind the flip, 8 behind the four
+        // products, 16 behind the first sum, 32 behind the second
+        constexpr int PM = (MODE == 5) ? 63 : MODE - 100;
+#define VC_A17_PAD(bit) do { if constexpr ((PM & (bit)) != 0) asm volatile("s_nop 15" : "+v"(X), "+v"(Y), "+v"(Z)); } while (0)
+        float fl = P[26], ca = P[24], sa = P[25], scv = sc;
+        if constexpr ((PM & 1) != 0) asm volatile("s_nop 15" : "+v"(fl), "+v"(ca), "+v"(sa), "+v"(scv), "+v"(X), "+v"(Y), "+v"(Z));
+        X = __fdiv_rn(X, scv); Y = __fdiv_rn(Y, scv); Z = __fdiv_rn(Z, scv); VC_A17_PAD(2);
+        if (fl != 0.0f) Y = -Y;
+        VC_A17_PAD(4);
+        float a = __fmul_rn(X, ca), b = __fmul_rn(Y, -sa), c = __fmul_rn(X, sa), e = __fmul_rn(Y, ca);
+        if constexpr ((PM & 8) != 0) asm volatile("s_nop 15" : "+v"(a), "+v"(b), "+v"(c), "+v"(e));
+        X = __fadd_rn(a, b);
+        if constexpr ((PM & 16) != 0) asm volatile("s_nop 15" : "+v"(X), "+v"(c), "+v"(e));
+        Y = __fadd_rn(c, e);
+        VC_A17_PAD(32);
+#undef VC_A17_PAD
+      } else if constexpr (MODE == 6) {   // round 6 lab: the block computed twice from opaque copies of its inputs and compared
+        float Xa = X, Ya = Y, Za = Z, Xb = X, Yb = Y, Zb = Z;
+        asm volatile("" : "+v"(Xb), "+v"(Yb), "+v"(Zb));
+        const float fl = P[26], ca = P[24], sa = P[25], nsa = -P[25];
+        {
+          Xa = __fdiv_rn(Xa, sc); Ya = __fdiv_rn(Ya, sc); Za = __fdiv_rn(Za, sc);
+          if (fl != 0.0f) Ya = -Ya;
+          const float X2 = __fadd_rn(__fmul_rn(Xa, ca), __fmul_rn(Ya, nsa));
+          const float Y2 = __fadd_rn(__fmul_rn(Xa, sa), __fmul_rn(Ya, ca));
+          Xa = X2; Ya = Y2;
+        }
+        asm volatile("" : "+v"(Xa), "+v"(Ya), "+v"(Za));
+        {
+          Xb = __fdiv_rn(Xb, sc); Yb = __fdiv_rn(Yb, sc); Zb = __fdiv_rn(Zb, sc);
+          if (fl != 0.0f) Yb = -Yb;
+          const float X2 = __fadd_rn(__fmul_rn(Xb, ca), __fmul_rn(Yb, nsa));
+          const float Y2 = __fadd_rn(__fmul_rn(Xb, sa), __fmul_rn(Yb, ca));
+          Xb = X2; Yb = Y2;
+        }
+        asm volatile("" : "+v"(Xb), "+v"(Yb), "+v"(Zb));
+        if (__float_as_int(Xa) != __float_as_int(Xb) || __float_as_int(Ya) != __float_as_int(Yb) || __float_as_int(Za) != __float_as_int(Zb))
+          atomicAdd(&g_a17_mismatch, 1ull);
+        X = Xa; Y = Ya; Z = Za;
+      } else {
       if constexpr (MODE == 3) {   // diagnostics only (not the reference's rounding): no IEEE division sequence in the block
         const float rs = __builtin_amdgcn_rcpf(sc);
         X = __fmul_rn(X, rs); Y = __fmul_rn(Y, rs); Z = __fmul_rn(Z, rs);
@@ -536,6 +583,7 @@ __global__ void __launch_bounds__(256) project_uv_kernel(const int32_t* __restri
       const float X2 = __fadd_rn(__fmul_rn(X, ca), __fmul_rn(Y, nsa));
       const float Y2 = __fadd_rn(__fmul_rn(X, sa), __fmul_rn(Y, ca));
       X = X2; Y = Y2;
+      }
     }
     float rect[3], hom[3];
 #pragma unroll
@@ -1225,6 +1273,12 @@ __global__ void __launch_bounds__(THREADS) row_order_kernel(const int32_t* __res
   }
 }
 
+int64_t a17_mismatch_read() {   // vc_debug_get a17_mismatch: synchronises the device
+  unsigned long long v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_a17_mismatch), sizeof(v)) != hipSuccess) return -1;
+  return (int64_t)v;
+}
+
 // diagnostics form of vc_project_uv for the geometry plan (plan.hip, vc_plan_desc.debug_buf / vc_debug_set plan_uv_mode)
 int project_uv_debug(const int32_t* indices, int64_t n, const float* params, int batch_size, int stride, int32_t* uv, int32_t* dbg,
                      int dbg_records, int mode, int has_trans, hipStream_t st) {
@@ -1232,13 +1286,22 @@ int project_uv_debug(const int32_t* indices, int64_t n, const float* params, int
   const double vs = 0.05 * stride;
   const float vsf = (float)vs;
   const float minx = (float)(0.0 + vs / 2), miny = (float)(-40.0 + vs / 2), minz = (float)(-3.0 + vs / 2);
+  const int lds = g_plan_uv_lds;   // round 6 lab: dynamic LDS bytes of the launch (a block that takes a CU's whole LDS shares it with no LDS-using block)
 #define VC_UV_LAUNCH(M, D)                                                                                                         \
-  hipLaunchKernelGGL((project_uv_kernel<M, D>), dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, indices, n, params, batch_size, stride, \
-                     vsf, vsf, vsf, minx, miny, minz, uv, (float*)nullptr, dbg, dbg_records, has_trans)
+  do {                                                                                                                             \
+    if (lds > 65536) VC_CHECK_HIP(hipFuncSetAttribute((const void*)project_uv_kernel<M, D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+    hipLaunchKernelGGL((project_uv_kernel<M, D>), dim3((unsigned)cdiv(n, 256)), dim3(256), (size_t)lds, st, indices, n, params, batch_size, stride, \
+                       vsf, vsf, vsf, minx, miny, minz, uv, (float*)nullptr, dbg, dbg_records, has_trans);                           \
+  } while (0)
   if (dbg) {
     if (mode == 1) VC_UV_LAUNCH(1, true); else if (mode == 2) VC_UV_LAUNCH(2, true); else if (mode == 3) VC_UV_LAUNCH(3, true); else VC_UV_LAUNCH(0, true);
   } else {
-    if (mode == 1) VC_UV_LAUNCH(1, false); else if (mode == 2) VC_UV_LAUNCH(2, false); else if (mode == 3) VC_UV_LAUNCH(3, false); else VC_UV_LAUNCH(0, false);
+    if (mode == 1) VC_UV_LAUNCH(1, false); else if (mode == 2) VC_UV_LAUNCH(2, false); else if (mode == 3) VC_UV_LAUNCH(3, false);
+    else if (mode == 4) VC_UV_LAUNCH(4, false); else if (mode == 5) VC_UV_LAUNCH(5, false); else if (mode == 6) VC_UV_LAUNCH(6, false);
+    else if (mode == 100) VC_UV_LAUNCH(100, false); else if (mode == 101) VC_UV_LAUNCH(101, false); else if (mode == 102) VC_UV_LAUNCH(102, false);
+    else if (mode == 104) VC_UV_LAUNCH(104, false); else if (mode == 108) VC_UV_LAUNCH(108, false); else if (mode == 116) VC_UV_LAUNCH(116, false);
+    else if (mode == 132) VC_UV_LAUNCH(132, false); else if (mode == 162) VC_UV_LAUNCH(162, false);
+    else VC_UV_LAUNCH(0, false);
   }
 #undef VC_UV_LAUNCH
   VC_CHECK_LAUNCH("project_uv_kernel<diagnostics>");
@@ -1478,6 +1541,8 @@ int vc_project_uv(const int32_t* indices, int64_t n, const float* params, int ba
                   float* depth, void* stream) {
   VC_REQUIRE(n >= 0 && params && stride >= 1 && (n == 0 || (indices && uv)), "vc_project_uv: null/invalid argument");
   if (n == 0) return VC_OK;
+  if ((g_plan_uv_mode != 0 || g_plan_uv_lds != 0) && !depth)   // developer diagnostics (vc_debug_set plan_uv_mode / plan_uv_lds; tools/a17_lab.py)
+    return project_uv_debug(indices, n, params, batch_size, stride, uv, nullptr, 0, g_plan_uv_mode, 1, (hipStream_t)stream);
   // hard-coded range / voxel size of the reference (spconv_backbone.py:8): python floats (fp64) rounded to fp32 on use
   const double vs = 0.05 * stride;
   const float vsf = (float)vs;
