@@ -221,17 +221,18 @@ def cpu_baseline(sample_frames=1, repeats=1):
         model.train()
         opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01)
         lw = make_loss_weights("cpu")
-        t0 = time.perf_counter()
-        train_step(model, opt, batch, lw)  # warm-up (allocator, thread pools)
-        warm = time.perf_counter() - t0
-        repeats = int(min(10, max(repeats, np.ceil(12.0 / max(warm, 1e-3)))))  # ~10-30 s of CPU work in total
-        t0 = time.perf_counter()
+        for _ in range(2):
+            train_step(model, opt, batch, lw)  # warm-ups (allocator, thread pools)
+        repeats = max(5, repeats)              # median of >= 5; ~7 s of CPU work in total, so that the GPU phase is most of the run
+        times = []
         for _ in range(repeats):
+            t0 = time.perf_counter()
             train_step(model, opt, batch, lw)
-        dt = (time.perf_counter() - t0) / repeats
+            times.append(time.perf_counter() - t0)
+        dt = sorted(times)[len(times) // 2]
     return {"value": round(sample_frames / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"{sample_frames} synthetic KITTI frame(s), VirConv-L fwd+bwd+Adam, oracle (torch-CPU gather-mm-scatter), "
-                      f"{repeats} timed step(s) of {dt:.2f} s after 1 warm-up"}
+                      f"median of {repeats} timed step(s) ({dt:.2f} s) after 2 warm-ups"}
 
 
 def run_infer(args, model, batch, device, rank, world):
@@ -337,13 +338,9 @@ def _kernel_name(tdir, tck, tcn, windowed=False):
     return f"gather_gemm_v2_kernel<CK={tck},CN={tcn},BWD={'true' if tdir == 'bwd' else 'false'},RT=1>"
 
 
-def _pmc_traffic(tdir, tck, tcn):
-    """HBM bytes per launch of the traced kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected in separate
-    runs of this same command and corrected as MI355X_MICROARCH.md prescribes; summary committed under profiles/).
-    PMC counters cannot be read from inside the process: the number is the one of the newest committed profile of this command,
-    and the JSON line says so (`traffic_source`); (None, None) if absent."""
-    stem = f"bwd_weight_{tck}_{tcn}" if tdir == "dw" else f"gather_gemm_{tck}_{tcn}_{tdir}"
-    for tag in ("r05", "r04", "r03", "r02"):
+def _pmc_traffic_of(stem):
+    """(bytes per launch, source) of the newest committed PMC profile `profiles/<tag>_traffic_<stem>.json`, or (None, None)."""
+    for tag in ("r06", "r05", "r04", "r03", "r02"):
         rel = os.path.join("profiles", f"{tag}_traffic_{stem}.json")
         try:
             with open(os.path.join(ROOT, rel)) as f:
@@ -351,6 +348,28 @@ def _pmc_traffic(tdir, tck, tcn):
         except Exception:
             continue
     return None, None
+
+
+def _hbm_line(trace, kernel, stem):
+    """The HBM side of the roofline for one bandwidth-bound kernel: algorithmic bytes of its launches / their HIP-event durations."""
+    if not trace:
+        return None
+    t_ms = sum(e["ms"] for e in trace)
+    byts = sum(e["bytes"] for e in trace)
+    traffic, src = _pmc_traffic_of(stem)
+    ach = byts / (t_ms * 1e-3) / 1e12
+    return {"kernel": kernel, "launches": len(trace), "algorithmic_mb_per_launch": round(byts / len(trace) / 1e6, 3),
+            "avg_us": round(t_ms / len(trace) * 1e3, 2), "achieved_tb_s": round(ach, 3), "frac_of_8tb_s": round(ach * 1e3 / HBM_PEAK_GBS, 4),
+            "traffic_mb": None if traffic is None else round(traffic / 1e6, 2), "traffic_source": src}
+
+
+def _pmc_traffic(tdir, tck, tcn):
+    """HBM bytes per launch of the traced kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected in separate
+    runs of this same command and corrected as MI355X_MICROARCH.md prescribes; summary committed under profiles/).
+    PMC counters cannot be read from inside the process: the number is the one of the newest committed profile of this command,
+    and the JSON line says so (`traffic_source`); (None, None) if absent."""
+    stem = f"bwd_weight_{tck}_{tcn}" if tdir == "dw" else f"gather_gemm_{tck}_{tcn}_{tdir}"
+    return _pmc_traffic_of(stem)
 
 
 def _traced_roofline(trace, args, tdir, tck, tcn, pmc):
@@ -572,6 +591,26 @@ def main(argv=None, plumbing=False):
         if rank == 0:
             plain = be.trace_end()
         assert be.lib.vc_debug_set(b"conv_bn_finish", 1) == 0
+    # The HBM side (BASELINE's metric names it: "HBM GB/s vs peak"): the largest bandwidth-bound kernel of the step by time -- the
+    # BatchNorm backward dx pass, 3 x 4 x N x C bytes per launch -- and the stage-1 conv (8 -> 8 channels: its pair table is the
+    # largest object it touches), each bracketed by HIP events inside a few more steps, outside the timed region.
+    hbm_bn = hbm_conv = None
+    if args.family_steps > 0 and can_trace and not plumbing:
+        for name in ("bn", "conv"):
+            if rank == 0:
+                if name == "bn":
+                    be.trace_begin("bn_dx", 0, 0, max_records=64 * args.family_steps)
+                else:
+                    be.trace_begin("fwd", 8, 8, max_records=64 * args.family_steps)
+            for _ in range(args.family_steps):
+                train_step(ddp, optimizer, batch, lw, grad_sync, raw)
+            sync()
+            if rank == 0:
+                t_ = be.trace_end()
+                if name == "bn":
+                    hbm_bn = t_
+                else:
+                    hbm_conv = t_
     parallel.barrier()
 
     # Host side of a step, for the record next to ms_per_step (which side bounds the step?): K steps ENQUEUED from an idle,
@@ -656,6 +695,17 @@ def main(argv=None, plumbing=False):
                 "family_note": f"{k} extra steps after the timed region, HIP events around every conv launch on its own stream; "
                                "family_frac = algorithmic flops of all conv kernels (forward, backward-input, weight gradient) / "
                                "wall time with at least one of them running; step_frac = the same flops / ms_per_step"})
+        hb = _hbm_line(hbm_bn, "bn_bwd_dx_pow2_kernel (BatchNorm + ReLU backward: dx; every launch of the step)", "bn_bwd_dx")
+        hc = _hbm_line(hbm_conv, "gather_gemm_v2_kernel<CK=8,CN=8,BWD=false> (stage-1 SubM conv forward)", "gather_gemm_8_8_fwd")
+        if hb is not None:    # flat keys: the bound the metric names besides frames/s
+            roof.update({"hbm_kernel": hb["kernel"], "hbm_algorithmic_mb_per_launch": hb["algorithmic_mb_per_launch"], "hbm_avg_us": hb["avg_us"],
+                         "hbm_achieved_tb_s": hb["achieved_tb_s"], "hbm_frac_of_8tb_s": hb["frac_of_8tb_s"], "hbm_traffic_mb": hb["traffic_mb"],
+                         "hbm_launches": hb["launches"], "hbm_traffic_source": hb["traffic_source"]})
+        if hc is not None:
+            roof.update({"hbm_conv_kernel": hc["kernel"], "hbm_conv_algorithmic_mb_per_launch": hc["algorithmic_mb_per_launch"],
+                         "hbm_conv_avg_us": hc["avg_us"], "hbm_conv_achieved_tb_s": hc["achieved_tb_s"],
+                         "hbm_conv_frac_of_8tb_s": hc["frac_of_8tb_s"], "hbm_conv_traffic_mb": hc["traffic_mb"],
+                         "hbm_conv_launches": hc["launches"], "hbm_conv_traffic_source": hc["traffic_source"]})
         if plain and tdir != "dw":
             pr = _traced_roofline(plain, args, tdir, tck, tcn, pmc=False)
             if pr is not None:

@@ -257,7 +257,12 @@ int vc_weighted_sum_backward(const float* gout, const float* g, int64_t nb_out, 
  *   calib : (B, 33) float32 = V2C (3x4 row-major) | R0 (3x3) | P2 (3x4)
  *   trans : (B, 3)  float32 = [rot, flip, scale] or NULL
  *   params: (B, 32) float32 scratch written by vc_project_prepare, read by vc_project_uv
- *   uv    : (n, 3) int32 [b, u, v];  depth (nullable): (n,) float32                                             */
+ *   uv    : (n, 3) int32 [b, u, v];  depth (nullable): (n,) float32
+ * CAUTION (LOG.md A.17, measured on MI355X / ROCm 7.2): while waves of this kernel share a compute unit with waves of this library's
+ * bf16-split conv kernels (vc_conv_forward / vc_conv_backward_input / vc_conv_backward_weight at >= 32 channels with f32_split /
+ * bw_split on, the default), lanes 48-63 of some of its waves compute wrong pixels.  Launch it where it cannot overlap them: on the
+ * stream of the feature passes, behind an event recorded there (what vc_plan_finish does with tables_wait_event), or on a stream
+ * whose CU mask is disjoint from theirs (profiles/r06_a17_cu_mask.md).                                            */
 int vc_project_prepare(const float* calib, const float* trans, int batch_size, float* params, void* stream);
 int vc_project_uv(const int32_t* indices, int64_t n, const float* params, int batch_size, int stride,
                   int32_t* uv, float* depth, void* stream);
@@ -473,7 +478,10 @@ int vc_pass_backward(const vc_pass_program* prog, const void* fwd_arena, size_t 
  * same shape -- the count is measurement work inside the timed step).  bench.py's roofline figure comes from here.
  * `dev_pairs`: device int64[max_records], caller-owned.
  * direction = -1 records EVERY gather-GEMM launch (record.direction 0 / 1) and every weight-gradient launch (2: kernel + its
- * reduce; ck = cin, cn = cout): the family- and step-level roofline figures of bench.py.                                 */
+ * reduce; ck = cin, cn = cout): the family- and step-level roofline figures of bench.py.
+ * direction = 3 records the launches of the BatchNorm-backward dx kernel (the largest bandwidth-bound kernel of a train step by time):
+ * ck = channel filter (0 = every channel count), cn ignored; record = {ck = cn = channels, n_src = n_out = rows, pairs = 0}: the HBM side
+ * of bench.py's roofline (algorithmic bytes 3 x 4 x rows x channels).                                                      */
 typedef struct vc_trace_record { float ms; int32_t kv, ck, cn, windowed; int64_t n_src, n_out, pairs; int32_t direction;
                                  float t0_ms /* start of the launch, since the first traced launch */; } vc_trace_record;
 int vc_trace_begin(int direction, int ck, int cn, int max_records, int64_t* dev_pairs);
@@ -601,7 +609,9 @@ typedef struct vc_plan_desc {
   int32_t defer_early_tables;               /* 1: vc_plan_begin builds NO table (also not those of a first block whose row count is the
                                                caller's): vc_plan_finish builds them all.  For callers that begin several plans -- or one
                                                plan a step early -- before finishing any */
-  int32_t reserved_;
+  int32_t allow_unfenced_projection;        /* 0 (default): vc_plan_finish REFUSES (VC_EINVAL) a plan with an image-space branch and no
+                                               tables_wait_event.  1: the caller asserts that no conv kernel of this library runs on the
+                                               device while the branch does (single stream, an idle device, a diagnostics run) */
   void* tables_wait_event;                  /* hipEvent_t or NULL: vc_plan_finish lets the stream wait for it between the integer tables and
                                                the image-space branch (pixel projection -- the plan's only floating-point kernel -- and
                                                the pixel tables of all blocks).  The caller records it behind the previous step's feature

@@ -238,3 +238,37 @@ def test_second_session_entry_points_validate_their_arguments_without_gpu():
     assert lib.vc_nms(dummy, 70000, 0.5, 1, dummy, dummy, dummy, 1 << 40, None) == _lib.VC_EINVAL and b"up to" in lib.vc_last_error()
     assert lib.vc_nms(dummy, 100, 0.5, 1, dummy, dummy, dummy, 8, None) == _lib.VC_EINVAL and b"workspace" in lib.vc_last_error()
     assert lib.vc_nms(dummy, 100, 0.5, 1, dummy, None, dummy, 1 << 20, None) == _lib.VC_EINVAL
+
+
+def test_plan_finish_refuses_an_unfenced_image_space_branch_without_gpu():
+    """LOG.md A.17 / VERDICT r5 #1d: a plan with a pixel projection and no `tables_wait_event` is refused unless the caller sets
+    `allow_unfenced_projection` -- leaving the field zero must not give the loop that projects voxels onto wrong pixels.  The check sits in
+    front of every launch (and of the state check), so it can be exercised on fake pointers."""
+    import ctypes as C
+    lib = _lib.load()
+    d = _lib.PlanDesc()
+    d.indices, d.n, d.batch_size = 0x1000, 100, 1
+    d.spatial_shape[0], d.spatial_shape[1], d.spatial_shape[2] = 41, 1600, 1408
+    d.calib, d.image_shape[0], d.image_shape[1] = 0x2000, 1600, 600
+    d.n_blocks = 1
+    B = d.blocks[0]
+    for a in range(3):
+        B.subm_ksize[a], B.subm_dilation[a] = 3, 1
+    B.has_2d, B.uv_stride = 1, 1
+    for a in range(2):
+        B.ksize2d[a], B.dilation2d[a] = 3, 1
+    state, out = _lib.PlanState(), _lib.PlanOut()
+    args = (C.byref(state), 0x3000, 0x4000, 1 << 20, C.byref(out), None)
+    assert lib.vc_plan_finish(C.byref(d), *args) == _lib.VC_EINVAL
+    assert b"tables_wait_event is NULL" in lib.vc_last_error() and b"A.17" in lib.vc_last_error()
+    # with the event named, or the explicit opt-out, the call gets as far as the state check (this state was never begun)
+    d.tables_wait_event = 0x5000
+    assert lib.vc_plan_finish(C.byref(d), *args) == _lib.VC_EINVAL and b"vc_plan_begin" in lib.vc_last_error()
+    d.tables_wait_event, d.allow_unfenced_projection = None, 1
+    assert lib.vc_plan_finish(C.byref(d), *args) == _lib.VC_EINVAL and b"vc_plan_begin" in lib.vc_last_error()
+    # a chain without an image-space branch (VirConv8x LiDAR stream) needs neither
+    d.allow_unfenced_projection, B.has_2d = 0, 0
+    assert lib.vc_plan_finish(C.byref(d), *args) == _lib.VC_EINVAL and b"vc_plan_begin" in lib.vc_last_error()
+    # the header says so where a C caller reads it
+    hdr = open(HEADER).read()
+    assert "allow_unfenced_projection" in hdr and "CAUTION (LOG.md A.17" in hdr

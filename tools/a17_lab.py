@@ -101,7 +101,7 @@ def layer_inputs(be, batch, bs, dev, which):
     return x, w, dy, rb3
 
 
-def emulate(coords, calib, aug, stride, knock):
+def emulate(coords, calib, aug, stride, knock, want_intermediates=False):
     """fp32 restatement of project_uv_kernel on the CPU, op for op (every product and sum rounded separately); `knock` names one
     alteration of the inverse augmentation.  -> (n, 2) int64 [u, v]"""
     f32 = torch.float32
@@ -152,6 +152,10 @@ def emulate(coords, calib, aug, stride, knock):
     hom = [((rect[0] * p2t[:, k, 0] + rect[1] * p2t[:, k, 1]) + rect[2] * p2t[:, k, 2]) + p2t[:, k, 3] for k in range(2)]
     u = torch.nan_to_num(hom[0] / rect[2], nan=0.0, posinf=2.0e9, neginf=-2.0e9).trunc().clamp(-2147483648, 2147483647).long()
     v = torch.nan_to_num(hom[1] / rect[2], nan=0.0, posinf=2.0e9, neginf=-2.0e9).trunc().clamp(-2147483648, 2147483647).long()
+    if want_intermediates:
+        return {"X0": X, "Y0": Y, "Z0": Z, "Xs": Xs, "Ys": Ys, "Yf": Yf, "Zs": Zs, "X2": X2, "Y2": Y2, "junk": Xs * sa - Yf * ca,
+                "Xs*sa": Xs * sa, "Xs*ca": Xs * ca, "ca*Yf": ca * Yf, "sa*Yf": sa * Yf, "ca": ca, "sa": sa, "sc": sc,
+                "rect0": rect[0], "rect1": rect[1], "rect2": rect[2], "hom0": hom[0], "hom1": hom[1]}
     return torch.stack([u.clamp(0, 1399) // stride, v.clamp(0, 599) // stride], 1)
 
 
@@ -238,6 +242,8 @@ def run_micro(args):
         assert base == "none", aggr
         return None
 
+    if args.dump:
+        return run_dump(args, be, batch, idx, params, refs, victim, make_chunk, aug, dev)
     outs = [torch.empty((n, 3), dtype=torch.int32, device=dev) for _ in range(args.victims)]
     strides = (1, 2, 4, 8)
     for aggr_spec in args.aggr.split(","):
@@ -254,7 +260,7 @@ def run_micro(args):
         for mode in [int(m) for m in args.mode.split(",")]:
             for lds in [int(v) for v in args.lds.split(",")]:
                 dset(be, "plan_uv_mode", mode); dset(be, "plan_uv_lds", lds)
-                if mode in (0, 4, 5, 6) or mode >= 100:   # these share the product kernel's arithmetic: equal on an idle GPU
+                if mode in (0, 4, 5, 6) or mode >= 100:  # (200 + k: code shifted by 4 k bytes)   # these share the product kernel's arithmetic: equal on an idle GPU
                     r = torch.empty((n, 3), dtype=torch.int32, device=dev)
                     assert be.lib.vc_project_uv(P(idx), n, P(params), bs, 1, P(r), None, ctypes.c_void_p(st0)) == 0
                     torch.cuda.synchronize()
@@ -313,6 +319,66 @@ def run_micro(args):
                                       "unexplained": int(left.sum()), "waves_touched": int(torch.unique(rows // 64).numel())}), flush=True)
 
 
+def run_dump(args, be, batch, idx, params, refs, victim, make_chunk, aug, dev):
+    """project_uv_kernel<MODE, true>: every row stores X, Y, Z (behind the inverse augmentation), rect[0..2], hom[0..1]; the wrong rows'
+    stored values against the fp32 emulation -- WHICH register holds WHAT in the lanes that go wrong."""
+    n, bs = idx.shape[0], 4
+    P = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    aggr, _, which = args.aggr.split(",")[0].partition(":")
+    chunk = make_chunk(aggr, which or args.layer)
+    dbg = torch.zeros((64 + 4 * n * 8,), dtype=torch.int32, device=dev)
+    dbg[3] = n
+    torch.cuda.synchronize()
+    mode = int(args.mode.split(",")[0])
+    dset(be, "plan_uv_mode", mode)
+    ptr = dbg.data_ptr()
+    lo, hi = ptr & 0xFFFFFFFF, ptr >> 32
+    dset(be, "plan_uv_dbg_lo", lo - (1 << 32) if lo >= (1 << 31) else lo)
+    dset(be, "plan_uv_dbg_hi", hi)
+    out = torch.empty((n, 3), dtype=torch.int32, device=dev)
+    kept, launches, bad_launches = [], 0, 0
+    for r_ in range(args.rounds):
+        chunk()
+        with torch.cuda.stream(victim):
+            for k in range(args.victims):
+                assert be.lib.vc_project_uv(P(idx), n, P(params), bs, 1, P(out), None, ctypes.c_void_p(victim.cuda_stream)) == 0
+                bad = (out != refs[1]).any(1).nonzero().squeeze(1)
+                s8 = dbg[64: 64 + n * 8].view(torch.float32).view(n, 8)[bad]
+                kept.append((bad, s8, out[bad]))
+                launches += 1
+        if r_ % 4 == 3:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    dset(be, "plan_uv_dbg_lo", 0); dset(be, "plan_uv_dbg_hi", 0)
+    rows = torch.cat([k[0] for k in kept]).cpu()
+    s8 = torch.cat([k[1] for k in kept]).cpu()
+    bad_launches = sum(1 for k in kept if k[0].numel())
+    print(json.dumps({"exp": "dump", "aggr": aggr, "mode": mode, "launches": launches, "bad_launches": bad_launches, "wrong_rows": int(rows.numel()),
+                      "lanes": sorted(set((rows % 64).tolist()))[:8]}), flush=True)
+    if rows.numel() == 0:
+        return
+    E = emulate(idx.cpu()[rows], batch["calib"], aug, 1, "none", True)
+    names = ["X", "Y", "Z", "rect0", "rect1", "rect2", "hom0", "hom1"]
+    want = [E["X2"], E["Y2"], E["Zs"], E["rect0"], E["rect1"], E["rect2"], E["hom0"], E["hom1"]]
+    bits = lambda t: t.contiguous().view(torch.int32)   # noqa: E731
+    summary = {}
+    for c, (nm, w) in enumerate(zip(names, want)):
+        summary[nm + " wrong"] = int((bits(s8[:, c]) != bits(w)).sum())
+    # what do the wrong X / Y / Z hold?
+    for c, nm in ((0, "X"), (1, "Y"), (2, "Z")):
+        wrong = bits(s8[:, c]) != bits(want[c])
+        holds = {}
+        for cand, t in E.items():
+            if cand in ("rect0", "rect1", "rect2", "hom0", "hom1"):
+                continue
+            holds[cand] = int(((bits(s8[:, c]) == bits(t)) & wrong).sum())
+        summary[nm + " holds"] = {k: v for k, v in holds.items() if v}
+    print(json.dumps({"exp": "dump-summary", **summary}), flush=True)
+    for j in range(min(6, rows.numel())):
+        print("# row", int(rows[j]), "lane", int(rows[j]) % 64, "stored", [float(v) for v in s8[j]], "| expected", [float(w[j]) for w in want],
+              "| Xs Yf Y0", float(E["Xs"][j]), float(E["Yf"][j]), float(E["Y0"][j]), "ca sa sc", float(E["ca"][j]), float(E["sa"][j]), float(E["sc"][j]), flush=True)
+
+
 def run_stress(args):
     import test_plan_stress_gpu as T
     dev = torch.device("cuda", 0)
@@ -365,6 +431,7 @@ if __name__ == "__main__":
     m.add_argument("--mode", default="0", help="comma list of victim kernel modes")
     m.add_argument("--lds", default="0", help="comma list of dynamic LDS bytes of the victim launch")
     m.add_argument("--set", default="", help="library switches for the aggressor: key=value,...")
+    m.add_argument("--dump", action="store_true", help="diagnostics build of the kernel (every row stores its intermediates): what do the wrong rows hold?")
     m.add_argument("--explain", action="store_true", help="match the wrong rows against an fp32 emulation with single steps altered")
     m.add_argument("--mask", default="none")
     m.add_argument("--rounds", type=int, default=100)

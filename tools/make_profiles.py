@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--stats")
     ap.add_argument("--pmc-fetch")
     ap.add_argument("--pmc-write")
-    ap.add_argument("--traced", default="bwd_weight_kernel<32, 32;gather_gemm_v2_kernel<64, 32, false",
+    ap.add_argument("--traced", default="bwd_weight_kernel<32, 32;gather_gemm_v2_kernel<64, 32, false;bn_bwd_dx_pow2_kernel;gather_gemm_v2_kernel<8, 8, false",
                     help="';'-separated name fragments of the kernels whose HBM bytes per launch go into profiles/<tag>_traffic_*.json")
     ap.add_argument("--command", default="python bench.py --steps 10 --warmup 5 --no-cpu-baseline")
     args = ap.parse_args()
@@ -116,7 +116,9 @@ def main():
             k = key[0]
             fk, wk = fe[k][1] / max(fe[k][0], 1), wr[k][1] / max(wr[k][0], 1)
             m = re.search(r"bwd_weight_kernel<(\d+), (\d+)", k)
-            if m:
+            if "bn_bwd_dx" in k:
+                fname = f"{args.tag}_traffic_bn_bwd_dx.json"
+            elif m:
                 fname = f"{args.tag}_traffic_bwd_weight_{m.group(1)}_{m.group(2)}.json"
             else:
                 m = re.search(r"<(\d+), (\d+), (false|true)", k)

@@ -180,7 +180,7 @@ class PlanDesc(C.Structure):
                 ("image_shape", _I32 * 2), ("input_discard", _I32), ("input_keep_seed", C.c_uint64), ("input_keep", _P),
                 ("input_keep_rows", _I64), ("n_blocks", _I32), ("blocks", PlanBlock * PLAN_MAX_BLOCKS), ("has_tail", _I32),
                 ("tail", PlanConv), ("discard_rate", _D), ("need_grad", _I32), ("row_order_fwd", _I32), ("defer_early_tables", _I32),
-                ("reserved_", _I32), ("tables_wait_event", _P),
+                ("allow_unfenced_projection", _I32), ("tables_wait_event", _P),
                 ("debug_buf", _P), ("debug_bytes", _I64)]
 
 

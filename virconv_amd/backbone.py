@@ -339,8 +339,7 @@ class _PlanScope:
 
     def publish(self, plan, defer_wait=False):
         """`defer_wait`: the main stream does NOT wait here; the event goes into plan["_fwd_ready"] and the caller waits for it where it
-        first reads the plan (VirConv8x: the LiDAR stream's pass starts behind its own tables, plan["_lidar_ready"], while the guarded
-        image-space branch of the virtual-point stream is still behind the previous step)."""
+        first reads the plan."""
         if self.on_gpu:
             if self.deferred:
                 # the forward pass waits for the tables IT reads.  The group-plan sorts and backward row orders are ENQUEUED by
@@ -861,9 +860,10 @@ class VirConv8x(nn.Module):
                     arenas.append(idx_l[rid])
                     plan["lidar"][rid] = (idx_l[rid], rbs)
                 begun_m = list(rids) if self.mm else []
-                if scope.on_gpu and begun_m:      # the LiDAR stream's pass need not wait for the guarded rest
-                    plan["_lidar_ready"] = torch.cuda.Event()
-                    plan["_lidar_ready"].record(scope.side)
+                # (Round 5 let the LiDAR stream's pass start behind its own tables -- plan["_lidar_ready"] -- while the virtual-point
+                # stream's image-space branch was still being built: that pass is made of the very conv kernels the pixel projection
+                # must not share a compute unit with, LOG.md A.17 / ADVICE r5.  The main stream now waits for the whole plan; the
+                # configuration is host-bound and measures the same.)
                 for i, rid in enumerate(begun_m):
                     trans_param, tags = mm_inputs(i, rid)
                     stages, _, keep0, kept0, ar = native_plan.build(self, blocks, None, idx_m[rid], batch_size, calib, trans_param, tags,
@@ -875,7 +875,7 @@ class VirConv8x(nn.Module):
                     plan["mm"][rid] = {"keep0": keep0, "in_indices": kept0 if active else idx_m[rid], "stages": stages,
                                        "trans_param": trans_param}
                 plan["_arenas"] = arenas
-                return scope.publish(plan, defer_wait="_lidar_ready" in plan)
+                return scope.publish(plan)
             # operator-by-operator plans (the eval path over the x-concatenated tensor; empty / CPU tensors): the whole plan waits
             scope.guard_tables()
             if self.training:
@@ -903,7 +903,7 @@ class VirConv8x(nn.Module):
                         stages, _, keep0, kept0, ar = native_plan.build(self, blocks, None, idx, batch_size, calib, trans_param, tags,
                                                                         self.layer_discard_rate, batch_dict, NRConvBlock.IMAGE_SHAPE,
                                                                         input_discard_tag=(f"mm_input{rid}" if active else None),
-                                                                        deferred=scope.deferred)
+                                                                        deferred=scope.deferred, guard=scope.guard)
                         plan["mm"][rid] = {"keep0": keep0, "in_indices": kept0 if active else idx, "stages": stages,
                                            "trans_param": trans_param}
                         continue
@@ -933,8 +933,6 @@ class VirConv8x(nn.Module):
             if not torch.is_tensor(calib):
                 calib = ops.calib_tensor(calib, batch_dict["voxel_features_mm"].device)
         plan = self.build_plan(batch_dict, rids, batch_size, calib) if self.plan_ahead else None
-        if plan is not None and "_lidar_ready" in plan:
-            torch.cuda.current_stream().wait_event(plan.pop("_lidar_ready"))
 
         if self.training:
             for rid in rids:

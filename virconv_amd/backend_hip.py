@@ -91,9 +91,11 @@ class HipBackend:
         stream, INSIDE the library (vc_trace_begin): whichever call issues the launch -- an operator, a post_act_block unit or
         the whole feature pass -- is timed as it runs in the product path.  The active pairs of each traced table are counted
         on the device right after the launch (outside the bracket)."""
-        assert direction in ("fwd", "bwd", "dw", "all")   # "dw": the weight gradient <CI, CO>; "all": every conv launch (ck, cn ignored)
+        # "dw": the weight gradient <CI, CO>; "all": every conv launch (ck, cn ignored); "bn_dx": bn_bwd_dx_pow2_kernel, the largest
+        # bandwidth-bound kernel of the step (ck = channel filter, 0 = every channel count)
+        assert direction in ("fwd", "bwd", "dw", "all", "bn_dx")
         self._trace_pairs = torch.zeros((max_records,), dtype=torch.int64, device="cuda")
-        check(self.lib.vc_trace_begin({"fwd": 0, "bwd": 1, "dw": 2, "all": -1}[direction], int(ck), int(cn), int(max_records),
+        check(self.lib.vc_trace_begin({"fwd": 0, "bwd": 1, "dw": 2, "all": -1, "bn_dx": 3}[direction], int(ck), int(cn), int(max_records),
                                       _ptr(self._trace_pairs)), "vc_trace_begin")
         self._trace_cap = int(max_records)
 
@@ -108,6 +110,10 @@ class HipBackend:
         self._trace_cap, self._trace_pairs = 0, None
         out = []
         for r in recs[:n.value]:
+            if r.direction == 3:   # BatchNorm backward dx: reads x and dy, writes dx (N x C fp32 each) + the per-channel vectors
+                out.append({"ms": r.ms, "flops": 0.0, "bytes": 4.0 * (3 * r.n_out * r.ck + 6 * r.ck), "pairs": 0, "n_out": int(r.n_out),
+                            "windowed": False, "dir": "bn_dx", "ck": int(r.ck), "cn": int(r.cn), "kv": 0, "t0_ms": float(r.t0_ms)})
+                continue
             out.append({"ms": r.ms, "flops": 2.0 * r.pairs * r.ck * r.cn,
                         "bytes": 4.0 * (r.n_src * r.ck + r.n_out * r.cn + r.kv * r.ck * r.cn) + 4.0 * r.kv * r.n_out,
                         "pairs": int(r.pairs), "n_out": int(r.n_out), "windowed": bool(r.windowed),

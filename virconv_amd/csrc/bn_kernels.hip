@@ -521,8 +521,10 @@ int bn_bwd_dx_launch(const float* x, const float* dy, int dy_stride, int dy_col0
   const int lg = bn_lg_c4(c);
   VC_REQUIRE(lg >= 0, "bn_bwd_dx_launch: channel count must be a power of two");
   const int rows_per_block = (256 >> lg) * kBnRowsPerThread;
+  const int tr = trace_open_aux(3, c, st);
   VC_LAUNCH_WITH_STOP_EVENT(bn_bwd_dx_pow2_kernel, dim3((unsigned)cdiv(n, rows_per_block)), dim3(256), 0, st, x, dy, dy_stride, dy_col0,
                      n, c, lg, mean, var, gamma, beta, eps, relu, sums, dx, (unsigned*)nullptr);
+  if (tr >= 0) trace_close_aux(tr, 3, c, n, st);
   VC_CHECK_LAUNCH("bn_bwd_dx_kernel");
   return VC_OK;
 }
@@ -631,8 +633,10 @@ int vc_bn_relu_backward(const float* x, const float* dy, int dy_stride, int dy_c
   const int lg = bn_lg_c4(c);
   if (lg >= 0) {
     const int rows_per_block = (256 >> lg) * kBnRowsPerThread;
+    const int tr = trace_open_aux(3, c, st);
     VC_LAUNCH_WITH_STOP_EVENT(bn_bwd_dx_pow2_kernel, dim3((unsigned)cdiv(n, rows_per_block)), dim3(256), 0, st, x, dy, dy_stride,
                        dy_col0, n, c, lg, mean, var, gamma, beta, eps, relu, sums, dx, absmax_out);
+    if (tr >= 0) trace_close_aux(tr, 3, c, n, st);
   } else {
     VC_REQUIRE(absmax_out == nullptr, "vc_bn_relu_backward: absmax_out needs a power-of-two channel count");
     VC_LAUNCH_WITH_STOP_EVENT(bn_bwd_dx_kernel, dim3((unsigned)cdiv(n * (c / 4), 256)), dim3(256), 0, st, x, dy, dy_stride,
@@ -670,8 +674,10 @@ int vc_bn_relu_backward_from_partial(const float* x, const float* dy, int dy_str
   const int lg = bn_lg_c4(c);
   VC_REQUIRE(lg >= 0, "vc_bn_relu_backward_from_partial: channel count must be a power of two");
   const int rows_per_block = (256 >> lg) * kBnRowsPerThread;
+  const int tr = trace_open_aux(3, c, st);
   VC_LAUNCH_WITH_STOP_EVENT(bn_bwd_dx_pow2_kernel, dim3((unsigned)cdiv(n, rows_per_block)), dim3(256), 0, st, x, dy, dy_stride, dy_col0,
                      n, c, lg, mean, var, gamma, beta, eps, relu, sums, dx, absmax_out);
+  if (tr >= 0) trace_close_aux(tr, 3, c, n, st);
   VC_CHECK_LAUNCH("bn_bwd_dx_kernel");
   return VC_OK;
 }

@@ -248,6 +248,11 @@ inline thread_local StopEventSlot t_stop_event;
     }                                                                                                             \
   } while (0)
 
+// kernel timing of a bandwidth-bound kernel (vc_trace_begin direction 3 = bn_bwd_dx_pow2_kernel, the largest of the step by time;
+// conv_kernels.hip): start / stop events around the launch on its stream, record = {channels, rows}
+int trace_open_aux(int dir, int c, hipStream_t st);
+void trace_close_aux(int i, int dir, int c, int64_t n, hipStream_t st);
+
 static inline uint64_t coord_hash_capacity(int64_t n) {
   uint64_t oct = 128;
   while (oct <= (uint64_t)n) oct <<= 1;

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <utility>
 #include <atomic>
 #include <mutex>
 
@@ -1181,47 +1182,121 @@ __device__ __forceinline__ void bw_group16(const float* __restrict__ x, const fl
     for (int jb = 0; jb < VB; ++jb) acc[ja][jb] = mfma16<OT_>(ah[ja], bh[jb], acc[ja][jb]);
 }
 
+// ---- operand gathers of the 32-pair group (round 6: 16-byte loads for 32- and 16-channel rows) ----------------------------------------
+// The MFMA wants, in lane (i, q), ONE channel per operand register set and the 8 pairs 8q..8q+7 of the group (K-slots e = 0..7).  The plain
+// form lets the lane load its VC = C / 16 channels from each of the 8 rows: 8-byte loads at C = 32, 4-byte loads at C = 16 -- and the unit
+// that is busy in this kernel is the texture addresser, which spends as long on a 512-byte instruction as on a 1-KB one
+// (profiles/r05_mfma_busy_dw.md: TA 58 % busy, matrix pipes 18 %).  The wide form gives the S = 64 / C lanes of a 16-lane row that share a
+// 16-byte channel block DIFFERENT rows of the octet (8 / S each), so every load is 16 bytes, and hands each lane the channel it owns from
+// the others' registers with DPP row rotations (v_mov_b32_dpp row_ror:8 / 4 / 12 with bank masks: register-to-register, no LDS):
+//   C = 32: lanes i, i ^ 8 share block i & 7; the lower loads slots 0..3, the upper 4..7; the lower ends up with channels 4 (i & 7) + {0, 1},
+//           the upper with + {2, 3}: 4 loads + 16 DPP moves instead of 8 loads.
+//   C = 16: lanes with equal i & 3 share block i & 3; lane loads slots 2 (i >> 2) + {0, 1}; ends up with channel 4 (i & 3) + (i >> 2):
+//           2 loads + 32 DPP moves instead of 8 loads.
+// The K-slot -> pair assignment (slot 8q + e = pair 8q + e of the group) is the plain form's, so a wide operand pairs with a plain one
+// (C = 64, already 16-byte loads); only the lane -> channel map differs (BwChan), and that is the epilogue's business.
+template <int CTRL, int BANK>
+__device__ __forceinline__ float dpp_banks(float old, float src) {   // lanes of the banks in BANK take `src` through CTRL, the others keep `old`
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xF, BANK, false));
+}
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <int C, bool WIDE>
+struct BwChan {   // channel of M / N index m (0..15), register set j (0..C/16-1)
+  static __device__ __forceinline__ int of(int m, int j) {
+    if constexpr (WIDE && C == 32) return 4 * (m & 7) + 2 * (m >> 3) + j;
+    else if constexpr (WIDE && C == 16) return 4 * (m & 3) + (m >> 2);
+    else return ((C >= 16) ? C / 16 : 1) * m + j;
+  }
+};
+
+// v[j][e]: channel BwChan<C, WIDE>::of(i, j) of the row of K-slot 8q + e (`rows` = its index in `base`'s rows), zero from slot `npairs` on
+template <int C, bool WIDE>
+__device__ __forceinline__ void bw_gather8(const float* __restrict__ base, const int* rows, int npairs, int i, int q, bool lane_ok,
+                                           float (&v)[(C >= 16) ? C / 16 : 1][8]) {
+  constexpr int VC = (C >= 16) ? C / 16 : 1;
+  if constexpr (WIDE && C == 32) {
+    float r[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int slot = q * 8 + (i >> 3) * 4 + t;
+      if (slot < npairs) VecLoad<4>::ld(base + (int64_t)rows[slot] * 32 + 4 * (i & 7), r[t]);
+      else r[t][0] = r[t][1] = r[t][2] = r[t][3] = 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        v[j][t] = dpp_banks<0x128, 0xC>(r[t][j], r[t][2 + j]);       // upper lanes: the lower partner's channel 2 + j of slot t
+        v[j][4 + t] = dpp_banks<0x128, 0x3>(r[t][2 + j], r[t][j]);   // lower lanes: the upper partner's channel j of slot 4 + t
+      }
+  } else if constexpr (WIDE && C == 16) {
+    float r[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int slot = q * 8 + (i >> 2) * 2 + t;
+      if (slot < npairs) VecLoad<4>::ld(base + (int64_t)rows[slot] * 16 + 4 * (i & 3), r[t]);
+      else r[t][0] = r[t][1] = r[t][2] = r[t][3] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[0][e] = 0.f;
+    // receiver bank h (= i >> 2) takes channel h of slot 2 h' + t from the lane 4 rho below it in its row (h' = h - rho mod 4)
+    static_for<4>([&](auto rho_) {
+      constexpr int RHO = decltype(rho_)::value;
+      static_for<4>([&](auto h_) {
+        constexpr int H = decltype(h_)::value;
+        constexpr int E0 = 2 * ((H - RHO) & 3);
+        constexpr int CTRL = (RHO == 0) ? 0xE4 : 0x120 + 4 * RHO;    // quad_perm:[0,1,2,3] (own registers) | row_ror:4 rho
+        v[0][E0] = dpp_banks<CTRL, 1 << H>(v[0][E0], r[0][H]);
+        v[0][E0 + 1] = dpp_banks<CTRL, 1 << H>(v[0][E0 + 1], r[1][H]);
+      });
+    });
+  } else {
+    float a[8][VC];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int slot = q * 8 + e;
+      if (slot < npairs && lane_ok) VecLoad<VC>::ld(base + (int64_t)rows[slot] * C + VC * i, a[e]);
+      else {
+#pragma unroll
+        for (int j = 0; j < VC; ++j) a[e][j] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VC; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[j][e] = a[e][j];
+  }
+}
+
 // OT = VC_OPERAND_X6 (fp32 products as six bf16 terms, see split3): 32 pairs per step on v_mfma_f32_16x16x32_bf16; lane (i, q) loads the
 // rows of the 8 pairs 8q..8q+7 of the group; per channel those 8 values are cut into three bf16 octets.  The gradient rows' pieces are
 // formed once per group, the input rows' pieces per channel column (register pressure: 8 (VA + VB) operand floats + 12 VB piece
 // registers are live beside the VA VB accumulator quads).
-template <int CI, int CO>
+template <int CI, int CO, bool WA, bool WB>
 __device__ __forceinline__ void bw_group32_x6(const float* __restrict__ x, const float* __restrict__ dy, const int* qi, const int* qo,
                                               int npairs, int i, int q, bool a_ok, bool b_ok,
                                               f32x4 (&acc)[(CI >= 16) ? CI / 16 : 1][(CO >= 16) ? CO / 16 : 1]) {
   constexpr int VA = (CI >= 16) ? CI / 16 : 1, VB = (CO >= 16) ? CO / 16 : 1;
-  float a[8][VA], b[8][VB];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int slot = q * 8 + r;
-    const bool ok = slot < npairs;
-    const int pin = ok ? qi[slot] : 0, pout = ok ? qo[slot] : 0;
-    if (ok && a_ok) VecLoad<VA>::ld(x + (int64_t)pin * CI + VA * i, a[r]);
-    else {
-#pragma unroll
-      for (int j = 0; j < VA; ++j) a[r][j] = 0.f;
-    }
-    if (ok && b_ok) VecLoad<VB>::ld(dy + (int64_t)pout * CO + VB * i, b[r]);
-    else {
-#pragma unroll
-      for (int j = 0; j < VB; ++j) b[r][j] = 0.f;
-    }
-  }
+  float a[VA][8], b[VB][8];
+  bw_gather8<CI, WA>(x, qi, npairs, i, q, a_ok, a);
+  bw_gather8<CO, WB>(dy, qo, npairs, i, q, b_ok, b);
   u32x4 bh[VB], bm[VB], bl[VB];
 #pragma unroll
   for (int j = 0; j < VB; ++j) {
-    const float t0[4] = {b[0][j], b[1][j], b[2][j], b[3][j]}, t1[4] = {b[4][j], b[5][j], b[6][j], b[7][j]};
     u32x2 h0, m0, l0, h1, m1, l1;
-    split3(t0, h0, m0, l0);
-    split3(t1, h1, m1, l1);
+    split3(&b[j][0], h0, m0, l0);
+    split3(&b[j][4], h1, m1, l1);
     bh[j] = u32x4{h0.x, h0.y, h1.x, h1.y}; bm[j] = u32x4{m0.x, m0.y, m1.x, m1.y}; bl[j] = u32x4{l0.x, l0.y, l1.x, l1.y};
   }
 #pragma unroll
   for (int ja = 0; ja < VA; ++ja) {
-    const float t0[4] = {a[0][ja], a[1][ja], a[2][ja], a[3][ja]}, t1[4] = {a[4][ja], a[5][ja], a[6][ja], a[7][ja]};
     u32x2 h0, m0, l0, h1, m1, l1;
-    split3(t0, h0, m0, l0);
-    split3(t1, h1, m1, l1);
+    split3(&a[ja][0], h0, m0, l0);
+    split3(&a[ja][4], h1, m1, l1);
     const u32x4 ah = {h0.x, h0.y, h1.x, h1.y}, am = {m0.x, m0.y, m1.x, m1.y}, al = {l0.x, l0.y, l1.x, l1.y};
 #pragma unroll
     for (int jb = 0; jb < VB; ++jb) {
@@ -1235,7 +1310,7 @@ __device__ __forceinline__ void bw_group32_x6(const float* __restrict__ x, const
 
 // OT != VC_OPERAND_F32: 16 pairs per MFMA step (v_mfma_f32_16x16x16_{f16,bf16}); lane (i, q) loads the rows of the 4 pairs
 // 4q..4q+3 of the group and packs, per channel, those 4 values (rounded to 16 bit) into one operand.
-template <int CI, int CO, int OT>
+template <int CI, int CO, int OT, bool WIDE = false>
 __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                          const int32_t* __restrict__ tbl, int64_t n_out, int kv,
                                                          int64_t rows_per_block, int nsplit, int legacy_order,
@@ -1252,6 +1327,13 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
 #endif
   constexpr int U = ((VA * VB >= 8) ? 2 : 4) * VC_BW_UMUL;             // groups of 4 pairs gathered per iteration
   constexpr int GP = (OT == VC_OPERAND_F32) ? 4 : (OT == VC_OPERAND_X6 ? 32 : 16);   // pairs per MFMA K-step
+  // measured (profiles/r06_dw_wide.md): 32-channel operands gain 5-11 % where the other operand is not the 64-channel one; the 16-channel
+  // form (2 loads + 32 DPP moves) loses 2-9 %: kept in the source (VC_BW_WIDE16) but not instantiated by default
+#ifndef VC_BW_WIDE16
+#define VC_BW_WIDE16 0
+#endif
+  constexpr bool WA = WIDE && OT == VC_OPERAND_X6 && (CI == 32 || (VC_BW_WIDE16 && CI == 16));
+  constexpr bool WB = WIDE && OT == VC_OPERAND_X6 && ((CO == 32 && CI != 64) || (VC_BW_WIDE16 && CO == 16));
   __shared__ int q_in[4][136];
   __shared__ int q_out[4][136];
   __shared__ float red[CI * CO];
@@ -1359,7 +1441,7 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
       }
     } else if constexpr (OT == VC_OPERAND_X6) {
       const int ng = qlen >> 5;
-      for (int g = 0; g < ng; ++g) bw_group32_x6<CI, CO>(x, dy, qi + g * 32, qo + g * 32, 32, i, q, a_ok, b_ok, acc);
+      for (int g = 0; g < ng; ++g) bw_group32_x6<CI, CO, WA, WB>(x, dy, qi + g * 32, qo + g * 32, 32, i, q, a_ok, b_ok, acc);
     } else {
       const int ng = qlen >> 4;
       for (int g = 0; g < ng; ++g) bw_group16<CI, CO, OT>(x, dy, qi + g * 16, qo + g * 16, 16, i, q, a_ok, b_ok, acc);
@@ -1394,7 +1476,7 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
         for (int jb = 0; jb < VB; ++jb)
           acc[ja][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ja], b[jb], acc[ja][jb], 0, 0, 0);
     } else if constexpr (OT == VC_OPERAND_X6) {
-      bw_group32_x6<CI, CO>(x, dy, qi, qo, qlen, i, q, a_ok, b_ok, acc);
+      bw_group32_x6<CI, CO, WA, WB>(x, dy, qi, qo, qlen, i, q, a_ok, b_ok, acc);
     } else {
       bw_group16<CI, CO, OT>(x, dy, qi, qo, qlen, i, q, a_ok, b_ok, acc);
     }
@@ -1409,7 +1491,7 @@ __global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict
         for (int jb = 0; jb < VB; ++jb)
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
-            const int m = q * 4 + reg, ci = VA * m + ja, co = VB * i + jb;
+            const int m = q * 4 + reg, ci = BwChan<CI, WA>::of(m, ja), co = BwChan<CO, WB>::of(i, jb);
             if (m < MA && i < NB) {
               float* p = &red[ci * CO + co];
               *p = (wv == 0) ? acc[ja][jb][reg] : (*p + acc[ja][jb][reg]);
@@ -1744,6 +1826,20 @@ static inline void trace_close(int i, int dir, int ck, int cn, const int32_t* tb
   } else {
     T.rec[i].pairs = -1;
   }
+  T.n = i + 1;
+}
+
+int trace_open_aux(int dir, int c, hipStream_t st) {
+  TraceState& T = g_trace;
+  if (!T.on || T.n >= T.cap || T.dir != dir || (T.ck != 0 && T.ck != c)) return -1;
+  const int i = T.n;
+  if (hipEventRecord(T.ev[2 * i], st) != hipSuccess) return -1;
+  return i;
+}
+void trace_close_aux(int i, int dir, int c, int64_t n, hipStream_t st) {
+  TraceState& T = g_trace;
+  if (hipEventRecord(T.ev[2 * i + 1], st) != hipSuccess) return;
+  T.rec[i] = vc_trace_record{0.f, 0, c, c, 0, n, n, 0, dir, 0.f};
   T.n = i + 1;
 }
 
@@ -2293,6 +2389,7 @@ static int dispatch_ck(int ck, int cn, const float* src, const float* src_centre
 int g_bw_rows_per_split = 1024;  // weight gradient: target rows per block (vc_debug_set bw_rows_per_split); more rows = fewer, longer blocks and fewer partial sums
 int g_bw_legacy_order = 0;      // debug: 1 = offset-major block order of the weight-gradient kernel
 int g_bw_split = 1;             // vc_debug_set bw_split: 1 (default) = weight-gradient products on the bf16 matrix cores as six split terms (bw_group32_x6); 0 = v_mfma_f32_16x16x4_f32
+int g_bw_wide = 1;              // vc_debug_set bw_wide: 16-byte operand gathers + DPP exchange in the split weight gradient at 32 / 16 channels (0: A/B)
 int g_bw_small = 1;             // vc_debug_set bw_small: 0 = bwd_weight_kernel for every shape; 1 = bwd_weight_small_kernel where it measured faster; 3 = wherever it applies
 int g_bw_variant = 1;           // vc_debug_set bw_variant: 1 = bwd_weight_kernel, 2 = bwd_weight_v2_kernel (dy window in LDS) where it applies
 extern int g_pass_dw_main_tail; // pass.hip
@@ -2302,6 +2399,7 @@ extern int g_pass_fork_ext_event; // pass.hip
 extern int g_bn_fused_partial;  // bn_kernels.hip
 extern int g_pass_defer_dw_reduce;  // pass.hip
 extern int g_plan_subm_bitmap, g_plan_image_2d, g_plan_parity_order, g_plan_params_pad, g_plan_reprepare, g_plan_uv_mode, g_plan_uv_poison, g_plan_uv_lds;   // plan.hip
+extern long long g_plan_uv_dbg;   // plan.hip
 int64_t a17_mismatch_read();   // index_kernels.hip
 extern int g_group_plan_radix, g_group_plan_onesweep, g_group_plan_multi_onesweep, g_plan_group_multi;   // group_kernels.hip
 extern int g_sp_mark_variant;    // index_kernels.hip
@@ -2372,7 +2470,9 @@ static int launch_bw(const float* x, const float* dy, const int32_t* tbl, int64_
   if constexpr (CI >= 16 && CO >= 16) {  // 16-bit operands only where both channel counts are >= 16 (as in the gather-GEMM)
     if (launched) {
     } else if (ot == VC_OPERAND_F32 && g_bw_split) {   // fp32 products as six bf16 terms (vc_debug_set bw_split)
-      hipLaunchKernelGGL((bwd_weight_kernel<CI, CO, VC_OPERAND_X6>), dim3(nblocks), dim3(256), 0, st, VC_ARGS);
+      constexpr bool HAS_WIDE = CI == 32 || (CO == 32 && CI != 64);   // 16-byte operand gathers (vc_debug_set bw_wide, default 1)
+      if (HAS_WIDE && g_bw_wide) hipLaunchKernelGGL((bwd_weight_kernel<CI, CO, VC_OPERAND_X6, HAS_WIDE>), dim3(nblocks), dim3(256), 0, st, VC_ARGS);
+      else hipLaunchKernelGGL((bwd_weight_kernel<CI, CO, VC_OPERAND_X6>), dim3(nblocks), dim3(256), 0, st, VC_ARGS);
       launched = true;
     } else if (ot == VC_OPERAND_F16) {
       hipLaunchKernelGGL((bwd_weight_kernel<CI, CO, VC_OPERAND_F16>), dim3(nblocks), dim3(256), 0, st, VC_ARGS);
@@ -2489,6 +2589,7 @@ int vc_debug_set(const char* key, int value) {
   if (!strcmp(key, "bw_legacy_order")) { g_bw_legacy_order = value; return VC_OK; }
   if (!strcmp(key, "bw_small")) { g_bw_small = value; return VC_OK; }
   if (!strcmp(key, "bw_split")) { g_bw_split = value; return VC_OK; }
+  if (!strcmp(key, "bw_wide")) { g_bw_wide = value; return VC_OK; }
   if (!strcmp(key, "bw_rows_per_split")) { if (value >= 256) g_bw_rows_per_split = value; return VC_OK; }
   if (!strcmp(key, "pass_dw_main_tail")) { g_pass_dw_main_tail = value; return VC_OK; }
   if (!strcmp(key, "pass_bwd_epilogue")) { g_pass_bwd_epilogue = value; return VC_OK; }
@@ -2507,6 +2608,8 @@ int vc_debug_set(const char* key, int value) {
   if (!strcmp(key, "plan_params_pad")) { g_plan_params_pad = value < 0 ? 0 : (value + 255) & ~255; return VC_OK; }
   if (!strcmp(key, "plan_reprepare")) { g_plan_reprepare = value; return VC_OK; }
   if (!strcmp(key, "plan_uv_mode")) { g_plan_uv_mode = value; return VC_OK; }
+  if (!strcmp(key, "plan_uv_dbg_lo")) { g_plan_uv_dbg = (g_plan_uv_dbg & ~0xFFFFFFFFLL) | (long long)(unsigned)value; return VC_OK; }   // a device address in two halves
+  if (!strcmp(key, "plan_uv_dbg_hi")) { g_plan_uv_dbg = (g_plan_uv_dbg & 0xFFFFFFFFLL) | ((long long)(unsigned)value << 32); return VC_OK; }
   if (!strcmp(key, "plan_uv_lds")) { g_plan_uv_lds = value < 0 ? 0 : (value > 160 * 1024 ? 160 * 1024 : value); return VC_OK; }
   if (!strcmp(key, "plan_uv_poison")) { g_plan_uv_poison = value; return VC_OK; }
   if (!strcmp(key, "plan_radix_sort")) return experiment_key(key, value, 0, &g_group_plan_radix);
@@ -2522,7 +2625,8 @@ int vc_debug_set(const char* key, int value) {
 }
 
 int vc_trace_begin(int direction, int ck, int cn, int max_records, int64_t* dev_pairs) {
-  VC_REQUIRE(((direction == -1) || ((direction >= 0 && direction <= 2) && ck >= 1 && cn >= 1)) && max_records >= 1 && dev_pairs,
+  VC_REQUIRE(((direction == -1) || ((direction >= 0 && direction <= 2) && ck >= 1 && cn >= 1) || (direction == 3 && ck >= 0)) &&
+                 max_records >= 1 && dev_pairs,
              "vc_trace_begin: invalid argument");
   TraceState& T = g_trace;
   T.on = false;

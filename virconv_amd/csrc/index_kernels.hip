@@ -472,6 +472,7 @@ __device__ __forceinline__ int sat_int(float f) {
 }
 
 extern int g_plan_uv_mode, g_plan_uv_lds;   // plan.hip
+extern long long g_plan_uv_dbg;
 __device__ unsigned long long g_a17_mismatch = 0;   // MODE 6: threads whose two computations of the inverse augmentation disagreed (vc_debug_get a17_mismatch)
 
 // MODE / DBG: developer diagnostics of LOG.md A.15 / A.17 (the product path is <0, false>).
@@ -490,6 +491,13 @@ __global__ void __launch_bounds__(256) project_uv_kernel(const int32_t* __restri
                                                          float minz, int32_t* __restrict__ uv,
                                                          float* __restrict__ depth, int32_t* dbg, int dbg_records, int has_trans_arg) {
   if constexpr (MODE == 4) __builtin_amdgcn_s_setprio(3);   // round 6 lab: this wave wins every issue arbitration on its SIMD
+  if constexpr (MODE >= 200 && MODE < 300) {   // round 6 lab: MODE 0 with its code moved by 4 (MODE - 200) bytes (s_nop 0 at the entry: code placement, not timing)
+#define VC_A17_SHIFT(n) asm volatile(".rept " #n "\n\ts_nop 0\n\t.endr")
+    if constexpr (MODE == 201) VC_A17_SHIFT(1); else if constexpr (MODE == 202) VC_A17_SHIFT(2); else if constexpr (MODE == 204) VC_A17_SHIFT(4);
+    else if constexpr (MODE == 208) VC_A17_SHIFT(8); else if constexpr (MODE == 212) VC_A17_SHIFT(12); else if constexpr (MODE == 216) VC_A17_SHIFT(16);
+    else if constexpr (MODE == 224) VC_A17_SHIFT(24); else if constexpr (MODE == 232) VC_A17_SHIFT(32);
+#undef VC_A17_SHIFT
+  }
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int4 r = *reinterpret_cast<const int4*>(indices + i * 4);  // [b, z, y, x]
@@ -531,7 +539,7 @@ __global__ void __launch_bounds__(256) project_uv_kernel(const int32_t* __restri
       X = has ? X2 : X; Y = has ? Y2 : Y; Z = has ? Zs : Z;
     } else if (has) {
       const float sc = P[27];
-      if constexpr (MODE == 5 || MODE >= 100) {   // round 6 lab: steps of the block fenced by 16 wait states (values pinned in VGPRs at each fence)
+      if constexpr (MODE == 5 || (MODE >= 100 && MODE < 200)) {   // round 6 lab: steps of the block fenced by 16 wait states (values pinned in VGPRs at each fence)
         // MODE 5: every fence; MODE 100 + mask: 1 behind the parameter loads, 2 behind the divisions, 4 behind the flip, 8 behind the four
         // products, 16 behind the first sum, 32 behind the second
         constexpr int PM = (MODE == 5) ? 63 : MODE - 100;
@@ -1301,6 +1309,9 @@ int project_uv_debug(const int32_t* indices, int64_t n, const float* params, int
     else if (mode == 100) VC_UV_LAUNCH(100, false); else if (mode == 101) VC_UV_LAUNCH(101, false); else if (mode == 102) VC_UV_LAUNCH(102, false);
     else if (mode == 104) VC_UV_LAUNCH(104, false); else if (mode == 108) VC_UV_LAUNCH(108, false); else if (mode == 116) VC_UV_LAUNCH(116, false);
     else if (mode == 132) VC_UV_LAUNCH(132, false); else if (mode == 162) VC_UV_LAUNCH(162, false);
+    else if (mode == 201) VC_UV_LAUNCH(201, false); else if (mode == 202) VC_UV_LAUNCH(202, false); else if (mode == 204) VC_UV_LAUNCH(204, false);
+    else if (mode == 208) VC_UV_LAUNCH(208, false); else if (mode == 212) VC_UV_LAUNCH(212, false); else if (mode == 216) VC_UV_LAUNCH(216, false);
+    else if (mode == 224) VC_UV_LAUNCH(224, false); else if (mode == 232) VC_UV_LAUNCH(232, false);
     else VC_UV_LAUNCH(0, false);
   }
 #undef VC_UV_LAUNCH
@@ -1541,8 +1552,8 @@ int vc_project_uv(const int32_t* indices, int64_t n, const float* params, int ba
                   float* depth, void* stream) {
   VC_REQUIRE(n >= 0 && params && stride >= 1 && (n == 0 || (indices && uv)), "vc_project_uv: null/invalid argument");
   if (n == 0) return VC_OK;
-  if ((g_plan_uv_mode != 0 || g_plan_uv_lds != 0) && !depth)   // developer diagnostics (vc_debug_set plan_uv_mode / plan_uv_lds; tools/a17_lab.py)
-    return project_uv_debug(indices, n, params, batch_size, stride, uv, nullptr, 0, g_plan_uv_mode, 1, (hipStream_t)stream);
+  if ((g_plan_uv_mode != 0 || g_plan_uv_lds != 0 || g_plan_uv_dbg != 0) && !depth)   // developer diagnostics (vc_debug_set plan_uv_mode / plan_uv_lds / plan_uv_dbg; tools/a17_lab.py)
+    return project_uv_debug(indices, n, params, batch_size, stride, uv, (int32_t*)(uintptr_t)g_plan_uv_dbg, 0, g_plan_uv_mode, 1, (hipStream_t)stream);
   // hard-coded range / voxel size of the reference (spconv_backbone.py:8): python floats (fp64) rounded to fp32 on use
   const double vs = 0.05 * stride;
   const float vsf = (float)vs;

@@ -37,6 +37,7 @@ int g_plan_params_pad = 0;    // vc_debug_set plan_params_pad: bytes of padding 
 int g_plan_reprepare = 0;     // vc_debug_set plan_reprepare: 1 = write the parameter block again right in front of every projection of
                               // vc_plan_finish (damage to the block between the two calls is then repaired: is the block what is hit?)
 int g_plan_uv_poison = 0;     // vc_debug_set plan_uv_poison: 1 = every uv buffer is filled with 0x7F bytes in front of the projection (diagnostics)
+long long g_plan_uv_dbg = 0;  // vc_debug_set plan_uv_dbg: device address of a diagnostics buffer for the stand-alone projection (project_uv_kernel<MODE, true>: every row's intermediates)
 int g_plan_uv_lds = 0;        // vc_debug_set plan_uv_lds: dynamic LDS bytes of the stand-alone projection launch (round 6 lab, tools/a17_lab.py)
 int g_plan_uv_mode = 0;       // vc_debug_set plan_uv_mode: project_uv_kernel<MODE> of the plan's projections (0 = product kernel)
 int project_uv_debug(const int32_t* indices, int64_t n, const float* params, int batch_size, int stride, int32_t* uv, int32_t* dbg,
@@ -1031,6 +1032,19 @@ int vc_plan_finish(const vc_plan_desc* d, vc_plan_state* state, void* arena_a, v
   if (rc != VC_OK) return rc;
   VC_REQUIRE(state && arena_a && arena_b && out, "vc_plan_finish: null argument");
   PlanState& S = *reinterpret_cast<PlanState*>(state);
+  {
+    // LOG.md A.17: the pixel projection computes wrong values in lanes 48-63 of some waves when its waves share a compute unit with
+    // the bf16-split gather-GEMM / weight-gradient waves (round 6: disjoint CU masks or a projection block that owns its CU's LDS
+    // remove it, profiles/r06_a17_cu_mask.md).  An unfenced image-space branch must be asked for, not got by leaving a field zero.
+    bool has2d = false;
+    for (int b = 0; b < d->n_blocks; ++b) has2d = has2d || d->blocks[b].has_2d != 0;
+    if (has2d && !d->tables_wait_event && !d->allow_unfenced_projection) {
+      set_error("vc_plan_finish: this plan has an image-space branch (pixel projection) and tables_wait_event is NULL: record an event on the "
+                "stream of the feature passes behind the previous pass and name it here, or set allow_unfenced_projection = 1 if no conv "
+                "kernel of this library can be running while the plan's tables are built (LOG.md A.17)");
+      return VC_EINVAL;
+    }
+  }
   VC_REQUIRE(S.magic == kPlanMagic && S.waited, "vc_plan_finish: call vc_plan_begin and vc_plan_wait first");
   size_t need = 0;
   {
@@ -1046,6 +1060,7 @@ int vc_plan_finish(const vc_plan_desc* d, vc_plan_state* state, void* arena_a, v
   // kernels of a running feature pass it computes wrong pixels in lanes 48-63 of some waves (LOG.md A.15 / A.17)
   bool any2d = false;
   for (int b = 0; b < d->n_blocks; ++b) any2d = any2d || d->blocks[b].has_2d != 0;
+  // (checked before anything is enqueued: see the top of this function)
   if (d->tables_wait_event && any2d) VC_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)d->tables_wait_event, 0));
   if (any2d) {
     PlanState T = S;

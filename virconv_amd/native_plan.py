@@ -26,6 +26,17 @@ _RING = 64                                # plans between their begin and their 
 ARENA_ALLOC = None                        # developer hook (tools/det_check.py): callable(n int32 words) -> tensor, instead of torch.empty
 
 
+_WARNED = []
+
+
+def _warn_unfenced():
+    if not _WARNED:
+        _WARNED.append(1)
+        import warnings
+        warnings.warn("VIRCONV_PLAN_GUARD=0: the pixel projection of the geometry plan runs unfenced; beside the conv kernels of a feature pass "
+                      "it computes wrong pixels in some waves (LOG.md A.17).  Diagnostics only.", RuntimeWarning, stacklevel=3)
+
+
 def _arena(nbytes: int, dev) -> torch.Tensor:
     nwords = (nbytes + 3) >> 2
     if ARENA_ALLOC is not None:
@@ -135,10 +146,13 @@ class ChainPlan:
     runs it after the forward pass is on its stream (backbone.join_plan).
     `guard` (torch.cuda.Event | None): the stream waits for it in front of its first TABLE kernel (vc_plan_desc.tables_wait_event;
     backbone.PLAN_GUARD).  `defer_tables`: vc_plan_begin builds no table at all -- for callers that begin several plans, or one a
-    step early, before they finish any (`finish(guard=...)` then names the event)."""
+    step early, before they finish any (`finish(guard=...)` then names the event).  A chain with an image-space branch and no guard
+    at all is refused unless `unfenced=True` (the caller's device is otherwise idle) or backbone.PLAN_GUARD == 0 (diagnostics)."""
 
     def __init__(self, model, kind: str, chain, tail, idx: torch.Tensor, batch_size: int, calib, trans_param, discard_tags, rate: float,
-                 batch_dict, image_shape, input_discard_tag=None, deferred=None, guard=None, defer_tables=False, debug_buf=None):
+                 batch_dict, image_shape, input_discard_tag=None, deferred=None, guard=None, defer_tables=False, debug_buf=None,
+                 unfenced=False):
+        self.unfenced = bool(unfenced)
         be = ops.get_backend()
         lib = be.lib
         dev = idx.device
@@ -159,6 +173,7 @@ class ChainPlan:
         d.need_grad = 1 if torch.is_grad_enabled() else 0
         d.row_order_fwd = 1 if ops.ROW_ORDER == "strided" else 0
         d.defer_early_tables = 1 if defer_tables else 0
+        d.allow_unfenced_projection = 0
         d.tables_wait_event = None
         if guard is not None:
             hold.append(guard)
@@ -233,6 +248,17 @@ class ChainPlan:
         if guard is not None:
             hold.append(guard)
             d.tables_wait_event = guard.cuda_event
+        if not d.tables_wait_event and any(cb.conv2d is not None for cb in self.chain):
+            # LOG.md A.17: an image-space branch without the fence has to be asked for (vc_plan_finish refuses it otherwise)
+            from . import backbone
+            if backbone.PLAN_GUARD == 0 or self.unfenced:
+                d.allow_unfenced_projection = 1
+                if backbone.PLAN_GUARD == 0:
+                    _warn_unfenced()
+            else:
+                raise RuntimeError("virconv_amd geometry plan: a plan with an image-space branch needs the event its pixel projection waits for "
+                                   "(`guard`: recorded on the stream of the feature passes; backbone._PlanScope does it) -- or `unfenced=True` "
+                                   "from a caller whose device is otherwise idle (LOG.md A.17)")
         _lib.check(lib.vc_plan_wait(dref, sref), "vc_plan_wait")          # the ONE host synchronisation of the plan
         self.counts_read = True
         nb = lib.vc_plan_finish_arena_bytes(dref, sref)
@@ -282,10 +308,10 @@ class ChainPlan:
 
 
 def build_chain(model, kind: str, chain, tail, idx: torch.Tensor, batch_size: int, calib, trans_param, discard_tags, rate: float,
-                batch_dict, image_shape, input_discard_tag=None, deferred=None, guard=None):
+                batch_dict, image_shape, input_discard_tag=None, deferred=None, guard=None, unfenced=False):
     """ChainPlan begun and finished back to back (see there)."""
     return ChainPlan(model, kind, chain, tail, idx, batch_size, calib, trans_param, discard_tags, rate, batch_dict, image_shape,
-                     input_discard_tag, deferred, guard).finish()
+                     input_discard_tag, deferred, guard, unfenced=unfenced).finish()
 
 
 def nrconv_stages(blocks, res):
@@ -322,10 +348,11 @@ def finish_nrconv(cp: ChainPlan, blocks, guard=None):
 
 
 def build(model, blocks, tail, idx: torch.Tensor, batch_size: int, calib, trans_param, discard_tags, rate: float, batch_dict,
-          image_shape, input_discard_tag=None, deferred=None, guard=None):
+          image_shape, input_discard_tag=None, deferred=None, guard=None, unfenced=False):
     """The plan of a chain of NRConvBlocks `blocks` = [(block, uv stride)] in the form backbone._plan_nrconv_chain returns:
     -> (stages, tail Rulebook | None, input keep | None, kept input indices | None, [arena_a, arena_b])."""
     res, rb_tail, in_keep, in_kept, arenas = build_chain(model, nrconv_kind(blocks, tail, input_discard_tag),
                                                          nrconv_blocks(blocks), tail, idx, batch_size, calib, trans_param,
-                                                         discard_tags, rate, batch_dict, image_shape, input_discard_tag, deferred, guard)
+                                                         discard_tags, rate, batch_dict, image_shape, input_discard_tag, deferred, guard,
+                                                         unfenced)
     return nrconv_stages(blocks, res), rb_tail, in_keep, in_kept, arenas
