@@ -200,7 +200,7 @@ def test_feature_pass_layout_and_validation_without_gpu():
     # kernel timing facility: argument checks; ending a trace that never began is a no-op
     n = C.c_int(-1)
     assert lib.vc_trace_end(None, 0, C.byref(n)) == _lib.VC_OK and n.value == 0
-    assert lib.vc_trace_begin(3, 64, 32, 16, 0x1000) == _lib.VC_EINVAL   # directions: 0 fwd, 1 bwd-input, 2 weight gradient, -1 all
+    assert lib.vc_trace_begin(4, 64, 32, 16, 0x1000) == _lib.VC_EINVAL   # directions: 0 fwd, 1 bwd-input, 2 weight gradient, 3 BatchNorm backward dx, -1 all
     assert lib.vc_trace_begin(0, 64, 32, 16, None) == _lib.VC_EINVAL
 
 

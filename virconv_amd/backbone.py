@@ -295,6 +295,46 @@ def _guard_wanted(device) -> bool:
     return PLAN_GUARD != 0
 
 
+# Round 6: WHAT the projection must be kept away from is known (tools/a17_lab.py, profiles/r06_a17_cu_mask.md): waves of the bf16-split
+# gather-GEMM / weight-gradient kernels on the same compute unit.  Every other kernel of a train step -- BatchNorm, group sums, the loss,
+# clip, AdamW, the exact-fp32-MFMA convs -- ran beside 800 projection launches without one wrong row, and the parameter-level soak
+# (tests/test_soak_gpu.py) is green.  So the event need not be the START of the next forward: a native backward pass marks its own end
+# (note_pass_end: behind its last conv kernel and the join of the weight-gradient stream) together with the library's count of conv
+# launches; if no conv kernel has been enqueued since, the next plan waits for THAT event and its image-space branch runs under the
+# clip / optimizer kernels instead of in a bubble in front of the forward pass (VIRCONV_PLAN_GUARD_EARLY=0: the round-5 placement).
+PLAN_GUARD_EARLY = os.environ.get("VIRCONV_PLAN_GUARD_EARLY", "1") != "0"
+_PASS_END = {}
+
+
+def _conv_launch_seq() -> int:
+    import ctypes
+    v = ctypes.c_int64(0)
+    be = ops.get_backend()
+    if not hasattr(be, "lib") or be.lib.vc_debug_get(b"conv_launch_seq", ctypes.byref(v)) != 0:
+        return -1
+    return int(v.value)
+
+
+def note_pass_end(device) -> None:
+    """Called by the native feature pass at the end of its backward sweep (current stream = the caller's main stream)."""
+    if not PLAN_GUARD_EARLY or PLAN_GUARD == 0:
+        return
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    _PASS_END[torch.device(device).index] = (ev, _conv_launch_seq(), torch.cuda.current_stream().cuda_stream)
+
+
+def _early_guard(device, main):
+    """The event of the last backward pass if nothing convolutional was enqueued behind it (and it sits on this stream), else None."""
+    rec = _PASS_END.pop(torch.device(device).index, None)
+    if rec is None:
+        return None
+    ev, seq, stream = rec
+    if seq < 0 or seq != _conv_launch_seq() or stream != main.cuda_stream:
+        return None
+    return ev
+
+
 class _PlanScope:
     """Run the geometry plan on the high-priority side stream (see VirConvL8x.build_plan) and hand the result to the main
     stream.  CPU tensors: a no-op scope.  `guard`: the event the plan's image-space branch waits for (see PLAN_GUARD), or None."""
@@ -311,7 +351,7 @@ class _PlanScope:
                 mark = _bound_run_ahead(ref_tensor.device, self.main)
             self.side = _plan_stream(ref_tensor.device)
             if not ahead and _guard_wanted(ref_tensor.device):   # (a plan begun ahead names the event when it is finished)
-                self.guard = mark
+                self.guard = (_early_guard(ref_tensor.device, self.main) if PLAN_GUARD_EARLY else None) or mark
             ready = batch_dict.get("inputs_ready_event")
             if ready is not None:
                 self.side.wait_event(ready)  # inputs were produced before this event: no need to wait for the stream tail

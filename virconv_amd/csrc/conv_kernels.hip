@@ -1929,6 +1929,10 @@ static inline bool use_window_kernel(int flags, int ot, const int32_t* rep, cons
 // are left to the BatchNorm kernels; 2 = tests: partial rows, then bn_finish_reference_kernel (the same three levels, one block).
 int g_conv_bn_finish = 1;
 static std::atomic<long long> g_fin_launches{0};   // vc_debug_get "conv_bn_finish_launches"
+// vc_debug_get "conv_launch_seq": conv kernel launches (gather-GEMM and weight gradient, any operand type) enqueued by this process so
+// far.  A caller that recorded an event behind a feature pass can tell later whether any conv kernel was enqueued since (backbone.py:
+// the event the pixel projection waits for, LOG.md A.17).
+static std::atomic<long long> g_conv_launch_seq{0};
 struct FinState {
   bool armed = false, taken = false;
   BnFinishRequest req{};
@@ -2016,6 +2020,7 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
   const int64_t rows_per_block = 4 * kRT * 16;
   ConvEpilogue epi = epi_in;
   g_last_windowed = false;
+  g_conv_launch_seq.fetch_add(1, std::memory_order_relaxed);
   // fragment-ordered weight image registered for this weight tensor and direction (vc_conv_pack_weights), or -- developer
   // switch conv_autopack, for stand-alone kernel timing -- packed right here into a scratch the library owns
   const float* wpk = nullptr;
@@ -2432,6 +2437,7 @@ static int launch_bw(const float* x, const float* dy, const int32_t* tbl, int64_
   int nsplit;
   int64_t rpb;
   bw_split(n_out, kv, CI, CO, nsplit, rpb);
+  g_conv_launch_seq.fetch_add(1, std::memory_order_relaxed);
 #ifdef VC_EXPERIMENTS
   if constexpr (CI % 16 == 0 && CO % 16 == 0) {
     if (g_bw_variant == 2 && ot == VC_OPERAND_F32 && rep == nullptr) {   // v2: dy window in LDS, offsets split over the waves
@@ -2537,6 +2543,7 @@ extern "C" {
 
 int vc_debug_get(const char* key, int64_t* value) {
   VC_REQUIRE(key && value, "vc_debug_get: null argument");
+  if (!strcmp(key, "conv_launch_seq")) { *value = (int64_t)g_conv_launch_seq.load(std::memory_order_relaxed); return VC_OK; }
   if (!strcmp(key, "conv_bn_finish_launches")) { *value = (int64_t)g_fin_launches.load(std::memory_order_relaxed); return VC_OK; }
   if (!strcmp(key, "f32_split")) { *value = g_f32_split; return VC_OK; }
   if (!strcmp(key, "a17_mismatch")) { *value = a17_mismatch_read(); return VC_OK; }

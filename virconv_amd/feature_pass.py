@@ -364,6 +364,10 @@ class PassFunction(torch.autograd.Function):
         side = be._side_stream(dev) if be.pass_overlap_dw() else None
         _lib.check(lib.vc_pass_backward(prog, call.arena.data_ptr(), call.arena.numel(), ext, _ptr(gin), arena.data_ptr(),
                                         nbytes, side, be.stream()), "vc_pass_backward")
+        # behind this point the stream carries no conv kernel of this pass any more (the weight-gradient stream is joined): the next
+        # forward's pixel projection may start here instead of at the next forward's entry (backbone.note_pass_end, LOG.md A.17)
+        from . import backbone
+        backbone.note_pass_end(dev)
         grads = []
         for i in range(len(P.grad_sizes)):
             if need[2 + i]:
