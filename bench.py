@@ -48,6 +48,7 @@ MODEL_CFG = dict(NAME="VirConvL8x", NUM_FILTERS=[16, 32, 64, 64], RETURN_NUM_FEA
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 MFMA_16BIT_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16/f16 dense MFMA peak (16x16x32 / 32x32x16; the 16x16x16 forms run at half of it)
 HBM_PEAK_GBS = 8000.0
+L2_GATHER_CEILING_TBS = 9.9   # tools/ubench/gather_ubench.hip, 16-byte row gathers with the best lane mapping (profiles/r02_gather_ubench.txt)
 
 
 def make_batch(frame_seeds, device, training=True):
@@ -201,7 +202,8 @@ def train_step(model, optimizer, batch, lw, grad_sync=None, raw=None, next_batch
     # train_utils.py:50.  The parameter list is taken once per model (walking the module tree for it costs 0.15 ms of host time per step)
     params = getattr(base, "_bench_param_list", None)
     if params is None:
-        params = base._bench_param_list = list(model.parameters())
+        from virconv_amd import feature_pass
+        params = base._bench_param_list = feature_pass.trainable_parameters(base)   # the flat parameters if the model was flattened
     torch.nn.utils.clip_grad_norm_(params, 10.0)
     optimizer.step()
     return loss
@@ -383,8 +385,13 @@ def _traced_roofline(trace, args, tdir, tck, tcn, pmc):
     ach = flops / (t_ms * 1e-3) / 1e12
     peak = MFMA_F32_PEAK_TFLOPS if args.operand == "f32" else MFMA_16BIT_PEAK_TFLOPS
     traffic, traffic_src = _pmc_traffic(tdir, tck, tcn) if (pmc and args.operand == "f32") else (None, None)
+    # what the conv kernels really run against (profiles/r06_dw_wide.md): every active pair gathers one source row (the
+    # weight gradient: two) from L2 into a CU; the row-gather micro-benchmark tops out at 8.7-9.9 TB/s on this chip (profiles/r02_gather_ubench.txt)
+    gathered = sum(e["pairs"] * 4.0 * ((e["ck"] + e["cn"]) if e["dir"] == "dw" else e["ck"]) for e in trace)
+    gtb = gathered / (t_ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
             "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "l2_gather_tb_s": round(gtb, 3), "l2_gather_frac_of_9p9_tb_s": round(gtb / L2_GATHER_CEILING_TBS, 4),
             "kernel": _kernel_name(tdir, tck, tcn, all(e["windowed"] for e in trace)),
             "launches": n_launch, "avg_us": round(t_ms / n_launch * 1e3, 2),
             "algorithmic_gflop_per_launch": round(flops / n_launch / 1e9, 4),
@@ -481,10 +488,16 @@ def main(argv=None, plumbing=False):
         model = VirConvL8x(MODEL_CFG, input_channels=8, grid_size=synth.GRID_SIZE).to(device)
     model.train()
     use_torch_ddp = os.environ.get("VIRCONV_TORCH_DDP") == "1"   # stock DistributedDataParallel instead (slower here)
+    # One flat parameter tensor per native pass (feature_pass.flatten_parameters): the stock clip and the stock fused AdamW then walk one or
+    # two tensors instead of 60 / 180, and the backward hands ONE gradient to autograd -- host time, not device time.  VIRCONV_FLAT_PARAMS=0:
+    # the per-parameter form (what stock DistributedDataParallel needs).
+    flat_on = os.environ.get("VIRCONV_FLAT_PARAMS", "1") != "0" and not use_torch_ddp and not plumbing
+    from virconv_amd import feature_pass
+    opt_params = feature_pass.flatten_parameters(model) if flat_on else list(model.parameters())
     ddp = parallel.wrap_ddp(model, device) if use_torch_ddp else model
-    grad_sync = None if use_torch_ddp else parallel.FlatGradAllReduce(model)
-    optimizer = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01,
-                                  fused=not plumbing)  # stock torch multi-tensor AdamW kernel (a16: optimizer stays stock torch)
+    grad_sync = None if use_torch_ddp else parallel.FlatGradAllReduce(model, opt_params)
+    optimizer = torch.optim.AdamW(opt_params, lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01,
+                                  fused=not plumbing)  # stock torch fused AdamW kernel (a16: optimizer stays stock torch)
     lw = make_loss_weights(device)
     torch.manual_seed(100 + rank)  # layer-discard permutations
     # the inputs are resident in HBM from here on: lets the backbone's geometry plan run ahead on its side stream
@@ -516,10 +529,17 @@ def main(argv=None, plumbing=False):
     # this does NOT remove the first-process-on-a-fresh-box penalty (7.5 ms vs 6.7-7.0 ms for later processes on the same
     # box, with or without 4 s of settling), whose cause is outside this process.
     settle = 0.0 if plumbing else float(os.environ.get("VIRCONV_SETTLE_SEC", "1.0"))
-    t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < settle:
-        train_step(ddp, optimizer, batch, lw, grad_sync, raw)
-        sync()
+    if world > 1:
+        # every rank must enter the gradient collective the same number of times: a wall-clock loop per rank does not (found by the
+        # two-ranks-on-one-GPU test of round 6: one rank ran one step more and waited for ever) -- a fixed count instead
+        for _ in range(int(settle / 0.005)):
+            train_step(ddp, optimizer, batch, lw, grad_sync, raw)
+            sync()
+    else:
+        t_settle = time.perf_counter()
+        while time.perf_counter() - t_settle < settle:
+            train_step(ddp, optimizer, batch, lw, grad_sync, raw)
+            sync()
 
     for _ in range(args.warmup):
         train_step(ddp, optimizer, batch, lw, grad_sync, raw)
@@ -539,6 +559,10 @@ def main(argv=None, plumbing=False):
     parallel.barrier()
     dt = time.perf_counter() - t0
     trace = be.trace_end() if can_trace else []
+    # every rank's own time and shard size, on rank 0 (load imbalance between ranks is visible in the line, not only its maximum)
+    per_rank = parallel.gather_to_rank0({"rank": rank, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                                         "voxels": int(batch["voxel_features"].shape[0]) if "voxel_features" in batch else None,
+                                         "frames": list(seeds)})
     dt = parallel.max_over_ranks(dt, device)
 
     # Second timed loop (reported beside the headline): the same K steps with the conv products on v_mfma_f32_16x16x4_f32 (exact fp32
@@ -641,6 +665,7 @@ def main(argv=None, plumbing=False):
         # steps, both fractions, the step-level fraction; tables and notes behind them
         roof = {"bound": "mfma", "achieved": traced["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": traced["frac"],
                 "traffic": traced["traffic"], "kernel": traced["kernel"],
+                "l2_gather_tb_s": traced["l2_gather_tb_s"], "l2_gather_frac_of_9p9_tb_s": traced["l2_gather_frac_of_9p9_tb_s"],
                 "frac_issue_pipe": round(traced["achieved"] / issue_peak, 4) if uses_split else traced["frac"],
                 "issue_pipe_peak": round(issue_peak, 1) if uses_split else peak,
                 "step_frac": None, "family_frac": None, "kernel_is_dominant": None, "kernel_ms_per_step": round(
@@ -735,7 +760,7 @@ def main(argv=None, plumbing=False):
         "config": {"workload": workload,
                    "frames_per_gpu": bs, "global_batch": bs * world,
                    "voxels_rank0": n_vox if args.frontend else int(batch["voxel_features"].shape[0]),
-                   "parallelism": f"dp{world}", "cpu_affinity": numa,
+                   "parallelism": f"dp{world}", "cpu_affinity": numa, "per_rank": per_rank,
                    "untimed_setup": {"settle_seconds_of_steps_before_warmup": settle, "allocator_priming_gib": 8,
                                      "gc_freeze": os.environ.get("VIRCONV_GC_FREEZE", "1") != "0",
                                      "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
@@ -743,7 +768,9 @@ def main(argv=None, plumbing=False):
                                                  if os.environ.get("VIRCONV_MAIN_PRIORITY", "-1") == "-1" else
                                                  "main + geometry plan (high priority) + weight-gradient side stream; main priority "
                                                  + os.environ["VIRCONV_MAIN_PRIORITY"]),
-                                     "row_order": ops.ROW_ORDER}},
+                                     "row_order": ops.ROW_ORDER,
+                                     "parameters": (f"{len(opt_params)} flat tensor(s) aliased by the modules' parameters (feature_pass.flatten_parameters)"
+                                                    if flat_on and len(opt_params) < 10 else "per module")}},
         "roofline": roof,
         "exact_f32_mfma": exact,
     }

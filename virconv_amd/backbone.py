@@ -895,21 +895,27 @@ class VirConv8x(nn.Module):
                 # work and overlap the previous step freely; only the image-space branch of the virtual-point stream waits for the guard
                 # event (PLAN_GUARD), inside its own vc_plan_finish -- behind its coordinate chain and count read, so no host read ever
                 # waits behind the guard
+                # every chain is BEGUN (coordinates, keeps, row counts: no host synchronisation) before any is finished: the count
+                # reads of the later chains are on the host by the time the first one's has been waited for (one spin, not one per chain)
+                begun_l = {rid: self._begin_lidar(idx_l[rid], batch_size, batch_dict, scope.deferred) for rid in rids}
+                begun_m = list(rids) if self.mm else []
+                cps_m = {}
+                for i, rid in enumerate(begun_m):
+                    trans_param, tags = mm_inputs(i, rid)
+                    cps_m[rid] = native_plan.begin(self, blocks, None, idx_m[rid], batch_size, calib, trans_param, tags,
+                                                   self.layer_discard_rate, batch_dict, NRConvBlock.IMAGE_SHAPE,
+                                                   input_discard_tag=(f"mm_input{rid}" if active else None), deferred=scope.deferred)
                 for rid in rids:
-                    rbs, _ = self._finish_lidar(self._begin_lidar(idx_l[rid], batch_size, batch_dict, scope.deferred), None, arenas)
+                    rbs, _ = self._finish_lidar(begun_l[rid], None, arenas)
                     arenas.append(idx_l[rid])
                     plan["lidar"][rid] = (idx_l[rid], rbs)
-                begun_m = list(rids) if self.mm else []
                 # (Round 5 let the LiDAR stream's pass start behind its own tables -- plan["_lidar_ready"] -- while the virtual-point
                 # stream's image-space branch was still being built: that pass is made of the very conv kernels the pixel projection
                 # must not share a compute unit with, LOG.md A.17 / ADVICE r5.  The main stream now waits for the whole plan; the
                 # configuration is host-bound and measures the same.)
                 for i, rid in enumerate(begun_m):
                     trans_param, tags = mm_inputs(i, rid)
-                    stages, _, keep0, kept0, ar = native_plan.build(self, blocks, None, idx_m[rid], batch_size, calib, trans_param, tags,
-                                                                    self.layer_discard_rate, batch_dict, NRConvBlock.IMAGE_SHAPE,
-                                                                    input_discard_tag=(f"mm_input{rid}" if active else None),
-                                                                    deferred=scope.deferred, guard=scope.guard)
+                    stages, _, keep0, kept0, ar = native_plan.finish_nrconv(cps_m[rid], blocks, scope.guard)
                     arenas.extend(ar)
                     arenas.append(idx_m[rid])
                     plan["mm"][rid] = {"keep0": keep0, "in_indices": kept0 if active else idx_m[rid], "stages": stages,

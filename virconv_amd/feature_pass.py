@@ -101,6 +101,18 @@ class _Program:
             self.outputs.append(cur)
         return cur
 
+    def flat(self):
+        """The flat parameter of this program's units (flatten_parameters) while it is still what the units' parameters alias, else None."""
+        fp = getattr(self, "_flat", None)
+        if fp is None:
+            return None
+        base, offs = fp.data_ptr(), self.grad_offsets
+        for i, (conv, bn) in enumerate(self.units):      # someone re-assigned a parameter (load_state_dict(assign=True), .to(), ...)
+            if (conv.weight.data_ptr() != base + 4 * offs[3 * i] or bn.weight.data_ptr() != base + 4 * offs[3 * i + 1]
+                    or bn.bias.data_ptr() != base + 4 * offs[3 * i + 2]):
+                return None
+        return fp
+
     def freeze(self):
         n = len(self.ops)
         self.c_ops = (_lib.PassOp * n)()
@@ -232,7 +244,7 @@ _PROGRAMS = weakref.WeakKeyDictionary()   # model -> {(discard_active, training)
 
 class _Call:
     """Everything one forward call filled in (kept alive for the backward of the same call)."""
-    __slots__ = ("prog", "c_prog", "c_bufs", "c_units", "c_tables", "c_keeps", "arena", "offsets", "keep_alive")
+    __slots__ = ("prog", "c_prog", "c_bufs", "c_units", "c_tables", "c_keeps", "arena", "offsets", "keep_alive", "flat")
 
 
 def _fill(P: _Program, feats, ctx, training: bool) -> Optional[_Call]:
@@ -317,6 +329,7 @@ class PassFunction(torch.autograd.Function):
         ctx.call = call
         # the backward re-reads the input features and every parameter through the raw pointers bound in `call`: saving them makes
         # autograd's version counters catch an in-place edit between forward and backward
+        ctx.flat_mode = call.flat is not None
         ctx.save_for_backward(feats, *params)
         outs = []
         for b in P.outputs:
@@ -344,9 +357,15 @@ class PassFunction(torch.autograd.Function):
                 assert g.dtype == torch.float32 and g.shape == (call.c_bufs[b].rows, P.cols[b])
                 hold.append(g)
                 ext[b] = g.data_ptr()
-        flat = torch.empty((P.grad_total,), dtype=torch.float32, device=dev)
-        base = flat.data_ptr()
         need = ctx.needs_input_grad
+        if ctx.flat_mode:
+            # ONE parameter tensor (flatten_parameters): its gradient IS the flat buffer -- zeroed, because the alignment gaps between
+            # the slots are part of the tensor the optimizer and the clip see
+            flat = torch.zeros((P.grad_total,), dtype=torch.float32, device=dev)
+            need = (need[0], None) + (need[2],) * (3 * len(P.units))
+        else:
+            flat = torch.empty((P.grad_total,), dtype=torch.float32, device=dev)
+        base = flat.data_ptr()
         for i in range(len(P.units)):
             u = call.c_units[i]
             o = P.grad_offsets
@@ -368,6 +387,9 @@ class PassFunction(torch.autograd.Function):
         # forward's pixel projection may start here instead of at the next forward's entry (backbone.note_pass_end, LOG.md A.17)
         from . import backbone
         backbone.note_pass_end(dev)
+        if ctx.flat_mode:
+            ctx.call = None
+            return (gin, None, flat if need[2] else None)
         grads = []
         for i in range(len(P.grad_sizes)):
             if need[2 + i]:
@@ -392,6 +414,9 @@ def _run_program(P: _Program, feats: torch.Tensor, ctx, training: bool):
     call = _fill(P, feats, ctx, training)
     if call is None:
         return None
+    call.flat = P.flat() if training else None
+    if call.flat is not None:
+        return PassFunction.apply(feats, call, call.flat)   # ONE parameter input, ONE gradient (flatten_parameters)
     return PassFunction.apply(feats, call, *params)
 
 
@@ -421,3 +446,71 @@ def run_8x_mm(model, feats: torch.Tensor, pm):
     discard = model._discard_active()
     P = _program(model, ("8x-mm", discard), lambda: build_virconv8x_mm_program(model, discard))
     return _run_program(P, feats, pm, True)
+
+
+# ------------------------------------------------------------------------------------------------ flat parameters (host time)
+# A train step's host time is not its launches (all C-ABI calls together: 1.0 ms of 3.3) but Python / autograd around them: 60 parameter
+# gradients handed back one by one (AccumulateGrad x 60), clip_grad_norm_ and the optimizer walking 60 tensors (0.5 ms; tools/hostsplit.py,
+# profiles/r05_hostsplit.txt).  flatten_parameters re-homes the parameters of a backbone's native-pass units into ONE fp32 buffer per
+# pass, laid out exactly like the pass's gradient buffer; the modules' own parameters become views of it (state_dict, checkpoint loading
+# through copy_, .weight accesses are unchanged), the pass takes the flat tensor as its single parameter input and returns ONE gradient.
+# The optimizer and the clip then run the stock torch functions on one or two tensors (what DistributedDataParallel's
+# gradient_as_bucket_view / FSDP's flat parameters do for the same reason).  The norm of one flat tensor rounds differently from the norm
+# of 60 per-tensor norms (last bit of the clip coefficient); everything else is element-wise and bit-identical (tests/test_flat_params_gpu.py).
+def _training_programs(model):
+    from .backbone import VirConv8x, VirConvL8x
+    discard = model._discard_active() if hasattr(model, "_discard_active") else False
+    if isinstance(model, VirConvL8x):
+        return [_program(model, ("L", d, True), lambda d=d: build_virconv_l_program(model, d, True)) for d in (discard, not discard)]
+    if isinstance(model, VirConv8x):
+        progs = [_program(model, ("8x-lidar",), lambda: build_virconv8x_lidar_program(model))]
+        if getattr(model, "mm", False):
+            progs += [_program(model, ("8x-mm", d), lambda d=d: build_virconv8x_mm_program(model, d)) for d in (discard, not discard)]
+        return progs
+    return []
+
+
+def flatten_parameters(model):
+    """-> the list of tensors to hand to the optimizer / clip_grad_norm_ / the gradient all-reduce instead of model.parameters():
+    one flat nn.Parameter per native pass (+ whatever parameter no pass covers).  Idempotent; the model must be on the GPU, in
+    training mode, with every unit parameter trainable (else nothing is changed and list(model.parameters()) comes back)."""
+    existing = getattr(model, "_vc_flat_params", None)
+    if existing is not None:
+        return list(existing)
+    params = list(model.parameters())
+    progs = _training_programs(model) if (params and params[0].is_cuda and model.training) else []
+    if not progs or not all(p.requires_grad and p.dtype == torch.float32 for p in params):
+        return params
+    groups = {}                                       # unit set -> programs that share it (discard on / off: the same units in the same order)
+    for P in progs:
+        groups.setdefault(tuple(id(m) for u in P.units for m in u), []).append(P)
+    covered, flats = set(), []
+    for key, plist in groups.items():
+        if any(k in covered for k in key):
+            return params                             # two passes over one module: not a layout this scheme serves
+        P = plist[0]
+        assert all(Q.grad_offsets == P.grad_offsets for Q in plist)
+        flat = torch.zeros((P.grad_total,), dtype=torch.float32, device=params[0].device)
+        offs = P.grad_offsets
+        with torch.no_grad():
+            for i, (conv, bn) in enumerate(P.units):
+                for t, o in ((conv.weight, offs[3 * i]), (bn.weight, offs[3 * i + 1]), (bn.bias, offs[3 * i + 2])):
+                    view = flat[o: o + t.numel()].view(t.shape)
+                    view.copy_(t)
+                    t.data = view                     # the module's parameter now aliases the flat buffer
+                    covered.add(id(t))
+        fp = torch.nn.Parameter(flat)
+        for Q in plist:
+            Q._flat = fp
+        flats.append(fp)
+        covered.update(key)
+    rest = [p for p in params if id(p) not in covered]
+    out = flats + rest
+    object.__setattr__(model, "_vc_flat_params", tuple(out))     # (not registered: state_dict and named_parameters are unchanged)
+    return out
+
+
+def trainable_parameters(model):
+    """What a training loop should optimise: the flat parameters if flatten_parameters ran on this model, else model.parameters()."""
+    fp = getattr(model, "_vc_flat_params", None)
+    return list(fp) if fp is not None else list(model.parameters())

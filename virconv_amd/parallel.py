@@ -23,7 +23,9 @@ def init_distributed(backend: str = None) -> tuple:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # VIRCONV_DIST_BACKEND=gloo: ranks that SHARE a GPU (tests/test_two_ranks_one_gpu.py: RCCL refuses two ranks on one device);
+            # gloo stages GPU tensors through the host
+            backend = os.environ.get("VIRCONV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -106,8 +108,9 @@ class FlatGradAllReduce:
     its per-parameter autograd hooks and forward-time bookkeeping, which cost ~3 ms of an 8 ms step here.  Parameters are
     broadcast from rank 0 at construction, like the DDP constructor does."""
 
-    def __init__(self, model: torch.nn.Module):
-        self.params = [p for p in model.parameters() if p.requires_grad]
+    def __init__(self, model: torch.nn.Module, params=None):
+        # `params`: what the optimizer steps on when that is not model.parameters() (feature_pass.flatten_parameters: one flat tensor per pass)
+        self.params = [p for p in (params if params is not None else model.parameters()) if p.requires_grad]
         self.active = dist.is_available() and dist.is_initialized()
         if self.active:
             with torch.no_grad():
@@ -165,6 +168,15 @@ def max_over_ranks(value: float, device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_to_rank0(obj):
+    """-> [obj of rank 0, obj of rank 1, ...] on rank 0 (None elsewhere); [obj] without a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [obj]
+    out = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
+    dist.gather_object(obj, out, dst=0)
+    return out
 
 
 def shutdown() -> None:
