@@ -53,6 +53,11 @@ typedef enum vc_operand {
 } vc_operand;
 
 const char* vc_version(void);
+/* Layout version of the structs that cross this boundary (vc_plan_desc, vc_pass_program, vc_trace_record, ...).  A binding compares
+ * vc_abi_version() with the VC_ABI_VERSION it was written against before it fills any of them: a field added to a struct (round 5:
+ * vc_pass_program.pack_all; round 6: vc_plan_desc.allow_unfenced_projection) otherwise reads as a silent zero on the other side. */
+#define VC_ABI_VERSION 6
+int vc_abi_version(void);
 const char* vc_last_error(void);
 /* developer switch for A/B measurements (tools/kbench.py): "conv_variant" = 1 | 2 */
 int vc_debug_set(const char* key, int value);

@@ -21,7 +21,11 @@ torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
 batch = bench.make_batch([0, 1, 2, 3], dev, True)
 model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).to(dev).train()
 gs = parallel.FlatGradAllReduce(model)
-opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, fused=True)
+import os as _os
+from virconv_amd import feature_pass as _fp
+# as bench.py: one flat parameter tensor per native pass (VIRCONV_FLAT_PARAMS=0: per module, the round-5 form)
+_opt_params = _fp.flatten_parameters(model) if _os.environ.get("VIRCONV_FLAT_PARAMS", "1") != "0" else list(model.parameters())
+opt = torch.optim.AdamW(_opt_params, lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, fused=True)
 lw = bench.make_loss_weights(dev)
 batch["inputs_ready_event"] = torch.cuda.Event()
 batch["inputs_ready_event"].record()
@@ -97,7 +101,7 @@ def timed(name, fn, *a, **k):
 
 _build_plan = model.build_plan
 model.build_plan = lambda *a, **k: timed("  forward: build_plan", _build_plan, *a, **k)
-params = list(model.parameters())
+params = _opt_params
 
 
 def step():

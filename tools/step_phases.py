@@ -26,7 +26,9 @@ be = ops.get_backend()
 assert be.lib.vc_debug_set(b"pass_dw_main_tail", args.dw_main_tail) == 0
 batch = bench.make_batch([0, 1, 2, 3], dev, True)
 model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).to(dev).train()
-opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, fused=True)
+from virconv_amd import feature_pass as _fp
+_opt_params = _fp.flatten_parameters(model)     # as bench.py: one flat parameter tensor per native pass
+opt = torch.optim.AdamW(_opt_params, lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, fused=True)
 lw = bench.make_loss_weights(dev)
 torch.cuda.synchronize()
 batch["inputs_ready_event"] = torch.cuda.Event()
@@ -50,7 +52,7 @@ def step(ev=None):
     mark(1)
     loss.backward()
     mark(2)
-    torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+    torch.nn.utils.clip_grad_norm_(_opt_params, 10.0)
     opt.step()
     mark(3)
 

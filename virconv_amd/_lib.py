@@ -12,6 +12,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 6     # = VC_ABI_VERSION of include/virconv_hip.h (struct layouts this file mirrors)
 LIB_PATH = os.environ.get("VIRCONV_LIB", os.path.join(_HERE, "libvirconv_hip.so"))  # override: A/B builds only
 
 OPERAND_TYPES = {"f32": 0, "f16": 1, "bf16": 2}  # vc_operand (include/virconv_hip.h)
@@ -23,6 +24,7 @@ _P, _I64, _I, _SZ, _F, _D = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_floa
 # name -> (restype, argtypes); must list every symbol of include/virconv_hip.h (checked by tests/test_abi.py)
 SIGNATURES = {
     "vc_version": (C.c_char_p, []),
+    "vc_abi_version": (_I, []),
     "vc_last_error": (C.c_char_p, []),
     "vc_debug_set": (_I, [C.c_char_p, _I]),
     "vc_debug_get": (_I, [C.c_char_p, _P]),
@@ -233,6 +235,9 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if lib.vc_abi_version() != ABI_VERSION:
+        raise VirConvError(f"{LIB_PATH} has struct layout version {lib.vc_abi_version()}, this binding was written against {ABI_VERSION}: "
+                           "rebuild the library (python -m virconv_amd.build --force)")
     _lib = lib
     return lib
 

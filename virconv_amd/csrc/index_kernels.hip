@@ -1327,6 +1327,7 @@ using namespace vc;
 extern "C" {
 
 const char* vc_version(void) { return "virconv_hip 0.1 (gfx950)"; }
+int vc_abi_version(void) { return VC_ABI_VERSION; }
 const char* vc_last_error(void) { return g_err; }
 
 size_t vc_hash_workspace_bytes(int64_t n) { return (size_t)coord_hash_capacity(n < 0 ? 0 : n) * 12; }

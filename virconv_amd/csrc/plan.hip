@@ -704,39 +704,41 @@ static int tables_2d(const vc_plan_desc* d, const PlanState& S, const int32_t* c
 // refuses a slot whose stamp moved on (more than kPlanEvents plans between their begin and their wait) instead of reading counts
 // that belong to another plan.
 static constexpr int kPlanEvents = 64;
+static constexpr int kPlanDevices = 16;
+// One ring PER DEVICE, created on first use of that device and never destroyed (round 6, ADVICE r5: the single ring of round 5 destroyed its
+// events when another device became current -- a process driving two GPUs, or a plan begun on one device and waited for while another is
+// current, lost in-flight plans with a misleading error).  S.ev_slot = device * kPlanEvents + slot.
 static std::mutex g_plan_ev_mutex;
-static hipEvent_t g_plan_ev[kPlanEvents] = {};
-static uint64_t g_plan_ev_gen[kPlanEvents] = {};
-static uint64_t g_plan_ev_next = 0;
-static int g_plan_ev_device = -1;
+static hipEvent_t g_plan_ev[kPlanDevices][kPlanEvents] = {};
+static uint64_t g_plan_ev_gen[kPlanDevices][kPlanEvents] = {};
+static uint64_t g_plan_ev_next[kPlanDevices] = {};
+static bool g_plan_ev_made[kPlanDevices] = {};
 
 // -> slot (>= 0) with S.ev_gen set, the event recorded on `st`; < 0: HIP error
 static int plan_event_record(PlanState& S, hipStream_t st) {
   std::lock_guard<std::mutex> lock(g_plan_ev_mutex);
   int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess) return -1;
-  if (g_plan_ev_device != dev) {   // first use (or another device current): events belong to the device they were created on
-    for (int i = 0; i < kPlanEvents; ++i) {
-      if (g_plan_ev[i]) (void)hipEventDestroy(g_plan_ev[i]);
-      g_plan_ev[i] = nullptr;
-      if (hipEventCreateWithFlags(&g_plan_ev[i], hipEventDisableTiming) != hipSuccess) { g_plan_ev_device = -1; return -1; }
-      g_plan_ev_gen[i] = 0;
-    }
-    g_plan_ev_device = dev;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kPlanDevices) return -1;
+  if (!g_plan_ev_made[dev]) {   // events belong to the device they were created on
+    for (int i = 0; i < kPlanEvents; ++i)
+      if (hipEventCreateWithFlags(&g_plan_ev[dev][i], hipEventDisableTiming) != hipSuccess) return -1;
+    g_plan_ev_made[dev] = true;
   }
-  const uint64_t gen = ++g_plan_ev_next;
+  const uint64_t gen = ++g_plan_ev_next[dev];
   const int slot = (int)(gen % kPlanEvents);
-  if (hipEventRecord(g_plan_ev[slot], st) != hipSuccess) return -1;
-  g_plan_ev_gen[slot] = gen;
-  S.ev_slot = slot;
+  if (hipEventRecord(g_plan_ev[dev][slot], st) != hipSuccess) return -1;
+  g_plan_ev_gen[dev][slot] = gen;
+  S.ev_slot = dev * kPlanEvents + slot;
   S.ev_gen = gen;
-  return slot;
+  return S.ev_slot;
 }
-// the plan's event, or nullptr when its slot has been recorded again by a later plan
+// the plan's event, or nullptr when its slot has been recorded again by a later plan of the same device
 static hipEvent_t plan_event_of(const PlanState& S) {
   std::lock_guard<std::mutex> lock(g_plan_ev_mutex);
-  if (S.ev_slot < 0 || S.ev_slot >= kPlanEvents || g_plan_ev_gen[S.ev_slot] != S.ev_gen) return nullptr;
-  return g_plan_ev[S.ev_slot];
+  if (S.ev_slot < 0 || S.ev_slot >= kPlanDevices * kPlanEvents) return nullptr;
+  const int dev = S.ev_slot / kPlanEvents, slot = S.ev_slot % kPlanEvents;
+  if (!g_plan_ev_made[dev] || g_plan_ev_gen[dev][slot] != S.ev_gen) return nullptr;
+  return g_plan_ev[dev][slot];
 }
 
 }  // namespace vc
@@ -917,6 +919,9 @@ int vc_plan_wait(const vc_plan_desc* d, vc_plan_state* state) {
     if (e == hipSuccess) break;
     if (e != hipErrorNotReady) { set_error("vc_plan_wait: %s", hipGetErrorString(e)); return VC_EHIP; }
   }
+  // the slot may have been recorded again WHILE this thread polled it (another thread began 64 plans): what completed is then a later plan's
+  // event, not this one's
+  VC_REQUIRE(plan_event_of(S) == ev, "vc_plan_wait: this plan's event slot was recorded again by a later plan while it was being waited for");
   const int32_t* hc = S.host_counts;
   const double keep_frac = 1.0 - d->discard_rate;
   int64_t cur_n = d->input_discard ? S.n_in_keep : d->n;
