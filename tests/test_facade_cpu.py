@@ -234,3 +234,25 @@ def test_geometry_plan_uses_the_one_read_rulebook_chain_when_no_discard_is_activ
     assert ka == kb and np.array_equal(ra.pair_fwd.numpy(), rb.pair_fwd.numpy()) and np.array_equal(ra.out_indices.numpy(), rb.out_indices.numpy())
     plan("spconv1_inplace", True)
     assert calls == [4]                                   # layer discard between the stages: per-conv rulebooks
+
+
+def test_plan_splits_with_one_read_equals_the_per_slab_nonzero_form():
+    """VirConv8x test-time path (spconv_backbone.py:314-337, decompose_tensor: strict begin < x < end): backbone.VirConv8x._plan_splits cuts
+    every slab of x_conv3 / x_conv4 / out with one host read; same kept rows, same order, same shifted coordinates as _plan_split."""
+    import torch
+    from virconv_amd.backbone import VirConv8x
+    g = torch.Generator().manual_seed(5)
+    co = {}
+    for k, (w, n) in {"x3": (1408, 5000), "x4": (704, 3000), "out": (704, 2000)}.items():
+        lin = torch.randperm(2 * 5 * 40 * w, generator=g)[:n].sort().values          # ascending (b, z, y, x) order, as a strided conv emits
+        b, r = lin // (5 * 40 * w), lin % (5 * 40 * w)
+        z, r = r // (40 * w), r % (40 * w)
+        idx = torch.stack([b, z, r // w, r % w], 1).int()
+        idx[::7, 3] = (idx[::7, 3] // (w // 4)) * (w // 4)                            # plenty of x == begin rows (dropped by the strict test)
+        co[k] = (idx, [5, 40, w])
+    for rids in (["", "1", "2"], [""], ["", "1", "2", "3"]):
+        got = VirConv8x._plan_splits(co, rids)
+        for i, rid in enumerate(rids):
+            for k in ("x3", "x4", "out"):
+                keep, idx, shape = VirConv8x._plan_split(co[k][0], co[k][1], i)
+                assert torch.equal(got[rid][k][0], keep) and torch.equal(got[rid][k][1], idx) and got[rid][k][2] == shape

@@ -23,6 +23,17 @@ from virconv_amd.backbone import VirConvL8x
 CFG = dict(MODEL_CFG, LAYER_DISCARD_MODE="spconv2_noop")   # what the reference's code does under spconv 2.x
 
 
+@pytest.fixture(autouse=True)
+def _fixture_thread_count():
+    """The fp32 CPU runs below are compared with a fixture made at 8 torch threads; torch's CPU reductions chunk by the thread COUNT (not by
+    the cores there are), so the count is pinned: OMP_NUM_THREADS=1 or a 32-thread box otherwise shift sums by fp32 re-association noise that
+    the tight bounds of these tests (1e-5 class) do not allow."""
+    n = torch.get_num_threads()
+    torch.set_num_threads(8)
+    yield
+    torch.set_num_threads(n)
+
+
 @pytest.fixture(scope="module")
 def fixture_inputs():
     g = load_golden("virconv_l_fullsize_ref.npz")
@@ -220,9 +231,14 @@ def test_8x_fullsize_oracle_backend_equals_the_reference_composition(oracle_back
         return
     outs, loss, grads, stats = _train_run_8x(d, "cpu")
     fx.check_outputs(outs, g, "train", names=fx.TENSORS_8X_TRAIN, k_rows=fx.K_ROWS_8X)
-    assert abs(loss - float(g["train_loss"])) <= 1e-2
+    # Round 6: the fp32 CPU run is compared with the fixture's FLOAT64 run, the fixture's own fp32 run as yardstick, exactly as the HIP test
+    # below does.  The former comparison with the fp32 run (|loss| 1e-2 absolute, gradients 2e-4 of max) held only at the thread count
+    # the fixture was made with: torch's CPU reductions sum in a thread-dependent order, and one flipped ReLU-mask entry moves a weight
+    # gradient by 2e-3 of its max (OMP_NUM_THREADS=1 and the GPU box's 32 threads both failed it, at the round-5 tree as well).
+    l64, l32 = float(g["train64_loss"]), float(g["train_loss"])
+    assert abs(loss - l64) <= max(1e-2, 3 * abs(l32 - l64)), (loss, l64, l32)
     fx.check_named(stats, g, "train_stat", rtol=1e-5)
-    fx.check_named(grads, g, "train_grad", rtol=2e-4)
+    _check_grads(grads, g, [])
 
 
 @pytest.mark.gpu

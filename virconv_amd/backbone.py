@@ -289,6 +289,7 @@ def _bound_run_ahead(device, main):
 #       tables, 3-D SubM tables) still overlap the previous step.
 #   2: the whole plan waits for that event (serial; A/B only).        0: no event (the round-4 loop; A/B and tools/det_check.py).
 PLAN_GUARD = int(os.environ.get("VIRCONV_PLAN_GUARD", "1"))
+NATIVE_CAT_PLAN = os.environ.get("VIRCONV_NATIVE_CAT_PLAN", "1") != "0"   # VirConv8x test-time path: chain plan over the x-concatenated tensor
 
 
 def _guard_wanted(device) -> bool:
@@ -824,11 +825,12 @@ class VirConv8x(nn.Module):
         chain = [native_plan.ChainBlock(None, first)] + [native_plan.ChainBlock(seq[0][0], seq[1][0]) for seq in stages]
         return first, co, stages, chain
 
-    def _begin_lidar(self, idx, batch_size, batch_dict, deferred):
-        """First half of the LiDAR stream's native chain plan (native_plan.ChainPlan): coordinates, row counts, the first 3-D table."""
+    def _begin_lidar(self, idx, batch_size, batch_dict, deferred, sparse_shape=None):
+        """First half of the LiDAR stream's native chain plan (native_plan.ChainPlan): coordinates, row counts, the first 3-D table.
+        `sparse_shape`: the grid when it is not the model's own (the x-concatenated test-time tensor, spconv_backbone.py:414-432)."""
         _, co, _, chain = self._lidar_chain()
         return native_plan.ChainPlan(self, "8x-lidar", chain, co, idx, batch_size, None, None, [None] * 4, 0.0, batch_dict,
-                                     NRConvBlock.IMAGE_SHAPE, None, deferred, None, False)
+                                     NRConvBlock.IMAGE_SHAPE, None, deferred, None, False, sparse_shape=sparse_shape)
 
     def _finish_lidar(self, cp, guard, arenas):
         first, co, stages, _ = self._lidar_chain()
@@ -871,6 +873,32 @@ class VirConv8x(nn.Module):
         idx = indices[keep].clone()
         idx[:, 3] -= begin
         return keep, idx.int(), [shape[0], shape[1], shape[2] // 4]
+
+    @staticmethod
+    def _plan_splits(co, rids):
+        """_plan_split for every slab and every tensor with ONE host read: rows sorted stably by slab (dropped rows last), the slab
+        sizes of the three tensors fetched together.  Same kept rows in the same order as the `nonzero` of _plan_split (the rows of a
+        strided conv's output are in ascending coordinate order and the sort is stable).  -> {rid: {"x3" | "x4" | "out": split}}"""
+        n_rot = len(rids)
+        metas = []
+        for k in ("x3", "x4", "out"):
+            indices, shape = co[k]
+            qw = shape[2] // 4
+            x = indices[:, 3].long()
+            slab = torch.div(x, qw, rounding_mode="floor")
+            key = torch.where((x % qw != 0) & (slab < n_rot), slab, torch.full_like(slab, n_rot))   # strict begin < x < end
+            metas.append((k, indices, shape, qw, torch.argsort(key, stable=True), torch.bincount(key, minlength=n_rot + 1)[:n_rot]))
+        counts = torch.stack([m[5] for m in metas]).cpu().tolist()                                   # the one host read
+        out = {rid: {} for rid in rids}
+        for (k, indices, shape, qw, order, _), cnt in zip(metas, counts):
+            off = 0
+            for i, rid in enumerate(rids):
+                keep = order[off: off + cnt[i]]
+                off += cnt[i]
+                idx = indices[keep].clone()
+                idx[:, 3] -= i * qw
+                out[rid][k] = (keep, idx.int(), [shape[0], shape[1], shape[2] // 4])
+        return out
 
     def build_plan(self, batch_dict, rids, batch_size, calib):
         ref = batch_dict["voxel_coords"]
@@ -922,22 +950,49 @@ class VirConv8x(nn.Module):
                                        "trans_param": trans_param}
                 plan["_arenas"] = arenas
                 return scope.publish(plan)
-            # operator-by-operator plans (the eval path over the x-concatenated tensor; empty / CPU tensors): the whole plan waits
+            # ---- test time (spconv_backbone.py:409-442): the rot_num copies concatenated along x into ONE tensor for the LiDAR stream
+            cat_native = False
+            if not self.training:
+                coords = []
+                for i, rid in enumerate(rids):
+                    c = batch_dict["voxel_coords" + rid].clone()
+                    c[:, 3] += i * self.sparse_shape[2]
+                    coords.append(c)
+                idx_cat = torch.cat(coords).int()
+                new_shape = [self.sparse_shape[0], self.sparse_shape[1], self.sparse_shape[2] * 4]
+                cells = batch_size * new_shape[0] * new_shape[1] * new_shape[2]
+                cat_native = bool(NATIVE_CAT_PLAN and native_plan.usable(idx_cat) and cells < (1 << 31)
+                                  and all(native_plan.usable(v, blocks) for v in idx_m.values()))
+            if cat_native:
+                # Round 6 (VERDICT r5 "missing" #4): every chain natively -- the LiDAR chain over the concatenated [41, 1600, 5632] grid
+                # (one count read for its four strided convs) and the rot_num virtual-point chains, all BEGUN before any is finished;
+                # the three slabs of x_conv3 / x_conv4 / out cut with ONE host read (_plan_splits) instead of nine `nonzero`s.  Integer
+                # tables overlap the previous frame; only the image-space branches wait for the guard (inside vc_plan_finish).
+                cp_l = self._begin_lidar(idx_cat, batch_size, batch_dict, None, new_shape)
+                cps_m = {}
+                for i, rid in enumerate(rids if self.mm else []):
+                    trans_param, tags = mm_inputs(i, rid)
+                    cps_m[rid] = native_plan.begin(self, blocks, None, idx_m[rid], batch_size, calib, trans_param, tags,
+                                                   self.layer_discard_rate, batch_dict, NRConvBlock.IMAGE_SHAPE,
+                                                   input_discard_tag=(f"mm_input{rid}" if active else None), deferred=scope.deferred)
+                rbs, co = self._finish_lidar(cp_l, None, arenas)
+                plan["lidar"]["cat"] = (idx_cat, rbs, new_shape)
+                plan["split"] = self._plan_splits(co, rids)
+                for i, rid in enumerate(rids if self.mm else []):
+                    trans_param, tags = mm_inputs(i, rid)
+                    stages, _, keep0, kept0, ar = native_plan.finish_nrconv(cps_m[rid], blocks, scope.guard)
+                    plan["mm"][rid] = {"keep0": keep0, "in_indices": kept0 if active else idx_m[rid], "stages": stages,
+                                       "trans_param": trans_param}
+                return scope.publish(plan)
+            # operator-by-operator plans (empty / CPU tensors, VIRCONV_NATIVE_CAT_PLAN=0): the whole plan waits
             scope.guard_tables()
             if self.training:
                 for rid in rids:
                     rbs, _ = self._plan_lidar(idx_l[rid], self.sparse_shape, batch_size)
                     plan["lidar"][rid] = (idx_l[rid], rbs)
             else:
-                coords = []
-                for i, rid in enumerate(rids):
-                    c = batch_dict["voxel_coords" + rid].clone()
-                    c[:, 3] += i * self.sparse_shape[2]
-                    coords.append(c)
-                idx = torch.cat(coords).int()
-                new_shape = [self.sparse_shape[0], self.sparse_shape[1], self.sparse_shape[2] * 4]
-                rbs, co = self._plan_lidar(idx, new_shape, batch_size)
-                plan["lidar"]["cat"] = (idx, rbs, new_shape)
+                rbs, co = self._plan_lidar(idx_cat, new_shape, batch_size)
+                plan["lidar"]["cat"] = (idx_cat, rbs, new_shape)
                 for i, rid in enumerate(rids):
                     plan["split"][rid] = {k: self._plan_split(co[k][0], co[k][1], i) for k in ("x3", "x4", "out")}
             if self.mm:

@@ -1866,6 +1866,7 @@ static float* autopack_scratch(bool bwd) {
 }
 // Wave-autonomous kernel (v4): vc_debug_set conv_v4 = 0 never (default) | 1 every eligible shape (both channel counts multiples
 // of 16, fp32 operands) | 2 = per launch (the rule below, from tools/kbench.py --v4 A/B runs)
+int g_conv_v3_split = 1;   // vc_debug_set conv_v3_split: the window kernel (experiments) takes the bf16-split products when f32_split is on
 int g_conv_v4 = 0;   // off: inside the train step (weight-gradient stream contending for the same CUs) the table ties or loses, 5.64 vs 5.60 ms
 // dx shift in the LDS-staged kernel (vc_debug_set conv_dxs; needs a weight image).  OFF: measured slower although it halves the
 // gathered rows -- SubM 64->32 194 -> 231 us, 32->32 113 -> 129 us, 16->16 65 -> 88 us, train step 5.60 -> 5.74 ms
@@ -2142,11 +2143,25 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
       // experiment switches (vc_debug_set): conv_wdma = W images through the LDS-DMA engine, conv_winrows = 24-row windows
       const bool wdma = g_conv_wdma && CN % 16 == 0 && epi_kind == VC_EPI_NONE;
       const int winrows = (g_conv_winrows == 24 && epi_kind == VC_EPI_NONE) ? 24 : 32;
-      const size_t lds = (size_t)(wdma ? 3 : 2) * NCH * NT * 64 * 4 * sizeof(float) + (size_t)kv * 64 * sizeof(int) +
+      // round 6: the six-term bf16 split on the window kernel (vc_debug_set conv_v3_split, default 1 = follow f32_split)
+      bool x6 = false;
+      if constexpr (CK % 32 == 0 && CN % 16 == 0) x6 = g_f32_split && g_conv_v3_split && ot == VC_OPERAND_F32 && !wdma;
+      const size_t lds = (size_t)(wdma ? 3 : 2) * NCH * NT * 64 * (x6 ? 24 : 16) + (size_t)kv * 64 * sizeof(int) +
                          (size_t)4 * (winrows + 1) * (CK + 4) * sizeof(float) + 16;
       const dim3 grid((unsigned)cdiv(n_out, 64));
 #define VC_ARGS3 src, n_src, tbl, w, out, n_out, kv, mirror, epi
 #define VC_L3(B_, E_, D_, R_) hipLaunchKernelGGL((gather_gemm_v3_kernel<CK, CN, B_, E_, D_, R_>), grid, dim3(256), lds, st, VC_ARGS3)
+      if constexpr (CK % 32 == 0 && CN % 16 == 0) {
+        if (x6) {
+#define VC_L3X(B_, E_, R_) hipLaunchKernelGGL((gather_gemm_v3_kernel<CK, CN, B_, E_, false, R_, VC_OPERAND_X6>), grid, dim3(256), lds, st, VC_ARGS3)
+          if (epi_kind == VC_EPI_NONE) { if (winrows == 24) VC_L3X(BWD, VC_EPI_NONE, 24); else VC_L3X(BWD, VC_EPI_NONE, 32); }
+          else if constexpr (!BWD) { if (epi_kind == VC_EPI_STATS) VC_L3X(false, VC_EPI_STATS, 32); else VC_L3X(false, VC_EPI_AFFINE, 32); }
+#undef VC_L3X
+          VC_CHECK_LAUNCH("gather_gemm_v3_kernel<split bf16>");
+          g_last_windowed = true;
+          return VC_OK;
+        }
+      }
       if (epi_kind == VC_EPI_NONE) {
         if constexpr (CN % 16 == 0) {
           if (wdma && winrows == 24) VC_L3(BWD, VC_EPI_NONE, true, 24);
@@ -2592,6 +2607,7 @@ int vc_debug_set(const char* key, int value) {
   if (!strcmp(key, "bw_variant")) return experiment_key(key, value, 1, &g_bw_variant);
   if (!strcmp(key, "conv_packed")) { g_conv_use_packed = value; return VC_OK; }
   if (!strcmp(key, "conv_window")) { g_conv_window = value; return VC_OK; }
+  if (!strcmp(key, "conv_v3_split")) { g_conv_v3_split = value; return VC_OK; }
   if (!strcmp(key, "conv_nw")) { g_conv_nw = (value == 8 || value == 4) ? value : 0; return VC_OK; }
   if (!strcmp(key, "bw_legacy_order")) { g_bw_legacy_order = value; return VC_OK; }
   if (!strcmp(key, "bw_small")) { g_bw_small = value; return VC_OK; }

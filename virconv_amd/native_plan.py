@@ -151,14 +151,17 @@ class ChainPlan:
 
     def __init__(self, model, kind: str, chain, tail, idx: torch.Tensor, batch_size: int, calib, trans_param, discard_tags, rate: float,
                  batch_dict, image_shape, input_discard_tag=None, deferred=None, guard=None, defer_tables=False, debug_buf=None,
-                 unfenced=False):
+                 unfenced=False, sparse_shape=None):
         self.unfenced = bool(unfenced)
+        self.sparse_shape = [int(v) for v in (sparse_shape if sparse_shape is not None else model.sparse_shape)]
         be = ops.get_backend()
         lib = be.lib
         dev = idx.device
         cache = _DESCS.setdefault(model, {})
+        if sparse_shape is not None:      # a chain over another grid than the model's (VirConv8x: the x-concatenated test-time tensor)
+            kind = (kind, tuple(self.sparse_shape))
         if kind not in cache:
-            cache[kind] = _static_desc(chain, tail, model.sparse_shape, image_shape)
+            cache[kind] = _static_desc(chain, tail, self.sparse_shape, image_shape)
         d = _lib.PlanDesc.from_buffer_copy(cache[kind])   # private copy: plans of one kind may be in flight together (plan-ahead, rids)
         hold = [idx, calib]
         d.indices, d.n, d.batch_size = idx.data_ptr(), idx.shape[0], int(batch_size)
@@ -281,7 +284,7 @@ class ChainPlan:
         arenas = (arena_a, arena_b)
         res = []
         in_keep = in_kept = None
-        cur_idx, shape = self.idx, list(self.model.sparse_shape)
+        cur_idx, shape = self.idx, list(self.sparse_shape)
         if self.input_discard_tag is not None:
             in_keep, in_kept = _keep_view(arenas, out.input_keep), _view(arenas, out.input_kept_indices)
             cur_idx = in_kept
