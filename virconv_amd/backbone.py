@@ -1072,7 +1072,17 @@ class VirConv8x(nn.Module):
                     coords.append(c)
                 new_shape = [self.sparse_shape[0], self.sparse_shape[1], self.sparse_shape[2] * 4]
                 sp = spconv.SparseConvTensor(feats, torch.cat(coords).int(), new_shape, batch_size)
-            x1, x2, x3, x4, out = self._lidar_stream(sp)
+            native = None
+            if plan is not None and feature_pass.usable_8x(self, feats, "lidar"):
+                native = feature_pass.run_8x_lidar(self, feats, rbs)      # the whole stream as ONE native call (eval BatchNorm folded)
+            if native is not None:
+                geo = [(idx, new_shape)] + [(rbs[seq[0][0].indice_key].out_indices, list(rbs[seq[0][0].indice_key].out_shape))
+                                            for seq in (self.conv2, self.conv3, self.conv4)]
+                rbo = rbs[self.conv_out[0].indice_key]
+                geo.append((rbo.out_indices, list(rbo.out_shape)))
+                x1, x2, x3, x4, out = [spconv.SparseConvTensor(f, gi, gs, batch_size, indice_dict=dict(rbs)) for f, (gi, gs) in zip(native, geo)]
+            else:
+                x1, x2, x3, x4, out = self._lidar_stream(sp)
             for i, rid in enumerate(rids):
                 if plan is not None:
                     sp_ = plan["split"][rid]

@@ -177,7 +177,7 @@ def build_virconv8x_lidar_program(model) -> _Program:
     return P.freeze()
 
 
-def build_virconv8x_mm_program(model, discard_active: bool) -> _Program:
+def build_virconv8x_mm_program(model, discard_active: bool, training: bool = True) -> _Program:
     """VirConv8x virtual-point stream (spconv_backbone.py:444-535): the input discard (:488-489) and four NRConvBlocks with the
     layer discard after the first three.  ctx = plan["mm"][rid]."""
     P = _Program()
@@ -185,7 +185,7 @@ def build_virconv8x_mm_program(model, discard_active: bool) -> _Program:
     if discard_active:
         cur = P.add_gather(cur, P.keep(lambda pm: pm["keep0"]))
     blocks = [model.vir_conv1, model.vir_conv2, model.vir_conv3, model.vir_conv4]
-    P.add_nrconv_chain(cur, blocks, [discard_active and bi < 3 for bi in range(4)], True, lambda pm, bi: pm["stages"][bi])
+    P.add_nrconv_chain(cur, blocks, [discard_active and bi < 3 for bi in range(4)], training, lambda pm, bi: pm["stages"][bi])
     return P.freeze()
 
 
@@ -229,14 +229,22 @@ def usable(model, feats: torch.Tensor, plan) -> bool:
 
 
 def usable_8x(model, feats: torch.Tensor, stream: str) -> bool:
-    """VirConv8x, training mode only: the LiDAR stream ("lidar") or the virtual-point stream ("mm")."""
-    if not (model.training and _backend_ok(feats)):
+    """VirConv8x: the LiDAR stream ("lidar") or the virtual-point stream ("mm"); training, and (round 6) eval without gradients -- the
+    test-time path over the x-concatenated tensor (spconv_backbone.py:409-442)."""
+    if not _backend_ok(feats):
         return False
     if stream == "lidar":
         seqs = [model.conv_input, model.conv_out] + [u for st in (model.conv1, model.conv2, model.conv3, model.conv4) for u in st]
     else:
         seqs = _nrconv_seqs([model.vir_conv1, model.vir_conv2, model.vir_conv3, model.vir_conv4])
-    return seqs is not None and _units_ok(seqs, True)
+    if seqs is None or not _units_ok(seqs, model.training):
+        return False
+    if not model.training:
+        if not NATIVE_PASS_EVAL:
+            return False
+        if torch.is_grad_enabled() and (feats.requires_grad or any(p.requires_grad for p in model.parameters())):
+            return False  # running statistics + gradients: the node-by-node path
+    return True
 
 
 _PROGRAMS = weakref.WeakKeyDictionary()   # model -> {(discard_active, training): _Program}; kept off the module (deepcopy / pickle safe)
@@ -437,15 +445,16 @@ def run(model, feats: torch.Tensor, plan):
 
 
 def run_8x_lidar(model, feats: torch.Tensor, rbs):
-    """VirConv8x LiDAR stream (training) -> [x_conv1..4, out] feature matrices or None."""
-    return _run_program(_program(model, ("8x-lidar",), lambda: build_virconv8x_lidar_program(model)), feats, rbs, True)
+    """VirConv8x LiDAR stream -> [x_conv1..4, out] feature matrices or None."""
+    return _run_program(_program(model, ("8x-lidar",), lambda: build_virconv8x_lidar_program(model)), feats, rbs, bool(model.training))
 
 
 def run_8x_mm(model, feats: torch.Tensor, pm):
-    """VirConv8x virtual-point stream (training) -> [m1..m4] feature matrices (each after its layer discard) or None."""
-    discard = model._discard_active()
-    P = _program(model, ("8x-mm", discard), lambda: build_virconv8x_mm_program(model, discard))
-    return _run_program(P, feats, pm, True)
+    """VirConv8x virtual-point stream -> [m1..m4] feature matrices (each after its layer discard) or None."""
+    discard, training = model._discard_active(), bool(model.training)
+    key = ("8x-mm", discard) if training else ("8x-mm", discard, False)
+    P = _program(model, key, lambda: build_virconv8x_mm_program(model, discard, training))
+    return _run_program(P, feats, pm, training)
 
 
 # ------------------------------------------------------------------------------------------------ flat parameters (host time)
