@@ -241,12 +241,19 @@ def run_infer(args, model, batch, device, rank, world):
     """BASELINE configs[1]: VirConv-L forward only, eval mode (no discard), `--batch-size` frames per GPU (1 in the config)."""
     model.eval()
 
+    # A serving loop holds the NEXT frame while it runs this one: the first half of that frame's geometry plan (coordinates, keeps, row
+    # counts: VirConvL8x.plan_ahead_begin, no host synchronisation) is enqueued before this frame's forward, so its one count read has
+    # long arrived when the next call asks for it.  VIRCONV_INFER_PLAN_AHEAD=0: plan in place (rounds 1-5).
+    ahead = os.environ.get("VIRCONV_INFER_PLAN_AHEAD", "1") != "0" and hasattr(model, "plan_ahead_begin")
+
     def step():
         bd = dict(batch)
         for k in batch:
             if k.startswith("voxel_features"):
                 bd[k] = batch[k].clone()      # the backbone zeroes RGB in place
         with torch.no_grad():
+            if ahead:
+                model.plan_ahead_begin(batch)     # the next frame (the same synthetic frame again)
             out = model(bd)
             return out["encoded_spconv_tensor"].dense()
 

@@ -34,7 +34,7 @@ def test_flat_all_reduce_and_stock_ddp_over_rccl_world_1_match_the_plain_run_and
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_world1_worker.py"), str(_free_port())], cwd=ROOT, env=_env(),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, f"rc {r.returncode}\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
-    assert "RCCL_WORLD1_OK" in r.stdout and "flat:" in r.stdout and "ddp:" in r.stdout
+    assert "RCCL_WORLD1_OK" in r.stdout and "flat:" in r.stdout and "ddp:" in r.stdout and "syncbn:" in r.stdout
     assert "watchdog" not in r.stderr.lower() and "core dumped" not in r.stderr.lower(), r.stderr[-3000:]
 
 

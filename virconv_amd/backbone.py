@@ -635,6 +635,8 @@ class VirConvL8x(nn.Module):
                 break
         else:
             return None            # no early plan for this batch (or not in this mode): the caller plans in place
+        if rid == "":
+            _bound_run_ahead(coords.device, torch.cuda.current_stream())   # the flow control every forward has (see _PlanScope)
         self._finish_ahead(a)
         _, _, idx, cp = a["entries"].pop(rid)
         res, rb_out, _, _, arenas = cp.finish()
