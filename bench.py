@@ -394,7 +394,7 @@ def _traced_roofline(trace, args, tdir, tck, tcn, pmc):
     traffic, traffic_src = _pmc_traffic(tdir, tck, tcn) if (pmc and args.operand == "f32") else (None, None)
     # what the conv kernels really run against (profiles/r06_dw_wide.md): every active pair gathers one source row (the
     # weight gradient: two) from L2 into a CU; the row-gather micro-benchmark tops out at 8.7-9.9 TB/s on this chip (profiles/r02_gather_ubench.txt)
-    gathered = sum(e["pairs"] * 4.0 * ((e["ck"] + e["cn"]) if e["dir"] == "dw" else e["ck"]) for e in trace)
+    gathered = sum(e.get("pairs", 0) * 4.0 * ((e.get("ck", 0) + e.get("cn", 0)) if e.get("dir") == "dw" else e.get("ck", 0)) for e in trace)
     gtb = gathered / (t_ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
             "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,

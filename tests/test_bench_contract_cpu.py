@@ -48,6 +48,11 @@ def test_traced_roofline_arithmetic():
     assert r["achieved"] == pytest.approx(tf, rel=1e-3) and r["frac"] == pytest.approx(tf / bench.MFMA_F32_PEAK_TFLOPS, abs=1e-4)
     assert r["launches"] == 2 and r["avg_us"] == pytest.approx(130.0, rel=1e-3) and r["traffic"] is None
     assert bench._traced_roofline([], args, "fwd", "64", "32", pmc=False) is None
+    # round 6: the bound the conv kernels really run against -- bytes of gathered rows / time (a weight gradient gathers two rows per pair)
+    tr = [{"ms": 0.1, "flops": 1.0, "bytes": 1.0, "windowed": False, "pairs": 1_000_000, "ck": 32, "cn": 32, "dir": "dw"}]
+    r = bench._traced_roofline(tr, args, "dw", "32", "32", pmc=False)
+    assert r["l2_gather_tb_s"] == pytest.approx(1e6 * 256 / 1e-4 / 1e12, rel=1e-3)
+    assert r["l2_gather_frac_of_9p9_tb_s"] == pytest.approx(r["l2_gather_tb_s"] / bench.L2_GATHER_CEILING_TBS, abs=1e-3)
 
 
 def test_every_line_of_the_round_file_parses_and_names_its_workload():

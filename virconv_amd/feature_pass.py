@@ -267,19 +267,20 @@ def _fill(P: _Program, feats, ctx, training: bool) -> Optional[_Call]:
         # yet; vc_pass_backward needs it: build it now and keep it on the rulebook
         be = ops.get_backend()
         for rb in tables:
-            if rb.rep is not None and rb.grp_plan is None:
+            if ops.rulebook_ptr(rb, "rep") is not None and ops.rulebook_ptr(rb, "grp_plan") is None:
                 rb.grp_plan = be.group_plan(rb.rep)
     c_tables = (_lib.PassTable * len(tables))()
     for i, rb in enumerate(tables):
         t = c_tables[i]
         subm = rb.kind == "subm"
-        kv = rb.pair_fwd.shape[0]
-        t.pair_fwd, t.pair_bwd, t.rep = rb.pair_fwd.data_ptr(), _ptr(rb.pair_bwd), _ptr(rb.rep)
-        t.order_fwd, t.order_bwd = _ptr(rb.order_fwd), _ptr(rb.order_bwd)
+        kv = rb.kv
+        rp = ops.rulebook_ptr      # (a plan's rulebooks hand out addresses without creating tensor views)
+        t.pair_fwd, t.pair_bwd, t.rep = rp(rb, "pair_fwd"), rp(rb, "pair_bwd"), rp(rb, "rep")
+        t.order_fwd, t.order_bwd = rp(rb, "order_fwd"), rp(rb, "order_bwd")
         t.n_in, t.n_out, t.kv, t.subm = rb.n_in, rb.n_out, kv, 1 if subm else 0
         t.centre = kv // 2 if subm else -1     # odd kernel sizes: the centre tap is the middle offset
         t.sorted_rows = 1 if rb.sorted_rows else 0
-        t.grp_plan = _ptr(rb.grp_plan)
+        t.grp_plan = rp(rb, "grp_plan")
     c_keeps = (C.c_void_p * max(len(keeps), 1))()
     for i, k in enumerate(keeps):
         assert k.dtype == torch.int64 and k.is_contiguous()

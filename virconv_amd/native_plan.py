@@ -120,17 +120,18 @@ def _table(arenas, t: _lib.PlanTableOut, kind, in_shape, conv, in_idx) -> ops.Ru
     """ops.Rulebook over views of the arenas; `in_idx`: the tensor holding the table's input coordinates."""
     ndim = conv.ndim
     out_shape = tuple(int(t.out_shape[a]) for a in range(ndim))
-    out_idx = in_idx if kind == "subm" else _view(arenas, t.out_indices)
     ks = tuple(int(k) for k in conv.kernel_size)
-    rb = ops.Rulebook(kind, _view(arenas, t.pair_fwd), _view(arenas, t.pair_bwd), _view1(arenas, t.rep), int(t.n_in), int(t.n_out),
-                      in_idx, out_idx, tuple(int(s) for s in in_shape), out_shape, ks,
-                      tuple(int(s) for s in conv.stride) if kind == "sparse" else (1,) * ndim,
-                      tuple(int(p) for p in conv.padding) if kind == "sparse" else tuple(k // 2 for k in ks),
-                      tuple(int(x) for x in conv.dilation))
-    rb.order_fwd, rb.order_bwd = _view1(arenas, t.order_fwd), _view1(arenas, t.order_bwd)
-    if t.grp_plan.arena >= 0:
-        rb.grp_plan = _view(arenas, t.grp_plan)
-    return rb
+
+    def lazy(v: _lib.PlanView, one_d=False):      # (arena, offset in words, rows, cols | 0): the view is made when somebody reads the field
+        return None if v.arena < 0 else (arenas[v.arena], v.offset >> 2, v.rows, 0 if one_d else v.cols)
+
+    views = {"pair_fwd": lazy(t.pair_fwd), "pair_bwd": lazy(t.pair_bwd), "rep": lazy(t.rep, True), "in_indices": in_idx,
+             "out_indices": in_idx if kind == "subm" else lazy(t.out_indices), "order_fwd": lazy(t.order_fwd, True),
+             "order_bwd": lazy(t.order_bwd, True), "grp_plan": lazy(t.grp_plan)}
+    return ops.PlanRulebook(kind, int(t.n_in), int(t.n_out), tuple(int(s) for s in in_shape), out_shape, ks,
+                            tuple(int(s) for s in conv.stride) if kind == "sparse" else (1,) * ndim,
+                            tuple(int(p) for p in conv.padding) if kind == "sparse" else tuple(k // 2 for k in ks),
+                            tuple(int(x) for x in conv.dilation), views)
 
 
 class ChainPlan:

@@ -86,6 +86,63 @@ class Rulebook:
         return int(np.ravel_multi_index(tuple(k // 2 for k in self.ksize), self.ksize))
 
 
+class PlanRulebook(Rulebook):
+    """A Rulebook whose tensors are views of a geometry-plan arena, CREATED ON FIRST ACCESS (round 6: host time).  A native plan has ~13
+    tables of up to eight views each; the native feature pass needs their addresses only (`ptr`), a Python consumer (tests, the
+    node-by-node path, a plan observer) gets ordinary tensors the first time it touches a field.  `views`: name -> tensor | None |
+    (arena int32 tensor, offset in words, rows, cols or 0 for a 1-D view)."""
+    _TENSORS = ("pair_fwd", "pair_bwd", "rep", "in_indices", "out_indices", "order_fwd", "order_bwd", "grp_plan")
+
+    def __init__(self, kind, n_in, n_out, in_shape, out_shape, ksize, stride, padding, dilation, views):   # noqa: D107 (no dataclass init)
+        d = self.__dict__
+        d["kind"], d["n_in"], d["n_out"] = kind, int(n_in), int(n_out)
+        d["in_shape"], d["out_shape"], d["ksize"], d["stride"], d["padding"], d["dilation"] = in_shape, out_shape, ksize, stride, padding, dilation
+        d["sorted_rows"] = False
+        for name in self._TENSORS:
+            d["_v_" + name] = views.get(name)
+
+    def ptr(self, name: str):
+        """Device address of a tensor field (None when absent) without creating the view."""
+        v = self.__dict__["_v_" + name]
+        if v is None:
+            return None
+        if type(v) is tuple:
+            return v[0].data_ptr() + 4 * v[1]
+        return v.data_ptr()
+
+    def has(self, name: str) -> bool:
+        return self.__dict__["_v_" + name] is not None
+
+
+def _plan_view_property(name):
+    key = "_v_" + name
+
+    def get(self):
+        v = self.__dict__[key]
+        if type(v) is tuple:
+            a, off, rows, cols = v
+            v = torch.as_strided(a, (rows, cols), (cols, 1), off) if cols else torch.as_strided(a, (rows,), (1,), off)
+            self.__dict__[key] = v
+        return v
+
+    def put(self, value):
+        self.__dict__[key] = value
+
+    return property(get, put)
+
+
+for _n in PlanRulebook._TENSORS:
+    setattr(PlanRulebook, _n, _plan_view_property(_n))
+
+
+def rulebook_ptr(rb: Rulebook, name: str):
+    """Address of `rb.<name>` (None when absent); for a PlanRulebook without materialising the view."""
+    if isinstance(rb, PlanRulebook):
+        return rb.ptr(name)
+    t = getattr(rb, name)
+    return None if t is None else t.data_ptr()
+
+
 def build_subm_rulebook(indices: torch.Tensor, spatial_shape, ksize, dilation=1, allow_duplicates: bool = False) -> Rulebook:
     ndim = indices.shape[1] - 1
     ks, dl = ntuple(ksize, ndim), ntuple(dilation, ndim)
