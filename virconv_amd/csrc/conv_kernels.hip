@@ -640,8 +640,8 @@ gather_gemm_v2_kernel(const float* __restrict__ src,
                                                              int centre, int mirror, ConvEpilogue epi) {
   static_assert(EPI == VC_EPI_NONE || RT == 1, "epilogues exist for the one-tile-per-wave kernel only");
   static_assert(!PK || (CK % 16 == 0 && (OT == VC_OPERAND_F32 || OT == VC_OPERAND_X6)), "packed weight images: fp32 operands, 16-channel K chunks");
-  static_assert(OT != VC_OPERAND_X6 || (RT == 1 && CK % 16 == 0 && !DXS && !IL), "split-bf16 products: one tile per wave, 16-channel K chunks");
-  static_assert(!DXS || (RT == 1 && CK % 16 == 0 && OT == VC_OPERAND_F32), "dx shift: one tile per wave, 16-byte row chunks, fp32");
+  static_assert(OT != VC_OPERAND_X6 || (RT == 1 && CK % 16 == 0 && !IL), "split-bf16 products: one tile per wave, 16-channel K chunks");
+  static_assert(!DXS || (RT == 1 && CK % 16 == 0 && (OT == VC_OPERAND_F32 || OT == VC_OPERAND_X6)), "dx shift: one tile per wave, 16-byte row chunks, fp32 rows (round 6: also with split products)");
   static_assert(!IL || (CK % 16 == 0 && !DXS), "interleaved source: 16-byte row chunks");
   static_assert(EPI == VC_EPI_NONE || (EPI == VC_EPI_BWD) == BWD, "STATS / AFFINE: forward kernel; BWD: backward-input kernel");
   constexpr int V = (CK >= 16) ? 4 : CK / 4;
@@ -2222,8 +2222,19 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
         size_t ldsx = (size_t)2 * NCH * NT * 64 * V * 6 + (size_t)(kv + 1) * (w8 ? 128 : 64) * sizeof(int) + 16;
         const dim3 gridx((unsigned)cdiv(n_out, w8 ? 128 : 64));
         fin_attach(epi, epi_kind, gridx.x, w8 ? 8 : 4, CN, ldsx);
+#ifdef VC_EXPERIMENTS
+#define VC_LX_DXS(B_, E_)                                                                                                         \
+    if (dxs && !w8) {  /* round 6: the dx shift (half the gathered rows) with split products: measured in profiles/r06_dxs_split.md */ \
+      hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, B_, 1, VC_OPERAND_X6, E_, 4, true, true>), gridx, dim3(256), ldsx, st, src, \
+                         src_centre, n_src, tbl, wpk, out, rep, order, n_out, kv, centre, mirror, epi);                           \
+      break;                                                                                                                      \
+    }
+#else
+#define VC_LX_DXS(B_, E_)
+#endif
 #define VC_LX(B_, E_)                                                                                                             \
   do {                                                                                                                            \
+    VC_LX_DXS(B_, E_)                                                                                                             \
     if (w8) hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, B_, 1, VC_OPERAND_X6, E_, 8, true>), gridx, dim3(512), ldsx, st, src, \
                                src_centre, n_src, tbl, wpk, out, rep, order, n_out, kv, centre, mirror, epi);                    \
     else hipLaunchKernelGGL((gather_gemm_v2_kernel<CK, CN, B_, 1, VC_OPERAND_X6, E_, 4, true>), gridx, dim3(256), ldsx, st, src,  \
@@ -2243,6 +2254,7 @@ static int launch_gg(const float* src, const float* src_centre, int64_t n_src, c
           else done = false;
         }
 #undef VC_LX
+#undef VC_LX_DXS
         if (done) {
           VC_CHECK_LAUNCH("gather_gemm_v2_kernel<split bf16>");
           return VC_OK;
