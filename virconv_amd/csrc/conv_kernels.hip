@@ -1310,8 +1310,18 @@ __device__ __forceinline__ void bw_group32_x6(const float* __restrict__ x, const
 
 // OT != VC_OPERAND_F32: 16 pairs per MFMA step (v_mfma_f32_16x16x16_{f16,bf16}); lane (i, q) loads the rows of the 4 pairs
 // 4q..4q+3 of the group and packs, per channel, those 4 values (rounded to 16 bit) into one operand.
+// A/B builds only (VIRCONV_HIPCC_EXTRA=-DVC_BW_WAVES=N): force N waves per SIMD on the weight-gradient kernel (round 6: the split form needs
+// 96-200 VGPRs = 2-5 waves; does a latency-bound gather kernel gain from more resident waves at the price of spills?  profiles/r06_dw_occupancy.md)
+#ifndef VC_BW_WAVES
+#define VC_BW_WAVES 0
+#endif
+#if VC_BW_WAVES > 0
+#define VC_BW_ATTR __attribute__((amdgpu_waves_per_eu(VC_BW_WAVES)))
+#else
+#define VC_BW_ATTR
+#endif
 template <int CI, int CO, int OT, bool WIDE = false>
-__global__ void __launch_bounds__(256) bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+__global__ void __launch_bounds__(256) VC_BW_ATTR bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                          const int32_t* __restrict__ tbl, int64_t n_out, int kv,
                                                          int64_t rows_per_block, int nsplit, int legacy_order,
                                                          float* __restrict__ partial, const int32_t* __restrict__ rep,
