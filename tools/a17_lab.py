@@ -260,7 +260,16 @@ def run_micro(args):
         for mode in [int(m) for m in args.mode.split(",")]:
             for lds in [int(v) for v in args.lds.split(",")]:
                 dset(be, "plan_uv_mode", mode); dset(be, "plan_uv_lds", lds)
-                if mode in (0, 4, 5, 6) or mode >= 100:  # (200 + k: code shifted by 4 k bytes)   # these share the product kernel's arithmetic: equal on an idle GPU
+                mrefs = refs
+                if 300 <= mode < 400:      # a PART of the block: this variant's own idle-GPU result is its reference
+                    torch.cuda.synchronize()
+                    mrefs = {}
+                    for s_ in (1, 2, 4, 8):
+                        r = torch.empty((n, 3), dtype=torch.int32, device=dev)
+                        assert be.lib.vc_project_uv(P(idx), n, P(params), bs, s_, P(r), None, ctypes.c_void_p(st0)) == 0
+                        mrefs[s_] = r
+                    torch.cuda.synchronize()
+                elif mode in (0, 4, 5, 6) or mode >= 100:  # (200 + k: code shifted by 4 k bytes; 4xx / 5xx: loads restated / checked)   # these share the product kernel's arithmetic: equal on an idle GPU
                     r = torch.empty((n, 3), dtype=torch.int32, device=dev)
                     assert be.lib.vc_project_uv(P(idx), n, P(params), bs, 1, P(r), None, ctypes.c_void_p(st0)) == 0
                     torch.cuda.synchronize()
@@ -281,7 +290,7 @@ def run_micro(args):
                             assert be.lib.vc_project_uv(P(idx), n, P(params), bs, strides[k % 4], P(outs[k]), None,
                                                         ctypes.c_void_p(victim.cuda_stream)) == 0
                         for k in range(args.victims):
-                            bad = (outs[k] != refs[strides[k % 4]]).any(1)
+                            bad = (outs[k] != mrefs[strides[k % 4]]).any(1)
                             cnt = bad.sum()
                             bad_rows += cnt
                             bad_launches += (cnt > 0).to(torch.int64)
@@ -302,7 +311,7 @@ def run_micro(args):
                        "set": args.set or None, "mode": mode, "lds": lds, "launches": args.rounds * args.victims, "rows_per_launch": n,
                        "bad_launches": int(bad_launches), "bad_rows": int(bad_rows), "bad_rows_lanes_48_63": int(sum(ln[48:])),
                        "bad_rows_other_lanes": int(sum(ln[:48])),
-                       "in_kernel_mismatch_threads": int(mm.value - mm0.value) if mode == 6 else None, "seconds": round(dt, 2)}
+                       "in_kernel_mismatch_threads": int(mm.value - mm0.value) if mode in (6, 501) else None, "seconds": round(dt, 2)}
                 print(json.dumps(res), flush=True)
                 if args.explain and kept:
                     rows = torch.cat([k_[0] for k_ in kept]).cpu()
@@ -379,6 +388,58 @@ def run_dump(args, be, batch, idx, params, refs, victim, make_chunk, aug, dev):
               "| Xs Yf Y0", float(E["Xs"][j]), float(E["Yf"][j]), float(E["Y0"][j]), "ca sa sc", float(E["ca"][j]), float(E["sa"][j]), float(E["sc"][j]), flush=True)
 
 
+def run_generic(args):
+    """Is the projection kernel special?  Generic vector-ALU-dense victims -- one torch kernel each, 50-150 dependent fp32 operations per element
+    behind one load -- on the victim stream beside the aggressor; every launch compared bit for bit with the same kernel on an idle GPU."""
+    dev = torch.device("cuda", 0)
+    be = ops.get_backend()
+    bs = 4
+    batch = bench.make_batch(list(range(bs)), dev, training=True)
+    victim, main, side = make_streams(args.mask, dev)
+    torch.cuda.set_stream(main)
+    be._side = side
+    layers = {}
+    x_, w_, dy_, rb_ = layer_inputs(be, batch, bs, dev, args.layer)
+    dset(be, "conv_autopack", 1); dset(be, "f32_split", 1)
+    chunk = (lambda: [be.conv_forward(x_, w_, rb_.pair_fwd, order=rb_.order_fwd) for _ in range(args.chunk)]) if args.aggr != "none" else (lambda: None)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    n = 1 << 20
+    a = (torch.rand((n,), generator=g) * 4 + 0.1).to(dev)
+    b = (torch.rand((n,), generator=g) * 2 - 1).to(dev)
+    victims = {
+        "lgamma": lambda: torch.lgamma(a),
+        "erfinv": lambda: torch.special.erfinv(b * 0.999),
+        "digamma": lambda: torch.digamma(a),
+        "atan2": lambda: torch.atan2(b, a),
+        "sinh": lambda: torch.sinh(b * 3),
+        "pow": lambda: torch.pow(a, b),
+        "div_chain (a / (a + 1) / (a + 2) ...: one fused addcdiv each, 8 launches)": lambda: torch.addcdiv(b, a, a + 1.0),
+    }
+    chunk()
+    torch.cuda.synchronize()
+    for name, fn in victims.items():
+        ref = fn()
+        torch.cuda.synchronize()
+        bad_l = torch.zeros((), dtype=torch.int64, device=dev)
+        bad_e = torch.zeros((), dtype=torch.int64, device=dev)
+        marks = []
+        for r_ in range(args.rounds):
+            chunk()
+            with torch.cuda.stream(victim):
+                for k in range(args.victims):
+                    y = fn()
+                    cnt = (y.view(torch.int32) != ref.view(torch.int32)).sum()
+                    bad_e += cnt
+                    bad_l += (cnt > 0).to(torch.int64)
+                ev = torch.cuda.Event(); ev.record(victim)
+            marks.append(ev)
+            if len(marks) > 2:
+                marks.pop(0).synchronize()
+        torch.cuda.synchronize()
+        print(json.dumps({"exp": "generic", "aggr": args.aggr + ":" + args.layer, "victim": name, "launches": args.rounds * args.victims,
+                          "elements_per_launch": n, "bad_launches": int(bad_l), "bad_elements": int(bad_e)}), flush=True)
+
+
 def run_stress(args):
     import test_plan_stress_gpu as T
     dev = torch.device("cuda", 0)
@@ -438,10 +499,17 @@ if __name__ == "__main__":
     m.add_argument("--victims", type=int, default=8)
     m.add_argument("--chunk", type=int, default=24, help="aggressor launches per round")
     m.add_argument("--rep", type=int, default=2, help="the batch's coordinate list repeated this many times per victim launch")
+    gq = sub.add_parser("generic")
+    gq.add_argument("--aggr", default="fwd")
+    gq.add_argument("--layer", default="s3")
+    gq.add_argument("--mask", default="none")
+    gq.add_argument("--rounds", type=int, default=100)
+    gq.add_argument("--victims", type=int, default=8)
+    gq.add_argument("--chunk", type=int, default=24)
     s = sub.add_parser("stress")
     s.add_argument("--mask", default="none")
     s.add_argument("--guard", type=int, default=0)
     s.add_argument("--steps", type=int, default=64)
     s.add_argument("--exact", type=int, default=0)
     a = ap.parse_args()
-    run_micro(a) if a.cmd == "micro" else run_stress(a)
+    {"micro": run_micro, "stress": run_stress, "generic": run_generic}[a.cmd](a)

@@ -569,7 +569,12 @@ class HipBackend:
         kv_total = sum(int(w.shape[1]) for w in w_passes)
         assert kv_total % D == 0
         k2 = kv_total // D
-        ky = kx = int(round(k2 ** 0.5))
+        if ksize is not None:      # (ky, kx) of the Conv2d (a non-square kernel cannot be inferred from the offset count)
+            ky, kx = int(ksize[0]), int(ksize[1])
+            assert ky * kx == k2, (ky, kx, k2)
+        else:
+            ky = kx = int(round(k2 ** 0.5))
+            assert ky * kx == k2, "bev_stem_conv_backward: non-square kernel -- pass ksize=(ky, kx)"
         assert ky * kx == k2, "square 2-D kernels only"
         shp = i32arr((D, H, W))
         st = _stream()
@@ -602,7 +607,7 @@ class HipBackend:
         return dense
 
     def bev_stem_conv_backward(self, features: torch.Tensor, indices: torch.Tensor, spatial_shape, batch_size: int, w_passes, cout: int,
-                               pair: torch.Tensor, gy: torch.Tensor, need_dx: bool, need_dw: bool):
+                               pair: torch.Tensor, gy: torch.Tensor, need_dx: bool, need_dw: bool, ksize=None):
         """Backward of `bev_stem_conv(..., want_nhwc=True)`: gy (cells, cout) -> (d features (n, C) | None, per-pass weight gradients
         [(cout, kv_pass, C), ...] | None).  dX: the forward-form gather-GEMM of gy over the transposed table (vc_bev_pairs_backward;
         a pass (C, kv_pass, cout) is exactly the (output channels, offsets, source channels) layout that kernel reads);
@@ -614,7 +619,12 @@ class HipBackend:
         D, H, W = (int(v) for v in spatial_shape)
         kv_total = int(pair.shape[0])
         k2 = kv_total // D
-        ky = kx = int(round(k2 ** 0.5))
+        if ksize is not None:      # (ky, kx) of the Conv2d (a non-square kernel cannot be inferred from the offset count)
+            ky, kx = int(ksize[0]), int(ksize[1])
+            assert ky * kx == k2, (ky, kx, k2)
+        else:
+            ky = kx = int(round(k2 ** 0.5))
+            assert ky * kx == k2, "bev_stem_conv_backward: non-square kernel -- pass ksize=(ky, kx)"
         dx, dws = None, None
         if need_dx:
             pair_bwd = torch.empty((kv_total, n), dtype=torch.int32, device=features.device)

@@ -32,6 +32,7 @@ class _StemConvFunction(torch.autograd.Function):
         be = ops.get_backend()
         y, pair = be.bev_stem_conv(feats, indices, spatial_shape, batch_size, passes, weight.shape[0], want_nhwc=True, want_pairs=True)
         ctx.save_for_backward(feats, weight)
+        ctx.weight_version = weight._version
         ctx.geom = (indices, tuple(int(v) for v in spatial_shape), int(batch_size), passes, pair)
         return y
 
@@ -40,8 +41,10 @@ class _StemConvFunction(torch.autograd.Function):
         feats, weight = ctx.saved_tensors
         indices, shape, bs, passes, pair = ctx.geom
         be = ops.get_backend()
+        if weight._version != ctx.weight_version:     # `passes` were packed from the weight as it was at forward time
+            raise RuntimeError("SparseBEVStem: the conv weight was modified in place between forward and backward")
         dx, dws = be.bev_stem_conv_backward(feats, indices, shape, bs, passes, weight.shape[0], pair, gy.contiguous(),
-                                            ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+                                            ctx.needs_input_grad[0], ctx.needs_input_grad[1], ksize=(weight.shape[2], weight.shape[3]))
         dw = None
         if dws is not None:
             cout, cd, ky, kx = weight.shape
@@ -108,6 +111,8 @@ class SparseBEVStem(nn.Module):
             # training through the stem: the conv as one autograd node over the sparse rows, BatchNorm2d + ReLU as the BEV backbone's
             # own modules on the NHWC rows seen as a channels-last (B, C, H, W) tensor (statistics over every cell of the map)
             y = _StemConvFunction.apply(t.features, conv.weight, t.indices, t.spatial_shape, t.batch_size, passes)
+            # (B, C, H, W) in channels-last strides: what the NHWC rows are, and what MIOpen's BatchNorm / the next convs take as is.  A
+            # consumer that calls .view() on the result needs .contiguous() first (the dense recipe's output is NCHW-contiguous).
             y4 = y.view(t.batch_size, int(t.spatial_shape[1]), int(t.spatial_shape[2]), conv.out_channels).permute(0, 3, 1, 2)
             return self._block[3](bn(y4))
         if bn.training:   # batch statistics over the WHOLE map (zeros of the empty cells included): the NHWC rows hold every cell

@@ -579,6 +579,16 @@ __global__ void __launch_bounds__(256) project_uv_kernel(const int32_t* __restri
         if (__float_as_int(Xa) != __float_as_int(Xb) || __float_as_int(Ya) != __float_as_int(Yb) || __float_as_int(Za) != __float_as_int(Zb))
           atomicAdd(&g_a17_mismatch, 1ull);
         X = Xa; Y = Ya; Z = Za;
+      } else if constexpr (MODE >= 300 && MODE < 400) {   // round 6 lab: PARTS of the block (its own idle-GPU result is the reference): which part must be there?
+        if constexpr (MODE == 302 || MODE == 305) { X = __fdiv_rn(X, sc); Y = __fdiv_rn(Y, sc); Z = __fdiv_rn(Z, sc); }   // 302 scale only
+        if constexpr (MODE == 304 || MODE == 305) { if (P[26] != 0.0f) Y = -Y; }                                           // 304 flip only; 305 scale + flip
+        if constexpr (MODE == 303) {                                                                                       // 303 rotation only
+          const float ca = P[24], sa = P[25], nsa = -P[25];
+          const float X2 = __fadd_rn(__fmul_rn(X, ca), __fmul_rn(Y, nsa));
+          const float Y2 = __fadd_rn(__fmul_rn(X, sa), __fmul_rn(Y, ca));
+          X = X2; Y = Y2;
+        }
+        // 301: nothing (the divergent branch on the flag word and an empty block)
       } else {
       if constexpr (MODE == 3) {   // diagnostics only (not the reference's rounding): no IEEE division sequence in the block
         const float rs = __builtin_amdgcn_rcpf(sc);
@@ -594,6 +604,66 @@ __global__ void __launch_bounds__(256) project_uv_kernel(const int32_t* __restri
       }
     }
     float rect[3], hom[3];
+    if constexpr (MODE == 701 || MODE == 702) {
+      // round 6 lab: is it the L1?  The six 16-byte loads of the matrix words written out by hand, waited for before any use -- 701 with
+      // sc0 sc1 (the requests go past the CU's vector L1 to L2), 702 plain (control: the same code through the L1)
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      f4 q0, q1, q2, q3, q4, q5;
+      if constexpr (MODE == 701)
+        asm volatile("global_load_dwordx4 %0, %6, off sc0 sc1\n\tglobal_load_dwordx4 %1, %6, off offset:16 sc0 sc1\n\t"
+                     "global_load_dwordx4 %2, %6, off offset:32 sc0 sc1\n\tglobal_load_dwordx4 %3, %6, off offset:48 sc0 sc1\n\t"
+                     "global_load_dwordx4 %4, %6, off offset:64 sc0 sc1\n\tglobal_load_dwordx4 %5, %6, off offset:80 sc0 sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5) : "v"(P) : "memory");
+      else
+        asm volatile("global_load_dwordx4 %0, %6, off\n\tglobal_load_dwordx4 %1, %6, off offset:16\n\t"
+                     "global_load_dwordx4 %2, %6, off offset:32\n\tglobal_load_dwordx4 %3, %6, off offset:48\n\t"
+                     "global_load_dwordx4 %4, %6, off offset:64\n\tglobal_load_dwordx4 %5, %6, off offset:80\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5) : "v"(P) : "memory");
+      const float p[24] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3], q2[0], q2[1], q2[2], q2[3],
+                           q3[0], q3[1], q3[2], q3[3], q4[0], q4[1], q4[2], q4[3], q5[0], q5[1], q5[2], q5[3]};
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        rect[c] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(X, p[0 + c]), __fmul_rn(Y, p[3 + c])), __fmul_rn(Z, p[6 + c])), p[9 + c]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        hom[c] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(rect[0], p[12 + c]), __fmul_rn(rect[1], p[15 + c])), __fmul_rn(rect[2], p[18 + c])),
+                           p[21 + c]);
+      u = sat_int(__fdiv_rn(hom[0], rect[2]));
+      v = sat_int(__fdiv_rn(hom[1], rect[2]));
+      dep = __fsub_rn(hom[2], p[21 + 2]);
+    } else
+    if constexpr (MODE == 401 || MODE == 402 || MODE == 403) {
+      // round 6 lab: is it the LOADS?  The 24 matrix words are loaded into named registers, all of them waited for (vmcnt(0)), and only then
+      // used -- 401: 16 idle cycles between the wait and the first use; 402: no idle cycles (control); 403: the wait, then every register
+      // read once more by a v_mov (one more pass over the loaded registers before the arithmetic)
+      float p[24];
+#pragma unroll
+      for (int k = 0; k < 24; ++k) p[k] = P[k];
+      if constexpr (MODE == 401)
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]),
+                     "+v"(p[8]), "+v"(p[9]), "+v"(p[10]), "+v"(p[11]), "+v"(p[12]), "+v"(p[13]), "+v"(p[14]), "+v"(p[15]), "+v"(p[16]), "+v"(p[17]),
+                     "+v"(p[18]), "+v"(p[19]), "+v"(p[20]), "+v"(p[21]), "+v"(p[22]), "+v"(p[23]));
+      else
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]),
+                     "+v"(p[8]), "+v"(p[9]), "+v"(p[10]), "+v"(p[11]), "+v"(p[12]), "+v"(p[13]), "+v"(p[14]), "+v"(p[15]), "+v"(p[16]), "+v"(p[17]),
+                     "+v"(p[18]), "+v"(p[19]), "+v"(p[20]), "+v"(p[21]), "+v"(p[22]), "+v"(p[23]));
+      if constexpr (MODE == 403) {
+#pragma unroll
+        for (int k = 0; k < 24; ++k) asm volatile("v_mov_b32 %0, %0" : "+v"(p[k]));
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        rect[c] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(X, p[0 + c]), __fmul_rn(Y, p[3 + c])), __fmul_rn(Z, p[6 + c])), p[9 + c]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        hom[c] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(rect[0], p[12 + c]), __fmul_rn(rect[1], p[15 + c])), __fmul_rn(rect[2], p[18 + c])),
+                           p[21 + c]);
+      u = sat_int(__fdiv_rn(hom[0], rect[2]));
+      v = sat_int(__fdiv_rn(hom[1], rect[2]));
+      dep = __fsub_rn(hom[2], p[21 + 2]);
+    } else {
 #pragma unroll
     for (int c = 0; c < 3; ++c)
       rect[c] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(X, P[0 + c]), __fmul_rn(Y, P[3 + c])), __fmul_rn(Z, P[6 + c])),
@@ -606,6 +676,7 @@ __global__ void __launch_bounds__(256) project_uv_kernel(const int32_t* __restri
     u = sat_int(__fdiv_rn(hom[0], rect[2]));
     v = sat_int(__fdiv_rn(hom[1], rect[2]));
     dep = __fsub_rn(hom[2], P[21 + 2]);
+    }
     if constexpr (DBG) {   // every row's intermediates, per stage (int 3 of the header: rows of capacity per stage region)
       const int cap = dbg[3];
       if (cap > 0 && i < cap) {
@@ -619,8 +690,16 @@ __global__ void __launch_bounds__(256) project_uv_kernel(const int32_t* __restri
   u = min(max(u, 0), 1400 - 1) / stride;
   v = min(max(v, 0), 600 - 1) / stride;
   int32_t* o = uv + i * 3;
+  if constexpr (MODE == 602) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(u), "+v"(v));   // round 6 lab: idle IN FRONT of the output store
   o[0] = b; o[1] = u; o[2] = v;
   if (depth) depth[i] = dep;
+  if constexpr (MODE == 601) asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // ... the store acknowledged + idle BEHIND it, before s_endpgm
+  if constexpr (MODE == 603) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");  // ... idle behind the store without waiting for it
+  if constexpr (MODE == 501) {   // round 6 lab: were the COORDINATES this thread computed with the ones in memory?  (read again, at the very end)
+    const volatile int32_t* iv = indices + i * 4;
+    const int b2 = iv[0], z2 = iv[1], y2 = iv[2], x2 = iv[3];
+    if (b2 != r.x || z2 != r.y || y2 != r.z || x2 != r.w) atomicAdd(&g_a17_mismatch, 1ull);
+  }
 }
 
 // ---- the image-space branch of every block of a geometry plan in one launch (plan.hip; Uv2dArgs, common.h): projection
@@ -1312,6 +1391,11 @@ int project_uv_debug(const int32_t* indices, int64_t n, const float* params, int
     else if (mode == 201) VC_UV_LAUNCH(201, false); else if (mode == 202) VC_UV_LAUNCH(202, false); else if (mode == 204) VC_UV_LAUNCH(204, false);
     else if (mode == 208) VC_UV_LAUNCH(208, false); else if (mode == 212) VC_UV_LAUNCH(212, false); else if (mode == 216) VC_UV_LAUNCH(216, false);
     else if (mode == 224) VC_UV_LAUNCH(224, false); else if (mode == 232) VC_UV_LAUNCH(232, false);
+    else if (mode == 301) VC_UV_LAUNCH(301, false); else if (mode == 302) VC_UV_LAUNCH(302, false); else if (mode == 303) VC_UV_LAUNCH(303, false);
+    else if (mode == 304) VC_UV_LAUNCH(304, false); else if (mode == 305) VC_UV_LAUNCH(305, false);
+    else if (mode == 501) VC_UV_LAUNCH(501, false); else if (mode == 601) VC_UV_LAUNCH(601, false); else if (mode == 602) VC_UV_LAUNCH(602, false);
+    else if (mode == 603) VC_UV_LAUNCH(603, false); else if (mode == 701) VC_UV_LAUNCH(701, false); else if (mode == 702) VC_UV_LAUNCH(702, false);
+    else if (mode == 401) VC_UV_LAUNCH(401, false); else if (mode == 402) VC_UV_LAUNCH(402, false); else if (mode == 403) VC_UV_LAUNCH(403, false);
     else VC_UV_LAUNCH(0, false);
   }
 #undef VC_UV_LAUNCH
