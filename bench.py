@@ -204,8 +204,11 @@ def train_step(model, optimizer, batch, lw, grad_sync=None, raw=None, next_batch
     if params is None:
         from virconv_amd import feature_pass
         params = base._bench_param_list = feature_pass.trainable_parameters(base)   # the flat parameters if the model was flattened
-    torch.nn.utils.clip_grad_norm_(params, 10.0)
-    optimizer.step()
+    if getattr(optimizer, "clips", False):
+        optimizer.step()                                  # virconv_amd.optim.ClipAdamW: the clip is part of the step (vc_clip_adamw)
+    else:
+        torch.nn.utils.clip_grad_norm_(params, 10.0)
+        optimizer.step()
     return loss
 
 
@@ -503,8 +506,15 @@ def main(argv=None, plumbing=False):
     opt_params = feature_pass.flatten_parameters(model) if flat_on else list(model.parameters())
     ddp = parallel.wrap_ddp(model, device) if use_torch_ddp else model
     grad_sync = None if use_torch_ddp else parallel.FlatGradAllReduce(model, opt_params)
-    optimizer = torch.optim.AdamW(opt_params, lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01,
-                                  fused=not plumbing)  # stock torch fused AdamW kernel (a16: optimizer stays stock torch)
+    # a16 (train_utils.py:50-51): clip_grad_norm_(10) + the Adam step with true weight decay.  On flat parameters these are the two launches of
+    # virconv_amd.optim.ClipAdamW (vc_clip_adamw); VIRCONV_FUSED_OPT=0, per-module parameters and the CPU plumbing run keep the stock pair
+    # (clip_grad_norm_ + torch's fused multi-tensor AdamW: 12 launches, 0.10 ms of device time on one flat tensor).
+    from virconv_amd import optim as vc_optim
+    fused_opt = flat_on and os.environ.get("VIRCONV_FUSED_OPT", "1") != "0" and vc_optim.supports(opt_params)
+    if fused_opt:
+        optimizer = vc_optim.ClipAdamW(opt_params, lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, max_norm=10.0)
+    else:
+        optimizer = torch.optim.AdamW(opt_params, lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, fused=not plumbing)
     lw = make_loss_weights(device)
     torch.manual_seed(100 + rank)  # layer-discard permutations
     # the inputs are resident in HBM from here on: lets the backbone's geometry plan run ahead on its side stream
@@ -777,7 +787,9 @@ def main(argv=None, plumbing=False):
                                                  + os.environ["VIRCONV_MAIN_PRIORITY"]),
                                      "row_order": ops.ROW_ORDER,
                                      "parameters": (f"{len(opt_params)} flat tensor(s) aliased by the modules' parameters (feature_pass.flatten_parameters)"
-                                                    if flat_on and len(opt_params) < 10 else "per module")}},
+                                                    if flat_on and len(opt_params) < 10 else "per module"),
+                                     "optimizer": ("virconv_amd.optim.ClipAdamW (vc_clip_adamw: clip_grad_norm_(10) + AdamW in two launches)" if fused_opt
+                                                   else "torch clip_grad_norm_(10) + torch.optim.AdamW(fused)")}},
         "roofline": roof,
         "exact_f32_mfma": exact,
     }

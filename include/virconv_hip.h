@@ -55,8 +55,8 @@ typedef enum vc_operand {
 const char* vc_version(void);
 /* Layout version of the structs that cross this boundary (vc_plan_desc, vc_pass_program, vc_trace_record, ...).  A binding compares
  * vc_abi_version() with the VC_ABI_VERSION it was written against before it fills any of them: a field added to a struct (round 5:
- * vc_pass_program.pack_all; round 6: vc_plan_desc.allow_unfenced_projection) otherwise reads as a silent zero on the other side. */
-#define VC_ABI_VERSION 6
+ * vc_pass_program.pack_all; round 6: vc_plan_desc.allow_unfenced_projection, vc_adam_tensor) otherwise reads as a silent zero on the other side. */
+#define VC_ABI_VERSION 7
 int vc_abi_version(void);
 const char* vc_last_error(void);
 /* developer switch for A/B measurements (tools/kbench.py): "conv_variant" = 1 | 2 */
@@ -254,6 +254,29 @@ int vc_group_sum_sorted(const float* dy, const int32_t* grp_plan, int64_t n, int
 size_t vc_weighted_sum_workspace_bytes(int64_t nb, int64_t e);
 int vc_weighted_sum(const float* x, int64_t nb, int64_t e, const float* g, float* out, void* ws, size_t ws_bytes, void* stream);
 int vc_weighted_sum_backward(const float* gout, const float* g, int64_t nb_out, int64_t e, float* dx, void* stream);
+
+/* Gradient clip + optimizer step over a few flat fp32 parameter vectors (row a16).  Replaces, for a model whose parameters alias one
+ * tensor per native pass (feature_pass.flatten_parameters), tools/train_utils/train_utils.py:50-51
+ *     clip_grad_norm_(model.parameters(), optim_cfg.GRAD_NORM_CLIP); optimizer.step()
+ * with the optimizer of tools/train_utils/optimization/__init__.py:19-32 (`adam_onecycle`: Adam, betas (0.9, 0.99), true_wd, bn_wd)
+ * stepped as fastai_optim.py:132-149 does: p *= 1 - wd * lr, then Adam with weight_decay 0 (= torch.optim.AdamW):
+ *     total_norm = sqrt(sum over ALL tensors of ||grad||^2);  coef = min(max_norm / (total_norm + 1e-6), 1)  (max_norm <= 0: coef = 1)
+ *     g = grad * coef;  m += (1 - beta1) * (g - m);  v = beta2 * v + (1 - beta2) * g * g
+ *     p = p * (1 - lr * wd) - lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ * `step` counts from 1; lr and beta1 are per call (the one-cycle schedule moves both every iteration).  Two launches, no atomics, no
+ * state in the workspace (nothing to zero): run-to-run bit-stable.  total_norm: optional device float.  scale_grads != 0 writes g back
+ * into `grad` (what clip_grad_norm_ leaves in .grad); otherwise `grad` is only read.  Tensors with n = 0 are skipped.            */
+#define VC_ADAM_MAX_TENSORS 16
+typedef struct vc_adam_tensor {
+  float* param;        /* n floats, updated in place */
+  float* grad;         /* n floats */
+  float* exp_avg;      /* n floats, zero before step 1 */
+  float* exp_avg_sq;   /* n floats, zero before step 1 */
+  int64_t n;
+} vc_adam_tensor;
+size_t vc_clip_adamw_workspace_bytes(int n_tensors);
+int vc_clip_adamw(const vc_adam_tensor* tensors, int n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  int64_t step, float max_norm, int scale_grads, float* total_norm, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ K9 projection
  * Voxel index -> image pixel index.  Replaces index2points + index2uv +

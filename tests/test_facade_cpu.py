@@ -256,3 +256,15 @@ def test_plan_splits_with_one_read_equals_the_per_slab_nonzero_form():
             for k in ("x3", "x4", "out"):
                 keep, idx, shape = VirConv8x._plan_split(co[k][0], co[k][1], i)
                 assert torch.equal(got[rid][k][0], keep) and torch.equal(got[rid][k][1], idx) and got[rid][k][2] == shape
+
+
+def test_clip_adamw_has_no_cpu_path():
+    """virconv_amd.optim.ClipAdamW is two HIP launches (vc_clip_adamw): CPU parameters are refused at construction, nothing falls back."""
+    import pytest
+    import torch
+    from virconv_amd import optim
+    p = torch.nn.Parameter(torch.zeros(8))
+    assert not optim.supports([p])
+    assert not optim.supports([])
+    with pytest.raises(ValueError, match="CUDA"):
+        optim.ClipAdamW([p])

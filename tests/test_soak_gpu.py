@@ -61,7 +61,13 @@ def _fresh(dev, model_kind="L"):
         model = VirConv8x(bench.MODEL_CFG_8X, 8, synth.GRID_SIZE).to(dev).train()
     else:
         model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).to(dev).train()
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, fused=True)
+    # as bench.main: flat parameters + the two-launch clip + AdamW (VIRCONV_FLAT_PARAMS=0 / VIRCONV_FUSED_OPT=0: the stock forms)
+    from virconv_amd import feature_pass, optim
+    params = feature_pass.flatten_parameters(model) if os.environ.get("VIRCONV_FLAT_PARAMS", "1") != "0" else list(model.parameters())
+    if os.environ.get("VIRCONV_FUSED_OPT", "1") != "0" and optim.supports(params):
+        opt = optim.ClipAdamW(params, lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, max_norm=10.0)
+    else:
+        opt = torch.optim.AdamW(params, lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, fused=True)
     return model, opt
 
 
@@ -70,6 +76,7 @@ def _state(model, opt, losses):
     for k, v in model.state_dict().items():
         out["model." + k] = v.detach().clone()
     names = {id(p): n for n, p in model.named_parameters()}
+    names.update({id(p): f"flat{i}" for i, p in enumerate(opt.param_groups[0]["params"]) if id(p) not in names})
     for p, st in opt.state.items():
         for k in ("exp_avg", "exp_avg_sq"):
             out[f"adam.{names[id(p)]}.{k}"] = st[k].detach().clone()

@@ -18,14 +18,22 @@ parallel.init_distributed()
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
-batch = bench.make_batch([0, 1, 2, 3], dev, True)
-model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).to(dev).train()
+if os.environ.get("MODEL", "L") == "8x":      # MODEL=8x: VirConv8x at its benchmark shape (2 frames per rank)
+    from virconv_amd.backbone import VirConv8x
+    batch = bench.make_batch_8x([0, 1], dev)
+    model = VirConv8x(bench.MODEL_CFG_8X, 8, synth.GRID_SIZE).to(dev).train()
+else:
+    batch = bench.make_batch([0, 1, 2, 3], dev, True)
+    model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).to(dev).train()
 gs = parallel.FlatGradAllReduce(model)
 import os as _os
 from virconv_amd import feature_pass as _fp
 # as bench.py: one flat parameter tensor per native pass (VIRCONV_FLAT_PARAMS=0: per module, the round-5 form)
 _opt_params = _fp.flatten_parameters(model) if _os.environ.get("VIRCONV_FLAT_PARAMS", "1") != "0" else list(model.parameters())
-opt = torch.optim.AdamW(_opt_params, lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, fused=True)
+from virconv_amd import optim as _vo
+_fused_opt = _os.environ.get("VIRCONV_FUSED_OPT", "1") != "0" and _vo.supports(_opt_params)      # as bench.py: clip + AdamW in two launches
+opt = (_vo.ClipAdamW(_opt_params, lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, max_norm=10.0) if _fused_opt else
+       torch.optim.AdamW(_opt_params, lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, fused=True))
 lw = bench.make_loss_weights(dev)
 batch["inputs_ready_event"] = torch.cuda.Event()
 batch["inputs_ready_event"].record()
@@ -114,7 +122,8 @@ def step():
     loss = timed("loss", bench.synthetic_loss, out, lw)
     timed("backward", loss.backward)
     timed("grad_sync", gs)
-    timed("clip_grad_norm_", torch.nn.utils.clip_grad_norm_, params, 10.0)
+    if not _fused_opt:
+        timed("clip_grad_norm_", torch.nn.utils.clip_grad_norm_, params, 10.0)
     timed("optimizer.step", opt.step)
 
 

@@ -28,7 +28,11 @@ batch = bench.make_batch([0, 1, 2, 3], dev, True)
 model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).to(dev).train()
 from virconv_amd import feature_pass as _fp
 _opt_params = _fp.flatten_parameters(model)     # as bench.py: one flat parameter tensor per native pass
-opt = torch.optim.AdamW(_opt_params, lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, fused=True)
+import os as _os
+from virconv_amd import optim as _vo
+_fused_opt = _os.environ.get("VIRCONV_FUSED_OPT", "1") != "0" and _vo.supports(_opt_params)      # as bench.py: clip + AdamW in two launches
+opt = (_vo.ClipAdamW(_opt_params, lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, max_norm=10.0) if _fused_opt else
+       torch.optim.AdamW(_opt_params, lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, fused=True))
 lw = bench.make_loss_weights(dev)
 torch.cuda.synchronize()
 batch["inputs_ready_event"] = torch.cuda.Event()
@@ -52,7 +56,8 @@ def step(ev=None):
     mark(1)
     loss.backward()
     mark(2)
-    torch.nn.utils.clip_grad_norm_(_opt_params, 10.0)
+    if not _fused_opt:
+        torch.nn.utils.clip_grad_norm_(_opt_params, 10.0)
     opt.step()
     mark(3)
 

@@ -23,7 +23,9 @@ def main(path: str, last: int = 6) -> None:
     for r in rows:
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0"), r.get("Stream_Id", "")))
     ev.sort()
-    ends = [i for i, e in enumerate(ev) if "multi_tensor_apply" in e[2] and "Adam" in e[2] or "fused_adam" in e[2].lower()]
+    ends = [i for i, e in enumerate(ev) if "clip_adamw_kernel" in e[2]]   # virconv_amd.optim.ClipAdamW; else the stock fused AdamW:
+    if len(ends) < last + 1:
+        ends = [i for i, e in enumerate(ev) if "multi_tensor_apply" in e[2] and "Adam" in e[2] or "fused_adam" in e[2].lower()]
     if len(ends) < last + 1:
         ends = [i for i, e in enumerate(ev) if "multi_tensor_apply" in e[2]]
     # one step may run several multi-tensor kernels back to back: keep the last of each burst
@@ -77,5 +79,15 @@ def main(path: str, last: int = 6) -> None:
         print(f"  {c:4d} {1e-3 * t:9.1f} {'main' if on else 'side'}  {n}")
 
 
+    if "--sequence" in sys.argv:
+        # every kernel of the last step in start order: offset from the step's first kernel, duration, queue, name
+        t0 = min(e[0] for e in seg)
+        qn = {k: i for i, k in enumerate(sorted(byq, key=lambda k: -sum(e[1] - e[0] for e in byq[k])))}
+        print("sequence of the last step (start us, duration us, queue rank by busy time: 0 = main, name):")
+        for s, e, n, q, st in sorted(seg):
+            print(f"  {1e-3 * (s - t0):9.1f} {1e-3 * (e - s):8.1f}  q{qn[(q, st)]}  {short(n)}")
+
+
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 6)
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    main(args[0], int(args[1]) if len(args) > 1 else 6)

@@ -12,7 +12,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 6     # = VC_ABI_VERSION of include/virconv_hip.h (struct layouts this file mirrors)
+ABI_VERSION = 7     # = VC_ABI_VERSION of include/virconv_hip.h (struct layouts this file mirrors)
 LIB_PATH = os.environ.get("VIRCONV_LIB", os.path.join(_HERE, "libvirconv_hip.so"))  # override: A/B builds only
 
 OPERAND_TYPES = {"f32": 0, "f16": 1, "bf16": 2}  # vc_operand (include/virconv_hip.h)
@@ -32,6 +32,8 @@ SIGNATURES = {
     "vc_weighted_sum_workspace_bytes": (_SZ, [_I64, _I64]),
     "vc_weighted_sum": (_I, [_P, _I64, _I64, _P, _P, _P, _SZ, _P]),
     "vc_weighted_sum_backward": (_I, [_P, _P, _I64, _I64, _P, _P]),
+    "vc_clip_adamw_workspace_bytes": (_SZ, [_I]),
+    "vc_clip_adamw": (_I, [_P, _I, _F, _F, _F, _F, _F, _I64, _F, _I, _P, _P, _SZ, _P]),
     "vc_hash_workspace_bytes": (_SZ, [_I64]),
     "vc_hash_build": (_I, [_P, _I64, _I, _P, _P, _SZ, _P]),
     "vc_subm_rulebook": (_I, [_P, _I64, _I, _P, _P, _P, _P, _SZ, _P, _P, _P]),
@@ -211,6 +213,13 @@ class PlanState(C.Structure):
 
 
 _lib = None
+
+
+ADAM_MAX_TENSORS = 16   # VC_ADAM_MAX_TENSORS
+
+
+class AdamTensor(C.Structure):   # vc_adam_tensor
+    _fields_ = [("param", _P), ("grad", _P), ("exp_avg", _P), ("exp_avg_sq", _P), ("n", _I64)]
 
 
 class VirConvError(RuntimeError):

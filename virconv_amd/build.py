@@ -30,6 +30,7 @@ SOURCES = {
     # rotated IoU / NMS: no mul+add contraction, so that the polygon arithmetic rounds like the reference's CPU build
     "nms_kernels.hip": ["-ffp-contract=off"],
     "group_kernels.hip": [],
+    "optim_kernels.hip": [],
     "unit.hip": [],
     "pass.hip": [],
     "plan.hip": [],

@@ -2439,8 +2439,8 @@ extern int g_pass_bwd_epilogue;
 extern int g_pass_pack_all;
 extern int g_pass_fork_ext_event; // pass.hip
 extern int g_bn_fused_partial;  // bn_kernels.hip
-extern int g_pass_defer_dw_reduce;  // pass.hip
-extern int g_plan_subm_bitmap, g_plan_image_2d, g_plan_parity_order, g_plan_params_pad, g_plan_reprepare, g_plan_uv_mode, g_plan_uv_poison, g_plan_uv_lds;   // plan.hip
+extern int g_pass_defer_dw_reduce, g_pass_dw_flush_mb;  // pass.hip
+extern int g_plan_subm_bitmap, g_plan_image_2d, g_plan_parity_order, g_plan_params_pad, g_plan_reprepare, g_plan_uv_mode, g_plan_uv_poison, g_plan_uv_lds, g_plan_uv_pad;   // plan.hip
 extern long long g_plan_uv_dbg;   // plan.hip
 int64_t a17_mismatch_read();   // index_kernels.hip
 extern int g_group_plan_radix, g_group_plan_onesweep, g_group_plan_multi_onesweep, g_plan_group_multi;   // group_kernels.hip
@@ -2643,6 +2643,7 @@ int vc_debug_set(const char* key, int value) {
   if (!strcmp(key, "bn_fused_partial")) { g_bn_fused_partial = value; return VC_OK; }
   if (!strcmp(key, "conv_bn_finish")) { g_conv_bn_finish = value; return VC_OK; }
   if (!strcmp(key, "pass_defer_dw_reduce")) { g_pass_defer_dw_reduce = value; return VC_OK; }
+  if (!strcmp(key, "pass_dw_flush_mb")) { g_pass_dw_flush_mb = value; return VC_OK; }
   if (!strcmp(key, "group_plan_onesweep")) { g_group_plan_onesweep = value; return VC_OK; }
   if (!strcmp(key, "sp_mark_variant")) { g_sp_mark_variant = value; return VC_OK; }
   if (!strcmp(key, "plan_subm_bitmap")) { g_plan_subm_bitmap = value; return VC_OK; }
@@ -2653,6 +2654,7 @@ int vc_debug_set(const char* key, int value) {
   if (!strcmp(key, "plan_params_pad")) { g_plan_params_pad = value < 0 ? 0 : (value + 255) & ~255; return VC_OK; }
   if (!strcmp(key, "plan_reprepare")) { g_plan_reprepare = value; return VC_OK; }
   if (!strcmp(key, "plan_uv_mode")) { g_plan_uv_mode = value; return VC_OK; }
+  if (!strcmp(key, "plan_uv_pad")) { g_plan_uv_pad = value != 0; return VC_OK; }
   if (!strcmp(key, "plan_uv_dbg_lo")) { g_plan_uv_dbg = (g_plan_uv_dbg & ~0xFFFFFFFFLL) | (long long)(unsigned)value; return VC_OK; }   // a device address in two halves
   if (!strcmp(key, "plan_uv_dbg_hi")) { g_plan_uv_dbg = (g_plan_uv_dbg & 0xFFFFFFFFLL) | ((long long)(unsigned)value << 32); return VC_OK; }
   if (!strcmp(key, "plan_uv_lds")) { g_plan_uv_lds = value < 0 ? 0 : (value > 160 * 1024 ? 160 * 1024 : value); return VC_OK; }

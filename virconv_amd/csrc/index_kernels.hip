@@ -471,7 +471,7 @@ __device__ __forceinline__ int sat_int(float f) {
   return (int)f;  // truncation toward zero
 }
 
-extern int g_plan_uv_mode, g_plan_uv_lds;   // plan.hip
+extern int g_plan_uv_mode, g_plan_uv_lds, g_plan_uv_pad;   // plan.hip
 extern long long g_plan_uv_dbg;
 __device__ unsigned long long g_a17_mismatch = 0;   // MODE 6: threads whose two computations of the inverse augmentation disagreed (vc_debug_get a17_mismatch)
 
@@ -705,6 +705,11 @@ __global__ void __launch_bounds__(256) project_uv_kernel(const int32_t* __restri
 // ---- the image-space branch of every block of a geometry plan in one launch (plan.hip; Uv2dArgs, common.h): projection
 // (the arithmetic of project_uv_kernel<0>, op for op: spconv_backbone.py:54-83) fused with the pixel marking of image_mark_kernel --
 // img[(b * U + u) * V + v] = 1 + the highest row of the pixel, runs of equal pixels in consecutive rows folded in the wave first.
+// PAD (LOG.md A.17 / A.21, profiles/r06_a17_cu_mask.md section 3): 16 idle cycles behind the parameter words, behind the inverse
+// augmentation and in front of the two divisions.  Same instructions, same results; in the stand-alone kernel ONE such pause anywhere in front of
+// the matrix loads took the wrong pixels beside dense bf16 MFMA kernels from ~430 of 800 launches to 0.  Not a fix (the cause is not known): a
+// second layer under the event fence, which stays the guarantee.  vc_debug_set plan_uv_pad = 0 selects the unpadded form (A/B, the lab).
+template <bool PAD>
 __device__ __forceinline__ void project_point(const int4 r, const float* __restrict__ params, int B, int stride, float vs, float minx,
                                               float miny, float minz, int& u, int& v) {
   const int b = r.x;
@@ -715,14 +720,17 @@ __device__ __forceinline__ void project_point(const int4 r, const float* __restr
     float Y = __fadd_rn(__fmul_rn((float)r.z, vs), miny);
     float Z = __fadd_rn(__fmul_rn((float)r.y, vs), minz);
     if (P[28] != 0.0f) {
-      const float sc = P[27];
+      float sc = P[27], ca = P[24], sa = P[25];
+      const float fl = P[26];
+      if constexpr (PAD) asm volatile("s_nop 15" : "+v"(sc), "+v"(ca), "+v"(sa));
       X = __fdiv_rn(X, sc); Y = __fdiv_rn(Y, sc); Z = __fdiv_rn(Z, sc);
-      if (P[26] != 0.0f) Y = -Y;
-      const float ca = P[24], sa = P[25], nsa = -P[25];
+      if (fl != 0.0f) Y = -Y;
+      const float nsa = -sa;
       const float X2 = __fadd_rn(__fmul_rn(X, ca), __fmul_rn(Y, nsa));
       const float Y2 = __fadd_rn(__fmul_rn(X, sa), __fmul_rn(Y, ca));
       X = X2; Y = Y2;
     }
+    if constexpr (PAD) asm volatile("s_nop 15" : "+v"(X), "+v"(Y), "+v"(Z));
     float rect[3], hom[2];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -733,6 +741,7 @@ __device__ __forceinline__ void project_point(const int4 r, const float* __restr
       hom[c] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(rect[0], P[12 + c]), __fmul_rn(rect[1], P[15 + c])),
                                    __fmul_rn(rect[2], P[18 + c])),
                          P[21 + c]);
+    if constexpr (PAD) asm volatile("s_nop 15" : "+v"(hom[0]), "+v"(hom[1]), "+v"(rect[2]));
     u = sat_int(__fdiv_rn(hom[0], rect[2]));
     v = sat_int(__fdiv_rn(hom[1], rect[2]));
   }
@@ -740,6 +749,7 @@ __device__ __forceinline__ void project_point(const int4 r, const float* __restr
   v = min(max(v, 0), 600 - 1) / stride;
 }
 
+template <bool PAD>
 __global__ void __launch_bounds__(256) uv_mark_multi_kernel(Uv2dArgs a) {
   int s = 0;
 #pragma unroll
@@ -753,7 +763,7 @@ __global__ void __launch_bounds__(256) uv_mark_multi_kernel(Uv2dArgs a) {
   if (live) {
     const int4 r = *reinterpret_cast<const int4*>(S.coords + i * 4);  // [b, z, y, x]
     int u, v;
-    project_point(r, a.params, a.B, S.stride, S.vs, S.minx, S.miny, S.minz, u, v);
+    project_point<PAD>(r, a.params, a.B, S.stride, S.vs, S.minx, S.miny, S.minz, u, v);
     int32_t* o = S.uv + i * 3;
     o[0] = r.x; o[1] = u; o[2] = v;
     if (r.x >= 0 && r.x < a.B && u >= 0 && u < S.U && v >= 0 && v < S.V) key = ((int64_t)r.x * S.U + u) * S.V + v;
@@ -773,7 +783,8 @@ __global__ void __launch_bounds__(256) uv_mark_multi_kernel(Uv2dArgs a) {
 
 int uv_mark_multi(const Uv2dArgs& a, unsigned total_blocks, hipStream_t st) {
   if (total_blocks == 0) return VC_OK;
-  hipLaunchKernelGGL(uv_mark_multi_kernel, dim3(total_blocks), dim3(256), 0, st, a);
+  if (g_plan_uv_pad) hipLaunchKernelGGL(uv_mark_multi_kernel<true>, dim3(total_blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(uv_mark_multi_kernel<false>, dim3(total_blocks), dim3(256), 0, st, a);
   VC_CHECK_LAUNCH("uv_mark_multi_kernel");
   return VC_OK;
 }

@@ -197,6 +197,11 @@ void bw_defer_begin();
 void bw_defer_enable(bool on);
 int bw_defer_flush(hipStream_t st);
 int g_pass_defer_dw_reduce = 1;   // vc_debug_set "pass_defer_dw_reduce": 0 = every weight gradient reduces at once (A/B)
+// vc_debug_set "pass_dw_flush_mb": the deferred reductions are launched whenever this many MB of partial sums are waiting (0 = one launch at
+// the end of the sweep, the round-5 form).  The single launch read ~170 MB in 39 us BEHIND the last weight gradient, with the main stream
+// already waiting at the join; flushed on the way, the bulk (stages 4 and 3: 64 x 64 and 32 x 32 weights, 24 MB of partials per layer) is
+// reduced under the main chain's kernels and the launch in the tail reads what stages 2 and 1 left (profiles/r06_step_sequence.txt).
+int g_pass_dw_flush_mb = 48;
 // vc_debug_set "pass_bwd_epilogue" (default 1): let the backward-input conv that delivers the LAST contribution to a buffer's
 // gradient add the earlier contribution in its epilogue and, when that buffer is the whole output of a unit, also form that
 // unit's BatchNorm-backward sums there (vc_conv_backward_input_epilogue): no gradient-add kernel, no reduction pass over
@@ -335,6 +340,7 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
 
   hipEvent_t* ev = (side != nullptr && !dry) ? pass_events() : nullptr;
   bool forked = false;
+  size_t deferred_bytes = 0;   // partial sums waiting for their reduce launch (g_pass_dw_flush_mb)
   int n_units_left = 0;  // units still ahead in the reverse sweep (for the main-tail schedule)
   for (int i = 0; i < p->n_ops; ++i) n_units_left += p->ops[i].kind == VC_PASS_UNIT ? 1 : 0;
 
@@ -447,6 +453,14 @@ static int backward_sweep(const vc_pass_program* p, const void* fwd_arena, const
         rc = weight_grad(defer ? dwp : arena + dw_off, side);
         bw_defer_enable(false);
         if (rc != VC_OK) return rc;
+        if (defer && !dry && g_pass_dw_flush_mb > 0) {
+          deferred_bytes += dw_bytes_of(t, u);
+          if (deferred_bytes >= ((size_t)g_pass_dw_flush_mb << 20) && units_left > 1) {
+            rc = bw_defer_flush(side);
+            if (rc != VC_OK) return rc;
+            deferred_bytes = 0;
+          }
+        }
       }
       if (need_dx) {
         const float* src = d_raw;

@@ -39,6 +39,7 @@ int g_plan_reprepare = 0;     // vc_debug_set plan_reprepare: 1 = write the para
 int g_plan_uv_poison = 0;     // vc_debug_set plan_uv_poison: 1 = every uv buffer is filled with 0x7F bytes in front of the projection (diagnostics)
 long long g_plan_uv_dbg = 0;  // vc_debug_set plan_uv_dbg: device address of a diagnostics buffer for the stand-alone projection (project_uv_kernel<MODE, true>: every row's intermediates)
 int g_plan_uv_lds = 0;        // vc_debug_set plan_uv_lds: dynamic LDS bytes of the stand-alone projection launch (round 6 lab, tools/a17_lab.py)
+int g_plan_uv_pad = 0;        // vc_debug_set plan_uv_pad: uv_mark_multi_kernel<PAD> (index_kernels.hip; LOG.md A.21) -- decided by tools/a17_lab.py stress
 int g_plan_uv_mode = 0;       // vc_debug_set plan_uv_mode: project_uv_kernel<MODE> of the plan's projections (0 = product kernel)
 int project_uv_debug(const int32_t* indices, int64_t n, const float* params, int batch_size, int stride, int32_t* uv, int32_t* dbg,
                      int dbg_records, int mode, int has_trans, hipStream_t st);   // index_kernels.hip
