@@ -17,6 +17,8 @@ B40="--steps 40 --warmup 12 --no-cpu-baseline --family-steps 0 --exact-steps 0"
 timeout 300 python bench.py $B40 > $D/bench40.log 2>&1
 VIRCONV_FLAT_PARAMS=0 timeout 300 python bench.py $B40 > $D/bench40_per_module_params.log 2>&1
 VIRCONV_PLAN_GUARD_EARLY=0 timeout 300 python bench.py $B40 > $D/bench40_guard_at_forward_entry.log 2>&1
+VIRCONV_FUSED_OPT=0 timeout 300 python bench.py $B40 > $D/bench40_stock_clip_adamw.log 2>&1
+VIRCONV_DEBUG_SET=pass_dw_flush_mb=0 timeout 300 python bench.py $B40 > $D/bench40_one_reduce_launch.log 2>&1
 timeout 300 python bench.py --model 8x $B40 > $D/bench_8x.log 2>&1
 VIRCONV_FLAT_PARAMS=0 timeout 300 python bench.py --model 8x $B40 > $D/bench_8x_per_module_params.log 2>&1
 timeout 300 python bench.py --model 8x --mode infer --steps 30 --warmup 10 > $D/infer_8x_rot3.log 2>&1
@@ -25,9 +27,10 @@ timeout 300 python bench.py --mode infer --batch-size 4 > $D/infer_bs4.log 2>&1
 timeout 300 python bench.py --frontend $B40 > $D/bench_frontend.log 2>&1
 timeout 300 python bench.py --operand f16 $B40 > $D/bench_f16.log 2>&1
 timeout 300 python bench.py --model 8x --operand f16 $B40 > $D/bench_8x_f16.log 2>&1
-line $D/bench40.log $D/bench40_per_module_params.log $D/bench40_guard_at_forward_entry.log $D/bench_8x.log $D/bench_8x_per_module_params.log $D/infer_8x_rot3.log $D/infer_bs1.log $D/infer_bs4.log $D/bench_frontend.log $D/bench_f16.log $D/bench_8x_f16.log
+line $D/bench40.log $D/bench40_per_module_params.log $D/bench40_guard_at_forward_entry.log $D/bench40_stock_clip_adamw.log $D/bench40_one_reduce_launch.log $D/bench_8x.log $D/bench_8x_per_module_params.log $D/infer_8x_rot3.log $D/infer_bs1.log $D/infer_bs4.log $D/bench_frontend.log $D/bench_f16.log $D/bench_8x_f16.log
 timeout 200 python tools/step_phases.py > $D/phases.txt 2>&1; tail -n 3 $D/phases.txt
 timeout 200 python tools/hostsplit.py 30 > $D/hostsplit.txt 2>&1; head -n 2 $D/hostsplit.txt
+MODEL=8x timeout 200 python tools/hostsplit.py 30 > $D/hostsplit_8x.txt 2>&1; head -n 2 $D/hostsplit_8x.txt
 timeout 400 python tools/kbench.py > $D/kbench.txt 2>&1; tail -n 1 $D/kbench.txt
 timeout 200 python tools/bevbench.py > $D/bevbench.txt 2>&1; tail -n 4 $D/bevbench.txt
 VIRCONV_STRESS_STEPS=512 timeout 600 python -m pytest tests/test_plan_stress_gpu.py -q -k "checksums or inference" > $D/stress_512.log 2>&1; echo "plan stress 512 rc=$?"; tail -n 1 $D/stress_512.log
@@ -40,6 +43,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$D/pmc_$c -o x -- python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --family-steps 0 --exact-steps 0 > $R/$D/p_$c.log 2>&1
 done
 cd $R; f=$(find $D/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $D/kernel_stats.csv
+f=$(find $D/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/trace_gaps.py "$f" 4 --sequence > $D/sequence.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do f=$(find $D/pmc_$c -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" $D/pmc_$c.csv; done
 find $D -name '*kernel_trace.csv' -delete; rm -rf $D/prof $D/pmc_FETCH_SIZE $D/pmc_WRITE_SIZE
 ls -la $D | head -50
