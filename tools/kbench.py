@@ -25,17 +25,22 @@ from virconv_amd import ops, synth  # noqa: E402
 PEAK = 157.3
 
 
-def timeit(fn, iters):
+def timeit(fn, iters, reps=3):
+    """us per call: the best of `reps` averages over `iters` back-to-back calls.  (One average is not robust: two round-6 tables carried a
+    single 27-30 ms stall of the box in one layer's 20 launches -- 1400-1600 us where every rerun says 56 / 92.)"""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3  # us
+    best = float("inf")
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / iters * 1e3)
+    return best
 
 
 def main():

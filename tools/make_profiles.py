@@ -31,6 +31,7 @@ FAMILIES = [
     ("group_sum (seg_sum / seg_fixup / plan keys; r1-r2: fixed-point + absmax + convert)", r"vc::(group_|seg_|absmax)"),
     ("sort (rocPRIM radix sort of the duplicate-pixel group plans)", r"rocprim"),
     ("loss (vc_weighted_sum: the benchmark's stand-in loss, fused product + reduction)", r"weighted_sum"),
+    ("optimizer (vc_clip_adamw: gradient norm + clip + AdamW over the flat parameters)", r"vc::(grad_sqsum|clip_adamw)"),
     ("other vc:: (project, gather/scatter rows, dense, voxelizer)", r"vc::"),
     ("memset/copy", r"__amd_rocclr"),
     ("torch (loss, optimizer, randperm, cat, ...)", r"."),

@@ -554,7 +554,7 @@ class HipBackend:
 
     def bev_stem_conv(self, features: torch.Tensor, indices: torch.Tensor, spatial_shape, batch_size: int, w_passes, cout: int,
                       scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, relu: bool = False,
-                      want_nhwc: bool = False, want_pairs: bool = False):
+                      want_nhwc: bool = False, want_pairs: bool = False, ksize=None):
         """First BEV conv on the sparse rows (base_bev_backbone.py:31-38 over height_compression.py:27-31):
         features (n, C) at indices (n, 4) [b, z, y, x] of a (D, H, W) grid -> (B, cout, H, W) = Conv2d(C * D -> cout, k, pad k // 2)
         of the height-compressed map, then y * scale + shift (BatchNorm) and ReLU folded into the layout pass.
@@ -574,7 +574,7 @@ class HipBackend:
             assert ky * kx == k2, (ky, kx, k2)
         else:
             ky = kx = int(round(k2 ** 0.5))
-            assert ky * kx == k2, "bev_stem_conv_backward: non-square kernel -- pass ksize=(ky, kx)"
+            assert ky * kx == k2, "bev_stem_conv: non-square kernel -- pass ksize=(ky, kx)"
         assert ky * kx == k2, "square 2-D kernels only"
         shp = i32arr((D, H, W))
         st = _stream()

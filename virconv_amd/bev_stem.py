@@ -30,7 +30,8 @@ class _StemConvFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, weight, indices, spatial_shape, batch_size, passes):
         be = ops.get_backend()
-        y, pair = be.bev_stem_conv(feats, indices, spatial_shape, batch_size, passes, weight.shape[0], want_nhwc=True, want_pairs=True)
+        y, pair = be.bev_stem_conv(feats, indices, spatial_shape, batch_size, passes, weight.shape[0], want_nhwc=True, want_pairs=True,
+                                   ksize=(weight.shape[2], weight.shape[3]))
         ctx.save_for_backward(feats, weight)
         ctx.weight_version = weight._version
         ctx.geom = (indices, tuple(int(v) for v in spatial_shape), int(batch_size), passes, pair)
@@ -116,7 +117,8 @@ class SparseBEVStem(nn.Module):
             y4 = y.view(t.batch_size, int(t.spatial_shape[1]), int(t.spatial_shape[2]), conv.out_channels).permute(0, 3, 1, 2)
             return self._block[3](bn(y4))
         if bn.training:   # batch statistics over the WHOLE map (zeros of the empty cells included): the NHWC rows hold every cell
-            y = be.bev_stem_conv(t.features, t.indices, t.spatial_shape, t.batch_size, passes, conv.out_channels, want_nhwc=True)
+            y = be.bev_stem_conv(t.features, t.indices, t.spatial_shape, t.batch_size, passes, conv.out_channels, want_nhwc=True,
+                                 ksize=conv.kernel_size)
             with torch.no_grad():
                 var, mean = torch.var_mean(y, dim=0, unbiased=False)
                 if bn.track_running_stats:
@@ -136,7 +138,8 @@ class SparseBEVStem(nn.Module):
             return dense
         scale = (bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)).contiguous()
         shift = (bn.bias.detach() - bn.running_mean * scale).contiguous()
-        return be.bev_stem_conv(t.features.detach(), t.indices, t.spatial_shape, t.batch_size, passes, conv.out_channels, scale, shift, True)
+        return be.bev_stem_conv(t.features.detach(), t.indices, t.spatial_shape, t.batch_size, passes, conv.out_channels, scale, shift, True,
+                                ksize=conv.kernel_size)
 
 
 class _StemSkippingBlock(nn.Sequential):
