@@ -32,7 +32,11 @@ else:
     gs = parallel.FlatGradAllReduce(model)
 _ts = bench.train_step
 bench.train_step = lambda m, o, b, l: _ts(m, o, b, l, gs)
-opt = torch.optim.AdamW(raw.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, fused=True)
+from virconv_amd import feature_pass as _fp, optim as _vo  # noqa: E402
+_params = _fp.flatten_parameters(raw) if _os.environ.get("VIRCONV_FLAT_PARAMS", "1") != "0" else list(raw.parameters())   # as bench.py
+opt = (_vo.ClipAdamW(_params, lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, max_norm=10.0)
+       if _os.environ.get("VIRCONV_FUSED_OPT", "1") != "0" and _vo.supports(_params) else
+       torch.optim.AdamW(_params, lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01, fused=True))
 lw = bench.make_loss_weights(dev)
 torch.cuda.synchronize()
 batch["inputs_ready_event"] = torch.cuda.Event()
@@ -48,12 +52,14 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f"enqueue {1e3 * (t1 - t0) / 5:.2f} ms/step, drained after +{1e3 * (t2 - t1):.2f} ms")
+N = int(_os.environ.get("STEPS", "40"))
 pr = cProfile.Profile()
-pr.enable()
-for _ in range(5):
+for _ in range(N):          # queue drained between steps: the count read of the plan never waits, what is left is enqueue cost
+    pr.enable()
     bench.train_step(model, opt, batch, lw)
-torch.cuda.synchronize()
-pr.disable()
+    pr.disable()
+    torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(45)
-st.sort_stats("cumulative").print_stats(45)
+print(f"{N} steps profiled (main thread only: the backward bodies run on autograd's worker thread)")
+st.sort_stats("tottime").print_stats(60)
+st.sort_stats("cumulative").print_stats(60)

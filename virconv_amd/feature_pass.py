@@ -107,6 +107,13 @@ class _Program:
         if fp is None:
             return None
         base, offs = fp.data_ptr(), self.grad_offsets
+        cache = self.__dict__.get("_unit_cache")
+        if cache is not None and all(h is not None for h in cache[1]):
+            # the addresses _unit_structs read for THIS call (it runs first and re-reads every tensor's address on every call)
+            for i, (_, ptrs) in enumerate(cache[1]):
+                if ptrs[0] != base + 4 * offs[3 * i] or ptrs[1] != base + 4 * offs[3 * i + 1] or ptrs[2] != base + 4 * offs[3 * i + 2]:
+                    return None
+            return fp
         for i, (conv, bn) in enumerate(self.units):      # someone re-assigned a parameter (load_state_dict(assign=True), .to(), ...)
             if (conv.weight.data_ptr() != base + 4 * offs[3 * i] or bn.weight.data_ptr() != base + 4 * offs[3 * i + 1]
                     or bn.bias.data_ptr() != base + 4 * offs[3 * i + 2]):
@@ -189,8 +196,37 @@ def build_virconv8x_mm_program(model, discard_active: bool, training: bool = Tru
     return P.freeze()
 
 
-def _units_ok(seqs, training: bool) -> bool:
-    return all(unit_is_plain(s) and s[1].training == training for s in seqs)
+_UNITS_OK = weakref.WeakKeyDictionary()   # model -> {key: (fingerprint, verdict)}
+
+
+def _units_fingerprint(seqs):
+    """What the verdict of `_units_ok` depends on, read without a function call per module: the identity of each unit's three modules
+    (a swapped BatchNorm -- convert_sync_batchnorm -- changes it) and the BatchNorm flags that can be flipped in place."""
+    fp = []
+    for s in seqs:
+        m = s._modules
+        conv, bn = m.get("0"), m.get("1")
+        d = bn.__dict__ if bn is not None else {}
+        w = conv._parameters.get("weight") if conv is not None else None
+        fp.append((id(conv), id(w), id(bn), id(m.get("2")), len(m), d.get("training"), d.get("momentum"), d.get("affine"),
+                   d.get("track_running_stats")))
+    return tuple(fp)
+
+
+def _units_ok(seqs, training: bool, model=None, key=None) -> bool:
+    """Every unit is the plain conv -> BatchNorm1d -> ReLU triple the kernels serve, in the given mode.  With `model`: the verdict is
+    kept per (model, key) and re-derived only when the fingerprint of the units changes (34 checks of ~4 us each per VirConv8x
+    step otherwise -- host time of configurations that are host-bound)."""
+    if model is None:
+        return all(unit_is_plain(s) and s[1].training == training for s in seqs)
+    fp = _units_fingerprint(seqs)
+    slot = _UNITS_OK.setdefault(model, {})
+    hit = slot.get((key, training))
+    if hit is not None and hit[0] == fp:
+        return hit[1]
+    verdict = all(unit_is_plain(s) and s[1].training == training for s in seqs)
+    slot[(key, training)] = (fp, verdict)
+    return verdict
 
 
 def _backend_ok(feats: torch.Tensor) -> bool:
@@ -213,7 +249,7 @@ def usable(model, feats: torch.Tensor, plan) -> bool:
     if not _backend_ok(feats):
         return False
     seqs = _nrconv_seqs([model.vir_conv1, model.vir_conv2, model.vir_conv3, model.vir_conv4])
-    if seqs is None or not _units_ok(seqs + [model.conv_out], model.training):
+    if seqs is None or not _units_ok(seqs + [model.conv_out], model.training, model, "L"):
         return False
     if not model.training:
         # eval: the node-by-node path is already ONE launch per unit (BatchNorm folded into the conv store); while the geometry plan
@@ -237,7 +273,7 @@ def usable_8x(model, feats: torch.Tensor, stream: str) -> bool:
         seqs = [model.conv_input, model.conv_out] + [u for st in (model.conv1, model.conv2, model.conv3, model.conv4) for u in st]
     else:
         seqs = _nrconv_seqs([model.vir_conv1, model.vir_conv2, model.vir_conv3, model.vir_conv4])
-    if seqs is None or not _units_ok(seqs, model.training):
+    if seqs is None or not _units_ok(seqs, model.training, model, stream):
         return False
     if not model.training:
         if not NATIVE_PASS_EVAL:
@@ -253,6 +289,33 @@ _PROGRAMS = weakref.WeakKeyDictionary()   # model -> {(discard_active, training)
 class _Call:
     """Everything one forward call filled in (kept alive for the backward of the same call)."""
     __slots__ = ("prog", "c_prog", "c_bufs", "c_units", "c_tables", "c_keeps", "arena", "offsets", "keep_alive", "flat")
+
+
+def _unit_structs(P: _Program):
+    """vc_pass_unit array of the program's units for one call.  The array is kept on the program and an entry is rewritten only when one of
+    its six tensors is another object or lives at another address than last time (flatten_parameters, .to(), load_state_dict(assign=True),
+    `p.data = ...`) or a BatchNorm scalar changed: the tensors are read through the modules' own dicts, not through nn.Module.__getattr__
+    -- 20-34 units x 11 attribute walks per forward were 0.1-0.2 ms of host time.  Every call gets its own copy (its backward reads it)."""
+    n = len(P.units)
+    cache = P.__dict__.get("_unit_cache")
+    if cache is None:
+        cache = P._unit_cache = ((_lib.PassUnit * n)(), [None] * n)
+    arr, held = cache
+    for i, (conv, bn) in enumerate(P.units):
+        bp, bb, bd = bn._parameters, bn._buffers, bn.__dict__
+        w, g, b = conv._parameters["weight"], bp["weight"], bp["bias"]
+        rm, rv, nbt = bb["running_mean"], bb["running_var"], bb["num_batches_tracked"]
+        ptrs = (w.data_ptr(), g.data_ptr(), b.data_ptr(), rm.data_ptr(), rv.data_ptr(), nbt.data_ptr() if nbt is not None else 0,
+                bd["momentum"], bd["eps"])
+        h = held[i]
+        if h is not None and h[0] is w and h[1] == ptrs:
+            continue
+        u = arr[i]
+        u.weight, u.gamma, u.beta, u.running_mean, u.running_var = ptrs[:5]
+        u.num_batches_tracked = ptrs[5] or None
+        u.cin, u.cout, u.momentum, u.eps = w.shape[-1], w.shape[0], ptrs[6], ptrs[7]
+        held[i] = (w, ptrs)
+    return (_lib.PassUnit * n).from_buffer_copy(arr)
 
 
 def _fill(P: _Program, feats, ctx, training: bool) -> Optional[_Call]:
@@ -295,14 +358,7 @@ def _fill(P: _Program, feats, ctx, training: bool) -> Optional[_Call]:
             b.rows = tables[ro[1]].n_out
         else:
             b.rows = keeps[ro[1]].shape[0]
-    c_units = (_lib.PassUnit * len(P.units))()
-    for i, (conv, bn) in enumerate(P.units):
-        u = c_units[i]
-        w = conv.weight
-        u.weight, u.gamma, u.beta = w.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr()
-        u.running_mean, u.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
-        u.num_batches_tracked = _ptr(bn.num_batches_tracked)
-        u.cin, u.cout, u.momentum, u.eps = w.shape[-1], w.shape[0], bn.momentum, bn.eps
+    c_units = _unit_structs(P)
     c_prog = _lib.PassProgram()
     c_prog.ops, c_prog.n_ops = P.c_ops, len(P.ops)
     c_prog.bufs, c_prog.n_bufs = c_bufs, len(P.cols)
@@ -416,8 +472,9 @@ def _run_program(P: _Program, feats: torch.Tensor, ctx, training: bool):
     if not feats.is_contiguous():
         feats = feats.contiguous()
     params = []
-    for conv, bn in P.units:
-        params += [conv.weight, bn.weight, bn.bias]
+    for conv, bn in P.units:     # (through the modules' own dicts: nn.Module.__getattr__ costs 1 us a piece, 60-100 of them per forward)
+        bp = bn._parameters
+        params += [conv._parameters["weight"], bp["weight"], bp["bias"]]
     if not all(p.is_contiguous() for p in params):
         return None
     call = _fill(P, feats, ctx, training)
