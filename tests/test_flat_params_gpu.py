@@ -85,3 +85,58 @@ def test_flat_parameters_train_like_per_module_parameters(kind):
     assert all(pr.flat() is not None for pr in feature_pass._training_programs(m1))
     w = next(iter(m1.parameters()))
     assert torch.equal(w, sd[next(iter(sd.keys()))])
+
+
+@pytest.mark.gpu
+def test_the_cached_unit_structs_follow_moved_tensors_and_the_cached_verdict_follows_swapped_modules():
+    """feature_pass keeps the vc_pass_unit array on the program and the units' plain-shape verdict behind a fingerprint (host time).  A
+    parameter or buffer that moves (p.data = ..., a re-registered buffer, load_state_dict(assign=True)) must be seen by the very next forward,
+    and a swapped BatchNorm must send the model off the native pass."""
+    import copy
+    import bench
+    from virconv_amd import feature_pass, synth
+    from virconv_amd.backbone import VirConvL8x
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).to(dev).eval()
+    batch = bench.make_batch([0], dev, training=False)
+
+    def fwd(m):
+        bd = dict(batch)
+        bd["voxel_features"] = batch["voxel_features"].clone()
+        with torch.no_grad():
+            out = m(bd)
+        return [out["encoded_spconv_tensor"].features.clone()] + [t.features.clone() for t in out["multi_scale_3d_features"].values()]
+
+    base = fwd(model)
+    assert all(torch.equal(a, b) for a, b in zip(base, fwd(model)))          # (second call: everything comes from the caches)
+    # move tensors: new storage with new VALUES, so a stale pointer would be visible in the output
+    conv, bn = model.vir_conv2.d3_conv1[0], model.vir_conv2.d3_conv1[1]
+    conv.weight.data = conv.weight.data.clone() * 1.5
+    bn.running_mean = bn.running_mean.clone() + 0.25                          # buffer re-registered: another tensor object
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    k0 = "vir_conv3.d2_conv2.1.weight"
+    sd[k0] = sd[k0] * 0.5
+    model.load_state_dict(sd, assign=True)                                    # every parameter becomes another object
+    moved = fwd(model)
+    fresh = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).to(dev).eval()
+    fresh.load_state_dict(copy.deepcopy(model.state_dict()))
+    want = fwd(fresh)
+    assert not all(torch.equal(a, b) for a, b in zip(base, moved))
+    assert all(torch.equal(a, b) for a, b in zip(moved, want))
+    # swap a BatchNorm for a subclass the kernels do not serve: the verdict must flip on the next call (node-by-node path, same numbers)
+    class OtherBN(torch.nn.BatchNorm1d):
+        pass
+    feats = batch["voxel_features"]
+    assert feature_pass.usable(model, feats, None)
+    old = model.vir_conv4.d2_conv1[1]
+    new = OtherBN(old.num_features, eps=old.eps, momentum=old.momentum).to(dev).eval()
+    new.load_state_dict(old.state_dict())
+    setattr(model.vir_conv4.d2_conv1, "1", new)        # (SparseSequential has no __setitem__, as spconv's)
+    assert not feature_pass.usable(model, feats, None)
+    for a, b in zip(fwd(model), want):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    setattr(model.vir_conv4.d2_conv1, "1", old)
+    assert feature_pass.usable(model, feats, None)
+    old.momentum = None                                                       # a flag flipped in place is part of the fingerprint
+    assert not feature_pass.usable(model, feats, None)
