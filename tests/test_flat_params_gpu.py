@@ -128,15 +128,20 @@ def test_the_cached_unit_structs_follow_moved_tensors_and_the_cached_verdict_fol
     class OtherBN(torch.nn.BatchNorm1d):
         pass
     feats = batch["voxel_features"]
-    assert feature_pass.usable(model, feats, None)
+
+    def usable():
+        with torch.no_grad():     # (eval with gradients enabled is the node-by-node path by design)
+            return feature_pass.usable(model, feats, None)
+
+    assert usable()
     old = model.vir_conv4.d2_conv1[1]
     new = OtherBN(old.num_features, eps=old.eps, momentum=old.momentum).to(dev).eval()
     new.load_state_dict(old.state_dict())
     setattr(model.vir_conv4.d2_conv1, "1", new)        # (SparseSequential has no __setitem__, as spconv's)
-    assert not feature_pass.usable(model, feats, None)
+    assert not usable()
     for a, b in zip(fwd(model), want):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
     setattr(model.vir_conv4.d2_conv1, "1", old)
-    assert feature_pass.usable(model, feats, None)
+    assert usable()
     old.momentum = None                                                       # a flag flipped in place is part of the fingerprint
-    assert not feature_pass.usable(model, feats, None)
+    assert not usable()
