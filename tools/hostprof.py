@@ -25,6 +25,39 @@ else:
     model = VirConvL8x(bench.MODEL_CFG, 8, synth.GRID_SIZE).to(dev).train()
 raw = model
 import os as _os
+if _os.environ.get("MODE") == "infer":   # MODE=infer [BS=1]: the forward-only loop of bench.run_infer (plan of the next frame begun ahead)
+    bs = int(_os.environ.get("BS", "1"))
+    batch = bench.make_batch(list(range(bs)), dev, training=False)
+    model.eval()
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
+
+    def istep():
+        bd = dict(batch)
+        bd["voxel_features"] = batch["voxel_features"].clone()
+        with torch.no_grad():
+            model.plan_ahead_begin(batch)
+            return model(bd)["encoded_spconv_tensor"].dense()
+
+    for _ in range(30):
+        istep()
+    torch.cuda.synchronize()
+    N = int(_os.environ.get("STEPS", "300"))
+    t0 = time.perf_counter()
+    for _ in range(N):
+        istep()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    print(f"enqueue {1e3 * (t1 - t0) / N:.3f} ms/frame, wall {1e3 * (time.perf_counter() - t0) / N:.3f} ms/frame")
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(N):
+        istep()
+    pr.disable()
+    torch.cuda.synchronize()
+    st = pstats.Stats(pr)
+    st.sort_stats("tottime").print_stats(70)
+    st.sort_stats("cumulative").print_stats(50)
+    sys.exit(0)
 gs = None
 if _os.environ.get('VIRCONV_TORCH_DDP') == '1':
     model = parallel.wrap_ddp(model, dev)

@@ -131,9 +131,10 @@ class NRConvBlock(nn.Module):
 
     # ---- geometry: everything below depends on coordinates only (never on features)
     def _keys(self):
-        k3 = self.d3_conv1[0].indice_key
-        k2 = self.d2_conv1[0].indice_key
-        kd = self.down_layer[0].indice_key if self.stride > 1 else None
+        m = self._modules                      # (through the module dicts: called per block and forward, nn.Module.__getattr__ is 1 us a piece)
+        k3 = m["d3_conv1"]._modules["0"].indice_key
+        k2 = m["d2_conv1"]._modules["0"].indice_key
+        kd = m["down_layer"]._modules["0"].indice_key if self.stride > 1 else None
         return kd, k3, k2
 
     def begin_down(self, indices, spatial_shape, batch_size):
@@ -321,8 +322,9 @@ def note_pass_end(device) -> None:
     if not PLAN_GUARD_EARLY or PLAN_GUARD == 0:
         return
     ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream())
-    _PASS_END[torch.device(device).index] = (ev, _conv_launch_seq(), torch.cuda.current_stream().cuda_stream)
+    st = _current_stream()
+    ev.record(st)
+    _PASS_END[torch.device(device).index] = (ev, _conv_launch_seq(), st.cuda_stream)
 
 
 def _early_guard(device, main):
@@ -336,6 +338,12 @@ def _early_guard(device, main):
     return ev
 
 
+def _current_stream():
+    """torch.cuda.current_stream() of the current device without its device-index normalisation (8 of its 10 us; a forward asks 4-7 times)."""
+    sid, didx, dtype = torch._C._cuda_getCurrentStream(torch._C._cuda_getDevice())
+    return torch.cuda.Stream(stream_id=sid, device_index=didx, device_type=dtype)
+
+
 class _PlanScope:
     """Run the geometry plan on the high-priority side stream (see VirConvL8x.build_plan) and hand the result to the main
     stream.  CPU tensors: a no-op scope.  `guard`: the event the plan's image-space branch waits for (see PLAN_GUARD), or None."""
@@ -346,7 +354,7 @@ class _PlanScope:
         # closures that enqueue what only backward passes read (native_plan.build_chain): run AFTER the event the forward waits for
         self.deferred = [] if (ref_tensor.is_cuda and PLAN_DEFER_BACKWARD) else None
         if self.on_gpu:
-            self.main = torch.cuda.current_stream()
+            self.main = _current_stream()
             mark = None
             if not ahead:   # (a plan begun a step ahead is bounded by the training loop itself)
                 mark = _bound_run_ahead(ref_tensor.device, self.main)
@@ -413,7 +421,7 @@ def join_plan(plan):
         with torch.cuda.stream(side):
             for fn in fns:
                 fn()
-        torch.cuda.current_stream().wait_stream(side)
+        _current_stream().wait_stream(side)
 
 
 def _draw_keep(rate, n, batch_dict, tag, device):
@@ -619,7 +627,7 @@ class VirConvL8x(nn.Module):
             guard = None
             if _guard_wanted(a["scope"].side.device):
                 guard = torch.cuda.Event()
-                guard.record(torch.cuda.current_stream())
+                guard.record(_current_stream())
             with torch.cuda.stream(a["scope"].side):
                 for _, _, _, cp in a["entries"].values():
                     cp.finish(guard)
@@ -636,14 +644,14 @@ class VirConvL8x(nn.Module):
         else:
             return None            # no early plan for this batch (or not in this mode): the caller plans in place
         if rid == "":
-            _bound_run_ahead(coords.device, torch.cuda.current_stream())   # the flow control every forward has (see _PlanScope)
+            _bound_run_ahead(coords.device, _current_stream())   # the flow control every forward has (see _PlanScope)
         self._finish_ahead(a)
         _, _, idx, cp = a["entries"].pop(rid)
         res, rb_out, _, _, arenas = cp.finish()
         plan = {"in_indices": idx, "stages": native_plan.nrconv_stages(a["blocks"], res),
                 "conv_out": {self.conv_out[0].indice_key: rb_out}, "_arenas": arenas + [idx]}
         scope = a["scope"]
-        main = torch.cuda.current_stream()
+        main = _current_stream()
         main.wait_event(a["fwd_ready"])
         if scope.deferred:
             plan["_deferred"] = (scope.side, scope.deferred)
@@ -1100,7 +1108,7 @@ class VirConv8x(nn.Module):
                     "multi_scale_3d_strides" + rid: dict(strides)})
 
         if plan is not None and "_fwd_ready" in plan:     # everything else of the plan (the virtual-point stream's tables)
-            torch.cuda.current_stream().wait_event(plan.pop("_fwd_ready"))
+            _current_stream().wait_event(plan.pop("_fwd_ready"))
         if self.mm:
             blocks = [(self.vir_conv1, 1), (self.vir_conv2, 2), (self.vir_conv3, 4), (self.vir_conv4, 8)]
             for i, rid in enumerate(rids):

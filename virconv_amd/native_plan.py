@@ -93,8 +93,9 @@ def usable(coords: torch.Tensor, blocks=None) -> bool:
     ok = bool(NATIVE_PLAN and getattr(be, "native_plan", False) and coords.is_cuda and coords.shape[0] > 0 and FAST_RANDOM_KEEP
               and ops.ROW_ORDER in ("bwd", "strided") and not ops.WINDOW_GATHER)
     if ok and blocks is not None:
-        ok = len(blocks) <= _lib.PLAN_MAX_BLOCKS and all(not blk.conv_depth and blk.d3_conv1[0].ndim == 3 and blk.d2_conv1[0].ndim == 2
-                                                         for blk, _ in blocks)
+        ok = len(blocks) <= _lib.PLAN_MAX_BLOCKS and all(
+            not blk.conv_depth and blk._modules["d3_conv1"]._modules["0"].ndim == 3 and blk._modules["d2_conv1"]._modules["0"].ndim == 2
+            for blk, _ in blocks)
     return ok
 
 
@@ -118,9 +119,14 @@ def _keep_view(arenas, v: _lib.PlanView):
 
 def _table(arenas, t: _lib.PlanTableOut, kind, in_shape, conv, in_idx) -> ops.Rulebook:
     """ops.Rulebook over views of the arenas; `in_idx`: the tensor holding the table's input coordinates."""
-    ndim = conv.ndim
-    out_shape = tuple(int(t.out_shape[a]) for a in range(ndim))
-    ks = tuple(int(k) for k in conv.kernel_size)
+    geom = conv.__dict__.get("_vc_geom")       # the conv's static geometry as tuples of ints, made once per module (host time per table)
+    if geom is None or geom[0] is not conv.kernel_size:
+        nd = conv.ndim
+        ks_ = tuple(int(k) for k in conv.kernel_size)
+        geom = conv.__dict__["_vc_geom"] = (conv.kernel_size, nd, ks_, tuple(int(s) for s in conv.stride), tuple(int(p) for p in conv.padding),
+                                            tuple(int(x) for x in conv.dilation), (1,) * nd, tuple(k // 2 for k in ks_))
+    _, ndim, ks, g_stride, g_padding, g_dilation, g_one, g_half = geom
+    out_shape = tuple(t.out_shape[:ndim])
 
     def lazy(v: _lib.PlanView, one_d=False):      # (arena, offset in words, rows, cols | 0): the view is made when somebody reads the field
         return None if v.arena < 0 else (arenas[v.arena], v.offset >> 2, v.rows, 0 if one_d else v.cols)
@@ -128,10 +134,9 @@ def _table(arenas, t: _lib.PlanTableOut, kind, in_shape, conv, in_idx) -> ops.Ru
     views = {"pair_fwd": lazy(t.pair_fwd), "pair_bwd": lazy(t.pair_bwd), "rep": lazy(t.rep, True), "in_indices": in_idx,
              "out_indices": in_idx if kind == "subm" else lazy(t.out_indices), "order_fwd": lazy(t.order_fwd, True),
              "order_bwd": lazy(t.order_bwd, True), "grp_plan": lazy(t.grp_plan)}
-    return ops.PlanRulebook(kind, int(t.n_in), int(t.n_out), tuple(int(s) for s in in_shape), out_shape, ks,
-                            tuple(int(s) for s in conv.stride) if kind == "sparse" else (1,) * ndim,
-                            tuple(int(p) for p in conv.padding) if kind == "sparse" else tuple(k // 2 for k in ks),
-                            tuple(int(x) for x in conv.dilation), views)
+    sparse = kind == "sparse"
+    return ops.PlanRulebook(kind, t.n_in, t.n_out, tuple(in_shape), out_shape, ks, g_stride if sparse else g_one,
+                            g_padding if sparse else g_half, g_dilation, views)
 
 
 class ChainPlan:

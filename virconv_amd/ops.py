@@ -79,11 +79,17 @@ class Rulebook:
 
     @property
     def kv(self) -> int:
-        return int(np.prod(self.ksize))
+        n = 1
+        for k in self.ksize:
+            n *= int(k)
+        return n
 
     @property
-    def centre(self) -> int:
-        return int(np.ravel_multi_index(tuple(k // 2 for k in self.ksize), self.ksize))
+    def centre(self) -> int:          # row-major index of the centre tap (what np.ravel_multi_index gives)
+        c = 0
+        for k in self.ksize:
+            c = c * int(k) + int(k) // 2
+        return c
 
 
 class PlanRulebook(Rulebook):

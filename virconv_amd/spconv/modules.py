@@ -40,14 +40,10 @@ class SparseSequential(SparseModule):
             self.add_module(name, module)
 
     def __getitem__(self, idx):
-        if not (-len(self) <= idx < len(self)):
+        mods = tuple(self._modules.values())     # (three entries in this code base: cheaper than walking an iterator)
+        if not (-len(mods) <= idx < len(mods)):
             raise IndexError("index {} is out of range".format(idx))
-        if idx < 0:
-            idx += len(self)
-        it = iter(self._modules.values())
-        for _ in range(idx):
-            next(it)
-        return next(it)
+        return mods[idx]
 
     def __len__(self):
         return len(self._modules)
