@@ -49,6 +49,8 @@ class ClipAdamW(torch.optim.Optimizer):
                              f"(feature_pass.flatten_parameters(model)), got {len(ps)} parameter(s)")
         self._lib = ops.get_backend().lib    # raises without libvirconv_hip.so
         self._device = ps[0].device
+        if self._device.index is None:
+            self._device = torch.device("cuda", torch.cuda.current_device())
         self._ws = None
         self._norm = None
 
@@ -93,7 +95,7 @@ class ClipAdamW(torch.optim.Optimizer):
         _lib.check(self._lib.vc_clip_adamw(C.cast(arr, C.c_void_p), len(live), float(g["lr"]), float(b1), float(b2), float(g["eps"]),
                                            float(g["weight_decay"]), steps.pop(), float(max_norm) if max_norm else 0.0,
                                            int(bool(g["scale_grads"])), self._norm.data_ptr(), self._ws.data_ptr(), n_ws,
-                                           torch.cuda.current_stream(self._device).cuda_stream), "vc_clip_adamw")
+                                           torch._C._cuda_getCurrentRawStream(self._device.index)), "vc_clip_adamw")
         return self._norm if loss is None else loss
 
     @property
