@@ -143,6 +143,11 @@ def test_clip_adamw_state_dict_moves_to_torch_adamw_and_back(hip_backend):
     sd["param_groups"][0].update(max_norm=10.0, scale_grads=False)
     c.load_state_dict(sd)
     assert all(float(c.state[p]["step"]) == 4.0 for p in c.param_groups[0]["params"])
+    # (fused AdamW keeps its step counter on the device; ClipAdamW takes it to the host at its first step, once)
+    for p, g in zip(c.param_groups[0]["params"], _grads(sizes, 4, 1.0)):
+        p.grad = g.to(dev)
+    c.step()
+    assert all(float(c.state[p]["step"]) == 5.0 and not c.state[p]["step"].is_cuda for p in c.param_groups[0]["params"])
 
 
 def test_clip_adamw_follows_a_one_cycle_schedule(hip_backend):

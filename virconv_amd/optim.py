@@ -77,6 +77,10 @@ class ClipAdamW(torch.optim.Optimizer):
             if grad.dtype != torch.float32 or not grad.is_contiguous() or grad.is_sparse or grad.device != p.device:
                 raise ValueError("ClipAdamW: gradients must be dense contiguous float32 tensors on the parameter's device")
             st = self._state_of(p)
+            if not torch.is_tensor(st["step"]):            # a checkpoint of an old torch: a Python number
+                st["step"] = torch.tensor(float(st["step"]), dtype=torch.float32)
+            elif st["step"].is_cuda:                       # a checkpoint of torch.optim.AdamW(fused=True): the counter lives on the device there;
+                st["step"] = st["step"].cpu()              # here the host needs it (one read, once)
             st["step"] += 1
             steps.add(int(st["step"]))
             arr[i] = AdamTensor(p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
