@@ -1863,6 +1863,12 @@ int g_conv_rt = 0;             // v2 row tiles per wave: 1 (64 rows/block) | 2 (
 // 64-channel instantiations from 6 to 8 waves per SIMD, yet only <CK=32, CN=64, backward-input> gets faster (235 -> 202 us,
 // 103 -> 96 us); the forward kernels tie (1207 vs 1210 us per pass) and the strided backward tables lose 5-7 %.
 int g_conv_nw = 0;
+// ... and for SMALL launches (vc_debug_set conv_nw8_below: output rows below which every >= 16-channel shape takes 8-wave blocks; 0 = never).
+// VirConv8x at its benchmark size (16 000 voxels per frame: launches of 20-60 k rows = 300-900 four-wave blocks for 256 CUs) gains 1.5-2 % with
+// 8-wave blocks below 62 000 rows (3.437 / 3.436 -> 3.385 / 3.374 ms per step; 40 000: 3.39, 100 000: 3.36-3.38, everywhere: 3.38-3.39; r6an);
+// VirConv-L's launches (64-310 k rows) are all above the threshold and lose with 8 waves everywhere (4.03 -> 4.14 ms, same call).  Results per
+// row do not depend on the block shape; the BatchNorm partial sums are grouped per wave, so their last bits do (fixed per shape, run to run).
+int g_conv_nw8_below = 62000;
 // developer switch conv_autopack (tools/kbench.py --autopack): the stand-alone conv entry points repack the weights into a
 // library-owned scratch right before the launch, so that a kernel can be timed with a fragment-ordered image without a pass
 // executor around it.  The product path never allocates: the pass executor packs into its caller-provided arena.
@@ -1908,6 +1914,7 @@ static inline int conv_block_waves(int ck, int cn, bool bwd, int64_t rows, bool 
   if (conv_use_v4(ck, cn, bwd, rows, ordered)) return 4;  // 64 rows per workgroup: the partial-row count of a 4-wave v2 block
   if (g_conv_nw == 8) return 8;
   if (g_conv_nw == 4) return 4;
+  if (rows < g_conv_nw8_below) return 8;
   return (bwd && ck == 32 && cn == 64) ? 8 : 4;
 }
 // Pair-compacted forward kernel (gather_gemm_pc_kernel) for tables with few active offsets per row.  The library recognises them
@@ -2631,6 +2638,7 @@ int vc_debug_set(const char* key, int value) {
   if (!strcmp(key, "conv_window")) { g_conv_window = value; return VC_OK; }
   if (!strcmp(key, "conv_v3_split")) { g_conv_v3_split = value; return VC_OK; }
   if (!strcmp(key, "conv_nw")) { g_conv_nw = (value == 8 || value == 4) ? value : 0; return VC_OK; }
+  if (!strcmp(key, "conv_nw8_below")) { g_conv_nw8_below = value; return VC_OK; }
   if (!strcmp(key, "bw_legacy_order")) { g_bw_legacy_order = value; return VC_OK; }
   if (!strcmp(key, "bw_small")) { g_bw_small = value; return VC_OK; }
   if (!strcmp(key, "bw_split")) { g_bw_split = value; return VC_OK; }
