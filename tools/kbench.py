@@ -27,7 +27,8 @@ PEAK = 157.3
 
 def timeit(fn, iters, reps=3):
     """us per call: the best of `reps` averages over `iters` back-to-back calls.  (One average is not robust: two round-6 tables carried a
-    single 27-30 ms stall of the box in one layer's 20 launches -- 1400-1600 us where every rerun says 56 / 92.)"""
+    single 27-30 ms pause in one layer's 20 launches -- 1400-1600 us where every rerun says 56 / 92.  The pause was Python's: a generation-2
+    garbage collection over torch's long-lived objects; main() freezes the collector now, as bench.py does.)"""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -44,6 +45,9 @@ def timeit(fn, iters, reps=3):
 
 
 def main():
+    import gc
+    gc.collect()
+    gc.freeze()      # as bench.py: keeps generation-2 collections (tens of ms over torch's ~10^6 long-lived objects) out of the timed loops
     ap = argparse.ArgumentParser()
     ap.add_argument("--bs", type=int, default=4)
     ap.add_argument("--iters", type=int, default=20)

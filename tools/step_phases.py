@@ -62,6 +62,9 @@ def step(ev=None):
     mark(3)
 
 
+import gc
+gc.collect()
+gc.freeze()      # as bench.py: a generation-2 collection of the ~10^6 objects `import torch` leaves is a 30-100 ms pause in the middle of the loop
 for _ in range(60):
     step()
 torch.cuda.synchronize()
