@@ -82,7 +82,9 @@ def test_new_entry_points_validate_their_arguments_without_gpu():
     assert lib.vc_conv_epilogue_supported(1 << 24, 64, 32, 27, 0) == 0                      # source >= 2 GiB: fallback kernel
     # one partial row (sum, sum of squares) per 16-row wave tile: 4 per 64-row block
     assert lib.vc_conv_stats_partial_floats(130, 130, 8, 32, 27, 0) == 3 * 4 * 2 * 32
-    assert lib.vc_conv_stats_partial_floats(130, 130, 32, 32, 27, 1) == 3 * 4 * 2 * 32
+    # ... for launches of >= 16-channel shapes under 62 000 output rows the blocks have 8 waves of 16 rows (round 6, conv_nw8_below): 8 per 128-row block
+    assert lib.vc_conv_stats_partial_floats(130, 130, 32, 32, 27, 1) == 2 * 8 * 2 * 32
+    assert lib.vc_conv_stats_partial_floats(100000, 100000, 32, 32, 27, 1) == ((100000 + 63) // 64) * 4 * 2 * 32
     # RoI grid pooling
     assert lib.vc_voxel_index_workspace_bytes(1000, 2, shp) > 2 * 21 * 400 * 352 // 8
     assert lib.vc_voxel_query(dummy, 1 << 30, 10, 2, shp, dummy, dummy, dummy, 5, 1, 1, 32, 1.0, 4, dummy, dummy, None) == _lib.VC_EINVAL
@@ -220,7 +222,9 @@ def test_second_session_entry_points_validate_their_arguments_without_gpu():
     assert b"takes no packed image" in lib.vc_last_error()
     assert lib.vc_conv_clear_packed_weights() == _lib.VC_OK
     # partial rows of the backward-input epilogue: per 16-row tile; a row-ordered <32, 64> launch keeps the 8-wave blocks
-    assert lib.vc_conv_bwd_stats_partial_floats(130, 32, 32, 0) == 3 * 4 * 2 * 32
+    # (round 6: launches under 62 000 rows take 8-wave blocks for every >= 16-channel shape -- 2 blocks x 8 waves for 130 rows; above: 4 per 64 rows)
+    assert lib.vc_conv_bwd_stats_partial_floats(130, 32, 32, 0) == 2 * 8 * 2 * 32
+    assert lib.vc_conv_bwd_stats_partial_floats(100000, 32, 32, 0) == ((100000 + 63) // 64) * 4 * 2 * 32
     assert lib.vc_conv_bwd_stats_partial_floats(130, 64, 32, 1) == 2 * 8 * 2 * 64
     # chained strided rulebook
     shp, k3 = _lib.i32arr([21, 400, 352]), _lib.i32arr([3, 3, 3])
