@@ -170,3 +170,41 @@ def test_train_step_gradients_with_and_without_the_in_kernel_finish_are_bit_iden
         for k in ref[part]:
             assert torch.equal(ref[part][k], got[part][k]), (part, k)
             assert torch.equal(got[part][k], again[part][k]), (part, k)
+
+
+@pytest.mark.parametrize("cin,cout,n", [(16, 32, 40009), (32, 32, 20000), (64, 64, 25000), (32, 64, 61000)])
+def test_eight_wave_blocks_of_small_launches_change_no_conv_result(hip_backend, cin, cout, n):
+    """Round 6: launches under 62 000 output rows take 8-wave (128-row) blocks for every >= 16-channel shape (vc_debug_set conv_nw8_below;
+    VirConv8x's launches are 300-900 four-wave blocks for 256 CUs).  A row's conv result does not depend on the block it is computed in:
+    y_raw and the backward-input gradient must be BIT-identical with either block shape; the BatchNorm sums are grouped per wave, so mean /
+    var (and with them y) may differ in their last bits, not more."""
+    be, lib = hip_backend, hip_backend.lib
+    rng = np.random.default_rng(7 * cin + cout)
+    shape = (21, 200, 176)
+    idx = _scene(rng, n, shape, 2)
+    pair, _ = be.subm_rulebook(torch.from_numpy(idx).cuda(), shape, (3, 3, 3), (1, 1, 1), want_rep=False)
+    x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).cuda()
+    dy = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.standard_normal((cout, 3, 3, 3, cin)) / 5).astype(np.float32)).cuda()
+    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32)).cuda()
+    beta = torch.from_numpy(rng.uniform(-0.5, 0.5, cout).astype(np.float32)).cuda()
+
+    def run(below):
+        assert lib.vc_debug_set(b"conv_nw8_below", below) == 0
+        rm = torch.full((cout,), 0.25, device="cuda")
+        rv = torch.full((cout,), 0.75, device="cuda")
+        nbt = torch.full((1,), 3, dtype=torch.int64, device="cuda")
+        y, y_raw, mean, var = be.post_act_block_forward(x, w, pair, None, "f32", False, gamma, beta, rm, rv, nbt, 0.01, 1e-3, True)
+        dx = be.conv_backward_input(dy, w, pair, n, True, 13, None, order=None, operand="f32")
+        torch.cuda.synchronize()
+        return y.clone(), y_raw.clone(), mean.clone(), var.clone(), dx.clone()
+
+    try:
+        four = run(0)
+        eight = run(62000)
+    finally:
+        assert lib.vc_debug_set(b"conv_nw8_below", 62000) == 0
+    assert torch.equal(four[1], eight[1]), "y_raw depends on the block shape"
+    assert torch.equal(four[4], eight[4]), "the backward-input gradient depends on the block shape"
+    assert torch.allclose(four[2], eight[2], rtol=1e-6, atol=1e-7) and torch.allclose(four[3], eight[3], rtol=1e-6, atol=1e-7)
+    assert torch.allclose(four[0], eight[0], rtol=1e-5, atol=1e-6)
