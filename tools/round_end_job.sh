@@ -4,12 +4,15 @@
 #   gpurun --timeout 3400 -- bash tools/round_end_job.sh
 cd "$GRAFT_REPO_ROOT"; R="$GRAFT_REPO_ROOT"; D=gpurun_out/${TAG:-r6z}; mkdir -p $D
 line() { for f in "$@"; do echo "$f $(grep -o '"ms_per_step": [0-9.]*' "$f" | head -1) $(grep -o '"value": [0-9.]*' "$f" | head -1) $(grep -o '"host_enqueue_ms_per_step": [0-9.]*' "$f" | head -1)"; done; }
+# LINES_ONLY=1: the bench lines, phases and host splits only (2 minutes; r6u)
+if [ -z "$LINES_ONLY" ]; then
 timeout 1700 python -m pytest tests -m gpu -q > $D/tests.log 2>&1; echo "testsall rc=$?"; tail -n 2 $D/tests.log
-if [ -f virconv_amd/libvirconv_hip_exp.so ]; then
+fi
+if [ -z "$LINES_ONLY" ] && [ -f virconv_amd/libvirconv_hip_exp.so ]; then
   VIRCONV_LIB=$R/virconv_amd/libvirconv_hip_exp.so timeout 900 python -m pytest tests/test_conv_v4_gpu.py tests/test_conv_pc_gpu.py tests/test_ops_gpu.py tests/test_round3_gpu.py tests/test_plan_gpu.py -m gpu -q > $D/experiments_suite.log 2>&1
   echo "experiments suite rc=$?"; tail -n 1 $D/experiments_suite.log
 fi
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $D/smoke.log 2>&1; tail -n 2 $D/smoke.log
+[ -z "$LINES_ONLY" ] && { timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $D/smoke.log 2>&1; tail -n 2 $D/smoke.log; }
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $D/bench_driver_form.log 2>&1
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $D/bench_driver_form_2.log 2>&1
 line $D/bench_driver_form.log $D/bench_driver_form_2.log
@@ -20,6 +23,7 @@ VIRCONV_PLAN_GUARD_EARLY=0 timeout 300 python bench.py $B40 > $D/bench40_guard_a
 VIRCONV_FUSED_OPT=0 timeout 300 python bench.py $B40 > $D/bench40_stock_clip_adamw.log 2>&1
 VIRCONV_DEBUG_SET=pass_dw_flush_mb=0 timeout 300 python bench.py $B40 > $D/bench40_one_reduce_launch.log 2>&1
 timeout 300 python bench.py --model 8x $B40 > $D/bench_8x.log 2>&1
+VIRCONV_DEBUG_SET=conv_nw8_below=0 timeout 300 python bench.py --model 8x $B40 > $D/bench_8x_four_wave_blocks.log 2>&1
 VIRCONV_FLAT_PARAMS=0 timeout 300 python bench.py --model 8x $B40 > $D/bench_8x_per_module_params.log 2>&1
 timeout 300 python bench.py --model 8x --mode infer --steps 30 --warmup 10 > $D/infer_8x_rot3.log 2>&1
 timeout 300 python bench.py --mode infer --batch-size 1 > $D/infer_bs1.log 2>&1
@@ -27,10 +31,11 @@ timeout 300 python bench.py --mode infer --batch-size 4 > $D/infer_bs4.log 2>&1
 timeout 300 python bench.py --frontend $B40 > $D/bench_frontend.log 2>&1
 timeout 300 python bench.py --operand f16 $B40 > $D/bench_f16.log 2>&1
 timeout 300 python bench.py --model 8x --operand f16 $B40 > $D/bench_8x_f16.log 2>&1
-line $D/bench40.log $D/bench40_per_module_params.log $D/bench40_guard_at_forward_entry.log $D/bench40_stock_clip_adamw.log $D/bench40_one_reduce_launch.log $D/bench_8x.log $D/bench_8x_per_module_params.log $D/infer_8x_rot3.log $D/infer_bs1.log $D/infer_bs4.log $D/bench_frontend.log $D/bench_f16.log $D/bench_8x_f16.log
+line $D/bench40.log $D/bench40_per_module_params.log $D/bench40_guard_at_forward_entry.log $D/bench40_stock_clip_adamw.log $D/bench40_one_reduce_launch.log $D/bench_8x.log $D/bench_8x_four_wave_blocks.log $D/bench_8x_per_module_params.log $D/infer_8x_rot3.log $D/infer_bs1.log $D/infer_bs4.log $D/bench_frontend.log $D/bench_f16.log $D/bench_8x_f16.log
 timeout 200 python tools/step_phases.py > $D/phases.txt 2>&1; tail -n 3 $D/phases.txt
 timeout 200 python tools/hostsplit.py 30 > $D/hostsplit.txt 2>&1; head -n 2 $D/hostsplit.txt
 MODEL=8x timeout 200 python tools/hostsplit.py 30 > $D/hostsplit_8x.txt 2>&1; head -n 2 $D/hostsplit_8x.txt
+[ -n "$LINES_ONLY" ] && { echo finished; exit 0; }
 timeout 400 python tools/kbench.py > $D/kbench.txt 2>&1; tail -n 1 $D/kbench.txt
 timeout 200 python tools/bevbench.py > $D/bevbench.txt 2>&1; tail -n 4 $D/bevbench.txt
 VIRCONV_STRESS_STEPS=512 timeout 600 python -m pytest tests/test_plan_stress_gpu.py -q -k "checksums or inference" > $D/stress_512.log 2>&1; echo "plan stress 512 rc=$?"; tail -n 1 $D/stress_512.log
